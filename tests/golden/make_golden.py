@@ -1,0 +1,365 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only).  The
+reference is imported unmodified on CPU with two shim modules for third-party
+imports that are absent offline (``einops_exts.rearrange_many`` -- a pure
+reshape helper -- and ``dac.nn.layers.Snake1d`` -- only constructed when
+use_snake=True, never on this path), exactly as SURVEY.md section 8c / Appendix D
+describe.  Fixtures hold DATA only: outputs of the reference (sub-sampled where
+large) plus the scalar settings of each case.  Inputs and weights are NOT
+stored; they are regenerated from ``jen1_amd.init_fill`` / ``jen1_amd.synth``
+by the tests, here and on the GPU box.
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py units tiny # a subset
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "jen-1-pytorch_amd"))
+
+import einops  # noqa: E402
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# ---- shims for absent third-party imports (see module docstring) -------------
+_m = types.ModuleType("einops_exts")
+_m.rearrange_many = lambda ts, pat, **kw: tuple(einops.rearrange(t, pat, **kw) for t in ts)
+sys.modules["einops_exts"] = _m
+_dac, _dacnn, _dacl = types.ModuleType("dac"), types.ModuleType("dac.nn"), types.ModuleType("dac.nn.layers")
+
+
+class _Snake1d(torch.nn.Module):
+    def __init__(self, *a, **k):
+        raise RuntimeError("Snake1d is not on the JEN-1 path")
+
+
+_dacl.Snake1d = _Snake1d
+sys.modules.update({"dac": _dac, "dac.nn": _dacnn, "dac.nn.layers": _dacl})
+sys.path.insert(0, "/root/reference")
+
+from jen1.model import blocks as rb  # noqa: E402
+from jen1.model.model import UNetCFG1d  # noqa: E402
+from jen1.diffusion.gdm.gdm import GaussianDiffusion  # noqa: E402
+from jen1.diffusion.gdm.noise_schedule import get_beta_schedule  # noqa: E402
+import utils.module as rmod  # noqa: E402
+
+from jen1_amd import synth  # noqa: E402
+from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config  # noqa: E402
+from jen1_amd.init_fill import fill, fill_normal, fill_uniform  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+SEED = 1234
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def load_filled(module: torch.nn.Module, prefix: str = "", seed: int = SEED):
+    sd = module.state_dict()
+    new = {k: T(fill(prefix + k, tuple(v.shape), seed)) for k, v in sd.items()}
+    module.load_state_dict(new)
+    return module.eval()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ------------------------------------------------------------------------------
+def gen_schedule():
+    out = {}
+    for name in ("linear", "cosine"):
+        betas, _ = get_beta_schedule(name, 1000)
+        betas = betas.to(torch.float32)
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cpu",
+                               sampling_timesteps=100)
+        for attr in ("betas", "alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                     "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_variance",
+                     "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            out[f"{name}.{attr}"] = getattr(gd, attr).numpy()
+    betas, _ = get_beta_schedule("linear", 1000)
+    for S in (10, 100):
+        gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective="noise", loss_type="l2", device="cpu",
+                               sampling_timesteps=S)
+        times = torch.linspace(-1, 999, steps=S + 1)
+        times = list(reversed(times.int().tolist()))
+        out[f"ddim_times.{S}"] = np.array(times, dtype=np.int64)
+        co = []
+        for t, tn in zip(times[:-1], times[1:]):
+            if tn < 0:
+                continue
+            a, an = gd.alphas_cumprod[t], gd.alphas_cumprod[tn]
+            sigma = 1.0 * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+            c = (1 - an - sigma ** 2).sqrt()
+            co.append([an.sqrt().item(), c.item(), sigma.item()])
+        out[f"ddim_coeffs.{S}"] = np.array(co, dtype=np.float32)
+    save("schedule", **out)
+
+
+# ------------------------------------------------------------------------------
+def gen_units():
+    out = {}
+    meta = {}
+    B, L = 2, 37
+    # a1: _Conv1d (blocks.py:34-53)
+    for (ci, co, k, s) in ((8, 12, 1, 1), (8, 12, 3, 1), (8, 12, 5, 2), (8, 12, 9, 4)):
+        m = load_filled(rb.Conv1d(in_channels=ci, out_channels=co, kernel_size=k, stride=s), f"u.conv.k{k}s{s}.")
+        x = T(fill_normal(f"u.conv.x.{ci}", (B, ci, L)))
+        for causal in (False, True):
+            out[f"conv.k{k}s{s}.c{int(causal)}"] = m(x, causal).numpy()
+    # a2: Upsample1d (blocks.py:69-95)
+    for f in (1, 2, 4):
+        m = load_filled(rb.Upsample1d(in_channels=8, out_channels=12, factor=f), f"u.up.f{f}.upsample.")
+        x = T(fill_normal("u.up.x", (B, 8, 11)))
+        out[f"upsample.f{f}"] = m(x).numpy()
+    # a5: ResnetBlock1d
+    for (ci, co, g) in ((16, 16, 8), (24, 16, 8), (17, 16, 1)):
+        m = load_filled(rb.ResnetBlock1d(in_channels=ci, out_channels=co, num_groups=g, context_mapping_features=32),
+                        f"u.res.{ci}.{co}.{g}.")
+        x = T(fill_normal(f"u.res.x.{ci}", (B, ci, L)))
+        mp = T(fill_normal("u.res.map", (B, 32)))
+        for causal in (False, True):
+            out[f"res.{ci}.{co}.{g}.c{int(causal)}"] = m(x, mp, causal).numpy()
+    # a7: Attention
+    feat, heads, hf = 32, 4, 8
+    att = load_filled(rb.Attention(features=feat, head_features=hf, num_heads=heads), "u.att.self.")
+    x = T(fill_normal("u.att.x", (B, 7, feat)))
+    for causal in (False, True):
+        out[f"att.self.c{int(causal)}"] = att(x, causal=causal).numpy()
+    xatt = load_filled(rb.Attention(features=feat, head_features=hf, num_heads=heads, context_features=48), "u.att.cross.")
+    ctx = T(fill_normal("u.att.ctx", (B, 9, 48)))
+    cm = torch.tensor([[1, 1, 1, 1, 0, 0, 0, 0, 1], [1, 1, 1, 1, 1, 1, 1, 0, 1]], dtype=torch.float32)
+    out["att.cross.masked"] = xatt(x, context=ctx, context_mask=cm).numpy()
+    out["att.cross.nomask"] = xatt(x, context=ctx).numpy()
+    # a9: Transformer1d (shared 1x1 conv, GN(32))
+    tr = load_filled(rb.Transformer1d(num_layers=1, channels=64, num_heads=4, head_features=16, multiplier=1,
+                                      context_features=48), "u.tr.")
+    xt = T(fill_normal("u.tr.x", (B, 64, 7)))
+    for causal in (False, True):
+        out[f"tr.c{int(causal)}"] = tr(xt, context=ctx, context_mask=cm, causal=causal).numpy()
+    # a10: Down / Up / Bottleneck blocks with odd lengths -> crop
+    kw = dict(num_groups=8, context_mapping_features=32, context_embedding_features=48,
+              attention_heads=4, attention_multiplier=1)
+    dn = load_filled(rb.DownsampleBlock1d(in_channels=16, out_channels=32, factor=2, num_layers=2, use_skip=True,
+                                          num_transformer_blocks=1, **kw), "u.down.")
+    xd = T(fill_normal("u.down.x", (B, 16, L)))
+    for causal in (False, True):
+        y, skips = dn(xd, mapping=mp, embedding=ctx, embedding_mask=cm, causal=causal)
+        out[f"down.c{int(causal)}.y"] = y.numpy()
+        for i, s in enumerate(skips):
+            out[f"down.c{int(causal)}.skip{i}"] = s.numpy()
+    up = load_filled(rb.UpsampleBlock1d(in_channels=32, out_channels=16, factor=2, num_layers=3, use_skip=True,
+                                        skip_channels=32, use_skip_scale=True, num_transformer_blocks=1, **kw), "u.up.")
+    xu = T(fill_normal("u.upb.x", (B, 32, 20)))          # longer than the skips (19) -> crop
+    sk = [T(fill_normal(f"u.upb.skip{i}", (B, 32, 19))) for i in range(3)]
+    for causal in (False, True):
+        out[f"upblock.c{int(causal)}"] = up(xu, skips=list(sk), mapping=mp, embedding=ctx, embedding_mask=cm, causal=causal).numpy()
+    bt = load_filled(rb.BottleneckBlock1d(channels=32, num_transformer_blocks=1, **kw), "u.bott.")
+    xb = T(fill_normal("u.bott.x", (B, 32, 5)))
+    out["bottleneck.c0"] = bt(xb, mapping=mp, embedding=ctx, embedding_mask=cm, causal=False).numpy()
+    # a11: time features (fp32 sin/cos of large arguments)
+    te = load_filled(rmod.TimePositionalEmbedding(dim=64, out_features=40), "u.time.")
+    tt = torch.tensor([0, 1, 9, 499, 989, 999], dtype=torch.long)
+    out["time.features"] = te(tt).numpy()
+    save("units", **out)
+
+
+# ------------------------------------------------------------------------------
+def _build(cfg):
+    model = UNetCFG1d(**cfg)
+    spec = UNetSpec(**cfg)
+    sd = model.state_dict()
+    got = [(k, tuple(v.shape)) for k, v in sd.items()]
+    assert got == spec.param_shapes(), "UNetSpec.param_shapes() disagrees with the reference state_dict"
+    load_filled(model)
+    return model, spec
+
+
+def _inputs(B, T_, task="text_guided"):
+    cond = synth.conditioning(B, T_, task)
+    x = synth.latents(B, T_)
+    return x, cond
+
+
+def gen_tiny():
+    cfg = tiny_model_config()
+    model, spec = _build(cfg)
+    B, T_ = 2, 300
+    x, cond = _inputs(B, T_)
+    xi, cond_i = _inputs(B, T_, "music_inpaint")
+    emb, mask = T(cond["cross_attn_cond"]), T(cond["cross_attn_masks"])
+    t = torch.tensor([999, 499], dtype=torch.long)
+    out = {"schema": np.array(json.dumps([[k, list(s)] for k, s in spec.param_shapes()]))}
+    cases = []
+    for scale in (1.0, 0.8):
+        for batch_cfg in (True, False):
+            for scale_cfg in (True, False):
+                for causal in (False, True):
+                    if scale == 1.0 and (not batch_cfg or scale_cfg):
+                        continue       # flags are ignored when embedding_scale == 1.0 (model.py:375-376)
+                    cases.append((scale, batch_cfg, scale_cfg, causal))
+    for (scale, batch_cfg, scale_cfg, causal) in cases:
+        y = model(T(x), t, embedding=emb, embedding_mask=mask, embedding_scale=scale, embedding_mask_proba=0.0,
+                  batch_cfg=batch_cfg, scale_cfg=scale_cfg, channels_list=[T(cond["input_concat_cond"])],
+                  features=None, causal=causal)
+        out[f"y.s{scale}.b{int(batch_cfg)}.r{int(scale_cfg)}.c{int(causal)}"] = y.numpy()[:, :, ::3]
+    # inpaint-style context channels (non-zero masked input + mask channel), full output kept
+    y = model(T(xi), t, embedding=emb, embedding_mask=mask, embedding_scale=0.8, embedding_mask_proba=0.0,
+              batch_cfg=True, scale_cfg=True, channels_list=[T(cond_i["input_concat_cond"])], features=None, causal=False)
+    out["y.inpaint"] = y.numpy()
+    # injected CFG-dropout rows (model.py:323-328): row 1 swapped to the fixed embedding
+    real = rmod.rand_bool
+    import jen1.model.model as rmodel
+    rmodel.rand_bool = lambda shape, proba, device=None: torch.tensor([False, True]).reshape(shape)
+    y = model(T(x), t, embedding=emb, embedding_mask=mask, embedding_scale=0.8, embedding_mask_proba=0.2,
+              batch_cfg=True, scale_cfg=True, channels_list=[T(cond["input_concat_cond"])], features=None, causal=False)
+    rmodel.rand_bool = real
+    out["y.dropout_row1"] = y.numpy()[:, :, ::3]
+    # no embedding mask at all
+    y = model(T(x), t, embedding=emb, embedding_mask=None, embedding_scale=0.8, batch_cfg=True, scale_cfg=False,
+              channels_list=[T(cond["input_concat_cond"])], features=None, causal=False)
+    out["y.nomask"] = y.numpy()[:, :, ::3]
+    save("tiny_unet", **out)
+    return model
+
+
+def gen_tiny_sampler(model=None):
+    cfg = tiny_model_config()
+    if model is None:
+        model, _ = _build(cfg)
+    B, T_, S = 2, 300, 10
+    _, cond = _inputs(B, T_)
+    cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+    betas, _ = get_beta_schedule("linear", 1000)
+    shape = (B, 128, T_)
+    init = synth.noise_list(1, shape, seed=7)[0]
+    noises = synth.noise_list(S, shape, seed=11)
+    out = {}
+
+    def run(proba, scale, batch_cfg, scale_cfg, causal, drops=None, objective="noise"):
+        gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective=objective, loss_type="l2", device="cpu",
+                               cfg_dropout_proba=proba, embedding_scale=scale, batch_cfg=batch_cfg,
+                               scale_cfg=scale_cfg, sampling_timesteps=S)
+        seq = [T(init)] + [T(n) for n in noises]
+        it = iter(seq)
+        r_randn, r_randn_like, r_bern = torch.randn, torch.randn_like, torch.bernoulli
+        torch.randn = lambda *a, **k: next(it).clone()
+        torch.randn_like = lambda *a, **k: next(it).clone()
+        if drops is not None:
+            dit = iter(drops)
+            torch.bernoulli = lambda p: T(np.asarray(next(dit), dtype=np.float32)).reshape(p.shape)
+        try:
+            y = gd.sample(model, shape, cond_t, causal=causal)
+        finally:
+            torch.randn, torch.randn_like, torch.bernoulli = r_randn, r_randn_like, r_bern
+        return y.numpy()
+
+    out["ddim10.cfg"] = run(0.0, 0.8, True, True, False)
+    out["ddim10.nocfg.causal"] = run(0.0, 1.0, False, False, True)[:, :, ::3]
+    drops = [[(i + b) % 3 == 0 for b in range(B)] for i in range(S)]
+    out["ddim10.dropout"] = run(0.2, 0.8, True, True, False, drops=drops)[:, :, ::3]
+    out["ddim10.dropout.rows"] = np.array(drops, dtype=bool)
+    out["ddim10.x0"] = run(0.0, 0.8, True, True, False, objective="x0")[:, :, ::3]
+    out["ddim10.v"] = run(0.0, 0.8, True, True, False, objective="v")[:, :, ::3]
+    save("tiny_sampler", **out)
+
+
+def gen_tiny_train(model=None):
+    cfg = tiny_model_config()
+    if model is None:
+        model, _ = _build(cfg)
+    B, T_ = 2, 300
+    out = {}
+    betas, _ = get_beta_schedule("linear", 1000)
+    names = ["to_in.block.block1.project.conv.weight", "downsamples.1.transformer.blocks.0.cross_attention.to_kv.weight",
+             "bottleneck.transformer.conv1d.conv.weight", "upsamples.0.upsample.weight",
+             "to_out.block.block2.groupnorm.weight", "to_time.0.0.weights", "fixed_embedding.embedding.weight",
+             "to_mapping.0.bias"]
+    out["grad_names"] = np.array(json.dumps(names))
+    for task, causal in (("text_guided", False), ("music_inpaint", False), ("music_cont", True)):
+        x0 = synth.latents(B, T_, key="clip")
+        cond = synth.conditioning(B, T_, task)
+        cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+        noise = fill_uniform(f"synth.trainnoise.{task}", (B, 128, T_), 3, 0.0, 1.0)
+        t = torch.tensor([17, 801], dtype=torch.long)
+        for objective in ("noise", "x0", "v"):
+            gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective=objective, loss_type="l2", device="cpu",
+                                   cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+            with torch.enable_grad():
+                model.zero_grad(set_to_none=True)
+                model.train()
+                loss = gd.training_loosses(model, T(x0), t, cond_t, noise=T(noise), causal=causal)
+                loss.backward()
+            out[f"loss.{task}.{objective}"] = np.float32(loss.item())
+            params = dict(model.named_parameters())
+            out[f"gradnorm.{task}.{objective}"] = np.array([params[n].grad.norm().item() for n in names], dtype=np.float32)
+            if task == "text_guided" and objective == "noise":
+                out["grad.to_time.0.0.weights"] = params["to_time.0.0.weights"].grad.numpy().copy()
+                out["grad.to_out.block.block2.project.conv.bias"] = params["to_out.block.block2.project.conv.bias"].grad.numpy().copy()
+    model.eval()
+    save("tiny_train", **out)
+
+
+def gen_full():
+    cfg = full_model_config()
+    model, spec = _build(cfg)
+    assert spec.num_params() == 296_543_106, spec.num_params()
+    B, T_ = 2, 1500
+    x, cond = _inputs(B, T_)
+    t = torch.tensor([999, 9], dtype=torch.long)
+    taps = {}
+
+    def hook(name):
+        def f(_m, _i, o):
+            o = o[0] if isinstance(o, tuple) else o
+            taps[name] = np.array([o.norm().item(), o.abs().max().item(), o.shape[-1]], dtype=np.float64)
+        return f
+    model.to_in.register_forward_hook(hook("to_in"))
+    for i, d in enumerate(model.downsamples):
+        d.register_forward_hook(hook(f"down{i}"))
+    model.bottleneck.register_forward_hook(hook("bottleneck"))
+    for i, u in enumerate(model.upsamples):
+        u.register_forward_hook(hook(f"up{i}"))
+    out = {}
+    y = model(T(x), t, embedding=T(cond["cross_attn_cond"]), embedding_mask=T(cond["cross_attn_masks"]),
+              embedding_scale=0.8, embedding_mask_proba=0.0, batch_cfg=True, scale_cfg=True,
+              channels_list=[T(cond["input_concat_cond"])], features=None, causal=False)
+    out["y.cfg"] = y.numpy()[:, :, ::16]
+    out["y.cfg.norm"] = np.array([y.norm().item(), y.abs().max().item()])
+    for k, v in taps.items():
+        out[f"tap.cfg.{k}"] = v
+    taps.clear()
+    y = model(T(x), t, embedding=T(cond["cross_attn_cond"]), embedding_mask=T(cond["cross_attn_masks"]),
+              embedding_scale=1.0, channels_list=[T(cond["input_concat_cond"])], features=None, causal=True)
+    out["y.nocfg.causal"] = y.numpy()[:, :, ::16]
+    for k, v in taps.items():
+        out[f"tap.nocfg.{k}"] = v
+    save("full_unet", **out)
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full"}
+    model = None
+    if "schedule" in which:
+        print("schedule"); gen_schedule()
+    if "units" in which:
+        print("units"); gen_units()
+    if "tiny" in which:
+        print("tiny"); model = gen_tiny()
+    if "sampler" in which:
+        print("sampler"); gen_tiny_sampler(model)
+    if "train" in which:
+        print("train"); gen_tiny_train(model)
+    if "full" in which:
+        print("full"); gen_full()
