@@ -1,0 +1,193 @@
+/*
+ * jen1_hip.h -- C ABI of libjen1_hip.so: the MI355X (gfx950) kernels behind the
+ * JEN-1 denoiser hot path.
+ *
+ * The reference (0417keito/JEN-1-pytorch) is pure Python/PyTorch: it has no FFI or
+ * operator plug-in interface; the seam is the nn.Module call contract between
+ * GaussianDiffusion and UNetCFG1d.  This header is the
+ * boundary a maintainer would bind to replace the stock ATen ops that path
+ * dispatches: every entry point cites the reference
+ * lines whose arithmetic it replaces.  Plain pointers and sizes only: no torch
+ * types.  All pointers are DEVICE pointers unless noted; every call enqueues on
+ * `stream` (a hipStream_t passed as void*) and returns immediately, so the calls
+ * are hipGraph-capturable.  Return value: 0 on success, non-zero on error, with
+ * a message available from jen1_last_error().
+ *
+ * Layout: activations are channel-last  [B][L][Cp]  (Cp = channels padded to a
+ * multiple of 32, padding lanes hold zeros) in JEN1_F32 or JEN1_BF16.  The
+ * reference layout [B][C][T] float32 appears only at the two ends of the
+ * denoiser (jen1_pack_input / jen1_cfg_ddim_step / jen1_unpack_output).
+ */
+#ifndef JEN1_HIP_H
+#define JEN1_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JEN1_F32 0
+#define JEN1_BF16 1
+
+/* prologue applied to the GEMM's activation operand while it is staged in LDS */
+#define JEN1_PRO_NONE 0
+#define JEN1_PRO_GN 1        /* GroupNorm (+FiLM)            blocks.py:140-143, :530 */
+#define JEN1_PRO_GN_SILU 2   /* GroupNorm (+FiLM) + SiLU      blocks.py:140-144      */
+#define JEN1_PRO_LN 3        /* LayerNorm                     blocks.py:427          */
+#define JEN1_PRO_SILU 4      /* SiLU only                     blocks.py:156-159      */
+
+#define JEN1_ACT_NONE 0
+#define JEN1_ACT_GELU 1      /* exact erf GELU                blocks.py:444, model.py:77-98 */
+
+/* tile configurations of jen1_conv_gemm (BM x BN output tile per 256-thread workgroup) */
+#define JEN1_CFG_128x128 0
+#define JEN1_CFG_128x64 1
+#define JEN1_CFG_64x64 2
+#define JEN1_CFG_64x32 3
+#define JEN1_CFG_64x16 4
+#define JEN1_NUM_CFG 5
+
+/*
+ * Fused implicit-GEMM 1-D convolution / linear layer.
+ *
+ *   y[b, q*ps_f + m/out_C - ps_off, m % out_C] =
+ *       rowscale * ( act( sum_{tap, c} W[tap][m][c] * pro(x[b, q*stride + tap - pad_left, c]) + bias ) + residual )
+ *
+ * with zero padding outside [0, L_in) applied AFTER the prologue, x the channel
+ * concatenation of x0 (c0 channels) and x1 (c1 channels, scaled by src1_scale).
+ * It replaces, in one launch:
+ *   _Conv1d pad + nn.Conv1d                      jen1/model/blocks.py:34-53
+ *   Upsample1d / nn.ConvTranspose1d (sub-pixel)  blocks.py:69-95   (ps_f = stride of the transposed conv)
+ *   ConvBlock1d GroupNorm -> FiLM -> SiLU -> conv blocks.py:137-145
+ *   skip concat + crop                           blocks.py:732-734, utils/module.py:186-204
+ *   ResnetBlock1d residual add                   blocks.py:231
+ *   nn.Linear with LayerNorm prologue, GELU, residual   blocks.py:427-429, :440-446, :485-488
+ *   MappingToScaleShift (SiLU -> Linear)         blocks.py:148-165
+ * and accumulates the statistics the NEXT norm layer needs (GroupNorm fine-group
+ * sums, LayerNorm row sums) in its epilogue.
+ */
+typedef struct jen1_conv_args {
+  const void* x0;            /* [B][L_in][ld0] */
+  const void* x1;            /* optional second channel range, [B][L_in][ld1] */
+  const void* w;             /* packed by jen1_pack_conv_weight_* (host side), see DESIGN.md */
+  const float* bias;         /* [out_C] or NULL */
+  const void* residual;      /* same row mapping as y, [..][ld_res] or NULL */
+  void* y;
+  const float* gn_stats0;    /* [B][32][2] (sum, sumsq) per fine group of x0 */
+  const float* gn_stats1;    /* same for x1 */
+  const float* gn_gamma;     /* [c0+c1] */
+  const float* gn_beta;      /* [c0+c1] */
+  const float* film;         /* [rows][film_ld] or NULL: scale at film_off+c, shift at film_off+film_C+c */
+  const int32_t* film_row;   /* [B] row of `film` for each batch element, or NULL (row = b) */
+  const float* ln_rowstats;  /* [B*L_in][2] (sum, sumsq) over ln_C channels */
+  const float* ln_gamma;     /* [c0] or NULL (weights pre-folded) */
+  const float* ln_beta;      /* [c0] or NULL */
+  const float* row_scale;    /* [B*y_brows] or NULL: multiplies the finished output row */
+  float* out_gn_stats;       /* [B][32][2] accumulated with atomics, or NULL */
+  float* out_rowstats;       /* [B*y_brows][2] accumulated with atomics, or NULL */
+  float* slab;               /* split-K partial sums workspace */
+  uint32_t* counters;        /* split-K arrival counters (zero on entry, left zero on exit) */
+  int32_t dtype;             /* JEN1_F32 / JEN1_BF16: element type of x0, x1, w, residual, y */
+  int32_t B, L_in, L_out;    /* L_out = number of GEMM positions q per batch element */
+  int32_t c0, c1, ld0, ld1;
+  int32_t taps, stride, pad_left;
+  int32_t M;                 /* GEMM rows = out_C * ps_f */
+  int32_t out_C, ps_f, ps_off;
+  int32_t L_y, y_brows, y_row0, ld_y, ld_res;
+  int32_t y_f32;             /* store y as float32 even when dtype is bf16 */
+  int32_t pro_mode;
+  int32_t gn_groups, gn_cpg, gn_count;
+  float gn_eps, src1_scale;
+  int32_t film_off, film_C, film_ld;
+  int32_t ln_C;
+  float ln_eps;
+  int32_t act;
+  int32_t out_cpf;           /* channels per fine group of out_gn_stats (= padded out_C / 32) */
+  int32_t tb, nb;            /* tile = nb batch elements x tb positions (nb*tb <= BN) */
+  int32_t kc_stage;          /* 32-channel chunks staged in LDS at a time */
+  int32_t splitk;
+  int32_t cfg;               /* JEN1_CFG_* */
+} jen1_conv_args;
+
+int jen1_conv_gemm(const jen1_conv_args* args, void* stream);
+/* dynamic LDS bytes jen1_conv_gemm will request for `args` (host helper, no launch) */
+int64_t jen1_conv_gemm_lds_bytes(const jen1_conv_args* args);
+/* BM / BN of a tile configuration */
+int jen1_cfg_bm(int cfg);
+int jen1_cfg_bn(int cfg);
+
+/*
+ * Multi-head attention core, softmax in fp32 with wavefront-shuffle reductions.
+ * q: [B][Nq][ldq] (head h at columns q_off + h*d ...), k/v: rows kv_row[b]*Nk .. +Nk of
+ * [*][ldkv] at columns k_off / v_off.  Padding keys are NOT masked with -inf: the
+ * reference zeroes K and V rows instead (done by the producer through row_scale).
+ * Replaces AttentionBase.forward math path, jen1/model/blocks.py:355-380, incl.
+ * causal_mask (:315-319).  out: [B][Nq][ldo] at columns h*d.
+ * kv_extra / extra_row: when extra_row[b] >= 0 the LAST key/value row (index Nk-1) of batch
+ * element b is read from kv_extra[extra_row[b]][kx_off / vx_off + h*d ...] instead: the text
+ * tokens' K/V are step-invariant and cached, only the appended time token (model.py:315-316)
+ * is projected per step.
+ */
+int jen1_attention(const void* q, const void* k, const void* v, void* out, const int32_t* kv_row,
+                   const void* kv_extra, const int32_t* extra_row, int ld_extra, int kx_off, int vx_off,
+                   int B, int H, int d, int Nq, int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off,
+                   int ldo, int causal, float scale, int dtype, void* stream);
+
+/*
+ * [B][C][T] float32 latents + [B][Cc][T] float32 context channels -> channel-last
+ * [nrep*B][T][ld] (ld >= C+Cc, padded with zeros), replicated nrep times along the
+ * batch (the CFG pair), plus GroupNorm fine-group sums.  Replaces torch.cat at
+ * jen1/model/model.py:240 and :332-349.
+ */
+int jen1_pack_input(const float* x, const float* ctx, void* y, float* gn_stats, int B, int C, int Cc, int T,
+                    int ld, int nrep, int dtype, void* stream);
+
+/* channel-last [B][T][ld] -> [B][C][T] float32 (the non-CFG exit of UNetCFG1d.forward). */
+int jen1_unpack_output(const void* y, float* out, int B, int C, int T, int ld, int dtype, void* stream);
+
+/* (sum, sumsq) over the first C columns of each row of x[rows][ld]  (LayerNorm statistics of the
+ * text context, blocks.py:401,427). */
+int jen1_row_stats(const void* x, float* stats, int rows, int C, int ld, int dtype, void* stream);
+
+/*
+ * Time features + MLP in float32: LearnedPositionalEmbedding -> Linear -> GELU
+ * (utils/module.py:58-79, model.py:84-89 / :286-291).  t: [n] int64 raw timesteps,
+ * freq: [half], w: [out][2*half+1], out: [n][out].
+ */
+int jen1_time_features(const int64_t* t, const float* freq, const float* w, const float* bias, float* out,
+                       int n, int half, int out_features, void* stream);
+
+/* y[n][out] = act(x[n][in] @ w[out][in]^T + bias), float32 (to_mapping, model.py:75-80). */
+int jen1_linear_f32(const float* x, const float* w, const float* bias, float* y, int n, int in_features,
+                    int out_features, int act, void* stream);
+
+/*
+ * CFG combine + std-rescale (model.py:362-369) fused with model_predictions and the
+ * DDIM update (gdm.py:128-131, :212-222).
+ *   net: channel-last [nrep*B][T][ld] denoiser output (nrep = 2: cond rows then uncond rows)
+ *   x:   [B][C][T] float32 current latents, noise: same shape or NULL
+ *   coef: device float[8] = {sqrt_recip, sqrt_recipm1, sqrt_alpha_next, c, sigma, last_step, -, -}
+ *   x_out: [B][C][T] float32 next latents;  eps_out / x0_out optional [B][C][T] float32.
+ * With nrep = 1 the CFG part is skipped (embedding_scale == 1).
+ */
+int jen1_cfg_ddim_step(const void* net, const float* x, const float* noise, const float* coef, float* x_out,
+                       float* eps_out, float* x0_out, int B, int C, int T, int ld, int nrep, float embedding_scale,
+                       int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype, void* stream);
+
+/* CFG combine + rescale only: writes the guided denoiser output [B][C][T] float32 (model.py:362-369). */
+int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale, int scale_cfg,
+                     float scale_phi, int dtype, void* stream);
+
+/* zero `bytes` bytes at p on the stream (statistics arena reset; capturable). */
+int jen1_memset_zero(void* p, int64_t bytes, void* stream);
+
+const char* jen1_last_error(void);
+/* "gfx950" build tag + ABI version, for the loader's sanity check */
+const char* jen1_build_info(void);
+int jen1_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JEN1_HIP_H */

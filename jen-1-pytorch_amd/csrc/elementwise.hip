@@ -1,0 +1,360 @@
+// Boundary / elementwise kernels of the JEN-1 denoiser step (gfx950).
+//   pack_input      [B][C][T] f32 (+ context channels) -> channel-last tile + GroupNorm sums
+//   unpack_output   channel-last -> [B][C][T] f32
+//   row_stats       LayerNorm row sums of an external tensor (text context)
+//   time_features   LearnedPositionalEmbedding -> Linear -> GELU, always float32
+//   linear_f32      tiny float32 Linear (+GELU) for the mapping MLP
+//   cfg_ddim_step   CFG combine + std rescale + x0/eps prediction + DDIM update, one pass
+#include <stdarg.h>
+
+#include "common.h"
+
+thread_local char g_jen1_err[512] = {0};
+
+int jen1_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_jen1_err, sizeof(g_jen1_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+extern "C" const char* jen1_last_error(void) { return g_jen1_err; }
+extern "C" const char* jen1_build_info(void) { return "libjen1_hip gfx950 (CDNA4) hipcc; abi 1"; }
+extern "C" int jen1_abi_version(void) { return 1; }
+
+extern "C" int jen1_memset_zero(void* p, int64_t bytes, void* stream) {
+  JEN1_CHECK(p && bytes >= 0, "memset_zero: bad arguments");
+  JEN1_HIP(hipMemsetAsync(p, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// [B][C][T] + [B][Cc][T]  ->  [nrep*B][T][ld]   (reference torch.cat, jen1/model/model.py:240, :332-349)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ ctx,
+                                                          T* __restrict__ y, float* __restrict__ stats, int B, int C,
+                                                          int Cc, int Tn, int ld, int nrep) {
+  __shared__ float tile[32][33];
+  __shared__ float st[64];
+  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (threadIdx.x < 64) st[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int cpf = ld / JEN1_FINE_GROUPS;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, t = t0 + tx;
+    float v = 0.f;
+    if (t < Tn) {
+      if (c < C) v = x[((size_t)b * C + c) * Tn + t];
+      else if (c < C + Cc) v = ctx[((size_t)b * Cc + (c - C)) * Tn + t];
+    }
+    tile[r][tx] = v;
+    if (stats && v != 0.f) {
+      const int fg = c / cpf;
+      atomicAdd(&st[2 * fg - 2 * (c0 / cpf)], v);          // local fine groups of this 32-channel slab
+      atomicAdd(&st[2 * fg - 2 * (c0 / cpf) + 1], v * v);
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int t = t0 + r, c = c0 + tx;
+    if (t < Tn) {
+      const T v = (T)tile[tx][r];
+      for (int rep = 0; rep < nrep; ++rep) y[((size_t)(rep * B + b) * Tn + t) * ld + c] = v;
+    }
+  }
+  if (stats && threadIdx.x < 64) {
+    const int fgl = threadIdx.x >> 1;
+    const int fg = c0 / cpf + fgl;
+    const float v = st[threadIdx.x];
+    if (fg < JEN1_FINE_GROUPS && v != 0.f)
+      for (int rep = 0; rep < nrep; ++rep) unsafeAtomicAdd(stats + (size_t)(rep * B + b) * 64 + fg * 2 + (threadIdx.x & 1), v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_output_kernel(const T* __restrict__ y, float* __restrict__ out, int C,
+                                                             int Tn, int ld) {
+  __shared__ float tile[32][33];
+  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int t = t0 + r, c = c0 + tx;
+    tile[r][tx] = (t < Tn && c < C) ? (float)y[((size_t)b * Tn + t) * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, t = t0 + tx;
+    if (c < C && t < Tn) out[((size_t)b * C + c) * Tn + t] = tile[tx][r];
+  }
+}
+
+// one wavefront per row: (sum, sumsq) over C columns  (LayerNorm statistics, blocks.py:401,427)
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int rows,
+                                                         int C, int ld) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f, q = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = (float)x[(size_t)row * ld + c];
+    s += v;
+    q += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  if (lane == 0) {
+    stats[2 * row] = s;
+    stats[2 * row + 1] = q;
+  }
+}
+
+// LearnedPositionalEmbedding + Linear + GELU (utils/module.py:58-79; model.py:84-89, :286-291).
+// The phase is ((t * w) * 2) * pi evaluated left to right in float32 exactly like the reference:
+// at t = 999 the argument is ~2e4 rad, one float32 ulp there is 2e-3 rad.
+__global__ __launch_bounds__(256) void time_features_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ out, int half, int out_features) {
+  extern __shared__ float feat[];   // [2*half + 1]
+  const int n = blockIdx.x;
+  const float tv = (float)t[n];
+  const int nin = 2 * half + 1;
+  for (int i = threadIdx.x; i < half; i += 256) {
+    const float f = __fmul_rn(__fmul_rn(__fmul_rn(tv, freq[i]), 2.0f), 3.14159274101257324f);
+    feat[1 + i] = sinf(f);
+    feat[1 + half + i] = cosf(f);
+  }
+  if (threadIdx.x == 0) feat[0] = tv;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int o = blockIdx.y * 4 + wave; o < out_features; o += gridDim.y * 4) {
+    float s = 0.f;
+    for (int i = lane; i < nin; i += 64) s = fmaf(feat[i], w[(size_t)o * nin + i], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[(size_t)n * out_features + o] = gelu_erf(s + bias[o]);
+  }
+}
+
+// y[n][o] = act(x[n] . w[o] + bias[o]); one wavefront per output feature, all rows
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int n,
+                                                          int in_f, int out_f, int act) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= out_f) return;
+  const float* wr = w + (size_t)o * in_f;
+  for (int r = 0; r < n; ++r) {
+    const float* xr = x + (size_t)r * in_f;
+    float s = 0.f;
+    for (int i = lane; i < in_f; i += 64) s = fmaf(xr[i], wr[i], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+      s += bias ? bias[o] : 0.f;
+      y[(size_t)r * out_f + o] = act == JEN1_ACT_GELU ? gelu_erf(s) : s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG combine + rescale (model.py:362-369) [+ model_predictions + DDIM update (gdm.py:128-140, 212-222)]
+// One workgroup = 32 time steps of one batch element, all C channels.
+template <typename T, bool DDIM>
+__global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net, const float* __restrict__ x,
+                                                        const float* __restrict__ noise, const float* __restrict__ coef,
+                                                        float* __restrict__ x_out, float* __restrict__ eps_out,
+                                                        float* __restrict__ x0_out, int B, int C, int Tn, int ld, int nrep,
+                                                        float scale, int scale_cfg, float phi, int objective, int clip_x0) {
+  extern __shared__ float tile[];   // [C][33]
+  const int t0 = blockIdx.x * 32, b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // phase 1: per (b, t) row -> guided output, written transposed into LDS
+  for (int r = wave; r < 32; r += 4) {
+    const int t = t0 + r;
+    if (t >= Tn) continue;           // wave-uniform
+    const T* pc = net + ((size_t)b * Tn + t) * ld;
+    const T* pu = net + ((size_t)(B + b) * Tn + t) * ld;
+    if (nrep == 1) {
+      for (int c = lane; c < C; c += 64) tile[c * 33 + r] = (float)pc[c];
+      continue;
+    }
+    float s_c = 0.f, s_g = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float oc = (float)pc[c], ou = (float)pu[c];
+      const float og = ou + (oc - ou) * scale;
+      tile[c * 33 + r] = og;
+      s_c += oc;
+      s_g += og;
+    }
+    if (scale_cfg) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        s_c += __shfl_xor(s_c, off);
+        s_g += __shfl_xor(s_g, off);
+      }
+      const float m_c = s_c / (float)C, m_g = s_g / (float)C;
+      float v_c = 0.f, v_g = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float dc = (float)pc[c] - m_c, dg = tile[c * 33 + r] - m_g;
+        v_c += dc * dc;
+        v_g += dg * dg;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        v_c += __shfl_xor(v_c, off);
+        v_g += __shfl_xor(v_g, off);
+      }
+      const float ratio = sqrtf(v_c / (float)(C - 1)) / sqrtf(v_g / (float)(C - 1));   // unbiased std (torch.std)
+      for (int c = lane; c < C; c += 64) {
+        const float og = tile[c * 33 + r];
+        tile[c * 33 + r] = phi * (og * ratio) + (1.0f - phi) * og;
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2: [C][T]-major elementwise
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t = t0 + tx;
+  if (t >= Tn) return;
+  float sr = 0.f, srm1 = 0.f, sa_n = 0.f, cc = 0.f, sg = 0.f, last = 0.f, sa_t = 0.f, s1m_t = 0.f;
+  if (DDIM) {
+    sr = coef[0]; srm1 = coef[1]; sa_n = coef[2]; cc = coef[3]; sg = coef[4]; last = coef[5]; sa_t = coef[6]; s1m_t = coef[7];
+  }
+  for (int c = ty; c < C; c += 8) {
+    const size_t idx = ((size_t)b * C + c) * Tn + t;
+    const float o = tile[c * 33 + tx];
+    if (!DDIM) {
+      x_out[idx] = o;
+      continue;
+    }
+    const float xv = x[idx];
+    float x0, eps;
+    if (objective == 0) {          // 'noise'
+      eps = o;
+      x0 = sr * xv - srm1 * eps;
+      if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    } else if (objective == 1) {   // 'x0'
+      x0 = o;
+      if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      eps = (sr * xv - x0) / srm1;
+    } else {                       // 'v'
+      x0 = sa_t * xv - s1m_t * o;
+      if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      eps = (sr * xv - x0) / srm1;
+    }
+    float xn;
+    if (last != 0.f) xn = x0;
+    else xn = x0 * sa_n + cc * eps + (noise ? sg * noise[idx] : 0.f);
+    x_out[idx] = xn;
+    if (eps_out) eps_out[idx] = eps;
+    if (x0_out) x0_out[idx] = x0;
+  }
+}
+
+}  // namespace
+
+extern "C" int jen1_pack_input(const float* x, const float* ctx, void* y, float* gn_stats, int B, int C, int Cc, int T,
+                               int ld, int nrep, int dtype, void* stream) {
+  JEN1_CHECK(x && y && (Cc == 0 || ctx), "pack_input: null pointer");
+  JEN1_CHECK(ld % 32 == 0 && ld >= C + Cc && nrep >= 1, "pack_input: ld=%d must be a multiple of 32 and >= %d", ld, C + Cc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((T + 31) / 32, ld / 32, B);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(pack_input_kernel<float>, grid, dim3(256), 0, s, x, ctx, (float*)y, gn_stats, B, C, Cc, T, ld, nrep);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, dim3(256), 0, s, x, ctx, (bf16_t*)y, gn_stats, B, C, Cc, T, ld, nrep);
+  else return jen1_set_error("pack_input: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_unpack_output(const void* y, float* out, int B, int C, int T, int ld, int dtype, void* stream) {
+  JEN1_CHECK(y && out, "unpack_output: null pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((T + 31) / 32, (C + 31) / 32, B);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(unpack_output_kernel<float>, grid, dim3(256), 0, s, (const float*)y, out, C, T, ld);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(unpack_output_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)y, out, C, T, ld);
+  else return jen1_set_error("unpack_output: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_row_stats(const void* x, float* stats, int rows, int C, int ld, int dtype, void* stream) {
+  JEN1_CHECK(x && stats && rows >= 1 && C >= 1 && ld >= C, "row_stats: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((rows + 3) / 4);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(row_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, rows, C, ld);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(row_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, stats, rows, C, ld);
+  else return jen1_set_error("row_stats: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_time_features(const int64_t* t, const float* freq, const float* w, const float* bias, float* out,
+                                  int n, int half, int out_features, void* stream) {
+  JEN1_CHECK(t && freq && w && bias && out && n >= 1 && half >= 1 && out_features >= 1, "time_features: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int gy = (out_features + 3) / 4;
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(time_features_kernel, dim3(n, gy), dim3(256), sizeof(float) * (2 * half + 1), s, t, freq, w, bias, out, half, out_features);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_linear_f32(const float* x, const float* w, const float* bias, float* y, int n, int in_features,
+                               int out_features, int act, void* stream) {
+  JEN1_CHECK(x && w && y && n >= 1 && in_features >= 1 && out_features >= 1, "linear_f32: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((out_features + 3) / 4), dim3(256), 0, s, x, w, bias, y, n, in_features, out_features, act);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool DDIM>
+static int launch_cfg(const void* net, const float* x, const float* noise, const float* coef, float* x_out, float* eps_out,
+                      float* x0_out, int B, int C, int T, int ld, int nrep, float scale, int scale_cfg, float phi,
+                      int objective, int clip_x0, int dtype, void* stream) {
+  JEN1_CHECK(net && x_out, "cfg step: null pointer");
+  JEN1_CHECK(nrep == 1 || nrep == 2, "cfg step: nrep must be 1 or 2");
+  JEN1_CHECK(C >= 2 && C <= 1024 && ld >= C, "cfg step: bad C/ld");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((T + 31) / 32, B);
+  const size_t lds = sizeof(float) * (size_t)C * 33;
+  if (dtype == JEN1_F32) {
+    auto kern = cfg_step_kernel<float, DDIM>;
+    static bool set = false;
+    if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
+  } else if (dtype == JEN1_BF16) {
+    auto kern = cfg_step_kernel<bf16_t, DDIM>;
+    static bool set = false;
+    if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
+  } else {
+    return jen1_set_error("cfg step: bad dtype");
+  }
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_cfg_ddim_step(const void* net, const float* x, const float* noise, const float* coef, float* x_out,
+                                  float* eps_out, float* x0_out, int B, int C, int T, int ld, int nrep,
+                                  float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0,
+                                  int dtype, void* stream) {
+  JEN1_CHECK(x && coef, "cfg_ddim_step: null x/coef");
+  JEN1_CHECK(objective >= 0 && objective <= 2, "cfg_ddim_step: bad objective");
+  return launch_cfg<true>(net, x, noise, coef, x_out, eps_out, x0_out, B, C, T, ld, nrep, embedding_scale, scale_cfg,
+                          scale_phi, objective, clip_x0, dtype, stream);
+}
+
+extern "C" int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale,
+                                int scale_cfg, float scale_phi, int dtype, void* stream) {
+  return launch_cfg<false>(net, nullptr, nullptr, nullptr, out, nullptr, nullptr, B, C, T, ld, 2, embedding_scale,
+                           scale_cfg, scale_phi, 0, 0, dtype, stream);
+}

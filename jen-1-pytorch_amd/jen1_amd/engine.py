@@ -1,0 +1,659 @@
+"""Execution engine of the denoiser: turns a ``UNetSpec`` + parameters into a static
+list of HIP kernel launches (a *plan*) per (batch, length, CFG-pair, causal) shape.
+
+Host-side counterpart of ``UNet1d.forward`` / ``UNetCFG1d.forward``
+(/root/reference/jen1/model/model.py:225-265, :299-376) and of every block in
+/root/reference/jen1/model/blocks.py.  PyTorch is used for device memory and
+streams only; all arithmetic on the path is a jen1_* kernel from libjen1_hip.so.
+Buffers and kernel arguments of a plan are allocated once, so replaying a plan
+enqueues ~300 launches with fixed pointers: exactly what a hipGraph captures.
+
+Design notes (DESIGN.md has the long form):
+  * activations are channel-last [B][L][C]; the reference's pad / cat / crop /
+    permute copies disappear into kernel index math;
+  * GroupNorm / LayerNorm never run as kernels: producers accumulate the sums in
+    their epilogue, consumers normalise in their LDS-staging prologue;
+  * cross-attention K/V of the 128 text tokens (and of the learned "fixed"
+    embedding used by the unconditional CFG half) are step-invariant: they are
+    projected once per conditioning (``set_context``) and only the time-token
+    row is projected per step (exact).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from .config import ResSpec, TransformerSpec, UNetSpec
+from .packing import (conv_weight_to_gemm, convT_weight_to_gemm, fold_layernorm, pack_gemm_weight)
+
+FG = 32  # fine groups per tensor for GroupNorm statistics
+
+
+def _ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Act:
+    """a channel-last activation [B][L][ld] plus the statistics its consumers need."""
+    __slots__ = ("t", "B", "L", "C", "ld", "gn", "rs")
+
+    def __init__(self, t, B, L, C, ld, gn=None, rs=None):
+        self.t, self.B, self.L, self.C, self.ld, self.gn, self.rs = t, B, L, C, ld, gn, rs
+
+
+class Weights:
+    """Packed, device-resident parameters in the compute dtype (+ float32 vectors)."""
+
+    def __init__(self, spec: UNetSpec, params: Dict[str, torch.Tensor], dtype: torch.dtype, device):
+        self.spec, self.dtype, self.device = spec, dtype, device
+        p = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in params.items()}
+        self.w: Dict[str, torch.Tensor] = {}
+        self.v: Dict[str, torch.Tensor] = {}
+        pk = lambda w_tmk: pack_gemm_weight(w_tmk, dtype)
+        f32 = lambda t: t.contiguous()
+
+        def padvec(t, n):
+            return torch.nn.functional.pad(t, (0, n - t.numel())).contiguous() if t.numel() != n else t.contiguous()
+
+        # ---- time MLPs stay float32 (tiny; phases up to 2e4 rad) -------------------------------
+        for k in ("to_time.0.0.weights", "to_time.0.1.weight", "to_time.0.1.bias", "to_mapping.0.weight",
+                  "to_mapping.0.bias", "to_mapping.2.weight", "to_mapping.2.bias"):
+            self.v[k] = f32(p[k])
+        if spec.use_xattn_time:
+            for k in ("to_time_embedding.0.0.weights", "to_time_embedding.0.1.weight", "to_time_embedding.0.1.bias"):
+                self.v[k] = f32(p[k])
+
+        # ---- ResnetBlock1d (blocks.py:168-231) ----------------------------------------------------
+        film_w, film_b, self.film_off = [], [], {}
+        off = 0
+        for r in spec.res_blocks():
+            n = r.name
+            cin_p = _ceil_to(r.c_in, 32)
+            self.w[f"{n}.conv1"] = pk(conv_weight_to_gemm(p[f"{n}.block1.project.conv.weight"]))
+            self.v[f"{n}.conv1.bias"] = f32(p[f"{n}.block1.project.conv.bias"])
+            self.v[f"{n}.gn1.g"] = padvec(p[f"{n}.block1.groupnorm.weight"], cin_p)
+            self.v[f"{n}.gn1.b"] = padvec(p[f"{n}.block1.groupnorm.bias"], cin_p)
+            self.w[f"{n}.conv2"] = pk(conv_weight_to_gemm(p[f"{n}.block2.project.conv.weight"]))
+            self.v[f"{n}.conv2.bias"] = f32(p[f"{n}.block2.project.conv.bias"])
+            self.v[f"{n}.gn2.g"] = f32(p[f"{n}.block2.groupnorm.weight"])
+            self.v[f"{n}.gn2.b"] = f32(p[f"{n}.block2.groupnorm.bias"])
+            if r.has_shortcut:
+                self.w[f"{n}.short"] = pk(conv_weight_to_gemm(p[f"{n}.to_out.conv.weight"]))
+                self.v[f"{n}.short.bias"] = f32(p[f"{n}.to_out.conv.bias"])
+            film_w.append(p[f"{n}.to_scale_shift.to_scale_shift.1.weight"])
+            film_b.append(p[f"{n}.to_scale_shift.to_scale_shift.1.bias"])
+            self.film_off[n] = off
+            off += 2 * r.c_out
+        self.film_ld = off
+        # MappingToScaleShift of all blocks as ONE GEMM on the shared mapping (blocks.py:148-165)
+        self.w["film"] = pk(torch.cat(film_w, 0)[None])
+        self.v["film.bias"] = torch.cat(film_b, 0).contiguous()
+
+        # ---- down / up sampling convs (blocks.py:55-95) -------------------------------------------
+        for d in spec.downs:
+            self.w[f"{d.name}.down"] = pk(conv_weight_to_gemm(p[f"{d.name}.downsample.conv.weight"]))
+            self.v[f"{d.name}.down.bias"] = f32(p[f"{d.name}.downsample.conv.bias"])
+        for u in spec.ups:
+            wt = p[f"{u.name}.upsample.weight"]
+            self.w[f"{u.name}.up"] = pk(conv_weight_to_gemm(wt) if u.factor == 1 else convT_weight_to_gemm(wt, u.factor))
+            self.v[f"{u.name}.up.bias"] = f32(p[f"{u.name}.upsample.bias"])
+
+        # ---- Transformer1d (blocks.py:497-537), LayerNorm folded into the projections -------------
+        kvx_w, kvx_b, self.kvx_off = [], [], {}
+        off = 0
+        self.kv_ctx: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        for t in spec.transformers():
+            n = t.name
+            assert t.num_layers == 1, "num_transformer_blocks > 1 is not used by JEN-1 configs"
+            b = f"{n}.blocks.0"
+            self.w[f"{n}.proj"] = pk(conv_weight_to_gemm(p[f"{n}.conv1d.conv.weight"]))
+            self.v[f"{n}.proj.bias"] = f32(p[f"{n}.conv1d.conv.bias"])
+            self.v[f"{n}.gn.g"] = f32(p[f"{n}.group_norm.weight"])
+            self.v[f"{n}.gn.b"] = f32(p[f"{n}.group_norm.bias"])
+            a = f"{b}.attention"
+            wq, bq = fold_layernorm(p[f"{a}.to_q.weight"], p[f"{a}.norm.weight"], p[f"{a}.norm.bias"])
+            wkv, bkv = fold_layernorm(p[f"{a}.to_kv.weight"], p[f"{a}.norm_context.weight"], p[f"{a}.norm_context.bias"])
+            self.w[f"{n}.qkv"] = pk(torch.cat([wq, wkv], 0)[None])
+            self.v[f"{n}.qkv.bias"] = torch.cat([bq, bkv], 0).contiguous()
+            self.w[f"{n}.o1"] = pk(p[f"{a}.attention.to_out.weight"][None])
+            self.v[f"{n}.o1.bias"] = f32(p[f"{a}.attention.to_out.bias"])
+            x = f"{b}.cross_attention"
+            wq2, bq2 = fold_layernorm(p[f"{x}.to_q.weight"], p[f"{x}.norm.weight"], p[f"{x}.norm.bias"])
+            self.w[f"{n}.q2"] = pk(wq2[None])
+            self.v[f"{n}.q2.bias"] = bq2.contiguous()
+            wkv2, bkv2 = fold_layernorm(p[f"{x}.to_kv.weight"], p[f"{x}.norm_context.weight"], p[f"{x}.norm_context.bias"])
+            self.w[f"{n}.kv2"] = pk(wkv2[None])
+            self.v[f"{n}.kv2.bias"] = bkv2.contiguous()
+            kvx_w.append(wkv2)
+            kvx_b.append(bkv2)
+            self.kvx_off[n] = off
+            off += wkv2.shape[0]
+            self.w[f"{n}.o2"] = pk(p[f"{x}.attention.to_out.weight"][None])
+            self.v[f"{n}.o2.bias"] = f32(p[f"{x}.attention.to_out.bias"])
+            self.w[f"{n}.ff1"] = pk(p[f"{b}.feed_forward.0.weight"][None])
+            self.v[f"{n}.ff1.bias"] = f32(p[f"{b}.feed_forward.0.bias"])
+            self.w[f"{n}.ff2"] = pk(p[f"{b}.feed_forward.2.weight"][None])
+            self.v[f"{n}.ff2.bias"] = f32(p[f"{b}.feed_forward.2.bias"])
+        self.kvx_ld = off
+        if kvx_w:
+            # time-token K/V rows of every cross-attention layer as ONE GEMM per step
+            self.w["kvx"] = pk(torch.cat(kvx_w, 0)[None])
+            self.v["kvx.bias"] = torch.cat(kvx_b, 0).contiguous()
+        self.fixed = p["fixed_embedding.embedding.weight"].contiguous()       # [ctx_len][F] float32
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+
+class KernelCtx:
+    """what an OpBuilder needs to know about the device / dtype (Engine provides the same fields)."""
+
+    def __init__(self, dtype: str = "f32", device="cuda", target_wgs: int = 256):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.dt = L.F32 if dtype == "f32" else L.BF16
+        self.tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.target_wgs = target_wgs
+
+
+class OpBuilder:
+    """Prepares jen1_* launches with fixed pointers; ``Plan`` builds the whole network with it,
+    the unit tests build single ops."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.ops: List[Callable[[int], None]] = []
+        self._splitk_args: List[L.ConvArgs] = []
+        self._slab_floats = 0
+        self._max_tiles = 0
+        self._keep: List[object] = []
+        self.slab = None
+        self.counters = None
+
+    def _empty(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.eng.tdtype, device=self.eng.device)
+
+    def finalize_workspace(self):
+        """split-K workspace shared by all launches of the builder (stream-ordered reuse)."""
+        if self._splitk_args:
+            dev = self.eng.device
+            self.slab = torch.empty((self._slab_floats,), dtype=torch.float32, device=dev)
+            self.counters = torch.zeros((self._max_tiles,), dtype=torch.int32, device=dev)
+            for a in self._splitk_args:
+                a.slab, a.counters = self.slab.data_ptr(), self.counters.data_ptr()
+
+    def run(self, stream: Optional[int] = None):
+        if stream is None:
+            stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        for op in self.ops:
+            op(stream)
+
+    # ---------------------------------------------------------------- the fused conv / linear op
+    def conv(self, ops, *, src0: Act, w: torch.Tensor, bias, out: Act, taps=1, stride=1, pad_left=0, L_out=None,
+             src1: Optional[Act] = None, src1_scale=1.0, ps_f=1, ps_off=0, L_y=None, y_row0=0, pro=L.PRO_NONE,
+             gn=None, film=None, ln=None, act=L.ACT_NONE, residual: Optional[Act] = None, row_scale=None,
+             y_f32=False, out_C=None, force=None):
+        eng = self.eng
+        a = L.ConvArgs()
+        a.x0, a.c0, a.ld0 = src0.t.data_ptr(), src0.ld, src0.ld
+        if src1 is not None:
+            a.x1, a.c1, a.ld1 = src1.t.data_ptr(), src1.ld, src1.ld
+            assert src1.L == src0.L and src1.B == src0.B
+        a.w, a.bias = w.data_ptr(), _ptr(bias)
+        a.dtype = eng.dt
+        a.B, a.L_in = src0.B, src0.L
+        a.L_out = L_out if L_out is not None else src0.L
+        a.taps, a.stride, a.pad_left = taps, stride, pad_left
+        out_C = out_C if out_C is not None else out.C
+        a.out_C, a.ps_f, a.ps_off = out_C, ps_f, ps_off
+        a.M = out_C * ps_f
+        assert w.shape[0] == taps and w.shape[1] * 16 == a.M and w.shape[2] * 32 == a.c0 + a.c1, \
+            (tuple(w.shape), taps, a.M, a.c0, a.c1)
+        a.y, a.ld_y = out.t.data_ptr(), out.ld
+        a.L_y = L_y if L_y is not None else (out.L - y_row0)
+        a.y_brows, a.y_row0 = out.L, y_row0
+        a.y_f32 = 1 if y_f32 else 0
+        if residual is not None:
+            a.residual, a.ld_res = residual.t.data_ptr(), residual.ld
+            assert residual.L == out.L and residual.B == out.B and y_row0 == 0
+        a.pro_mode = pro
+        a.src1_scale = float(src1_scale)
+        if pro in (L.PRO_GN, L.PRO_GN_SILU):
+            groups, creal, gamma, beta, eps = gn
+            a.gn_groups = groups
+            a.gn_cpg = creal // groups if groups > 1 else max(creal, a.c0 + a.c1)
+            a.gn_count = (creal // groups) * src0.L
+            a.gn_eps = eps
+            a.gn_gamma, a.gn_beta = gamma.data_ptr(), beta.data_ptr()
+            assert gamma.numel() == a.c0 + a.c1, (gamma.numel(), a.c0, a.c1)
+            a.gn_stats0 = src0.gn.data_ptr()
+            if src1 is not None:
+                a.gn_stats1 = src1.gn.data_ptr()
+            if film is not None:
+                ftab, frow, foff, fC = film
+                a.film, a.film_row = ftab.data_ptr(), _ptr(frow)
+                a.film_off, a.film_C, a.film_ld = foff, fC, ftab.shape[-1]
+        if pro == L.PRO_LN:
+            lnC, g_, b_ = ln
+            a.ln_rowstats, a.ln_C, a.ln_eps = src0.rs.data_ptr(), lnC, 1e-5
+            a.ln_gamma, a.ln_beta = _ptr(g_), _ptr(b_)
+        a.act = act
+        a.row_scale = _ptr(row_scale)
+        if out.gn is not None and not y_f32:
+            a.out_gn_stats, a.out_cpf = out.gn.data_ptr(), out.ld // FG
+        if out.rs is not None:
+            a.out_rowstats = out.rs.data_ptr()
+        self._choose_tiles(a, force)
+        if a.splitk > 1:
+            self._splitk_args.append(a)
+        self._keep.append(a)
+        lib = eng.lib
+        ref = C.byref(a)
+        ops.append(lambda s, ref=ref, lib=lib: L.check(lib.jen1_conv_gemm(ref, s), "jen1_conv_gemm"))
+        return out
+
+    def _choose_tiles(self, a: L.ConvArgs, force=None):
+        """Tile / split-K heuristics.  Deep levels (few positions, big weights) are
+        weight-streaming bound: small N tile, K split so that >= ~1 workgroup per CU streams."""
+        eng = self.eng
+        rows = a.B * a.L_out
+        M = a.M
+        kch = (a.c0 + a.c1) // 32
+        if force is not None and "cfg" in force:
+            cfg = force["cfg"]
+        elif rows >= 1024:
+            cfg = L.CFG_128x128 if M >= 128 else L.CFG_64x64
+        elif rows > 32:
+            cfg = L.CFG_128x64 if M >= 256 else L.CFG_64x64
+        elif rows > 16:
+            cfg = L.CFG_64x32
+        else:
+            cfg = L.CFG_64x16
+        BM, BN = eng.lib.jen1_cfg_bm(cfg), eng.lib.jen1_cfg_bn(cfg)
+        tb = min(a.L_out, BN)
+        nb = max(1, min(a.B, BN // tb))
+        a.cfg, a.tb, a.nb = cfg, tb, nb
+        n_tiles = -(-a.L_out // tb) * -(-a.B // nb)
+        m_tiles = -(-M // BM)
+        wgs = n_tiles * m_tiles
+        splitk = 1
+        if force is not None and "splitk" in force:
+            splitk = force["splitk"]
+        elif wgs < eng.target_wgs and kch >= 4:
+            want = min(-(-eng.target_wgs // wgs), kch // 2, 32)
+            # legal split counts: every slice non-empty, slices aligned to the x0/x1 boundary
+            best = 1
+            for sk in range(2, want + 1):
+                cps = -(-kch // sk)
+                if (sk - 1) * cps >= kch:
+                    continue
+                if a.c1 and (a.c0 // 32) % cps != 0:
+                    continue
+                best = sk
+            splitk = best
+        a.splitk = splitk
+        cps = -(-kch // splitk)
+        # LDS stage: as many 32-channel chunks as fit comfortably (<= 64 KiB keeps 2 WGs / CU)
+        stage = cps
+        while True:
+            a.kc_stage = stage
+            ok_boundary = (not a.c1) or ((a.c0 // 32) % min(stage, cps) == 0)
+            nbytes = eng.lib.jen1_conv_gemm_lds_bytes(C.byref(a))
+            if ok_boundary and (nbytes <= 64 * 1024 or stage == 1):
+                break
+            stage -= 1
+        assert nbytes <= 160 * 1024, f"LDS {nbytes} B too large (tb={tb}, nb={nb}, taps={a.taps}, stride={a.stride})"
+        if splitk > 1:
+            self._slab_floats = max(self._slab_floats, wgs * splitk * BM * BN)
+            self._max_tiles = max(self._max_tiles, wgs)
+
+    def attention(self, ops, *, q: Act, q_off, kv_t: torch.Tensor, ldkv, k_off, v_off, out: Act, H, d, Nk, causal,
+                  kv_row=None, kv_extra=None, extra_row=None, ld_extra=0, kx_off=0, vx_off=0):
+        eng = self.eng
+        args = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
+                _ptr(extra_row), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
+                1 if causal else 0, float(d) ** -0.5, eng.dt)
+        lib = eng.lib
+        ops.append(lambda s, args=args, lib=lib: L.check(lib.jen1_attention(*args, s), "jen1_attention"))
+
+
+
+class Plan(OpBuilder):
+    """Pre-allocated buffers + prepared launches for one (B, T, nrep, causal) shape."""
+
+    def __init__(self, eng: "Engine", B: int, T: int, nrep: int, causal: bool):
+        super().__init__(eng)
+        self.B, self.T, self.nrep, self.causal = B, T, nrep, causal
+        self.Beff = B * nrep
+        self.ctx_ops: List[Callable[[int], None]] = []
+        self.taps: Dict[str, Act] = {}
+        self.n_launch = 0
+        self._build()
+
+    # ---------------------------------------------------------------- allocation helpers
+    def _stats(self, nfloats: int) -> torch.Tensor:
+        o = self._arena_used
+        self._arena_used += _ceil_to(nfloats, 64)
+        assert self._arena_used <= self.arena.numel(), "statistics arena overflow"
+        return self.arena[o: o + nfloats]
+
+    def new_act(self, B, L, C, gn=False, rs=False, dtype=None) -> Act:
+        ld = _ceil_to(C, 32)
+        if ld != C:
+            t = torch.zeros((B, L, ld), dtype=dtype or self.eng.tdtype, device=self.eng.device)
+        else:
+            t = self._empty((B, L, ld), dtype)
+        return Act(t, B, L, C, ld, self._stats(B * 64) if gn else None, self._stats(B * L * 2) if rs else None)
+
+    # ---------------------------------------------------------------- network blocks
+    def resblock(self, r: ResSpec, src0: Act, src1: Optional[Act], causal: bool, gn=True) -> Act:
+        """ResnetBlock1d.forward (blocks.py:219-231): 2 launches (+1 for a 1x1 shortcut)."""
+        W, ops = self.eng.W, self.ops
+        n = r.name
+        sc = self.eng.skip_scale if src1 is not None else 1.0
+        pad = 2 if causal else 1
+        h = self.new_act(src0.B, src0.L, r.c_out, gn=True)
+        self.conv(ops, src0=src0, src1=src1, src1_scale=sc, w=W.w[f"{n}.conv1"], bias=W.v[f"{n}.conv1.bias"], out=h,
+                  taps=3, pad_left=pad, pro=L.PRO_GN_SILU,
+                  gn=(r.groups, r.c_in, W.v[f"{n}.gn1.g"], W.v[f"{n}.gn1.b"], 1e-5))
+        if r.has_shortcut:
+            res = self.new_act(src0.B, src0.L, r.c_out)
+            self.conv(ops, src0=src0, src1=src1, src1_scale=sc, w=W.w[f"{n}.short"], bias=W.v[f"{n}.short.bias"], out=res)
+        else:
+            assert src1 is None
+            res = src0
+        y = self.new_act(src0.B, src0.L, r.c_out, gn=gn)
+        self.conv(ops, src0=h, w=W.w[f"{n}.conv2"], bias=W.v[f"{n}.conv2.bias"], out=y, taps=3, pad_left=pad,
+                  pro=L.PRO_GN_SILU, gn=(r.groups, r.c_out, W.v[f"{n}.gn2.g"], W.v[f"{n}.gn2.b"], 1e-5),
+                  film=(self.film, self.film_row, W.film_off[n], r.c_out), residual=res)
+        return y
+
+    def transformer(self, t: TransformerSpec, x: Act, causal: bool) -> Act:
+        """Transformer1d.forward + TransformerBlock.forward (blocks.py:528-537, :483-489): 10 launches."""
+        W, ops, eng = self.eng.W, self.ops, self.eng
+        n, Cc, H, d = t.name, t.channels, t.heads, t.head_features
+        mid = H * d
+        Bf, Lx = x.B, x.L
+        x1 = self.new_act(Bf, Lx, Cc, rs=True)
+        self.conv(ops, src0=x, w=W.w[f"{n}.proj"], bias=W.v[f"{n}.proj.bias"], out=x1, pro=L.PRO_GN,
+                  gn=(32, Cc, W.v[f"{n}.gn.g"], W.v[f"{n}.gn.b"], 1e-6))
+        qkv = self.new_act(Bf, Lx, 3 * mid)
+        self.conv(ops, src0=x1, w=W.w[f"{n}.qkv"], bias=W.v[f"{n}.qkv.bias"], out=qkv, pro=L.PRO_LN, ln=(Cc, None, None))
+        a1 = self.new_act(Bf, Lx, mid)
+        self.attention(ops, q=qkv, q_off=0, kv_t=qkv.t, ldkv=qkv.ld, k_off=mid, v_off=2 * mid, out=a1, H=H, d=d, Nk=Lx,
+                       causal=causal)
+        x2 = self.new_act(Bf, Lx, Cc, rs=True)
+        self.conv(ops, src0=a1, w=W.w[f"{n}.o1"], bias=W.v[f"{n}.o1.bias"], out=x2, residual=x1)
+        q2 = self.new_act(Bf, Lx, mid)
+        self.conv(ops, src0=x2, w=W.w[f"{n}.q2"], bias=W.v[f"{n}.q2.bias"], out=q2, pro=L.PRO_LN, ln=(Cc, None, None))
+        a2 = self.new_act(Bf, Lx, mid)
+        kv = self.kv_ctx[n]
+        self.attention(ops, q=q2, q_off=0, kv_t=kv, ldkv=2 * mid, k_off=0, v_off=mid, out=a2, H=H, d=d, Nk=eng.spec.ctx_len,
+                       causal=False, kv_row=self.kv_row,
+                       kv_extra=self.kvx.t if eng.spec.use_xattn_time else None,
+                       extra_row=self.extra_row if eng.spec.use_xattn_time else None, ld_extra=W.kvx_ld,
+                       kx_off=W.kvx_off[n], vx_off=W.kvx_off[n] + mid)
+        x3 = self.new_act(Bf, Lx, Cc)
+        self.conv(ops, src0=a2, w=W.w[f"{n}.o2"], bias=W.v[f"{n}.o2.bias"], out=x3, residual=x2)
+        f1 = self.new_act(Bf, Lx, Cc * t.multiplier)
+        self.conv(ops, src0=x3, w=W.w[f"{n}.ff1"], bias=W.v[f"{n}.ff1.bias"], out=f1, act=L.ACT_GELU)
+        x4 = self.new_act(Bf, Lx, Cc)
+        self.conv(ops, src0=f1, w=W.w[f"{n}.ff2"], bias=W.v[f"{n}.ff2.bias"], out=x4, residual=x3)
+        y = self.new_act(Bf, Lx, Cc, gn=True)
+        self.conv(ops, src0=x4, w=W.w[f"{n}.proj"], bias=W.v[f"{n}.proj.bias"], out=y)
+        return y
+
+    # ---------------------------------------------------------------- whole network
+    def _build(self):
+        eng, spec, W = self.eng, self.eng.spec, self.eng.W
+        lib, dev = eng.lib, eng.device
+        B, Be, T, causal = self.B, self.Beff, self.T, self.causal
+        f32 = torch.float32
+        n_tr = len(spec.transformers())
+        lens = spec.level_lengths(T)
+        Ltr = max([lens[i + 1] for i, d in enumerate(spec.downs) if d.transformer] + [lens[-1]])
+        self.arena = torch.zeros(600 * Be * 64 + (4 * n_tr + 8) * Be * Ltr * 2 + 4096, dtype=f32, device=dev)
+        self._arena_used = 0
+        ops = self.ops
+
+        # ---- static inputs --------------------------------------------------------------------
+        Cx, Cc = spec.in_channels, spec.ctx_ch0
+        self.x_in = torch.zeros((B, Cx, T), dtype=f32, device=dev)
+        self.ctx_in = torch.zeros((B, max(Cc, 1), T), dtype=f32, device=dev)
+        self.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        F, NL = spec.ctx_features, spec.ctx_max_length
+        self.emb_in = torch.zeros((B, NL, F), dtype=f32, device=dev)
+        self.mask_in = torch.ones((B, spec.ctx_len), dtype=f32, device=dev)
+        ar = torch.arange(B, dtype=torch.int32, device=dev)
+        self.film_row = (torch.arange(Be, dtype=torch.int32, device=dev) % B).contiguous()
+        # rows [0,B): conditional half reads text slot b + per-step time row; rows [B,2B): fixed slot
+        self.kv_row = torch.cat([ar, ar + B])[:Be].contiguous() if self.nrep == 2 else ar.clone()
+        self.extra_row = torch.cat([ar, torch.full_like(ar, -1)])[:Be].contiguous() if self.nrep == 2 else ar.clone()
+
+        arena_bytes = self.arena.numel() * 4
+        arena_ptr = self.arena.data_ptr()
+        ops.append(lambda s: L.check(lib.jen1_memset_zero(arena_ptr, arena_bytes, s), "memset"))
+
+        # ---- 1. pack [B,C,T] + context channels -> channel-last, CFG pair replicated -------------
+        X0 = self.new_act(Be, T, Cx + Cc, gn=True)
+        a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), X0.gn.data_ptr(), B, Cx, Cc, T,
+             X0.ld, self.nrep, eng.dt)
+        ops.append(lambda s, a=a: L.check(lib.jen1_pack_input(*a, s), "jen1_pack_input"))
+
+        # ---- 2. time -> mapping -> FiLM scale/shift of all ResBlocks (model.py:204-223) -------------
+        mf, half = spec.mapping_features, spec.channels // 2
+        tf = torch.empty((B, mf), dtype=f32, device=dev)
+        m1 = torch.empty((B, mf), dtype=f32, device=dev)
+        self.mapping = torch.empty((B, mf), dtype=f32, device=dev)
+        v = W.v
+        a = (self.t_in.data_ptr(), v["to_time.0.0.weights"].data_ptr(), v["to_time.0.1.weight"].data_ptr(),
+             v["to_time.0.1.bias"].data_ptr(), tf.data_ptr(), B, half, mf)
+        ops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
+        a = (tf.data_ptr(), v["to_mapping.0.weight"].data_ptr(), v["to_mapping.0.bias"].data_ptr(), m1.data_ptr(), B, mf, mf, L.ACT_GELU)
+        ops.append(lambda s, a=a: L.check(lib.jen1_linear_f32(*a, s), "jen1_linear_f32"))
+        a = (m1.data_ptr(), v["to_mapping.2.weight"].data_ptr(), v["to_mapping.2.bias"].data_ptr(), self.mapping.data_ptr(), B, mf, mf, L.ACT_GELU)
+        ops.append(lambda s, a=a: L.check(lib.jen1_linear_f32(*a, s), "jen1_linear_f32"))
+        map_t = Act(self._empty((1, B, mf)), 1, B, mf, mf)
+        self._add_cast(ops, self.mapping, map_t.t)
+        self.film = torch.empty((B, W.film_ld), dtype=f32, device=dev)
+        film_act = Act(self.film.view(1, B, W.film_ld), 1, B, W.film_ld, W.film_ld)
+        self.conv(ops, src0=map_t, w=W.w["film"], bias=W.v["film.bias"], out=film_act, pro=L.PRO_SILU, y_f32=True)
+
+        # ---- 3. time token of the text context -> its K/V row for every cross-attention ------------
+        self.kv_ctx: Dict[str, torch.Tensor] = {}
+        if n_tr:
+            for t in spec.transformers():
+                self.kv_ctx[t.name] = torch.zeros((2 * B, spec.ctx_len, 2 * t.heads * t.head_features),
+                                                  dtype=eng.tdtype, device=dev)
+        self.kvx = None
+        if spec.use_xattn_time and n_tr:
+            tok = torch.empty((B, F), dtype=f32, device=dev)
+            a = (self.t_in.data_ptr(), v["to_time_embedding.0.0.weights"].data_ptr(), v["to_time_embedding.0.1.weight"].data_ptr(),
+                 v["to_time_embedding.0.1.bias"].data_ptr(), tok.data_ptr(), B, half, F)
+            ops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
+            tok_t = Act(self._empty((1, B, F)), 1, B, F, F, rs=self._stats(B * 2))
+            self._add_cast(ops, tok, tok_t.t)
+            a = (tok_t.t.data_ptr(), tok_t.rs.data_ptr(), B, F, F, eng.dt)
+            ops.append(lambda s, a=a: L.check(lib.jen1_row_stats(*a, s), "jen1_row_stats"))
+            self.kvx = self.new_act(1, B, W.kvx_ld)
+            self.conv(ops, src0=tok_t, w=W.w["kvx"], bias=W.v["kvx.bias"], out=self.kvx, pro=L.PRO_LN, ln=(F, None, None))
+
+        # ---- 4. UNet1d.forward (model.py:243-262) ------------------------------------------------
+        x = self.resblock(spec.to_in, X0, None, causal=False)
+        self.taps["to_in"] = x
+        skip0 = x
+        skips_list: List[List[Act]] = []
+        for i, d in enumerate(spec.downs):
+            f, k = d.factor, d.kernel
+            Lo = (x.L + f - 1) // f
+            y = self.new_act(Be, Lo, d.c_out, gn=True)
+            self.conv(ops, src0=x, w=W.w[f"{d.name}.down"], bias=W.v[f"{d.name}.down.bias"], out=y, taps=k, stride=f,
+                      pad_left=(k - 1) if causal else (k - 1) // 2, L_out=Lo)
+            x = y
+            skips = []
+            for r in d.blocks:
+                x = self.resblock(r, x, None, causal)
+                skips.append(x)
+            if d.transformer:
+                x = self.transformer(d.transformer, x, causal)
+                skips.append(x)
+            skips_list.append(skips)
+            self.taps[f"down{i}"] = x
+        x = self.resblock(spec.bott_pre, x, None, causal)
+        if spec.bott_tr:
+            x = self.transformer(spec.bott_tr, x, causal)
+        x = self.resblock(spec.bott_post, x, None, causal)
+        self.taps["bottleneck"] = x
+        for idx, u in enumerate(spec.ups):
+            skips = skips_list.pop()
+            for r in u.blocks:
+                sk = skips.pop()
+                assert x.L == sk.L, (x.L, sk.L)      # crop already folded into the producing upsample
+                x = self.resblock(r, x, sk, causal)
+            if u.transformer:
+                x = self.transformer(u.transformer, x, causal)
+            f = u.factor
+            last = idx == len(spec.ups) - 1
+            # length the next consumer needs: the skips of the next level (or T at the top)
+            L_need = skip0.L if last else skips_list[-1][-1].L
+            y = self.new_act(Be, L_need, u.c_out, gn=True)
+            if f == 1:
+                assert L_need == x.L
+                self.conv(ops, src0=x, w=W.w[f"{u.name}.up"], bias=W.v[f"{u.name}.up.bias"], out=y, taps=3, pad_left=1,
+                          residual=skip0 if last else None)
+            else:
+                p = f // 2 + f % 2
+                diff = f * x.L - L_need
+                assert diff >= 0
+                self.conv(ops, src0=x, w=W.w[f"{u.name}.up"], bias=W.v[f"{u.name}.up.bias"], out=y, taps=2, pad_left=1,
+                          L_out=x.L + 1, ps_f=f, ps_off=p + diff // 2, out_C=u.c_out,
+                          residual=skip0 if last else None)
+            x = y
+            self.taps[f"up{idx}"] = x
+        out = self.resblock(spec.to_out, x, None, causal=False, gn=False)
+        self.net_out = out
+        self.taps["out"] = out
+
+        # ---- 5. context ops: text K/V (hoisted out of the step loop) -------------------------------
+        if n_tr:
+            cops = self.ctx_ops
+            self.emb_t = Act(self._empty((B, NL, F)), B, NL, F, F)
+            self.emb_rs = torch.zeros((B * NL * 2,), dtype=f32, device=dev)
+            self.emb_t.rs = self.emb_rs
+            self._add_cast(cops, self.emb_in, self.emb_t.t)
+            a = (self.emb_t.t.data_ptr(), self.emb_rs.data_ptr(), B * NL, F, F, eng.dt)
+            cops.append(lambda s, a=a: L.check(lib.jen1_row_stats(*a, s), "jen1_row_stats"))
+            self.mask_flat = self.mask_in.view(-1)
+            for t in spec.transformers():
+                kv = self.kv_ctx[t.name]
+                mid2 = kv.shape[-1]
+                slot = Act(kv[:B], B, spec.ctx_len, mid2, mid2)
+                self.conv(cops, src0=self.emb_t, w=W.w[f"{t.name}.kv2"], bias=W.v[f"{t.name}.kv2.bias"], out=slot,
+                          L_y=NL, pro=L.PRO_LN, ln=(F, None, None), row_scale=self.mask_flat)
+
+        # ---- split-K workspace shared by all launches of the plan (stream-ordered reuse) -----------
+        self.finalize_workspace()
+        self.n_launch = len(self.ops)
+
+    def _add_cast(self, ops, src: torch.Tensor, dst: torch.Tensor):
+        """dtype cast through torch (device plumbing, captured like any other node)."""
+        ops.append(lambda s, src=src, dst=dst: dst.view(src.shape).copy_(src))
+
+    # ---------------------------------------------------------------- running
+    def set_context(self, embedding: torch.Tensor, mask: Optional[torch.Tensor], stream: int):
+        """Project the text tokens' K/V for every cross-attention layer (once per conditioning)."""
+        eng, B = self.eng, self.B
+        if not self.kv_ctx:
+            return
+        self.emb_in.copy_(embedding.to(torch.float32))
+        self.mask_in.fill_(1.0)
+        if mask is not None:
+            self.mask_in[:, : eng.spec.ctx_max_length].copy_(mask.to(torch.float32))
+        for op in self.ctx_ops:
+            op(stream)
+        # unconditional slots: learned fixed embedding, masked with the SAME text mask (model.py:337)
+        for name, kv in self.kv_ctx.items():
+            kv[B:].copy_(eng.kv_fixed[name][None] * self.mask_in[:, :, None].to(kv.dtype))
+
+    def set_rows(self, drop_rows: Optional[torch.Tensor], uncond_only: bool = False):
+        """Select, per effective batch row, which cached K/V slot cross-attention reads.
+        drop_rows[b] = True swaps row b to the fixed embedding (CFG dropout, model.py:323-328)."""
+        B = self.B
+        ar = torch.arange(B, dtype=torch.int32, device=self.eng.device)
+        if uncond_only:
+            cond_row, cond_extra = ar + B, torch.full_like(ar, -1)
+        elif drop_rows is None:
+            cond_row, cond_extra = ar, ar
+        else:
+            d = drop_rows.to(device=self.eng.device, dtype=torch.bool)
+            cond_row = torch.where(d, ar + B, ar)
+            cond_extra = torch.where(d, torch.full_like(ar, -1), ar)
+        if self.nrep == 2:
+            self.kv_row.copy_(torch.cat([cond_row, ar + B]))
+            self.extra_row.copy_(torch.cat([cond_extra, torch.full_like(ar, -1)]))
+        else:
+            self.kv_row.copy_(cond_row)
+            self.extra_row.copy_(cond_extra)
+
+
+class Engine:
+    def __init__(self, spec: UNetSpec, params: Dict[str, torch.Tensor], dtype: str = "bf16", device="cuda"):
+        assert dtype in ("f32", "bf16")
+        self.lib = L.load()
+        self.spec = spec
+        self.device = torch.device(device)
+        self.dt = L.F32 if dtype == "f32" else L.BF16
+        self.tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
+        self.target_wgs = 256
+        self.plans: Dict[Tuple[int, int, int, bool], Plan] = {}
+        self.load_params(params)
+
+    def load_params(self, params: Dict[str, torch.Tensor]):
+        self.W = Weights(self.spec, params, self.tdtype, self.device)
+        self.plans.clear()
+        self.kv_fixed: Dict[str, torch.Tensor] = {}
+        self._project_fixed_embedding()
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _project_fixed_embedding(self):
+        """K/V of the learned fixed embedding (the unconditional CFG context, model.py:321):
+        batch- and step-invariant, projected once per weight load."""
+        spec, W = self.spec, self.W
+        if not spec.transformers():
+            return
+        lib, dev = self.lib, self.device
+        n, F = spec.ctx_len, spec.ctx_features
+        fx = W.fixed[:n].to(self.tdtype).contiguous()
+        rs = torch.zeros((n * 2,), dtype=torch.float32, device=dev)
+        s = self._stream()
+        L.check(lib.jen1_row_stats(fx.data_ptr(), rs.data_ptr(), n, F, F, self.dt, s), "jen1_row_stats")
+        tmp = OpBuilder(self)
+        src = Act(fx.view(1, n, F), 1, n, F, F, rs=rs)
+        for t in spec.transformers():
+            mid2 = 2 * t.heads * t.head_features
+            out = torch.empty((n, mid2), dtype=self.tdtype, device=dev)
+            tmp.conv(tmp.ops, src0=src, w=W.w[f"{t.name}.kv2"], bias=W.v[f"{t.name}.kv2.bias"],
+                     out=Act(out.view(1, n, mid2), 1, n, mid2, mid2), pro=L.PRO_LN, ln=(F, None, None),
+                     force={"splitk": 1})
+            self.kv_fixed[t.name] = out
+        tmp.finalize_workspace()
+        tmp.run(s)
+        torch.cuda.synchronize(dev)
+
+    def plan(self, B: int, T: int, nrep: int, causal: bool) -> Plan:
+        key = (B, T, nrep, bool(causal))
+        if key not in self.plans:
+            self.plans[key] = Plan(self, B, T, nrep, bool(causal))
+        return self.plans[key]

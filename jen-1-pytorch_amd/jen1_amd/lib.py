@@ -1,0 +1,123 @@
+"""ctypes binding of libjen1_hip.so (C ABI declared in include/jen1_hip.h).
+
+There is NO fallback: if the shared library has not been built (``python -c
+"import __graft_entry__ as g; g.build()"``) every product entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(HERE)
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+LIB_PATH = os.path.join(HERE, "libjen1_hip.so")
+CSRC = os.path.join(PKG_ROOT, "csrc")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+SOURCES = ["conv_gemm.hip", "attention.hip", "elementwise.hip"]
+
+F32, BF16 = 0, 1
+PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU = 0, 1
+CFG_128x128, CFG_128x64, CFG_64x64, CFG_64x32, CFG_64x16 = 0, 1, 2, 3, 4
+
+c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
+
+
+class ConvArgs(C.Structure):
+    """mirror of ``jen1_conv_args`` (include/jen1_hip.h) -- field order is ABI."""
+    _fields_ = [
+        ("x0", c_void_p), ("x1", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("residual", c_void_p),
+        ("y", c_void_p), ("gn_stats0", c_void_p), ("gn_stats1", c_void_p), ("gn_gamma", c_void_p),
+        ("gn_beta", c_void_p), ("film", c_void_p), ("film_row", c_void_p), ("ln_rowstats", c_void_p),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("row_scale", c_void_p), ("out_gn_stats", c_void_p),
+        ("out_rowstats", c_void_p), ("slab", c_void_p), ("counters", c_void_p),
+        ("dtype", c_int), ("B", c_int), ("L_in", c_int), ("L_out", c_int),
+        ("c0", c_int), ("c1", c_int), ("ld0", c_int), ("ld1", c_int),
+        ("taps", c_int), ("stride", c_int), ("pad_left", c_int),
+        ("M", c_int), ("out_C", c_int), ("ps_f", c_int), ("ps_off", c_int),
+        ("L_y", c_int), ("y_brows", c_int), ("y_row0", c_int), ("ld_y", c_int), ("ld_res", c_int),
+        ("y_f32", c_int), ("pro_mode", c_int),
+        ("gn_groups", c_int), ("gn_cpg", c_int), ("gn_count", c_int),
+        ("gn_eps", c_float), ("src1_scale", c_float),
+        ("film_off", c_int), ("film_C", c_int), ("film_ld", c_int),
+        ("ln_C", c_int), ("ln_eps", c_float),
+        ("act", c_int), ("out_cpf", c_int), ("tb", c_int), ("nb", c_int),
+        ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int),
+    ]
+
+
+# every symbol include/jen1_hip.h declares: (name, restype, argtypes)
+_P = c_void_p
+SYMBOLS = {
+    "jen1_conv_gemm": (c_int, [C.POINTER(ConvArgs), _P]),
+    "jen1_conv_gemm_lds_bytes": (c_int64, [C.POINTER(ConvArgs)]),
+    "jen1_cfg_bm": (c_int, [c_int]),
+    "jen1_cfg_bn": (c_int, [c_int]),
+    "jen1_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 + [c_float, c_int, _P]),
+    "jen1_pack_input": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "jen1_unpack_output": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
+    "jen1_row_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
+    "jen1_time_features": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "jen1_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "jen1_cfg_ddim_step": (c_int, [_P] * 7 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
+    "jen1_cfg_combine": (c_int, [_P, _P] + [c_int] * 4 + [c_float, c_int, c_float, c_int, _P]),
+    "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
+    "jen1_last_error": (C.c_char_p, []),
+    "jen1_build_info": (C.c_char_p, []),
+    "jen1_abi_version": (c_int, []),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class Jen1HipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into jen1_amd/libjen1_hip.so (hipcc cross-compiles
+    without a GPU).  Skips the compile when the library is newer than every source."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h")]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+           *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise Jen1HipError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Jen1HipError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` from the repo root. "
+            "There is no CPU / eager fallback for the denoiser path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # raises AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.jen1_abi_version() != 1:
+        raise Jen1HipError("libjen1_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().jen1_last_error()
+        raise Jen1HipError(f"{what}: {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,152 @@
+"""``UNetCFG1d``: drop-in for /root/reference/jen1/model/model.py:268-376.
+
+Same constructor kwargs, same ``state_dict`` keys, same
+``forward`` signature and keyword names (the call sites are
+jen1/diffusion/gdm/gdm.py:118-125 and :251-258).  The arithmetic runs in
+libjen1_hip.so through ``engine.Engine``; this module only routes tensors.
+
+``compute_dtype``: "f32" is the parity mode (fp32 storage, exact-fp32 MFMA; the
+1e-3 gate of BASELINE.json is checked in this mode), "bf16" the fast mode
+(bf16 storage, fp32 accumulate).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .config import UNetSpec
+from .engine import Engine, Plan
+from .init_fill import fill
+
+
+class _Node(nn.Module):
+    """parameter container; nested nodes reproduce the reference's dotted key names."""
+
+
+def _register(root: nn.Module, key: str, value: torch.Tensor):
+    parts = key.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, _Node())
+        m = getattr(m, p)
+    m.register_parameter(parts[-1], nn.Parameter(value, requires_grad=True))
+
+
+class UNetCFG1d(nn.Module):
+    """UNet1d with classifier-free guidance on MI355X (reference model.py:268)."""
+
+    def __init__(self, context_embedding_max_length: int, context_embedding_features: int,
+                 use_xattn_time: bool = False, *, compute_dtype: str = "bf16", device="cuda",
+                 init_seed: Optional[int] = 1234, **kwargs):
+        super().__init__()
+        self.spec = UNetSpec(context_embedding_max_length=context_embedding_max_length,
+                             context_embedding_features=context_embedding_features,
+                             use_xattn_time=use_xattn_time, **kwargs)
+        self.compute_dtype = compute_dtype
+        self._device = torch.device(device)
+        for key, shape in self.spec.param_shapes():
+            if init_seed is None:
+                v = torch.zeros(shape, dtype=torch.float32)
+            else:
+                v = torch.from_numpy(fill(key, shape, init_seed))
+            _register(self, key, v.to(self._device))
+        self._engine: Optional[Engine] = None
+        self._ctx_key = None
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
+
+    # ------------------------------------------------------------------ plumbing
+    def _invalidate(self):
+        self._engine = None
+        self._ctx_key = None
+
+    def engine(self) -> Engine:
+        if self._engine is None:
+            L.load()   # raises when the HIP extension is missing: there is no fallback
+            if self._device.type != "cuda":
+                raise L.Jen1HipError("UNetCFG1d needs a ROCm GPU (device='cuda'); no CPU path exists in this package")
+            self._engine = Engine(self.spec, {k: v for k, v in self.state_dict().items()}, self.compute_dtype, self._device)
+        return self._engine
+
+    def repack(self):
+        """Re-pack weights after an optimiser step / in-place parameter change."""
+        self._invalidate()
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self._device).cuda_stream
+
+    def _prepare(self, plan: Plan, x, time, embedding, embedding_mask, channels_list, drop_rows, uncond_only=False):
+        plan.x_in.copy_(x.to(torch.float32))
+        plan.t_in.copy_(time.to(torch.int64))
+        if self.spec.ctx_ch0:
+            assert channels_list is not None and channels_list[0] is not None, "Missing context"   # model.py:189
+            ch = channels_list[0]
+            assert ch.shape[1] == self.spec.ctx_ch0, f"Expected context with {self.spec.ctx_ch0} channels at idx 0"
+            plan.ctx_in.copy_(ch.to(torch.float32))
+        # the text K/V cache is keyed on the identity (weakref) + in-place version of the tensors
+        k = self._ctx_key
+        hit = (k is not None and k[0] is plan and k[1]() is embedding and k[2] == embedding._version and
+               ((embedding_mask is None and k[3] is None) or
+                (embedding_mask is not None and k[3] is not None and k[3]() is embedding_mask and k[4] == embedding_mask._version)))
+        if not hit:
+            plan.set_context(embedding, embedding_mask, self._stream())
+            self._ctx_key = (plan, weakref.ref(embedding), embedding._version,
+                             None if embedding_mask is None else weakref.ref(embedding_mask),
+                             None if embedding_mask is None else embedding_mask._version)
+        plan.set_rows(drop_rows, uncond_only)
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, time: torch.Tensor, *, embedding: torch.Tensor,
+                embedding_mask: Optional[torch.Tensor] = None, embedding_scale: float = 1.0,
+                embedding_mask_proba: float = 0.0, batch_cfg: bool = False, scale_cfg: bool = False,
+                scale_phi: float = 0.7, features=None, channels_list: Optional[Sequence[torch.Tensor]] = None,
+                causal: Optional[bool] = False, dropout_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same contract as the reference forward (model.py:299-376); returns a fresh
+        float32 [B, out_channels, T] tensor.  ``dropout_rows`` (bool[B]) optionally injects
+        the CFG-dropout draw that the reference takes from ``rand_bool`` (model.py:325)."""
+        assert features is None, "context_features is unused on the JEN-1 path"
+        eng = self.engine()
+        lib = eng.lib
+        B, _, T = x.shape
+        causal = bool(causal)
+        drop = None
+        if embedding_mask_proba > 0.0:
+            if dropout_rows is not None:
+                drop = dropout_rows
+            elif embedding_mask_proba >= 1.0:
+                drop = torch.ones(B, dtype=torch.bool, device=self._device)
+            else:   # rand_bool (utils/module.py:36-42)
+                drop = torch.bernoulli(torch.full((B,), float(embedding_mask_proba), device=self._device)).to(torch.bool)
+        Co = self.spec.out_channels
+        out = torch.empty((B, Co, T), dtype=torch.float32, device=self._device)
+        s = self._stream()
+        if embedding_scale != 1.0:
+            if batch_cfg:
+                plan = eng.plan(B, T, 2, causal)
+                self._prepare(plan, x, time, embedding, embedding_mask, channels_list, drop)
+                plan.run(s)
+                net = plan.net_out
+            else:
+                plan = eng.plan(B, T, 1, causal)
+                both = torch.empty((2 * B, T, plan.net_out.ld), dtype=eng.tdtype, device=self._device)
+                self._prepare(plan, x, time, embedding, embedding_mask, channels_list, drop)
+                plan.run(s)
+                both[:B].copy_(plan.net_out.t)
+                plan.set_rows(None, uncond_only=True)
+                plan.run(s)
+                both[B:].copy_(plan.net_out.t)
+                net = type(plan.net_out)(both, 2 * B, T, Co, plan.net_out.ld)
+            L.check(lib.jen1_cfg_combine(net.t.data_ptr(), out.data_ptr(), B, Co, T, net.ld, float(embedding_scale),
+                                         1 if scale_cfg else 0, float(scale_phi), eng.dt, s), "jen1_cfg_combine")
+            return out
+        plan = eng.plan(B, T, 1, causal)
+        self._prepare(plan, x, time, embedding, embedding_mask, channels_list, drop)
+        plan.run(s)
+        L.check(lib.jen1_unpack_output(plan.net_out.t.data_ptr(), out.data_ptr(), B, Co, T, plan.net_out.ld, eng.dt, s),
+                "jen1_unpack_output")
+        return out
