@@ -255,7 +255,8 @@ class OpBuilder:
         self._choose_tiles(a, force)
         if a.splitk > 1:
             self._splitk_args.append(a)
-        self._keep.append(a)
+        # the prepared launch holds raw pointers: keep every tensor it references alive
+        self._keep.append((a, src0, src1, w, bias, out, residual, row_scale, gn, film, ln))
         lib = eng.lib
         ref = C.byref(a)
         ops.append(lambda s, ref=ref, lib=lib: L.check(lib.jen1_conv_gemm(ref, s), "jen1_conv_gemm"))
@@ -323,6 +324,7 @@ class OpBuilder:
                 _ptr(extra_row), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
                 1 if causal else 0, float(d) ** -0.5, eng.dt)
         lib = eng.lib
+        self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row))
         ops.append(lambda s, args=args, lib=lib: L.check(lib.jen1_attention(*args, s), "jen1_attention"))
 
 
