@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -194,6 +195,12 @@ class OpBuilder:
     def run(self, stream: Optional[int] = None):
         if stream is None:
             stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        if os.environ.get("JEN1_DEBUG_SYNC"):
+            for i, op in enumerate(self.ops):
+                print(f"[jen1] op {i}: {getattr(op, 'label', '?')}", flush=True)
+                op(stream)
+                torch.cuda.synchronize(self.eng.device)
+            return
         for op in self.ops:
             op(stream)
 
@@ -201,7 +208,7 @@ class OpBuilder:
     def conv(self, ops, *, src0: Act, w: torch.Tensor, bias, out: Act, taps=1, stride=1, pad_left=0, L_out=None,
              src1: Optional[Act] = None, src1_scale=1.0, ps_f=1, ps_off=0, L_y=None, y_row0=0, pro=L.PRO_NONE,
              gn=None, film=None, ln=None, act=L.ACT_NONE, residual: Optional[Act] = None, row_scale=None,
-             y_f32=False, out_C=None, force=None):
+             y_f32=False, out_C=None, force=None, label=""):
         eng = self.eng
         a = L.ConvArgs()
         a.x0, a.c0, a.ld0 = src0.t.data_ptr(), src0.ld, src0.ld
@@ -259,7 +266,10 @@ class OpBuilder:
         self._keep.append((a, src0, src1, w, bias, out, residual, row_scale, gn, film, ln))
         lib = eng.lib
         ref = C.byref(a)
-        ops.append(lambda s, ref=ref, lib=lib: L.check(lib.jen1_conv_gemm(ref, s), "jen1_conv_gemm"))
+        fn = lambda s, ref=ref, lib=lib: L.check(lib.jen1_conv_gemm(ref, s), "jen1_conv_gemm")
+        fn.label = (f"conv[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} s={a.stride} M={a.M} "
+                    f"ps={a.ps_f}/{a.ps_off} Ly={a.L_y} pro={a.pro_mode} cfg={a.cfg} tb={a.tb} nb={a.nb} kst={a.kc_stage} sk={a.splitk}")
+        ops.append(fn)
         return out
 
     def _choose_tiles(self, a: L.ConvArgs, force=None):
@@ -325,7 +335,9 @@ class OpBuilder:
                 1 if causal else 0, float(d) ** -0.5, eng.dt)
         lib = eng.lib
         self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row))
-        ops.append(lambda s, args=args, lib=lib: L.check(lib.jen1_attention(*args, s), "jen1_attention"))
+        fn = lambda s, args=args, lib=lib: L.check(lib.jen1_attention(*args, s), "jen1_attention")
+        fn.label = f"attention B={q.B} H={H} d={d} Nq={q.L} Nk={Nk} causal={causal}"
+        ops.append(fn)
 
 
 
@@ -456,6 +468,7 @@ class Plan(OpBuilder):
         tf = torch.empty((B, mf), dtype=f32, device=dev)
         m1 = torch.empty((B, mf), dtype=f32, device=dev)
         self.mapping = torch.empty((B, mf), dtype=f32, device=dev)
+        self._keep += [tf, m1]          # referenced by raw pointer below
         v = W.v
         a = (self.t_in.data_ptr(), v["to_time.0.0.weights"].data_ptr(), v["to_time.0.1.weight"].data_ptr(),
              v["to_time.0.1.bias"].data_ptr(), tf.data_ptr(), B, half, mf)
@@ -479,6 +492,7 @@ class Plan(OpBuilder):
         self.kvx = None
         if spec.use_xattn_time and n_tr:
             tok = torch.empty((B, F), dtype=f32, device=dev)
+            self._keep.append(tok)
             a = (self.t_in.data_ptr(), v["to_time_embedding.0.0.weights"].data_ptr(), v["to_time_embedding.0.1.weight"].data_ptr(),
                  v["to_time_embedding.0.1.bias"].data_ptr(), tok.data_ptr(), B, half, F)
             ops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
