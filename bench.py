@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- denoiser steps/sec of the JEN-1 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one denoiser step of the DDIM sampler: one UNetCFG1d forward over the batch plus the
+fused x0/eps prediction and DDIM update (reference gdm.py:202-222).  Workload at N=1 is
+BASELINE.json configs[1]: full JEN-1 1D-UNet (296.5 M parameters, random init), B=8 synthetic
+Encodec latents 128x1500, 100-step DDIM schedule, bf16 storage / fp32 accumulate.  With N>1 every
+rank runs its own B=8 batch (independent samples, no data-path collective): weak scaling.
+
+The JSON line also carries
+  roofline      -- fused conv-GEMM kernel family (the dominant kernel): algorithmic HBM bytes per
+                   launch / measured average launch duration (HIP events on the launch stream)
+                   against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md;
+  cpu_baseline  -- the numpy oracle (a port of the reference's CPU path) timed on this box's host
+                   cores on a bounded sample of the same workload (rank 0, N=1 only);
+  extra         -- configs[2] (CFG pair, effective batch 16) measured the same way.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "jen-1-pytorch_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--length", type=int, default=1500)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="configs[0] tiny UNet (plumbing check)")
+    return ap.parse_args()
+
+
+def dev(a, device):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def build_stepper(model, B, T, device, cfg_pair, use_graph):
+    from jen1_amd import synth
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device=device,
+                           cfg_dropout_proba=0.0, embedding_scale=0.8 if cfg_pair else 1.0, batch_cfg=True,
+                           scale_cfg=True, sampling_timesteps=100)
+    cond = {k: dev(v, device) for k, v in synth.conditioning(B, T).items()}
+    st = gd.stepper(model, (B, 128, T), cond, causal=False, use_graph=use_graph)
+    st.reset(dev(synth.latents(B, T), device))
+    return st
+
+
+def timed_steps(st, steps, warmup, barrier):
+    for i in range(warmup):
+        st.step(i % st.num_steps)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        st.step((warmup + i) % st.num_steps)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0
+
+
+def conv_roofline(st, reps=3):
+    """Average duration of the fused conv-GEMM launches of one denoiser step, measured with HIP
+    events recorded on the launch stream around every launch (eager replay of the same plan)."""
+    plan = st.plan
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+    convs = [op for op in plan.ops if getattr(op, "kind", "") == "conv_gemm"]
+    n = len(convs)
+    tot_ms = 0.0
+    per_op = np.zeros(n)
+    for rep in range(reps + 1):
+        evs = []
+        for op in plan.ops:
+            if getattr(op, "kind", "") == "conv_gemm":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                op(s)
+                e1.record(stream)
+                evs.append((e0, e1))
+            else:
+                op(s)
+        torch.cuda.synchronize()
+        if rep == 0:
+            continue            # first pass warms caches / clocks
+        d = np.array([a.elapsed_time(b) for a, b in evs])
+        per_op += d
+        tot_ms += float(d.sum())
+    per_op /= reps
+    w_bytes = sum(op.w_bytes for op in convs)
+    a_bytes = sum(op.act_bytes for op in convs)
+    flops = sum(op.flops for op in convs)
+    conv_ms = tot_ms / reps
+    alg = w_bytes + a_bytes
+    achieved = alg / (conv_ms * 1e-3) / 1e9
+    top = sorted(range(n), key=lambda i: -per_op[i])[:5]
+    if os.environ.get("JEN1_BENCH_OPS"):
+        with open(os.environ["JEN1_BENCH_OPS"], "w") as f:
+            for i in range(n):
+                f.write(f"{per_op[i] * 1e3:8.1f} us  w={convs[i].w_bytes / 1e6:7.2f}MB act={convs[i].act_bytes / 1e6:6.2f}MB  {convs[i].label}\n")
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": "conv_gemm_kernel<*> (fused GroupNorm/LayerNorm + conv/linear implicit GEMM)",
+        "launches_per_step": n, "avg_launch_us": round(conv_ms * 1e3 / n, 2), "conv_ms_per_step": round(conv_ms, 4),
+        "alg_bytes_per_step": int(alg), "alg_weight_bytes": int(w_bytes), "alg_act_bytes": int(a_bytes),
+        "alg_bytes_per_launch": int(alg / n), "executed_gflop_per_step": round(flops / 1e9, 2),
+        "slowest_launches_us": [[convs[i].label.split(" pro=")[0], round(per_op[i] * 1e3, 1)] for i in top],
+    }
+
+
+def cpu_baseline(B, T, tiny):
+    """The CPU oracle (numpy port of the reference path) on the host cores: bounded sample."""
+    from jen1_amd import synth
+    from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config
+    from jen1_amd.init_fill import fill
+    from oracle import jen1_oracle as O
+    cfg = tiny_model_config() if tiny else full_model_config()
+    spec = UNetSpec(**cfg)
+    net = O.OracleUNetCFG1d({k: fill(k, s, 1234) for k, s in spec.param_shapes()}, **cfg)
+    x, cond = synth.latents(B, T), synth.conditioning(B, T)
+    t = np.full((B,), 999, dtype=np.int64)
+    kw = dict(embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=1.0,
+              channels_list=[cond["input_concat_cond"]], causal=False)
+    net(x, t, **kw)                                    # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < 12.0 and len(times) < 10):
+        t0 = time.perf_counter()
+        net(x, t, **kw)
+        times.append(time.perf_counter() - t0)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": round(1.0 / float(np.median(times)), 4), "unit": "denoiser steps/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} UNetCFG1d forwards (no CFG) at B={B}, T={T} with the numpy oracle, median; "
+                      f"min {min(times):.3f}s max {max(times):.3f}s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank,
+                                device_id=torch.device(device))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from jen1_amd.config import full_model_config, tiny_model_config
+    from jen1_amd.model import UNetCFG1d
+    cfg = tiny_model_config() if args.tiny else full_model_config()
+    B, T = args.batch, args.length
+    model = UNetCFG1d(**cfg, compute_dtype=args.dtype, device=device)
+    st = build_stepper(model, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
+    dt = timed_steps(st, args.steps, args.warmup, barrier)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * args.steps / dt
+
+    out = {
+        "metric": "denoiser steps/sec (B=8, 128x1500 latents)", "value": round(value, 2), "unit": "denoiser steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[1] full JEN-1 1D-UNet (296.5M params)")
+                   + f", B={B} per GPU, latents 128x{T}, 100-step DDIM schedule, no CFG, hipGraph-replayed step",
+                   "global_batch": B * world, "seq_len": T, "parallelism": f"replicas x{world} (independent samples)"},
+    }
+    if rank == 0:
+        out["roofline"] = conv_roofline(st)
+        out["launches_per_step"] = st.plan.n_launch + 1
+        if not args.no_extra:
+            st2 = build_stepper(model, B, T, device, cfg_pair=True, use_graph=not args.no_graph)
+            dt2 = timed_steps(st2, max(10, args.steps // 2), max(3, args.warmup // 2), lambda: None)
+            n2 = max(10, args.steps // 2)
+            r2 = conv_roofline(st2)
+            out["extra"] = {"configs[2] CFG pair (2B=16) + rescale, steps/s": round(n2 / dt2, 2),
+                            "ms_per_step": round(dt2 / n2 * 1e3, 4),
+                            "roofline_frac": r2["frac"], "alg_bytes_per_step": r2["alg_bytes_per_step"],
+                            "conv_ms_per_step": r2["conv_ms_per_step"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, T, args.tiny)
+        print(json.dumps(out))
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

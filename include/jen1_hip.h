@@ -40,12 +40,15 @@ extern "C" {
 #define JEN1_ACT_NONE 0
 #define JEN1_ACT_GELU 1      /* exact erf GELU                blocks.py:444, model.py:77-98 */
 
-/* tile configurations of jen1_conv_gemm (BM x BN output tile per 256-thread workgroup) */
-#define JEN1_CFG_128x128 0
-#define JEN1_CFG_128x64 1
-#define JEN1_CFG_64x64 2
-#define JEN1_CFG_64x32 3
-#define JEN1_CFG_64x16 4
+/* tile configurations of jen1_conv_gemm: BM x BN output tile per 256-thread workgroup.
+ * W* = "wide": 4 waves x 16*MF output rows, K not split (activation-heavy levels);
+ * S* = "streaming": one 16-row M tile, the 4 waves split K and reduce through LDS (deep levels,
+ *      pure weight streaming: 16-row tiles give >= 64 workgroups at C_out = 1024). */
+#define JEN1_CFG_W64x64 0
+#define JEN1_CFG_W128x64 1
+#define JEN1_CFG_S16x64 2
+#define JEN1_CFG_S16x32 3
+#define JEN1_CFG_S16x16 4
 #define JEN1_NUM_CFG 5
 
 /*
@@ -108,6 +111,8 @@ typedef struct jen1_conv_args {
   int32_t kc_stage;          /* 32-channel chunks staged in LDS at a time */
   int32_t splitk;
   int32_t cfg;               /* JEN1_CFG_* */
+  int32_t direct;            /* 1: no LDS staging, activation fragments straight from global memory
+                                (streaming cfgs only, pro_mode must be JEN1_PRO_NONE) */
 } jen1_conv_args;
 
 int jen1_conv_gemm(const jen1_conv_args* args, void* stream);
@@ -116,6 +121,30 @@ int64_t jen1_conv_gemm_lds_bytes(const jen1_conv_args* args);
 /* BM / BN of a tile configuration */
 int jen1_cfg_bm(int cfg);
 int jen1_cfg_bn(int cfg);
+
+/*
+ * Normalise (+FiLM) (+SiLU) a small channel-last tensor ONCE, ahead of a streaming GEMM.
+ * On the deep levels (T' <= 24) a GEMM has up to 192 M-tile workgroups that would each redo the
+ * prologue of the same tiny activation tile; this pre-pass does it once.
+ *   mode JEN1_PRO_GN / JEN1_PRO_GN_SILU: GroupNorm over the channel concat [x0, x1*src1_scale]
+ *        (+ x*(scale+1)+shift)(+ SiLU)                       blocks.py:140-144, :530, :732-734
+ *   mode JEN1_PRO_LN: LayerNorm (gamma/beta optional)           blocks.py:427
+ * y: [B][L][c0+c1] in `dtype`.  Statistics come from the producers' epilogues (same layout as
+ * jen1_conv_args.gn_stats* / ln_rowstats).
+ */
+typedef struct jen1_norm_args {
+  const void* x0; const void* x1; void* y;
+  const float* gn_stats0; const float* gn_stats1;
+  const float* gamma; const float* beta;       /* [c0+c1]; may be NULL for LN (standardise only) */
+  const float* film; const int32_t* film_row;
+  const float* ln_rowstats;
+  int32_t dtype, mode, B, L, c0, c1, ld0, ld1, ld_y;
+  int32_t groups, cpg, count;
+  float eps, src1_scale;
+  int32_t film_off, film_C, film_ld;
+} jen1_norm_args;
+
+int jen1_norm_apply(const jen1_norm_args* args, void* stream);
 
 /*
  * Multi-head attention core, softmax in fp32 with wavefront-shuffle reductions.

@@ -74,7 +74,7 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&o)[4]) {
   *reinterpret_cast<bf16x4*>(p) = a;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // precise variant for the float32 parity mode (expf, IEEE division)
 __device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

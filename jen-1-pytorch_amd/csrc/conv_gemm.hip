@@ -17,25 +17,31 @@
 //     separate norm/activation pass).
 //   * MFMA: v_mfma_f32_16x16x32_bf16 (bf16 mode) or 8 x v_mfma_f32_16x16x4_f32
 //     (float32 parity mode, exact fp32 FMA chain).  64-lane wavefronts, 4 waves / WG.
+//   * Two wave layouts: WM=4 (4 waves x 16*MF output rows, K not split) for the wide
+//     levels, and WK=4 (one 16-row M tile, the 4 waves split K and reduce through LDS)
+//     for the deep, skinny levels where a launch is pure weight streaming: 16-row M
+//     tiles give >= 64 workgroups for C_out = 1024 without any inter-workgroup reduction.
+//   * latency structure: every independent global load (weight ring, first activation
+//     batch, statistics, gamma/beta) is issued before the first barrier; taps that only
+//     see zero padding are skipped together with their weights (exact).
 //   * epilogue: bias, GELU, residual, row mask, sub-pixel (transposed-conv) row
 //     mapping with crop, and the statistics of the NEXT norm layer (GroupNorm
 //     fine-group sums, LayerNorm row sums) via LDS + global float atomics.
-//   * split-K for the deep, skinny levels (T' <= 24): partial slabs + agent-scope
-//     release / ticket / acquire, last-arriving workgroup reduces and runs the
-//     epilogue (cdna_hip_programming.md section 5 "in-launch split-K reduction").
+//   * optional inter-workgroup split-K: partial slabs + agent-scope release / ticket /
+//     acquire, last arriver reduces (cdna_hip_programming.md section 5).
 #include "common.h"
 
 namespace {
 
 struct Layout {
   int ldsld;      // LDS row pitch in elements (stage channels + 8)
-  int seg;        // staged input rows per batch element
-  int tile_off, tab_a_off, tab_b_off, grp_off, row_off, stats_off, misc_off, total;
+  int seg;        // staged input rows per batch element (all taps live)
+  int tile_off, gam_off, bet_off, grp_off, row_off, stats_off, red_off, misc_off, total;
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 
-__host__ __device__ inline Layout make_layout(const jen1_conv_args& a, int esize) {
+__host__ __device__ inline Layout make_layout(const jen1_conv_args& a, int esize, int red_floats) {
   Layout L;
   const int kch_total = (a.c0 + a.c1) / 32;
   const int cps = (kch_total + a.splitk - 1) / a.splitk;
@@ -44,18 +50,21 @@ __host__ __device__ inline Layout make_layout(const jen1_conv_args& a, int esize
   L.seg = (a.tb - 1) * a.stride + a.taps;
   int off = 0;
   L.tile_off = off;
-  off = align16(off + a.nb * L.seg * L.ldsld * esize);
+  if (!a.direct) off = align16(off + a.nb * L.seg * L.ldsld * esize);
   const bool gn = (a.pro_mode == JEN1_PRO_GN || a.pro_mode == JEN1_PRO_GN_SILU);
-  L.tab_a_off = off;
-  if (gn) off = align16(off + a.nb * stage_ch * 4);
-  L.tab_b_off = off;
-  if (gn) off = align16(off + a.nb * stage_ch * 4);
+  const bool tabs = gn || (a.pro_mode == JEN1_PRO_LN && a.ln_gamma);
+  L.gam_off = off;
+  if (tabs) off = align16(off + a.nb * stage_ch * 4);
+  L.bet_off = off;
+  if (tabs) off = align16(off + a.nb * stage_ch * 4);
   L.grp_off = off;
   if (gn) off = align16(off + a.nb * JEN1_FINE_GROUPS * 2 * 4);
   L.row_off = off;
   if (a.pro_mode == JEN1_PRO_LN) off = align16(off + a.nb * L.seg * 2 * 4);
   L.stats_off = off;
   if (a.out_gn_stats) off = align16(off + a.nb * JEN1_FINE_GROUPS * 2 * 4);
+  L.red_off = off;
+  off = align16(off + red_floats * 4);
   L.misc_off = off;
   off += 16;
   L.total = off;
@@ -89,35 +98,64 @@ __device__ __forceinline__ void frag_load(f32x8& f, const float* p) {
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
 __device__ __forceinline__ void frag_load(bf16x8& f, const bf16_t* p) { f = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void frag_zero(f32x8& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = 0.f;
+}
+__device__ __forceinline__ void frag_zero(bf16x8& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16_t)0.f;
+}
+__device__ __forceinline__ void frag_to_float(const f32x8& f, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f.v[j];
+}
+__device__ __forceinline__ void frag_to_float(const bf16x8& f, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (float)f[j];
+}
 
-template <typename T, int MF, int NF, int WM, int WN, int PF>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const jen1_conv_args a) {
+__device__ __forceinline__ void float_to_frag(f32x8& f, const float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = o[j];
+}
+__device__ __forceinline__ void float_to_frag(bf16x8& f, const float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16_t)o[j];
+}
+
+constexpr int VB = 4;   // activation vectors (8 channels each) per thread per staging batch
+
+template <typename T, int MF, int NF, int WM, int WK, int PF, bool DIRECT>
+__global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv_args a) {
   typedef typename FragOf<T>::type Frag;
+  constexpr int NT = 64 * WM * WK;     // threads per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 16 * MF * WM;
   constexpr bool PRECISE = is_f32<T>::value;
+  constexpr int RED_FLOATS = (WK > 1) ? (WK - 1) * WM * MF * NF * 256 : 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave % WM, wk = wave / WM;
   const int li = lane & 15, lg = lane >> 4;
 
-  const Layout L = make_layout(a, (int)sizeof(T));
+  const Layout L = make_layout(a, (int)sizeof(T), RED_FLOATS);
   T* tile = reinterpret_cast<T*>(smem + L.tile_off);
-  float* tab_a = reinterpret_cast<float*>(smem + L.tab_a_off);
-  float* tab_b = reinterpret_cast<float*>(smem + L.tab_b_off);
+  float* gam_s = reinterpret_cast<float*>(smem + L.gam_off);
+  float* bet_s = reinterpret_cast<float*>(smem + L.bet_off);
   float* grp = reinterpret_cast<float*>(smem + L.grp_off);
   float* rowtab = reinterpret_cast<float*>(smem + L.row_off);
   float* st_lds = reinterpret_cast<float*>(smem + L.stats_off);
+  float* red = reinterpret_cast<float*>(smem + L.red_off);
   int* misc = reinterpret_cast<int*>(smem + L.misc_off);
 
   // ---- tile coordinates -------------------------------------------------------------------
   const int tiles_t = (a.L_out + a.tb - 1) / a.tb;
   const int bt = blockIdx.y / tiles_t, tt = blockIdx.y - bt * tiles_t;
   const int b0 = bt * a.nb, t0 = tt * a.tb;
-  const int seg = L.seg, ldsld = L.ldsld;
-  const int tin0 = t0 * a.stride - a.pad_left;
+  const int ldsld = L.ldsld;
   const int ctot = a.c0 + a.c1;
   const int kch_total = ctot / 32;
   const int cps = (kch_total + a.splitk - 1) / a.splitk;
@@ -128,13 +166,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const jen1_conv_args a) 
   const int mt_base = blockIdx.x * (BM / 16) + wm * MF;
   const int n_rows = a.nb * a.tb;
 
+  // live taps: a tap whose input rows are all zero padding for every position of this tile
+  // contributes nothing -- skip it and its weights (exact).  At T' = 1 this drops 2/3 of a k=3 conv.
+  int tap_lo = 0, tap_hi = a.taps - 1;
+  {
+    const int t_last = ((t0 + a.tb < a.L_out) ? t0 + a.tb : a.L_out) - 1;
+    while (tap_lo < tap_hi && t_last * a.stride + tap_lo - a.pad_left < 0) ++tap_lo;
+    while (tap_hi > tap_lo && t0 * a.stride + tap_hi - a.pad_left >= a.L_in) --tap_hi;
+  }
+  const int ntaps = tap_hi - tap_lo + 1;
+  const int seg = (a.tb - 1) * a.stride + ntaps;
+  const int tin0 = t0 * a.stride + tap_lo - a.pad_left;
+
   // per-lane output column mapping
   int rowbase[NF];
   int n_b[NF], n_t[NF];
   bool n_ok[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
-    const int n = (wn * NF + nf) * 16 + li;
+    const int n = nf * 16 + li;
     const int bl = n / a.tb, tl = n - bl * a.tb;
     n_ok[nf] = (n < n_rows) && (b0 + bl < a.B) && (t0 + tl < a.L_out);
     n_b[nf] = bl;
@@ -150,13 +200,201 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const jen1_conv_args a) 
 
   const T* wbase = reinterpret_cast<const T*>(a.w);
   const bool gn = (a.pro_mode == JEN1_PRO_GN || a.pro_mode == JEN1_PRO_GN_SILU);
+  const bool ln = (a.pro_mode == JEN1_PRO_LN);
   const bool do_silu = (a.pro_mode == JEN1_PRO_GN_SILU || a.pro_mode == JEN1_PRO_SILU);
+  const bool tabs = gn || (ln && a.ln_gamma);
+  const int stage_chunks = (ldsld - 8) / 32;
 
-  // ---- one-time prologue tables: GroupNorm group statistics / LayerNorm row statistics ----
+  // ---- helpers ------------------------------------------------------------------------------
+  // weight fragment of this wave for (tap, chunk): clamped so the prefetch ring never runs off the end
+  auto load_a = [&](Frag(&dst)[MF], int tap, int kc) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int mt = mt_base + mf;
+      mt = mt < MT ? mt : MT - 1;
+      frag_load(dst[mf], wbase + ((size_t)((size_t)tap * MT + mt) * kch_total + kc) * 512 + lane * 8);
+    }
+  };
+  // activation batch: raw vectors (+ FiLM scale/shift vectors) of the staging loop
+  struct Batch {
+    Frag x[VB];
+  };
+  auto load_batch = [&](Batch& bt_, int v0, int sch, int cst) {
+    const int vpr = sch >> 3;
+    const int nvec = a.nb * seg * vpr;
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int v = v0 + u * NT + tid;
+      const int vv = v < nvec ? v : 0;
+      const int row = vv / vpr, cv = vv - row * vpr;
+      const int bl = row / seg, r = row - bl * seg;
+      const int b = b0 + bl, tin = tin0 + r;
+      const int c = cst + cv * 8;
+      const bool ok = v < nvec && b < a.B && tin >= 0 && tin < a.L_in;
+      const size_t grow = (size_t)(ok ? b : 0) * a.L_in + (ok ? tin : 0);
+      // branch-free (clamped address + select) so the staging loads are counted, not drained
+      const T* p = (c < a.c0) ? reinterpret_cast<const T*>(a.x0) + grow * a.ld0 + c
+                              : reinterpret_cast<const T*>(a.x1) + grow * a.ld1 + (c - a.c0);
+      frag_load(bt_.x[u], p);
+      if (!ok) frag_zero(bt_.x[u]);
+    }
+  };
+  auto store_batch = [&](const Batch& bt_, int v0, int sch, int cst) {
+    const int vpr = sch >> 3;
+    const int nvec = a.nb * seg * vpr;
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int v = v0 + u * NT + tid;
+      if (v >= nvec) continue;
+      const int row = v / vpr, cv = v - row * vpr;
+      const int bl = row / seg, r = row - bl * seg;
+      const int b = b0 + bl, tin = tin0 + r;
+      const int cl = cv * 8;
+      const int c = cst + cl;
+      float x[8];
+      frag_to_float(bt_.x[u], x);
+      const bool ok = (b < a.B) && (tin >= 0) && (tin < a.L_in);   // zero padding is applied AFTER the prologue
+      if (ok) {
+        if (gn) {
+          const float sc = (c >= a.c0) ? a.src1_scale : 1.0f;
+          int g0 = c / a.gn_cpg;
+          g0 = g0 < a.gn_groups ? g0 : a.gn_groups - 1;
+          const bool one_group = (c - g0 * a.gn_cpg + 8 <= a.gn_cpg) || (g0 == a.gn_groups - 1);
+          const float* gt = gam_s + bl * sch + cl;     // gamma * (1 + film scale)
+          const float* bt2 = bet_s + bl * sch + cl;    // beta * (1 + film scale) + film shift
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            int g = g0;
+            if (!one_group) {
+              g = (c + j) / a.gn_cpg;
+              g = g < a.gn_groups ? g : a.gn_groups - 1;
+            }
+            const float mean = grp[2 * (bl * a.gn_groups + g)], rstd = grp[2 * (bl * a.gn_groups + g) + 1];
+            const float A = rstd * gt[j];
+            x[j] = x[j] * (A * sc) + (bt2[j] - mean * A);
+          }
+        } else {
+          if (c >= a.c0 && a.src1_scale != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] *= a.src1_scale;
+          }
+          if (ln) {
+            const float mean = rowtab[2 * row], rstd = rowtab[2 * row + 1];
+            if (a.ln_gamma) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) x[j] = (x[j] - mean) * rstd * gam_s[bl * sch + cl + j] + bet_s[bl * sch + cl + j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) x[j] = (x[j] - mean) * rstd;
+            }
+          }
+        }
+        if (do_silu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
+        }
+      }
+      store8(tile + (size_t)row * ldsld + cl, x);
+    }
+  };
+
+  if constexpr (DIRECT) {
+    // ---- streaming path (deep levels): no LDS tile, no barrier.  The activation operand was
+    // normalised / activated once by jen1_norm_apply; here both operands of every (tap, chunk)
+    // step sit in one register ring that is refilled right after its slot is consumed.
+    const int nmy_d = (kc_end - kc_begin - wk + WK - 1) / WK;
+    const int nmy = nmy_d > 0 ? nmy_d : 0;
+    const int iters = ntaps * nmy;
+    const T* x0p = reinterpret_cast<const T*>(a.x0);
+    const T* x1p = reinterpret_cast<const T*>(a.x1);
+    Frag ra[PF][MF], rb[PF][NF];
+    // branch-free operand loads: every ring slot issues exactly MF + NF loads, so the compiler can
+    // count them (s_waitcnt vmcnt((PF-1)*(MF+NF))) instead of draining the ring; out-of-range rows
+    // read a clamped valid address and are zeroed by a select afterwards.
+    const T* nbase0[NF];
+    const T* nbase1[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const size_t rb0 = (size_t)(n_ok[nf] ? b0 + n_b[nf] : 0) * a.L_in;
+      nbase0[nf] = x0p + rb0 * a.ld0;
+      nbase1[nf] = a.c1 ? x1p + rb0 * a.ld1 - a.c0 : nbase0[nf];
+    }
+    auto load_slot = [&](Frag(&fa)[MF], Frag(&fb)[NF], int seq) {
+      const int sq = seq < iters ? seq : (iters > 0 ? iters - 1 : 0);
+      const int tp = nmy > 0 ? sq / nmy : 0;
+      const int jj = sq - tp * nmy;
+      int kc = kc_begin + wk + WK * jj;
+      kc = kc < kc_end ? kc : kc_end - 1;
+      load_a(fa, tap_lo + tp, kc);
+      const int c = kc * 32 + lg * 8;
+      const bool src1 = c >= a.c0;
+      const int ld = src1 ? a.ld1 : a.ld0;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int tin = (t0 + n_t[nf]) * a.stride + tap_lo + tp - a.pad_left;
+        const bool ok = n_ok[nf] && tin >= 0 && tin < a.L_in;
+        const T* base = src1 ? nbase1[nf] : nbase0[nf];
+        frag_load(fb[nf], base + (size_t)(ok ? tin : 0) * ld + c);
+        if (!ok) frag_zero(fb[nf]);
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_slot(ra[u], rb[u], u);
+    const bool scale1 = (a.c1 > 0) && (a.src1_scale != 1.0f);
+    for (int it = 0; it < iters; it += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (it + u < iters) {
+          if (scale1) {
+            const int tp = (it + u) / nmy;
+            const int kc = kc_begin + wk + WK * ((it + u) - tp * nmy);
+            if (kc * 32 >= a.c0) {
+#pragma unroll
+              for (int nf = 0; nf < NF; ++nf) {
+                float xv[8];
+                frag_to_float(rb[u][nf], xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] *= a.src1_scale;
+                float_to_frag(rb[u][nf], xv);
+              }
+            }
+          }
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) mma32(acc[mf][nf], ra[u][mf], rb[u][nf]);
+        }
+        load_slot(ra[u], rb[u], it + u + PF);
+      }
+    }
+    if (a.out_gn_stats) {
+      for (int i = tid; i < a.nb * 64; i += NT) st_lds[i] = 0.f;
+      __syncthreads();
+    }
+  } else {
+  // ==== phase 0: issue every independent global load =========================================
+  // (a) weight ring of the first stage
+  Frag ring[PF][MF];
+  int p_tap = 0, p_j = 0;                 // prefetch cursor: (live tap index, this wave's chunk index)
+  int nch = (kc_begin + stage_chunks <= kc_end) ? stage_chunks : (kc_end - kc_begin);
+  int nmy = (nch - wk + WK - 1) / WK;     // chunks of this wave in the stage: kcl = wk + WK*j
+  nmy = nmy > 0 ? nmy : 0;
+  auto ring_fill = [&](int ks, int nmy_) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int jj = p_j < nmy_ ? p_j : (nmy_ > 0 ? nmy_ - 1 : 0);
+      load_a(ring[u], tap_lo + p_tap, ks + wk + WK * jj < kc_end ? ks + wk + WK * jj : kc_end - 1);
+      if (++p_j >= nmy_) { p_j = 0; if (p_tap + 1 < ntaps) ++p_tap; else p_j = nmy_ > 0 ? nmy_ - 1 : 0; }
+    }
+  };
+  ring_fill(kc_begin, nmy);
+  // (b) first activation batch of the first stage
+  Batch cur;
+  load_batch(cur, 0, nch * 32, kc_begin * 32);
+  // (c) small tables: GroupNorm group statistics, LayerNorm row statistics
   if (gn) {
-    // grp[bl][g] = (mean, rstd) of group g of batch element b0+bl, merged from fine-group sums
     const int G = a.gn_groups;
-    for (int i = tid; i < a.nb * G; i += 256) {
+    for (int i = tid; i < a.nb * G; i += NT) {
       const int bl = i / G, g = i - bl * G;
       const int b = b0 + bl;
       float mean = 0.f, rstd = 0.f;
@@ -193,9 +431,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const jen1_conv_args a) 
       grp[2 * i + 1] = rstd;
     }
   }
-  if (a.pro_mode == JEN1_PRO_LN) {
+  if (ln) {
     const float inv_c = 1.0f / (float)a.ln_C;
-    for (int i = tid; i < a.nb * seg; i += 256) {
+    for (int i = tid; i < a.nb * seg; i += NT) {
       const int bl = i / seg, r = i - bl * seg;
       const int b = b0 + bl, tin = tin0 + r;
       float mean = 0.f, rstd = 0.f;
@@ -211,287 +449,272 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const jen1_conv_args a) 
     }
   }
   if (a.out_gn_stats) {
-    for (int i = tid; i < a.nb * 64; i += 256) st_lds[i] = 0.f;
+    for (int i = tid; i < a.nb * 64; i += NT) st_lds[i] = 0.f;
   }
 
-  // ---- K loop over LDS stages ---------------------------------------------------------------
-  const int stage_chunks = (L.ldsld - 8) / 32;
+  // ==== K loop over LDS stages ===============================================================
+  bool first_stage = true;
   for (int ks = kc_begin; ks < kc_end; ks += stage_chunks) {
-    const int nch = (ks + stage_chunks <= kc_end) ? stage_chunks : (kc_end - ks);
-    const int sch = nch * 32;          // channels in this stage
-    const int cst = ks * 32;           // first channel (concat space)
-    __syncthreads();                   // previous stage fully consumed; tables above visible
-    if (gn) {
-      // per-(batch element, channel) affine: v = x * A + B  (GroupNorm * gamma + beta, then FiLM)
-      for (int i = tid; i < a.nb * sch; i += 256) {
-        const int bl = i / sch, cl = i - bl * sch;
-        const int c = cst + cl;
-        const int b = b0 + bl;
-        float A = 0.f, Bc = 0.f;
-        if (b < a.B) {
-          int g = c / a.gn_cpg;
-          g = g < a.gn_groups ? g : a.gn_groups - 1;
-          const float mean = grp[2 * (bl * a.gn_groups + g)], rstd = grp[2 * (bl * a.gn_groups + g) + 1];
-          const float gam = a.gn_gamma[c], bet = a.gn_beta[c];
-          const float sc = (c >= a.c0) ? a.src1_scale : 1.0f;
-          A = rstd * gam;
-          Bc = bet - mean * A;
-          A *= sc;
-          if (a.film) {
-            const int fr = a.film_row ? a.film_row[b] : b;
-            const float* fp = a.film + (size_t)fr * a.film_ld + a.film_off;
-            const float fs = fp[c] + 1.0f, fh = fp[a.film_C + c];
-            A *= fs;
-            Bc = Bc * fs + fh;
-          }
-        }
-        tab_a[i] = A;
-        tab_b[i] = Bc;
-      }
-      __syncthreads();
+    nch = (ks + stage_chunks <= kc_end) ? stage_chunks : (kc_end - ks);
+    nmy = (nch - wk + WK - 1) / WK;
+    nmy = nmy > 0 ? nmy : 0;
+    const int sch = nch * 32;
+    const int cst = ks * 32;
+    if (!first_stage) {
+      __syncthreads();                 // previous stage fully consumed
+      p_tap = 0; p_j = 0;
+      ring_fill(ks, nmy);
+      load_batch(cur, 0, sch, cst);
     }
-    // stage the activation tile (+ halo) with the prologue applied; zeros outside [0, L_in)
-    {
-      const int vpr = sch / 8;
-      const int nvec = a.nb * seg * vpr;
-      for (int v = tid; v < nvec; v += 256) {
-        const int row = v / vpr, cv = v - row * vpr;
-        const int bl = row / seg, r = row - bl * seg;
-        const int b = b0 + bl, tin = tin0 + r;
-        const int cl = cv * 8;
-        int c = cst + cl;
-        float x[8];
-        const bool ok = (b < a.B) && (tin >= 0) && (tin < a.L_in);
-        if (ok) {
-          if (c < a.c0) {
-            load8(reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.L_in + tin) * a.ld0 + c, x);
-          } else {
-            load8(reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.L_in + tin) * a.ld1 + (c - a.c0), x);
-            if (!gn && a.src1_scale != 1.0f) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) x[j] *= a.src1_scale;
-            }
-          }
-          if (gn) {
-            const float* ta = tab_a + bl * sch + cl;
-            const float* tb_ = tab_b + bl * sch + cl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = x[j] * ta[j] + tb_[j];
-          } else if (a.pro_mode == JEN1_PRO_LN) {
-            const float mean = rowtab[2 * row], rstd = rowtab[2 * row + 1];
-            if (a.ln_gamma) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) x[j] = (x[j] - mean) * rstd * a.ln_gamma[c + j] + a.ln_beta[c + j];
-            } else {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) x[j] = (x[j] - mean) * rstd;
-            }
-          }
-          if (do_silu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x[j] = 0.f;
+    if (tabs) {
+      const float* gsrc = gn ? a.gn_gamma : a.ln_gamma;
+      const float* bsrc = gn ? a.gn_beta : a.ln_beta;
+      for (int i = tid; i < a.nb * sch; i += NT) {
+        const int bl = i / sch, cl = i - bl * sch;
+        float gv = gsrc[cst + cl], bv = bsrc[cst + cl];
+        if (gn && a.film && b0 + bl < a.B) {
+          const int fr = a.film_row ? a.film_row[b0 + bl] : b0 + bl;
+          const float* fp = a.film + (size_t)fr * a.film_ld + a.film_off + cst + cl;
+          const float fs = fp[0] + 1.0f;
+          gv *= fs;
+          bv = bv * fs + fp[a.film_C];
         }
-        store8(tile + (size_t)row * ldsld + cl, x);
+        gam_s[i] = gv;
+        bet_s[i] = bv;
+      }
+    }
+    __syncthreads();                   // tables (and st_lds zeroing) visible
+    {
+      const int nvec = a.nb * seg * (sch >> 3);
+      for (int v0 = 0; v0 < nvec; v0 += NT * VB) {
+        Batch nxt;
+        const bool more = v0 + NT * VB < nvec;
+        if (more) load_batch(nxt, v0 + NT * VB, sch, cst);
+        store_batch(cur, v0, sch, cst);
+        if (more) cur = nxt;
       }
     }
     __syncthreads();
 
-    // ---- MFMA loop: taps x chunks, A fragments streamed from global with a PF-deep ring ----
-    const int iters = a.taps * nch;
-    int ptap = 0, pk = 0;   // prefetch cursor
-    auto load_a = [&](Frag(&dst)[MF], int tap, int kcl) {
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        int mt = mt_base + mf;
-        mt = mt < MT ? mt : MT - 1;
-        const T* p = wbase + ((size_t)((size_t)tap * MT + mt) * kch_total + (ks + kcl)) * 512 + lane * 8;
-        frag_load(dst[mf], p);
-      }
-    };
-    auto advance = [&](int& tap, int& kcl) {
-      if (++kcl == nch) {
-        kcl = 0;
-        if (tap + 1 < a.taps) ++tap; else kcl = nch - 1;   // clamp at the last fragment
-      }
-    };
-    Frag cur[PF][MF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      load_a(cur[u], ptap, pk);
-      advance(ptap, pk);
-    }
-    int ctap = 0, ck = 0;
+    // ---- MFMA loop: this wave's (live tap, chunk) pairs, weights from the prefetch ring -------
+    const int iters = ntaps * nmy;
+    int c_tap = 0, c_j = 0;
     for (int it = 0; it < iters; it += PF) {
       Frag nxt[PF][MF];
+      {
+        // refill: next PF fragments (clamped at the end of the stage)
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        load_a(nxt[u], ptap, pk);
-        advance(ptap, pk);
+        for (int u = 0; u < PF; ++u) {
+          const int jj = p_j < nmy ? p_j : nmy - 1;
+          int kc = ks + wk + WK * jj;
+          kc = kc < kc_end ? kc : kc_end - 1;
+          load_a(nxt[u], tap_lo + p_tap, kc);
+          if (++p_j >= nmy) { p_j = 0; if (p_tap + 1 < ntaps) ++p_tap; else p_j = nmy - 1; }
+        }
       }
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         if (it + u < iters) {
+          const int kcl = wk + WK * c_j;
           Frag bfr[NF];
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
-            frag_load(bfr[nf], tile + (size_t)(rowbase[nf] + ctap) * ldsld + ck * 32 + lg * 8);
+            frag_load(bfr[nf], tile + (size_t)(rowbase[nf] + c_tap) * ldsld + kcl * 32 + lg * 8);
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) mma32(acc[mf][nf], cur[u][mf], bfr[nf]);
-          if (++ck == nch) { ck = 0; ++ctap; }
+            for (int nf = 0; nf < NF; ++nf) mma32(acc[mf][nf], ring[u][mf], bfr[nf]);
+          if (++c_j == nmy) { c_j = 0; ++c_tap; }
         }
       }
 #pragma unroll
       for (int u = 0; u < PF; ++u)
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) cur[u][mf] = nxt[u][mf];
+        for (int mf = 0; mf < MF; ++mf) ring[u][mf] = nxt[u][mf];
     }
+    first_stage = false;
   }
 
-  // ---- split-K: publish partial slab, last arriver reduces ---------------------------------
+  }   // !DIRECT
+
+  // ==== intra-workgroup K reduction (WK > 1): waves wk > 0 hand their partials to wk == 0 =====
+  if (WK > 1) {
+    if (wk > 0) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          *reinterpret_cast<float4*>(red + ((size_t)(((wk - 1) * WM + wm) * MF + mf) * NF + nf) * 256 + lane * 4) =
+              make_float4(acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]);
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int w2 = 1; w2 < WK; ++w2)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const float4 o = *reinterpret_cast<const float4*>(red + ((size_t)(((w2 - 1) * WM + wm) * MF + mf) * NF + nf) * 256 + lane * 4);
+            acc[mf][nf][0] += o.x; acc[mf][nf][1] += o.y; acc[mf][nf][2] += o.z; acc[mf][nf][3] += o.w;
+          }
+    }
+  }
+  const bool owner = (wk == 0);        // waves that hold finished (or to-be-published) accumulators
+
+  // ==== inter-workgroup split-K: publish partial slab, last arriver reduces ==================
+  // Fence-free form of the hand-off (cdna_hip_programming.md Guideline 16, R1): the partial tile is
+  // stored WRITE-THROUGH (relaxed agent-scope 8-byte atomic stores lower to `global_store ... sc1`),
+  // every storing wave drains vmcnt, one lane takes a ticket; the last arriver reads the other slabs
+  // with sc1 loads (L1 bypass), so neither a release nor an acquire fence is needed.
   if (a.splitk > 1) {
+    typedef unsigned long long u64;
     const unsigned tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-    float* slab = a.slab + ((size_t)tile_id * a.splitk) * (size_t)(MF * NF * 1024);
-    float* mine = slab + (size_t)z * (MF * NF * 1024);
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf)
-        *reinterpret_cast<float4*>(mine + (size_t)(mf * NF + nf) * 1024 + tid * 4) =
-            make_float4(acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      misc[0] = (int)__hip_atomic_fetch_add(a.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const int ticket = misc[0];
-    if (ticket != a.splitk - 1) return;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(a.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    for (int zz = 0; zz < a.splitk; ++zz) {
-      if (zz == z) continue;
-      const float* other = slab + (size_t)zz * (MF * NF * 1024);
+    constexpr int SLAB = WM * MF * NF * 256;     // floats per (tile, split)
+    float* slab = a.slab + ((size_t)tile_id * a.splitk) * (size_t)SLAB;
+    float* mine = slab + (size_t)z * SLAB;
+    if (owner) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-          const float4 o = *reinterpret_cast<const float4*>(other + (size_t)(mf * NF + nf) * 1024 + tid * 4);
-          acc[mf][nf][0] += o.x; acc[mf][nf][1] += o.y; acc[mf][nf][2] += o.z; acc[mf][nf][3] += o.w;
+          u64* p = reinterpret_cast<u64*>(mine + ((size_t)(wm * MF + mf) * NF + nf) * 256 + lane * 4);
+          const u64 lo = ((u64)__float_as_uint(acc[mf][nf][1]) << 32) | __float_as_uint(acc[mf][nf][0]);
+          const u64 hi = ((u64)__float_as_uint(acc[mf][nf][3]) << 32) | __float_as_uint(acc[mf][nf][2]);
+          __hip_atomic_store(p, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      misc[0] = (int)__hip_atomic_fetch_add(a.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = misc[0];
+    if (ticket != a.splitk - 1) return;
+    if (tid == 0) __hip_atomic_store(a.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (owner) {
+      for (int zz = 0; zz < a.splitk; ++zz) {
+        if (zz == z) continue;
+        const float* other = slab + (size_t)zz * SLAB;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            u64* p = reinterpret_cast<u64*>(const_cast<float*>(other) + ((size_t)(wm * MF + mf) * NF + nf) * 256 + lane * 4);
+            const u64 lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[mf][nf][0] += __uint_as_float((unsigned)lo);
+            acc[mf][nf][1] += __uint_as_float((unsigned)(lo >> 32));
+            acc[mf][nf][2] += __uint_as_float((unsigned)hi);
+            acc[mf][nf][3] += __uint_as_float((unsigned)(hi >> 32));
+          }
+      }
     }
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------
-  T* yT = reinterpret_cast<T*>(a.y);
-  float* yF = reinterpret_cast<float*>(a.y);
-  const T* res = reinterpret_cast<const T*>(a.residual);
-  float rs_sum[NF], rs_sq[NF];
-  int yrow_n[NF];
+  // ==== epilogue (owner waves) =================================================================
+  if (owner) {
+    T* yT = reinterpret_cast<T*>(a.y);
+    float* yF = reinterpret_cast<float*>(a.y);
+    const T* res = reinterpret_cast<const T*>(a.residual);
+    float rs_sum[NF], rs_sq[NF];
+    int yrow_n[NF];
 #pragma unroll
-  for (int nf = 0; nf < NF; ++nf) { rs_sum[nf] = 0.f; rs_sq[nf] = 0.f; yrow_n[nf] = -1; }
+    for (int nf = 0; nf < NF; ++nf) { rs_sum[nf] = 0.f; rs_sq[nf] = 0.f; yrow_n[nf] = -1; }
 
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
-    const int mt = mt_base + mf;
-    const int m = mt * 16 + lg * 4;
-    const bool m_ok = mt < MT;
-    const int ph = m_ok ? m / a.out_C : 0;
-    const int co = m - ph * a.out_C;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (m_ok && a.bias) {
-      const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-      bias4[0] = bb.x; bias4[1] = bb.y; bias4[2] = bb.z; bias4[3] = bb.w;
-    }
-    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};   // nb == 1 path: per channel-pair sums over nf
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int b = b0 + n_b[nf];
-      const int ty = (t0 + n_t[nf]) * a.ps_f + ph - a.ps_off;
-      const bool ok = m_ok && n_ok[nf] && ty >= 0 && ty < a.L_y;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias4[r];
-      if (a.act == JEN1_ACT_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    for (int mf = 0; mf < MF; ++mf) {
+      const int mt = mt_base + mf;
+      const int m = mt * 16 + lg * 4;
+      const bool m_ok = mt < MT;
+      const int ph = m_ok ? m / a.out_C : 0;
+      const int co = m - ph * a.out_C;
+      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (m_ok && a.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+        bias4[0] = bb.x; bias4[1] = bb.y; bias4[2] = bb.z; bias4[3] = bb.w;
       }
-      if (ok) {
-        const size_t yrow = (size_t)b * a.y_brows + a.y_row0 + ty;
-        yrow_n[nf] = (int)yrow;
-        if (res) {
-          float rr[4];
-          load4(res + yrow * a.ld_res + co, rr);
+      float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};   // nb == 1 path: per channel-pair sums over nf
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += rr[r];
+      for (int nf = 0; nf < NF; ++nf) {
+        const int b = b0 + n_b[nf];
+        const int ty = (t0 + n_t[nf]) * a.ps_f + ph - a.ps_off;
+        const bool ok = m_ok && n_ok[nf] && ty >= 0 && ty < a.L_y;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias4[r];
+        if (a.act == JEN1_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
-        if (a.row_scale) {
-          const float s = a.row_scale[yrow];
+        if (ok) {
+          const size_t yrow = (size_t)b * a.y_brows + a.y_row0 + ty;
+          yrow_n[nf] = (int)yrow;
+          if (res) {
+            float rr[4];
+            load4(res + yrow * a.ld_res + co, rr);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= s;
-        }
-        if (a.y_f32) store4(yF + yrow * a.ld_y + co, v);
-        else store4(yT + yrow * a.ld_y + co, v);
-        rs_sum[nf] += (v[0] + v[1]) + (v[2] + v[3]);
-        rs_sq[nf] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        if (a.out_gn_stats) {
-          if (a.nb == 1) {
-            gs[0] += v[0] + v[1]; gq[0] += v[0] * v[0] + v[1] * v[1];
-            gs[1] += v[2] + v[3]; gq[1] += v[2] * v[2] + v[3] * v[3];
-          } else {
+            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+          }
+          if (a.row_scale) {
+            const float s = a.row_scale[yrow];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-              const int fg = (co + 2 * p) / a.out_cpf;
-              atomicAdd(&st_lds[(n_b[nf] * JEN1_FINE_GROUPS + fg) * 2], v[2 * p] + v[2 * p + 1]);
-              atomicAdd(&st_lds[(n_b[nf] * JEN1_FINE_GROUPS + fg) * 2 + 1], v[2 * p] * v[2 * p] + v[2 * p + 1] * v[2 * p + 1]);
+            for (int r = 0; r < 4; ++r) v[r] *= s;
+          }
+          if (a.y_f32) store4(yF + yrow * a.ld_y + co, v);
+          else store4(yT + yrow * a.ld_y + co, v);
+          rs_sum[nf] += (v[0] + v[1]) + (v[2] + v[3]);
+          rs_sq[nf] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          if (a.out_gn_stats) {
+            if (a.nb == 1) {
+              gs[0] += v[0] + v[1]; gq[0] += v[0] * v[0] + v[1] * v[1];
+              gs[1] += v[2] + v[3]; gq[1] += v[2] * v[2] + v[3] * v[3];
+            } else {
+#pragma unroll
+              for (int p = 0; p < 2; ++p) {
+                const int fg = (co + 2 * p) / a.out_cpf;
+                atomicAdd(&st_lds[(n_b[nf] * JEN1_FINE_GROUPS + fg) * 2], v[2 * p] + v[2 * p + 1]);
+                atomicAdd(&st_lds[(n_b[nf] * JEN1_FINE_GROUPS + fg) * 2 + 1], v[2 * p] * v[2 * p] + v[2 * p + 1] * v[2 * p + 1]);
+              }
             }
           }
         }
       }
-    }
-    if (a.out_gn_stats && a.nb == 1) {
-      // all 16 columns of a fragment belong to the same batch element: reduce across them
+      if (a.out_gn_stats && a.nb == 1) {
+        // all 16 columns of a fragment belong to the same batch element: reduce across them
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        float s = gs[p], q = gq[p];
+        for (int p = 0; p < 2; ++p) {
+          float s = gs[p], q = gq[p];
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          s += __shfl_xor(s, off);
-          q += __shfl_xor(q, off);
-        }
-        if (li == 0 && m_ok) {
-          const int fg = (co + 2 * p) / a.out_cpf;
-          atomicAdd(&st_lds[fg * 2], s);
-          atomicAdd(&st_lds[fg * 2 + 1], q);
+          for (int off = 1; off < 16; off <<= 1) {
+            s += __shfl_xor(s, off);
+            q += __shfl_xor(q, off);
+          }
+          if (li == 0 && m_ok) {
+            const int fg = (co + 2 * p) / a.out_cpf;
+            atomicAdd(&st_lds[fg * 2], s);
+            atomicAdd(&st_lds[fg * 2 + 1], q);
+          }
         }
       }
     }
-  }
-  if (a.out_rowstats) {
+    if (a.out_rowstats) {
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      float s = rs_sum[nf], q = rs_sq[nf];
-      s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-      s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-      if (lg == 0 && yrow_n[nf] >= 0) {
-        unsafeAtomicAdd(a.out_rowstats + (size_t)yrow_n[nf] * 2, s);
-        unsafeAtomicAdd(a.out_rowstats + (size_t)yrow_n[nf] * 2 + 1, q);
+      for (int nf = 0; nf < NF; ++nf) {
+        float s = rs_sum[nf], q = rs_sq[nf];
+        s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        if (lg == 0 && yrow_n[nf] >= 0) {
+          unsafeAtomicAdd(a.out_rowstats + (size_t)yrow_n[nf] * 2, s);
+          unsafeAtomicAdd(a.out_rowstats + (size_t)yrow_n[nf] * 2 + 1, q);
+        }
       }
     }
   }
   if (a.out_gn_stats) {
     __syncthreads();
-    for (int i = tid; i < a.nb * 64; i += 256) {
+    for (int i = tid; i < a.nb * 64; i += NT) {
       const int b = b0 + i / 64;
       const float v = st_lds[i];
       if (b < a.B && v != 0.f) unsafeAtomicAdd(a.out_gn_stats + (size_t)b * 64 + (i & 63), v);
@@ -499,11 +722,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const jen1_conv_args a) 
   }
 }
 
-template <typename T, int MF, int NF, int WM, int WN, int PF>
+template <int MF, int NF, int WM, int WK>
+constexpr int red_floats() { return (WK > 1) ? (WK - 1) * WM * MF * NF * 256 : 0; }
+
+struct CfgDesc {
+  int MF, NF, WM, WK;
+};
+// JEN1_CFG_*: 0 = 64x64 wide, 1 = 128x64 wide, 2..4 = 16-row weight-streaming tiles (K split over the waves)
+#ifndef JEN1_SWK
+#define JEN1_SWK 4      // waves (= K slices) per streaming workgroup
+#endif
+constexpr CfgDesc kCfg[JEN1_NUM_CFG] = {{1, 4, 4, 1}, {2, 4, 4, 1}, {1, 4, 1, JEN1_SWK}, {1, 2, 1, JEN1_SWK}, {1, 1, 1, JEN1_SWK}};
+
+inline int cfg_red_floats(int cfg) {
+  const CfgDesc d = kCfg[cfg];
+  return d.WK > 1 ? (d.WK - 1) * d.WM * d.MF * d.NF * 256 : 0;
+}
+
+template <typename T, int MF, int NF, int WM, int WK, int PF, bool DIRECT>
 int launch(const jen1_conv_args& a, hipStream_t s) {
   constexpr int BM = 16 * MF * WM;
-  const Layout L = make_layout(a, (int)sizeof(T));
-  auto kern = conv_gemm_kernel<T, MF, NF, WM, WN, PF>;
+  const Layout L = make_layout(a, (int)sizeof(T), red_floats<MF, NF, WM, WK>());
+  auto kern = conv_gemm_kernel<T, MF, NF, WM, WK, PF, DIRECT>;
   static bool attr_set = false;
   if (!attr_set) {
     JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -512,19 +752,31 @@ int launch(const jen1_conv_args& a, hipStream_t s) {
   const int tiles_t = (a.L_out + a.tb - 1) / a.tb;
   const int tiles_b = (a.B + a.nb - 1) / a.nb;
   dim3 grid((a.M + BM - 1) / BM, tiles_t * tiles_b, a.splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(256), L.total, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WK), L.total, s, a);
   JEN1_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T>
 int dispatch(const jen1_conv_args& a, hipStream_t s) {
+  constexpr int PFW = is_f32<T>::value ? 4 : 8;     // prefetch ring depth of the wide layouts
+  constexpr int PFS = is_f32<T>::value ? 4 : 6;     // ... of the weight-streaming layouts (LDS-staged B)
+  constexpr int PFD = is_f32<T>::value ? 3 : 4;     // ... of the direct streaming layouts (A and B in the ring)
+  constexpr int PFD16 = is_f32<T>::value ? 6 : 10;  // one A + one B fragment per slot: deep ring
+  if (a.direct) {
+    switch (a.cfg) {
+      case JEN1_CFG_S16x64: return launch<T, 1, 4, 1, JEN1_SWK, PFD, true>(a, s);
+      case JEN1_CFG_S16x32: return launch<T, 1, 2, 1, JEN1_SWK, PFD + 2, true>(a, s);
+      case JEN1_CFG_S16x16: return launch<T, 1, 1, 1, JEN1_SWK, PFD16, true>(a, s);
+    }
+    return jen1_set_error("jen1_conv_gemm: direct mode needs a streaming (S16) cfg, got %d", a.cfg);
+  }
   switch (a.cfg) {
-    case JEN1_CFG_128x128: return launch<T, 4, 4, 2, 2, 1>(a, s);
-    case JEN1_CFG_128x64: return launch<T, 2, 4, 4, 1, 1>(a, s);
-    case JEN1_CFG_64x64: return launch<T, 1, 4, 4, 1, 2>(a, s);
-    case JEN1_CFG_64x32: return launch<T, 1, 2, 4, 1, 4>(a, s);
-    case JEN1_CFG_64x16: return launch<T, 1, 1, 4, 1, 4>(a, s);
+    case JEN1_CFG_W64x64: return launch<T, 1, 4, 4, 1, PFW, false>(a, s);
+    case JEN1_CFG_W128x64: return launch<T, 2, 4, 4, 1, PFW, false>(a, s);
+    case JEN1_CFG_S16x64: return launch<T, 1, 4, 1, JEN1_SWK, PFS, false>(a, s);
+    case JEN1_CFG_S16x32: return launch<T, 1, 2, 1, JEN1_SWK, PFS, false>(a, s);
+    case JEN1_CFG_S16x16: return launch<T, 1, 1, 1, JEN1_SWK, PFS, false>(a, s);
   }
   return jen1_set_error("jen1_conv_gemm: unknown cfg %d", a.cfg);
 }
@@ -532,20 +784,12 @@ int dispatch(const jen1_conv_args& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int jen1_cfg_bm(int cfg) {
-  switch (cfg) {
-    case JEN1_CFG_128x128: case JEN1_CFG_128x64: return 128;
-    case JEN1_CFG_64x64: case JEN1_CFG_64x32: case JEN1_CFG_64x16: return 64;
-  }
-  return -1;
+  if (cfg < 0 || cfg >= JEN1_NUM_CFG) return -1;
+  return 16 * kCfg[cfg].MF * kCfg[cfg].WM;
 }
 extern "C" int jen1_cfg_bn(int cfg) {
-  switch (cfg) {
-    case JEN1_CFG_128x128: return 128;
-    case JEN1_CFG_128x64: case JEN1_CFG_64x64: return 64;
-    case JEN1_CFG_64x32: return 32;
-    case JEN1_CFG_64x16: return 16;
-  }
-  return -1;
+  if (cfg < 0 || cfg >= JEN1_NUM_CFG) return -1;
+  return 16 * kCfg[cfg].NF;
 }
 
 static int validate(const jen1_conv_args& a) {
@@ -568,7 +812,7 @@ static int validate(const jen1_conv_args& a) {
     JEN1_CHECK((a.splitk - 1) * cps < kch, "conv_gemm: splitk %d leaves an empty K slice (chunks %d)", a.splitk, kch);
     const int st = a.kc_stage < cps ? a.kc_stage : cps;
     // a stage must not straddle the x0/x1 boundary
-    JEN1_CHECK(a.c1 == 0 || ((a.c0 / 32) % st == 0 && (a.splitk == 1 || (a.c0 / 32) % cps == 0)), "conv_gemm: stage/split straddles the source boundary");
+    JEN1_CHECK(a.direct || a.c1 == 0 || ((a.c0 / 32) % st == 0 && (a.splitk == 1 || (a.c0 / 32) % cps == 0)), "conv_gemm: stage/split straddles the source boundary");
   }
   JEN1_CHECK(a.splitk == 1 || (a.slab && a.counters), "conv_gemm: split-K needs slab and counters");
   if (a.pro_mode == JEN1_PRO_GN || a.pro_mode == JEN1_PRO_GN_SILU) {
@@ -579,15 +823,15 @@ static int validate(const jen1_conv_args& a) {
   }
   if (a.pro_mode == JEN1_PRO_LN) JEN1_CHECK(a.ln_rowstats && a.ln_C >= 1 && a.c1 == 0 && (!a.ln_gamma || a.ln_beta), "conv_gemm: incomplete LayerNorm prologue");
   JEN1_CHECK(!a.out_gn_stats || (a.out_cpf >= 2 && a.out_cpf % 2 == 0), "conv_gemm: out_cpf must be even");
-  const jen1_conv_args& aa = a;
-  const Layout L = make_layout(aa, a.dtype == JEN1_F32 ? 4 : 2);
+  JEN1_CHECK(!a.direct || a.pro_mode == JEN1_PRO_NONE, "conv_gemm: direct (no-LDS) mode takes no prologue; run jen1_norm_apply first");
+  const Layout L = make_layout(a, a.dtype == JEN1_F32 ? 4 : 2, cfg_red_floats(a.cfg));
   JEN1_CHECK(L.total <= 160 * 1024, "conv_gemm: LDS request %d B exceeds 160 KiB (tb=%d nb=%d kc_stage=%d)", L.total, a.tb, a.nb, a.kc_stage);
   return 0;
 }
 
 extern "C" int64_t jen1_conv_gemm_lds_bytes(const jen1_conv_args* args) {
-  if (!args) return -1;
-  return make_layout(*args, args->dtype == JEN1_F32 ? 4 : 2).total;
+  if (!args || args->cfg < 0 || args->cfg >= JEN1_NUM_CFG) return -1;
+  return make_layout(*args, args->dtype == JEN1_F32 ? 4 : 2, cfg_red_floats(args->cfg)).total;
 }
 
 extern "C" int jen1_conv_gemm(const jen1_conv_args* args, void* stream) {

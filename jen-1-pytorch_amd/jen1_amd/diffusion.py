@@ -12,6 +12,7 @@ buffer refreshed.
 from __future__ import annotations
 
 import math
+import os
 from functools import partial
 from typing import List, Optional, Sequence, Tuple
 
@@ -155,88 +156,35 @@ class GaussianDiffusion(torch.nn.Module):
                     dropout_rows: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True):
         """gdm.py:181-225.  The keyword-only extras inject the RNG draws (parity tests);
         by default they come from torch's device generator like the reference's."""
-        if not isinstance(model, UNetCFG1d):
-            return self._ddim_generic(model, shape, conditioning, return_all_timesteps, causal, init_data,
-                                      init_noise, step_noises, dropout_rows)
-        B, C, T = shape
-        eng = model.engine()
-        lib = eng.lib
         cfg = self.embedding_scale != 1.0
-        if cfg and not self.batch_cfg:
+        if not isinstance(model, UNetCFG1d) or (cfg and not self.batch_cfg):
             return self._ddim_generic(model, shape, conditioning, return_all_timesteps, causal, init_data,
                                       init_noise, step_noises, dropout_rows)
-        nrep = 2 if cfg else 1
-        plan = eng.plan(B, T, nrep, bool(causal))
-        coef, times = self.ddim_coeff_table()
+        B = shape[0]
+        st = self.stepper(model, shape, conditioning, causal=causal, use_graph=use_graph)
         audio = torch.randn(shape, device=self.device) if init_noise is None else init_noise.to(self.device, torch.float32).reshape(shape)
         if init_data is not None:
             audio = audio + init_data
+        st.reset(audio)
         audios = [audio.clone()]
-        zt = torch.zeros((B,), dtype=torch.int64, device=self.device)
-        model._prepare(plan, audio, zt, conditioning["cross_attn_cond"], conditioning["cross_attn_masks"],
-                       [conditioning["input_concat_cond"]], None)
-        coef_cur = torch.zeros((8,), dtype=torch.float32, device=self.device)
-        noise_buf = torch.zeros(shape, dtype=torch.float32, device=self.device)
-        Co = model.spec.out_channels
-        net = plan.net_out
-
-        def step(s):
-            plan.run(s)
-            L.check(lib.jen1_cfg_ddim_step(net.t.data_ptr(), plan.x_in.data_ptr(), noise_buf.data_ptr(), coef_cur.data_ptr(),
-                                           plan.x_in.data_ptr(), None, None, B, Co, T, net.ld, nrep,
-                                           float(self.embedding_scale), 1 if (cfg and self.scale_cfg) else 0, 0.7,
-                                           _OBJ[self.objective], 1, eng.dt, s), "jen1_cfg_ddim_step")
-
-        graph = None
-        if use_graph:
-            graph = self._capture(("ddim", id(plan), self.objective, self.embedding_scale, self.scale_cfg), step,
-                                  keep=(coef_cur, noise_buf))
-            if graph is not None:
-                coef_cur, noise_buf = graph[1]
-                graph = graph[0]
-            plan.x_in.copy_(audio)          # the capture warm-up advanced x_in once: restore it
-        S = times.numel()
-        for i in range(S):
-            plan.t_in.copy_(times[i].expand(B))
-            coef_cur.copy_(coef[i])
+        for i in range(st.num_steps):
+            drop = None
             if self.cfg_dropout_proba > 0.0:
                 if dropout_rows is not None:
-                    plan.set_rows(torch.as_tensor(dropout_rows[i]))
+                    drop = torch.as_tensor(dropout_rows[i])
                 elif self.cfg_dropout_proba >= 1.0:
-                    plan.set_rows(torch.ones(B, dtype=torch.bool))
-                else:
-                    plan.set_rows(torch.bernoulli(torch.full((B,), float(self.cfg_dropout_proba), device=self.device)).to(torch.bool))
-            if i < S - 1:
-                if step_noises is not None:
-                    noise_buf.copy_(step_noises[i].to(self.device, torch.float32))
-                else:
-                    noise_buf.normal_()
+                    drop = torch.ones(B, dtype=torch.bool)
+                else:   # rand_bool at sampling time too (gdm.py:121 -> model.py:323-328)
+                    drop = torch.bernoulli(torch.full((B,), float(self.cfg_dropout_proba), device=self.device)).to(torch.bool)
             if return_all_timesteps:
-                audios.append(plan.x_in.clone())
-            if graph is not None:
-                graph.replay()
-            else:
-                step(torch.cuda.current_stream(self.device).cuda_stream)
-        out = plan.x_in.clone()
+                audios.append(st.x.clone())
+            st.step(i, noise=None if step_noises is None or i >= len(step_noises) else step_noises[i], drop_rows=drop,
+                    set_rows=self.cfg_dropout_proba > 0.0)
+        out = st.x.clone()
         return out if not return_all_timesteps else torch.stack(audios, dim=1)
 
-    def _capture(self, key, step_fn, keep):
-        """Capture ``step_fn`` once per plan as a hipGraph; later calls reuse it together with
-        the static side buffers it was captured with."""
-        if key in self._graphs:
-            return self._graphs[key]
-        dev = self.device
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):       # warm-up outside capture (lazy module / attribute init)
-            step_fn(side.cuda_stream)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step_fn(torch.cuda.current_stream(dev).cuda_stream)
-        self._graphs[key] = (g, keep)
-        return self._graphs[key]
+    def stepper(self, model, shape, conditioning, causal=False, use_graph=True, n_streams=None) -> "DDIMStepper":
+        return DDIMStepper(self, model, shape, conditioning, causal, use_graph, n_streams)
 
     def _ddim_generic(self, model, shape, conditioning, return_all_timesteps, causal, init_data, init_noise, step_noises,
                       dropout_rows):
@@ -321,3 +269,142 @@ class GaussianDiffusion(torch.nn.Module):
             raise ValueError(f"unknown objective {self.objective}")
         loss = self.loss_fn(model_out, target, reduction="none")
         return loss.reshape(loss.shape[0], -1).mean(dim=1).mean()
+
+
+class DDIMStepper:
+    """One fused denoiser step = denoiser plan + ``jen1_cfg_ddim_step`` (CFG combine, std rescale,
+    x0/eps prediction, DDIM update), captured once as a hipGraph and replayed per step.  Per step only
+    three small device-side updates happen outside the graph: the timestep vector, the coefficient
+    row and the noise buffer (gdm.py:203, :212-218).
+
+    Concurrency: every kernel of the denoiser is latency-bound and occupies a fraction of the 256
+    CUs, and the samples of a batch are independent, so the batch is split into ``n_streams``
+    sub-batches whose plans run on parallel HIP streams inside the one captured graph (fork/join).
+    Weights are streamed once per sub-batch; HBM has the headroom."""
+
+    def __init__(self, gd: GaussianDiffusion, model: UNetCFG1d, shape, conditioning, causal=False, use_graph=True,
+                 n_streams: Optional[int] = None):
+        self.gd, self.model = gd, model
+        B, C, T = shape
+        self.shape = (B, C, T)
+        dev = gd.device
+        eng = model.engine()
+        self.eng, self.lib = eng, eng.lib
+        cfg = gd.embedding_scale != 1.0
+        assert not (cfg and not gd.batch_cfg), "the fused stepper needs batch_cfg=True when embedding_scale != 1"
+        self.nrep = 2 if cfg else 1
+        if n_streams is None:
+            n_streams = int(os.environ.get("JEN1_STREAMS", "1"))
+        n_streams = max(1, min(n_streams, B))
+        sizes = [B // n_streams + (1 if i < B % n_streams else 0) for i in range(n_streams)]
+        self.coef, self.times = gd.ddim_coeff_table()
+        self.num_steps = int(self.times.numel())
+        self.coef_cur = torch.zeros((8,), dtype=torch.float32, device=dev)
+        self.noise_buf = torch.zeros(shape, dtype=torch.float32, device=dev)
+        self._cond = conditioning                     # keep the conditioning tensors alive
+        Co = model.spec.out_channels
+        lib = self.lib
+        self.parts = []
+        b0 = 0
+        used = {}
+        for i, nb in enumerate(sizes):
+            slot = used.get(nb, 0)
+            used[nb] = slot + 1
+            plan = eng.plan(nb, T, self.nrep, bool(causal), slot=slot)
+            sl = slice(b0, b0 + nb)
+            emb = conditioning["cross_attn_cond"][sl]
+            msk = None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"][sl]
+            cc = conditioning["input_concat_cond"]
+            zt = torch.zeros((nb,), dtype=torch.int64, device=dev)
+            model._prepare(plan, plan.x_in, zt, emb, msk, [None if cc is None else cc[sl]], None)
+            plan._cond_refs = (emb, msk)              # the K/V cache key holds weakrefs: keep the slices alive
+            net = plan.net_out
+            noise_ptr = self.noise_buf[sl].data_ptr()
+            args = (net.t.data_ptr(), plan.x_in.data_ptr(), noise_ptr, self.coef_cur.data_ptr(),
+                    plan.x_in.data_ptr(), None, None, nb, Co, T, net.ld, self.nrep, float(gd.embedding_scale),
+                    1 if (cfg and gd.scale_cfg) else 0, 0.7, _OBJ[gd.objective], 1, eng.dt)
+
+            def run(s, plan=plan, args=args):
+                plan.run(s)
+                L.check(lib.jen1_cfg_ddim_step(*args, s), "jen1_cfg_ddim_step")
+
+            self.parts.append((sl, plan, run))
+            b0 += nb
+        self.plan = self.parts[0][1]                  # (first sub-plan; used by the bench's per-launch roofline)
+        self.streams = [torch.cuda.Stream(dev) for _ in self.parts] if len(self.parts) > 1 else []
+        self.graph = None
+        self.graphs = None
+        if use_graph:
+            saved = self.x.clone()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):             # warm-up outside capture (lazy attribute init)
+                self._run_all()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            if self.streams and os.environ.get("JEN1_GRAPH_PER_STREAM", "1") == "1":
+                # one graph per sub-batch, each replayed on its own stream: ROCm's hipGraph runs the
+                # branches of a single graph one after the other, separate graphs on separate streams
+                # can overlap on the hardware queues
+                self.graphs = []
+                for _, _, run in self.parts:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        run(torch.cuda.current_stream(dev).cuda_stream)
+                    self.graphs.append(g)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._run_all()
+                self.graph = g
+            self.reset(saved)                         # the warm-up advanced x once: restore
+
+    def _run_all(self):
+        """enqueue every sub-batch; with several parts they fork onto side streams and join back."""
+        dev = self.gd.device
+        cur = torch.cuda.current_stream(dev)
+        if not self.streams:
+            self.parts[0][2](cur.cuda_stream)
+            return
+        for st, (_, _, run) in zip(self.streams, self.parts):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                run(st.cuda_stream)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    @property
+    def x(self) -> torch.Tensor:
+        """current latents [B, C, T] (the sub-batches live in their plans' input buffers)."""
+        if len(self.parts) == 1:
+            return self.parts[0][1].x_in
+        return torch.cat([p.x_in for _, p, _ in self.parts], dim=0)
+
+    def reset(self, x0: torch.Tensor):
+        x0 = x0.to(torch.float32)
+        for sl, plan, _ in self.parts:
+            plan.x_in.copy_(x0[sl])
+
+    def step(self, i: int, noise: Optional[torch.Tensor] = None, drop_rows=None, set_rows=False):
+        for sl, plan, _ in self.parts:
+            plan.t_in.copy_(self.times[i].expand(plan.B))
+            if set_rows:
+                plan.set_rows(None if drop_rows is None else torch.as_tensor(drop_rows)[sl])
+        self.coef_cur.copy_(self.coef[i])
+        if i < self.num_steps - 1:
+            if noise is not None:
+                self.noise_buf.copy_(noise.to(self.noise_buf.device, torch.float32))
+            else:
+                self.noise_buf.normal_()
+        if self.graphs is not None:
+            cur = torch.cuda.current_stream(self.gd.device)
+            for st, g in zip(self.streams, self.graphs):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    g.replay()
+            for st in self.streams:
+                cur.wait_stream(st)
+        elif self.graph is not None:
+            self.graph.replay()
+        else:
+            self._run_all()

@@ -164,6 +164,8 @@ class KernelCtx:
         self.dt = L.F32 if dtype == "f32" else L.BF16
         self.tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
         self.target_wgs = target_wgs
+        self.splitk_target_wgs = 512
+        self.splitk_min_bytes = 1 << 20
 
 
 class OpBuilder:
@@ -260,66 +262,117 @@ class OpBuilder:
         if out.rs is not None:
             a.out_rowstats = out.rs.data_ptr()
         self._choose_tiles(a, force)
+        lib = eng.lib
+        streaming = a.cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
+        want_direct = streaming and (force is None or force.get("direct", True))
+        if want_direct and pro in (L.PRO_GN, L.PRO_GN_SILU, L.PRO_LN):
+            # deep level: up to M/16 workgroups would each redo the prologue of the same tiny tile --
+            # normalise / activate it ONCE (jen1_norm_apply), then stream the GEMM with no LDS staging
+            na = L.NormArgs()
+            ctot = a.c0 + a.c1
+            xh = self._empty((a.B, a.L_in, ctot))
+            na.x0, na.x1, na.y = a.x0, a.x1, xh.data_ptr()
+            na.dtype, na.mode, na.B, na.L = eng.dt, pro, a.B, a.L_in
+            na.c0, na.c1, na.ld0, na.ld1, na.ld_y = a.c0, a.c1, a.ld0, a.ld1, ctot
+            na.src1_scale = a.src1_scale
+            if pro == L.PRO_LN:
+                na.ln_rowstats, na.count, na.eps = a.ln_rowstats, a.ln_C, a.ln_eps
+                na.gamma, na.beta = a.ln_gamma, a.ln_beta
+            else:
+                na.gn_stats0, na.gn_stats1 = a.gn_stats0, a.gn_stats1
+                na.gamma, na.beta = a.gn_gamma, a.gn_beta
+                na.groups, na.cpg, na.count, na.eps = a.gn_groups, a.gn_cpg, a.gn_count, a.gn_eps
+                na.film, na.film_row = a.film, a.film_row
+                na.film_off, na.film_C, na.film_ld = a.film_off, a.film_C, a.film_ld
+            nref = C.byref(na)
+            nfn = lambda s, nref=nref, lib=lib: L.check(lib.jen1_norm_apply(nref, s), "jen1_norm_apply")
+            nfn.label = f"norm_apply[{label}] mode={pro} B={a.B} L={a.L_in} C={ctot}"
+            nfn.kind = "norm_apply"
+            ops.append(nfn)
+            self._keep.append((na, xh))
+            a.x0, a.c0, a.ld0 = xh.data_ptr(), ctot, ctot
+            a.x1, a.c1, a.ld1 = None, 0, 0
+            a.src1_scale = 1.0
+            a.pro_mode = L.PRO_NONE
+            a.direct = 1
+        elif want_direct and pro == L.PRO_NONE:
+            a.direct = 1
+        if a.direct:
+            a.kc_stage = max(1, (a.c0 + a.c1) // 32)
         if a.splitk > 1:
             self._splitk_args.append(a)
         # the prepared launch holds raw pointers: keep every tensor it references alive
         self._keep.append((a, src0, src1, w, bias, out, residual, row_scale, gn, film, ln))
-        lib = eng.lib
         ref = C.byref(a)
         fn = lambda s, ref=ref, lib=lib: L.check(lib.jen1_conv_gemm(ref, s), "jen1_conv_gemm")
+        # algorithmic traffic / work of this launch (weights once + conv input + output)
+        es = 4 if eng.dt == L.F32 else 2
+        c_real = src0.C + (src1.C if src1 is not None else 0)
+        fn.kind = "conv_gemm"
+        fn.w_bytes = taps * a.M * c_real * es
+        fn.act_bytes = a.B * a.L_in * c_real * es + a.B * a.L_y * out_C * (4 if y_f32 else es)
+        fn.flops = 2 * taps * a.M * c_real * a.B * a.L_out
         fn.label = (f"conv[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} s={a.stride} M={a.M} "
-                    f"ps={a.ps_f}/{a.ps_off} Ly={a.L_y} pro={a.pro_mode} cfg={a.cfg} tb={a.tb} nb={a.nb} kst={a.kc_stage} sk={a.splitk}")
+                    f"ps={a.ps_f}/{a.ps_off} Ly={a.L_y} pro={a.pro_mode} cfg={a.cfg} tb={a.tb} nb={a.nb} kst={a.kc_stage} sk={a.splitk} "
+                    f"direct={a.direct}")
         ops.append(fn)
         return out
 
     def _choose_tiles(self, a: L.ConvArgs, force=None):
-        """Tile / split-K heuristics.  Deep levels (few positions, big weights) are
-        weight-streaming bound: small N tile, K split so that >= ~1 workgroup per CU streams."""
+        """Tile heuristics.  Wide (W*) tiles when there are enough positions to fill the chip with
+        64-row M tiles; otherwise 16-row streaming (S*) tiles whose 4 waves split K: a deep level
+        is pure weight streaming and needs many small workgroups, not a big tile."""
         eng = self.eng
+        lib = eng.lib
         rows = a.B * a.L_out
         M = a.M
         kch = (a.c0 + a.c1) // 32
+
+        def tiles(cfg):
+            BM, BN = lib.jen1_cfg_bm(cfg), lib.jen1_cfg_bn(cfg)
+            tb = min(a.L_out, BN)
+            nb = max(1, min(a.B, BN // tb))
+            return BM, BN, tb, nb, -(-a.L_out // tb) * -(-a.B // nb) * -(-M // BM)
+
         if force is not None and "cfg" in force:
             cfg = force["cfg"]
-        elif rows >= 1024:
-            cfg = L.CFG_128x128 if M >= 128 else L.CFG_64x64
-        elif rows > 32:
-            cfg = L.CFG_128x64 if M >= 256 else L.CFG_64x64
-        elif rows > 16:
-            cfg = L.CFG_64x32
         else:
-            cfg = L.CFG_64x16
-        BM, BN = eng.lib.jen1_cfg_bm(cfg), eng.lib.jen1_cfg_bn(cfg)
-        tb = min(a.L_out, BN)
-        nb = max(1, min(a.B, BN // tb))
+            wide = L.CFG_W128x64 if M >= 512 else L.CFG_W64x64
+            if tiles(wide)[4] >= eng.target_wgs * 3 // 4:
+                cfg = wide
+            elif rows <= 16:
+                cfg = L.CFG_S16x16
+            elif rows <= 32:
+                cfg = L.CFG_S16x32
+            else:
+                cfg = L.CFG_S16x64
+        BM, BN, tb, nb, wgs = tiles(cfg)
         a.cfg, a.tb, a.nb = cfg, tb, nb
-        n_tiles = -(-a.L_out // tb) * -(-a.B // nb)
-        m_tiles = -(-M // BM)
-        wgs = n_tiles * m_tiles
         splitk = 1
         if force is not None and "splitk" in force:
             splitk = force["splitk"]
-        elif wgs < eng.target_wgs and kch >= 4:
-            want = min(-(-eng.target_wgs // wgs), kch // 2, 32)
-            # legal split counts: every slice non-empty, slices aligned to the x0/x1 boundary
-            best = 1
-            for sk in range(2, want + 1):
-                cps = -(-kch // sk)
-                if (sk - 1) * cps >= kch:
-                    continue
-                if a.c1 and (a.c0 // 32) % cps != 0:
-                    continue
-                best = sk
-            splitk = best
+        elif cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16) and a.pro_mode != L.PRO_SILU:
+            # weight streaming needs ~2000 waves with a full prefetch ring in flight to approach HBM
+            # bandwidth: split K across workgroups when the M tiles alone give too few of them
+            wbytes = a.taps * M * (a.c0 + a.c1) * (4 if eng.dt == L.F32 else 2)
+            if wbytes >= eng.splitk_min_bytes and wgs < eng.splitk_target_wgs:
+                want = -(-eng.splitk_target_wgs // wgs)
+                # every wave keeps >= 2 (tap, chunk) steps; 4 waves share one K slice
+                max_sk = max(1, (a.taps * kch) // 8)
+                splitk = max(1, min(want, max_sk, kch))
+                while splitk > 1 and (splitk - 1) * -(-kch // splitk) >= kch:
+                    splitk -= 1
         a.splitk = splitk
         cps = -(-kch // splitk)
-        # LDS stage: as many 32-channel chunks as fit comfortably (<= 64 KiB keeps 2 WGs / CU)
+        # LDS stage: the whole K range of the workgroup in one stage whenever it fits (a second stage
+        # costs a barrier and a global round trip); wide tiles stay <= 64 KiB to keep 2 WGs per CU
+        limit = 64 * 1024 if cfg in (L.CFG_W64x64, L.CFG_W128x64) else 150 * 1024
         stage = cps
         while True:
             a.kc_stage = stage
             ok_boundary = (not a.c1) or ((a.c0 // 32) % min(stage, cps) == 0)
-            nbytes = eng.lib.jen1_conv_gemm_lds_bytes(C.byref(a))
-            if ok_boundary and (nbytes <= 64 * 1024 or stage == 1):
+            nbytes = lib.jen1_conv_gemm_lds_bytes(C.byref(a))
+            if ok_boundary and (nbytes <= limit or stage == 1):
                 break
             stage -= 1
         assert nbytes <= 160 * 1024, f"LDS {nbytes} B too large (tb={tb}, nb={nb}, taps={a.taps}, stride={a.stride})"
@@ -631,7 +684,9 @@ class Engine:
         self.tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
         self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
         self.target_wgs = 256
-        self.plans: Dict[Tuple[int, int, int, bool], Plan] = {}
+        self.splitk_target_wgs = int(os.environ.get("JEN1_SPLITK_WGS", "256"))
+        self.splitk_min_bytes = int(os.environ.get("JEN1_SPLITK_MIN_BYTES", str(2 << 20)))
+        self.plans: Dict[Tuple[int, int, int, bool, int], Plan] = {}
         self.load_params(params)
 
     def load_params(self, params: Dict[str, torch.Tensor]):
@@ -668,8 +723,10 @@ class Engine:
         tmp.run(s)
         torch.cuda.synchronize(dev)
 
-    def plan(self, B: int, T: int, nrep: int, causal: bool) -> Plan:
-        key = (B, T, nrep, bool(causal))
+    def plan(self, B: int, T: int, nrep: int, causal: bool, slot: int = 0) -> Plan:
+        """``slot`` distinguishes plans of the same shape that must own separate buffers because
+        they run concurrently on different streams (sub-batches of one sampler step)."""
+        key = (B, T, nrep, bool(causal), slot)
         if key not in self.plans:
             self.plans[key] = Plan(self, B, T, nrep, bool(causal))
         return self.plans[key]

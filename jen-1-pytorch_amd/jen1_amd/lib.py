@@ -13,7 +13,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-LIB_PATH = os.path.join(HERE, "libjen1_hip.so")
+LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "attention.hip", "elementwise.hip"]
@@ -21,7 +21,7 @@ SOURCES = ["conv_gemm.hip", "attention.hip", "elementwise.hip"]
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU = 0, 1
-CFG_128x128, CFG_128x64, CFG_64x64, CFG_64x32, CFG_64x16 = 0, 1, 2, 3, 4
+CFG_W64x64, CFG_W128x64, CFG_S16x64, CFG_S16x32, CFG_S16x16 = 0, 1, 2, 3, 4
 
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
 
@@ -45,7 +45,18 @@ class ConvArgs(C.Structure):
         ("film_off", c_int), ("film_C", c_int), ("film_ld", c_int),
         ("ln_C", c_int), ("ln_eps", c_float),
         ("act", c_int), ("out_cpf", c_int), ("tb", c_int), ("nb", c_int),
-        ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int),
+        ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int), ("direct", c_int),
+    ]
+
+
+class NormArgs(C.Structure):
+    """mirror of ``jen1_norm_args`` (include/jen1_hip.h)."""
+    _fields_ = [
+        ("x0", c_void_p), ("x1", c_void_p), ("y", c_void_p), ("gn_stats0", c_void_p), ("gn_stats1", c_void_p),
+        ("gamma", c_void_p), ("beta", c_void_p), ("film", c_void_p), ("film_row", c_void_p), ("ln_rowstats", c_void_p),
+        ("dtype", c_int), ("mode", c_int), ("B", c_int), ("L", c_int), ("c0", c_int), ("c1", c_int),
+        ("ld0", c_int), ("ld1", c_int), ("ld_y", c_int), ("groups", c_int), ("cpg", c_int), ("count", c_int),
+        ("eps", c_float), ("src1_scale", c_float), ("film_off", c_int), ("film_C", c_int), ("film_ld", c_int),
     ]
 
 
@@ -54,6 +65,7 @@ _P = c_void_p
 SYMBOLS = {
     "jen1_conv_gemm": (c_int, [C.POINTER(ConvArgs), _P]),
     "jen1_conv_gemm_lds_bytes": (c_int64, [C.POINTER(ConvArgs)]),
+    "jen1_norm_apply": (c_int, [C.POINTER(NormArgs), _P]),
     "jen1_cfg_bm": (c_int, [c_int]),
     "jen1_cfg_bn": (c_int, [c_int]),
     "jen1_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 + [c_float, c_int, _P]),

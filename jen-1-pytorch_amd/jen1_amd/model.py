@@ -88,13 +88,13 @@ class UNetCFG1d(nn.Module):
             assert ch.shape[1] == self.spec.ctx_ch0, f"Expected context with {self.spec.ctx_ch0} channels at idx 0"
             plan.ctx_in.copy_(ch.to(torch.float32))
         # the text K/V cache is keyed on the identity (weakref) + in-place version of the tensors
-        k = self._ctx_key
-        hit = (k is not None and k[0] is plan and k[1]() is embedding and k[2] == embedding._version and
+        k = getattr(plan, "_ctx_key", None)
+        hit = (k is not None and k[1]() is embedding and k[2] == embedding._version and
                ((embedding_mask is None and k[3] is None) or
                 (embedding_mask is not None and k[3] is not None and k[3]() is embedding_mask and k[4] == embedding_mask._version)))
         if not hit:
             plan.set_context(embedding, embedding_mask, self._stream())
-            self._ctx_key = (plan, weakref.ref(embedding), embedding._version,
+            plan._ctx_key = (plan, weakref.ref(embedding), embedding._version,
                              None if embedding_mask is None else weakref.ref(embedding_mask),
                              None if embedding_mask is None else embedding_mask._version)
         plan.set_rows(drop_rows, uncond_only)

@@ -95,10 +95,11 @@ def test_conv1d_matches_golden_and_torch(ctx, k, s, causal):
     assert rel_err(y, golden("units")[f"conv.k{k}s{s}.c{int(causal)}"]) < TOL[mode]
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 12, 13, 14])
 @pytest.mark.parametrize("splitk", [1, 3])
 def test_conv_all_tile_configs_and_splitk(ctx, cfg, splitk):
-    """every tile configuration and the split-K reduction give the same convolution."""
+    """every tile configuration (10+k = streaming cfg k with LDS staging instead of the direct
+    register-ring path) and the split-K reduction give the same convolution."""
     from jen1_amd.engine import OpBuilder
     kc, mode = ctx
     torch.manual_seed(cfg * 7 + splitk)
@@ -110,7 +111,7 @@ def test_conv_all_tile_configs_and_splitk(ctx, cfg, splitk):
     ob = OpBuilder(kc)
     out = new_out(kc, B, Ln, Co)
     ob.conv(ob.ops, src0=to_cl(x, kc), w=pack_conv(w, kc), bias=b, out=out, taps=k, pad_left=1,
-            force={"cfg": cfg, "splitk": splitk})
+            force={"cfg": cfg % 10, "splitk": splitk, "direct": cfg < 10})
     run(ob)
     if splitk > 1:
         assert int(ob.counters.abs().sum().item()) == 0, "split-K counters must be left at zero"
@@ -195,17 +196,19 @@ def test_groupnorm_film_silu_prologue(ctx, two_src, film):
         fh = ftab[frow.long()][:, 7 + Ct: 7 + 2 * Ct, None]
         h = h * (fs + 1) + fh
     ref = F.conv1d(F.pad(F.silu(h), (2, 0)), w, bias) + resid          # causal padding
-    ob = OpBuilder(kc)
-    out = new_out(kc, B, Ln, Co, gn=True, rs=True)
-    ob.conv(ob.ops, src0=to_cl(x0, kc), src1=to_cl(x1, kc) if two_src else None, src1_scale=sc if two_src else 1.0,
-            w=pack_conv(w, kc), bias=bias, out=out, taps=3, pad_left=2, pro=L.PRO_GN_SILU,
-            gn=(G, Ct, gam, bet, 1e-5), film=(ftab, frow, 7, Ct) if film else None, residual=to_cl(resid, kc))
-    run(ob)
-    y = from_cl(out)
-    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TOL[mode]
-    exp = to_cl(y, kc)
-    assert rel_err(out.gn.cpu().numpy(), exp.gn.cpu().numpy()) < 2e-3
-    assert rel_err(out.rs.cpu().numpy(), exp.rs.cpu().numpy()) < 2e-3
+    for force in (None, {"cfg": 0}, {"cfg": 2, "direct": False}, {"cfg": 3}):
+        ob = OpBuilder(kc)
+        out = new_out(kc, B, Ln, Co, gn=True, rs=True)
+        ob.conv(ob.ops, src0=to_cl(x0, kc), src1=to_cl(x1, kc) if two_src else None, src1_scale=sc if two_src else 1.0,
+                w=pack_conv(w, kc), bias=bias, out=out, taps=3, pad_left=2, pro=L.PRO_GN_SILU,
+                gn=(G, Ct, gam, bet, 1e-5), film=(ftab, frow, 7, Ct) if film else None, residual=to_cl(resid, kc),
+                force=force)
+        run(ob)
+        y = from_cl(out)
+        assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TOL[mode], force
+        exp = to_cl(y, kc)
+        assert rel_err(out.gn.cpu().numpy(), exp.gn.cpu().numpy()) < 2e-3, force
+        assert rel_err(out.rs.cpu().numpy(), exp.rs.cpu().numpy()) < 2e-3, force
 
 
 def test_layernorm_prologue_gelu_rowscale(ctx):
@@ -222,7 +225,7 @@ def test_layernorm_prologue_gelu_rowscale(ctx):
     mask = (torch.rand(B * Ln, device="cuda") > 0.3).float()
     ref = F.gelu(F.linear(F.layer_norm(x, (Ci,), gam, bet), w, bias)) * mask.view(B, Ln, 1)
     from jen1_amd.packing import pack_gemm_weight
-    for folded in (False, True):
+    for folded, force in ((False, None), (True, None), (False, {"cfg": 0}), (True, {"cfg": 2, "direct": False})):
         ob = OpBuilder(kc)
         out = new_out(kc, B, Ln, Co)
         src = to_cl(x.permute(0, 2, 1).contiguous(), kc)
@@ -230,12 +233,12 @@ def test_layernorm_prologue_gelu_rowscale(ctx):
             from jen1_amd.packing import fold_layernorm
             wf, bf = fold_layernorm(w, gam, bet)
             ob.conv(ob.ops, src0=src, w=pack_gemm_weight(wf[None], kc.tdtype), bias=(bf + bias).contiguous(), out=out,
-                    pro=L.PRO_LN, ln=(Ci, None, None), act=L.ACT_GELU, row_scale=mask)
+                    pro=L.PRO_LN, ln=(Ci, None, None), act=L.ACT_GELU, row_scale=mask, force=force)
         else:
             ob.conv(ob.ops, src0=src, w=pack_gemm_weight(w[None], kc.tdtype), bias=bias, out=out, pro=L.PRO_LN,
-                    ln=(Ci, gam, bet), act=L.ACT_GELU, row_scale=mask)
+                    ln=(Ci, gam, bet), act=L.ACT_GELU, row_scale=mask, force=force)
         run(ob)
-        assert rel_err(out.t[:, :, :Co].float().cpu().numpy(), ref.cpu().numpy()) < TOL[mode], folded
+        assert rel_err(out.t[:, :, :Co].float().cpu().numpy(), ref.cpu().numpy()) < TOL[mode], (folded, force)
 
 
 def test_silu_prologue_f32_output(ctx):
