@@ -112,7 +112,14 @@ typedef struct jen1_conv_args {
   int32_t splitk;
   int32_t cfg;               /* JEN1_CFG_* */
   int32_t direct;            /* 1: no LDS staging, activation fragments straight from global memory
-                                (streaming cfgs only, pro_mode must be JEN1_PRO_NONE) */
+                                (streaming cfgs only, pro_mode must be JEN1_PRO_NONE, src1_scale == 1) */
+  const void* zeros;         /* direct mode: >= (c0+c1) zero elements; padding rows read from here */
+  int32_t tiles_t;           /* derived by jen1_conv_gemm (callers leave 0) */
+  float inv_tiles_t, inv_tb; /* derived by jen1_conv_gemm */
+  const float* ln_u;         /* ln_fold: [M] row sums of the (gamma-folded, dtype-rounded) weights */
+  int32_t ln_fold;           /* 1: LayerNorm applied in the epilogue instead of a prologue:
+                                y = rstd_n * (acc - mean_n * ln_u[m]) + bias   (taps = 1 only; the row
+                                statistics of the INPUT rows come from ln_rowstats / ln_C / ln_eps) */
 } jen1_conv_args;
 
 int jen1_conv_gemm(const jen1_conv_args* args, void* stream);

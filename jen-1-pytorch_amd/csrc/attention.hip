@@ -15,7 +15,12 @@
 namespace {
 
 constexpr int QCHUNK = 32;
+constexpr int MAXV = 9;    // 8-element vectors per thread for one K or V tile: ceil(141*128/8/256) = 9
 
+// Memory-level parallelism matters more than arithmetic here: with <= 128 workgroups there is one wave
+// per SIMD, and a loop that loads and immediately consumes costs one full memory latency per trip.  So
+// every Q, K and V vector of the tile is requested up front (V waits in registers while the scores are
+// computed on K), and only then does the kernel touch LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ v, T* __restrict__ out,
@@ -39,64 +44,128 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
   const size_t kvbase = (size_t)(kv_row ? kv_row[b] : b) * Nk;
   // optional per-step last key row (the time token of the text context, model.py:315-316)
   const int xr = (kv_extra && extra_row) ? extra_row[b] : -1;
-  // stage Q chunk and K (as float)
-  for (int i = tid; i < nq * d; i += 256) {
-    const int r = i / d, c = i - r * d;
-    q_s[r * dp + c] = (float)q[((size_t)b * Nq + q0 + r) * ldq + q_off + h * d + c];
+  const int vpr = d >> 3;                        // 8-element vectors per row
+  const int nkv = Nk * vpr, nqv = nq * vpr;
+
+  // ---- issue all loads -----------------------------------------------------------------------
+  float kreg[MAXV][8], qreg[2][8];
+  typename VecOf<T>::type vraw[MAXV];
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int i = tid + u * 256;
+    const int ii = i < nkv ? i : 0;
+    const int r = ii / vpr, c = (ii - r * vpr) * 8;
+    const bool ex = (xr >= 0 && r == Nk - 1);
+    const T* kp = ex ? kv_extra + (size_t)xr * ld_extra + kx_off + h * d + c : k + (kvbase + r) * ldkv + k_off + h * d + c;
+    const T* vp = ex ? kv_extra + (size_t)xr * ld_extra + vx_off + h * d + c : v + (kvbase + r) * ldkv + v_off + h * d + c;
+    load8(kp, kreg[u]);
+    vraw[u] = *reinterpret_cast<const typename VecOf<T>::type*>(vp);
   }
-  for (int i = tid; i < Nk * d; i += 256) {
-    const int r = i / d, c = i - r * d;
-    kv_s[r * dp + c] = (xr >= 0 && r == Nk - 1) ? (float)kv_extra[(size_t)xr * ld_extra + kx_off + h * d + c]
-                                                : (float)k[(kvbase + r) * ldkv + k_off + h * d + c];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {                  // QCHUNK * 128 / 8 / 256 = 2 vectors per thread at most
+    const int i = tid + u * 256;
+    const int ii = i < nqv ? i : 0;
+    const int r = ii / vpr, c = (ii - r * vpr) * 8;
+    load8(q + ((size_t)b * Nq + q0 + r) * ldq + q_off + h * d + c, qreg[u]);
+  }
+  // ---- K, Q -> LDS ------------------------------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int i = tid + u * 256;
+    if (i < nkv) {
+      const int r = i / vpr, c = (i - r * vpr) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kv_s[r * dp + c + e] = kreg[u][e];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + u * 256;
+    if (i < nqv) {
+      const int r = i / vpr, c = (i - r * vpr) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q_s[r * dp + c + e] = qreg[u][e];
+    }
   }
   __syncthreads();
-  // scores
-  for (int i = tid; i < nq * Nk; i += 256) {
-    const int r = i / Nk, j = i - r * Nk;
-    const float* qp = q_s + r * dp;
-    const float* kp = kv_s + j * dp;
-    float s = 0.f;
-    for (int c = 0; c < d; ++c) s = fmaf(qp[c], kp[c], s);
-    s *= scale;
-    if (causal && j > (q0 + r) + (Nk - Nq)) s = -3.402823466e+38f;
-    p_s[r * Nk + j] = s;
+  // ---- scores: one thread = one query row x 4 keys (keys strided by njb so lanes stay conflict-free) ----
+  {
+    const int njb = (Nk + 3) >> 2;
+    for (int i = tid; i < nq * njb; i += 256) {
+      const int r = i / njb, jb = i - r * njb;
+      const float* qp = q_s + r * dp;
+      const int j0 = jb, j1 = jb + njb, j2 = jb + 2 * njb, j3 = jb + 3 * njb;
+      const float* k0 = kv_s + j0 * dp;
+      const float* k1 = kv_s + (j1 < Nk ? j1 : j0) * dp;
+      const float* k2 = kv_s + (j2 < Nk ? j2 : j0) * dp;
+      const float* k3 = kv_s + (j3 < Nk ? j3 : j0) * dp;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int c = 0; c < d; ++c) {
+        const float qv = qp[c];
+        s0 = fmaf(qv, k0[c], s0);
+        s1 = fmaf(qv, k1[c], s1);
+        s2 = fmaf(qv, k2[c], s2);
+        s3 = fmaf(qv, k3[c], s3);
+      }
+      const int lim = (q0 + r) + (Nk - Nq);      // causal: keep j <= i + (Nk - Nq)  (blocks.py:315-319)
+      const float NEG = -3.402823466e+38f;
+      float* pr = p_s + r * Nk;
+      pr[j0] = (causal && j0 > lim) ? NEG : s0 * scale;
+      if (j1 < Nk) pr[j1] = (causal && j1 > lim) ? NEG : s1 * scale;
+      if (j2 < Nk) pr[j2] = (causal && j2 > lim) ? NEG : s2 * scale;
+      if (j3 < Nk) pr[j3] = (causal && j3 > lim) ? NEG : s3 * scale;
+    }
   }
   __syncthreads();
-  // V replaces K in LDS while the softmax runs on p_s
-  for (int i = tid; i < Nk * d; i += 256) {
-    const int r = i / d, c = i - r * d;
-    kv_s[r * dp + c] = (xr >= 0 && r == Nk - 1) ? (float)kv_extra[(size_t)xr * ld_extra + vx_off + h * d + c]
-                                                : (float)v[(kvbase + r) * ldkv + v_off + h * d + c];
+  // ---- V (already in registers) replaces K in LDS ---------------------------------------------
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int i = tid + u * 256;
+    if (i < nkv) {
+      const int r = i / vpr, c = (i - r * vpr) * 8;
+      float vv[8];
+      vec_to_float(vraw[u], vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kv_s[r * dp + c + e] = vv[e];
+    }
   }
-  // one wavefront per row: shuffle max, exp, shuffle sum
+  // ---- softmax: one wavefront per row, 64-lane shuffle max / sum --------------------------------
   {
     const int wave = tid >> 6, lane = tid & 63;
     for (int r = wave; r < nq; r += 4) {
       float* pr = p_s + r * Nk;
-      float m = -3.402823466e+38f;
-      for (int j = lane; j < Nk; j += 64) m = fmaxf(m, pr[j]);
+      float e0 = -3.402823466e+38f, e1 = e0, e2 = e0;            // Nk <= 192: three per lane
+      if (lane < Nk) e0 = pr[lane];
+      if (lane + 64 < Nk) e1 = pr[lane + 64];
+      if (lane + 128 < Nk) e2 = pr[lane + 128];
+      float m = fmaxf(e0, fmaxf(e1, e2));
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-      float sum = 0.f;
-      for (int j = lane; j < Nk; j += 64) {
-        const float e = expf(pr[j] - m);
-        pr[j] = e;
-        sum += e;
-      }
+      e0 = (lane < Nk) ? expf(e0 - m) : 0.f;
+      e1 = (lane + 64 < Nk) ? expf(e1 - m) : 0.f;
+      e2 = (lane + 128 < Nk) ? expf(e2 - m) : 0.f;
+      float sum = e0 + e1 + e2;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
       const float inv = 1.0f / sum;
-      for (int j = lane; j < Nk; j += 64) pr[j] *= inv;
+      if (lane < Nk) pr[lane] = e0 * inv;
+      if (lane + 64 < Nk) pr[lane + 64] = e1 * inv;
+      if (lane + 128 < Nk) pr[lane + 128] = e2 * inv;
     }
   }
   __syncthreads();
-  // out = P V
+  // ---- out = P V ---------------------------------------------------------------------------------
   for (int i = tid; i < nq * d; i += 256) {
     const int r = i / d, c = i - r * d;
     const float* pr = p_s + r * Nk;
-    float o = 0.f;
-    for (int j = 0; j < Nk; ++j) o = fmaf(pr[j], kv_s[j * dp + c], o);
-    out[((size_t)b * Nq + q0 + r) * ldo + h * d + c] = (T)o;
+    float o0 = 0.f, o1 = 0.f;
+    int j = 0;
+    for (; j + 1 < Nk; j += 2) {
+      o0 = fmaf(pr[j], kv_s[j * dp + c], o0);
+      o1 = fmaf(pr[j + 1], kv_s[(j + 1) * dp + c], o1);
+    }
+    if (j < Nk) o0 = fmaf(pr[j], kv_s[j * dp + c], o0);
+    out[((size_t)b * Nq + q0 + r) * ldo + h * d + c] = (T)(o0 + o1);
   }
 }
 
@@ -107,7 +176,9 @@ extern "C" int jen1_attention(const void* q, const void* k, const void* v, void*
                               int H, int d, int Nq, int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off,
                               int ldo, int causal, float scale, int dtype, void* stream) {
   JEN1_CHECK(q && k && v && out, "attention: null pointer");
-  JEN1_CHECK(B >= 1 && H >= 1 && d >= 1 && Nq >= 1 && Nk >= 1, "attention: bad sizes");
+  JEN1_CHECK(B >= 1 && H >= 1 && d >= 8 && d % 8 == 0 && Nq >= 1 && Nk >= 1, "attention: bad sizes (head dim must be a multiple of 8)");
+  JEN1_CHECK(Nk <= 192 && (Nk * (d / 8) + 255) / 256 <= 9 && d <= 128, "attention: Nk=%d d=%d outside the small-N kernel's range", Nk, d);
+  JEN1_CHECK(ldq % 8 == 0 && ldkv % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && (!kv_extra || (ld_extra % 8 == 0 && kx_off % 8 == 0 && vx_off % 8 == 0)), "attention: offsets / strides must be multiples of 8 elements");
   JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "attention: bad dtype");
   const int dp = d + 1;
   const size_t lds = sizeof(float) * ((size_t)Nk * dp + (size_t)QCHUNK * dp + (size_t)QCHUNK * Nk);

@@ -74,6 +74,25 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&o)[4]) {
   *reinterpret_cast<bf16x4*>(p) = a;
 }
 
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+  typedef f32x8 type;
+};
+template <>
+struct VecOf<bf16_t> {
+  typedef bf16x8 type;
+};
+__device__ __forceinline__ void vec_to_float(const f32x8& f, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f.v[j];
+}
+__device__ __forceinline__ void vec_to_float(const bf16x8& f, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (float)f[j];
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // precise variant for the float32 parity mode (expf, IEEE division)
 __device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }

@@ -8,9 +8,11 @@
 //   D[m][n] = sum_{tap, c} W[tap][m][c] * pro(X[n -> (b, q*stride + tap - pad_left)][c])
 //
 //   * A operand = weights, pre-packed on the host into MFMA fragment order
-//     [tap][m/16][c/32][lane 0..63][8] so that every wave-instruction streams one
-//     contiguous 1 KiB (bf16) / 2 KiB (f32) block from HBM -- the step is
-//     weight-streaming bound.
+//     [tap][c/32][m/16][lane 0..63][8] so that every wave-instruction streams one
+//     contiguous 1 KiB (bf16) / 2 KiB (f32) block from HBM, and the workgroups of a launch
+//     (different m tiles, same k chunk at the same time) read one contiguous span that
+//     spreads over all memory channels -- the step is weight-streaming bound
+//     (SURVEY.md section 8d).
 //   * B operand = channel-last activations [B][L][C]; the tile (+ conv halo) is staged
 //     ONCE in LDS with the GroupNorm(+FiLM)+SiLU / LayerNorm prologue applied, then
 //     every tap reads a row-shifted view of it (no F.pad copy, no cat copy, no
@@ -36,7 +38,7 @@ namespace {
 struct Layout {
   int ldsld;      // LDS row pitch in elements (stage channels + 8)
   int seg;        // staged input rows per batch element (all taps live)
-  int tile_off, gam_off, bet_off, grp_off, row_off, stats_off, red_off, misc_off, total;
+  int tile_off, gam_off, bet_off, grp_off, fine_off, row_off, stats_off, red_off, misc_off, total;
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
@@ -59,6 +61,8 @@ __host__ __device__ inline Layout make_layout(const jen1_conv_args& a, int esize
   if (tabs) off = align16(off + a.nb * stage_ch * 4);
   L.grp_off = off;
   if (gn) off = align16(off + a.nb * JEN1_FINE_GROUPS * 2 * 4);
+  L.fine_off = off;
+  if (gn) off = align16(off + a.nb * 128 * 4);
   L.row_off = off;
   if (a.pro_mode == JEN1_PRO_LN) off = align16(off + a.nb * L.seg * 2 * 4);
   L.stats_off = off;
@@ -146,14 +150,15 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
   float* gam_s = reinterpret_cast<float*>(smem + L.gam_off);
   float* bet_s = reinterpret_cast<float*>(smem + L.bet_off);
   float* grp = reinterpret_cast<float*>(smem + L.grp_off);
+  float* fine = reinterpret_cast<float*>(smem + L.fine_off);
   float* rowtab = reinterpret_cast<float*>(smem + L.row_off);
   float* st_lds = reinterpret_cast<float*>(smem + L.stats_off);
   float* red = reinterpret_cast<float*>(smem + L.red_off);
   int* misc = reinterpret_cast<int*>(smem + L.misc_off);
 
   // ---- tile coordinates -------------------------------------------------------------------
-  const int tiles_t = (a.L_out + a.tb - 1) / a.tb;
-  const int bt = blockIdx.y / tiles_t, tt = blockIdx.y - bt * tiles_t;
+  const int tiles_t = a.tiles_t;
+  const int bt = (int)(((float)blockIdx.y + 0.5f) * a.inv_tiles_t), tt = blockIdx.y - bt * tiles_t;
   const int b0 = bt * a.nb, t0 = tt * a.tb;
   const int ldsld = L.ldsld;
   const int ctot = a.c0 + a.c1;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     const int n = nf * 16 + li;
-    const int bl = n / a.tb, tl = n - bl * a.tb;
+    const int bl = (int)(((float)n + 0.5f) * a.inv_tb), tl = n - bl * a.tb;     // exact for n < 64
     n_ok[nf] = (n < n_rows) && (b0 + bl < a.B) && (t0 + tl < a.L_out);
     n_b[nf] = bl;
     n_t[nf] = tl;
@@ -198,6 +203,61 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const bool owner = (wk == 0);        // waves that finish the tile (hold the reduced accumulators)
+  const T* res = reinterpret_cast<const T*>(a.residual);
+// ---- epilogue operands (bias, residual, row mask) are requested NOW, before the main loop: with one
+// wave per SIMD every load-use pair that is not overlapped costs a full memory latency at the end
+  bool okk[MF][NF];
+  size_t yrow[MF][NF];
+  int co_m[MF];
+  bool m_okk[MF];
+  float bias4[MF][4];
+  float rr[MF][NF][4];
+  float rsc[MF][NF];
+  float lnu[MF][4];          // ln_fold: row sums of the folded weights
+  float2 lnrs[NF];           // ln_fold: (sum, sumsq) of the input row behind output column nf
+  if (owner) {
+    if (a.ln_fold) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const size_t irow = n_ok[nf] ? (size_t)(b0 + n_b[nf]) * a.L_in + t0 + n_t[nf] : 0;
+        lnrs[nf] = *reinterpret_cast<const float2*>(a.ln_rowstats + irow * 2);
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        int mt = mt_base + mf;
+        mt = mt < MT ? mt : MT - 1;
+        const float4 uu = *reinterpret_cast<const float4*>(a.ln_u + mt * 16 + lg * 4);
+        lnu[mf][0] = uu.x; lnu[mf][1] = uu.y; lnu[mf][2] = uu.z; lnu[mf][3] = uu.w;
+      }
+    }
+  #pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int mt = mt_base + mf;
+      const int m = mt * 16 + lg * 4;
+      m_okk[mf] = mt < MT;
+      const int ph = (m_okk[mf] && a.ps_f > 1) ? m / a.out_C : 0;
+      co_m[mf] = m_okk[mf] ? m - ph * a.out_C : 0;
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) bias4[mf][r] = 0.f;
+      if (a.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co_m[mf]);
+        bias4[mf][0] = bb.x; bias4[mf][1] = bb.y; bias4[mf][2] = bb.z; bias4[mf][3] = bb.w;
+      }
+  #pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int ty = (t0 + n_t[nf]) * a.ps_f + ph - a.ps_off;
+        okk[mf][nf] = m_okk[mf] && n_ok[nf] && ty >= 0 && ty < a.L_y;
+        yrow[mf][nf] = okk[mf][nf] ? (size_t)(b0 + n_b[nf]) * a.y_brows + a.y_row0 + ty : 0;
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) rr[mf][nf][r] = 0.f;
+        if (res) load4(res + yrow[mf][nf] * a.ld_res + co_m[mf], rr[mf][nf]);
+        rsc[mf][nf] = a.row_scale ? a.row_scale[yrow[mf][nf]] : 1.0f;
+      }
+    }
+
+
+  }
   const T* wbase = reinterpret_cast<const T*>(a.w);
   const bool gn = (a.pro_mode == JEN1_PRO_GN || a.pro_mode == JEN1_PRO_GN_SILU);
   const bool ln = (a.pro_mode == JEN1_PRO_LN);
@@ -212,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     for (int mf = 0; mf < MF; ++mf) {
       int mt = mt_base + mf;
       mt = mt < MT ? mt : MT - 1;
-      frag_load(dst[mf], wbase + ((size_t)((size_t)tap * MT + mt) * kch_total + kc) * 512 + lane * 8);
+      frag_load(dst[mf], wbase + ((size_t)((size_t)tap * kch_total + kc) * MT + mt) * 512 + lane * 8);
     }
   };
   // activation batch: raw vectors (+ FiLM scale/shift vectors) of the staging loop
@@ -300,71 +360,69 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
 
   if constexpr (DIRECT) {
     // ---- streaming path (deep levels): no LDS tile, no barrier.  The activation operand was
-    // normalised / activated once by jen1_norm_apply; here both operands of every (tap, chunk)
-    // step sit in one register ring that is refilled right after its slot is consumed.
-    const int nmy_d = (kc_end - kc_begin - wk + WK - 1) / WK;
-    const int nmy = nmy_d > 0 ? nmy_d : 0;
+    // normalised / activated once by jen1_norm_apply; both operands of every (tap, chunk) step sit in
+    // one register ring.  With ~64 workgroups of 4 waves there is ONE wave per SIMD, so the kernel is
+    // bound by instruction latency, not bandwidth: the loop is kept to a handful of instructions per
+    // slot -- incremental weight pointer, per-tap row pointers, rows that fall into the zero padding
+    // point at a zero row (no select), exactly 1 + NF loads per slot so vmcnt is counted precisely.
+    static_assert(MF == 1, "streaming tiles are 16 rows");
+    const int nch_w = kc_end - kc_begin;
+    int nmy = (nch_w - wk + WK - 1) / WK;
+    nmy = nmy > 0 ? nmy : 0;
     const int iters = ntaps * nmy;
     const T* x0p = reinterpret_cast<const T*>(a.x0);
     const T* x1p = reinterpret_cast<const T*>(a.x1);
-    Frag ra[PF][MF], rb[PF][NF];
-    // branch-free operand loads: every ring slot issues exactly MF + NF loads, so the compiler can
-    // count them (s_waitcnt vmcnt((PF-1)*(MF+NF))) instead of draining the ring; out-of-range rows
-    // read a clamped valid address and are zeroed by a select afterwards.
-    const T* nbase0[NF];
-    const T* nbase1[NF];
+    const T* zrow = reinterpret_cast<const T*>(a.zeros);
+    if (iters > 0) {
+      const int mt = mt_base < MT ? mt_base : MT - 1;
+      const size_t a_tap_stride = (size_t)MT * kch_total * 512;
+      const T* pa_tap0 = wbase + ((size_t)((size_t)tap_lo * kch_total + kc_begin + wk) * MT + mt) * 512 + lane * 8;
+      const size_t a_j_stride = (size_t)WK * MT * 512;
+      const T* rp0[NF];      // row pointers of the current prefetch tap (source 0 / source 1), minus nothing:
+      const T* rp1[NF];      // the chunk column offset is added per slot
+      auto setup_tap = [&](int tp) {
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const size_t rb0 = (size_t)(n_ok[nf] ? b0 + n_b[nf] : 0) * a.L_in;
-      nbase0[nf] = x0p + rb0 * a.ld0;
-      nbase1[nf] = a.c1 ? x1p + rb0 * a.ld1 - a.c0 : nbase0[nf];
-    }
-    auto load_slot = [&](Frag(&fa)[MF], Frag(&fb)[NF], int seq) {
-      const int sq = seq < iters ? seq : (iters > 0 ? iters - 1 : 0);
-      const int tp = nmy > 0 ? sq / nmy : 0;
-      const int jj = sq - tp * nmy;
-      int kc = kc_begin + wk + WK * jj;
-      kc = kc < kc_end ? kc : kc_end - 1;
-      load_a(fa, tap_lo + tp, kc);
-      const int c = kc * 32 + lg * 8;
-      const bool src1 = c >= a.c0;
-      const int ld = src1 ? a.ld1 : a.ld0;
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int tin = (t0 + n_t[nf]) * a.stride + tap_lo + tp - a.pad_left;
-        const bool ok = n_ok[nf] && tin >= 0 && tin < a.L_in;
-        const T* base = src1 ? nbase1[nf] : nbase0[nf];
-        frag_load(fb[nf], base + (size_t)(ok ? tin : 0) * ld + c);
-        if (!ok) frag_zero(fb[nf]);
-      }
-    };
-#pragma unroll
-    for (int u = 0; u < PF; ++u) load_slot(ra[u], rb[u], u);
-    const bool scale1 = (a.c1 > 0) && (a.src1_scale != 1.0f);
-    for (int it = 0; it < iters; it += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        if (it + u < iters) {
-          if (scale1) {
-            const int tp = (it + u) / nmy;
-            const int kc = kc_begin + wk + WK * ((it + u) - tp * nmy);
-            if (kc * 32 >= a.c0) {
-#pragma unroll
-              for (int nf = 0; nf < NF; ++nf) {
-                float xv[8];
-                frag_to_float(rb[u][nf], xv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] *= a.src1_scale;
-                float_to_frag(rb[u][nf], xv);
-              }
-            }
-          }
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) mma32(acc[mf][nf], ra[u][mf], rb[u][nf]);
+        for (int nf = 0; nf < NF; ++nf) {
+          const int tin = (t0 + n_t[nf]) * a.stride + tap_lo + tp - a.pad_left;
+          const bool ok = n_ok[nf] && tin >= 0 && tin < a.L_in;
+          const size_t row = (size_t)(b0 + n_b[nf]) * a.L_in + tin;
+          rp0[nf] = ok ? x0p + row * a.ld0 : zrow;
+          rp1[nf] = ok ? (a.c1 ? x1p + row * a.ld1 - a.c0 : x0p + row * a.ld0) : zrow - (a.c1 ? a.c0 : 0);
         }
-        load_slot(ra[u], rb[u], it + u + PF);
+      };
+      int p_tp = 0, p_j = 0;
+      const T* pa = pa_tap0;
+      setup_tap(0);
+      auto issue = [&](Frag& fa, Frag(&fb)[NF]) {
+        frag_load(fa, pa);
+        const int kc = kc_begin + wk + WK * p_j;
+        const int coff = kc * 32 + lg * 8;
+        const bool s1 = kc * 32 >= a.c0;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) frag_load(fb[nf], (s1 ? rp1[nf] : rp0[nf]) + coff);
+        // advance the prefetch cursor; past the end it parks on the last valid slot
+        if (p_j + 1 < nmy) {
+          ++p_j;
+          pa += a_j_stride;
+        } else if (p_tp + 1 < ntaps) {
+          p_j = 0;
+          ++p_tp;
+          pa = pa_tap0 + (size_t)p_tp * a_tap_stride;
+          setup_tap(p_tp);
+        }
+      };
+      Frag ra[PF], rb[PF][NF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) issue(ra[u], rb[u]);
+      for (int it = 0; it < iters; it += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          if (it + u < iters) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) mma32(acc[0][nf], ra[u], rb[u][nf]);
+          }
+          issue(ra[u], rb[u]);
+        }
       }
     }
     if (a.out_gn_stats) {
@@ -391,33 +449,43 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
   // (b) first activation batch of the first stage
   Batch cur;
   load_batch(cur, 0, nch * 32, kc_begin * 32);
-  // (c) small tables: GroupNorm group statistics, LayerNorm row statistics
+  // (c) small tables: GroupNorm group statistics, LayerNorm row statistics.  The fine-group sums are
+  // fetched with ONE load per thread (all in flight together) and merged from LDS: a per-group loop of
+  // dependent global loads would cost one memory latency per fine group.
   if (gn) {
     const int G = a.gn_groups;
+    for (int i = tid; i < a.nb * 64; i += NT) {
+      const int bl = i >> 6, src = (i >> 5) & 1, f = i & 31;
+      const int b = b0 + bl;
+      const float* st = src ? a.gn_stats1 : a.gn_stats0;
+      float2 v = make_float2(0.f, 0.f);
+      if (st && b < a.B) v = *reinterpret_cast<const float2*>(st + (size_t)b * 64 + 2 * f);
+      fine[2 * i] = v.x;
+      fine[2 * i + 1] = v.y;
+    }
+    __syncthreads();
     for (int i = tid; i < a.nb * G; i += NT) {
       const int bl = i / G, g = i - bl * G;
       const int b = b0 + bl;
       float mean = 0.f, rstd = 0.f;
       if (b < a.B) {
         int lo = g * a.gn_cpg, hi = (g == G - 1) ? ctot : lo + a.gn_cpg;
-        const float* st;
-        int cpf;
+        int src = 0, cpf;
         float sc = 1.f;
         if (lo >= a.c0) {
-          st = a.gn_stats1 + (size_t)b * 64;
+          src = 1;
           lo -= a.c0; hi -= a.c0;
           cpf = a.c1 / JEN1_FINE_GROUPS;
           sc = a.src1_scale;
         } else {
-          st = a.gn_stats0 + (size_t)b * 64;
           cpf = a.c0 / JEN1_FINE_GROUPS;
           if (hi > a.c0) hi = a.c0;
         }
         float s = 0.f, q = 0.f;
         const int f0 = lo / cpf, f1 = (hi + cpf - 1) / cpf;
         for (int f = f0; f < f1; ++f) {
-          s += st[2 * f];
-          q += st[2 * f + 1];
+          s += fine[2 * ((bl * 2 + src) * 32 + f)];
+          q += fine[2 * ((bl * 2 + src) * 32 + f) + 1];
         }
         s *= sc;
         q *= sc * sc;
@@ -469,6 +537,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     if (tabs) {
       const float* gsrc = gn ? a.gn_gamma : a.ln_gamma;
       const float* bsrc = gn ? a.gn_beta : a.ln_beta;
+#pragma unroll 4
       for (int i = tid; i < a.nb * sch; i += NT) {
         const int bl = i / sch, cl = i - bl * sch;
         float gv = gsrc[cst + cl], bv = bsrc[cst + cl];
@@ -560,7 +629,6 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
           }
     }
   }
-  const bool owner = (wk == 0);        // waves that hold finished (or to-be-published) accumulators
 
   // ==== inter-workgroup split-K: publish partial slab, last arriver reduces ==================
   // Fence-free form of the hand-off (cdna_hip_programming.md Guideline 16, R1): the partial tile is
@@ -617,53 +685,44 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
   if (owner) {
     T* yT = reinterpret_cast<T*>(a.y);
     float* yF = reinterpret_cast<float*>(a.y);
-    const T* res = reinterpret_cast<const T*>(a.residual);
     float rs_sum[NF], rs_sq[NF];
     int yrow_n[NF];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) { rs_sum[nf] = 0.f; rs_sq[nf] = 0.f; yrow_n[nf] = -1; }
 
+    // ---- pass 2: finish, store, statistics
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      const int mt = mt_base + mf;
-      const int m = mt * 16 + lg * 4;
-      const bool m_ok = mt < MT;
-      const int ph = m_ok ? m / a.out_C : 0;
-      const int co = m - ph * a.out_C;
-      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (m_ok && a.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-        bias4[0] = bb.x; bias4[1] = bb.y; bias4[2] = bb.z; bias4[3] = bb.w;
-      }
+      const int co = co_m[mf];
+      const bool m_ok = m_okk[mf];
       float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};   // nb == 1 path: per channel-pair sums over nf
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        const int b = b0 + n_b[nf];
-        const int ty = (t0 + n_t[nf]) * a.ps_f + ph - a.ps_off;
-        const bool ok = m_ok && n_ok[nf] && ty >= 0 && ty < a.L_y;
         float v[4];
+        if (a.ln_fold) {
+          // Linear(LayerNorm(x)) = rstd * (W'x - mean * rowsum(W')) + W beta   (blocks.py:427-429)
+          const float inv_c = 1.0f / (float)a.ln_C;
+          const float mean = lnrs[nf].x * inv_c;
+          float var = lnrs[nf].y * inv_c - mean * mean;
+          var = var < 0.f ? 0.f : var;
+          const float rstd = PRECISE ? 1.0f / sqrtf(var + a.ln_eps) : rsqrtf(var + a.ln_eps);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias4[r];
+          for (int r = 0; r < 4; ++r) v[r] = (acc[mf][nf][r] - mean * lnu[mf][r]) * rstd + bias4[mf][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias4[mf][r];
+        }
         if (a.act == JEN1_ACT_GELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
-        if (ok) {
-          const size_t yrow = (size_t)b * a.y_brows + a.y_row0 + ty;
-          yrow_n[nf] = (int)yrow;
-          if (res) {
-            float rr[4];
-            load4(res + yrow * a.ld_res + co, rr);
+        if (okk[mf][nf]) {
+          const size_t yr = yrow[mf][nf];
+          yrow_n[nf] = (int)yr;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-          }
-          if (a.row_scale) {
-            const float s = a.row_scale[yrow];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= s;
-          }
-          if (a.y_f32) store4(yF + yrow * a.ld_y + co, v);
-          else store4(yT + yrow * a.ld_y + co, v);
+          for (int r = 0; r < 4; ++r) v[r] = (v[r] + rr[mf][nf][r]) * rsc[mf][nf];
+          if (a.y_f32) store4(yF + yr * a.ld_y + co, v);
+          else store4(yT + yr * a.ld_y + co, v);
           rs_sum[nf] += (v[0] + v[1]) + (v[2] + v[3]);
           rs_sq[nf] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
           if (a.out_gn_stats) {
@@ -824,6 +883,10 @@ static int validate(const jen1_conv_args& a) {
   if (a.pro_mode == JEN1_PRO_LN) JEN1_CHECK(a.ln_rowstats && a.ln_C >= 1 && a.c1 == 0 && (!a.ln_gamma || a.ln_beta), "conv_gemm: incomplete LayerNorm prologue");
   JEN1_CHECK(!a.out_gn_stats || (a.out_cpf >= 2 && a.out_cpf % 2 == 0), "conv_gemm: out_cpf must be even");
   JEN1_CHECK(!a.direct || a.pro_mode == JEN1_PRO_NONE, "conv_gemm: direct (no-LDS) mode takes no prologue; run jen1_norm_apply first");
+  JEN1_CHECK(!a.direct || (a.zeros && (a.c1 == 0 || a.src1_scale == 1.0f)), "conv_gemm: direct mode needs a zero row and src1_scale == 1 (fold the scale into the weights)");
+  JEN1_CHECK(a.nb * a.tb <= 64 && a.L_out / a.tb + 1 < (1 << 20), "conv_gemm: tile too large for the reciprocal index math");
+  JEN1_CHECK(!a.ln_fold || (a.ln_u && a.ln_rowstats && a.ln_C >= 1 && a.taps == 1 && a.stride == 1 && a.L_out == a.L_in && a.ps_f == 1 && a.c1 == 0 && a.pro_mode == JEN1_PRO_NONE),
+             "conv_gemm: ln_fold needs ln_u / ln_rowstats, taps = 1 and no prologue");
   const Layout L = make_layout(a, a.dtype == JEN1_F32 ? 4 : 2, cfg_red_floats(a.cfg));
   JEN1_CHECK(L.total <= 160 * 1024, "conv_gemm: LDS request %d B exceeds 160 KiB (tb=%d nb=%d kc_stage=%d)", L.total, a.tb, a.nb, a.kc_stage);
   return 0;
@@ -837,6 +900,11 @@ extern "C" int64_t jen1_conv_gemm_lds_bytes(const jen1_conv_args* args) {
 extern "C" int jen1_conv_gemm(const jen1_conv_args* args, void* stream) {
   JEN1_CHECK(args != nullptr, "conv_gemm: null args");
   if (int rc = validate(*args)) return rc;
+  jen1_conv_args a = *args;
+  // derived launch constants (kept out of the kernel's serial prologue)
+  a.tiles_t = (a.L_out + a.tb - 1) / a.tb;
+  a.inv_tiles_t = 1.0f / (float)a.tiles_t;
+  a.inv_tb = 1.0f / (float)a.tb;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return args->dtype == JEN1_F32 ? dispatch<float>(*args, s) : dispatch<bf16_t>(*args, s);
+  return a.dtype == JEN1_F32 ? dispatch<float>(a, s) : dispatch<bf16_t>(a, s);
 }

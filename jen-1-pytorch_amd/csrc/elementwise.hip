@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
   if (threadIdx.x < 64) st[threadIdx.x] = 0.f;
   __syncthreads();
   const int cpf = ld / JEN1_FINE_GROUPS;
-  for (int r = ty; r < 32; r += 8) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 8 * i;
     const int c = c0 + r, t = t0 + tx;
     float v = 0.f;
     if (t < Tn) {
@@ -52,10 +54,19 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
       else if (c < C + Cc) v = ctx[((size_t)b * Cc + (c - C)) * Tn + t];
     }
     tile[r][tx] = v;
-    if (stats && v != 0.f) {
-      const int fg = c / cpf;
-      atomicAdd(&st[2 * fg - 2 * (c0 / cpf)], v);          // local fine groups of this 32-channel slab
-      atomicAdd(&st[2 * fg - 2 * (c0 / cpf) + 1], v * v);
+    if (stats) {
+      // the 32 lanes of a half-wave hold one channel: reduce over time with shuffles, one LDS atomic per channel
+      float sv = v, sq = v * v;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) {
+        sv += __shfl_xor(sv, off);
+        sq += __shfl_xor(sq, off);
+      }
+      if (tx == 0 && sq != 0.f) {
+        const int fg = c / cpf;
+        atomicAdd(&st[2 * fg - 2 * (c0 / cpf)], sv);          // local fine groups of this 32-channel slab
+        atomicAdd(&st[2 * fg - 2 * (c0 / cpf) + 1], sq);
+      }
     }
   }
   __syncthreads();
@@ -143,7 +154,8 @@ __global__ __launch_bounds__(256) void time_features_kernel(const int64_t* __res
   }
 }
 
-// y[n][o] = act(x[n] . w[o] + bias[o]); one wavefront per output feature, all rows
+// y[n][o] = act(x[n] . w[o] + bias[o]); one wavefront per output feature; rows are processed 8 at a time
+// so that the loads of a pass are all in flight together (one wave per SIMD: latency, not bandwidth)
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int n,
                                                           int in_f, int out_f, int act) {
@@ -151,15 +163,28 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
   const int lane = threadIdx.x & 63;
   if (o >= out_f) return;
   const float* wr = w + (size_t)o * in_f;
-  for (int r = 0; r < n; ++r) {
-    const float* xr = x + (size_t)r * in_f;
-    float s = 0.f;
-    for (int i = lane; i < in_f; i += 64) s = fmaf(xr[i], wr[i], s);
+  const float bo = bias ? bias[o] : 0.f;
+  for (int r0 = 0; r0 < n; r0 += 8) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < in_f; i += 64) {
+      const float wv = wr[i];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) {
-      s += bias ? bias[o] : 0.f;
-      y[(size_t)r * out_f + o] = act == JEN1_ACT_GELU ? gelu_erf(s) : s;
+      for (int k = 0; k < 8; ++k) {
+        const int r = r0 + k < n ? r0 + k : n - 1;
+        s[k] = fmaf(x[(size_t)r * in_f + i], wv, s[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+    }
+    if (lane < 8 && r0 + lane < n) {
+      float v = s[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v = (lane == k) ? s[k] : v;
+      v += bo;
+      y[(size_t)(r0 + lane) * out_f + o] = act == JEN1_ACT_GELU ? gelu_erf(v) : v;
     }
   }
 }
@@ -176,25 +201,39 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
   extern __shared__ float tile[];   // [C][33]
   const int t0 = blockIdx.x * 32, b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // phase 1: per (b, t) row -> guided output, written transposed into LDS
-  for (int r = wave; r < 32; r += 4) {
-    const int t = t0 + r;
-    if (t >= Tn) continue;           // wave-uniform
+  constexpr int RPW = 8;            // rows (time steps) per wave
+  constexpr int CPL = 4;            // channels per lane: C <= 256
+  // phase 1: per (b, t) row -> guided output, written transposed into LDS.  All rows of the wave are
+  // loaded before any is reduced (memory-level parallelism; one wave per SIMD here).
+  float oc[RPW][CPL], ou[RPW][CPL];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wave + 4 * i;
+    const int t = (t0 + r < Tn) ? t0 + r : Tn - 1;
     const T* pc = net + ((size_t)b * Tn + t) * ld;
-    const T* pu = net + ((size_t)(B + b) * Tn + t) * ld;
-    if (nrep == 1) {
-      for (int c = lane; c < C; c += 64) tile[c * 33 + r] = (float)pc[c];
-      continue;
+    const T* pu = net + ((size_t)((nrep == 2 ? B : 0) + b) * Tn + t) * ld;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      const int cc_ = c < C ? c : 0;
+      oc[i][k] = (float)pc[cc_];
+      ou[i][k] = (float)pu[cc_];
     }
+  }
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wave + 4 * i;
+    if (t0 + r >= Tn) continue;      // wave-uniform
+    float og[CPL];
     float s_c = 0.f, s_g = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float oc = (float)pc[c], ou = (float)pu[c];
-      const float og = ou + (oc - ou) * scale;
-      tile[c * 33 + r] = og;
-      s_c += oc;
-      s_g += og;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const bool cv = lane + 64 * k < C;
+      og[k] = (nrep == 2) ? ou[i][k] + (oc[i][k] - ou[i][k]) * scale : oc[i][k];
+      s_c += cv ? oc[i][k] : 0.f;
+      s_g += cv ? og[k] : 0.f;
     }
-    if (scale_cfg) {
+    if (nrep == 2 && scale_cfg) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         s_c += __shfl_xor(s_c, off);
@@ -202,10 +241,12 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
       }
       const float m_c = s_c / (float)C, m_g = s_g / (float)C;
       float v_c = 0.f, v_g = 0.f;
-      for (int c = lane; c < C; c += 64) {
-        const float dc = (float)pc[c] - m_c, dg = tile[c * 33 + r] - m_g;
-        v_c += dc * dc;
-        v_g += dg * dg;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        const bool cv = lane + 64 * k < C;
+        const float dc = oc[i][k] - m_c, dg = og[k] - m_g;
+        v_c += cv ? dc * dc : 0.f;
+        v_g += cv ? dg * dg : 0.f;
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
@@ -213,14 +254,15 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
         v_g += __shfl_xor(v_g, off);
       }
       const float ratio = sqrtf(v_c / (float)(C - 1)) / sqrtf(v_g / (float)(C - 1));   // unbiased std (torch.std)
-      for (int c = lane; c < C; c += 64) {
-        const float og = tile[c * 33 + r];
-        tile[c * 33 + r] = phi * (og * ratio) + (1.0f - phi) * og;
-      }
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) og[k] = phi * (og[k] * ratio) + (1.0f - phi) * og[k];
     }
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      if (lane + 64 * k < C) tile[(lane + 64 * k) * 33 + r] = og[k];
   }
   __syncthreads();
-  // phase 2: [C][T]-major elementwise
+  // phase 2: [C][T]-major elementwise, 8 channels per pass with their loads issued together
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t = t0 + tx;
   if (t >= Tn) return;
@@ -228,34 +270,46 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
   if (DDIM) {
     sr = coef[0]; srm1 = coef[1]; sa_n = coef[2]; cc = coef[3]; sg = coef[4]; last = coef[5]; sa_t = coef[6]; s1m_t = coef[7];
   }
-  for (int c = ty; c < C; c += 8) {
-    const size_t idx = ((size_t)b * C + c) * Tn + t;
-    const float o = tile[c * 33 + tx];
-    if (!DDIM) {
-      x_out[idx] = o;
-      continue;
+  for (int cb = 0; cb < C; cb += 64) {
+    float xv[8], nv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cb + ty + 8 * k;
+      const size_t idx = ((size_t)b * C + (c < C ? c : 0)) * Tn + t;
+      xv[k] = DDIM ? x[idx] : 0.f;
+      nv[k] = (DDIM && noise) ? noise[idx] : 0.f;
     }
-    const float xv = x[idx];
-    float x0, eps;
-    if (objective == 0) {          // 'noise'
-      eps = o;
-      x0 = sr * xv - srm1 * eps;
-      if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-    } else if (objective == 1) {   // 'x0'
-      x0 = o;
-      if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-      eps = (sr * xv - x0) / srm1;
-    } else {                       // 'v'
-      x0 = sa_t * xv - s1m_t * o;
-      if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-      eps = (sr * xv - x0) / srm1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cb + ty + 8 * k;
+      if (c >= C) continue;
+      const size_t idx = ((size_t)b * C + c) * Tn + t;
+      const float o = tile[c * 33 + tx];
+      if (!DDIM) {
+        x_out[idx] = o;
+        continue;
+      }
+      float x0, eps;
+      if (objective == 0) {          // 'noise'
+        eps = o;
+        x0 = sr * xv[k] - srm1 * eps;
+        if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      } else if (objective == 1) {   // 'x0'
+        x0 = o;
+        if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        eps = (sr * xv[k] - x0) / srm1;
+      } else {                       // 'v'
+        x0 = sa_t * xv[k] - s1m_t * o;
+        if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        eps = (sr * xv[k] - x0) / srm1;
+      }
+      float xn;
+      if (last != 0.f) xn = x0;
+      else xn = x0 * sa_n + cc * eps + sg * nv[k];
+      x_out[idx] = xn;
+      if (eps_out) eps_out[idx] = eps;
+      if (x0_out) x0_out[idx] = x0;
     }
-    float xn;
-    if (last != 0.f) xn = x0;
-    else xn = x0 * sa_n + cc * eps + (noise ? sg * noise[idx] : 0.f);
-    x_out[idx] = xn;
-    if (eps_out) eps_out[idx] = eps;
-    if (x0_out) x0_out[idx] = x0;
   }
 }
 
@@ -280,6 +334,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const jen1_norm_args a)
   const int c = active ? (v - row * vpr) * 8 : 0;
   float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float gam[8], bet[8], fs[8], fh[8];
+  float2 rsv = make_float2(0.f, 1.f);
+  if (active && !gn) rsv = *reinterpret_cast<const float2*>(a.ln_rowstats + ((size_t)b * a.L + row) * 2);
   if (active) {
     if (c < a.c0) load8(reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.L + row) * a.ld0 + c, x);
     else load8(reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.L + row) * a.ld1 + (c - a.c0), x);
@@ -299,26 +355,36 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const jen1_norm_args a)
     }
   }
   if (gn) {
+    // 2 x 32 fine-group (sum, sumsq) pairs of this batch element: one load per thread, all in flight
+    // together (a per-group loop of dependent loads costs a memory latency per fine group)
+    __shared__ float fine[128];
+    if (tid < 64) {
+      const int src = tid >> 5, f = tid & 31;
+      const float* st = src ? a.gn_stats1 : a.gn_stats0;
+      float2 v = make_float2(0.f, 0.f);
+      if (st) v = *reinterpret_cast<const float2*>(st + (size_t)b * 64 + 2 * f);
+      fine[2 * tid] = v.x;
+      fine[2 * tid + 1] = v.y;
+    }
+    __syncthreads();
     if (tid < a.groups) {
       const int g = tid;
       int lo = g * a.cpg, hi = (g == a.groups - 1) ? ctot : lo + a.cpg;
-      const float* st;
-      int cpf;
+      int src = 0, cpf;
       float sc = 1.f;
       if (lo >= a.c0) {
-        st = a.gn_stats1 + (size_t)b * 64;
+        src = 1;
         lo -= a.c0; hi -= a.c0;
         cpf = a.c1 / JEN1_FINE_GROUPS;
         sc = a.src1_scale;
       } else {
-        st = a.gn_stats0 + (size_t)b * 64;
         cpf = a.c0 / JEN1_FINE_GROUPS;
         if (hi > a.c0) hi = a.c0;
       }
       float s = 0.f, q = 0.f;
       for (int f = lo / cpf; f < (hi + cpf - 1) / cpf; ++f) {
-        s += st[2 * f];
-        q += st[2 * f + 1];
+        s += fine[2 * (src * 32 + f)];
+        q += fine[2 * (src * 32 + f) + 1];
       }
       s *= sc;
       q *= sc * sc;
@@ -349,10 +415,9 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const jen1_norm_args a)
       if (a.mode == JEN1_PRO_GN_SILU) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
     }
   } else {
-    const float* rs = a.ln_rowstats + ((size_t)b * a.L + row) * 2;
     const float inv_c = 1.0f / (float)a.count;
-    const float mean = rs[0] * inv_c;
-    float var = rs[1] * inv_c - mean * mean;
+    const float mean = rsv.x * inv_c;
+    float var = rsv.y * inv_c - mean * mean;
     var = var < 0.f ? 0.f : var;
     const float rstd = PRECISE ? 1.0f / sqrtf(var + a.eps) : rsqrtf(var + a.eps);
 #pragma unroll
@@ -424,7 +489,7 @@ static int launch_cfg(const void* net, const float* x, const float* noise, const
                       int objective, int clip_x0, int dtype, void* stream) {
   JEN1_CHECK(net && x_out, "cfg step: null pointer");
   JEN1_CHECK(nrep == 1 || nrep == 2, "cfg step: nrep must be 1 or 2");
-  JEN1_CHECK(C >= 2 && C <= 1024 && ld >= C, "cfg step: bad C/ld");
+  JEN1_CHECK(C >= 2 && C <= 256 && ld >= C, "cfg step: C must be in [2, 256]");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((T + 31) / 32, B);
   const size_t lds = sizeof(float) * (size_t)C * 33;

@@ -62,6 +62,11 @@ class Weights:
         pk = lambda w_tmk: pack_gemm_weight(w_tmk, dtype)
         f32 = lambda t: t.contiguous()
 
+        def rowsum(w_mk):
+            """row sums of the weights exactly as the MFMA sees them (rounded to the compute dtype):
+            the epilogue form of LayerNorm subtracts mean * rowsum(W') from the accumulator"""
+            return w_mk.to(dtype).to(torch.float32).sum(dim=1).contiguous()
+
         def padvec(t, n):
             return torch.nn.functional.pad(t, (0, n - t.numel())).contiguous() if t.numel() != n else t.contiguous()
 
@@ -88,7 +93,12 @@ class Weights:
             self.v[f"{n}.gn2.g"] = f32(p[f"{n}.block2.groupnorm.weight"])
             self.v[f"{n}.gn2.b"] = f32(p[f"{n}.block2.groupnorm.bias"])
             if r.has_shortcut:
-                self.w[f"{n}.short"] = pk(conv_weight_to_gemm(p[f"{n}.to_out.conv.weight"]))
+                wsc = conv_weight_to_gemm(p[f"{n}.to_out.conv.weight"]).clone()
+                if r.c_in == 2 * r.c_out and spec.use_skip_scale:
+                    # up-path shortcut reads cat([x, skip * 2^-1/2]) (blocks.py:732-734): the scale is folded
+                    # into the skip half of the 1x1 weights so the GEMM can stream both sources unscaled
+                    wsc[:, :, r.c_out:] *= 2 ** -0.5
+                self.w[f"{n}.short"] = pk(wsc)
                 self.v[f"{n}.short.bias"] = f32(p[f"{n}.to_out.conv.bias"])
             film_w.append(p[f"{n}.to_scale_shift.to_scale_shift.1.weight"])
             film_b.append(p[f"{n}.to_scale_shift.to_scale_shift.1.bias"])
@@ -125,15 +135,18 @@ class Weights:
             wkv, bkv = fold_layernorm(p[f"{a}.to_kv.weight"], p[f"{a}.norm_context.weight"], p[f"{a}.norm_context.bias"])
             self.w[f"{n}.qkv"] = pk(torch.cat([wq, wkv], 0)[None])
             self.v[f"{n}.qkv.bias"] = torch.cat([bq, bkv], 0).contiguous()
+            self.v[f"{n}.qkv.u"] = rowsum(torch.cat([wq, wkv], 0))
             self.w[f"{n}.o1"] = pk(p[f"{a}.attention.to_out.weight"][None])
             self.v[f"{n}.o1.bias"] = f32(p[f"{a}.attention.to_out.bias"])
             x = f"{b}.cross_attention"
             wq2, bq2 = fold_layernorm(p[f"{x}.to_q.weight"], p[f"{x}.norm.weight"], p[f"{x}.norm.bias"])
             self.w[f"{n}.q2"] = pk(wq2[None])
             self.v[f"{n}.q2.bias"] = bq2.contiguous()
+            self.v[f"{n}.q2.u"] = rowsum(wq2)
             wkv2, bkv2 = fold_layernorm(p[f"{x}.to_kv.weight"], p[f"{x}.norm_context.weight"], p[f"{x}.norm_context.bias"])
             self.w[f"{n}.kv2"] = pk(wkv2[None])
             self.v[f"{n}.kv2.bias"] = bkv2.contiguous()
+            self.v[f"{n}.kv2.u"] = rowsum(wkv2)
             kvx_w.append(wkv2)
             kvx_b.append(bkv2)
             self.kvx_off[n] = off
@@ -149,6 +162,7 @@ class Weights:
             # time-token K/V rows of every cross-attention layer as ONE GEMM per step
             self.w["kvx"] = pk(torch.cat(kvx_w, 0)[None])
             self.v["kvx.bias"] = torch.cat(kvx_b, 0).contiguous()
+            self.v["kvx.u"] = rowsum(torch.cat(kvx_w, 0))
         self.fixed = p["fixed_embedding.embedding.weight"].contiguous()       # [ctx_len][F] float32
 
     def nbytes(self) -> int:
@@ -181,6 +195,7 @@ class OpBuilder:
         self._keep: List[object] = []
         self.slab = None
         self.counters = None
+        self.zero_row = torch.zeros((8192,), dtype=torch.float32, device=eng.device)   # padding rows of direct GEMMs
 
     def _empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.eng.tdtype, device=self.eng.device)
@@ -225,7 +240,7 @@ class OpBuilder:
         out_C = out_C if out_C is not None else out.C
         a.out_C, a.ps_f, a.ps_off = out_C, ps_f, ps_off
         a.M = out_C * ps_f
-        assert w.shape[0] == taps and w.shape[1] * 16 == a.M and w.shape[2] * 32 == a.c0 + a.c1, \
+        assert w.shape[0] == taps and w.shape[2] * 16 == a.M and w.shape[1] * 32 == a.c0 + a.c1, \
             (tuple(w.shape), taps, a.M, a.c0, a.c1)
         a.y, a.ld_y = out.t.data_ptr(), out.ld
         a.L_y = L_y if L_y is not None else (out.L - y_row0)
@@ -251,8 +266,10 @@ class OpBuilder:
                 ftab, frow, foff, fC = film
                 a.film, a.film_row = ftab.data_ptr(), _ptr(frow)
                 a.film_off, a.film_C, a.film_ld = foff, fC, ftab.shape[-1]
+        ln_u = None
         if pro == L.PRO_LN:
-            lnC, g_, b_ = ln
+            lnC, g_, b_ = ln[:3]
+            ln_u = ln[3] if len(ln) > 3 else None
             a.ln_rowstats, a.ln_C, a.ln_eps = src0.rs.data_ptr(), lnC, 1e-5
             a.ln_gamma, a.ln_beta = _ptr(g_), _ptr(b_)
         a.act = act
@@ -265,7 +282,14 @@ class OpBuilder:
         lib = eng.lib
         streaming = a.cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
         want_direct = streaming and (force is None or force.get("direct", True))
-        if want_direct and pro in (L.PRO_GN, L.PRO_GN_SILU, L.PRO_LN):
+        if want_direct and pro == L.PRO_LN and ln_u is not None and a.ln_gamma is None and taps == 1 and stride == 1 \
+                and src1 is None and (force is None or force.get("ln_fold", True)):
+            # LayerNorm folded into the epilogue: no pre-pass, the GEMM streams the raw rows
+            a.ln_fold, a.ln_u = 1, ln_u.data_ptr()
+            a.pro_mode = L.PRO_NONE
+            a.direct = 1
+            self._keep.append(ln_u)
+        elif want_direct and pro in (L.PRO_GN, L.PRO_GN_SILU, L.PRO_LN):
             # deep level: up to M/16 workgroups would each redo the prologue of the same tiny tile --
             # normalise / activate it ONCE (jen1_norm_apply), then stream the GEMM with no LDS staging
             na = L.NormArgs()
@@ -297,7 +321,11 @@ class OpBuilder:
             a.direct = 1
         elif want_direct and pro == L.PRO_NONE:
             a.direct = 1
+        if a.direct and a.c1 and a.src1_scale != 1.0:
+            a.direct = 0          # a raw scaled second source needs the LDS path (or pre-scaled weights)
         if a.direct:
+            assert a.c0 + a.c1 <= 8192
+            a.zeros = self.zero_row.data_ptr()
             a.kc_stage = max(1, (a.c0 + a.c1) // 32)
         if a.splitk > 1:
             self._splitk_args.append(a)
@@ -434,7 +462,7 @@ class Plan(OpBuilder):
                   gn=(r.groups, r.c_in, W.v[f"{n}.gn1.g"], W.v[f"{n}.gn1.b"], 1e-5))
         if r.has_shortcut:
             res = self.new_act(src0.B, src0.L, r.c_out)
-            self.conv(ops, src0=src0, src1=src1, src1_scale=sc, w=W.w[f"{n}.short"], bias=W.v[f"{n}.short.bias"], out=res)
+            self.conv(ops, src0=src0, src1=src1, src1_scale=1.0, w=W.w[f"{n}.short"], bias=W.v[f"{n}.short.bias"], out=res)
         else:
             assert src1 is None
             res = src0
@@ -454,14 +482,16 @@ class Plan(OpBuilder):
         self.conv(ops, src0=x, w=W.w[f"{n}.proj"], bias=W.v[f"{n}.proj.bias"], out=x1, pro=L.PRO_GN,
                   gn=(32, Cc, W.v[f"{n}.gn.g"], W.v[f"{n}.gn.b"], 1e-6))
         qkv = self.new_act(Bf, Lx, 3 * mid)
-        self.conv(ops, src0=x1, w=W.w[f"{n}.qkv"], bias=W.v[f"{n}.qkv.bias"], out=qkv, pro=L.PRO_LN, ln=(Cc, None, None))
+        self.conv(ops, src0=x1, w=W.w[f"{n}.qkv"], bias=W.v[f"{n}.qkv.bias"], out=qkv, pro=L.PRO_LN,
+                  ln=(Cc, None, None, W.v[f"{n}.qkv.u"]))
         a1 = self.new_act(Bf, Lx, mid)
         self.attention(ops, q=qkv, q_off=0, kv_t=qkv.t, ldkv=qkv.ld, k_off=mid, v_off=2 * mid, out=a1, H=H, d=d, Nk=Lx,
                        causal=causal)
         x2 = self.new_act(Bf, Lx, Cc, rs=True)
         self.conv(ops, src0=a1, w=W.w[f"{n}.o1"], bias=W.v[f"{n}.o1.bias"], out=x2, residual=x1)
         q2 = self.new_act(Bf, Lx, mid)
-        self.conv(ops, src0=x2, w=W.w[f"{n}.q2"], bias=W.v[f"{n}.q2.bias"], out=q2, pro=L.PRO_LN, ln=(Cc, None, None))
+        self.conv(ops, src0=x2, w=W.w[f"{n}.q2"], bias=W.v[f"{n}.q2.bias"], out=q2, pro=L.PRO_LN,
+                  ln=(Cc, None, None, W.v[f"{n}.q2.u"]))
         a2 = self.new_act(Bf, Lx, mid)
         kv = self.kv_ctx[n]
         self.attention(ops, q=q2, q_off=0, kv_t=kv, ldkv=2 * mid, k_off=0, v_off=mid, out=a2, H=H, d=d, Nk=eng.spec.ctx_len,
@@ -554,7 +584,8 @@ class Plan(OpBuilder):
             a = (tok_t.t.data_ptr(), tok_t.rs.data_ptr(), B, F, F, eng.dt)
             ops.append(lambda s, a=a: L.check(lib.jen1_row_stats(*a, s), "jen1_row_stats"))
             self.kvx = self.new_act(1, B, W.kvx_ld)
-            self.conv(ops, src0=tok_t, w=W.w["kvx"], bias=W.v["kvx.bias"], out=self.kvx, pro=L.PRO_LN, ln=(F, None, None))
+            self.conv(ops, src0=tok_t, w=W.w["kvx"], bias=W.v["kvx.bias"], out=self.kvx, pro=L.PRO_LN,
+                      ln=(F, None, None, W.v["kvx.u"]))
 
         # ---- 4. UNet1d.forward (model.py:243-262) ------------------------------------------------
         x = self.resblock(spec.to_in, X0, None, causal=False)

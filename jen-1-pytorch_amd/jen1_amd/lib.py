@@ -46,6 +46,8 @@ class ConvArgs(C.Structure):
         ("ln_C", c_int), ("ln_eps", c_float),
         ("act", c_int), ("out_cpf", c_int), ("tb", c_int), ("nb", c_int),
         ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int), ("direct", c_int),
+        ("zeros", c_void_p), ("tiles_t", c_int), ("inv_tiles_t", c_float), ("inv_tb", c_float),
+        ("ln_u", c_void_p), ("ln_fold", c_int),
     ]
 
 

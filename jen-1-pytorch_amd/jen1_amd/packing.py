@@ -1,9 +1,12 @@
 """Host-side weight packing into the MFMA fragment order jen1_conv_gemm streams.
 
-Packed layout (DESIGN.md "weights in HBM"):  [tap][m/16][c/32][lane 0..63][8]
+Packed layout (DESIGN.md "weights in HBM"):  [tap][c/32][m/16][lane 0..63][8]
 with lane = g*16 + i, element j  <->  W[tap][m = 16*mt + i][c = 32*kc + 8*g + j].
 One wave-instruction therefore reads one contiguous 1 KiB (bf16) / 2 KiB (f32)
-block, and consecutive K chunks of one (tap, m-tile) are consecutive in memory.
+block.  The M tile is the fastest block index on purpose: the workgroups of a launch own
+different M tiles and walk K in lockstep, so at any instant their loads form one contiguous
+span that spreads over all HBM channels (with M-tile-major blocks they sat 32 KiB apart and
+camped on a few channels).
 
 All functions take the reference's parameter tensors (reference ``state_dict``
 layouts) and return device tensors in the compute dtype.
@@ -18,7 +21,7 @@ def _ceil_to(x: int, m: int) -> int:
 
 
 def pack_gemm_weight(w_tmk: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """w_tmk: [taps][M][K] float32 (already in GEMM form) -> packed [taps][M/16][Kp/32][64][8].
+    """w_tmk: [taps][M][K] float32 (already in GEMM form) -> packed [taps][Kp/32][M/16][64][8].
     M must be a multiple of 16; K is zero-padded to a multiple of 32."""
     taps, M, K = w_tmk.shape
     assert M % 16 == 0, M
@@ -26,8 +29,8 @@ def pack_gemm_weight(w_tmk: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if Kp != K:
         w_tmk = torch.nn.functional.pad(w_tmk, (0, Kp - K))
     w = w_tmk.reshape(taps, M // 16, 16, Kp // 32, 4, 8)          # [tap, mt, i, kc, g, j]
-    w = w.permute(0, 1, 3, 4, 2, 5).contiguous()                   # [tap, mt, kc, g, i, j]
-    return w.reshape(taps, M // 16, Kp // 32, 64, 8).to(dtype).contiguous()
+    w = w.permute(0, 3, 1, 4, 2, 5).contiguous()                   # [tap, kc, mt, g, i, j]
+    return w.reshape(taps, Kp // 32, M // 16, 64, 8).to(dtype).contiguous()
 
 
 def conv_weight_to_gemm(w: torch.Tensor) -> torch.Tensor:

@@ -225,7 +225,11 @@ def test_layernorm_prologue_gelu_rowscale(ctx):
     mask = (torch.rand(B * Ln, device="cuda") > 0.3).float()
     ref = F.gelu(F.linear(F.layer_norm(x, (Ci,), gam, bet), w, bias)) * mask.view(B, Ln, 1)
     from jen1_amd.packing import pack_gemm_weight
-    for folded, force in ((False, None), (True, None), (False, {"cfg": 0}), (True, {"cfg": 2, "direct": False})):
+    from jen1_amd.packing import fold_layernorm as _fold
+    wf_, _ = _fold(w, gam, bet)
+    u_fold = wf_.to(kc.tdtype).float().sum(1).contiguous()
+    for folded, force in ((False, None), (True, None), (False, {"cfg": 0}), (True, {"cfg": 2, "direct": False}),
+                          (True, {"cfg": 2, "epi": True}), (True, {"cfg": 4, "epi": True})):
         ob = OpBuilder(kc)
         out = new_out(kc, B, Ln, Co)
         src = to_cl(x.permute(0, 2, 1).contiguous(), kc)
@@ -233,7 +237,8 @@ def test_layernorm_prologue_gelu_rowscale(ctx):
             from jen1_amd.packing import fold_layernorm
             wf, bf = fold_layernorm(w, gam, bet)
             ob.conv(ob.ops, src0=src, w=pack_gemm_weight(wf[None], kc.tdtype), bias=(bf + bias).contiguous(), out=out,
-                    pro=L.PRO_LN, ln=(Ci, None, None), act=L.ACT_GELU, row_scale=mask, force=force)
+                    pro=L.PRO_LN, ln=(Ci, None, None, u_fold) if (force or {}).get("epi") else (Ci, None, None),
+                    act=L.ACT_GELU, row_scale=mask, force=force)
         else:
             ob.conv(ob.ops, src0=src, w=pack_gemm_weight(w[None], kc.tdtype), bias=bias, out=out, pro=L.PRO_LN,
                     ln=(Ci, gam, bet), act=L.ACT_GELU, row_scale=mask, force=force)
