@@ -116,6 +116,8 @@ typedef struct jen1_conv_args {
   const void* zeros;         /* direct mode: >= (c0+c1) zero elements; padding rows read from here */
   int32_t tiles_t;           /* derived by jen1_conv_gemm (callers leave 0) */
   float inv_tiles_t, inv_tb; /* derived by jen1_conv_gemm */
+  const int32_t* film_step;  /* optional device scalar: when non-NULL every batch element uses FiLM row
+                                film_step[0] (per-step tables of a sampler; overrides film_row) */
   const float* ln_u;         /* ln_fold: [M] row sums of the (gamma-folded, dtype-rounded) weights */
   int32_t ln_fold;           /* 1: LayerNorm applied in the epilogue instead of a prologue:
                                 y = rstd_n * (acc - mean_n * ln_u[m]) + bias   (taps = 1 only; the row
@@ -149,6 +151,7 @@ typedef struct jen1_norm_args {
   int32_t groups, cpg, count;
   float eps, src1_scale;
   int32_t film_off, film_C, film_ld;
+  const int32_t* film_step;  /* see jen1_conv_args.film_step */
 } jen1_norm_args;
 
 int jen1_norm_apply(const jen1_norm_args* args, void* stream);
@@ -163,10 +166,11 @@ int jen1_norm_apply(const jen1_norm_args* args, void* stream);
  * kv_extra / extra_row: when extra_row[b] >= 0 the LAST key/value row (index Nk-1) of batch
  * element b is read from kv_extra[extra_row[b]][kx_off / vx_off + h*d ...] instead: the text
  * tokens' K/V are step-invariant and cached, only the appended time token (model.py:315-316)
- * is projected per step.
+ * is projected per step.  extra_step (optional device scalar): rows with extra_row[b] >= 0 read row
+ * extra_step[0] of kv_extra instead (per-step table of a sampler).
  */
 int jen1_attention(const void* q, const void* k, const void* v, void* out, const int32_t* kv_row,
-                   const void* kv_extra, const int32_t* extra_row, int ld_extra, int kx_off, int vx_off,
+                   const void* kv_extra, const int32_t* extra_row, const int32_t* extra_step, int ld_extra, int kx_off, int vx_off,
                    int B, int H, int d, int Nq, int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off,
                    int ldo, int causal, float scale, int dtype, void* stream);
 
@@ -208,8 +212,13 @@ int jen1_linear_f32(const float* x, const float* w, const float* bias, float* y,
  * With nrep = 1 the CFG part is skipped (embedding_scale == 1).
  */
 int jen1_cfg_ddim_step(const void* net, const float* x, const float* noise, const float* coef, float* x_out,
-                       float* eps_out, float* x0_out, int B, int C, int T, int ld, int nrep, float embedding_scale,
-                       int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype, void* stream);
+                       float* eps_out, float* x0_out, const int32_t* step_idx, int B, int C, int T, int ld, int nrep,
+                       float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype,
+                       void* stream);
+/* step_idx (optional device scalar s): coef and noise are tables, row s is used (coef + 8 s, noise + s B C T).
+ * jen1_step_advance increments the scalar; it is the last node of a captured sampler step, so replaying the
+ * graph S times walks the schedule with no host-side update in between. */
+int jen1_step_advance(int32_t* step_idx, void* stream);
 
 /* CFG combine + rescale only: writes the guided denoiser output [B][C][T] float32 (model.py:362-369). */
 int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale, int scale_cfg,

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
                                                          const T* __restrict__ v, T* __restrict__ out,
                                                          const int32_t* __restrict__ kv_row,
                                                          const T* __restrict__ kv_extra,
-                                                         const int32_t* __restrict__ extra_row, int ld_extra,
+                                                         const int32_t* __restrict__ extra_row,
+                                                         const int32_t* __restrict__ extra_step, int ld_extra,
                                                          int kx_off, int vx_off, int H, int d, int Nq,
                                                          int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off,
                                                          int ldo, int causal, float scale) {
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 
   const size_t kvbase = (size_t)(kv_row ? kv_row[b] : b) * Nk;
   // optional per-step last key row (the time token of the text context, model.py:315-316)
-  const int xr = (kv_extra && extra_row) ? extra_row[b] : -1;
+  int xr = (kv_extra && extra_row) ? extra_row[b] : -1;
+  if (xr >= 0 && extra_step) xr = extra_step[0];
   const int vpr = d >> 3;                        // 8-element vectors per row
   const int nkv = Nk * vpr, nqv = nq * vpr;
 
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 }  // namespace
 
 extern "C" int jen1_attention(const void* q, const void* k, const void* v, void* out, const int32_t* kv_row,
-                              const void* kv_extra, const int32_t* extra_row, int ld_extra, int kx_off, int vx_off, int B,
+                              const void* kv_extra, const int32_t* extra_row, const int32_t* extra_step, int ld_extra,
+                              int kx_off, int vx_off, int B,
                               int H, int d, int Nq, int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off,
                               int ldo, int causal, float scale, int dtype, void* stream) {
   JEN1_CHECK(q && k && v && out, "attention: null pointer");
@@ -190,13 +193,13 @@ extern "C" int jen1_attention(const void* q, const void* k, const void* v, void*
     static bool set = false;
     if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out,
-                       kv_row, (const float*)kv_extra, extra_row, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale);
+                       kv_row, (const float*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale);
   } else {
     auto kern = attention_kernel<bf16_t>;
     static bool set = false;
     if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (bf16_t*)out, kv_row, (const bf16_t*)kv_extra, extra_row, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale);
+                       (bf16_t*)out, kv_row, (const bf16_t*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale);
   }
   JEN1_HIP(hipGetLastError());
   return 0;

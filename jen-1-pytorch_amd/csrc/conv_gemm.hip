@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
         const int bl = i / sch, cl = i - bl * sch;
         float gv = gsrc[cst + cl], bv = bsrc[cst + cl];
         if (gn && a.film && b0 + bl < a.B) {
-          const int fr = a.film_row ? a.film_row[b0 + bl] : b0 + bl;
+          const int fr = a.film_step ? a.film_step[0] : (a.film_row ? a.film_row[b0 + bl] : b0 + bl);
           const float* fp = a.film + (size_t)fr * a.film_ld + a.film_off + cst + cl;
           const float fs = fp[0] + 1.0f;
           gv *= fs;

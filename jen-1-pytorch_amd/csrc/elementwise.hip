@@ -196,9 +196,15 @@ template <typename T, bool DDIM>
 __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net, const float* __restrict__ x,
                                                         const float* __restrict__ noise, const float* __restrict__ coef,
                                                         float* __restrict__ x_out, float* __restrict__ eps_out,
-                                                        float* __restrict__ x0_out, int B, int C, int Tn, int ld, int nrep,
+                                                        float* __restrict__ x0_out, const int32_t* __restrict__ step_idx,
+                                                        int B, int C, int Tn, int ld, int nrep,
                                                         float scale, int scale_cfg, float phi, int objective, int clip_x0) {
   extern __shared__ float tile[];   // [C][33]
+  if (DDIM && step_idx) {            // per-step rows of the coefficient / noise tables
+    const int st = step_idx[0];
+    coef += (size_t)st * 8;
+    if (noise) noise += (size_t)st * B * C * Tn;
+  }
   const int t0 = blockIdx.x * 32, b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int RPW = 8;            // rows (time steps) per wave
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const jen1_norm_args a)
       bet[j] = a.beta ? a.beta[c + j] : 0.0f;
     }
     if (gn && a.film) {
-      const int fr = a.film_row ? a.film_row[b] : b;
+      const int fr = a.film_step ? a.film_step[0] : (a.film_row ? a.film_row[b] : b);
       const float* fp = a.film + (size_t)fr * a.film_ld + a.film_off + c;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -485,7 +491,7 @@ extern "C" int jen1_linear_f32(const float* x, const float* w, const float* bias
 
 template <bool DDIM>
 static int launch_cfg(const void* net, const float* x, const float* noise, const float* coef, float* x_out, float* eps_out,
-                      float* x0_out, int B, int C, int T, int ld, int nrep, float scale, int scale_cfg, float phi,
+                      float* x0_out, const int32_t* step_idx, int B, int C, int T, int ld, int nrep, float scale, int scale_cfg, float phi,
                       int objective, int clip_x0, int dtype, void* stream) {
   JEN1_CHECK(net && x_out, "cfg step: null pointer");
   JEN1_CHECK(nrep == 1 || nrep == 2, "cfg step: nrep must be 1 or 2");
@@ -497,12 +503,12 @@ static int launch_cfg(const void* net, const float* x, const float* noise, const
     auto kern = cfg_step_kernel<float, DDIM>;
     static bool set = false;
     if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
   } else if (dtype == JEN1_BF16) {
     auto kern = cfg_step_kernel<bf16_t, DDIM>;
     static bool set = false;
     if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
   } else {
     return jen1_set_error("cfg step: bad dtype");
   }
@@ -510,19 +516,28 @@ static int launch_cfg(const void* net, const float* x, const float* noise, const
   return 0;
 }
 
+__global__ void step_advance_kernel(int32_t* step_idx) { step_idx[0] += 1; }
+
+extern "C" int jen1_step_advance(int32_t* step_idx, void* stream) {
+  JEN1_CHECK(step_idx, "step_advance: null pointer");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), step_idx);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int jen1_cfg_ddim_step(const void* net, const float* x, const float* noise, const float* coef, float* x_out,
-                                  float* eps_out, float* x0_out, int B, int C, int T, int ld, int nrep,
-                                  float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0,
-                                  int dtype, void* stream) {
+                                  float* eps_out, float* x0_out, const int32_t* step_idx, int B, int C, int T, int ld,
+                                  int nrep, float embedding_scale, int scale_cfg, float scale_phi, int objective,
+                                  int clip_x0, int dtype, void* stream) {
   JEN1_CHECK(x && coef, "cfg_ddim_step: null x/coef");
   JEN1_CHECK(objective >= 0 && objective <= 2, "cfg_ddim_step: bad objective");
-  return launch_cfg<true>(net, x, noise, coef, x_out, eps_out, x0_out, B, C, T, ld, nrep, embedding_scale, scale_cfg,
+  return launch_cfg<true>(net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, embedding_scale, scale_cfg,
                           scale_phi, objective, clip_x0, dtype, stream);
 }
 
 extern "C" int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale,
                                 int scale_cfg, float scale_phi, int dtype, void* stream) {
-  return launch_cfg<false>(net, nullptr, nullptr, nullptr, out, nullptr, nullptr, B, C, T, ld, 2, embedding_scale,
+  return launch_cfg<false>(net, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, B, C, T, ld, 2, embedding_scale,
                            scale_cfg, scale_phi, 0, 0, dtype, stream);
 }
 

@@ -273,14 +273,16 @@ class GaussianDiffusion(torch.nn.Module):
 
 class DDIMStepper:
     """One fused denoiser step = denoiser plan + ``jen1_cfg_ddim_step`` (CFG combine, std rescale,
-    x0/eps prediction, DDIM update), captured once as a hipGraph and replayed per step.  Per step only
-    three small device-side updates happen outside the graph: the timestep vector, the coefficient
-    row and the noise buffer (gdm.py:203, :212-218).
+    x0/eps prediction, DDIM update) + ``jen1_step_advance``, captured once as a hipGraph.
 
-    Concurrency: every kernel of the denoiser is latency-bound and occupies a fraction of the 256
-    CUs, and the samples of a batch are independent, so the batch is split into ``n_streams``
-    sub-batches whose plans run on parallel HIP streams inside the one captured graph (fork/join).
-    Weights are streamed once per sub-batch; HBM has the headroom."""
+    Everything that depends only on the schedule is hoisted out of the loop (exact): the time MLP,
+    the FiLM GEMM of all 56 ResBlocks and the time-token K/V GEMM are evaluated once for all S
+    timesteps (``Plan.run_time`` in table mode), the DDIM coefficients and the per-step noise are
+    tables, and every kernel indexes them through a device-side step counter -- so sampling is S
+    replays of one graph with no host-side update in between (gdm.py:202-222).
+
+    ``n_streams`` > 1 splits the batch into sub-batches on parallel HIP streams (implemented and
+    parity-tested; ROCm 7.2 serialises them, so the default is 1)."""
 
     def __init__(self, gd: GaussianDiffusion, model: UNetCFG1d, shape, conditioning, causal=False, use_graph=True,
                  n_streams: Optional[int] = None):
@@ -298,40 +300,50 @@ class DDIMStepper:
         n_streams = max(1, min(n_streams, B))
         sizes = [B // n_streams + (1 if i < B % n_streams else 0) for i in range(n_streams)]
         self.coef, self.times = gd.ddim_coeff_table()
-        self.num_steps = int(self.times.numel())
-        self.coef_cur = torch.zeros((8,), dtype=torch.float32, device=dev)
-        self.noise_buf = torch.zeros(shape, dtype=torch.float32, device=dev)
+        S = self.num_steps = int(self.times.numel())
+        self.coef = self.coef.contiguous()
+        # per-step noise table [S][B][C][T] (614 MB at B=8, T=1500: nothing against 288 GB of HBM)
+        self.noise_all = torch.zeros((S,) + tuple(shape), dtype=torch.float32, device=dev)
+        self._noise_fresh = False
         self._cond = conditioning                     # keep the conditioning tensors alive
         Co = model.spec.out_channels
         lib = self.lib
         self.parts = []
         b0 = 0
         used = {}
+        s0 = torch.cuda.current_stream(dev).cuda_stream
         for i, nb in enumerate(sizes):
             slot = used.get(nb, 0)
             used[nb] = slot + 1
-            plan = eng.plan(nb, T, self.nrep, bool(causal), slot=slot)
+            plan = eng.plan(nb, T, self.nrep, bool(causal), slot=slot, n_t=S)
             sl = slice(b0, b0 + nb)
             emb = conditioning["cross_attn_cond"][sl]
             msk = None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"][sl]
             cc = conditioning["input_concat_cond"]
-            zt = torch.zeros((nb,), dtype=torch.int64, device=dev)
-            model._prepare(plan, plan.x_in, zt, emb, msk, [None if cc is None else cc[sl]], None)
+            model._prepare(plan, plan.x_in, None, emb, msk, [None if cc is None else cc[sl]], None)
             plan._cond_refs = (emb, msk)              # the K/V cache key holds weakrefs: keep the slices alive
+            plan.t_in.copy_(self.times)
+            plan.run_time(s0)                         # FiLM / time-token K/V tables for all S timesteps
             net = plan.net_out
-            noise_ptr = self.noise_buf[sl].data_ptr()
-            args = (net.t.data_ptr(), plan.x_in.data_ptr(), noise_ptr, self.coef_cur.data_ptr(),
-                    plan.x_in.data_ptr(), None, None, nb, Co, T, net.ld, self.nrep, float(gd.embedding_scale),
-                    1 if (cfg and gd.scale_cfg) else 0, 0.7, _OBJ[gd.objective], 1, eng.dt)
+            # noise table slice of this sub-batch: row stride is the full batch, so give each part its own
+            # contiguous table when the batch is split
+            ntab = self.noise_all if len(sizes) == 1 else torch.zeros((S, nb, C, T), dtype=torch.float32, device=dev)
+            args = (net.t.data_ptr(), plan.x_in.data_ptr(), ntab.data_ptr(), self.coef.data_ptr(),
+                    plan.x_in.data_ptr(), None, None, plan.step_idx.data_ptr(), nb, Co, T, net.ld, self.nrep,
+                    float(gd.embedding_scale), 1 if (cfg and gd.scale_cfg) else 0, 0.7, _OBJ[gd.objective], 1, eng.dt)
+            sp = plan.step_idx.data_ptr()
 
-            def run(s, plan=plan, args=args):
+            def run(s, plan=plan, args=args, sp=sp):
                 plan.run(s)
                 L.check(lib.jen1_cfg_ddim_step(*args, s), "jen1_cfg_ddim_step")
+                L.check(lib.jen1_step_advance(sp, s), "jen1_step_advance")
 
-            self.parts.append((sl, plan, run))
+            self.parts.append((sl, plan, run, ntab))
             b0 += nb
         self.plan = self.parts[0][1]                  # (first sub-plan; used by the bench's per-launch roofline)
         self.streams = [torch.cuda.Stream(dev) for _ in self.parts] if len(self.parts) > 1 else []
+        self._next = 0
+        self._set_step(0)                             # the cached plan may carry a previous run's counter
         self.graph = None
         self.graphs = None
         if use_graph:
@@ -343,11 +355,8 @@ class DDIMStepper:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             if self.streams and os.environ.get("JEN1_GRAPH_PER_STREAM", "1") == "1":
-                # one graph per sub-batch, each replayed on its own stream: ROCm's hipGraph runs the
-                # branches of a single graph one after the other, separate graphs on separate streams
-                # can overlap on the hardware queues
                 self.graphs = []
-                for _, _, run in self.parts:
+                for _, _, run, _ in self.parts:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         run(torch.cuda.current_stream(dev).cuda_stream)
@@ -357,7 +366,7 @@ class DDIMStepper:
                 with torch.cuda.graph(g):
                     self._run_all()
                 self.graph = g
-            self.reset(saved)                         # the warm-up advanced x once: restore
+            self.reset(saved)                         # the warm-up advanced x and the step counter: restore
 
     def _run_all(self):
         """enqueue every sub-batch; with several parts they fork onto side streams and join back."""
@@ -366,7 +375,7 @@ class DDIMStepper:
         if not self.streams:
             self.parts[0][2](cur.cuda_stream)
             return
-        for st, (_, _, run) in zip(self.streams, self.parts):
+        for st, (_, _, run, _) in zip(self.streams, self.parts):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 run(st.cuda_stream)
@@ -378,24 +387,42 @@ class DDIMStepper:
         """current latents [B, C, T] (the sub-batches live in their plans' input buffers)."""
         if len(self.parts) == 1:
             return self.parts[0][1].x_in
-        return torch.cat([p.x_in for _, p, _ in self.parts], dim=0)
+        return torch.cat([p.x_in for _, p, _, _ in self.parts], dim=0)
 
-    def reset(self, x0: torch.Tensor):
+    def _set_step(self, i: int):
+        for _, plan, _, _ in self.parts:
+            plan.step_idx.fill_(i)
+        self._next = i
+
+    def reset(self, x0: torch.Tensor, fresh_noise: bool = True):
+        """start a trajectory at x0; unless noises are injected per step, draw the whole per-step noise
+        table now (gdm.py:218 draws randn_like inside the loop: same distribution, one launch)."""
         x0 = x0.to(torch.float32)
-        for sl, plan, _ in self.parts:
+        for sl, plan, _, _ in self.parts:
             plan.x_in.copy_(x0[sl])
+        if fresh_noise:
+            self.noise_all.normal_()
+            self._push_noise(None)
+        self._set_step(0)
+
+    def _push_noise(self, i):
+        if len(self.parts) == 1:
+            return
+        for sl, _, _, ntab in self.parts:
+            if i is None:
+                ntab.copy_(self.noise_all[:, sl])
+            else:
+                ntab[i].copy_(self.noise_all[i, sl])
 
     def step(self, i: int, noise: Optional[torch.Tensor] = None, drop_rows=None, set_rows=False):
-        for sl, plan, _ in self.parts:
-            plan.t_in.copy_(self.times[i].expand(plan.B))
-            if set_rows:
+        if i != self._next:
+            self._set_step(i)
+        if set_rows:
+            for sl, plan, _, _ in self.parts:
                 plan.set_rows(None if drop_rows is None else torch.as_tensor(drop_rows)[sl])
-        self.coef_cur.copy_(self.coef[i])
-        if i < self.num_steps - 1:
-            if noise is not None:
-                self.noise_buf.copy_(noise.to(self.noise_buf.device, torch.float32))
-            else:
-                self.noise_buf.normal_()
+        if noise is not None and i < self.num_steps - 1:
+            self.noise_all[i].copy_(noise.to(self.noise_all.device, torch.float32))
+            self._push_noise(i)
         if self.graphs is not None:
             cur = torch.cuda.current_stream(self.gd.device)
             for st, g in zip(self.streams, self.graphs):
@@ -408,3 +435,4 @@ class DDIMStepper:
             self.graph.replay()
         else:
             self._run_all()
+        self._next = i + 1

@@ -263,9 +263,10 @@ class OpBuilder:
             if src1 is not None:
                 a.gn_stats1 = src1.gn.data_ptr()
             if film is not None:
-                ftab, frow, foff, fC = film
+                ftab, frow, foff, fC = film[:4]
                 a.film, a.film_row = ftab.data_ptr(), _ptr(frow)
                 a.film_off, a.film_C, a.film_ld = foff, fC, ftab.shape[-1]
+                a.film_step = _ptr(film[4]) if len(film) > 4 else None
         ln_u = None
         if pro == L.PRO_LN:
             lnC, g_, b_ = ln[:3]
@@ -306,7 +307,7 @@ class OpBuilder:
                 na.gn_stats0, na.gn_stats1 = a.gn_stats0, a.gn_stats1
                 na.gamma, na.beta = a.gn_gamma, a.gn_beta
                 na.groups, na.cpg, na.count, na.eps = a.gn_groups, a.gn_cpg, a.gn_count, a.gn_eps
-                na.film, na.film_row = a.film, a.film_row
+                na.film, na.film_row, na.film_step = a.film, a.film_row, a.film_step
                 na.film_off, na.film_C, na.film_ld = a.film_off, a.film_C, a.film_ld
             nref = C.byref(na)
             nfn = lambda s, nref=nref, lib=lib: L.check(lib.jen1_norm_apply(nref, s), "jen1_norm_apply")
@@ -409,13 +410,13 @@ class OpBuilder:
             self._max_tiles = max(self._max_tiles, wgs)
 
     def attention(self, ops, *, q: Act, q_off, kv_t: torch.Tensor, ldkv, k_off, v_off, out: Act, H, d, Nk, causal,
-                  kv_row=None, kv_extra=None, extra_row=None, ld_extra=0, kx_off=0, vx_off=0):
+                  kv_row=None, kv_extra=None, extra_row=None, ld_extra=0, kx_off=0, vx_off=0, extra_step=None):
         eng = self.eng
         args = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
-                _ptr(extra_row), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
+                _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
                 1 if causal else 0, float(d) ** -0.5, eng.dt)
         lib = eng.lib
-        self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row))
+        self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row, extra_step))
         fn = lambda s, args=args, lib=lib: L.check(lib.jen1_attention(*args, s), "jen1_attention")
         fn.label = f"attention B={q.B} H={H} d={d} Nq={q.L} Nk={Nk} causal={causal}"
         ops.append(fn)
@@ -425,10 +426,17 @@ class OpBuilder:
 class Plan(OpBuilder):
     """Pre-allocated buffers + prepared launches for one (B, T, nrep, causal) shape."""
 
-    def __init__(self, eng: "Engine", B: int, T: int, nrep: int, causal: bool):
+    def __init__(self, eng: "Engine", B: int, T: int, nrep: int, causal: bool, n_t: Optional[int] = None):
+        """n_t = None: one timestep per batch element (the general forward).  n_t = S: *table mode* of a
+        sampler -- the timestep-only work (time MLP, FiLM GEMM, time-token K/V GEMM) is evaluated once for
+        all S schedule entries (``run_time``) and every kernel of the step indexes the tables through the
+        device-side counter ``step_idx``, so a captured step replays with no host-side update."""
         super().__init__(eng)
         self.B, self.T, self.nrep, self.causal = B, T, nrep, causal
         self.Beff = B * nrep
+        self.table_mode = n_t is not None
+        self.n_t = n_t if n_t is not None else B
+        self.time_ops: List[Callable[[int], None]] = []
         self.ctx_ops: List[Callable[[int], None]] = []
         self.taps: Dict[str, Act] = {}
         self.n_launch = 0
@@ -469,7 +477,7 @@ class Plan(OpBuilder):
         y = self.new_act(src0.B, src0.L, r.c_out, gn=gn)
         self.conv(ops, src0=h, w=W.w[f"{n}.conv2"], bias=W.v[f"{n}.conv2.bias"], out=y, taps=3, pad_left=pad,
                   pro=L.PRO_GN_SILU, gn=(r.groups, r.c_out, W.v[f"{n}.gn2.g"], W.v[f"{n}.gn2.b"], 1e-5),
-                  film=(self.film, self.film_row, W.film_off[n], r.c_out), residual=res)
+                  film=(self.film, self.film_row, W.film_off[n], r.c_out, self.step_idx if self.table_mode else None), residual=res)
         return y
 
     def transformer(self, t: TransformerSpec, x: Act, causal: bool) -> Act:
@@ -498,7 +506,8 @@ class Plan(OpBuilder):
                        causal=False, kv_row=self.kv_row,
                        kv_extra=self.kvx.t if eng.spec.use_xattn_time else None,
                        extra_row=self.extra_row if eng.spec.use_xattn_time else None, ld_extra=W.kvx_ld,
-                       kx_off=W.kvx_off[n], vx_off=W.kvx_off[n] + mid)
+                       kx_off=W.kvx_off[n], vx_off=W.kvx_off[n] + mid,
+                       extra_step=self.step_idx if (self.table_mode and eng.spec.use_xattn_time) else None)
         x3 = self.new_act(Bf, Lx, Cc)
         self.conv(ops, src0=a2, w=W.w[f"{n}.o2"], bias=W.v[f"{n}.o2.bias"], out=x3, residual=x2)
         f1 = self.new_act(Bf, Lx, Cc * t.multiplier)
@@ -526,7 +535,9 @@ class Plan(OpBuilder):
         Cx, Cc = spec.in_channels, spec.ctx_ch0
         self.x_in = torch.zeros((B, Cx, T), dtype=f32, device=dev)
         self.ctx_in = torch.zeros((B, max(Cc, 1), T), dtype=f32, device=dev)
-        self.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        NT_ = self.n_t
+        self.t_in = torch.zeros((NT_,), dtype=torch.int64, device=dev)
+        self.step_idx = torch.zeros((1,), dtype=torch.int32, device=dev)
         F, NL = spec.ctx_features, spec.ctx_max_length
         self.emb_in = torch.zeros((B, NL, F), dtype=f32, device=dev)
         self.mask_in = torch.ones((B, spec.ctx_len), dtype=f32, device=dev)
@@ -547,24 +558,26 @@ class Plan(OpBuilder):
         ops.append(lambda s, a=a: L.check(lib.jen1_pack_input(*a, s), "jen1_pack_input"))
 
         # ---- 2. time -> mapping -> FiLM scale/shift of all ResBlocks (model.py:204-223) -------------
+        # (timestep-only work: ``time_ops``; one row per batch element, or per schedule entry in table mode)
+        tops = self.time_ops
         mf, half = spec.mapping_features, spec.channels // 2
-        tf = torch.empty((B, mf), dtype=f32, device=dev)
-        m1 = torch.empty((B, mf), dtype=f32, device=dev)
-        self.mapping = torch.empty((B, mf), dtype=f32, device=dev)
+        tf = torch.empty((NT_, mf), dtype=f32, device=dev)
+        m1 = torch.empty((NT_, mf), dtype=f32, device=dev)
+        self.mapping = torch.empty((NT_, mf), dtype=f32, device=dev)
         self._keep += [tf, m1]          # referenced by raw pointer below
         v = W.v
         a = (self.t_in.data_ptr(), v["to_time.0.0.weights"].data_ptr(), v["to_time.0.1.weight"].data_ptr(),
-             v["to_time.0.1.bias"].data_ptr(), tf.data_ptr(), B, half, mf)
-        ops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
-        a = (tf.data_ptr(), v["to_mapping.0.weight"].data_ptr(), v["to_mapping.0.bias"].data_ptr(), m1.data_ptr(), B, mf, mf, L.ACT_GELU)
-        ops.append(lambda s, a=a: L.check(lib.jen1_linear_f32(*a, s), "jen1_linear_f32"))
-        a = (m1.data_ptr(), v["to_mapping.2.weight"].data_ptr(), v["to_mapping.2.bias"].data_ptr(), self.mapping.data_ptr(), B, mf, mf, L.ACT_GELU)
-        ops.append(lambda s, a=a: L.check(lib.jen1_linear_f32(*a, s), "jen1_linear_f32"))
-        map_t = Act(self._empty((1, B, mf)), 1, B, mf, mf)
-        self._add_cast(ops, self.mapping, map_t.t)
-        self.film = torch.empty((B, W.film_ld), dtype=f32, device=dev)
-        film_act = Act(self.film.view(1, B, W.film_ld), 1, B, W.film_ld, W.film_ld)
-        self.conv(ops, src0=map_t, w=W.w["film"], bias=W.v["film.bias"], out=film_act, pro=L.PRO_SILU, y_f32=True)
+             v["to_time.0.1.bias"].data_ptr(), tf.data_ptr(), NT_, half, mf)
+        tops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
+        a = (tf.data_ptr(), v["to_mapping.0.weight"].data_ptr(), v["to_mapping.0.bias"].data_ptr(), m1.data_ptr(), NT_, mf, mf, L.ACT_GELU)
+        tops.append(lambda s, a=a: L.check(lib.jen1_linear_f32(*a, s), "jen1_linear_f32"))
+        a = (m1.data_ptr(), v["to_mapping.2.weight"].data_ptr(), v["to_mapping.2.bias"].data_ptr(), self.mapping.data_ptr(), NT_, mf, mf, L.ACT_GELU)
+        tops.append(lambda s, a=a: L.check(lib.jen1_linear_f32(*a, s), "jen1_linear_f32"))
+        map_t = Act(self._empty((1, NT_, mf)), 1, NT_, mf, mf)
+        self._add_cast(tops, self.mapping, map_t.t)
+        self.film = torch.empty((NT_, W.film_ld), dtype=f32, device=dev)
+        film_act = Act(self.film.view(1, NT_, W.film_ld), 1, NT_, W.film_ld, W.film_ld)
+        self.conv(tops, src0=map_t, w=W.w["film"], bias=W.v["film.bias"], out=film_act, pro=L.PRO_SILU, y_f32=True)
 
         # ---- 3. time token of the text context -> its K/V row for every cross-attention ------------
         self.kv_ctx: Dict[str, torch.Tensor] = {}
@@ -574,17 +587,18 @@ class Plan(OpBuilder):
                                                   dtype=eng.tdtype, device=dev)
         self.kvx = None
         if spec.use_xattn_time and n_tr:
-            tok = torch.empty((B, F), dtype=f32, device=dev)
+            tok = torch.empty((NT_, F), dtype=f32, device=dev)
             self._keep.append(tok)
             a = (self.t_in.data_ptr(), v["to_time_embedding.0.0.weights"].data_ptr(), v["to_time_embedding.0.1.weight"].data_ptr(),
-                 v["to_time_embedding.0.1.bias"].data_ptr(), tok.data_ptr(), B, half, F)
-            ops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
-            tok_t = Act(self._empty((1, B, F)), 1, B, F, F, rs=self._stats(B * 2))
-            self._add_cast(ops, tok, tok_t.t)
-            a = (tok_t.t.data_ptr(), tok_t.rs.data_ptr(), B, F, F, eng.dt)
-            ops.append(lambda s, a=a: L.check(lib.jen1_row_stats(*a, s), "jen1_row_stats"))
-            self.kvx = self.new_act(1, B, W.kvx_ld)
-            self.conv(ops, src0=tok_t, w=W.w["kvx"], bias=W.v["kvx.bias"], out=self.kvx, pro=L.PRO_LN,
+                 v["to_time_embedding.0.1.bias"].data_ptr(), tok.data_ptr(), NT_, half, F)
+            tops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
+            tok_rs = torch.zeros((NT_ * 2,), dtype=f32, device=dev)     # outside the per-step arena
+            tok_t = Act(self._empty((1, NT_, F)), 1, NT_, F, F, rs=tok_rs)
+            self._add_cast(tops, tok, tok_t.t)
+            a = (tok_t.t.data_ptr(), tok_t.rs.data_ptr(), NT_, F, F, eng.dt)
+            tops.append(lambda s, a=a: L.check(lib.jen1_row_stats(*a, s), "jen1_row_stats"))
+            self.kvx = Act(self._empty((1, NT_, W.kvx_ld)), 1, NT_, W.kvx_ld, W.kvx_ld)
+            self.conv(tops, src0=tok_t, w=W.w["kvx"], bias=W.v["kvx.bias"], out=self.kvx, pro=L.PRO_LN,
                       ln=(F, None, None, W.v["kvx.u"]))
 
         # ---- 4. UNet1d.forward (model.py:243-262) ------------------------------------------------
@@ -662,7 +676,21 @@ class Plan(OpBuilder):
 
         # ---- split-K workspace shared by all launches of the plan (stream-ordered reuse) -----------
         self.finalize_workspace()
-        self.n_launch = len(self.ops)
+        self.n_launch = len(self.ops) + (0 if self.table_mode else len(self.time_ops))
+
+    def run_time(self, stream: Optional[int] = None):
+        """timestep-only work (time MLP -> FiLM table, time token -> K/V rows) for every entry of t_in"""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        for op in self.time_ops:
+            op(stream)
+
+    def run(self, stream: Optional[int] = None):
+        if stream is None:
+            stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        if not self.table_mode:
+            self.run_time(stream)       # general forward: the timesteps change with every call
+        super().run(stream)
 
     def _add_cast(self, ops, src: torch.Tensor, dst: torch.Tensor):
         """dtype cast through torch (device plumbing, captured like any other node)."""
@@ -715,9 +743,9 @@ class Engine:
         self.tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
         self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
         self.target_wgs = 256
-        self.splitk_target_wgs = int(os.environ.get("JEN1_SPLITK_WGS", "256"))
+        self.splitk_target_wgs = int(os.environ.get("JEN1_SPLITK_WGS", "128"))
         self.splitk_min_bytes = int(os.environ.get("JEN1_SPLITK_MIN_BYTES", str(2 << 20)))
-        self.plans: Dict[Tuple[int, int, int, bool, int], Plan] = {}
+        self.plans: Dict[tuple, Plan] = {}
         self.load_params(params)
 
     def load_params(self, params: Dict[str, torch.Tensor]):
@@ -754,10 +782,11 @@ class Engine:
         tmp.run(s)
         torch.cuda.synchronize(dev)
 
-    def plan(self, B: int, T: int, nrep: int, causal: bool, slot: int = 0) -> Plan:
+    def plan(self, B: int, T: int, nrep: int, causal: bool, slot: int = 0, n_t: Optional[int] = None) -> Plan:
         """``slot`` distinguishes plans of the same shape that must own separate buffers because
-        they run concurrently on different streams (sub-batches of one sampler step)."""
-        key = (B, T, nrep, bool(causal), slot)
+        they run concurrently on different streams (sub-batches of one sampler step); ``n_t`` selects
+        the sampler's table mode (see Plan)."""
+        key = (B, T, nrep, bool(causal), slot, n_t)
         if key not in self.plans:
-            self.plans[key] = Plan(self, B, T, nrep, bool(causal))
+            self.plans[key] = Plan(self, B, T, nrep, bool(causal), n_t)
         return self.plans[key]

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
         ("act", c_int), ("out_cpf", c_int), ("tb", c_int), ("nb", c_int),
         ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int), ("direct", c_int),
         ("zeros", c_void_p), ("tiles_t", c_int), ("inv_tiles_t", c_float), ("inv_tb", c_float),
-        ("ln_u", c_void_p), ("ln_fold", c_int),
+        ("film_step", c_void_p), ("ln_u", c_void_p), ("ln_fold", c_int),
     ]
 
 
@@ -59,6 +59,7 @@ class NormArgs(C.Structure):
         ("dtype", c_int), ("mode", c_int), ("B", c_int), ("L", c_int), ("c0", c_int), ("c1", c_int),
         ("ld0", c_int), ("ld1", c_int), ("ld_y", c_int), ("groups", c_int), ("cpg", c_int), ("count", c_int),
         ("eps", c_float), ("src1_scale", c_float), ("film_off", c_int), ("film_C", c_int), ("film_ld", c_int),
+        ("film_step", c_void_p),
     ]
 
 
@@ -70,13 +71,14 @@ SYMBOLS = {
     "jen1_norm_apply": (c_int, [C.POINTER(NormArgs), _P]),
     "jen1_cfg_bm": (c_int, [c_int]),
     "jen1_cfg_bn": (c_int, [c_int]),
-    "jen1_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 + [c_float, c_int, _P]),
+    "jen1_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 + [c_float, c_int, _P]),
     "jen1_pack_input": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "jen1_unpack_output": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     "jen1_row_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_time_features": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "jen1_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "jen1_cfg_ddim_step": (c_int, [_P] * 7 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
+    "jen1_cfg_ddim_step": (c_int, [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
+    "jen1_step_advance": (c_int, [_P, _P]),
     "jen1_cfg_combine": (c_int, [_P, _P] + [c_int] * 4 + [c_float, c_int, c_float, c_int, _P]),
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
     "jen1_last_error": (C.c_char_p, []),

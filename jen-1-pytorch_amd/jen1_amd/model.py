@@ -81,7 +81,8 @@ class UNetCFG1d(nn.Module):
 
     def _prepare(self, plan: Plan, x, time, embedding, embedding_mask, channels_list, drop_rows, uncond_only=False):
         plan.x_in.copy_(x.to(torch.float32))
-        plan.t_in.copy_(time.to(torch.int64))
+        if not plan.table_mode:
+            plan.t_in.copy_(time.to(torch.int64))
         if self.spec.ctx_ch0:
             assert channels_list is not None and channels_list[0] is not None, "Missing context"   # model.py:189
             ch = channels_list[0]

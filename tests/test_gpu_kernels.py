@@ -383,9 +383,22 @@ def test_cfg_ddim_step(ctx, objective, last):
     xo, eo, x0o = (torch.zeros(B, Cc, T, device="cuda") for _ in range(3))
     s = torch.cuda.current_stream().cuda_stream
     obj = {"noise": 0, "x0": 1, "v": 2}[objective]
-    L.check(lib.jen1_cfg_ddim_step(net.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), xo.data_ptr(), eo.data_ptr(),
-                                   x0o.data_ptr(), B, Cc, T, Cc, 2, 0.8, 1, 0.7, obj, 1, kc.dt, s))
+    # coefficients / noise as per-step tables indexed by a device-side counter (row 2 holds the real data)
+    coef_tab = torch.zeros(4, 8, device="cuda")
+    coef_tab[2] = coef
+    noise_tab = torch.randn(4, B, Cc, T, device="cuda")
+    noise_tab[2] = noise
+    step = torch.tensor([2], dtype=torch.int32, device="cuda")
+    L.check(lib.jen1_cfg_ddim_step(net.data_ptr(), x.data_ptr(), noise_tab.data_ptr(), coef_tab.data_ptr(), xo.data_ptr(),
+                                   eo.data_ptr(), x0o.data_ptr(), step.data_ptr(), B, Cc, T, Cc, 2, 0.8, 1, 0.7, obj, 1, kc.dt, s))
+    L.check(lib.jen1_step_advance(step.data_ptr(), s))
     torch.cuda.synchronize()
+    assert int(step.item()) == 3
+    xo2 = torch.zeros_like(xo)
+    L.check(lib.jen1_cfg_ddim_step(net.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), xo2.data_ptr(), None,
+                                   None, None, B, Cc, T, Cc, 2, 0.8, 1, 0.7, obj, 1, kc.dt, s))
+    torch.cuda.synchronize()
+    assert torch.equal(xo, xo2), "table-indexed and direct coefficient/noise paths must agree bit for bit"
     nf = net.float().permute(0, 2, 1)
     out, outm = nf[:B], nf[B:]
     oc = outm + (out - outm) * 0.8

@@ -255,4 +255,7 @@ def test_sampler_full_size_properties(full_model_f32):
         assert torch.isfinite(y).all()
         assert float(y.abs().max()) <= 1.0 + 1e-6
         outs.append(y.cpu().numpy())
-    assert rel_err(outs[1], outs[0]) < 1e-4
+    # graph replay vs eager: same kernels, same order.  A single forward repeats to ~4e-7 (float atomics reorder
+    # the GroupNorm/LayerNorm sums); four steps from t=999, where x0 = 157*(...) is clamped, amplify that to
+    # ~1e-4 run to run (eager vs eager shows the same spread), so the check uses the 1e-3 parity gate.
+    assert rel_err(outs[1], outs[0]) < F32_TOL
