@@ -162,6 +162,26 @@ def cpu_baseline(B, T, tiny):
                       f"min {min(times):.3f}s max {max(times):.3f}s"}
 
 
+def init_dist(world, rank, device, backend="nccl"):
+    """one process per GPU; RCCL ("nccl" on ROCm) is used only for the barrier and the max-over-ranks time:
+    sampling shards by sample, there is no data-path collective."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
+    dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
+    return dist
+
+
+def aggregate(dist, dt, steps, world, device):
+    """whole-job throughput: all ranks' steps / the slowest rank's time"""
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, world * steps / dt
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,12 +189,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank,
-                                device_id=torch.device(device))
+    dist = init_dist(world, rank, device)
 
     def barrier():
         if dist is not None:
@@ -187,11 +202,7 @@ def main():
     model = UNetCFG1d(**cfg, compute_dtype=args.dtype, device=device)
     st = build_stepper(model, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
     dt = timed_steps(st, args.steps, args.warmup, barrier)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    value = world * args.steps / dt
+    dt, value = aggregate(dist, dt, args.steps, world, device)
 
     out = {
         "metric": "denoiser steps/sec (B=8, 128x1500 latents)", "value": round(value, 2), "unit": "denoiser steps/s",

@@ -1,0 +1,255 @@
+"""CPU-only tests: the C ABI of libjen1_hip.so (exports, struct layout, argument validation -- none of
+which needs a GPU), the host-side logic (packing, schedule tables, generic sampler) and the loud failure
+of the product path when no GPU / no library is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, SEED, golden, rel_err
+from jen1_amd import lib as L
+from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config
+from oracle import jen1_oracle as O
+
+HEADER = os.path.join(ROOT, "include", "jen1_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L.build()
+    return L.load()
+
+
+# ------------------------------------------------------------------ C ABI
+def test_every_declared_symbol_is_exported(lib):
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = set(re.findall(r"\b(jen1_[a-z0-9_]+)\s*\(", src))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_build_info_and_tile_table(lib):
+    assert lib.jen1_abi_version() == 1
+    assert b"gfx950" in lib.jen1_build_info()
+    assert [(lib.jen1_cfg_bm(c), lib.jen1_cfg_bn(c)) for c in range(5)] == [(64, 64), (128, 64), (16, 64), (16, 32), (16, 16)]
+    assert lib.jen1_cfg_bm(99) == -1
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors vs the C compiler's view of include/jen1_hip.h"""
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "jen1_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(jen1_conv_args), offsetof(jen1_conv_args, dtype), offsetof(jen1_conv_args, gn_eps),
+         offsetof(jen1_conv_args, cfg), offsetof(jen1_conv_args, zeros), offsetof(jen1_conv_args, ln_fold), sizeof(jen1_norm_args));
+  return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.dirname(HEADER), src, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    a = L.ConvArgs
+    want = [C.sizeof(a), a.dtype.offset, a.gn_eps.offset, a.cfg.offset, a.zeros.offset, a.ln_fold.offset, C.sizeof(L.NormArgs)]
+    assert got == want
+
+
+def test_argument_validation_reports_errors_without_a_gpu(lib):
+    a = L.ConvArgs()
+    assert lib.jen1_conv_gemm(None, None) != 0 and b"null args" in lib.jen1_last_error()
+    a.x0, a.w, a.y = 16, 16, 16
+    a.dtype, a.c0, a.ld0 = L.F32, 40, 40               # not a multiple of 32
+    assert lib.jen1_conv_gemm(C.byref(a), None) != 0
+    assert b"multiples of 32" in lib.jen1_last_error()
+    a.c0, a.ld0, a.M, a.out_C, a.ps_f = 64, 64, 32, 32, 1
+    a.taps, a.stride, a.B, a.L_in, a.L_out = 3, 1, 2, 10, 10
+    a.ld_y, a.cfg, a.tb, a.nb, a.kc_stage, a.splitk = 32, L.CFG_S16x16, 10, 2, 2, 1     # nb*tb = 20 > BN = 16
+    assert lib.jen1_conv_gemm(C.byref(a), None) != 0
+    assert b"exceeds BN" in lib.jen1_last_error()
+    a.tb, a.nb, a.direct, a.pro_mode = 10, 1, 1, L.PRO_GN_SILU
+    assert lib.jen1_conv_gemm(C.byref(a), None) != 0          # incomplete GroupNorm prologue / direct with prologue
+    assert lib.jen1_attention(None, None, None, None, None, None, None, None, 0, 0, 0, 1, 1, 8, 1, 1, 8, 0, 8, 0, 0, 8, 0,
+                              1.0, L.F32, None) != 0
+    n = L.NormArgs()
+    assert lib.jen1_norm_apply(C.byref(n), None) != 0
+
+
+def test_product_path_fails_loudly_without_gpu_or_library():
+    from jen1_amd.model import UNetCFG1d
+    if not torch.cuda.is_available():
+        m = UNetCFG1d(**tiny_model_config(), device="cpu")
+        with pytest.raises(L.Jen1HipError):
+            m.engine()
+    # a missing shared library is an error, never a fallback
+    code = ("import sys; sys.path.insert(0, %r); from jen1_amd import lib\n"
+            "try:\n    lib.load()\nexcept lib.Jen1HipError as e:\n    print('RAISED', 'no CPU / eager fallback' in str(e))\n") % os.path.join(ROOT, "jen-1-pytorch_amd")
+    env = dict(os.environ, JEN1_LIB="/nonexistent/libjen1_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
+    assert "RAISED True" in out
+    # nothing in the product package imports the oracle
+    pkg = os.path.join(ROOT, "jen-1-pytorch_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dp, f)).read().replace("the oracle", ""), f
+
+
+# ------------------------------------------------------------------ host logic
+def test_level_table_matches_survey_appendix_b():
+    spec = UNetSpec(**full_model_config())
+    assert spec.num_params() == 296_543_106
+    assert spec.level_lengths(1500) == [1500, 1500, 375, 94, 24, 12, 6, 3, 2, 1]
+    assert spec.level_lengths(9000) == [9000, 9000, 2250, 563, 141, 71, 36, 18, 9, 5]
+    assert spec.level_lengths(300)[:5] == [300, 300, 75, 19, 5]
+    assert len(spec.res_blocks()) == 56 and len(spec.transformers()) == 13
+    with pytest.raises(AssertionError):
+        UNetSpec(**dict(tiny_model_config(), bogus_kwarg=1))           # reference model.py:110
+
+
+def test_weight_packing_layout_and_transposed_conv():
+    from jen1_amd.packing import conv_weight_to_gemm, convT_weight_to_gemm, fold_layernorm, pack_gemm_weight
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(2, 48, 70, generator=g)                                 # [taps][M][K], K padded to 96
+    pk = pack_gemm_weight(w, torch.float32)
+    assert pk.shape == (2, 3, 3, 64, 8)
+    for (tap, m, c) in [(0, 0, 0), (1, 17, 33), (1, 47, 69), (0, 31, 64)]:
+        lane = ((c % 32) // 8) * 16 + (m % 16)
+        assert pk[tap, c // 32, m // 16, lane, c % 8] == w[tap, m, c]
+    assert float(pk[:, 2, :, 16:, :].abs().max()) == 0.0                   # K = 70: chunk 2 only has k 64..69 (g = 0)
+    assert float(pack_gemm_weight(torch.ones(1, 16, 33), torch.float32)[0, 1, 0].sum()) == 16.0
+    # ConvTranspose1d(k=2f, s=f) == 2-tap sub-pixel GEMM (reference blocks.py:88-95)
+    for f in (2, 4):
+        ci, co, Ln = 6, 5, 7
+        wt = torch.randn(ci, co, 2 * f, generator=g)
+        x = torch.randn(2, ci, Ln, generator=g)
+        ref = O.conv_transpose1d(x.numpy(), wt.numpy(), None, f, f // 2 + f % 2, f % 2)
+        wg = convT_weight_to_gemm(wt, f).numpy()                              # [2][f*co][ci]
+        p = f // 2 + f % 2
+        xp = np.pad(x.numpy(), ((0, 0), (0, 0), (1, 1)))                      # x[q-1], x[q] with zero ends
+        out = np.zeros_like(ref)
+        for q in range(Ln + 1):
+            y = np.einsum("mc,bc->bm", wg[0], xp[:, :, q]) + np.einsum("mc,bc->bm", wg[1], xp[:, :, q + 1])
+            for r in range(f):
+                t = q * f + r - p
+                if 0 <= t < f * Ln:
+                    out[:, :, t] = y[:, r * co:(r + 1) * co]
+        assert rel_err(out, ref) < 1e-5
+    # LayerNorm folding: Linear(LN(x)) == (W diag(gamma)) xhat + W beta
+    W_, gam, bet = torch.randn(5, 9, generator=g), torch.rand(9, generator=g) + 0.5, torch.randn(9, generator=g)
+    xx = torch.randn(4, 9, generator=g)
+    wf, bf = fold_layernorm(W_, gam, bet)
+    xh = (xx - xx.mean(-1, keepdim=True)) / torch.sqrt(xx.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(xx, (9,), gam, bet), W_)
+    assert torch.allclose(xh @ wf.T + bf, ref, atol=1e-5)
+    assert conv_weight_to_gemm(torch.zeros(3, 4, 5)).shape == (5, 3, 4)
+
+
+def test_diffusion_tables_and_coefficients_match_reference_goldens():
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    g = golden("schedule")
+    for name in ("linear", "cosine"):
+        betas, none = get_beta_schedule(name, 1000)
+        assert none is None
+        np.testing.assert_allclose(betas.numpy().astype(np.float32), g[f"{name}.betas"], rtol=2e-7)
+        gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective="noise", loss_type="l2", device="cpu", sampling_timesteps=100)
+        for attr in ("alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                     "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            np.testing.assert_allclose(getattr(gd, attr).numpy(), g[f"{name}.{attr}"], rtol=1e-6, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        get_beta_schedule("angle", 10)
+    betas, _ = get_beta_schedule("linear", 1000)
+    for S in (10, 100):
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cpu", sampling_timesteps=S)
+        pairs = gd.ddim_time_pairs()
+        assert [p[0] for p in pairs] + [pairs[-1][1]] == list(g[f"ddim_times.{S}"])
+        coef, times = gd.ddim_coeff_table()
+        assert coef.shape == (S, 8) and times.tolist() == [p[0] for p in pairs]
+        np.testing.assert_allclose(coef[:-1, 2:5].numpy(), g[f"ddim_coeffs.{S}"], rtol=2e-6, atol=1e-8)
+        assert coef[-1, 5] == 1.0 and float(coef[:-1, 5].abs().sum()) == 0.0       # only the last step is "x = x0"
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(steps=10, betas=betas[:10], objective="eps", loss_type="l2", device="cpu")
+
+
+@pytest.mark.parametrize("objective", ["noise", "x0", "v"])
+def test_generic_sampler_and_loss_match_oracle_on_cpu(objective):
+    """the literal host restatement of ddim_sample / training_loosses (any callable model) against the numpy oracle"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    betas, _ = get_beta_schedule("linear", 1000)
+    S, shape = 6, (2, 4, 9)
+    rng = np.random.default_rng(3)
+    Wm = rng.standard_normal((4, 4)).astype(np.float32) * 0.3
+
+    def np_model(x, t, **kw):
+        return np.einsum("oc,bct->bot", Wm, x).astype(np.float32) + (t[:, None, None] / 1000.0).astype(np.float32)
+
+    def th_model(x, t, **kw):
+        return torch.einsum("oc,bct->bot", torch.from_numpy(Wm), x) + (t[:, None, None] / 1000.0).float()
+
+    cond = {"cross_attn_cond": None, "cross_attn_masks": None, "global_cond": None, "input_concat_cond": None}
+    init = rng.standard_normal(shape).astype(np.float32)
+    noises = [rng.standard_normal(shape).astype(np.float32) for _ in range(S)]
+    og = O.OracleGaussianDiffusion(steps=1000, betas=O.get_beta_schedule("linear", 1000), objective=objective,
+                                   cfg_dropout_proba=0.0, embedding_scale=1.0, sampling_timesteps=S)
+    ref = og.ddim_sample(lambda x, t, **kw: np_model(x, t), shape, cond, init_noise=init, step_noises=noises)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective=objective, loss_type="l2", device="cpu", cfg_dropout_proba=0.0,
+                           embedding_scale=1.0, sampling_timesteps=S)
+    got = gd.sample(th_model, shape, cond, init_noise=torch.from_numpy(init), step_noises=[torch.from_numpy(n) for n in noises])
+    assert rel_err(got.numpy(), ref) < 1e-4
+    allsteps = gd.sample(th_model, shape, cond, return_all_timesteps=True, init_noise=torch.from_numpy(init),
+                         step_noises=[torch.from_numpy(n) for n in noises])
+    assert allsteps.shape == (2, S + 1, 4, 9)                                  # [B, S+1, C, T] like gdm.py:224
+    x0 = rng.standard_normal(shape).astype(np.float32)
+    t = np.array([3, 700])
+    nz = rng.random(shape).astype(np.float32)
+    want = og.training_losses(lambda x, t, **kw: np_model(x, t), x0, t, cond, nz)
+    have = gd.training_loosses(th_model, torch.from_numpy(x0), torch.from_numpy(t), cond, noise=torch.from_numpy(nz))
+    assert abs(float(have) - float(want)) <= 1e-5 * abs(float(want))
+
+
+def test_init_fill_is_deterministic_and_keyed():
+    from jen1_amd.init_fill import fill
+    a, b = fill("to_in.block.block1.project.conv.weight", (4, 3, 3), SEED), fill("to_in.block.block1.project.conv.weight", (4, 3, 3), SEED)
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    assert not np.array_equal(a, fill("to_in.block.block2.project.conv.weight", (4, 3, 3), SEED))
+    assert abs(float(fill("x.groupnorm.weight", (1000,), SEED).mean()) - 1.0) < 0.05       # norm gammas sit around 1
+
+
+# ------------------------------------------------------------------ multi-process (gloo, world_size 2)
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import bench
+    dist = bench.init_dist(world, rank, "cpu", backend="gloo")
+    dist.barrier()
+    dt, value = bench.aggregate(dist, 0.5 * (rank + 1), steps=10, world=world, device="cpu")
+    dist.barrier()
+    q.put((rank, dt, value))
+    dist.destroy_process_group()
+
+
+def test_bench_rank_aggregation_gloo_world2():
+    """N>1 path of bench.py: barrier + max-over-ranks time, whole-job value = all ranks' steps / slowest rank"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert [r[0] for r in res] == [0, 1]
+    for _, dt, value in res:
+        assert dt == pytest.approx(1.0) and value == pytest.approx(2 * 10 / 1.0)
