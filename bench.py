@@ -122,9 +122,16 @@ def conv_roofline(st, reps=3):
         with open(os.environ["JEN1_BENCH_OPS"], "w") as f:
             for i in range(n):
                 f.write(f"{per_op[i] * 1e3:8.1f} us  w={convs[i].w_bytes / 1e6:7.2f}MB act={convs[i].act_bytes / 1e6:6.2f}MB  {convs[i].label}\n")
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC run of this same command (profiles/, rocprofv3 --pmc)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pm.get("launches_per_step") == n:
+            traffic = pm["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     return {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "kernel": "conv_gemm_kernel<*> (fused GroupNorm/LayerNorm + conv/linear implicit GEMM)",
         "launches_per_step": n, "avg_launch_us": round(conv_ms * 1e3 / n, 2), "conv_ms_per_step": round(conv_ms, 4),
         "alg_bytes_per_step": int(alg), "alg_weight_bytes": int(w_bytes), "alg_act_bytes": int(a_bytes),
