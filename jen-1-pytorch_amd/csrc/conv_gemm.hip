@@ -33,6 +33,15 @@
 //     acquire, last arriver reduces (cdna_hip_programming.md section 5).
 #include "common.h"
 
+// Tuning builds only (-DJEN1_PROFILE): workgroup (0,0,0), thread 0 records the constant-rate 100 MHz
+// s_memrealtime counter at phase boundaries into args.slab (reused as a debug buffer).
+#ifdef JEN1_PROFILE
+#define JEN1_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && a.slab) \
+    reinterpret_cast<unsigned long long*>(a.slab)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define JEN1_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 struct Layout {
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
   const int wm = wave % WM, wk = wave / WM;
   const int li = lane & 15, lg = lane >> 4;
 
+  JEN1_STAMP(0);
   const Layout L = make_layout(a, (int)sizeof(T), RED_FLOATS);
   T* tile = reinterpret_cast<T*>(smem + L.tile_off);
   float* gam_s = reinterpret_cast<float*>(smem + L.gam_off);
@@ -373,6 +383,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     const T* x0p = reinterpret_cast<const T*>(a.x0);
     const T* x1p = reinterpret_cast<const T*>(a.x1);
     const T* zrow = reinterpret_cast<const T*>(a.zeros);
+    JEN1_STAMP(1);
     if (iters > 0) {
       const int mt = mt_base < MT ? mt_base : MT - 1;
       const size_t a_tap_stride = (size_t)MT * kch_total * 512;
@@ -414,6 +425,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
       Frag ra[PF], rb[PF][NF];
 #pragma unroll
       for (int u = 0; u < PF; ++u) issue(ra[u], rb[u]);
+      JEN1_STAMP(2);
       for (int it = 0; it < iters; it += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -421,6 +433,9 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) mma32(acc[0][nf], ra[u], rb[u][nf]);
           }
+#ifdef JEN1_PROFILE
+          if (it == 0 && u == 0) { if (acc[0][0][0] == 12345.f) __builtin_amdgcn_s_sleep(1); JEN1_STAMP(3); }
+#endif
           issue(ra[u], rb[u]);
         }
       }
@@ -430,6 +445,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
       __syncthreads();
     }
   } else {
+  JEN1_STAMP(1);
   // ==== phase 0: issue every independent global load =========================================
   // (a) weight ring of the first stage
   Frag ring[PF][MF];
@@ -520,6 +536,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     for (int i = tid; i < a.nb * 64; i += NT) st_lds[i] = 0.f;
   }
 
+  JEN1_STAMP(2);
   // ==== K loop over LDS stages ===============================================================
   bool first_stage = true;
   for (int ks = kc_begin; ks < kc_end; ks += stage_chunks) {
@@ -553,6 +570,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
       }
     }
     __syncthreads();                   // tables (and st_lds zeroing) visible
+    JEN1_STAMP(3);
     {
       const int nvec = a.nb * seg * (sch >> 3);
       for (int v0 = 0; v0 < nvec; v0 += NT * VB) {
@@ -565,6 +583,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     }
     __syncthreads();
 
+    JEN1_STAMP(4);
     // ---- MFMA loop: this wave's (live tap, chunk) pairs, weights from the prefetch ring -------
     const int iters = ntaps * nmy;
     int c_tap = 0, c_j = 0;
@@ -606,6 +625,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
 
   }   // !DIRECT
 
+  JEN1_STAMP(5);
   // ==== intra-workgroup K reduction (WK > 1): waves wk > 0 hand their partials to wk == 0 =====
   if (WK > 1) {
     if (wk > 0) {
@@ -681,6 +701,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     }
   }
 
+  JEN1_STAMP(6);
   // ==== epilogue (owner waves) =================================================================
   if (owner) {
     T* yT = reinterpret_cast<T*>(a.y);
@@ -771,6 +792,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
       }
     }
   }
+  JEN1_STAMP(7);
   if (a.out_gn_stats) {
     __syncthreads();
     for (int i = tid; i < a.nb * 64; i += NT) {
@@ -779,6 +801,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
       if (b < a.B && v != 0.f) unsafeAtomicAdd(a.out_gn_stats + (size_t)b * 64 + (i & 63), v);
     }
   }
+  JEN1_STAMP(8);
 }
 
 template <int MF, int NF, int WM, int WK>
