@@ -70,6 +70,20 @@ extern "C" {
  * and accumulates the statistics the NEXT norm layer needs (GroupNorm fine-group
  * sums, LayerNorm row sums) in its epilogue.
  */
+/* One K segment of a direct-mode (streaming) GEMM: the K axis of the packed weight is the
+ * concatenation of the segments' 32-channel chunks, segment s contributes
+ *     sum_{c < 32*kch} W_s[m][c] * x[b, q*stride + shift, c]       (zero outside [0, L_in)).
+ * Conv taps (_Conv1d, blocks.py:42-53), the skip concat (blocks.py:732-734) and a ResnetBlock1d
+ * 1x1 shortcut folded into its second conv (blocks.py:219-231) are all expressed this way. */
+#define JEN1_MAX_SEG 16
+typedef struct jen1_conv_seg {
+  const void* x;             /* [B][L_in][ld] in the launch dtype */
+  int32_t ld;                /* row pitch in elements (>= 32*kch, multiple of 8) */
+  int32_t shift;             /* input row = q*stride + shift */
+  int32_t kch;               /* 32-channel chunks */
+  int32_t reserved;
+} jen1_conv_seg;
+
 typedef struct jen1_conv_args {
   const void* x0;            /* [B][L_in][ld0] */
   const void* x1;            /* optional second channel range, [B][L_in][ld1] */
@@ -122,6 +136,9 @@ typedef struct jen1_conv_args {
   int32_t ln_fold;           /* 1: LayerNorm applied in the epilogue instead of a prologue:
                                 y = rstd_n * (acc - mean_n * ln_u[m]) + bias   (taps = 1 only; the row
                                 statistics of the INPUT rows come from ln_rowstats / ln_C / ln_eps) */
+  int32_t nseg;              /* direct mode: > 0 = explicit K segments below (x0/x1/c0/c1/taps/pad_left are
+                                then ignored); 0 = segments derived as (tap, source) pairs */
+  jen1_conv_seg seg[JEN1_MAX_SEG];
 } jen1_conv_args;
 
 int jen1_conv_gemm(const jen1_conv_args* args, void* stream);

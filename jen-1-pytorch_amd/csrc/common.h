@@ -18,6 +18,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 extern thread_local char g_jen1_err[512];
 int jen1_set_error(const char* fmt, ...);
 
+// stream_gemm.hip: launcher of jen1_conv_gemm's direct (weight-streaming) mode
+int jen1_stream_gemm_launch(const jen1_conv_args& a, void* stream);
+
 #define JEN1_CHECK(cond, ...)                  \
   do {                                         \
     if (!(cond)) return jen1_set_error(__VA_ARGS__); \

@@ -139,7 +139,7 @@ __device__ __forceinline__ void float_to_frag(bf16x8& f, const float (&o)[8]) {
 
 constexpr int VB = 4;   // activation vectors (8 channels each) per thread per staging batch
 
-template <typename T, int MF, int NF, int WM, int WK, int PF, bool DIRECT>
+template <typename T, int MF, int NF, int WM, int WK, int PF>
 __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv_args a) {
   typedef typename FragOf<T>::type Frag;
   constexpr int NT = 64 * WM * WK;     // threads per workgroup
@@ -368,83 +368,6 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     }
   };
 
-  if constexpr (DIRECT) {
-    // ---- streaming path (deep levels): no LDS tile, no barrier.  The activation operand was
-    // normalised / activated once by jen1_norm_apply; both operands of every (tap, chunk) step sit in
-    // one register ring.  With ~64 workgroups of 4 waves there is ONE wave per SIMD, so the kernel is
-    // bound by instruction latency, not bandwidth: the loop is kept to a handful of instructions per
-    // slot -- incremental weight pointer, per-tap row pointers, rows that fall into the zero padding
-    // point at a zero row (no select), exactly 1 + NF loads per slot so vmcnt is counted precisely.
-    static_assert(MF == 1, "streaming tiles are 16 rows");
-    const int nch_w = kc_end - kc_begin;
-    int nmy = (nch_w - wk + WK - 1) / WK;
-    nmy = nmy > 0 ? nmy : 0;
-    const int iters = ntaps * nmy;
-    const T* x0p = reinterpret_cast<const T*>(a.x0);
-    const T* x1p = reinterpret_cast<const T*>(a.x1);
-    const T* zrow = reinterpret_cast<const T*>(a.zeros);
-    JEN1_STAMP(1);
-    if (iters > 0) {
-      const int mt = mt_base < MT ? mt_base : MT - 1;
-      const size_t a_tap_stride = (size_t)MT * kch_total * 512;
-      const T* pa_tap0 = wbase + ((size_t)((size_t)tap_lo * kch_total + kc_begin + wk) * MT + mt) * 512 + lane * 8;
-      const size_t a_j_stride = (size_t)WK * MT * 512;
-      const T* rp0[NF];      // row pointers of the current prefetch tap (source 0 / source 1), minus nothing:
-      const T* rp1[NF];      // the chunk column offset is added per slot
-      auto setup_tap = [&](int tp) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-          const int tin = (t0 + n_t[nf]) * a.stride + tap_lo + tp - a.pad_left;
-          const bool ok = n_ok[nf] && tin >= 0 && tin < a.L_in;
-          const size_t row = (size_t)(b0 + n_b[nf]) * a.L_in + tin;
-          rp0[nf] = ok ? x0p + row * a.ld0 : zrow;
-          rp1[nf] = ok ? (a.c1 ? x1p + row * a.ld1 - a.c0 : x0p + row * a.ld0) : zrow - (a.c1 ? a.c0 : 0);
-        }
-      };
-      int p_tp = 0, p_j = 0;
-      const T* pa = pa_tap0;
-      setup_tap(0);
-      auto issue = [&](Frag& fa, Frag(&fb)[NF]) {
-        frag_load(fa, pa);
-        const int kc = kc_begin + wk + WK * p_j;
-        const int coff = kc * 32 + lg * 8;
-        const bool s1 = kc * 32 >= a.c0;
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) frag_load(fb[nf], (s1 ? rp1[nf] : rp0[nf]) + coff);
-        // advance the prefetch cursor; past the end it parks on the last valid slot
-        if (p_j + 1 < nmy) {
-          ++p_j;
-          pa += a_j_stride;
-        } else if (p_tp + 1 < ntaps) {
-          p_j = 0;
-          ++p_tp;
-          pa = pa_tap0 + (size_t)p_tp * a_tap_stride;
-          setup_tap(p_tp);
-        }
-      };
-      Frag ra[PF], rb[PF][NF];
-#pragma unroll
-      for (int u = 0; u < PF; ++u) issue(ra[u], rb[u]);
-      JEN1_STAMP(2);
-      for (int it = 0; it < iters; it += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          if (it + u < iters) {
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) mma32(acc[0][nf], ra[u], rb[u][nf]);
-          }
-#ifdef JEN1_PROFILE
-          if (it == 0 && u == 0) { if (acc[0][0][0] == 12345.f) __builtin_amdgcn_s_sleep(1); JEN1_STAMP(3); }
-#endif
-          issue(ra[u], rb[u]);
-        }
-      }
-    }
-    if (a.out_gn_stats) {
-      for (int i = tid; i < a.nb * 64; i += NT) st_lds[i] = 0.f;
-      __syncthreads();
-    }
-  } else {
   JEN1_STAMP(1);
   // ==== phase 0: issue every independent global load =========================================
   // (a) weight ring of the first stage
@@ -622,8 +545,6 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
     }
     first_stage = false;
   }
-
-  }   // !DIRECT
 
   JEN1_STAMP(5);
   // ==== intra-workgroup K reduction (WK > 1): waves wk > 0 hand their partials to wk == 0 =====
@@ -821,11 +742,11 @@ inline int cfg_red_floats(int cfg) {
   return d.WK > 1 ? (d.WK - 1) * d.WM * d.MF * d.NF * 256 : 0;
 }
 
-template <typename T, int MF, int NF, int WM, int WK, int PF, bool DIRECT>
+template <typename T, int MF, int NF, int WM, int WK, int PF>
 int launch(const jen1_conv_args& a, hipStream_t s) {
   constexpr int BM = 16 * MF * WM;
   const Layout L = make_layout(a, (int)sizeof(T), red_floats<MF, NF, WM, WK>());
-  auto kern = conv_gemm_kernel<T, MF, NF, WM, WK, PF, DIRECT>;
+  auto kern = conv_gemm_kernel<T, MF, NF, WM, WK, PF>;
   static bool attr_set = false;
   if (!attr_set) {
     JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -843,22 +764,12 @@ template <typename T>
 int dispatch(const jen1_conv_args& a, hipStream_t s) {
   constexpr int PFW = is_f32<T>::value ? 4 : 8;     // prefetch ring depth of the wide layouts
   constexpr int PFS = is_f32<T>::value ? 4 : 6;     // ... of the weight-streaming layouts (LDS-staged B)
-  constexpr int PFD = is_f32<T>::value ? 3 : 4;     // ... of the direct streaming layouts (A and B in the ring)
-  constexpr int PFD16 = is_f32<T>::value ? 6 : 10;  // one A + one B fragment per slot: deep ring
-  if (a.direct) {
-    switch (a.cfg) {
-      case JEN1_CFG_S16x64: return launch<T, 1, 4, 1, JEN1_SWK, PFD, true>(a, s);
-      case JEN1_CFG_S16x32: return launch<T, 1, 2, 1, JEN1_SWK, PFD + 2, true>(a, s);
-      case JEN1_CFG_S16x16: return launch<T, 1, 1, 1, JEN1_SWK, PFD16, true>(a, s);
-    }
-    return jen1_set_error("jen1_conv_gemm: direct mode needs a streaming (S16) cfg, got %d", a.cfg);
-  }
   switch (a.cfg) {
-    case JEN1_CFG_W64x64: return launch<T, 1, 4, 4, 1, PFW, false>(a, s);
-    case JEN1_CFG_W128x64: return launch<T, 2, 4, 4, 1, PFW, false>(a, s);
-    case JEN1_CFG_S16x64: return launch<T, 1, 4, 1, JEN1_SWK, PFS, false>(a, s);
-    case JEN1_CFG_S16x32: return launch<T, 1, 2, 1, JEN1_SWK, PFS, false>(a, s);
-    case JEN1_CFG_S16x16: return launch<T, 1, 1, 1, JEN1_SWK, PFS, false>(a, s);
+    case JEN1_CFG_W64x64: return launch<T, 1, 4, 4, 1, PFW>(a, s);
+    case JEN1_CFG_W128x64: return launch<T, 2, 4, 4, 1, PFW>(a, s);
+    case JEN1_CFG_S16x64: return launch<T, 1, 4, 1, JEN1_SWK, PFS>(a, s);
+    case JEN1_CFG_S16x32: return launch<T, 1, 2, 1, JEN1_SWK, PFS>(a, s);
+    case JEN1_CFG_S16x16: return launch<T, 1, 1, 1, JEN1_SWK, PFS>(a, s);
   }
   return jen1_set_error("jen1_conv_gemm: unknown cfg %d", a.cfg);
 }
@@ -876,18 +787,31 @@ extern "C" int jen1_cfg_bn(int cfg) {
 
 static int validate(const jen1_conv_args& a) {
   JEN1_CHECK(a.dtype == JEN1_F32 || a.dtype == JEN1_BF16, "conv_gemm: bad dtype %d", a.dtype);
-  JEN1_CHECK(a.x0 && a.w && a.y, "conv_gemm: null x0/w/y");
-  JEN1_CHECK(a.c0 > 0 && a.c0 % 32 == 0 && a.c1 >= 0 && a.c1 % 32 == 0, "conv_gemm: c0/c1 must be multiples of 32 (%d,%d)", a.c0, a.c1);
-  JEN1_CHECK(a.c1 == 0 || a.x1, "conv_gemm: c1 > 0 without x1");
-  JEN1_CHECK(a.ld0 >= a.c0 && a.ld0 % 8 == 0 && (a.c1 == 0 || (a.ld1 >= a.c1 && a.ld1 % 8 == 0)), "conv_gemm: bad ld0/ld1");
+  JEN1_CHECK(a.w && a.y, "conv_gemm: null w/y");
+  JEN1_CHECK(a.nseg >= 0 && a.nseg <= JEN1_MAX_SEG, "conv_gemm: bad nseg %d", a.nseg);
+  JEN1_CHECK(a.nseg == 0 || a.direct, "conv_gemm: explicit K segments need direct mode");
+  int kch = 0;       // 32-channel chunks the K split operates on
+  if (a.nseg > 0) {
+    for (int s = 0; s < a.nseg; ++s) {
+      const jen1_conv_seg& g = a.seg[s];
+      JEN1_CHECK(g.x && g.kch >= 1 && g.ld >= 32 * g.kch && g.ld % 8 == 0, "conv_gemm: bad K segment %d (kch=%d ld=%d)", s, g.kch, g.ld);
+      kch += g.kch;
+    }
+  } else {
+    JEN1_CHECK(a.x0, "conv_gemm: null x0");
+    JEN1_CHECK(a.c0 > 0 && a.c0 % 32 == 0 && a.c1 >= 0 && a.c1 % 32 == 0, "conv_gemm: c0/c1 must be multiples of 32 (%d,%d)", a.c0, a.c1);
+    JEN1_CHECK(a.c1 == 0 || a.x1, "conv_gemm: c1 > 0 without x1");
+    JEN1_CHECK(a.ld0 >= a.c0 && a.ld0 % 8 == 0 && (a.c1 == 0 || (a.ld1 >= a.c1 && a.ld1 % 8 == 0)), "conv_gemm: bad ld0/ld1");
+    JEN1_CHECK(a.taps >= 1, "conv_gemm: bad taps");
+    kch = (a.c0 + a.c1) / 32 * (a.direct ? a.taps : 1);      // direct mode splits the flat (tap, chunk) list
+  }
   JEN1_CHECK(a.M > 0 && a.M % 16 == 0 && a.out_C > 0 && a.out_C % 16 == 0 && a.M == a.out_C * a.ps_f, "conv_gemm: bad M/out_C/ps_f (%d,%d,%d)", a.M, a.out_C, a.ps_f);
-  JEN1_CHECK(a.taps >= 1 && a.stride >= 1 && a.B >= 1 && a.L_in >= 1 && a.L_out >= 1, "conv_gemm: bad geometry");
+  JEN1_CHECK(a.stride >= 1 && a.B >= 1 && a.L_in >= 1 && a.L_out >= 1, "conv_gemm: bad geometry");
   JEN1_CHECK(a.ld_y % 4 == 0 && (!a.residual || a.ld_res % 4 == 0), "conv_gemm: ld_y/ld_res must be multiples of 4");
   const int bn = jen1_cfg_bn(a.cfg);
   JEN1_CHECK(bn > 0, "conv_gemm: bad cfg %d", a.cfg);
   JEN1_CHECK(a.tb >= 1 && a.nb >= 1 && a.nb * a.tb <= bn, "conv_gemm: tile nb*tb=%d*%d exceeds BN=%d", a.nb, a.tb, bn);
   JEN1_CHECK(a.kc_stage >= 1 && a.splitk >= 1, "conv_gemm: bad kc_stage/splitk");
-  const int kch = (a.c0 + a.c1) / 32;
   JEN1_CHECK(a.splitk <= kch, "conv_gemm: splitk %d > chunks %d", a.splitk, kch);
   {
     const int cps = (kch + a.splitk - 1) / a.splitk;
@@ -906,12 +830,17 @@ static int validate(const jen1_conv_args& a) {
   if (a.pro_mode == JEN1_PRO_LN) JEN1_CHECK(a.ln_rowstats && a.ln_C >= 1 && a.c1 == 0 && (!a.ln_gamma || a.ln_beta), "conv_gemm: incomplete LayerNorm prologue");
   JEN1_CHECK(!a.out_gn_stats || (a.out_cpf >= 2 && a.out_cpf % 2 == 0), "conv_gemm: out_cpf must be even");
   JEN1_CHECK(!a.direct || a.pro_mode == JEN1_PRO_NONE, "conv_gemm: direct (no-LDS) mode takes no prologue; run jen1_norm_apply first");
-  JEN1_CHECK(!a.direct || (a.zeros && (a.c1 == 0 || a.src1_scale == 1.0f)), "conv_gemm: direct mode needs a zero row and src1_scale == 1 (fold the scale into the weights)");
+  JEN1_CHECK(!a.direct || a.nseg > 0 || a.c1 == 0 || a.src1_scale == 1.0f, "conv_gemm: direct mode needs src1_scale == 1 (fold the scale into the weights)");
+  JEN1_CHECK(!a.direct || (a.cfg >= JEN1_CFG_S16x64 && a.cfg <= JEN1_CFG_S16x16), "conv_gemm: direct mode needs a streaming (S16) cfg, got %d", a.cfg);
+  JEN1_CHECK(!a.direct || a.ps_f <= 8, "conv_gemm: direct mode supports ps_f <= 8");
   JEN1_CHECK(a.nb * a.tb <= 64 && a.L_out / a.tb + 1 < (1 << 20), "conv_gemm: tile too large for the reciprocal index math");
-  JEN1_CHECK(!a.ln_fold || (a.ln_u && a.ln_rowstats && a.ln_C >= 1 && a.taps == 1 && a.stride == 1 && a.L_out == a.L_in && a.ps_f == 1 && a.c1 == 0 && a.pro_mode == JEN1_PRO_NONE),
-             "conv_gemm: ln_fold needs ln_u / ln_rowstats, taps = 1 and no prologue");
-  const Layout L = make_layout(a, a.dtype == JEN1_F32 ? 4 : 2, cfg_red_floats(a.cfg));
-  JEN1_CHECK(L.total <= 160 * 1024, "conv_gemm: LDS request %d B exceeds 160 KiB (tb=%d nb=%d kc_stage=%d)", L.total, a.tb, a.nb, a.kc_stage);
+  JEN1_CHECK(!a.ln_fold || (a.direct && a.ln_u && a.ln_rowstats && a.ln_C >= 1 && (a.nseg > 0 ? (a.nseg == 1 && a.seg[0].shift == 0) : (a.taps == 1 && a.pad_left == 0 && a.c1 == 0)) &&
+                            a.stride == 1 && a.L_out == a.L_in && a.ps_f == 1 && a.pro_mode == JEN1_PRO_NONE),
+             "conv_gemm: ln_fold needs direct mode, ln_u / ln_rowstats, one unshifted segment and no prologue");
+  if (!a.direct) {
+    const Layout L = make_layout(a, a.dtype == JEN1_F32 ? 4 : 2, cfg_red_floats(a.cfg));
+    JEN1_CHECK(L.total <= 160 * 1024, "conv_gemm: LDS request %d B exceeds 160 KiB (tb=%d nb=%d kc_stage=%d)", L.total, a.tb, a.nb, a.kc_stage);
+  }
   return 0;
 }
 
@@ -928,6 +857,7 @@ extern "C" int jen1_conv_gemm(const jen1_conv_args* args, void* stream) {
   a.tiles_t = (a.L_out + a.tb - 1) / a.tb;
   a.inv_tiles_t = 1.0f / (float)a.tiles_t;
   a.inv_tb = 1.0f / (float)a.tb;
+  if (a.direct) return jen1_stream_gemm_launch(a, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return a.dtype == JEN1_F32 ? dispatch<float>(a, s) : dispatch<bf16_t>(a, s);
 }

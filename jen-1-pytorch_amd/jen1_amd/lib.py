@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-SOURCES = ["conv_gemm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "attention.hip", "elementwise.hip"]
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -24,6 +24,14 @@ ACT_NONE, ACT_GELU = 0, 1
 CFG_W64x64, CFG_W128x64, CFG_S16x64, CFG_S16x32, CFG_S16x16 = 0, 1, 2, 3, 4
 
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
+
+
+MAX_SEG = 16
+
+
+class ConvSeg(C.Structure):
+    """mirror of ``jen1_conv_seg``."""
+    _fields_ = [("x", c_void_p), ("ld", c_int), ("shift", c_int), ("kch", c_int), ("reserved", c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -47,7 +55,8 @@ class ConvArgs(C.Structure):
         ("act", c_int), ("out_cpf", c_int), ("tb", c_int), ("nb", c_int),
         ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int), ("direct", c_int),
         ("zeros", c_void_p), ("tiles_t", c_int), ("inv_tiles_t", c_float), ("inv_tb", c_float),
-        ("film_step", c_void_p), ("ln_u", c_void_p), ("ln_fold", c_int),
+        ("film_step", c_void_p), ("ln_u", c_void_p), ("ln_fold", c_int), ("nseg", c_int),
+        ("seg", ConvSeg * MAX_SEG),
     ]
 
 
