@@ -41,28 +41,79 @@ struct SegDev {
   int32_t gend;       // cumulative chunk count up to and including this segment
 };
 
-struct StreamArgs {
+// Kernel arguments, ordered by when a wave needs them.  Scalar (kernarg) loads are a memory round
+// trip each; the kernel reads every field of a block in straight-line code so that they leave as ONE
+// batch: `hot` before the first weight load, `epi` while the prefetch ring is in flight.
+struct HotArgs {
   const void* w;
-  const float* bias;
+  uint32_t w_bytes;
+  int32_t G, cps, MT;
+  int32_t B, L_in, L_out, stride, tb, nb, tiles_t;
+  float inv_tiles_t, inv_tb;
+  int32_t nseg;
+  SegDev first[4];    // copies of seg[0..3]: the first usable segment is picked without a dependent load
+};
+struct EpiArgs {
+  const float* bias;          // every pointer has a byte extent: 0 = absent (descriptor loads return 0)
   const void* residual;
-  void* y;
-  const float* ln_rowstats;
-  const float* ln_u;
   const float* row_scale;
+  const float* ln_u;
+  const float* ln_rowstats;
+  void* y;
   float* out_gn_stats;
   float* out_rowstats;
+  uint32_t bias_bytes, res_bytes, rsc_bytes, lnu_bytes, lnrs_bytes;
+  int32_t out_C, ps_f, ps_off, L_y, y_brows, y_row0, ld_y, ld_res, y_f32, act, ln_fold, ngrp;
+  float inv_cpf, ln_eps, inv_lnC;
+};
+struct StreamArgs {
+  HotArgs hot;
+  EpiArgs epi;
   float* slab;
   unsigned* counters;
   unsigned long long* dbg;
+  int32_t splitk;
   SegDev seg[JEN1_MAX_SEG];
-  uint32_t w_bytes;
-  int32_t nseg, G, cps, splitk;
-  int32_t B, L_in, L_out, stride;
-  int32_t MT, out_C, ps_f, ps_off, L_y, y_brows, y_row0, ld_y, ld_res, y_f32, act, tb, nb, tiles_t;
-  float inv_tiles_t, inv_tb, inv_cpf, ln_eps, inv_lnC;
-  int32_t ln_fold;
-  int32_t ngrp;       // statistics fine groups a 16-channel tile can touch (2 when out_cpf >= 16)
 };
+
+static_assert(sizeof(HotArgs) == 160 && sizeof(EpiArgs) == 144 && offsetof(StreamArgs, epi) == 160, "kernarg blocks are read with fixed-size scalar loads");
+
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+
+// One batch of scalar loads + one wait.  (Left to the compiler, the kernarg reads are sunk next to their
+// uses behind uniform branches: 6-8 dependent scalar-memory round trips before the first weight load.)
+__device__ __forceinline__ HotArgs load_hot_args() {
+  const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  u32x16 k0, k1;
+  u32x8 k2;
+  unsigned t0, t1, t2, t3;
+  // the four single-dword loads only pull the epilogue block and the head of the segment table into the
+  // scalar cache, so that the later batches hit it instead of paying a memory round trip
+  asm volatile("s_load_dwordx16 %0, %7, 0x0\n\ts_load_dwordx16 %1, %7, 0x40\n\ts_load_dwordx8 %2, %7, 0x80\n\t"
+               "s_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(kp) : "memory");
+  struct Raw { unsigned d[40]; } raw;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { raw.d[i] = k0[i]; raw.d[16 + i] = k1[i]; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) raw.d[32 + i] = k2[i];
+  return __builtin_bit_cast(HotArgs, raw);
+}
+__device__ __forceinline__ EpiArgs load_epi_args() {
+  const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  u32x16 k0, k1;
+  u32x4 k2;
+  asm volatile("s_load_dwordx16 %0, %3, 0xa0\n\ts_load_dwordx16 %1, %3, 0xe0\n\ts_load_dwordx4 %2, %3, 0x120\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(k0), "=&s"(k1), "=&s"(k2) : "s"(kp) : "memory");
+  struct Raw { unsigned d[36]; } raw;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { raw.d[i] = k0[i]; raw.d[16 + i] = k1[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) raw.d[32 + i] = k2[i];
+  return __builtin_bit_cast(EpiArgs, raw);
+}
 
 constexpr unsigned OOB = 0x80000000u;     // per-lane offset beyond every descriptor range: loads return 0
 constexpr int RSRC_FLAGS = 0x00020000;
@@ -118,15 +169,17 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
   const int li = lane & 15, lg = lane >> 4;
   SG_STAMP(0);
 
-  // ---- tile coordinates (all wave-uniform) ---------------------------------------------------
+  // ---- everything the first weight load depends on, from ONE batch of kernarg loads ----------
+  const HotArgs h = load_hot_args();
   const int by = blockIdx.y;
-  const int bt = (int)(((float)by + 0.5f) * a.inv_tiles_t), tt = by - bt * a.tiles_t;
-  const int b0 = bt * a.nb, t0 = tt * a.tb;
+  const int bt = (int)(((float)by + 0.5f) * h.inv_tiles_t), tt = by - bt * h.tiles_t;
+  const int b0 = bt * h.nb, t0 = tt * h.tb;
   const int mt = blockIdx.x, z = blockIdx.z;
-  const int g0 = z * a.cps;
-  const int g1 = (g0 + a.cps < a.G) ? g0 + a.cps : a.G;
-  const int t_last = ((t0 + a.tb < a.L_out) ? t0 + a.tb : a.L_out) - 1;
-  const int n_rows = a.nb * a.tb;
+  const int g0 = z * h.cps;
+  const int g1 = (g0 + h.cps < h.G) ? g0 + h.cps : h.G;
+  const int t_last = ((t0 + h.tb < h.L_out) ? t0 + h.tb : h.L_out) - 1;
+  const int n_rows = h.nb * h.tb;
+  const int tmin = t0 * h.stride, tmax = t_last * h.stride;
 
   // ---- this lane's activation rows (one per 16-column fragment) ------------------------------
   int rowi[NF], tpos[NF], n_b[NF], n_t[NF];
@@ -134,12 +187,12 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     const int n = nf * 16 + li;
-    const int bl = (int)(((float)n + 0.5f) * a.inv_tb), tl = n - bl * a.tb;     // exact for n < 64
-    n_ok[nf] = (n < n_rows) && (b0 + bl < a.B) && (t0 + tl < a.L_out);
+    const int bl = (int)(((float)n + 0.5f) * h.inv_tb), tl = n - bl * h.tb;     // exact for n < 64
+    n_ok[nf] = (n < n_rows) && (b0 + bl < h.B) && (t0 + tl < h.L_out);
     n_b[nf] = bl;
     n_t[nf] = tl;
-    rowi[nf] = (b0 + bl) * a.L_in;
-    tpos[nf] = (t0 + tl) * a.stride;
+    rowi[nf] = (b0 + bl) * h.L_in;
+    tpos[nf] = (t0 + tl) * h.stride;
   }
 
   f32x4 acc[NF];
@@ -147,7 +200,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
   for (int nf = 0; nf < NF; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- K cursor of this wave: chunk cur_g of segment s_cur, chunks lo+wk, lo+wk+4, ... ----------
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)a.w_bytes, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(h.w), 0, (int)h.w_bytes, RSRC_FLAGS);
   __amdgpu_buffer_rsrc_t rx = rw;
   unsigned voffA = (unsigned)lane * (8u * ES);
   unsigned voff[NF];
@@ -155,32 +208,65 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
   int s_cur = -1, cur_g = 0, cur_hi = 0;
   int issued = 0, total = 0x7fffffff;
   bool parked = false;
+  // enter segment: per-lane row offsets (rows in the conv zero padding -> out-of-range -> 0)
+  auto enter = [&](const void* x, unsigned nbytes, int ldb, int sh, int sb, int lo, int hi) {
+    cur_g = lo + wk;
+    cur_hi = hi;
+    soffA = (unsigned)(cur_g * h.MT + mt) * BLK;
+    soffB = (unsigned)(cur_g - sb) * CHB;
+    rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)nbytes, RSRC_FLAGS);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int tin = tpos[nf] + sh;
+      const bool ok = n_ok[nf] && tin >= 0 && tin < h.L_in;
+      voff[nf] = ok ? (unsigned)((rowi[nf] + tin) * ldb) + (unsigned)lg * (8u * ES) : OOB;
+    }
+  };
+  // a segment is usable by this wave if some position of the tile reads a real input row through it
+  // (else it only multiplies zero padding: skipped together with its weights) and the wave owns a chunk
   auto advance = [&]() -> bool {
-    for (int s = s_cur + 1; s < a.nseg; ++s) {
+    for (int s = s_cur + 1; s < h.nseg; ++s) {
       const int sb = s ? a.seg[s - 1].gend : 0, se = a.seg[s].gend;
       const int lo = sb > g0 ? sb : g0, hi = se < g1 ? se : g1;
       const int sh = a.seg[s].shift;
-      // live: some position of this tile reads a real input row through this segment
-      const bool live = (t_last * a.stride + sh >= 0) && (t0 * a.stride + sh < a.L_in);
-      if (live && lo + wk < hi) {
+      if ((tmax + sh >= 0) && (tmin + sh < h.L_in) && lo + wk < hi) {
         s_cur = s;
-        cur_g = lo + wk;
-        cur_hi = hi;
-        soffA = (unsigned)(cur_g * a.MT + mt) * BLK;
-        soffB = (unsigned)(cur_g - sb) * CHB;
-        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.seg[s].x), 0, (int)a.seg[s].nbytes, RSRC_FLAGS);
-        const int ldb = a.seg[s].ldb;
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-          const int tin = tpos[nf] + sh;
-          const bool ok = n_ok[nf] && tin >= 0 && tin < a.L_in;
-          voff[nf] = ok ? (unsigned)((rowi[nf] + tin) * ldb) + (unsigned)lg * (8u * ES) : OOB;
-        }
+        enter(a.seg[s].x, a.seg[s].nbytes, a.seg[s].ldb, sh, sb, lo, hi);
         return true;
       }
     }
     return false;
   };
+  // first usable segment among the four preloaded ones: branch-free, no dependent scalar load
+  bool any;
+  {
+    int pick = -1, p_sb = 0, p_lo = 0, p_hi = 0, p_sh = 0, p_ldb = 0;
+    unsigned p_nb = 0;
+    const void* p_x = h.w;
+#pragma unroll
+    for (int s = 3; s >= 0; --s) {
+      const int sb = s ? h.first[s - 1].gend : 0, se = h.first[s].gend;
+      const int lo = sb > g0 ? sb : g0, hi = se < g1 ? se : g1;
+      const int sh = h.first[s].shift;
+      const bool use = (tmax + sh >= 0) && (tmin + sh < h.L_in) && (lo + wk < hi);
+      pick = use ? s : pick;
+      p_sb = use ? sb : p_sb;
+      p_lo = use ? lo : p_lo;
+      p_hi = use ? hi : p_hi;
+      p_sh = use ? sh : p_sh;
+      p_ldb = use ? h.first[s].ldb : p_ldb;
+      p_nb = use ? h.first[s].nbytes : p_nb;
+      p_x = use ? h.first[s].x : p_x;
+    }
+    if (pick >= 0) {
+      s_cur = pick;
+      enter(p_x, p_nb, p_ldb, p_sh, p_sb, p_lo, p_hi);
+      any = true;
+    } else {
+      s_cur = 3;
+      any = advance();
+    }
+  }
   auto issue = [&](Frag& fa, Frag(&fb)[NF]) {
     bload<JEN1_W_AUX>(fa, rw, voffA, soffA);
 #pragma unroll
@@ -189,7 +275,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
       ++issued;
       cur_g += 4;
       if (cur_g < cur_hi) {
-        soffA += 4u * BLK * (unsigned)a.MT;
+        soffA += 4u * BLK * (unsigned)h.MT;
         soffB += 4u * CHB;
       } else if (!advance()) {
         // past the end: the ring keeps issuing (the load count per slot must stay fixed for vmcnt),
@@ -203,50 +289,55 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
     }
   };
 
-  // ---- epilogue operands: requested right after the ring is filled, used at the very end -----
+  // ---- epilogue operands: requested right after the ring is filled, used at the very end.
+  // Absent operands have a zero-length descriptor (loads return 0): no branches, one kernarg batch.
   const bool owner = (wk == 0);
-  const T* res = reinterpret_cast<const T*>(a.residual);
   bool okk[NF];
   int yrow[NF];
   int co = 0;
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, lnu = {0.f, 0.f, 0.f, 0.f};
   float rr[NF][4];
   float rsc[NF];
-  float lnu[4] = {0.f, 0.f, 0.f, 0.f};
   float2 lnrs[NF];
+  EpiArgs e;
   auto request_epilogue_operands = [&]() {
+    const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.bias), 0, (int)e.bias_bytes, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_lnu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.ln_u), 0, (int)e.lnu_bytes, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e.residual), 0, (int)e.res_bytes, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.row_scale), 0, (int)e.rsc_bytes, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_lnrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.ln_rowstats), 0, (int)e.lnrs_bytes, RSRC_FLAGS);
     const int m = mt * 16 + lg * 4;
     int ph = 0;
-    for (int k = 1; k < a.ps_f; ++k) ph += (m >= k * a.out_C) ? 1 : 0;
-    co = m - ph * a.out_C;
-    if (a.bias) {
-      const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-      bias4[0] = bb.x; bias4[1] = bb.y; bias4[2] = bb.z; bias4[3] = bb.w;
-    }
-    if (a.ln_fold) {
-      const float4 uu = *reinterpret_cast<const float4*>(a.ln_u + m);
-      lnu[0] = uu.x; lnu[1] = uu.y; lnu[2] = uu.z; lnu[3] = uu.w;
-    }
+    for (int k = 1; k < e.ps_f; ++k) ph += (m >= k * e.out_C) ? 1 : 0;
+    co = m - ph * e.out_C;
+    bias4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (unsigned)co * 4u, 0, 0));
+    lnu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_lnu, (unsigned)m * 4u, 0, 0));
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-      const int ty = (t0 + n_t[nf]) * a.ps_f + ph - a.ps_off;
-      okk[nf] = n_ok[nf] && ty >= 0 && ty < a.L_y;
-      yrow[nf] = okk[nf] ? (b0 + n_b[nf]) * a.y_brows + a.y_row0 + ty : 0;
+      const int ty = (t0 + n_t[nf]) * e.ps_f + ph - e.ps_off;
+      okk[nf] = n_ok[nf] && ty >= 0 && ty < e.L_y;
+      yrow[nf] = okk[nf] ? (b0 + n_b[nf]) * e.y_brows + e.y_row0 + ty : 0;
+      const unsigned roff = okk[nf] ? ((unsigned)yrow[nf] * (unsigned)e.ld_res + (unsigned)co) * ES : OOB;
+      if (PRECISE) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, roff, 0, 0));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rr[nf][r] = 0.f;
-      if (res) load4(res + (size_t)((unsigned)yrow[nf] * (unsigned)a.ld_res + (unsigned)co), rr[nf]);
-      rsc[nf] = a.row_scale ? a.row_scale[yrow[nf]] : 1.0f;
-      if (a.ln_fold) {
-        const int irow = n_ok[nf] ? rowi[nf] + t0 + n_t[nf] : 0;
-        lnrs[nf] = *reinterpret_cast<const float2*>(a.ln_rowstats + 2 * irow);
+        for (int r = 0; r < 4; ++r) rr[nf][r] = v[r];
+      } else {
+        const bf16x4 v = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r_res, roff, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr[nf][r] = (float)v[r];
       }
+      const float sc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsc, (unsigned)yrow[nf] * 4u, 0, 0));
+      rsc[nf] = e.rsc_bytes ? sc : 1.0f;
+      const int irow = n_ok[nf] ? rowi[nf] + t0 + n_t[nf] : 0;
+      const u32x2 st = __builtin_amdgcn_raw_buffer_load_b64(r_lnrs, (unsigned)irow * 8u, 0, 0);
+      lnrs[nf] = make_float2(__uint_as_float(st.x), __uint_as_float(st.y));
     }
   };
 
   // ---- main loop ------------------------------------------------------------------------------
   {
     Frag ra[PF], rb[PF][NF];
-    const bool any = advance();
     if (any) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) issue(ra[u], rb[u]);
@@ -254,9 +345,10 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
       total = 0;
     }
     SG_STAMP(1);
+    e = load_epi_args();
     if (owner) request_epilogue_operands();
-    if (a.out_gn_stats) {
-      for (int i = tid; i < a.nb * a.ngrp * 2; i += 256) st_lds[i] = 0.f;
+    if (e.out_gn_stats) {
+      for (int i = tid; i < h.nb * e.ngrp * 2; i += 256) st_lds[i] = 0.f;
     }
     SG_STAMP(2);
     if (any) {
@@ -340,31 +432,31 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
 
   // ---- epilogue (wave 0): bias / folded LayerNorm, GELU, residual, row mask, store, statistics ----
   if (owner) {
-    T* yT = reinterpret_cast<T*>(a.y);
-    float* yF = reinterpret_cast<float*>(a.y);
+    T* yT = reinterpret_cast<T*>(e.y);
+    float* yF = reinterpret_cast<float*>(e.y);
     // fine groups of the statistics this 16-row tile can touch: fg0 .. fg0 + ngrp - 1
     const int co_tile = co - lg * 4;                                   // first output channel of the tile
-    const int fg0 = (int)(((float)co_tile + 0.5f) * a.inv_cpf);
+    const int fg0 = (int)(((float)co_tile + 0.5f) * e.inv_cpf);
     float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
     int rel[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) rel[p] = (int)(((float)(co + 2 * p) + 0.5f) * a.inv_cpf) - fg0;
+    for (int p = 0; p < 2; ++p) rel[p] = (int)(((float)(co + 2 * p) + 0.5f) * e.inv_cpf) - fg0;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       float v[4];
-      if (a.ln_fold) {
+      if (e.ln_fold) {
         // Linear(LayerNorm(x)) = rstd * (W'x - mean * rowsum(W')) + W beta   (blocks.py:427-429)
-        const float mean = lnrs[nf].x * a.inv_lnC;
-        float var = lnrs[nf].y * a.inv_lnC - mean * mean;
+        const float mean = lnrs[nf].x * e.inv_lnC;
+        float var = lnrs[nf].y * e.inv_lnC - mean * mean;
         var = var < 0.f ? 0.f : var;
-        const float rstd = PRECISE ? 1.0f / sqrtf(var + a.ln_eps) : rsqrtf(var + a.ln_eps);
+        const float rstd = PRECISE ? 1.0f / sqrtf(var + e.ln_eps) : rsqrtf(var + e.ln_eps);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (acc[nf][r] - mean * lnu[r]) * rstd + bias4[r];
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[nf][r] + bias4[r];
       }
-      if (a.act == JEN1_ACT_GELU) {
+      if (e.act == JEN1_ACT_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       }
@@ -372,19 +464,19 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
       if (okk[nf]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (v[r] + rr[nf][r]) * rsc[nf];
-        const size_t off = (size_t)((unsigned)yrow[nf] * (unsigned)a.ld_y + (unsigned)co);
-        if (a.y_f32) store4(yF + off, v);
+        const size_t off = (size_t)((unsigned)yrow[nf] * (unsigned)e.ld_y + (unsigned)co);
+        if (e.y_f32) store4(yF + off, v);
         else store4(yT + off, v);
         const float s01 = v[0] + v[1], s23 = v[2] + v[3];
         const float q01 = v[0] * v[0] + v[1] * v[1], q23 = v[2] * v[2] + v[3] * v[3];
         s2 = s01 + s23;
         q2 = q01 + q23;
-        if (a.out_gn_stats) {
-          if (a.nb == 1) {
+        if (e.out_gn_stats) {
+          if (h.nb == 1) {
             gs[0] += s01; gq[0] += q01;
             gs[1] += s23; gq[1] += q23;
           } else {
-            float* sl = st_lds + n_b[nf] * a.ngrp * 2;
+            float* sl = st_lds + n_b[nf] * e.ngrp * 2;
             atomicAdd(sl + rel[0] * 2, s01);
             atomicAdd(sl + rel[0] * 2 + 1, q01);
             atomicAdd(sl + rel[1] * 2, s23);
@@ -392,16 +484,16 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
           }
         }
       }
-      if (a.out_rowstats) {
+      if (e.out_rowstats) {
         s2 += __shfl_xor(s2, 16); q2 += __shfl_xor(q2, 16);
         s2 += __shfl_xor(s2, 32); q2 += __shfl_xor(q2, 32);
         if (lg == 0 && okk[nf]) {
-          unsafeAtomicAdd(a.out_rowstats + 2 * yrow[nf], s2);
-          unsafeAtomicAdd(a.out_rowstats + 2 * yrow[nf] + 1, q2);
+          unsafeAtomicAdd(e.out_rowstats + 2 * yrow[nf], s2);
+          unsafeAtomicAdd(e.out_rowstats + 2 * yrow[nf] + 1, q2);
         }
       }
     }
-    if (a.out_gn_stats && a.nb == 1) {
+    if (e.out_gn_stats && h.nb == 1) {
       // all columns belong to one batch element: reduce across the 16 columns of the fragment
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -418,16 +510,16 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
       }
     }
     SG_STAMP(6);
-    if (a.out_gn_stats) {
+    if (e.out_gn_stats) {
       // (the LDS atomics above are this wave's own: the LDS pipeline is in order, no barrier needed)
-      const int per_b = a.ngrp * 2;
+      const int per_b = e.ngrp * 2;
       const float inv_per_b = 1.0f / (float)per_b;
-      for (int i = lane; i < a.nb * per_b; i += 64) {
-        const int bl = (int)(((float)i + 0.5f) * inv_per_b), e = i - bl * per_b;
+      for (int i = lane; i < h.nb * per_b; i += 64) {
+        const int bl = (int)(((float)i + 0.5f) * inv_per_b), el = i - bl * per_b;
         const int b = b0 + bl;
         const float v = st_lds[i];
-        const int fg = fg0 + (e >> 1);
-        if (b < a.B && fg < JEN1_FINE_GROUPS && v != 0.f) unsafeAtomicAdd(a.out_gn_stats + (size_t)b * 64 + fg * 2 + (e & 1), v);
+        const int fg = fg0 + (el >> 1);
+        if (b < h.B && fg < JEN1_FINE_GROUPS && v != 0.f) unsafeAtomicAdd(e.out_gn_stats + (size_t)b * 64 + fg * 2 + (el & 1), v);
       }
     }
   }
@@ -436,9 +528,9 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
 
 template <typename T, int NF, int PF>
 int launch_stream(const StreamArgs& sa, hipStream_t s) {
-  const int tiles_b = (sa.B + sa.nb - 1) / sa.nb;
-  dim3 grid(sa.MT, sa.tiles_t * tiles_b, sa.splitk);
-  const size_t lds = (size_t)(4 + 3 * NF * 256 + sa.nb * sa.ngrp * 2) * sizeof(float);
+  const int tiles_b = (sa.hot.B + sa.hot.nb - 1) / sa.hot.nb;
+  dim3 grid(sa.hot.MT, sa.hot.tiles_t * tiles_b, sa.splitk);
+  const size_t lds = (size_t)(4 + 3 * NF * 256 + sa.hot.nb * sa.epi.ngrp * 2) * sizeof(float);
   hipLaunchKernelGGL((stream_gemm_kernel<T, NF, PF>), grid, dim3(256), lds, s, sa);
   JEN1_HIP(hipGetLastError());
   return 0;
@@ -470,14 +562,14 @@ int launch_stream(const StreamArgs& sa, hipStream_t s) {
 int jen1_stream_gemm_launch(const jen1_conv_args& a, void* stream) {
   StreamArgs sa;
   memset(&sa, 0, sizeof(sa));
+  HotArgs& h = sa.hot;
+  EpiArgs& e = sa.epi;
   const int es = a.dtype == JEN1_F32 ? 4 : 2;
-  sa.w = a.w; sa.bias = a.bias; sa.residual = a.residual; sa.y = a.y;
-  sa.ln_rowstats = a.ln_rowstats; sa.ln_u = a.ln_u; sa.row_scale = a.row_scale;
-  sa.out_gn_stats = a.out_gn_stats; sa.out_rowstats = a.out_rowstats;
-  sa.slab = a.slab; sa.counters = a.counters;
+  sa.slab = a.slab; sa.counters = a.counters; sa.splitk = a.splitk;
 #ifdef JEN1_PROFILE
   sa.dbg = (a.splitk == 1) ? reinterpret_cast<unsigned long long*>(a.slab) : nullptr;
 #endif
+  // ---- K segments ------------------------------------------------------------------------------
   const int64_t rows_in = (int64_t)a.B * a.L_in;
   int G = 0, ns = 0;
   if (a.nseg > 0) {
@@ -502,28 +594,41 @@ int jen1_stream_gemm_launch(const jen1_conv_args& a, void* stream) {
       }
     }
   }
-  sa.nseg = ns;
-  sa.G = G;
-  sa.splitk = a.splitk;
-  sa.cps = (G + a.splitk - 1) / a.splitk;
-  JEN1_CHECK((a.splitk - 1) * sa.cps < G, "conv_gemm: splitk %d leaves an empty K slice (%d chunks)", a.splitk, G);
-  sa.MT = a.M / 16;
-  const int64_t wb = (int64_t)G * sa.MT * 512 * es;
+  for (int s = 0; s < 4; ++s) {
+    if (s < ns) h.first[s] = sa.seg[s];
+    else h.first[s] = SegDev{a.w, 0u, 0, 0, G};      // empty: [G, G) holds no chunk
+  }
+  h.nseg = ns;
+  h.G = G;
+  h.cps = (G + a.splitk - 1) / a.splitk;
+  JEN1_CHECK((a.splitk - 1) * h.cps < G, "conv_gemm: splitk %d leaves an empty K slice (%d chunks)", a.splitk, G);
+  h.MT = a.M / 16;
+  const int64_t wb = (int64_t)G * h.MT * 512 * es;
   JEN1_CHECK(wb < (int64_t)OOB, "conv_gemm: packed weight too large for 31-bit offsets");
-  sa.w_bytes = (uint32_t)wb;
-  sa.B = a.B; sa.L_in = a.L_in; sa.L_out = a.L_out; sa.stride = a.stride;
-  sa.out_C = a.out_C; sa.ps_f = a.ps_f; sa.ps_off = a.ps_off; sa.L_y = a.L_y; sa.y_brows = a.y_brows;
-  sa.y_row0 = a.y_row0; sa.ld_y = a.ld_y; sa.ld_res = a.ld_res; sa.y_f32 = a.y_f32; sa.act = a.act;
-  sa.tb = a.tb; sa.nb = a.nb;
-  sa.tiles_t = (a.L_out + a.tb - 1) / a.tb;
-  sa.inv_tiles_t = 1.0f / (float)sa.tiles_t;
-  sa.inv_tb = 1.0f / (float)a.tb;
-  sa.inv_cpf = a.out_gn_stats ? 1.0f / (float)a.out_cpf : 1.0f;
-  sa.ngrp = (!a.out_gn_stats || a.out_cpf >= 16) ? 2 : 16 / a.out_cpf + 1;
-  sa.ln_eps = a.ln_eps;
-  sa.inv_lnC = a.ln_fold ? 1.0f / (float)a.ln_C : 0.f;
-  sa.ln_fold = a.ln_fold;
-  JEN1_CHECK((int64_t)a.B * a.y_brows * a.ld_y < (int64_t)1 << 31, "conv_gemm: output too large for 32-bit element offsets");
+  h.w = a.w;
+  h.w_bytes = (uint32_t)wb;
+  h.B = a.B; h.L_in = a.L_in; h.L_out = a.L_out; h.stride = a.stride;
+  h.tb = a.tb; h.nb = a.nb;
+  h.tiles_t = (a.L_out + a.tb - 1) / a.tb;
+  h.inv_tiles_t = 1.0f / (float)h.tiles_t;
+  h.inv_tb = 1.0f / (float)a.tb;
+  // ---- epilogue ----------------------------------------------------------------------------------
+  const int64_t y_rows = (int64_t)a.B * a.y_brows;
+  JEN1_CHECK(y_rows * a.ld_y * 4 < (int64_t)OOB && (!a.residual || y_rows * a.ld_res * es < (int64_t)OOB),
+             "conv_gemm: output too large for 31-bit offsets");
+  e.bias = a.bias; e.bias_bytes = a.bias ? (uint32_t)a.out_C * 4u : 0u;
+  e.residual = a.residual; e.res_bytes = a.residual ? (uint32_t)(y_rows * a.ld_res * es) : 0u;
+  e.row_scale = a.row_scale; e.rsc_bytes = a.row_scale ? (uint32_t)(y_rows * 4) : 0u;
+  e.ln_u = a.ln_fold ? a.ln_u : nullptr; e.lnu_bytes = a.ln_fold ? (uint32_t)a.M * 4u : 0u;
+  e.ln_rowstats = a.ln_fold ? a.ln_rowstats : nullptr; e.lnrs_bytes = a.ln_fold ? (uint32_t)(rows_in * 8) : 0u;
+  e.y = a.y; e.out_gn_stats = a.out_gn_stats; e.out_rowstats = a.out_rowstats;
+  e.out_C = a.out_C; e.ps_f = a.ps_f; e.ps_off = a.ps_off; e.L_y = a.L_y; e.y_brows = a.y_brows;
+  e.y_row0 = a.y_row0; e.ld_y = a.ld_y; e.ld_res = a.ld_res; e.y_f32 = a.y_f32; e.act = a.act;
+  e.ln_fold = a.ln_fold;
+  e.ngrp = (!a.out_gn_stats || a.out_cpf >= 16) ? 2 : 16 / a.out_cpf + 1;
+  e.inv_cpf = a.out_gn_stats ? 1.0f / (float)a.out_cpf : 1.0f;
+  e.ln_eps = a.ln_eps;
+  e.inv_lnC = a.ln_fold ? 1.0f / (float)a.ln_C : 0.f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a.dtype == JEN1_F32) {
     switch (a.cfg) {
