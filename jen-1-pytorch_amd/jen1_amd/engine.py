@@ -100,6 +100,10 @@ class Weights:
                     wsc[:, :, r.c_out:] *= 2 ** -0.5
                 self.w[f"{n}.short"] = pk(wsc)
                 self.v[f"{n}.short.bias"] = f32(p[f"{n}.to_out.conv.bias"])
+                # streaming levels: the 1x1 shortcut rides along as extra K segments of the second conv
+                # (y = conv2(h) + to_out(x), blocks.py:229-231): one launch, no residual operand
+                self.w[f"{n}.conv2s"] = torch.cat([self.w[f"{n}.conv2"].flatten(0, 1), self.w[f"{n}.short"].flatten(0, 1)], 0).contiguous()
+                self.v[f"{n}.conv2s.bias"] = (self.v[f"{n}.conv2.bias"] + self.v[f"{n}.short.bias"]).contiguous()
             film_w.append(p[f"{n}.to_scale_shift.to_scale_shift.1.weight"])
             film_b.append(p[f"{n}.to_scale_shift.to_scale_shift.1.bias"])
             self.film_off[n] = off
@@ -157,6 +161,12 @@ class Weights:
             self.v[f"{n}.ff1.bias"] = f32(p[f"{b}.feed_forward.0.bias"])
             self.w[f"{n}.ff2"] = pk(p[f"{b}.feed_forward.2.weight"][None])
             self.v[f"{n}.ff2.bias"] = f32(p[f"{b}.feed_forward.2.bias"])
+            # streaming levels: the output 1x1 conv applied to x + ff2(f) is ONE GEMM over the K concat
+            # [x | f] with weights [P | P @ W_ff2] (blocks.py:446, :488, :536): no x4 round trip
+            wp64 = p[f"{n}.conv1d.conv.weight"][:, :, 0].double()
+            wm = torch.cat([wp64, wp64 @ p[f"{b}.feed_forward.2.weight"].double()], 1).float()
+            self.w[f"{n}.ffp"] = pk(wm[None]).flatten(0, 1).contiguous()
+            self.v[f"{n}.ffp.bias"] = (p[f"{n}.conv1d.conv.bias"].double() + wp64 @ p[f"{b}.feed_forward.2.bias"].double()).float().contiguous()
         self.kvx_ld = off
         if kvx_w:
             # time-token K/V rows of every cross-attention layer as ONE GEMM per step
@@ -180,6 +190,8 @@ class KernelCtx:
         self.target_wgs = target_wgs
         self.splitk_target_wgs = 512
         self.splitk_min_bytes = 1 << 20
+        self.fuse_shortcut = True
+        self.fuse_ff_out = True
 
 
 class OpBuilder:
@@ -195,7 +207,6 @@ class OpBuilder:
         self._keep: List[object] = []
         self.slab = None
         self.counters = None
-        self.zero_row = torch.zeros((8192,), dtype=torch.float32, device=eng.device)   # padding rows of direct GEMMs
 
     def _empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.eng.tdtype, device=self.eng.device)
@@ -225,7 +236,9 @@ class OpBuilder:
     def conv(self, ops, *, src0: Act, w: torch.Tensor, bias, out: Act, taps=1, stride=1, pad_left=0, L_out=None,
              src1: Optional[Act] = None, src1_scale=1.0, ps_f=1, ps_off=0, L_y=None, y_row0=0, pro=L.PRO_NONE,
              gn=None, film=None, ln=None, act=L.ACT_NONE, residual: Optional[Act] = None, row_scale=None,
-             y_f32=False, out_C=None, force=None, label=""):
+             y_f32=False, out_C=None, force=None, label="", extra_segs=None):
+        """extra_segs: [(Act, row_shift)] raw sources appended to the K axis after the (tap, source) pairs of
+        src0/src1 (streaming / direct mode only); ``w`` is then the flat packed weight [chunks][M/16][64][8]."""
         eng = self.eng
         a = L.ConvArgs()
         a.x0, a.c0, a.ld0 = src0.t.data_ptr(), src0.ld, src0.ld
@@ -240,8 +253,13 @@ class OpBuilder:
         out_C = out_C if out_C is not None else out.C
         a.out_C, a.ps_f, a.ps_off = out_C, ps_f, ps_off
         a.M = out_C * ps_f
-        assert w.shape[0] == taps and w.shape[2] * 16 == a.M and w.shape[1] * 32 == a.c0 + a.c1, \
-            (tuple(w.shape), taps, a.M, a.c0, a.c1)
+        if extra_segs:
+            k_extra = sum(e.ld for e, _ in extra_segs)
+            assert w.dim() == 4 and w.shape[1] * 16 == a.M and w.shape[0] * 32 == taps * (a.c0 + a.c1) + k_extra, \
+                (tuple(w.shape), taps, a.M, a.c0, a.c1, k_extra)
+        else:
+            assert w.shape[0] == taps and w.shape[2] * 16 == a.M and w.shape[1] * 32 == a.c0 + a.c1, \
+                (tuple(w.shape), taps, a.M, a.c0, a.c1)
         a.y, a.ld_y = out.t.data_ptr(), out.ld
         a.L_y = L_y if L_y is not None else (out.L - y_row0)
         a.y_brows, a.y_row0 = out.L, y_row0
@@ -279,7 +297,7 @@ class OpBuilder:
             a.out_gn_stats, a.out_cpf = out.gn.data_ptr(), out.ld // FG
         if out.rs is not None:
             a.out_rowstats = out.rs.data_ptr()
-        self._choose_tiles(a, force)
+        self._choose_tiles(a, force, k_extra=(sum(e.ld for e, _ in extra_segs) // 32 if extra_segs else 0))
         lib = eng.lib
         streaming = a.cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
         want_direct = streaming and (force is None or force.get("direct", True))
@@ -325,29 +343,61 @@ class OpBuilder:
         if a.direct and a.c1 and a.src1_scale != 1.0:
             a.direct = 0          # a raw scaled second source needs the LDS path (or pre-scaled weights)
         if a.direct:
-            assert a.c0 + a.c1 <= 8192
-            a.zeros = self.zero_row.data_ptr()
             a.kc_stage = max(1, (a.c0 + a.c1) // 32)
+        if extra_segs:
+            assert a.direct, "extra K segments need the streaming (direct) mode"
+            segs = []
+            for tap in range(taps):
+                segs.append((a.x0, a.ld0, tap - pad_left, a.c0 // 32))
+                if a.c1:
+                    segs.append((a.x1, a.ld1, tap - pad_left, a.c1 // 32))
+            for e, sh in extra_segs:
+                assert e.B == a.B and e.L == a.L_in and e.t.dtype == eng.tdtype
+                segs.append((e.t.data_ptr(), e.ld, sh, e.ld // 32))
+            assert len(segs) <= L.MAX_SEG
+            a.nseg = len(segs)
+            for i, (xp, ld, sh, kch) in enumerate(segs):
+                a.seg[i].x, a.seg[i].ld, a.seg[i].shift, a.seg[i].kch = xp, ld, sh, kch
         if a.splitk > 1:
             self._splitk_args.append(a)
         # the prepared launch holds raw pointers: keep every tensor it references alive
-        self._keep.append((a, src0, src1, w, bias, out, residual, row_scale, gn, film, ln))
+        self._keep.append((a, src0, src1, w, bias, out, residual, row_scale, gn, film, ln, extra_segs))
         ref = C.byref(a)
         fn = lambda s, ref=ref, lib=lib: L.check(lib.jen1_conv_gemm(ref, s), "jen1_conv_gemm")
         # algorithmic traffic / work of this launch (weights once + conv input + output)
         es = 4 if eng.dt == L.F32 else 2
         c_real = src0.C + (src1.C if src1 is not None else 0)
+        c_extra = sum(e.C for e, _ in extra_segs) if extra_segs else 0
         fn.kind = "conv_gemm"
-        fn.w_bytes = taps * a.M * c_real * es
-        fn.act_bytes = a.B * a.L_in * c_real * es + a.B * a.L_y * out_C * (4 if y_f32 else es)
-        fn.flops = 2 * taps * a.M * c_real * a.B * a.L_out
+        fn.w_bytes = (taps * c_real + c_extra) * a.M * es
+        fn.act_bytes = a.B * a.L_in * (c_real + c_extra) * es + a.B * a.L_y * out_C * (4 if y_f32 else es)
+        fn.flops = 2 * (taps * c_real + c_extra) * a.M * a.B * a.L_out
         fn.label = (f"conv[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} s={a.stride} M={a.M} "
                     f"ps={a.ps_f}/{a.ps_off} Ly={a.L_y} pro={a.pro_mode} cfg={a.cfg} tb={a.tb} nb={a.nb} kst={a.kc_stage} sk={a.splitk} "
                     f"direct={a.direct}")
         ops.append(fn)
         return out
 
-    def _choose_tiles(self, a: L.ConvArgs, force=None):
+    def pick_cfg(self, B: int, L_out: int, M: int) -> int:
+        """wide tile when the positions alone fill the chip with 64-row M tiles, else a 16-row streaming tile"""
+        lib, eng = self.eng.lib, self.eng
+
+        def ntiles(cfg):
+            BM, BN = lib.jen1_cfg_bm(cfg), lib.jen1_cfg_bn(cfg)
+            tb = min(L_out, BN)
+            nb = max(1, min(B, BN // tb))
+            return -(-L_out // tb) * -(-B // nb) * -(-M // BM)
+
+        wide = L.CFG_W128x64 if M >= 512 else L.CFG_W64x64
+        if ntiles(wide) >= eng.target_wgs * 3 // 4:
+            return wide
+        rows = B * L_out
+        return L.CFG_S16x16 if rows <= 16 else L.CFG_S16x32 if rows <= 32 else L.CFG_S16x64
+
+    def streams(self, B: int, L_out: int, M: int) -> bool:
+        return self.pick_cfg(B, L_out, M) in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
+
+    def _choose_tiles(self, a: L.ConvArgs, force=None, k_extra=0):
         """Tile heuristics.  Wide (W*) tiles when there are enough positions to fill the chip with
         64-row M tiles; otherwise 16-row streaming (S*) tiles whose 4 waves split K: a deep level
         is pure weight streaming and needs many small workgroups, not a big tile."""
@@ -366,15 +416,7 @@ class OpBuilder:
         if force is not None and "cfg" in force:
             cfg = force["cfg"]
         else:
-            wide = L.CFG_W128x64 if M >= 512 else L.CFG_W64x64
-            if tiles(wide)[4] >= eng.target_wgs * 3 // 4:
-                cfg = wide
-            elif rows <= 16:
-                cfg = L.CFG_S16x16
-            elif rows <= 32:
-                cfg = L.CFG_S16x32
-            else:
-                cfg = L.CFG_S16x64
+            cfg = self.pick_cfg(a.B, a.L_out, M)
         BM, BN, tb, nb, wgs = tiles(cfg)
         a.cfg, a.tb, a.nb = cfg, tb, nb
         splitk = 1
@@ -383,13 +425,14 @@ class OpBuilder:
         elif cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16) and a.pro_mode != L.PRO_SILU:
             # weight streaming needs ~2000 waves with a full prefetch ring in flight to approach HBM
             # bandwidth: split K across workgroups when the M tiles alone give too few of them
-            wbytes = a.taps * M * (a.c0 + a.c1) * (4 if eng.dt == L.F32 else 2)
+            G = a.taps * kch + k_extra          # the streaming kernel splits the flat (segment, chunk) list
+            wbytes = G * 32 * M * (4 if eng.dt == L.F32 else 2)
             if wbytes >= eng.splitk_min_bytes and wgs < eng.splitk_target_wgs:
                 want = -(-eng.splitk_target_wgs // wgs)
-                # every wave keeps >= 2 (tap, chunk) steps; 4 waves share one K slice
-                max_sk = max(1, (a.taps * kch) // 8)
+                # every wave keeps >= 2 chunks; 4 waves share one K slice
+                max_sk = max(1, G // 8)
                 splitk = max(1, min(want, max_sk, kch))
-                while splitk > 1 and (splitk - 1) * -(-kch // splitk) >= kch:
+                while splitk > 1 and ((splitk - 1) * -(-G // splitk) >= G or (splitk - 1) * -(-kch // splitk) >= kch):
                     splitk -= 1
         a.splitk = splitk
         cps = -(-kch // splitk)
@@ -468,16 +511,24 @@ class Plan(OpBuilder):
         self.conv(ops, src0=src0, src1=src1, src1_scale=sc, w=W.w[f"{n}.conv1"], bias=W.v[f"{n}.conv1.bias"], out=h,
                   taps=3, pad_left=pad, pro=L.PRO_GN_SILU,
                   gn=(r.groups, r.c_in, W.v[f"{n}.gn1.g"], W.v[f"{n}.gn1.b"], 1e-5))
+        y = self.new_act(src0.B, src0.L, r.c_out, gn=gn)
+        gn2 = (r.groups, r.c_out, W.v[f"{n}.gn2.g"], W.v[f"{n}.gn2.b"], 1e-5)
+        film = (self.film, self.film_row, W.film_off[n], r.c_out, self.step_idx if self.table_mode else None)
+        srcs_raw = [src0] + ([src1] if src1 is not None else [])
+        if r.has_shortcut and self.eng.fuse_shortcut and self.streams(src0.B, src0.L, r.c_out) \
+                and all(s_.ld == s_.C for s_ in srcs_raw) and 3 + len(srcs_raw) <= L.MAX_SEG:
+            # streaming level: the 1x1 shortcut is two more K segments of the second conv
+            self.conv(ops, src0=h, w=W.w[f"{n}.conv2s"], bias=W.v[f"{n}.conv2s.bias"], out=y, taps=3, pad_left=pad,
+                      pro=L.PRO_GN_SILU, gn=gn2, film=film, extra_segs=[(s_, 0) for s_ in srcs_raw])
+            return y
         if r.has_shortcut:
             res = self.new_act(src0.B, src0.L, r.c_out)
             self.conv(ops, src0=src0, src1=src1, src1_scale=1.0, w=W.w[f"{n}.short"], bias=W.v[f"{n}.short.bias"], out=res)
         else:
             assert src1 is None
             res = src0
-        y = self.new_act(src0.B, src0.L, r.c_out, gn=gn)
         self.conv(ops, src0=h, w=W.w[f"{n}.conv2"], bias=W.v[f"{n}.conv2.bias"], out=y, taps=3, pad_left=pad,
-                  pro=L.PRO_GN_SILU, gn=(r.groups, r.c_out, W.v[f"{n}.gn2.g"], W.v[f"{n}.gn2.b"], 1e-5),
-                  film=(self.film, self.film_row, W.film_off[n], r.c_out, self.step_idx if self.table_mode else None), residual=res)
+                  pro=L.PRO_GN_SILU, gn=gn2, film=film, residual=res)
         return y
 
     def transformer(self, t: TransformerSpec, x: Act, causal: bool) -> Act:
@@ -512,9 +563,12 @@ class Plan(OpBuilder):
         self.conv(ops, src0=a2, w=W.w[f"{n}.o2"], bias=W.v[f"{n}.o2.bias"], out=x3, residual=x2)
         f1 = self.new_act(Bf, Lx, Cc * t.multiplier)
         self.conv(ops, src0=x3, w=W.w[f"{n}.ff1"], bias=W.v[f"{n}.ff1.bias"], out=f1, act=L.ACT_GELU)
+        y = self.new_act(Bf, Lx, Cc, gn=True)
+        if eng.fuse_ff_out and self.streams(Bf, Lx, Cc) and x3.ld == Cc and f1.ld == f1.C:
+            self.conv(ops, src0=x3, w=W.w[f"{n}.ffp"], bias=W.v[f"{n}.ffp.bias"], out=y, extra_segs=[(f1, 0)])
+            return y
         x4 = self.new_act(Bf, Lx, Cc)
         self.conv(ops, src0=f1, w=W.w[f"{n}.ff2"], bias=W.v[f"{n}.ff2.bias"], out=x4, residual=x3)
-        y = self.new_act(Bf, Lx, Cc, gn=True)
         self.conv(ops, src0=x4, w=W.w[f"{n}.proj"], bias=W.v[f"{n}.proj.bias"], out=y)
         return y
 
@@ -745,6 +799,8 @@ class Engine:
         self.target_wgs = 256
         self.splitk_target_wgs = int(os.environ.get("JEN1_SPLITK_WGS", "128"))
         self.splitk_min_bytes = int(os.environ.get("JEN1_SPLITK_MIN_BYTES", str(2 << 20)))
+        self.fuse_shortcut = os.environ.get("JEN1_FUSE_SHORTCUT", "1") != "0"
+        self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
         self.plans: Dict[tuple, Plan] = {}
         self.load_params(params)
 
