@@ -192,6 +192,7 @@ class KernelCtx:
         self.splitk_min_bytes = 1 << 20
         self.fuse_shortcut = True
         self.fuse_ff_out = True
+        self.stream_bn = 64
 
 
 class OpBuilder:
@@ -392,7 +393,8 @@ class OpBuilder:
         if ntiles(wide) >= eng.target_wgs * 3 // 4:
             return wide
         rows = B * L_out
-        return L.CFG_S16x16 if rows <= 16 else L.CFG_S16x32 if rows <= 32 else L.CFG_S16x64
+        cap = eng.stream_bn
+        return L.CFG_S16x16 if (rows <= 16 or cap <= 16) else L.CFG_S16x32 if (rows <= 32 or cap <= 32) else L.CFG_S16x64
 
     def streams(self, B: int, L_out: int, M: int) -> bool:
         return self.pick_cfg(B, L_out, M) in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
@@ -798,7 +800,8 @@ class Engine:
         self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
         self.target_wgs = 256
         self.splitk_target_wgs = int(os.environ.get("JEN1_SPLITK_WGS", "128"))
-        self.splitk_min_bytes = int(os.environ.get("JEN1_SPLITK_MIN_BYTES", str(2 << 20)))
+        self.splitk_min_bytes = int(os.environ.get("JEN1_SPLITK_MIN_BYTES", str(8 << 20)))
+        self.stream_bn = int(os.environ.get("JEN1_STREAM_BN", "16"))
         self.fuse_shortcut = os.environ.get("JEN1_FUSE_SHORTCUT", "1") != "0"
         self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
         self.plans: Dict[tuple, Plan] = {}
