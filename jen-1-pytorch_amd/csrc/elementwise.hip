@@ -319,119 +319,6 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Pre-pass for the deep (streaming) levels: GroupNorm(+FiLM)(+SiLU) over the channel concat of two
-// sources, or LayerNorm, applied ONCE to a small channel-last tensor (reference blocks.py:140-144,
-// :427, :530, :732-734).  One thread = one 8-channel vector; one workgroup = 256 vectors of one
-// batch element; the group statistics of that element are merged from the fine-group sums in LDS.
-template <typename T>
-__global__ __launch_bounds__(256) void norm_apply_kernel(const jen1_norm_args a) {
-  __shared__ float grp[64];
-  const int b = blockIdx.y;
-  const int tid = threadIdx.x;
-  const int ctot = a.c0 + a.c1;
-  const bool gn = (a.mode == JEN1_PRO_GN || a.mode == JEN1_PRO_GN_SILU);
-  constexpr bool PRECISE = is_f32<T>::value;
-  // issue this thread's loads first
-  const int vpr = ctot >> 3;
-  const int v = blockIdx.x * 256 + tid;
-  const bool active = v < a.L * vpr;
-  const int row = active ? v / vpr : 0;
-  const int c = active ? (v - row * vpr) * 8 : 0;
-  float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float gam[8], bet[8], fs[8], fh[8];
-  float2 rsv = make_float2(0.f, 1.f);
-  if (active && !gn) rsv = *reinterpret_cast<const float2*>(a.ln_rowstats + ((size_t)b * a.L + row) * 2);
-  if (active) {
-    if (c < a.c0) load8(reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.L + row) * a.ld0 + c, x);
-    else load8(reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.L + row) * a.ld1 + (c - a.c0), x);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      gam[j] = a.gamma ? a.gamma[c + j] : 1.0f;
-      bet[j] = a.beta ? a.beta[c + j] : 0.0f;
-    }
-    if (gn && a.film) {
-      const int fr = a.film_step ? a.film_step[0] : (a.film_row ? a.film_row[b] : b);
-      const float* fp = a.film + (size_t)fr * a.film_ld + a.film_off + c;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        fs[j] = fp[j] + 1.0f;
-        fh[j] = fp[a.film_C + j];
-      }
-    }
-  }
-  if (gn) {
-    // 2 x 32 fine-group (sum, sumsq) pairs of this batch element: one load per thread, all in flight
-    // together (a per-group loop of dependent loads costs a memory latency per fine group)
-    __shared__ float fine[128];
-    if (tid < 64) {
-      const int src = tid >> 5, f = tid & 31;
-      const float* st = src ? a.gn_stats1 : a.gn_stats0;
-      float2 v = make_float2(0.f, 0.f);
-      if (st) v = *reinterpret_cast<const float2*>(st + (size_t)b * 64 + 2 * f);
-      fine[2 * tid] = v.x;
-      fine[2 * tid + 1] = v.y;
-    }
-    __syncthreads();
-    if (tid < a.groups) {
-      const int g = tid;
-      int lo = g * a.cpg, hi = (g == a.groups - 1) ? ctot : lo + a.cpg;
-      int src = 0, cpf;
-      float sc = 1.f;
-      if (lo >= a.c0) {
-        src = 1;
-        lo -= a.c0; hi -= a.c0;
-        cpf = a.c1 / JEN1_FINE_GROUPS;
-        sc = a.src1_scale;
-      } else {
-        cpf = a.c0 / JEN1_FINE_GROUPS;
-        if (hi > a.c0) hi = a.c0;
-      }
-      float s = 0.f, q = 0.f;
-      for (int f = lo / cpf; f < (hi + cpf - 1) / cpf; ++f) {
-        s += fine[2 * (src * 32 + f)];
-        q += fine[2 * (src * 32 + f) + 1];
-      }
-      s *= sc;
-      q *= sc * sc;
-      const float inv_n = 1.0f / (float)a.count;
-      const float mean = s * inv_n;
-      float var = q * inv_n - mean * mean;
-      var = var < 0.f ? 0.f : var;
-      grp[2 * g] = mean;
-      grp[2 * g + 1] = PRECISE ? 1.0f / sqrtf(var + a.eps) : rsqrtf(var + a.eps);
-    }
-    __syncthreads();
-  }
-  if (!active) return;
-  if (gn) {
-    const float sc = (c >= a.c0) ? a.src1_scale : 1.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int g = (c + j) / a.cpg;
-      g = g < a.groups ? g : a.groups - 1;
-      float A = grp[2 * g + 1] * gam[j];
-      float Bc = bet[j] - grp[2 * g] * A;
-      A *= sc;
-      if (a.film) {
-        A *= fs[j];
-        Bc = Bc * fs[j] + fh[j];
-      }
-      x[j] = x[j] * A + Bc;
-      if (a.mode == JEN1_PRO_GN_SILU) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
-    }
-  } else {
-    const float inv_c = 1.0f / (float)a.count;
-    const float mean = rsv.x * inv_c;
-    float var = rsv.y * inv_c - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    const float rstd = PRECISE ? 1.0f / sqrtf(var + a.eps) : rsqrtf(var + a.eps);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (x[j] - mean) * rstd * gam[j] + bet[j];
-  }
-  store8(reinterpret_cast<T*>(a.y) + ((size_t)b * a.L + row) * a.ld_y + c, x);
-}
-
 }  // namespace
 
 extern "C" int jen1_pack_input(const float* x, const float* ctx, void* y, float* gn_stats, int B, int C, int Cc, int T,
@@ -539,27 +426,4 @@ extern "C" int jen1_cfg_combine(const void* net, float* out, int B, int C, int T
                                 int scale_cfg, float scale_phi, int dtype, void* stream) {
   return launch_cfg<false>(net, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, B, C, T, ld, 2, embedding_scale,
                            scale_cfg, scale_phi, 0, 0, dtype, stream);
-}
-
-extern "C" int jen1_norm_apply(const jen1_norm_args* a, void* stream) {
-  JEN1_CHECK(a && a->x0 && a->y, "norm_apply: null pointer");
-  JEN1_CHECK(a->dtype == JEN1_F32 || a->dtype == JEN1_BF16, "norm_apply: bad dtype");
-  JEN1_CHECK(a->c0 > 0 && a->c0 % 8 == 0 && a->c1 >= 0 && a->c1 % 8 == 0 && (a->c1 == 0 || a->x1), "norm_apply: bad channels");
-  JEN1_CHECK(a->ld_y >= a->c0 + a->c1 && a->ld_y % 8 == 0, "norm_apply: bad ld_y");
-  const bool gn = (a->mode == JEN1_PRO_GN || a->mode == JEN1_PRO_GN_SILU);
-  JEN1_CHECK(gn || a->mode == JEN1_PRO_LN, "norm_apply: bad mode %d", a->mode);
-  if (gn) {
-    JEN1_CHECK(a->gn_stats0 && a->gamma && a->beta && a->groups >= 1 && a->groups <= 32 && a->cpg >= 1 && a->count >= 1, "norm_apply: incomplete GroupNorm");
-    JEN1_CHECK(a->c0 % 32 == 0 && a->c1 % 32 == 0, "norm_apply: GroupNorm sources must be multiples of 32 channels");
-    JEN1_CHECK(a->c1 == 0 || (a->gn_stats1 && a->c0 % a->cpg == 0), "norm_apply: bad two-source GroupNorm");
-  } else {
-    JEN1_CHECK(a->ln_rowstats && a->c1 == 0 && a->count >= 1, "norm_apply: incomplete LayerNorm");
-  }
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nvec = a->L * ((a->c0 + a->c1) / 8);
-  dim3 grid((nvec + 255) / 256, a->B);
-  if (a->dtype == JEN1_F32) hipLaunchKernelGGL(norm_apply_kernel<float>, grid, dim3(256), 0, s, *a);
-  else hipLaunchKernelGGL(norm_apply_kernel<bf16_t>, grid, dim3(256), 0, s, *a);
-  JEN1_HIP(hipGetLastError());
-  return 0;
 }

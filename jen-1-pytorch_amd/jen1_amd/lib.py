@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip"]
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4

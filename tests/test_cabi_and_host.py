@@ -53,6 +53,7 @@ def test_struct_layout_matches_header():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(jen1_conv_args), offsetof(jen1_conv_args, dtype), offsetof(jen1_conv_args, gn_eps),
          offsetof(jen1_conv_args, cfg), offsetof(jen1_conv_args, zeros), offsetof(jen1_conv_args, ln_fold), sizeof(jen1_norm_args));
+  printf("%zu %zu %zu %d\n", offsetof(jen1_conv_args, nseg), offsetof(jen1_conv_args, seg), sizeof(jen1_conv_seg), JEN1_MAX_SEG);
   return 0;
 }
 '''
@@ -62,7 +63,8 @@ int main(void) {
         subprocess.run(["gcc", "-I", os.path.dirname(HEADER), src, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     a = L.ConvArgs
-    want = [C.sizeof(a), a.dtype.offset, a.gn_eps.offset, a.cfg.offset, a.zeros.offset, a.ln_fold.offset, C.sizeof(L.NormArgs)]
+    want = [C.sizeof(a), a.dtype.offset, a.gn_eps.offset, a.cfg.offset, a.zeros.offset, a.ln_fold.offset, C.sizeof(L.NormArgs),
+            a.nseg.offset, a.seg.offset, C.sizeof(L.ConvSeg), L.MAX_SEG]
     assert got == want
 
 
@@ -80,6 +82,15 @@ def test_argument_validation_reports_errors_without_a_gpu(lib):
     assert b"exceeds BN" in lib.jen1_last_error()
     a.tb, a.nb, a.direct, a.pro_mode = 10, 1, 1, L.PRO_GN_SILU
     assert lib.jen1_conv_gemm(C.byref(a), None) != 0          # incomplete GroupNorm prologue / direct with prologue
+    # explicit K segments: only in direct mode, every segment needs a pointer and a sane pitch
+    a.pro_mode, a.direct, a.nseg = L.PRO_NONE, 0, 2
+    assert lib.jen1_conv_gemm(C.byref(a), None) != 0 and b"need direct mode" in lib.jen1_last_error()
+    a.direct = 1
+    a.seg[0].x, a.seg[0].ld, a.seg[0].kch = 16, 64, 2
+    a.seg[1].x, a.seg[1].ld, a.seg[1].kch = 16, 32, 2            # pitch smaller than the channels it claims
+    assert lib.jen1_conv_gemm(C.byref(a), None) != 0 and b"bad K segment 1" in lib.jen1_last_error()
+    a.nseg = L.MAX_SEG + 1
+    assert lib.jen1_conv_gemm(C.byref(a), None) != 0 and b"bad nseg" in lib.jen1_last_error()
     assert lib.jen1_attention(None, None, None, None, None, None, None, None, 0, 0, 0, 1, 1, 8, 1, 1, 8, 0, 8, 0, 0, 8, 0,
                               1.0, L.F32, None) != 0
     n = L.NormArgs()

@@ -211,6 +211,44 @@ def test_groupnorm_film_silu_prologue(ctx, two_src, film):
         assert rel_err(out.rs.cpu().numpy(), exp.rs.cpu().numpy()) < 2e-3, force
 
 
+@pytest.mark.parametrize("splitk", [1, 2])
+@pytest.mark.parametrize("Ln", [1, 2, 13])
+def test_extra_k_segments_fused_shortcut(ctx, splitk, Ln):
+    """ResnetBlock1d second half on a streaming level: conv k=3 over GroupNorm+SiLU(h) plus the 1x1 shortcut over
+    the raw [x, skip] as two extra K segments of the same launch (blocks.py:219-231, :732-734); Ln = 1, 2 exercise
+    the dead-segment skip (taps that only see zero padding)."""
+    from jen1_amd import lib as L
+    from jen1_amd.engine import OpBuilder
+    from jen1_amd.packing import conv_weight_to_gemm, pack_gemm_weight
+    kc, mode = ctx
+    torch.manual_seed(5 + Ln)
+    B, Ch, C0, C1, Co, G = 4, 64, 64, 32, 128, 8
+    h = torch.randn(B, Ch, Ln, device="cuda") * 1.3 + 0.2
+    x0 = torch.randn(B, C0, Ln, device="cuda")
+    x1 = torch.randn(B, C1, Ln, device="cuda")
+    gam, bet = torch.rand(Ch, device="cuda") + 0.5, torch.randn(Ch, device="cuda") * 0.1
+    w2 = torch.randn(Co, Ch, 3, device="cuda") / (Ch * 3) ** 0.5
+    ws = torch.randn(Co, C0 + C1, 1, device="cuda") / (C0 + C1) ** 0.5
+    b2, bs = torch.randn(Co, device="cuda") * 0.1, torch.randn(Co, device="cuda") * 0.1
+    ref = F.conv1d(F.pad(F.silu(F.group_norm(h, G, gam, bet, 1e-5)), (1, 1)), w2, b2) + F.conv1d(torch.cat([x0, x1], 1), ws, bs)
+    wf = torch.cat([pack_gemm_weight(conv_weight_to_gemm(w2), kc.tdtype).flatten(0, 1),
+                    pack_gemm_weight(conv_weight_to_gemm(ws), kc.tdtype).flatten(0, 1)], 0).contiguous()
+    ob = OpBuilder(kc)
+    out = new_out(kc, B, Ln, Co, gn=True, rs=True)
+    ob.conv(ob.ops, src0=to_cl(h, kc), w=wf, bias=b2 + bs, out=out, taps=3, pad_left=1, pro=L.PRO_GN_SILU,
+            gn=(G, Ch, gam, bet, 1e-5), extra_segs=[(to_cl(x0, kc), 0), (to_cl(x1, kc), 0)],
+            force={"cfg": L.CFG_S16x16 if B * Ln <= 16 else L.CFG_S16x64, "splitk": splitk})
+    run(ob)
+    y = from_cl(out)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TOL[mode]
+    # the kernel sums the float32 values it is about to round; with Ln = 1 a fine group holds 4 numbers, so in
+    # bf16 mode the sums of the ROUNDED outputs differ by up to one bf16 ulp of an element
+    exp = to_cl(y, kc)
+    stol = 2e-3 if mode == "f32" else 1e-2
+    assert rel_err(out.gn.cpu().numpy(), exp.gn.cpu().numpy()) < stol
+    assert rel_err(out.rs.cpu().numpy(), exp.rs.cpu().numpy()) < stol
+
+
 def test_layernorm_prologue_gelu_rowscale(ctx):
     """Linear(LayerNorm(x)) with GELU epilogue and a row mask (blocks.py:427-434, :440-446)."""
     from jen1_amd import lib as L
