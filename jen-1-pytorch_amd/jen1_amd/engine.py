@@ -193,6 +193,7 @@ class KernelCtx:
         self.fuse_shortcut = True
         self.fuse_ff_out = True
         self.stream_bn = 64
+        self.stream_max_wgs = 100000
 
 
 class OpBuilder:
@@ -379,22 +380,32 @@ class OpBuilder:
         ops.append(fn)
         return out
 
+    @staticmethod
+    def tile_geometry(B: int, L_out: int, BN: int):
+        """positions per tile (balanced over the tiles of a row: 24 positions in 16-wide tiles are 12 + 12,
+        not 16 + 8) and batch elements per tile"""
+        nt = -(-L_out // BN)
+        tb = -(-L_out // nt)
+        nb = max(1, min(B, BN // tb))
+        return tb, nb, nt * -(-B // nb)
+
     def pick_cfg(self, B: int, L_out: int, M: int) -> int:
         """wide tile when the positions alone fill the chip with 64-row M tiles, else a 16-row streaming tile"""
         lib, eng = self.eng.lib, self.eng
 
         def ntiles(cfg):
             BM, BN = lib.jen1_cfg_bm(cfg), lib.jen1_cfg_bn(cfg)
-            tb = min(L_out, BN)
-            nb = max(1, min(B, BN // tb))
-            return -(-L_out // tb) * -(-B // nb) * -(-M // BM)
+            return self.tile_geometry(B, L_out, BN)[2] * -(-M // BM)
 
         wide = L.CFG_W128x64 if M >= 512 else L.CFG_W64x64
         if ntiles(wide) >= eng.target_wgs * 3 // 4:
             return wide
-        rows = B * L_out
-        cap = eng.stream_bn
-        return L.CFG_S16x16 if (rows <= 16 or cap <= 16) else L.CFG_S16x32 if (rows <= 32 or cap <= 32) else L.CFG_S16x64
+        # streaming: the narrowest tile (least activation traffic through each CU's L1) unless that makes
+        # more workgroups than the chip holds at once
+        for cfg, bn in ((L.CFG_S16x16, 16), (L.CFG_S16x32, 32)):
+            if bn <= eng.stream_bn and (ntiles(cfg) <= eng.stream_max_wgs or bn == eng.stream_bn):
+                return cfg
+        return L.CFG_S16x64
 
     def streams(self, B: int, L_out: int, M: int) -> bool:
         return self.pick_cfg(B, L_out, M) in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
@@ -411,9 +422,8 @@ class OpBuilder:
 
         def tiles(cfg):
             BM, BN = lib.jen1_cfg_bm(cfg), lib.jen1_cfg_bn(cfg)
-            tb = min(a.L_out, BN)
-            nb = max(1, min(a.B, BN // tb))
-            return BM, BN, tb, nb, -(-a.L_out // tb) * -(-a.B // nb) * -(-M // BM)
+            tb, nb, nt = self.tile_geometry(a.B, a.L_out, BN)
+            return BM, BN, tb, nb, nt * -(-M // BM)
 
         if force is not None and "cfg" in force:
             cfg = force["cfg"]
@@ -801,7 +811,8 @@ class Engine:
         self.target_wgs = 256
         self.splitk_target_wgs = int(os.environ.get("JEN1_SPLITK_WGS", "128"))
         self.splitk_min_bytes = int(os.environ.get("JEN1_SPLITK_MIN_BYTES", str(8 << 20)))
-        self.stream_bn = int(os.environ.get("JEN1_STREAM_BN", "16"))
+        self.stream_bn = int(os.environ.get("JEN1_STREAM_BN", "64"))
+        self.stream_max_wgs = int(os.environ.get("JEN1_STREAM_MAX_WGS", "768"))
         self.fuse_shortcut = os.environ.get("JEN1_FUSE_SHORTCUT", "1") != "0"
         self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
         self.plans: Dict[tuple, Plan] = {}
