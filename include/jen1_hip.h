@@ -139,6 +139,12 @@ typedef struct jen1_conv_args {
   int32_t nseg;              /* direct mode: > 0 = explicit K segments below (x0/x1/c0/c1/taps/pad_left are
                                 then ignored); 0 = segments derived as (tap, source) pairs */
   jen1_conv_seg seg[JEN1_MAX_SEG];
+  int32_t m_split;           /* direct mode, 0 = off: a dual-range GEMM that produces two dependent layers in one
+                                launch, e.g. [x3 | f] = [x2 + W_o a ; gelu(W_1 W_o a + W_1 x2 + b)]
+                                (blocks.py:485-488, :440-446).  Output rows m < m_split sum only the first k_split
+                                chunks of K, take the residual and feed out_rowstats; rows >= m_split sum all of K
+                                and take `act`.  Multiple of 16. */
+  int32_t k_split;           /* 32-channel chunks of K summed by the rows below m_split */
 } jen1_conv_args;
 
 int jen1_conv_gemm(const jen1_conv_args* args, void* stream);

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
                                                          int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off,
                                                          int ldo, int causal, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  jen1_prefetch_kernarg<128>();
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh - b * H;
   const int q0 = blockIdx.y * QCHUNK;

@@ -101,6 +101,48 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 __device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Touch the kernel-argument segment with one batch of scalar loads (one per 64-byte line, results discarded;
+// never past the last line that holds an explicit argument).  hipcc sinks kernarg reads next to their uses,
+// often behind uniform branches; on a cold scalar cache each of those is a serial memory round trip.  After
+// this batch they all hit.
+template <int NBYTES>
+__device__ __forceinline__ void jen1_prefetch_kernarg() {
+  const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int FULL = (NBYTES + 63) / 64;
+  constexpr int LINES = FULL >= 16 ? 16 : FULL >= 12 ? 12 : FULL >= 8 ? 8 : FULL >= 4 ? 4 : FULL >= 2 ? 2 : 0;
+  unsigned t[16];
+  if constexpr (LINES == 2) {
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t[0]), "=&s"(t[1])
+                 : "s"(kp)
+                 : "memory");
+  }
+  if constexpr (LINES == 4) {
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t[0]), "=&s"(t[1]), "=&s"(t[2]), "=&s"(t[3])
+                 : "s"(kp)
+                 : "memory");
+  }
+  if constexpr (LINES == 8) {
+    asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t[0]), "=&s"(t[1]), "=&s"(t[2]), "=&s"(t[3]), "=&s"(t[4]), "=&s"(t[5]), "=&s"(t[6]), "=&s"(t[7])
+                 : "s"(kp)
+                 : "memory");
+  }
+  if constexpr (LINES == 12) {
+    asm volatile("s_load_dword %0, %12, 0x0\n\ts_load_dword %1, %12, 0x40\n\ts_load_dword %2, %12, 0x80\n\ts_load_dword %3, %12, 0xc0\n\ts_load_dword %4, %12, 0x100\n\ts_load_dword %5, %12, 0x140\n\ts_load_dword %6, %12, 0x180\n\ts_load_dword %7, %12, 0x1c0\n\ts_load_dword %8, %12, 0x200\n\ts_load_dword %9, %12, 0x240\n\ts_load_dword %10, %12, 0x280\n\ts_load_dword %11, %12, 0x2c0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t[0]), "=&s"(t[1]), "=&s"(t[2]), "=&s"(t[3]), "=&s"(t[4]), "=&s"(t[5]), "=&s"(t[6]), "=&s"(t[7]), "=&s"(t[8]), "=&s"(t[9]), "=&s"(t[10]), "=&s"(t[11])
+                 : "s"(kp)
+                 : "memory");
+  }
+  if constexpr (LINES == 16) {
+    asm volatile("s_load_dword %0, %16, 0x0\n\ts_load_dword %1, %16, 0x40\n\ts_load_dword %2, %16, 0x80\n\ts_load_dword %3, %16, 0xc0\n\ts_load_dword %4, %16, 0x100\n\ts_load_dword %5, %16, 0x140\n\ts_load_dword %6, %16, 0x180\n\ts_load_dword %7, %16, 0x1c0\n\ts_load_dword %8, %16, 0x200\n\ts_load_dword %9, %16, 0x240\n\ts_load_dword %10, %16, 0x280\n\ts_load_dword %11, %16, 0x2c0\n\ts_load_dword %12, %16, 0x300\n\ts_load_dword %13, %16, 0x340\n\ts_load_dword %14, %16, 0x380\n\ts_load_dword %15, %16, 0x3c0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t[0]), "=&s"(t[1]), "=&s"(t[2]), "=&s"(t[3]), "=&s"(t[4]), "=&s"(t[5]), "=&s"(t[6]), "=&s"(t[7]), "=&s"(t[8]), "=&s"(t[9]), "=&s"(t[10]), "=&s"(t[11]), "=&s"(t[12]), "=&s"(t[13]), "=&s"(t[14]), "=&s"(t[15])
+                 : "s"(kp)
+                 : "memory");
+  }
+}
+
 template <typename T>
 struct is_f32 {
   static constexpr bool value = false;

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_gemm_kernel(const jen1_conv
   const int wm = wave % WM, wk = wave / WM;
   const int li = lane & 15, lg = lane >> 4;
 
+  jen1_prefetch_kernarg<sizeof(jen1_conv_args)>();
   JEN1_STAMP(0);
   const Layout L = make_layout(a, (int)sizeof(T), RED_FLOATS);
   T* tile = reinterpret_cast<T*>(smem + L.tile_off);
@@ -837,6 +838,9 @@ static int validate(const jen1_conv_args& a) {
   JEN1_CHECK(!a.ln_fold || (a.direct && a.ln_u && a.ln_rowstats && a.ln_C >= 1 && (a.nseg > 0 ? (a.nseg == 1 && a.seg[0].shift == 0) : (a.taps == 1 && a.pad_left == 0 && a.c1 == 0)) &&
                             a.stride == 1 && a.L_out == a.L_in && a.ps_f == 1 && a.pro_mode == JEN1_PRO_NONE),
              "conv_gemm: ln_fold needs direct mode, ln_u / ln_rowstats, one unshifted segment and no prologue");
+  JEN1_CHECK(a.m_split == 0 || (a.direct && a.m_split % 16 == 0 && a.m_split > 0 && a.m_split < a.M && a.k_split >= 1 && a.k_split <= kch &&
+                               a.ps_f == 1 && !a.ln_fold && !a.out_gn_stats),
+             "conv_gemm: bad dual-range split (m_split=%d k_split=%d)", a.m_split, a.k_split);
   if (!a.direct) {
     const Layout L = make_layout(a, a.dtype == JEN1_F32 ? 4 : 2, cfg_red_floats(a.cfg));
     JEN1_CHECK(L.total <= 160 * 1024, "conv_gemm: LDS request %d B exceeds 160 KiB (tb=%d nb=%d kc_stage=%d)", L.total, a.tb, a.nb, a.kc_stage);

@@ -52,6 +52,9 @@ struct HotArgs {
   float inv_tiles_t, inv_tb;
   int32_t nseg;
   SegDev first[4];    // copies of seg[0..3]: the first usable segment is picked without a dependent load
+  int32_t mt_split;   // dual-range GEMM: M tiles below it sum only the first g_split chunks (0 = off)
+  int32_t g_split;
+  int32_t pad[6];
 };
 struct EpiArgs {
   const float* bias;          // every pointer has a byte extent: 0 = absent (descriptor loads return 0)
@@ -76,7 +79,7 @@ struct StreamArgs {
   SegDev seg[JEN1_MAX_SEG];
 };
 
-static_assert(sizeof(HotArgs) == 160 && sizeof(EpiArgs) == 144 && offsetof(StreamArgs, epi) == 160, "kernarg blocks are read with fixed-size scalar loads");
+static_assert(sizeof(HotArgs) == 192 && sizeof(EpiArgs) == 144 && offsetof(StreamArgs, epi) == 192, "kernarg blocks are read with fixed-size scalar loads");
 
 typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
@@ -85,27 +88,24 @@ typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 // uses behind uniform branches: 6-8 dependent scalar-memory round trips before the first weight load.)
 __device__ __forceinline__ HotArgs load_hot_args() {
   const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-  u32x16 k0, k1;
-  u32x8 k2;
+  u32x16 k0, k1, k2;
   unsigned t0, t1, t2, t3;
   // the four single-dword loads only pull the epilogue block and the head of the segment table into the
   // scalar cache, so that the later batches hit it instead of paying a memory round trip
-  asm volatile("s_load_dwordx16 %0, %7, 0x0\n\ts_load_dwordx16 %1, %7, 0x40\n\ts_load_dwordx8 %2, %7, 0x80\n\t"
+  asm volatile("s_load_dwordx16 %0, %7, 0x0\n\ts_load_dwordx16 %1, %7, 0x40\n\ts_load_dwordx16 %2, %7, 0x80\n\t"
                "s_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\t"
                "s_waitcnt lgkmcnt(0)"
                : "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(kp) : "memory");
-  struct Raw { unsigned d[40]; } raw;
+  struct Raw { unsigned d[48]; } raw;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { raw.d[i] = k0[i]; raw.d[16 + i] = k1[i]; }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) raw.d[32 + i] = k2[i];
+  for (int i = 0; i < 16; ++i) { raw.d[i] = k0[i]; raw.d[16 + i] = k1[i]; raw.d[32 + i] = k2[i]; }
   return __builtin_bit_cast(HotArgs, raw);
 }
 __device__ __forceinline__ EpiArgs load_epi_args() {
   const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
   u32x16 k0, k1;
   u32x4 k2;
-  asm volatile("s_load_dwordx16 %0, %3, 0xa0\n\ts_load_dwordx16 %1, %3, 0xe0\n\ts_load_dwordx4 %2, %3, 0x120\n\ts_waitcnt lgkmcnt(0)"
+  asm volatile("s_load_dwordx16 %0, %3, 0xc0\n\ts_load_dwordx16 %1, %3, 0x100\n\ts_load_dwordx4 %2, %3, 0x140\n\ts_waitcnt lgkmcnt(0)"
                : "=&s"(k0), "=&s"(k1), "=&s"(k2) : "s"(kp) : "memory");
   struct Raw { unsigned d[36]; } raw;
 #pragma unroll
@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
   const int b0 = bt * h.nb, t0 = tt * h.tb;
   const int mt = blockIdx.x, z = blockIdx.z;
   const int g0 = z * h.cps;
-  const int g1 = (g0 + h.cps < h.G) ? g0 + h.cps : h.G;
+  const bool low_m = mt < h.mt_split;         // dual-range GEMM (see jen1_conv_args.m_split)
+  const int g_end = low_m ? h.g_split : h.G;
+  const int g1 = (g0 + h.cps < g_end) ? g0 + h.cps : g_end;
   const int t_last = ((t0 + h.tb < h.L_out) ? t0 + h.tb : h.L_out) - 1;
   const int n_rows = h.nb * h.tb;
   const int tmin = t0 * h.stride, tmax = t_last * h.stride;
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
   auto request_epilogue_operands = [&]() {
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.bias), 0, (int)e.bias_bytes, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t r_lnu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.ln_u), 0, (int)e.lnu_bytes, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e.residual), 0, (int)e.res_bytes, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e.residual), 0,
+                                                                           (h.mt_split == 0 || low_m) ? (int)e.res_bytes : 0, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t r_rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.row_scale), 0, (int)e.rsc_bytes, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t r_lnrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.ln_rowstats), 0, (int)e.lnrs_bytes, RSRC_FLAGS);
     const int m = mt * 16 + lg * 4;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[nf][r] + bias4[r];
       }
-      if (e.act == JEN1_ACT_GELU) {
+      if (e.act == JEN1_ACT_GELU && !low_m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       }
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
           }
         }
       }
-      if (e.out_rowstats) {
+      if (e.out_rowstats && (h.mt_split == 0 || low_m)) {
         s2 += __shfl_xor(s2, 16); q2 += __shfl_xor(q2, 16);
         s2 += __shfl_xor(s2, 32); q2 += __shfl_xor(q2, 32);
         if (lg == 0 && okk[nf]) {
@@ -612,6 +615,8 @@ int jen1_stream_gemm_launch(const jen1_conv_args& a, void* stream) {
   h.tiles_t = (a.L_out + a.tb - 1) / a.tb;
   h.inv_tiles_t = 1.0f / (float)h.tiles_t;
   h.inv_tb = 1.0f / (float)a.tb;
+  h.mt_split = a.m_split / 16;
+  h.g_split = a.m_split ? a.k_split : 0;
   // ---- epilogue ----------------------------------------------------------------------------------
   const int64_t y_rows = (int64_t)a.B * a.y_brows;
   JEN1_CHECK(y_rows * a.ld_y * 4 < (int64_t)OOB && (!a.residual || y_rows * a.ld_res * es < (int64_t)OOB),

@@ -44,11 +44,19 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 class Act:
-    """a channel-last activation [B][L][ld] plus the statistics its consumers need."""
-    __slots__ = ("t", "B", "L", "C", "ld", "gn", "rs")
+    """a channel-last activation [B][L][ld] plus the statistics its consumers need.
+    ``ld`` is the row pitch; ``cp`` the channels a GEMM reads (C padded to 32): they differ only for a column
+    window of a wider tensor (``cols``)."""
+    __slots__ = ("t", "B", "L", "C", "ld", "gn", "rs", "cp")
 
-    def __init__(self, t, B, L, C, ld, gn=None, rs=None):
+    def __init__(self, t, B, L, C, ld, gn=None, rs=None, cp=None):
         self.t, self.B, self.L, self.C, self.ld, self.gn, self.rs = t, B, L, C, ld, gn, rs
+        self.cp = cp if cp is not None else ld
+
+    def cols(self, c0: int, n: int, rs=None) -> "Act":
+        """channels [c0, c0 + n) of this tensor as an activation of its own (same row pitch)"""
+        assert c0 % 32 == 0 and n % 32 == 0 and c0 + n <= self.ld
+        return Act(self.t[:, :, c0:], self.B, self.L, n, self.ld, None, rs, cp=n)
 
 
 class Weights:
@@ -161,6 +169,15 @@ class Weights:
             self.v[f"{n}.ff1.bias"] = f32(p[f"{b}.feed_forward.0.bias"])
             self.w[f"{n}.ff2"] = pk(p[f"{b}.feed_forward.2.weight"][None])
             self.v[f"{n}.ff2.bias"] = f32(p[f"{b}.feed_forward.2.bias"])
+            # streaming levels: cross-attention output projection and the first FeedForward layer as ONE
+            # dual-range GEMM over the K concat [a | x2]:  x3 = x2 + W_o a + b_o  (rows < C, K = a only) and
+            # f = gelu(W_1 x3 + b_1) = gelu((W_1 W_o) a + W_1 x2 + W_1 b_o + b_1)   (blocks.py:485-488, :440-446)
+            wo64, w164 = p[f"{x}.attention.to_out.weight"].double(), p[f"{b}.feed_forward.0.weight"].double()
+            top = torch.cat([wo64, torch.zeros(wo64.shape[0], w164.shape[1], dtype=torch.float64, device=device)], 1)
+            bot = torch.cat([w164 @ wo64, w164], 1)
+            self.w[f"{n}.o2f1"] = pk(torch.cat([top, bot], 0).float()[None]).flatten(0, 1).contiguous()
+            self.v[f"{n}.o2f1.bias"] = torch.cat([p[f"{x}.attention.to_out.bias"].double(),
+                                                  p[f"{b}.feed_forward.0.bias"].double() + w164 @ p[f"{x}.attention.to_out.bias"].double()]).float().contiguous()
             # streaming levels: the output 1x1 conv applied to x + ff2(f) is ONE GEMM over the K concat
             # [x | f] with weights [P | P @ W_ff2] (blocks.py:446, :488, :536): no x4 round trip
             wp64 = p[f"{n}.conv1d.conv.weight"][:, :, 0].double()
@@ -192,6 +209,7 @@ class KernelCtx:
         self.splitk_min_bytes = 1 << 20
         self.fuse_shortcut = True
         self.fuse_ff_out = True
+        self.fuse_o2_ff1 = True
         self.stream_bn = 64
         self.stream_max_wgs = 100000
 
@@ -238,14 +256,14 @@ class OpBuilder:
     def conv(self, ops, *, src0: Act, w: torch.Tensor, bias, out: Act, taps=1, stride=1, pad_left=0, L_out=None,
              src1: Optional[Act] = None, src1_scale=1.0, ps_f=1, ps_off=0, L_y=None, y_row0=0, pro=L.PRO_NONE,
              gn=None, film=None, ln=None, act=L.ACT_NONE, residual: Optional[Act] = None, row_scale=None,
-             y_f32=False, out_C=None, force=None, label="", extra_segs=None):
+             y_f32=False, out_C=None, force=None, label="", extra_segs=None, m_split=0, k_split=0):
         """extra_segs: [(Act, row_shift)] raw sources appended to the K axis after the (tap, source) pairs of
         src0/src1 (streaming / direct mode only); ``w`` is then the flat packed weight [chunks][M/16][64][8]."""
         eng = self.eng
         a = L.ConvArgs()
-        a.x0, a.c0, a.ld0 = src0.t.data_ptr(), src0.ld, src0.ld
+        a.x0, a.c0, a.ld0 = src0.t.data_ptr(), src0.cp, src0.ld
         if src1 is not None:
-            a.x1, a.c1, a.ld1 = src1.t.data_ptr(), src1.ld, src1.ld
+            a.x1, a.c1, a.ld1 = src1.t.data_ptr(), src1.cp, src1.ld
             assert src1.L == src0.L and src1.B == src0.B
         a.w, a.bias = w.data_ptr(), _ptr(bias)
         a.dtype = eng.dt
@@ -256,7 +274,7 @@ class OpBuilder:
         a.out_C, a.ps_f, a.ps_off = out_C, ps_f, ps_off
         a.M = out_C * ps_f
         if extra_segs:
-            k_extra = sum(e.ld for e, _ in extra_segs)
+            k_extra = sum(e.cp for e, _ in extra_segs)
             assert w.dim() == 4 and w.shape[1] * 16 == a.M and w.shape[0] * 32 == taps * (a.c0 + a.c1) + k_extra, \
                 (tuple(w.shape), taps, a.M, a.c0, a.c1, k_extra)
         else:
@@ -299,7 +317,7 @@ class OpBuilder:
             a.out_gn_stats, a.out_cpf = out.gn.data_ptr(), out.ld // FG
         if out.rs is not None:
             a.out_rowstats = out.rs.data_ptr()
-        self._choose_tiles(a, force, k_extra=(sum(e.ld for e, _ in extra_segs) // 32 if extra_segs else 0))
+        self._choose_tiles(a, force, k_extra=(sum(e.cp for e, _ in extra_segs) // 32 if extra_segs else 0))
         lib = eng.lib
         streaming = a.cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
         want_direct = streaming and (force is None or force.get("direct", True))
@@ -346,6 +364,9 @@ class OpBuilder:
             a.direct = 0          # a raw scaled second source needs the LDS path (or pre-scaled weights)
         if a.direct:
             a.kc_stage = max(1, (a.c0 + a.c1) // 32)
+        if m_split:
+            assert a.direct, "a dual-range GEMM needs the streaming (direct) mode"
+            a.m_split, a.k_split = m_split, k_split
         if extra_segs:
             assert a.direct, "extra K segments need the streaming (direct) mode"
             segs = []
@@ -355,7 +376,7 @@ class OpBuilder:
                     segs.append((a.x1, a.ld1, tap - pad_left, a.c1 // 32))
             for e, sh in extra_segs:
                 assert e.B == a.B and e.L == a.L_in and e.t.dtype == eng.tdtype
-                segs.append((e.t.data_ptr(), e.ld, sh, e.ld // 32))
+                segs.append((e.t.data_ptr(), e.ld, sh, e.cp // 32))
             assert len(segs) <= L.MAX_SEG
             a.nseg = len(segs)
             for i, (xp, ld, sh, kch) in enumerate(segs):
@@ -528,7 +549,7 @@ class Plan(OpBuilder):
         film = (self.film, self.film_row, W.film_off[n], r.c_out, self.step_idx if self.table_mode else None)
         srcs_raw = [src0] + ([src1] if src1 is not None else [])
         if r.has_shortcut and self.eng.fuse_shortcut and self.streams(src0.B, src0.L, r.c_out) \
-                and all(s_.ld == s_.C for s_ in srcs_raw) and 3 + len(srcs_raw) <= L.MAX_SEG:
+                and all(s_.cp == s_.C for s_ in srcs_raw) and 3 + len(srcs_raw) <= L.MAX_SEG:
             # streaming level: the 1x1 shortcut is two more K segments of the second conv
             self.conv(ops, src0=h, w=W.w[f"{n}.conv2s"], bias=W.v[f"{n}.conv2s.bias"], out=y, taps=3, pad_left=pad,
                       pro=L.PRO_GN_SILU, gn=gn2, film=film, extra_segs=[(s_, 0) for s_ in srcs_raw])
@@ -571,12 +592,19 @@ class Plan(OpBuilder):
                        extra_row=self.extra_row if eng.spec.use_xattn_time else None, ld_extra=W.kvx_ld,
                        kx_off=W.kvx_off[n], vx_off=W.kvx_off[n] + mid,
                        extra_step=self.step_idx if (self.table_mode and eng.spec.use_xattn_time) else None)
-        x3 = self.new_act(Bf, Lx, Cc)
-        self.conv(ops, src0=a2, w=W.w[f"{n}.o2"], bias=W.v[f"{n}.o2.bias"], out=x3, residual=x2)
-        f1 = self.new_act(Bf, Lx, Cc * t.multiplier)
-        self.conv(ops, src0=x3, w=W.w[f"{n}.ff1"], bias=W.v[f"{n}.ff1.bias"], out=f1, act=L.ACT_GELU)
+        Cf = Cc * t.multiplier
+        if eng.fuse_o2_ff1 and eng.fuse_ff_out and self.streams(Bf, Lx, Cc) and Cc % 32 == 0 and mid % 32 == 0 and x2.ld == Cc:
+            xf = self.new_act(Bf, Lx, Cc + Cf)
+            self.conv(ops, src0=a2, w=W.w[f"{n}.o2f1"], bias=W.v[f"{n}.o2f1.bias"], out=xf, residual=x2, act=L.ACT_GELU,
+                      extra_segs=[(x2, 0)], m_split=Cc, k_split=mid // 32)
+            x3, f1 = xf.cols(0, Cc), xf.cols(Cc, Cf)
+        else:
+            x3 = self.new_act(Bf, Lx, Cc)
+            self.conv(ops, src0=a2, w=W.w[f"{n}.o2"], bias=W.v[f"{n}.o2.bias"], out=x3, residual=x2)
+            f1 = self.new_act(Bf, Lx, Cf)
+            self.conv(ops, src0=x3, w=W.w[f"{n}.ff1"], bias=W.v[f"{n}.ff1.bias"], out=f1, act=L.ACT_GELU)
         y = self.new_act(Bf, Lx, Cc, gn=True)
-        if eng.fuse_ff_out and self.streams(Bf, Lx, Cc) and x3.ld == Cc and f1.ld == f1.C:
+        if eng.fuse_ff_out and self.streams(Bf, Lx, Cc) and x3.cp == Cc and f1.cp == f1.C:
             self.conv(ops, src0=x3, w=W.w[f"{n}.ffp"], bias=W.v[f"{n}.ffp.bias"], out=y, extra_segs=[(f1, 0)])
             return y
         x4 = self.new_act(Bf, Lx, Cc)
@@ -815,6 +843,7 @@ class Engine:
         self.stream_max_wgs = int(os.environ.get("JEN1_STREAM_MAX_WGS", "768"))
         self.fuse_shortcut = os.environ.get("JEN1_FUSE_SHORTCUT", "1") != "0"
         self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
+        self.fuse_o2_ff1 = os.environ.get("JEN1_FUSE_O2_FF1", "1") != "0"
         self.plans: Dict[tuple, Plan] = {}
         self.load_params(params)
 

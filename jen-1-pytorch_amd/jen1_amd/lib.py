@@ -56,7 +56,7 @@ class ConvArgs(C.Structure):
         ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int), ("direct", c_int),
         ("zeros", c_void_p), ("tiles_t", c_int), ("inv_tiles_t", c_float), ("inv_tb", c_float),
         ("film_step", c_void_p), ("ln_u", c_void_p), ("ln_fold", c_int), ("nseg", c_int),
-        ("seg", ConvSeg * MAX_SEG),
+        ("seg", ConvSeg * MAX_SEG), ("m_split", c_int), ("k_split", c_int),
     ]
 
 
