@@ -132,7 +132,7 @@ def conv_roofline(st, reps=3):
     return {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": "conv_gemm_kernel<*> (fused GroupNorm/LayerNorm + conv/linear implicit GEMM)",
+        "kernel": "jen1_conv_gemm family: stream_gemm_kernel<*> + conv_gemm_kernel<*> (fused norm + conv/linear implicit GEMM)",
         "launches_per_step": n, "avg_launch_us": round(conv_ms * 1e3 / n, 2), "conv_ms_per_step": round(conv_ms, 4),
         "alg_bytes_per_step": int(alg), "alg_weight_bytes": int(w_bytes), "alg_act_bytes": int(a_bytes),
         "alg_bytes_per_launch": int(alg / n), "executed_gflop_per_step": round(flops / 1e9, 2),
