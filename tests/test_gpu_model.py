@@ -259,3 +259,20 @@ def test_sampler_full_size_properties(full_model_f32):
     # the GroupNorm/LayerNorm sums); four steps from t=999, where x0 = 157*(...) is clamped, amplify that to
     # ~1e-4 run to run (eager vs eager shows the same spread), so the check uses the 1e-3 parity gate.
     assert rel_err(outs[1], outs[0]) < F32_TOL
+
+
+def test_text_conditioner_tail_projection_and_mask():
+    """T5Conditioner.forward tail: proj_out(last_hidden_state) * attention_mask (conditioners.py:106-111) on the HIP path."""
+    from jen1_amd.tasks import TextConditionerTail
+    torch.manual_seed(3)
+    B, N, F = 3, 128, 1024
+    w, b = torch.randn(F, F) / F ** 0.5, torch.randn(F) * 0.1
+    hid = torch.randn(B, N, F, device="cuda")
+    mask = (torch.arange(N, device="cuda")[None, :] < torch.tensor([5, 77, 128], device="cuda")[:, None])
+    ref = (hid @ w.cuda().T + b.cuda()) * mask[..., None].float()
+    for dtype, tol in (("f32", F32_TOL), ("bf16", BF16_TOL)):
+        tail = TextConditionerTail(w, b, dtype=dtype)
+        emb, m = tail(hid, mask)
+        assert m is mask and emb.dtype == torch.float32
+        assert rel_err(emb.cpu().numpy(), ref.cpu().numpy()) < tol
+        assert float(emb[0, 5:].abs().max()) == 0.0
