@@ -49,7 +49,15 @@ extern "C" {
 #define JEN1_CFG_S16x64 2
 #define JEN1_CFG_S16x32 3
 #define JEN1_CFG_S16x16 4
-#define JEN1_NUM_CFG 5
+/* T* = "tile": the lean kernel of the long levels (T' >= 64): 4 waves x 16*MF output rows, one batch element per
+ *      tile (nb = 1), GroupNorm / SiLU / no prologue, no split-K; BM = all output channels when M <= 256 */
+#define JEN1_CFG_T128x64 5
+#define JEN1_CFG_T128x32 6
+#define JEN1_CFG_T128x16 7
+#define JEN1_CFG_T256x32 8
+#define JEN1_CFG_T256x16 9
+#define JEN1_CFG_T64x64 10
+#define JEN1_NUM_CFG 11
 
 /*
  * Fused implicit-GEMM 1-D convolution / linear layer.

@@ -20,6 +20,8 @@ int jen1_set_error(const char* fmt, ...);
 
 // stream_gemm.hip: launcher of jen1_conv_gemm's direct (weight-streaming) mode
 int jen1_stream_gemm_launch(const jen1_conv_args& a, void* stream);
+// tile_gemm.hip: launcher of the JEN1_CFG_T* tile configurations
+int jen1_tile_gemm_launch(const jen1_conv_args& a, void* stream);
 
 #define JEN1_CHECK(cond, ...)                  \
   do {                                         \

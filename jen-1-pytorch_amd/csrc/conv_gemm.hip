@@ -736,7 +736,10 @@ struct CfgDesc {
 #ifndef JEN1_SWK
 #define JEN1_SWK 4      // waves (= K slices) per streaming workgroup
 #endif
-constexpr CfgDesc kCfg[JEN1_NUM_CFG] = {{1, 4, 4, 1}, {2, 4, 4, 1}, {1, 4, 1, JEN1_SWK}, {1, 2, 1, JEN1_SWK}, {1, 1, 1, JEN1_SWK}};
+constexpr CfgDesc kCfg[JEN1_NUM_CFG] = {{1, 4, 4, 1}, {2, 4, 4, 1}, {1, 4, 1, JEN1_SWK}, {1, 2, 1, JEN1_SWK}, {1, 1, 1, JEN1_SWK},
+                                        // T* tiles (tile_gemm.hip): MF, NF with 4 waves along M
+                                        {2, 4, 4, 1}, {2, 2, 4, 1}, {2, 1, 4, 1}, {4, 2, 4, 1}, {4, 1, 4, 1}, {1, 4, 4, 1}};
+inline bool is_tile_cfg(int cfg) { return cfg >= JEN1_CFG_T128x64 && cfg <= JEN1_CFG_T64x64; }
 
 inline int cfg_red_floats(int cfg) {
   const CfgDesc d = kCfg[cfg];
@@ -841,7 +844,9 @@ static int validate(const jen1_conv_args& a) {
   JEN1_CHECK(a.m_split == 0 || (a.direct && a.m_split % 16 == 0 && a.m_split > 0 && a.m_split < a.M && a.k_split >= 1 && a.k_split <= kch &&
                                a.ps_f == 1 && !a.ln_fold && !a.out_gn_stats),
              "conv_gemm: bad dual-range split (m_split=%d k_split=%d)", a.m_split, a.k_split);
-  if (!a.direct) {
+  JEN1_CHECK(!is_tile_cfg(a.cfg) || (!a.direct && a.nb == 1 && (a.ps_f == 1 || a.out_C % jen1_cfg_bm(a.cfg) == 0)),
+             "conv_gemm: T* tiles need nb = 1, no direct mode and, for sub-pixel outputs, out_C a multiple of BM");
+  if (!a.direct && !is_tile_cfg(a.cfg)) {
     const Layout L = make_layout(a, a.dtype == JEN1_F32 ? 4 : 2, cfg_red_floats(a.cfg));
     JEN1_CHECK(L.total <= 160 * 1024, "conv_gemm: LDS request %d B exceeds 160 KiB (tb=%d nb=%d kc_stage=%d)", L.total, a.tb, a.nb, a.kc_stage);
   }
@@ -862,6 +867,7 @@ extern "C" int jen1_conv_gemm(const jen1_conv_args* args, void* stream) {
   a.inv_tiles_t = 1.0f / (float)a.tiles_t;
   a.inv_tb = 1.0f / (float)a.tb;
   if (a.direct) return jen1_stream_gemm_launch(a, stream);
+  if (is_tile_cfg(a.cfg)) return jen1_tile_gemm_launch(a, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return a.dtype == JEN1_F32 ? dispatch<float>(a, s) : dispatch<bf16_t>(a, s);
 }

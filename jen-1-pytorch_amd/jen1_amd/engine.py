@@ -210,6 +210,8 @@ class KernelCtx:
         self.fuse_shortcut = True
         self.fuse_ff_out = True
         self.fuse_o2_ff1 = True
+        self.use_tile_kernel = True
+        self.tile_min_rows = 512
         self.stream_bn = 64
         self.stream_max_wgs = 100000
 
@@ -317,7 +319,11 @@ class OpBuilder:
             a.out_gn_stats, a.out_cpf = out.gn.data_ptr(), out.ld // FG
         if out.rs is not None:
             a.out_rowstats = out.rs.data_ptr()
-        self._choose_tiles(a, force, k_extra=(sum(e.cp for e, _ in extra_segs) // 32 if extra_segs else 0))
+        tile_ok = (pro in (L.PRO_NONE, L.PRO_GN, L.PRO_GN_SILU, L.PRO_SILU) and act == L.ACT_NONE and row_scale is None and out.rs is None
+                   and not extra_segs and not m_split and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] > 1 or src1 is None)
+                   and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] == 1 or
+                        (a.gn_cpg % (a.c0 // FG) == 0 and (a.c1 == 0 or a.gn_cpg % (a.c1 // FG) == 0))))
+        self._choose_tiles(a, force, k_extra=(sum(e.cp for e, _ in extra_segs) // 32 if extra_segs else 0), tile_ok=tile_ok)
         lib = eng.lib
         streaming = a.cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
         want_direct = streaming and (force is None or force.get("direct", True))
@@ -410,6 +416,33 @@ class OpBuilder:
         nb = max(1, min(B, BN // tb))
         return tb, nb, nt * -(-B // nb)
 
+    TILE_CFGS = (L.CFG_T256x32, L.CFG_T256x16, L.CFG_T128x64, L.CFG_T128x32, L.CFG_T128x16, L.CFG_T64x64)
+
+    def pick_tile_cfg(self, B: int, L_out: int, M: int, out_C: int, ps_f: int, lds_ok) -> Optional[int]:
+        """long levels (>= 512 positions in the launch): the lean tile kernel, with all output channels in one
+        workgroup when M <= 256 and the position tile chosen so that about one workgroup per CU exists"""
+        lib, eng = self.eng.lib, self.eng
+        if not eng.use_tile_kernel or B * L_out < eng.tile_min_rows:
+            return None
+        best = None
+        bms = (64,) if M <= 64 else (128,) if M <= 128 else (256, 128)
+        for cfg in self.TILE_CFGS:
+            BM, BN = lib.jen1_cfg_bm(cfg), lib.jen1_cfg_bn(cfg)
+            if BM not in bms:
+                continue
+            if ps_f > 1 and out_C % BM != 0:
+                continue
+            if BN > L_out and BN > 16:
+                continue
+            tb = self.tile_geometry(B, L_out, BN)[0]
+            if not lds_ok(cfg, tb):
+                continue
+            wgs = -(-M // BM) * -(-L_out // tb) * B
+            score = (min(wgs, eng.target_wgs), -(-(-M // BM)), BN)       # fill the chip, then fewest M tiles, then wide
+            if best is None or score > best[0]:
+                best = (score, cfg)
+        return None if best is None else best[1]
+
     def pick_cfg(self, B: int, L_out: int, M: int) -> int:
         """wide tile when the positions alone fill the chip with 64-row M tiles, else a 16-row streaming tile"""
         lib, eng = self.eng.lib, self.eng
@@ -429,9 +462,12 @@ class OpBuilder:
         return L.CFG_S16x64
 
     def streams(self, B: int, L_out: int, M: int) -> bool:
+        """will a plain conv of this shape run on the streaming kernel (where K-segment fusions pay)?"""
+        if self.eng.use_tile_kernel and B * L_out >= self.eng.tile_min_rows:
+            return False
         return self.pick_cfg(B, L_out, M) in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
 
-    def _choose_tiles(self, a: L.ConvArgs, force=None, k_extra=0):
+    def _choose_tiles(self, a: L.ConvArgs, force=None, k_extra=0, tile_ok=False):
         """Tile heuristics.  Wide (W*) tiles when there are enough positions to fill the chip with
         64-row M tiles; otherwise 16-row streaming (S*) tiles whose 4 waves split K: a deep level
         is pure weight streaming and needs many small workgroups, not a big tile."""
@@ -446,11 +482,23 @@ class OpBuilder:
             tb, nb, nt = self.tile_geometry(a.B, a.L_out, BN)
             return BM, BN, tb, nb, nt * -(-M // BM)
 
+        es = 4 if eng.dt == L.F32 else 2
+
+        def tile_lds_ok(cfg, tb):
+            rows_in = (tb - 1) * a.stride + a.taps
+            ctot = a.c0 + a.c1
+            return rows_in * (ctot + 8) * es + 8 * ctot + 8 * (lib.jen1_cfg_bm(cfg) // 2 + 2) + 64 <= 150 * 1024
+
         if force is not None and "cfg" in force:
             cfg = force["cfg"]
         else:
-            cfg = self.pick_cfg(a.B, a.L_out, M)
+            cfg = self.pick_tile_cfg(a.B, a.L_out, M, a.out_C, a.ps_f, tile_lds_ok) if tile_ok else None
+            if cfg is None:
+                cfg = self.pick_cfg(a.B, a.L_out, M)
         BM, BN, tb, nb, wgs = tiles(cfg)
+        if cfg in self.TILE_CFGS:
+            a.cfg, a.tb, a.nb, a.splitk, a.kc_stage = cfg, tb, 1, 1, 1
+            return
         a.cfg, a.tb, a.nb = cfg, tb, nb
         splitk = 1
         if force is not None and "splitk" in force:
@@ -844,6 +892,8 @@ class Engine:
         self.fuse_shortcut = os.environ.get("JEN1_FUSE_SHORTCUT", "1") != "0"
         self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
         self.fuse_o2_ff1 = os.environ.get("JEN1_FUSE_O2_FF1", "1") != "0"
+        self.use_tile_kernel = os.environ.get("JEN1_TILE_KERNEL", "1") != "0"
+        self.tile_min_rows = int(os.environ.get("JEN1_TILE_MIN_ROWS", "512"))
         self.plans: Dict[tuple, Plan] = {}
         self.load_params(params)
 

@@ -16,12 +16,13 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip"]
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU = 0, 1
 CFG_W64x64, CFG_W128x64, CFG_S16x64, CFG_S16x32, CFG_S16x16 = 0, 1, 2, 3, 4
+CFG_T128x64, CFG_T128x32, CFG_T128x16, CFG_T256x32, CFG_T256x16, CFG_T64x64 = 5, 6, 7, 8, 9, 10
 
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
 

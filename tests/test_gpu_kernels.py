@@ -168,6 +168,107 @@ def test_upsample_golden(ctx):
         assert rel_err(from_cl(out)[:, :12].cpu().numpy(), g[f"upsample.f{f}"]) < TOL[mode]
 
 
+# ------------------------------------------------------------------ the lean tile kernel of the long levels (T* cfgs)
+TILE_CFGS = [5, 6, 7, 8, 9, 10]
+
+
+@pytest.mark.parametrize("cfg", TILE_CFGS)
+@pytest.mark.parametrize("k,s", [(3, 1), (9, 4), (5, 2), (1, 1)])
+def test_tile_kernel_plain_and_strided_conv(ctx, cfg, k, s):
+    """jen1_conv_gemm with the T* tile configurations: plain / strided convolution (blocks.py:34-53), partial tiles in
+    both directions, output statistics."""
+    from jen1_amd.engine import OpBuilder
+    kc, mode = ctx
+    torch.manual_seed(cfg * 11 + k)
+    B, Ci, Co, Ln = 3, 96, 192, 117
+    x = torch.randn(B, Ci, Ln, device="cuda")
+    w = torch.randn(Co, Ci, k, device="cuda") / (Ci * k) ** 0.5
+    b = torch.randn(Co, device="cuda") * 0.1
+    pl = (k - 1) // 2
+    Lo = -(-Ln // s)
+    ref = F.conv1d(F.pad(x, (pl, k - 1 - pl)), w, b, stride=s)
+    assert ref.shape[-1] == Lo
+    ob = OpBuilder(kc)
+    out = new_out(kc, B, Lo, Co, gn=True)
+    ob.conv(ob.ops, src0=to_cl(x, kc), w=pack_conv(w, kc), bias=b, out=out, taps=k, stride=s, pad_left=pl, L_out=Lo, force={"cfg": cfg})
+    run(ob)
+    y = from_cl(out)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TOL[mode]
+    assert rel_err(out.gn.cpu().numpy(), to_cl(y, kc).gn.cpu().numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("cfg", TILE_CFGS)
+@pytest.mark.parametrize("two_src,film,groups", [(False, False, 8), (True, True, 8), (False, True, 1), (True, False, 4)])
+def test_tile_kernel_groupnorm_film_silu(ctx, cfg, two_src, film, groups):
+    """ConvBlock1d on the tile kernel: GroupNorm -> FiLM -> SiLU -> conv k=3 over [x, skip * 2^-1/2] + residual + statistics
+    (blocks.py:137-145, :219-231, :732-734); groups = 1 is the Patcher / Unpatcher case (blocks.py:251, :279)."""
+    from jen1_amd import lib as L
+    from jen1_amd.engine import OpBuilder
+    kc, mode = ctx
+    if groups == 1 and two_src:
+        pytest.skip("single group over two sources is not a JEN-1 shape")
+    torch.manual_seed(cfg + 100)
+    B, C0, C1, Co, Ln = 2, 64, 64 if two_src else 0, 128, 150
+    sc = 2 ** -0.5
+    x0 = torch.randn(B, C0, Ln, device="cuda") * 1.5 + 0.3
+    x1 = torch.randn(B, C1, Ln, device="cuda") * 0.7 - 0.2 if two_src else None
+    Ct = C0 + C1
+    gam, bet = torch.rand(Ct, device="cuda") + 0.5, torch.randn(Ct, device="cuda") * 0.1
+    w = torch.randn(Co, Ct, 3, device="cuda") / (Ct * 3) ** 0.5
+    bias = torch.randn(Co, device="cuda") * 0.1
+    resid = torch.randn(B, Co, Ln, device="cuda")
+    ftab = torch.randn(5, 2 * Ct + 7, device="cuda") * 0.3
+    frow = torch.tensor([4, 0], dtype=torch.int32, device="cuda")
+    xin = x0 if not two_src else torch.cat([x0, x1 * sc], 1)
+    h = F.group_norm(xin, groups, gam, bet, 1e-5)
+    if film:
+        fs = ftab[frow.long()][:, 7: 7 + Ct, None]
+        fh = ftab[frow.long()][:, 7 + Ct: 7 + 2 * Ct, None]
+        h = h * (fs + 1) + fh
+    ref = F.conv1d(F.pad(F.silu(h), (1, 1)), w, bias) + resid
+    ob = OpBuilder(kc)
+    out = new_out(kc, B, Ln, Co, gn=True)
+    ob.conv(ob.ops, src0=to_cl(x0, kc), src1=to_cl(x1, kc) if two_src else None, src1_scale=sc if two_src else 1.0,
+            w=pack_conv(w, kc), bias=bias, out=out, taps=3, pad_left=1, pro=L.PRO_GN_SILU,
+            gn=(groups, Ct, gam, bet, 1e-5), film=(ftab, frow, 7, Ct) if film else None, residual=to_cl(resid, kc), force={"cfg": cfg})
+    run(ob)
+    y = from_cl(out)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TOL[mode]
+    assert rel_err(out.gn.cpu().numpy(), to_cl(y, kc).gn.cpu().numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("cfg", [5, 6, 7, 10])
+@pytest.mark.parametrize("f,crop", [(4, 0), (4, 3), (2, 1)])
+def test_tile_kernel_conv_transpose_subpixel(ctx, cfg, f, crop):
+    """Upsample1d on the tile kernel: ConvTranspose1d(k=2f, s=f) as a 2-tap sub-pixel GEMM with the centre crop folded
+    into the store and the final residual (blocks.py:88-95, utils/module.py:186-204, model.py:261)."""
+    from jen1_amd import lib as L
+    from jen1_amd.engine import OpBuilder
+    from jen1_amd.packing import convT_weight_to_gemm, pack_gemm_weight
+    kc, mode = ctx
+    BM = L.load().jen1_cfg_bm(cfg)
+    Co = 128 if BM <= 128 else 256
+    torch.manual_seed(f + cfg)
+    B, Ci, Ln = 2, 64, 70
+    x = torch.randn(B, Ci, Ln, device="cuda")
+    w = torch.randn(Ci, Co, 2 * f, device="cuda") / (Co * 2 * f) ** 0.5
+    b = torch.randn(Co, device="cuda") * 0.1
+    p = f // 2 + f % 2
+    full = F.conv_transpose1d(x, w, b, stride=f, padding=p, output_padding=f % 2)
+    L_need = f * Ln - crop
+    st = crop // 2
+    resid = torch.randn(B, Co, L_need, device="cuda")
+    ref = full[:, :, st: st + L_need] + resid
+    ob = OpBuilder(kc)
+    out = new_out(kc, B, L_need, Co, gn=True)
+    ob.conv(ob.ops, src0=to_cl(x, kc), w=pack_gemm_weight(convT_weight_to_gemm(w, f), kc.tdtype), bias=b, out=out,
+            taps=2, pad_left=1, L_out=Ln + 1, ps_f=f, ps_off=p + st, out_C=Co, residual=to_cl(resid, kc), force={"cfg": cfg})
+    run(ob)
+    y = from_cl(out)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TOL[mode]
+    assert rel_err(out.gn.cpu().numpy(), to_cl(y, kc).gn.cpu().numpy()) < 2e-3
+
+
 # ------------------------------------------------------------------ fused prologues / epilogues
 @pytest.mark.parametrize("two_src", [False, True])
 @pytest.mark.parametrize("film", [False, True])
