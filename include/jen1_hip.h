@@ -206,6 +206,20 @@ int jen1_attention(const void* q, const void* k, const void* v, void* out, const
                    int ldo, int causal, float scale, int dtype, void* stream);
 
 /*
+ * Same, with a deferred LayerNorm finish: when a launch produced raw = W' x for a LayerNorm-folded projection
+ * together with x itself (jen1_conv_args.m_split), the row statistics of x are only complete after that launch, so
+ *     q = rstd_row * (raw - mean_row * ln_u[col]) + ln_b[col]            (blocks.py:427-429)
+ * is applied here while the operand is staged.  ln_rowstats: [rows][2] (sum, sumsq over ln_C channels) indexed by the
+ * operand's row; ln_u / ln_b: indexed by the operand's COLUMN in its tensor (q_off + h*d + c, k_off + ..., v_off + ...).
+ * finish_q applies it to Q, finish_kv to K and V (self-attention only: no kv_row / kv_extra, Nq == Nk).
+ */
+int jen1_attention_fin(const void* q, const void* k, const void* v, void* out, const int32_t* kv_row,
+                       const void* kv_extra, const int32_t* extra_row, const int32_t* extra_step, int ld_extra, int kx_off, int vx_off,
+                       int B, int H, int d, int Nq, int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off,
+                       int ldo, int causal, float scale, const float* ln_rowstats, const float* ln_u, const float* ln_b,
+                       int ln_C, float ln_eps, int finish_q, int finish_kv, int dtype, void* stream);
+
+/*
  * [B][C][T] float32 latents + [B][Cc][T] float32 context channels -> channel-last
  * [nrep*B][T][ld] (ld >= C+Cc, padded with zeros), replicated nrep times along the
  * batch (the CFG pair), plus GroupNorm fine-group sums.  Replaces torch.cat at

@@ -169,6 +169,25 @@ class Weights:
             self.v[f"{n}.ff1.bias"] = f32(p[f"{b}.feed_forward.0.bias"])
             self.w[f"{n}.ff2"] = pk(p[f"{b}.feed_forward.2.weight"][None])
             self.v[f"{n}.ff2.bias"] = f32(p[f"{b}.feed_forward.2.bias"])
+            # streaming levels: a projection and the LayerNorm-folded projection that consumes its output as ONE
+            # dual-range GEMM; the LayerNorm finish rstd (raw - mean u) + b moves into the attention kernel
+            #   [x1 | qkv_raw] = [P ; Wqkv' P] xh + [p_b ; Wqkv' p_b]                        (blocks.py:530-531, :427-429)
+            #   [x2 | q2_raw]  = [W_o | 0 ; Wq2' W_o | Wq2'] [a1 | x1] + [b_o ; Wq2' b_o]     (+ x1 on the x2 rows)
+            P64, pb64 = p[f"{n}.conv1d.conv.weight"][:, :, 0].double(), p[f"{n}.conv1d.conv.bias"].double()
+            wqkv64, wq264 = torch.cat([wq, wkv], 0).double(), wq2.double()
+            self.w[f"{n}.pqkv"] = pk(torch.cat([P64, wqkv64 @ P64], 0).float()[None]).flatten(0, 1).contiguous()
+            self.v[f"{n}.pqkv.bias"] = torch.cat([pb64, wqkv64 @ pb64]).float().contiguous()
+            Cc_, mid_ = P64.shape[0], wq264.shape[0]
+            zc = lambda m_: torch.zeros(m_, dtype=torch.float32, device=device)
+            self.v[f"{n}.pqkv.u"] = torch.cat([zc(Cc_), self.v[f"{n}.qkv.u"]]).contiguous()
+            self.v[f"{n}.pqkv.b"] = torch.cat([zc(Cc_), self.v[f"{n}.qkv.bias"]]).contiguous()
+            wo164, bo164 = p[f"{a}.attention.to_out.weight"].double(), p[f"{a}.attention.to_out.bias"].double()
+            top1 = torch.cat([wo164, torch.zeros(Cc_, Cc_, dtype=torch.float64, device=device)], 1)
+            bot1 = torch.cat([wq264 @ wo164, wq264], 1)
+            self.w[f"{n}.o1q2"] = pk(torch.cat([top1, bot1], 0).float()[None]).flatten(0, 1).contiguous()
+            self.v[f"{n}.o1q2.bias"] = torch.cat([bo164, wq264 @ bo164]).float().contiguous()
+            self.v[f"{n}.o1q2.u"] = torch.cat([zc(Cc_), self.v[f"{n}.q2.u"]]).contiguous()
+            self.v[f"{n}.o1q2.b"] = torch.cat([zc(Cc_), self.v[f"{n}.q2.bias"]]).contiguous()
             # streaming levels: cross-attention output projection and the first FeedForward layer as ONE
             # dual-range GEMM over the K concat [a | x2]:  x3 = x2 + W_o a + b_o  (rows < C, K = a only) and
             # f = gelu(W_1 x3 + b_1) = gelu((W_1 W_o) a + W_1 x2 + W_1 b_o + b_1)   (blocks.py:485-488, :440-446)
@@ -211,7 +230,10 @@ class KernelCtx:
         self.fuse_ff_out = True
         self.fuse_o2_ff1 = True
         self.use_tile_kernel = True
+        self.fuse_ln_proj = True
         self.tile_min_rows = 512
+        self.tile_target_wgs = 256
+        self.tile_one_round = False
         self.stream_bn = 64
         self.stream_max_wgs = 100000
 
@@ -258,7 +280,7 @@ class OpBuilder:
     def conv(self, ops, *, src0: Act, w: torch.Tensor, bias, out: Act, taps=1, stride=1, pad_left=0, L_out=None,
              src1: Optional[Act] = None, src1_scale=1.0, ps_f=1, ps_off=0, L_y=None, y_row0=0, pro=L.PRO_NONE,
              gn=None, film=None, ln=None, act=L.ACT_NONE, residual: Optional[Act] = None, row_scale=None,
-             y_f32=False, out_C=None, force=None, label="", extra_segs=None, m_split=0, k_split=0):
+             y_f32=False, out_C=None, force=None, label="", extra_segs=None, m_split=0, k_split=0, flat_w=False):
         """extra_segs: [(Act, row_shift)] raw sources appended to the K axis after the (tap, source) pairs of
         src0/src1 (streaming / direct mode only); ``w`` is then the flat packed weight [chunks][M/16][64][8]."""
         eng = self.eng
@@ -275,8 +297,8 @@ class OpBuilder:
         out_C = out_C if out_C is not None else out.C
         a.out_C, a.ps_f, a.ps_off = out_C, ps_f, ps_off
         a.M = out_C * ps_f
-        if extra_segs:
-            k_extra = sum(e.cp for e, _ in extra_segs)
+        if extra_segs or flat_w:
+            k_extra = sum(e.cp for e, _ in extra_segs) if extra_segs else 0
             assert w.dim() == 4 and w.shape[1] * 16 == a.M and w.shape[0] * 32 == taps * (a.c0 + a.c1) + k_extra, \
                 (tuple(w.shape), taps, a.M, a.c0, a.c1, k_extra)
         else:
@@ -438,7 +460,8 @@ class OpBuilder:
             if not lds_ok(cfg, tb):
                 continue
             wgs = -(-M // BM) * -(-L_out // tb) * B
-            score = (min(wgs, eng.target_wgs), -(-(-M // BM)), BN)       # fill the chip, then fewest M tiles, then wide
+            tgt = eng.tile_target_wgs
+            score = (wgs if wgs <= tgt else tgt - (1 if eng.tile_one_round else 0) * (wgs - tgt) / wgs, -(-(-M // BM)), BN)
             if best is None or score > best[0]:
                 best = (score, cfg)
         return None if best is None else best[1]
@@ -534,14 +557,16 @@ class OpBuilder:
             self._max_tiles = max(self._max_tiles, wgs)
 
     def attention(self, ops, *, q: Act, q_off, kv_t: torch.Tensor, ldkv, k_off, v_off, out: Act, H, d, Nk, causal,
-                  kv_row=None, kv_extra=None, extra_row=None, ld_extra=0, kx_off=0, vx_off=0, extra_step=None):
+                  kv_row=None, kv_extra=None, extra_row=None, ld_extra=0, kx_off=0, vx_off=0, extra_step=None, fin=None):
+        """fin = (rowstats, u, b, ln_C, eps, finish_q, finish_kv): deferred LayerNorm finish (jen1_attention_fin)"""
         eng = self.eng
+        rs_, u_, b_, lnC, eps, fq, fkv = fin if fin is not None else (None, None, None, 0, 0.0, 0, 0)
         args = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
                 _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
-                1 if causal else 0, float(d) ** -0.5, eng.dt)
+                1 if causal else 0, float(d) ** -0.5, _ptr(rs_), _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, eng.dt)
         lib = eng.lib
-        self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row, extra_step))
-        fn = lambda s, args=args, lib=lib: L.check(lib.jen1_attention(*args, s), "jen1_attention")
+        self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row, extra_step, fin))
+        fn = lambda s, args=args, lib=lib: L.check(lib.jen1_attention_fin(*args, s), "jen1_attention")
         fn.label = f"attention B={q.B} H={H} d={d} Nq={q.L} Nk={Nk} causal={causal}"
         ops.append(fn)
 
@@ -618,30 +643,45 @@ class Plan(OpBuilder):
         n, Cc, H, d = t.name, t.channels, t.heads, t.head_features
         mid = H * d
         Bf, Lx = x.B, x.L
-        x1 = self.new_act(Bf, Lx, Cc, rs=True)
-        self.conv(ops, src0=x, w=W.w[f"{n}.proj"], bias=W.v[f"{n}.proj.bias"], out=x1, pro=L.PRO_GN,
-                  gn=(32, Cc, W.v[f"{n}.gn.g"], W.v[f"{n}.gn.b"], 1e-6))
-        qkv = self.new_act(Bf, Lx, 3 * mid)
-        self.conv(ops, src0=x1, w=W.w[f"{n}.qkv"], bias=W.v[f"{n}.qkv.bias"], out=qkv, pro=L.PRO_LN,
-                  ln=(Cc, None, None, W.v[f"{n}.qkv.u"]))
-        a1 = self.new_act(Bf, Lx, mid)
-        self.attention(ops, q=qkv, q_off=0, kv_t=qkv.t, ldkv=qkv.ld, k_off=mid, v_off=2 * mid, out=a1, H=H, d=d, Nk=Lx,
-                       causal=causal)
-        x2 = self.new_act(Bf, Lx, Cc, rs=True)
-        self.conv(ops, src0=a1, w=W.w[f"{n}.o1"], bias=W.v[f"{n}.o1.bias"], out=x2, residual=x1)
-        q2 = self.new_act(Bf, Lx, mid)
-        self.conv(ops, src0=x2, w=W.w[f"{n}.q2"], bias=W.v[f"{n}.q2.bias"], out=q2, pro=L.PRO_LN,
-                  ln=(Cc, None, None, W.v[f"{n}.q2.u"]))
-        a2 = self.new_act(Bf, Lx, mid)
+        gn_in = (32, Cc, W.v[f"{n}.gn.g"], W.v[f"{n}.gn.b"], 1e-6)
         kv = self.kv_ctx[n]
-        self.attention(ops, q=q2, q_off=0, kv_t=kv, ldkv=2 * mid, k_off=0, v_off=mid, out=a2, H=H, d=d, Nk=eng.spec.ctx_len,
-                       causal=False, kv_row=self.kv_row,
-                       kv_extra=self.kvx.t if eng.spec.use_xattn_time else None,
-                       extra_row=self.extra_row if eng.spec.use_xattn_time else None, ld_extra=W.kvx_ld,
-                       kx_off=W.kvx_off[n], vx_off=W.kvx_off[n] + mid,
-                       extra_step=self.step_idx if (self.table_mode and eng.spec.use_xattn_time) else None)
+        xattn = dict(kv_t=kv, ldkv=2 * mid, k_off=0, v_off=mid, H=H, d=d, Nk=eng.spec.ctx_len, causal=False, kv_row=self.kv_row,
+                     kv_extra=self.kvx.t if eng.spec.use_xattn_time else None,
+                     extra_row=self.extra_row if eng.spec.use_xattn_time else None, ld_extra=W.kvx_ld,
+                     kx_off=W.kvx_off[n], vx_off=W.kvx_off[n] + mid,
+                     extra_step=self.step_idx if (self.table_mode and eng.spec.use_xattn_time) else None)
+        a1 = self.new_act(Bf, Lx, mid)
+        a2 = self.new_act(Bf, Lx, mid)
+        if eng.fuse_ln_proj and self.streams(Bf, Lx, Cc) and Cc % 32 == 0 and mid % 32 == 0 and Lx * (d // 8) <= 512:
+            # 5 launches instead of 7: each projection rides with the LayerNorm-folded projection that follows it,
+            # the LayerNorm finish is applied by the attention kernel (jen1_attention_fin)
+            xq1 = self.new_act(Bf, Lx, Cc + 3 * mid, rs=True)
+            self.conv(ops, src0=x, w=W.w[f"{n}.pqkv"], bias=W.v[f"{n}.pqkv.bias"], out=xq1, pro=L.PRO_GN, gn=gn_in,
+                      m_split=Cc, k_split=Cc // 32, flat_w=True)
+            x1 = xq1.cols(0, Cc, rs=xq1.rs)
+            self.attention(ops, q=xq1, q_off=Cc, kv_t=xq1.t, ldkv=xq1.ld, k_off=Cc + mid, v_off=Cc + 2 * mid, out=a1, H=H, d=d, Nk=Lx,
+                           causal=causal, fin=(xq1.rs, W.v[f"{n}.pqkv.u"], W.v[f"{n}.pqkv.b"], Cc, 1e-5, 1, 1))
+            xq2 = self.new_act(Bf, Lx, Cc + mid, rs=True)
+            self.conv(ops, src0=a1, w=W.w[f"{n}.o1q2"], bias=W.v[f"{n}.o1q2.bias"], out=xq2, residual=x1,
+                      extra_segs=[(x1, 0)], m_split=Cc, k_split=mid // 32)
+            x2 = xq2.cols(0, Cc, rs=xq2.rs)
+            self.attention(ops, q=xq2, q_off=Cc, out=a2, fin=(xq2.rs, W.v[f"{n}.o1q2.u"], W.v[f"{n}.o1q2.b"], Cc, 1e-5, 1, 0), **xattn)
+        else:
+            x1 = self.new_act(Bf, Lx, Cc, rs=True)
+            self.conv(ops, src0=x, w=W.w[f"{n}.proj"], bias=W.v[f"{n}.proj.bias"], out=x1, pro=L.PRO_GN, gn=gn_in)
+            qkv = self.new_act(Bf, Lx, 3 * mid)
+            self.conv(ops, src0=x1, w=W.w[f"{n}.qkv"], bias=W.v[f"{n}.qkv.bias"], out=qkv, pro=L.PRO_LN,
+                      ln=(Cc, None, None, W.v[f"{n}.qkv.u"]))
+            self.attention(ops, q=qkv, q_off=0, kv_t=qkv.t, ldkv=qkv.ld, k_off=mid, v_off=2 * mid, out=a1, H=H, d=d, Nk=Lx,
+                           causal=causal)
+            x2 = self.new_act(Bf, Lx, Cc, rs=True)
+            self.conv(ops, src0=a1, w=W.w[f"{n}.o1"], bias=W.v[f"{n}.o1.bias"], out=x2, residual=x1)
+            q2 = self.new_act(Bf, Lx, mid)
+            self.conv(ops, src0=x2, w=W.w[f"{n}.q2"], bias=W.v[f"{n}.q2.bias"], out=q2, pro=L.PRO_LN,
+                      ln=(Cc, None, None, W.v[f"{n}.q2.u"]))
+            self.attention(ops, q=q2, q_off=0, out=a2, **xattn)
         Cf = Cc * t.multiplier
-        if eng.fuse_o2_ff1 and eng.fuse_ff_out and self.streams(Bf, Lx, Cc) and Cc % 32 == 0 and mid % 32 == 0 and x2.ld == Cc:
+        if eng.fuse_o2_ff1 and eng.fuse_ff_out and self.streams(Bf, Lx, Cc) and Cc % 32 == 0 and mid % 32 == 0 and x2.cp == Cc:
             xf = self.new_act(Bf, Lx, Cc + Cf)
             self.conv(ops, src0=a2, w=W.w[f"{n}.o2f1"], bias=W.v[f"{n}.o2f1.bias"], out=xf, residual=x2, act=L.ACT_GELU,
                       extra_segs=[(x2, 0)], m_split=Cc, k_split=mid // 32)
@@ -892,8 +932,11 @@ class Engine:
         self.fuse_shortcut = os.environ.get("JEN1_FUSE_SHORTCUT", "1") != "0"
         self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
         self.fuse_o2_ff1 = os.environ.get("JEN1_FUSE_O2_FF1", "1") != "0"
+        self.fuse_ln_proj = os.environ.get("JEN1_FUSE_LN_PROJ", "1") != "0"
         self.use_tile_kernel = os.environ.get("JEN1_TILE_KERNEL", "1") != "0"
         self.tile_min_rows = int(os.environ.get("JEN1_TILE_MIN_ROWS", "512"))
+        self.tile_target_wgs = int(os.environ.get("JEN1_TILE_TARGET_WGS", "256"))
+        self.tile_one_round = os.environ.get("JEN1_TILE_ONE_ROUND", "0") != "0"
         self.plans: Dict[tuple, Plan] = {}
         self.load_params(params)
 

@@ -444,6 +444,43 @@ def test_attention_core(ctx, d, Nq, Nk, causal):
     assert rel_err(out.t.float().cpu().numpy(), ref.cpu().numpy()) < (1e-5 if mode == "f32" else 1e-2)
 
 
+@pytest.mark.parametrize("N,causal", [(1, False), (6, True), (24, False)])
+def test_attention_deferred_layernorm_finish(ctx, N, causal):
+    """jen1_attention_fin: Q / K / V arrive as raw = W' x of a LayerNorm-folded projection; the kernel applies
+    rstd (raw - mean u) + b from the row statistics of x (blocks.py:427-429), then the usual attention."""
+    from jen1_amd.engine import Act, OpBuilder
+    kc, mode = ctx
+    torch.manual_seed(N)
+    B, H, d, C = 2, 4, 32, 96
+    mid = H * d
+    x = torch.randn(B, N, C, device="cuda") * 1.3 + 0.4
+    gam, bet = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.2
+    W = torch.randn(3 * mid, C, device="cuda") / C ** 0.5
+    Wf = (W * gam[None, :]).to(kc.tdtype).float()             # folded weights as the GEMM sees them
+    bf = W @ bet
+    raw = (x @ Wf.T)
+    t = torch.zeros(B, N, C + 3 * mid, device="cuda")
+    t[:, :, :C], t[:, :, C:] = x, raw
+    tt = t.to(kc.tdtype).contiguous()
+    rawr = tt.float()[:, :, C:]
+    rs = torch.stack([x.sum(-1), (x * x).sum(-1)], -1).reshape(-1).contiguous()
+    u = torch.cat([torch.zeros(C, device="cuda"), Wf.sum(1)]).contiguous()
+    bfull = torch.cat([torch.zeros(C, device="cuda"), bf]).contiguous()
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    qkv = (rawr - mean * Wf.sum(1)) / torch.sqrt(var + 1e-5) + bf
+    qh, kh, vh = (z.reshape(B, N, H, d).transpose(1, 2) for z in qkv.split(mid, dim=-1))
+    sim = qh @ kh.transpose(-1, -2) * d ** -0.5
+    if causal:
+        sim = sim.masked_fill(torch.ones(N, N, dtype=torch.bool, device="cuda").triu(1), -torch.finfo(torch.float32).max)
+    ref = (sim.softmax(-1) @ vh).transpose(1, 2).reshape(B, N, mid)
+    ob = OpBuilder(kc)
+    out = Act(torch.zeros((B, N, mid), dtype=kc.tdtype, device="cuda"), B, N, mid, mid)
+    ob.attention(ob.ops, q=Act(tt, B, N, C + 3 * mid, C + 3 * mid), q_off=C, kv_t=tt, ldkv=C + 3 * mid, k_off=C + mid, v_off=C + 2 * mid,
+                 out=out, H=H, d=d, Nk=N, causal=causal, fin=(rs, u, bfull, C, 1e-5, 1, 1))
+    run(ob)
+    assert rel_err(out.t.float().cpu().numpy(), ref.cpu().numpy()) < (2e-5 if mode == "f32" else 2e-2)
+
+
 # ------------------------------------------------------------------ boundary kernels
 def test_pack_unpack_roundtrip_and_stats(ctx):
     from jen1_amd import lib as L
