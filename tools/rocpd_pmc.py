@@ -24,7 +24,7 @@ idx = [i for i, r in enumerate(rows) if 'pack_input' in r[0]]
 a, b = idx[which], idx[which + 1] if which + 1 < len(idx) else len(rows)
 agg = collections.defaultdict(lambda: [0, 0.0])
 for n, _, v in rows[a:b]:
-    key = ('conv_gemm' if ('conv_gemm' in n or 'stream_gemm' in n) else 'norm_apply' if 'norm_apply' in n else 'attention' if 'attention' in n else n.split('(')[0][-36:])
+    key = ('conv_gemm' if ('conv_gemm' in n or 'stream_gemm' in n or 'tile_gemm' in n or 'TileArgs' in n) else 'norm_apply' if 'norm_apply' in n else 'attention' if 'attention' in n else n.split('(')[0][-36:])
     agg[key][0] += 1
     agg[key][1] += v
 tot = sum(v[1] for v in agg.values())

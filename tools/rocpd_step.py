@@ -22,7 +22,7 @@ print("gap avg/median/max us:", statistics.mean(gaps), statistics.median(gaps), 
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in step:
     n = r[0]
-    key = ('stream_gemm' if 'stream_gemm' in n else 'conv_gemm(wide)' if 'conv_gemm' in n else 'norm_apply' if 'norm_apply' in n else 'attention' if 'attention' in n else n.split('(')[0][-40:])
+    key = ('stream_gemm' if 'stream_gemm' in n else 'tile_gemm' if ('tile_gemm' in n or 'TileArgs' in n) else 'conv_gemm(wide)' if 'conv_gemm' in n else 'norm_apply' if 'norm_apply' in n else 'attention' if 'attention' in n else n.split('(')[0][-40:])
     wg = (r[3] // r[6]) * r[4] * r[5]
     k = (key, wg, r[7])
     agg[k][0] += 1
