@@ -140,6 +140,29 @@ def conv_roofline(st, reps=3):
     }
 
 
+def optimizer_step_bench(n_params, device, reps=5):
+    """SURVEY.md section 8 row a16 measured on its own: clip_grad_norm_ + AdamW over the full model's parameter count
+    (jen1_grad_sqnorm + jen1_adamw_step on flat float32 buffers).  Algorithmic bytes: the norm reads g (4 B), the update
+    reads p, g, m, v and writes p, m, v (28 B) = 32 B per parameter."""
+    from jen1_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.randn(n_params, device=device) * 0.02)
+    opt = FusedAdamW([p], lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1, max_norm=0.7)
+    p.grad.normal_(0, 1e-3)
+    for _ in range(2):
+        opt.step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        opt.step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = 32.0 * n_params / (ms * 1e-3) / 1e9
+    return {"what": "clip_grad_norm_(0.7) + AdamW step over %d float32 parameters (row a16)" % n_params, "ms": round(ms, 3),
+            "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def cpu_baseline(B, T, tiny):
     """The CPU oracle (numpy port of the reference path) on the host cores: bounded sample."""
     from jen1_amd import synth
@@ -231,6 +254,8 @@ def main():
                             "ms_per_step": round(dt2 / n2 * 1e3, 4),
                             "roofline_frac": r2["frac"], "alg_bytes_per_step": r2["alg_bytes_per_step"],
                             "conv_ms_per_step": r2["conv_ms_per_step"]}
+            if not args.tiny:
+                out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.tiny)
         print(json.dumps(out))

@@ -272,6 +272,18 @@ int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, f
 /* zero `bytes` bytes at p on the stream (statistics arena reset; capturable). */
 int jen1_memset_zero(void* p, int64_t bytes, void* stream);
 
+/*
+ * Optimiser step of the trainer (trainer.py:144-149, train.py:56-60) on flat float32 buffers:
+ *   jen1_grad_sqnorm: out[0] += sum(g^2)                       (first half of nn.utils.clip_grad_norm_; zero `out` first)
+ *   jen1_adamw_step : g' = g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6))  (second half; gnorm_sq NULL or max_norm <= 0: no clip)
+ *                     then torch.optim.AdamW.step() number `step` (1-based) with decoupled weight decay, in place.
+ *                     skip_nonfinite: a non-finite norm leaves p, m, v untouched (GradScaler.step semantics).
+ * gnorm_sq is read on the device, so clip + update needs no host synchronisation.
+ */
+int jen1_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
+int jen1_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, const float* gnorm_sq, float max_norm, int skip_nonfinite, void* stream);
+
 const char* jen1_last_error(void);
 /* "gfx950" build tag + ABI version, for the loader's sanity check */
 const char* jen1_build_info(void);

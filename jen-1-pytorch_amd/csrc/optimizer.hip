@@ -1,0 +1,142 @@
+// Optimiser step of the JEN-1 trainer on gfx950:
+//   nn.utils.clip_grad_norm_(model.parameters(), 0.7) -> torch.optim.AdamW.step()
+//   (/root/reference/trainer.py:144-149, /root/reference/train.py:56-60: lr 3e-5, betas (0.9, 0.95), weight_decay 0.1,
+//    one parameter group: the decay applies to every parameter).
+// Elementwise over 296.5 M float32 parameters + gradient + two moments: 28 bytes per parameter, purely HBM-bound.
+//   jen1_grad_sqnorm : sum of squares of the flat gradient -> one device float (block partials + one atomic per block)
+//   jen1_adamw_step  : reads that device scalar, so clip + AdamW is ONE pass with no host synchronisation:
+//                      g' = g * min(1, max_norm / (||g|| + 1e-6));  p *= 1 - lr wd;  m, v updates;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+//   A non-finite gradient norm skips the step (GradScaler semantics of trainer.py:147 when fp16 is on).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+  const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));   // streamed once: keep it out of the caches
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+constexpr int OPT_THREADS = 256;
+constexpr int OPT_VEC_PER_THREAD = 4;        // float4 vectors per thread per grid-stride pass
+
+__global__ __launch_bounds__(OPT_THREADS) void grad_sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float red[OPT_THREADS / 64];
+  const int64_t nv = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float s = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * OPT_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < nv; i += stride * OPT_VEC_PER_THREAD) {
+    float4 v[OPT_VEC_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < OPT_VEC_PER_THREAD; ++u) {
+      const int64_t j = i + u * stride;
+      v[u] = j < nv ? nt_load4(g4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < OPT_VEC_PER_THREAD; ++u) s += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float t = g[(nv << 2) + threadIdx.x];
+    s += t * t;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < OPT_THREADS / 64; ++w) t += red[w];
+    atomicAdd(out, t);
+  }
+}
+
+struct AdamArgs {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  const float* gnorm_sq;     // device scalar (sum of squares over ALL parameters) or NULL: no clipping
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay, max_norm, bc1, inv_sqrt_bc2;
+  int32_t skip_nonfinite;
+};
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float coef) {
+  g *= coef;
+  p *= 1.0f - a.lr * a.weight_decay;
+  m = a.beta1 * m + (1.0f - a.beta1) * g;                      // torch: exp_avg.lerp_(grad, 1 - beta1)
+  v = a.beta2 * v + (1.0f - a.beta2) * g * g;
+  const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+  p -= (a.lr / a.bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(const AdamArgs a) {
+  float coef = 1.0f;
+  if (a.gnorm_sq) {
+    const float nrm = sqrtf(a.gnorm_sq[0]);
+    if (a.skip_nonfinite && !(nrm <= 3.0e38f)) return;          // inf / nan gradients: leave parameters and moments untouched
+    if (a.max_norm > 0.f) {
+      const float c = a.max_norm / (nrm + 1e-6f);
+      coef = c < 1.0f ? c : 1.0f;
+    }
+  }
+  const int64_t nv = a.n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(a.p);
+  const float4* g4 = reinterpret_cast<const float4*>(a.g);
+  float4* m4 = reinterpret_cast<float4*>(a.m);
+  float4* v4 = reinterpret_cast<float4*>(a.v);
+  const int64_t stride = (int64_t)gridDim.x * OPT_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < nv; i += stride) {
+    float4 p = p4[i], m = m4[i], v = v4[i];
+    const float4 g = nt_load4(g4 + i);
+    adam1(p.x, g.x, m.x, v.x, a, coef);
+    adam1(p.y, g.y, m.y, v.y, a, coef);
+    adam1(p.z, g.z, m.z, v.z, a, coef);
+    adam1(p.w, g.w, m.w, v.w, a, coef);
+    p4[i] = p;
+    m4[i] = m;
+    v4[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    const int64_t j = (nv << 2) + threadIdx.x;
+    float p = a.p[j], m = a.m[j], v = a.v[j];
+    adam1(p, a.g[j], m, v, a, coef);
+    a.p[j] = p; a.m[j] = m; a.v[j] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int jen1_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
+  JEN1_CHECK(g && out && n > 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "grad_sqnorm: null / unaligned pointer or empty tensor");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nv = n >> 2;
+  int64_t blocks = (nv + OPT_THREADS * OPT_VEC_PER_THREAD - 1) / (OPT_THREADS * OPT_VEC_PER_THREAD);
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, g, n, out);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, const float* gnorm_sq, float max_norm, int skip_nonfinite, void* stream) {
+  JEN1_CHECK(p && g && m && v && n > 0, "adamw_step: null pointer or empty tensor");
+  JEN1_CHECK(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0,
+             "adamw_step: buffers must be 16-byte aligned");
+  JEN1_CHECK(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adamw_step: bad step / betas");
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.gnorm_sq = gnorm_sq; a.n = n;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.max_norm = max_norm;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+  a.skip_nonfinite = skip_nonfinite;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nv = n >> 2;
+  int64_t blocks = (nv + OPT_THREADS - 1) / OPT_THREADS;
+  blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, a);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}

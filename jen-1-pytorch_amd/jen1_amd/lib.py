@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip", "optimizer.hip"]
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -91,6 +91,8 @@ SYMBOLS = {
     "jen1_cfg_ddim_step": (c_int, [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
     "jen1_step_advance": (c_int, [_P, _P]),
     "jen1_cfg_combine": (c_int, [_P, _P] + [c_int] * 4 + [c_float, c_int, c_float, c_int, _P]),
+    "jen1_grad_sqnorm": (c_int, [_P, c_int64, _P, _P]),
+    "jen1_adamw_step": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [c_int, _P, c_float, c_int, _P]),
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),

@@ -1,0 +1,117 @@
+"""Optimiser step and data-parallel gradient exchange of the trainer (SURVEY.md section 8 rows a16 and e).
+
+Host-side mirror of /root/reference/train.py:56-60, :84 and /root/reference/trainer.py:139-150:
+``torch.optim.AdamW(lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1)`` over ONE parameter group,
+``nn.utils.clip_grad_norm_(parameters, 0.7)``, ``LinearLR`` (factor 1/3 -> 1 over 5 optimiser steps) and, under DDP
+(train.py:88-89), the mean all-reduce of the gradients.  Parameters, gradients and both moments live in flat float32
+buffers (the model's parameters become views of the flat buffer), so clip + AdamW is two HIP launches over 296.5 M
+elements (jen1_grad_sqnorm, jen1_adamw_step) with no host synchronisation, and the gradient exchange is a few large
+RCCL all-reduces over xGMI instead of 979 small ones.  The backward pass that produces the gradients is NOT part of
+this round: the class works on whatever fills ``flat_grad``.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import lib as L
+
+
+class LinearLR:
+    """torch.optim.lr_scheduler.LinearLR defaults (train.py:84): factor start_factor -> 1 over total_iters steps."""
+
+    def __init__(self, base_lr: float, start_factor: float = 1.0 / 3, end_factor: float = 1.0, total_iters: int = 5, last_epoch: int = -1):
+        self.base_lr, self.start_factor, self.end_factor, self.total_iters = base_lr, start_factor, end_factor, total_iters
+        self.last_epoch = last_epoch + 1
+
+    def factor(self) -> float:
+        t = min(self.last_epoch, self.total_iters)
+        return self.start_factor + (self.end_factor - self.start_factor) * t / self.total_iters
+
+    def get_last_lr(self) -> float:
+        return self.base_lr * self.factor()
+
+    def step(self) -> None:
+        self.last_epoch += 1
+
+
+class FusedAdamW:
+    """AdamW + global-norm clipping over flat buffers.  ``params``: the model's parameters (any device for construction;
+    ``step`` needs the GPU).  After construction every ``p.data`` is a view of ``flat_param`` and every ``p.grad`` a view
+    of ``flat_grad`` (so autograd, or a test, writes gradients straight into the flat buffer)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 3e-5, betas=(0.9, 0.95), eps: float = 1e-8,
+                 weight_decay: float = 0.1, max_norm: Optional[float] = 0.7, skip_nonfinite: bool = False):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        assert self.params and all(p.dtype == torch.float32 for p in self.params), "float32 master parameters (train.py:56)"
+        dev = self.params[0].device
+        # every tensor starts on a 16-byte boundary of the flat buffer (float4 access in the kernels)
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.numel = n
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + p.numel()].view_as(p)
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_norm, self.skip_nonfinite = max_norm, skip_nonfinite
+        self.step_count = 0
+        self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def zero_grad(self) -> None:
+        self.flat_grad.zero_()
+
+    def grad_norm(self) -> torch.Tensor:
+        """total L2 norm of the gradient as a device scalar (what clip_grad_norm_ returns)"""
+        return self._gnorm_sq.sqrt()
+
+    def step(self, lr: Optional[float] = None) -> None:
+        """clip_grad_norm_ + AdamW.step() (trainer.py:145-147) on the current stream"""
+        lib = L.load()
+        if self.flat_param.device.type != "cuda":
+            raise L.Jen1HipError("FusedAdamW.step needs a ROCm GPU; no CPU path exists in this package")
+        s = torch.cuda.current_stream(self.flat_param.device).cuda_stream
+        self.step_count += 1
+        gn = None
+        if self.max_norm is not None or self.skip_nonfinite:
+            self._gnorm_sq.zero_()
+            L.check(lib.jen1_grad_sqnorm(self.flat_grad.data_ptr(), self.numel, self._gnorm_sq.data_ptr(), s), "jen1_grad_sqnorm")
+            gn = self._gnorm_sq.data_ptr()
+        L.check(lib.jen1_adamw_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                    self.numel, float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                    float(self.weight_decay), self.step_count, gn, float(self.max_norm or 0.0), 1 if self.skip_nonfinite else 0, s),
+                "jen1_adamw_step")
+
+    def state_dict(self) -> dict:
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "betas": self.betas,
+                "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+def allreduce_gradients(flat_grad: torch.Tensor, group=None, bucket_bytes: int = 256 << 20) -> None:
+    """DDP gradient exchange (train.py:88-89): mean over ranks, in place, in a few large buckets (xGMI rings are
+    per-link bound: big messages, not 979 small ones).  ``backend="nccl"`` is RCCL on ROCm; gloo on CPU for tests."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    per = max(1, bucket_bytes // flat_grad.element_size())
+    works = []
+    for o in range(0, flat_grad.numel(), per):
+        works.append(dist.all_reduce(flat_grad[o:o + per], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    flat_grad.mul_(1.0 / world)

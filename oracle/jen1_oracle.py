@@ -534,3 +534,33 @@ def task_mask(task: str, T: int, *, mask_length: Optional[int] = None, mask_star
 def input_concat_cond(masked_input: Array, mask: Array) -> Array:
     """cat([x*mask, mask], dim=1) -> [b, 129, T] (trainer.py:271; generation.py:171-185)."""
     return np.concatenate([masked_input, np.broadcast_to(mask, (masked_input.shape[0], 1, masked_input.shape[2]))], axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# optimiser step (SURVEY.md section 8 row a16): trainer.py:144-149, train.py:56-60, :84
+def clip_grad_norm(grads, max_norm: float):
+    """nn.utils.clip_grad_norm_ (L2, error_if_nonfinite=False): returns (clipped grads, total_norm)."""
+    total = float(np.sqrt(sum(float(np.sum(g.astype(np.float64) ** 2)) for g in grads)))
+    coef = min(1.0, max_norm / (total + 1e-6))
+    return [(g * np.float32(coef)).astype(np.float32) for g in grads], total
+
+
+def adamw_step(p, g, m, v, step: int, lr=3e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1):
+    """one torch.optim.AdamW step (decoupled weight decay, single-tensor formulation), float32 like the reference;
+    returns (p, m, v).  ``step`` is 1-based."""
+    f = np.float32
+    b1, b2 = f(betas[0]), f(betas[1])
+    p = (p * f(1.0 - lr * weight_decay)).astype(f)
+    m = (b1 * m + (f(1) - b1) * g).astype(f)
+    v = (b2 * v + (f(1) - b2) * g * g).astype(f)
+    bc1 = 1.0 - betas[0] ** step
+    bc2 = 1.0 - betas[1] ** step
+    denom = (np.sqrt(v) / f(np.sqrt(bc2)) + f(eps)).astype(f)
+    p = (p - f(lr / bc1) * (m / denom)).astype(f)
+    return p, m, v
+
+
+def linear_lr_factor(it: int, start_factor: float = 1.0 / 3, end_factor: float = 1.0, total_iters: int = 5) -> float:
+    """torch.optim.lr_scheduler.LinearLR closed form (train.py:84): factor after ``it`` scheduler steps."""
+    t = min(it, total_iters)
+    return start_factor + (end_factor - start_factor) * t / total_iters

@@ -1,0 +1,161 @@
+"""Optimiser step and gradient exchange (e).
+CPU: the oracle restatement against torch.optim.AdamW / clip_grad_norm_ / LinearLR (the reference uses exactly these:
+train.py:56-60, :84, trainer.py:144-149), the flat-buffer host logic, the bucketed mean all-reduce on gloo world-2.
+GPU: jen1_grad_sqnorm + jen1_adamw_step through the C ABI against the oracle and torch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import jen1_oracle as O  # noqa: E402  (the checker, tests only)
+from jen1_amd.optim import FusedAdamW, LinearLR, allreduce_gradients  # noqa: E402
+
+SHAPES = [(37, 5, 3), (128,), (64, 33), (1,), (19, 7)]
+
+
+def _torch_run(params0, grads, steps, lr0=3e-5, max_norm=0.7):
+    ps = [torch.nn.Parameter(torch.from_numpy(p.copy())) for p in params0]
+    opt = torch.optim.AdamW(ps, lr=lr0, betas=(0.9, 0.95), weight_decay=0.1)
+    sched = torch.optim.lr_scheduler.LinearLR(opt)
+    norms = []
+    for k in range(steps):
+        for p, g in zip(ps, grads[k]):
+            p.grad = torch.from_numpy(g.copy())
+        norms.append(float(torch.nn.utils.clip_grad_norm_(ps, max_norm)))
+        opt.step()
+        sched.step()
+    return [p.detach().numpy() for p in ps], norms
+
+
+def _data(steps, seed=0, scale=1.0):
+    rng = np.random.default_rng(seed)
+    params0 = [rng.standard_normal(s).astype(np.float32) for s in SHAPES]
+    grads = [[(rng.standard_normal(s) * scale).astype(np.float32) for s in SHAPES] for _ in range(steps)]
+    return params0, grads
+
+
+def test_oracle_adamw_clip_linearlr_match_torch():
+    steps = 7
+    params0, grads = _data(steps, scale=0.3)
+    want, norms = _torch_run(params0, grads, steps)
+    ps = [p.copy() for p in params0]
+    ms = [np.zeros_like(p) for p in ps]
+    vs = [np.zeros_like(p) for p in ps]
+    for k in range(steps):
+        g, total = O.clip_grad_norm(grads[k], 0.7)
+        assert abs(total - norms[k]) < 1e-4 * norms[k]
+        lr = 3e-5 * O.linear_lr_factor(k)
+        for i in range(len(ps)):
+            ps[i], ms[i], vs[i] = O.adamw_step(ps[i], g[i], ms[i], vs[i], k + 1, lr=lr)
+    for a, b in zip(ps, want):
+        assert np.abs(a - b).max() <= 2e-7 * max(1.0, np.abs(b).max())
+    sched = LinearLR(3e-5)
+    for k in range(9):
+        assert abs(sched.get_last_lr() - 3e-5 * O.linear_lr_factor(k)) < 1e-12
+        sched.step()
+
+
+def test_flat_buffers_are_views_and_aligned():
+    params0, _ = _data(1)
+    ps = [torch.nn.Parameter(torch.from_numpy(p.copy())) for p in params0]
+    opt = FusedAdamW(ps)
+    assert all(o % 4 == 0 for o in opt.offsets) and opt.numel % 4 == 0
+    for p, p0, o in zip(ps, params0, opt.offsets):
+        assert np.array_equal(p.detach().numpy(), p0)
+        assert p.data_ptr() == opt.flat_param.data_ptr() + 4 * o and p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * o
+    ps[2].grad.fill_(2.0)
+    assert float(opt.flat_grad.sum()) == 2.0 * ps[2].numel()
+    opt.zero_grad()
+    assert float(ps[2].grad.abs().sum()) == 0.0
+    if not torch.cuda.is_available():
+        from jen1_amd.lib import Jen1HipError
+        with pytest.raises(Jen1HipError):
+            opt.step()
+
+
+def _allreduce_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    allreduce_gradients(g, bucket_bytes=1024)            # 4 buckets of 256 floats
+    q.put((rank, g.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_mean_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    want = np.arange(1000, dtype=np.float32) * 1.5        # mean of 1x and 2x
+    assert np.allclose(outs[0], want) and np.allclose(outs[1], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_norm,scale", [(0.7, 0.3), (0.7, 1e-3), (None, 0.3)])
+def test_fused_adamw_matches_oracle_and_torch(max_norm, scale):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    steps = 5
+    params0, grads = _data(steps, seed=3, scale=scale)
+    ps = [torch.nn.Parameter(torch.from_numpy(p.copy()).cuda()) for p in params0]
+    opt = FusedAdamW(ps, lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1, max_norm=max_norm)
+    sched = LinearLR(3e-5)
+    ref, ms, vs = [p.copy() for p in params0], [np.zeros_like(p) for p in params0], [np.zeros_like(p) for p in params0]
+    for k in range(steps):
+        for p, g in zip(ps, grads[k]):
+            p.grad.copy_(torch.from_numpy(g))
+        opt.step(lr=sched.get_last_lr())
+        g = grads[k]
+        if max_norm is not None:
+            g, total = O.clip_grad_norm(g, max_norm)
+            assert abs(float(opt.grad_norm()) - total) < 1e-5 * total
+        for i in range(len(ref)):
+            ref[i], ms[i], vs[i] = O.adamw_step(ref[i], g[i], ms[i], vs[i], k + 1, lr=sched.get_last_lr())
+        sched.step()
+    # float32 throughout; the kernel's a*b+c are fused multiply-adds while numpy / torch round every operation:
+    # a few ulp after 5 steps (1 ulp of a value in [2, 4) is 2.4e-7)
+    tol = 1e-6
+    for p, r in zip(ps, ref):
+        assert np.abs(p.detach().cpu().numpy() - r).max() <= tol * max(1.0, np.abs(r).max())
+    if max_norm is not None:
+        want, _ = _torch_run(params0, grads, steps, max_norm=max_norm)
+        for p, r in zip(ps, want):
+            assert np.abs(p.detach().cpu().numpy() - r).max() <= tol * max(1.0, np.abs(r).max())
+
+
+@pytest.mark.gpu
+def test_fused_adamw_skips_nonfinite_and_large_buffer():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    n = (1 << 22) + 3
+    p = torch.nn.Parameter(torch.randn(n, device="cuda"))
+    opt = FusedAdamW([p], max_norm=0.7, skip_nonfinite=True)
+    before = p.detach().clone()
+    p.grad.normal_()
+    p.grad[12345] = float("inf")
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(p.detach(), before) and float(opt.exp_avg.abs().sum()) == 0.0
+    p.grad.normal_()
+    g = p.grad.clone()
+    opt.step()
+    total = float(g.double().norm())
+    assert abs(float(opt.grad_norm()) - total) < 1e-4 * total
+    coef = min(1.0, 0.7 / (total + 1e-6))
+    m = 0.1 * g * coef
+    v = 0.05 * (g * coef) ** 2
+    want = before * (1 - 3e-5 * 0.1) - (3e-5 / (1 - 0.9 ** 2)) * m / (v.sqrt() / (1 - 0.95 ** 2) ** 0.5 + 1e-8)
+    assert float((p.detach() - want).abs().max()) < 1e-6
