@@ -12,16 +12,46 @@
 // producer does through its row_scale epilogue.
 #include "common.h"
 
+#ifdef JEN1_PROFILE
+__device__ unsigned long long* g_attn_dbg = nullptr;
+extern "C" int jen1_debug_set_attention_buffer(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#define AT_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_attn_dbg) g_attn_dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AT_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
-constexpr int QCHUNK = 32;
-constexpr int FMAX = 2;    // K/V vectors per thread that may carry a deferred LayerNorm finish (self-attention: Nk <= 24)
-constexpr int MAXV = 9;    // 8-element vectors per thread for one K or V tile: ceil(141*128/8/256) = 9
+constexpr int QCHUNK = 32;     // queries per workgroup: two 16-row MFMA tiles
+constexpr int FMAX = 2;        // K/V vectors per thread that may carry a deferred LayerNorm finish (self-attention: Nk <= 24)
+constexpr int MAXV = 9;        // 8-element vectors per thread for one K or V tile: ceil(141*128/8/256) = 9
 
-// Memory-level parallelism matters more than arithmetic here: with <= 128 workgroups there is one wave
-// per SIMD, and a loop that loads and immediately consumes costs one full memory latency per trip.  So
-// every Q, K and V vector of the tile is requested up front (V waits in registers while the scores are
-// computed on K), and only then does the kernel touch LDS.
+template <typename T> struct AFrag;
+template <> struct AFrag<bf16_t> { typedef bf16x8 type; };
+template <> struct AFrag<float> { typedef f32x8 type; };
+__device__ __forceinline__ void amma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void amma(f32x4& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void lds_frag(bf16x8& f, const bf16_t* p) { f = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void lds_frag(f32x8& f, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+
+// One 256-thread workgroup per (batch element, head, 32-query chunk).
+//   * every Q, K and V vector of the tile (and the operands of a deferred LayerNorm finish) is requested up front;
+//     with <= 128 workgroups there is one wave per SIMD, so a load-use loop would cost a memory latency per trip;
+//   * Q K^T and P V run on the matrix cores (v_mfma_f32_16x16x32_bf16, or 16x16x4_f32 in the float32 parity mode:
+//     exact fp32 products) from LDS tiles: Q [32][d], K [Nk][d], then V transposed [d][Nk] in K's place;
+//   * softmax in float32, one wavefront per row, 64-lane __shfl_xor max / sum (blocks.py:367-371).
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ v, T* __restrict__ out,
@@ -34,67 +64,85 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
                                                          int ldo, int causal, float scale,
                                                          const float* __restrict__ fin_stats, const float* __restrict__ fin_u,
                                                          const float* __restrict__ fin_b, float fin_inv_c, float fin_eps,
-                                                         int fin_q, int fin_kv) {
+                                                         int fin_q, int fin_kv, float inv_H, int log2_vpr) {
+  typedef typename AFrag<T>::type Frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool PRECISE = is_f32<T>::value;
-  jen1_prefetch_kernarg<176>();
+  jen1_prefetch_kernarg<184>();
+  AT_STAMP(0);
   const int bh = blockIdx.x;
-  const int b = bh / H, h = bh - b * H;
+  const int b = (int)(((float)bh + 0.5f) * inv_H), h = bh - b * H;
   const int q0 = blockIdx.y * QCHUNK;
   const int nq = (Nq - q0 < QCHUNK) ? (Nq - q0) : QCHUNK;
-  const int tid = threadIdx.x;
-  const int dp = d + 1;                          // padded row pitch (floats) -> conflict-free column walks
-  float* kv_s = reinterpret_cast<float*>(smem);  // [Nk][dp]  K first, V later
-  float* q_s = kv_s + Nk * dp;                   // [QCHUNK][dp]
-  float* p_s = q_s + QCHUNK * dp;                // [QCHUNK][Nk]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int NKP = (Nk + 31) & ~31;               // keys padded to the MFMA K step of P V
+  const int DP = d < 32 ? 32 : d;                // Q / K columns the matrix cores read (zero beyond d)
+  const int DC = d < 16 ? 16 : d;                // V^T rows they read
+  const int dq = DP + 8;                         // row pitch of Q / K (elements): 16-byte rows, banks spread
+  const int vt = NKP + 8;                        // row pitch of V^T and P
+  const int sp = NKP + 1;                        // row pitch of the float32 scores
+  T* q_s = reinterpret_cast<T*>(smem);                               // [32][dq]
+  T* kv_s = q_s + QCHUNK * dq;                                      // K [NKP][dq], later V^T [d][vt]
+  const int kv_elems = (NKP * dq > DC * vt) ? NKP * dq : DC * vt;
+  float* s_s = reinterpret_cast<float*>(kv_s + ((kv_elems + 7) & ~7));   // [32][sp]
+  T* p_s = reinterpret_cast<T*>(s_s + ((QCHUNK * sp + 3) & ~3));      // [32][vt]
 
-  const size_t kvbase = (size_t)(kv_row ? kv_row[b] : b) * Nk;
+  const int kvbase = (kv_row ? kv_row[b] : b) * Nk;
   // optional per-step last key row (the time token of the text context, model.py:315-316)
   int xr = (kv_extra && extra_row) ? extra_row[b] : -1;
   if (xr >= 0 && extra_step) xr = extra_step[0];
-  const int vpr = d >> 3;                        // 8-element vectors per row
+  const int vpr = 1 << log2_vpr;                 // 8-element vectors per row (d = 8 * vpr)
   const int nkv = Nk * vpr, nqv = nq * vpr;
+  const int hd = h * d;
+  AT_STAMP(1);
 
   // ---- issue all loads -----------------------------------------------------------------------
   // Deferred LayerNorm-folded projections (fin_*): the producer GEMM wrote raw = W' x; the row statistics of x
   // were only complete once that launch ended, so the affine finish  rstd_row (raw - mean_row u[col]) + b[col]
   // (blocks.py:427-429) is applied here, on the way into LDS.  Its operands ride along with the Q/K/V loads.
-  float kreg[MAXV][8], qreg[2][8];
-  typename VecOf<T>::type vraw[MAXV];
+  typedef typename VecOf<T>::type Vec;
+  Vec kraw[MAXV], vraw[MAXV], qraw[2];
   float2 kst[FMAX], qst[2];
   float uk[FMAX][8], bk[FMAX][8], uv[FMAX][8], bv[FMAX][8], uq[2][8], bq[2][8];
 #pragma unroll
   for (int u = 0; u < MAXV; ++u) {
     const int i = tid + u * 256;
-    const int ii = i < nkv ? i : 0;
-    const int r = ii / vpr, c = (ii - r * vpr) * 8;
-    const bool ex = (xr >= 0 && r == Nk - 1);
-    const T* kp = ex ? kv_extra + (size_t)xr * ld_extra + kx_off + h * d + c : k + (kvbase + r) * ldkv + k_off + h * d + c;
-    const T* vp = ex ? kv_extra + (size_t)xr * ld_extra + vx_off + h * d + c : v + (kvbase + r) * ldkv + v_off + h * d + c;
-    load8(kp, kreg[u]);
-    vraw[u] = *reinterpret_cast<const typename VecOf<T>::type*>(vp);
-    if (u < FMAX) {
-      if (fin_kv && i < nkv) {
-        kst[u] = *reinterpret_cast<const float2*>(fin_stats + 2 * (kvbase + r));
-        load8(fin_u + k_off + h * d + c, uk[u]);
-        load8(fin_b + k_off + h * d + c, bk[u]);
-        load8(fin_u + v_off + h * d + c, uv[u]);
-        load8(fin_b + v_off + h * d + c, bv[u]);
+    if (i < nkv) {
+      const int r = i >> log2_vpr, c = (i & (vpr - 1)) * 8;
+      const bool ex = (xr >= 0 && r == Nk - 1);
+      const T* kp = ex ? kv_extra + (size_t)((unsigned)xr * (unsigned)ld_extra + (unsigned)(kx_off + hd + c))
+                       : k + (size_t)((unsigned)(kvbase + r) * (unsigned)ldkv + (unsigned)(k_off + hd + c));
+      const T* vp = ex ? kv_extra + (size_t)((unsigned)xr * (unsigned)ld_extra + (unsigned)(vx_off + hd + c))
+                       : v + (size_t)((unsigned)(kvbase + r) * (unsigned)ldkv + (unsigned)(v_off + hd + c));
+      kraw[u] = *reinterpret_cast<const Vec*>(kp);
+      vraw[u] = *reinterpret_cast<const Vec*>(vp);
+      if (u < FMAX) {
+        if (fin_kv) {
+          kst[u] = *reinterpret_cast<const float2*>(fin_stats + 2 * (kvbase + r));
+          load8(fin_u + k_off + hd + c, uk[u]);
+          load8(fin_b + k_off + hd + c, bk[u]);
+          load8(fin_u + v_off + hd + c, uv[u]);
+          load8(fin_b + v_off + hd + c, bv[u]);
+        }
       }
     }
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {                  // QCHUNK * 128 / 8 / 256 = 2 vectors per thread at most
     const int i = tid + u * 256;
-    const int ii = i < nqv ? i : 0;
-    const int r = ii / vpr, c = (ii - r * vpr) * 8;
-    load8(q + ((size_t)b * Nq + q0 + r) * ldq + q_off + h * d + c, qreg[u]);
-    if (fin_q && i < nqv) {
-      qst[u] = *reinterpret_cast<const float2*>(fin_stats + 2 * ((size_t)b * Nq + q0 + r));
-      load8(fin_u + q_off + h * d + c, uq[u]);
-      load8(fin_b + q_off + h * d + c, bq[u]);
+    if (i < nqv) {
+      const int r = i >> log2_vpr, c = (i & (vpr - 1)) * 8;
+      qraw[u] = *reinterpret_cast<const Vec*>(q + (size_t)((unsigned)(b * Nq + q0 + r) * (unsigned)ldq + (unsigned)(q_off + hd + c)));
+      if (fin_q) {
+        qst[u] = *reinterpret_cast<const float2*>(fin_stats + 2 * (b * Nq + q0 + r));
+        load8(fin_u + q_off + hd + c, uq[u]);
+        load8(fin_b + q_off + hd + c, bq[u]);
+      }
     }
   }
+  AT_STAMP(2);
   auto finish = [&](float (&x)[8], const float2 st, const float (&uu)[8], const float (&bb)[8]) {
     const float mean = st.x * fin_inv_c;
     float var = st.y * fin_inv_c - mean * mean;
@@ -103,83 +151,128 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = (x[e] - mean * uu[e]) * rstd + bb[e];
   };
+  // ---- zero the padding the matrix cores will read: Q rows >= nq, K rows >= Nk (and columns >= d of a narrow head) ----
+  {
+    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (d < 32) {
+      for (int i = tid; i < (QCHUNK + NKP) * (dq >> 3); i += 256) store8(q_s + i * 8, z8);     // Q and K tiles are contiguous
+      __syncthreads();
+    } else {
+      for (int i = tid; i < (QCHUNK - nq) * vpr; i += 256) store8(q_s + (nq + (i >> log2_vpr)) * dq + (i & (vpr - 1)) * 8, z8);
+      for (int i = tid; i < (NKP - Nk) * vpr; i += 256) store8(kv_s + (Nk + (i >> log2_vpr)) * dq + (i & (vpr - 1)) * 8, z8);
+    }
+  }
   // ---- K, Q -> LDS ------------------------------------------------------------------------------
 #pragma unroll
   for (int u = 0; u < MAXV; ++u) {
     const int i = tid + u * 256;
     if (i < nkv) {
-      const int r = i / vpr, c = (i - r * vpr) * 8;
+      const int r = i >> log2_vpr, c = (i & (vpr - 1)) * 8;
+      bool raw_copy = true;
       if (u < FMAX) {
-        if (fin_kv) finish(kreg[u], kst[u], uk[u], bk[u]);
+        if (fin_kv) {
+          float x[8];
+          vec_to_float(kraw[u], x);
+          finish(x, kst[u], uk[u], bk[u]);
+          store8(kv_s + r * dq + c, x);
+          raw_copy = false;
+        }
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) kv_s[r * dp + c + e] = kreg[u][e];
+      if (raw_copy) *reinterpret_cast<Vec*>(kv_s + r * dq + c) = kraw[u];
     }
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int i = tid + u * 256;
     if (i < nqv) {
-      const int r = i / vpr, c = (i - r * vpr) * 8;
-      if (fin_q) finish(qreg[u], qst[u], uq[u], bq[u]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q_s[r * dp + c + e] = qreg[u][e];
-    }
-  }
-  __syncthreads();
-  // ---- scores: one thread = one query row x 4 keys (keys strided by njb so lanes stay conflict-free) ----
-  {
-    const int njb = (Nk + 3) >> 2;
-    for (int i = tid; i < nq * njb; i += 256) {
-      const int r = i / njb, jb = i - r * njb;
-      const float* qp = q_s + r * dp;
-      const int j0 = jb, j1 = jb + njb, j2 = jb + 2 * njb, j3 = jb + 3 * njb;
-      const float* k0 = kv_s + j0 * dp;
-      const float* k1 = kv_s + (j1 < Nk ? j1 : j0) * dp;
-      const float* k2 = kv_s + (j2 < Nk ? j2 : j0) * dp;
-      const float* k3 = kv_s + (j3 < Nk ? j3 : j0) * dp;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      for (int c = 0; c < d; ++c) {
-        const float qv = qp[c];
-        s0 = fmaf(qv, k0[c], s0);
-        s1 = fmaf(qv, k1[c], s1);
-        s2 = fmaf(qv, k2[c], s2);
-        s3 = fmaf(qv, k3[c], s3);
+      const int r = i >> log2_vpr, c = (i & (vpr - 1)) * 8;
+      if (fin_q) {
+        float x[8];
+        vec_to_float(qraw[u], x);
+        finish(x, qst[u], uq[u], bq[u]);
+        store8(q_s + r * dq + c, x);
+      } else {
+        *reinterpret_cast<Vec*>(q_s + r * dq + c) = qraw[u];
       }
-      const int lim = (q0 + r) + (Nk - Nq);      // causal: keep j <= i + (Nk - Nq)  (blocks.py:315-319)
-      const float NEG = -3.402823466e+38f;
-      float* pr = p_s + r * Nk;
-      pr[j0] = (causal && j0 > lim) ? NEG : s0 * scale;
-      if (j1 < Nk) pr[j1] = (causal && j1 > lim) ? NEG : s1 * scale;
-      if (j2 < Nk) pr[j2] = (causal && j2 > lim) ? NEG : s2 * scale;
-      if (j3 < Nk) pr[j3] = (causal && j3 > lim) ? NEG : s3 * scale;
     }
   }
   __syncthreads();
-  // ---- V (already in registers) replaces K in LDS ---------------------------------------------
+  AT_STAMP(3);
+  // ---- scores on the matrix cores: wave w takes key tiles w, w + 4, ... for both query tiles --------------------
+  {
+    const int nkt = NKP >> 4;
+    const int nqt = (nq + 15) >> 4;
+    for (int kt = wave; kt < nkt; kt += 4) {
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      for (int c = 0; c < DP; c += 32) {
+        Frag kb;
+        lds_frag(kb, kv_s + (kt * 16 + li) * dq + c + lg * 8);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          if (qt < nqt) {
+            Frag qa;
+            lds_frag(qa, q_s + (qt * 16 + li) * dq + c + lg * 8);
+            amma(acc[qt], qa, kb);
+          }
+        }
+      }
+      // lane (li, lg) holds rows 4 lg + r (queries), column li (key)
+      const int j = kt * 16 + li;
+      const float NEG = -3.402823466e+38f;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        if (qt < nqt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = qt * 16 + lg * 4 + r;
+            const int lim = (q0 + qi) + (Nk - Nq);      // causal: keep j <= i + (Nk - Nq)  (blocks.py:315-319)
+            s_s[qi * sp + j] = (causal && j > lim) ? NEG : acc[qt][r] * scale;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  AT_STAMP(4);
+  // ---- V (already in registers) replaces K in LDS, transposed: V^T [d][keys] is the B operand of P V ------------
+  {
+    if (d < 16) {
+      for (int i = tid; i < DC * vt; i += 256) kv_s[i] = (T)0.f;
+      __syncthreads();
+    } else {
+      for (int i = tid; i < d * (NKP - Nk); i += 256) {            // keys >= Nk contribute nothing
+        const int c = i / (NKP - Nk), j = Nk + (i - c * (NKP - Nk));
+        kv_s[c * vt + j] = (T)0.f;
+      }
+    }
+  }
 #pragma unroll
   for (int u = 0; u < MAXV; ++u) {
     const int i = tid + u * 256;
     if (i < nkv) {
-      const int r = i / vpr, c = (i - r * vpr) * 8;
+      const int r = i >> log2_vpr, c = (i & (vpr - 1)) * 8;
       float vv[8];
       vec_to_float(vraw[u], vv);
       if (u < FMAX) {
         if (fin_kv) finish(vv, kst[u], uv[u], bv[u]);
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) kv_s[r * dp + c + e] = vv[e];
+      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + r] = (T)vv[e];
     }
   }
-  // ---- softmax: one wavefront per row, 64-lane shuffle max / sum --------------------------------
+  // ---- softmax: one wavefront per row, 64-lane shuffle max / sum; P in the operand dtype --------------------------
   {
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int r = wave; r < nq; r += 4) {
-      float* pr = p_s + r * Nk;
+    for (int r = wave; r < QCHUNK; r += 4) {
+      T* pr = p_s + r * vt;
+      if (r >= nq) {                                              // padding rows of the second query tile
+        for (int j = lane; j < NKP; j += 64) pr[j] = (T)0.f;
+        continue;
+      }
+      const float* sr = s_s + r * sp;
       float e0 = -3.402823466e+38f, e1 = e0, e2 = e0;            // Nk <= 192: three per lane
-      if (lane < Nk) e0 = pr[lane];
-      if (lane + 64 < Nk) e1 = pr[lane + 64];
-      if (lane + 128 < Nk) e2 = pr[lane + 128];
+      if (lane < Nk) e0 = sr[lane];
+      if (lane + 64 < Nk) e1 = sr[lane + 64];
+      if (lane + 128 < Nk) e2 = sr[lane + 128];
       float m = fmaxf(e0, fmaxf(e1, e2));
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -190,25 +283,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
       const float inv = 1.0f / sum;
-      if (lane < Nk) pr[lane] = e0 * inv;
-      if (lane + 64 < Nk) pr[lane + 64] = e1 * inv;
-      if (lane + 128 < Nk) pr[lane + 128] = e2 * inv;
+      if (lane < NKP) pr[lane] = (T)(e0 * inv);
+      if (lane + 64 < NKP) pr[lane + 64] = (T)(e1 * inv);
+      if (lane + 128 < NKP) pr[lane + 128] = (T)(e2 * inv);
     }
   }
   __syncthreads();
-  // ---- out = P V ---------------------------------------------------------------------------------
-  for (int i = tid; i < nq * d; i += 256) {
-    const int r = i / d, c = i - r * d;
-    const float* pr = p_s + r * Nk;
-    float o0 = 0.f, o1 = 0.f;
-    int j = 0;
-    for (; j + 1 < Nk; j += 2) {
-      o0 = fmaf(pr[j], kv_s[j * dp + c], o0);
-      o1 = fmaf(pr[j + 1], kv_s[(j + 1) * dp + c], o1);
+  AT_STAMP(5);
+  // ---- out = P V on the matrix cores: tiles (query tile, 16 channels) dealt to the waves ---------------------------
+  {
+    const int nqt = (nq + 15) >> 4;
+    const int nct = DC >> 4;
+    for (int t = wave; t < nqt * nct; t += 4) {
+      const int qt = t / nct, ct = t - qt * nct;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NKP; j += 32) {
+        Frag pa, vb;
+        lds_frag(pa, p_s + (qt * 16 + li) * vt + j + lg * 8);
+        lds_frag(vb, kv_s + (ct * 16 + li) * vt + j + lg * 8);
+        amma(acc, pa, vb);
+      }
+      // lane holds rows 4 lg + r (queries), column li (channel)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qt * 16 + lg * 4 + r;
+        if (qi < nq && ct * 16 + li < d) out[(size_t)((unsigned)(b * Nq + q0 + qi) * (unsigned)ldo + (unsigned)(hd + ct * 16 + li))] = (T)acc[r];
+      }
     }
-    if (j < Nk) o0 = fmaf(pr[j], kv_s[j * dp + c], o0);
-    out[((size_t)b * Nq + q0 + r) * ldo + h * d + c] = (T)(o0 + o1);
   }
+  AT_STAMP(6);
 }
 
 }  // namespace
@@ -228,26 +331,33 @@ extern "C" int jen1_attention_fin(const void* q, const void* k, const void* v, v
   JEN1_CHECK(!fin || (ln_rowstats && ln_u && ln_b && ln_C >= 1), "attention: a deferred LayerNorm finish needs rowstats, u, bias and ln_C");
   JEN1_CHECK(!finish_kv || (!kv_row && !kv_extra && Nk * (d / 8) <= 256 * FMAX && Nq == Nk),
              "attention: the K/V finish is for self-attention over at most %d vectors", 256 * FMAX);
-  const int dp = d + 1;
-  const size_t lds = sizeof(float) * ((size_t)Nk * dp + (size_t)QCHUNK * dp + (size_t)QCHUNK * Nk);
+  JEN1_CHECK(d == 8 || d == 16 || d == 32 || d == 64 || d == 128, "attention: head dim %d must be 8, 16, 32, 64 or 128", d);
+  const size_t es = dtype == JEN1_F32 ? 4 : 2;
+  const int DP = d < 32 ? 32 : d, DC = d < 16 ? 16 : d;
+  const int NKP = (Nk + 31) & ~31, dq = DP + 8, vt = NKP + 8, sp = NKP + 1;
+  const size_t kv_elems = (size_t)((NKP * dq > DC * vt) ? NKP * dq : DC * vt);
+  const size_t lds = es * (size_t)QCHUNK * dq + es * ((kv_elems + 7) & ~(size_t)7) + sizeof(float) * (((size_t)QCHUNK * sp + 3) & ~(size_t)3) + es * (size_t)QCHUNK * vt;
   JEN1_CHECK(lds <= 160 * 1024, "attention: Nk=%d d=%d needs %zu B of LDS (> 160 KiB)", Nk, d, lds);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(B * H, (Nq + QCHUNK - 1) / QCHUNK);
   const float inv_c = fin ? 1.0f / (float)ln_C : 0.f;
+  const float inv_H = 1.0f / (float)H;
+  int log2_vpr = 0;
+  while ((8 << log2_vpr) < d) ++log2_vpr;
   if (dtype == JEN1_F32) {
     auto kern = attention_kernel<float>;
     static bool set = false;
     if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out,
                        kv_row, (const float*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale,
-                       ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv);
+                       ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv, inv_H, log2_vpr);
   } else {
     auto kern = attention_kernel<bf16_t>;
     static bool set = false;
     if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (bf16_t*)out, kv_row, (const bf16_t*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale,
-                       ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv);
+                       ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv, inv_H, log2_vpr);
   }
   JEN1_HIP(hipGetLastError());
   return 0;
