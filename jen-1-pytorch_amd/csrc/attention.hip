@@ -46,6 +46,26 @@ __device__ __forceinline__ void lds_frag(f32x8& f, const float* p) {
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
 
+// reductions over the 16 lanes of a DPP row without touching LDS: xor 1, xor 2 (quad permutes), then the two mirrors
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f<0x141>(v));     // row_half_mirror
+  v = fmaxf(v, dpp_f<0x140>(v));     // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+
 // One 256-thread workgroup per (batch element, head, 32-query chunk).
 //   * every Q, K and V vector of the tile (and the operands of a deferred LayerNorm finish) is requested up front;
 //     with <= 128 workgroups there is one wave per SIMD, so a load-use loop would cost a memory latency per trip;
@@ -82,7 +102,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
   const int DC = d < 16 ? 16 : d;                // V^T rows they read
   const int dq = DP + 8;                         // row pitch of Q / K (elements): 16-byte rows, banks spread
   const int vt = NKP + 8;                        // row pitch of V^T and P
-  const int sp = NKP + 1;                        // row pitch of the float32 scores
+  const int sp = NKP + 4;                        // row pitch of the float32 scores (float4 reads in the softmax)
   T* q_s = reinterpret_cast<T*>(smem);                               // [32][dq]
   T* kv_s = q_s + QCHUNK * dq;                                      // K [NKP][dq], later V^T [d][vt]
   const int kv_elems = (NKP * dq > DC * vt) ? NKP * dq : DC * vt;
@@ -240,9 +260,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
       for (int i = tid; i < DC * vt; i += 256) kv_s[i] = (T)0.f;
       __syncthreads();
     } else {
-      for (int i = tid; i < d * (NKP - Nk); i += 256) {            // keys >= Nk contribute nothing
-        const int c = i / (NKP - Nk), j = Nk + (i - c * (NKP - Nk));
-        kv_s[c * vt + j] = (T)0.f;
+      for (int i = tid; i < d * 32; i += 256) {                    // keys >= Nk contribute nothing (NKP - Nk < 32)
+        const int c = i >> 5, j = Nk + (i & 31);
+        if (j < NKP) kv_s[c * vt + j] = (T)0.f;
       }
     }
   }
@@ -260,32 +280,50 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
       for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + r] = (T)vv[e];
     }
   }
-  // ---- softmax: one wavefront per row, 64-lane shuffle max / sum; P in the operand dtype --------------------------
+  AT_STAMP(7);
+  // ---- softmax in float32 (blocks.py:367-371): 16 lanes per row, four rows per wavefront at a time; every lane owns
+  // a contiguous run of keys (up to three float4 reads, all issued together), reductions are four DPP steps inside
+  // the 16-lane row -- no serial LDS round trips.  P is written in the operand dtype.
   {
-    for (int r = wave; r < QCHUNK; r += 4) {
+    const int sub = lane & 15, rsel = lane >> 4;
+    const int kpl = ((NKP >> 4) + 3) & ~3;                        // keys per lane: 4, 8 or 12 (NKP <= 192)
+    const int j0 = sub * kpl;
+#pragma unroll 1
+    for (int it = 0; it < QCHUNK / 16; ++it) {
+      const int r = it * 16 + wave * 4 + rsel;
       T* pr = p_s + r * vt;
-      if (r >= nq) {                                              // padding rows of the second query tile
-        for (int j = lane; j < NKP; j += 64) pr[j] = (T)0.f;
-        continue;
+      if (r >= nq) {                                              // padding rows of the query tiles
+        for (int j = sub; j < NKP; j += 16) pr[j] = (T)0.f;
+      } else {
+        const float* sr = s_s + r * sp + j0;
+        float4 x[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) x[t] = (4 * t < kpl && j0 + 4 * t < NKP) ? *reinterpret_cast<const float4*>(sr + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float e[12];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { e[4 * t] = x[t].x; e[4 * t + 1] = x[t].y; e[4 * t + 2] = x[t].z; e[4 * t + 3] = x[t].w; }
+        float m = -3.402823466e+38f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+          const bool in = t < kpl && j0 + t < Nk;
+          e[t] = in ? e[t] : -3.402823466e+38f;
+          m = fmaxf(m, e[t]);
+        }
+        m = row16_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+          const bool in = t < kpl && j0 + t < Nk;
+          e[t] = in ? (PRECISE ? expf(e[t] - m) : __expf(e[t] - m)) : 0.f;
+          sum += e[t];
+        }
+        sum = row16_sum(sum);
+        const float inv = PRECISE ? 1.0f / sum : __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+          if (t < kpl && j0 + t < NKP) pr[j0 + t] = (T)(e[t] * inv);
+        }
       }
-      const float* sr = s_s + r * sp;
-      float e0 = -3.402823466e+38f, e1 = e0, e2 = e0;            // Nk <= 192: three per lane
-      if (lane < Nk) e0 = sr[lane];
-      if (lane + 64 < Nk) e1 = sr[lane + 64];
-      if (lane + 128 < Nk) e2 = sr[lane + 128];
-      float m = fmaxf(e0, fmaxf(e1, e2));
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-      e0 = (lane < Nk) ? expf(e0 - m) : 0.f;
-      e1 = (lane + 64 < Nk) ? expf(e1 - m) : 0.f;
-      e2 = (lane + 128 < Nk) ? expf(e2 - m) : 0.f;
-      float sum = e0 + e1 + e2;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-      const float inv = 1.0f / sum;
-      if (lane < NKP) pr[lane] = (T)(e0 * inv);
-      if (lane + 64 < NKP) pr[lane + 64] = (T)(e1 * inv);
-      if (lane + 128 < NKP) pr[lane + 128] = (T)(e2 * inv);
     }
   }
   __syncthreads();
@@ -334,7 +372,7 @@ extern "C" int jen1_attention_fin(const void* q, const void* k, const void* v, v
   JEN1_CHECK(d == 8 || d == 16 || d == 32 || d == 64 || d == 128, "attention: head dim %d must be 8, 16, 32, 64 or 128", d);
   const size_t es = dtype == JEN1_F32 ? 4 : 2;
   const int DP = d < 32 ? 32 : d, DC = d < 16 ? 16 : d;
-  const int NKP = (Nk + 31) & ~31, dq = DP + 8, vt = NKP + 8, sp = NKP + 1;
+  const int NKP = (Nk + 31) & ~31, dq = DP + 8, vt = NKP + 8, sp = NKP + 4;
   const size_t kv_elems = (size_t)((NKP * dq > DC * vt) ? NKP * dq : DC * vt);
   const size_t lds = es * (size_t)QCHUNK * dq + es * ((kv_elems + 7) & ~(size_t)7) + sizeof(float) * (((size_t)QCHUNK * sp + 3) & ~(size_t)3) + es * (size_t)QCHUNK * vt;
   JEN1_CHECK(lds <= 160 * 1024, "attention: Nk=%d d=%d needs %zu B of LDS (> 160 KiB)", Nk, d, lds);
