@@ -94,12 +94,15 @@ __device__ __forceinline__ void mma(f32x4& acc, const f32x8& a, const f32x8& b) 
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
+#ifndef JEN1_TILE_W_AUX
+#define JEN1_TILE_W_AUX 0      // cache policy of the weight ring (2 = nt)
+#endif
 __device__ __forceinline__ void bload(bf16x8& f, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  f = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  f = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, JEN1_TILE_W_AUX));
 }
 __device__ __forceinline__ void bload(f32x8& f, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0);
+  const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, JEN1_TILE_W_AUX);
+  const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, JEN1_TILE_W_AUX);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     f.v[j] = __uint_as_float(lo[j]);
