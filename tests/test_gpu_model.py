@@ -236,6 +236,24 @@ def test_full_unet_bf16_reported_error():
     assert e < BF16_TOL
 
 
+def test_full_unet_long_sequence_T9000(full_model_f32):
+    """BASELINE configs[4] shape (B=1, 128x9000: self-attention over 141 positions, 6x the conv work): no golden is
+    committed for it (the reference forward takes minutes here), so this checks size-independent properties: finite
+    output of the right shape, float32 and bf16 modes agree within the bf16 tolerance."""
+    from jen1_amd.model import UNetCFG1d
+    B, T = 1, 9000
+    x, cond = synth.latents(B, T), synth.conditioning(B, T)
+    t = np.array([499], dtype=np.int64)
+    y32 = _fwd(full_model_f32, x, t, cond, embedding_scale=1.0, causal=False)
+    assert np.isfinite(y32).all() and y32.shape == (B, 128, T)
+    mb = UNetCFG1d(**full_model_config(), compute_dtype="bf16", device="cuda")
+    yb = _fwd(mb, x, t, cond, embedding_scale=1.0, causal=False)
+    e = rel_err(yb, y32)
+    print(f"full UNet T=9000: bf16 vs f32 max-abs/max-ref = {e:.3e}")
+    assert e < BF16_TOL
+    del mb
+
+
 def test_sampler_full_size_properties(full_model_f32):
     """size-independent properties at BASELINE size (B=2 to stay in memory/time): every x0 prediction is
     clamped to [-1, 1] so the final DDIM sample is; graph replay == eager; finite everywhere."""
