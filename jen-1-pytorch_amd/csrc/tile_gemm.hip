@@ -117,6 +117,19 @@ __device__ __forceinline__ void lds_read(f32x8& f, const float* p) {
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
 
+// sum over the 16 lanes of a DPP row (the 16 positions of an MFMA tile) without touching LDS
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror
+  return v;
+}
+
 constexpr int VB = 4;          // staging vectors (8 channels) per thread per batch
 
 template <typename T, int MF, int NF, int PF>
@@ -362,12 +375,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
       // all columns of the tile belong to batch element b: reduce over the 16 columns, then LDS, then global
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        float s = gs[p], q2 = gq[p];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          s += __shfl_xor(s, off);
-          q2 += __shfl_xor(q2, off);
-        }
+        const float s = row16_sum(gs[p]), q2 = row16_sum(gq[p]);
         if (li == 0) {
           const int rel = (int)(((float)(co + 2 * p) + 0.5f) * e.inv_out_cpf) - fgw0;
           atomicAdd(st_lds + 2 * rel, s);
