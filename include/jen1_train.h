@@ -1,0 +1,99 @@
+/*
+ * jen1_train.h -- C ABI of the training (forward-with-saves + backward) kernels in libjen1_hip.so.
+ *
+ * The reference trains through torch.autograd (trainer.py:141 `scaler.scale(loss / n).backward()`), i.e. it has
+ * no interface of its own for the backward pass: the seam is the autograd formula of every operator on the path
+ * ("for training ops -- registered with an autograd formula").  Each entry point below is
+ * the forward or the backward of one such operator; jen1_amd/train.py binds them as torch.autograd.Function's.
+ *
+ * Layout: activations are channel-last rows, x[row][c] with a row pitch `ld` (elements) that is a multiple of 8
+ * and zero padding columns; row = b * L + t.  Statistics, gradients of parameters and every reduction are
+ * float32.  dtype: JEN1_F32 (parity mode) or JEN1_BF16 (bf16 storage, float32 accumulation).
+ * All functions return 0 on success (jen1_last_error() otherwise) and only enqueue work on `stream`.
+ */
+#ifndef JEN1_TRAIN_H
+#define JEN1_TRAIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * One operand of jen1_train_gemm.  Element (row r, tap, inner index k) of batch z lives at
+ *   p + (z / zdiv) * zs0 + (z % zdiv) * zs1 + tap * tap_stride + R * ld_r + K * ld_k      (element units)
+ * where (R, K) = (r, k) except along `map_axis` (1: rows, 2: inner index), whose index i = b * map_L + t is sent to
+ *   s = t * map_mul + tap * map_tapmul + map_shift;  if map_div > 1: s must be divisible, s /= map_div;
+ *   valid iff 0 <= s < map_Lsrc;   mapped index = b * map_Lsrc + s;   invalid elements read as 0.
+ * This one rule is the zero padding of _Conv1d (blocks.py:45-50: mul = stride, tapmul = 1, shift = -pad_left),
+ * its data gradient and ConvTranspose1d (blocks.py:80-88: mul = 1, tapmul = -1, shift = +pad, div = stride).
+ * 16-byte loads are used when the contiguous axis (ld_k == 1 or ld_r == 1) is the unmapped one and aligned.
+ */
+typedef struct jen1_gemm_operand {
+  const void* p;
+  int64_t zs0, zs1;
+  int64_t ld_r, ld_k, tap_stride;
+  int32_t zdiv;
+  int32_t map_axis;
+  int32_t map_L, map_Lsrc, map_mul, map_tapmul, map_shift, map_div;
+} jen1_gemm_operand;
+
+/*
+ * C[z][tap?][m][n] (+)= alpha * sum_{tap?} sum_k A(m, tap, k) * B(n, tap, k)  (+ bias[n])
+ *   taps_in_z = 0: taps are summed (forward conv, data gradient);  1: one output matrix per tap (weight gradient)
+ *   C element address: c + (z / c_zdiv) * c_zs0 + (z % c_zdiv) * c_zs1 + tap * c_tap_stride + m * ldc_m + n * ldc_n
+ *   c_f32: C is float32 whatever dtype is;  atomic: C += through float atomics (needs c_f32; required by splitk > 1)
+ *   accumulate: C += without atomics (exclusive tiles);  splitk: the K range is cut into `splitk` slices.
+ * Replaces: F.conv1d / F.conv_transpose1d / F.linear / einsum forward and their autograd formulas on the path
+ * (blocks.py:34-53, 69-95, 337-380, 440-446; model.py:75-89).
+ */
+typedef struct jen1_gemm_args {
+  jen1_gemm_operand a, b;
+  void* c;
+  const void* bias;        /* float32 [N] or NULL */
+  int64_t c_zs0, c_zs1, ldc_m, ldc_n, c_tap_stride;
+  int32_t c_zdiv;
+  int32_t M, N, K, taps, batches;
+  int32_t taps_in_z, splitk, atomic, accumulate, c_f32, dtype;
+  float alpha;
+  int32_t reserved;
+} jen1_gemm_args;
+
+int jen1_train_gemm(const jen1_gemm_args* args, void* stream);
+
+/* --- GroupNorm (+FiLM) (+SiLU): ConvBlock1d's prologue, blocks.py:137-143; Transformer1d's GroupNorm, :509 ---
+ * sums[B][G][2] float32 = (sum x, sum x^2) over the group (zeroed by the call).  film: [B][film_ld] float32 or bf16
+ * (same dtype as x) holding scale at [c] and shift at [C + c], or NULL.  flags bit0: SiLU. */
+int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int ld, int groups, int dtype, void* stream);
+int jen1_gn_apply(const void* x, const float* sums, const float* gamma, const float* beta, const void* film, int film_ld,
+                  void* y, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
+/* backward: P[B][C][4] and Gm[B][G][2] are float32 scratch (zeroed by the call); dgamma/dbeta are ACCUMULATED
+ * (float32, the parameter's .grad); dfilm [B][2C] float32 is written (NULL when film is NULL). */
+int jen1_gn_backward(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,
+                     int film_ld, void* dx, float* dgamma, float* dbeta, float* dfilm, float* P, float* Gm, int B, int L, int C,
+                     int ld, int groups, float eps, int flags, int dtype, void* stream);
+
+/* --- LayerNorm over the last axis (blocks.py:400-401): stats[rows][2] = (mean, rstd) --- */
+int jen1_ln_forward(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, int ld,
+                    float eps, int dtype, void* stream);
+int jen1_ln_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* dgamma,
+                     float* dbeta, int rows, int C, int ld, int dtype, void* stream);
+
+/* --- pointwise activations: mode 0 GELU(erf) (blocks.py:443, model.py:77-89), 1 SiLU (blocks.py:158) --- */
+int jen1_act_forward(const void* x, void* y, int64_t n, int mode, int dtype, void* stream);
+int jen1_act_backward(const void* dy, const void* x, void* dx, int64_t n, int mode, int dtype, void* stream);
+
+/* --- softmax over keys (blocks.py:367-371): s float32 [Z][Nq][ld_s] (already scaled) -> p (dtype) [Z][Nq][ld_p];
+ * causal keeps j <= i + (Nk - Nq) (blocks.py:315-319); padding columns Nk..ld_p-1 of p are written as 0.
+ * backward: ds = p * (dp - sum_j dp*p), dp float32 [Z][Nq][ld_s], ds (dtype) [Z][Nq][ld_p]. */
+int jen1_softmax_forward(const float* s, void* p, int rows, int Nq, int Nk, int ld_s, int ld_p, int causal, int dtype, void* stream);
+int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, int Nk, int ld_s, int ld_p, int dtype, void* stream);
+
+/* out[c] += sum_rows x[row][c]  (bias gradients), float32 accumulate */
+int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JEN1_TRAIN_H */

@@ -1,0 +1,282 @@
+// jen1_train_gemm: the one matrix-core kernel of the training path (include/jen1_train.h).
+//
+// Forward conv / linear / attention products, their data gradients and their weight gradients are all
+//   C[m][n] = alpha * sum_tap sum_k A(m, tap, k) * B(n, tap, k)
+// with operands addressed through (row stride, inner stride, tap stride) and an optional index map that
+// restates the zero padding / striding of _Conv1d and ConvTranspose1d (reference blocks.py:34-53, 69-95).
+// 64 x 64 output tile per workgroup, 4 waves as 2 x 2, each 2 x 2 MFMA 16x16 tiles; K step 32 staged through LDS
+// with the next step's global loads in flight during the MFMAs.  Operands that are contiguous along the output
+// row instead of along K (data gradient's weights, every weight-gradient operand) are transposed on the way into
+// LDS, so the MFMA fragments are always 8 consecutive K values of one row.
+#include "common.h"
+#include "jen1_train.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32, NT = 256;
+
+struct Operand {
+  const void* p;
+  long long ld_r, ld_k, tap_stride;
+  int map_axis, map_L, map_Lsrc, map_mul, map_tapmul, map_shift, map_div;
+  int rows;   // number of valid rows (M or N)
+};
+
+struct GemmDev {
+  Operand a, b;
+  void* c;
+  const float* bias;
+  long long ldc_m, ldc_n, c_tap_stride;
+  long long a_zs0, a_zs1, b_zs0, b_zs1, c_zs0, c_zs1;
+  int a_zdiv, b_zdiv, c_zdiv;
+  int M, N, K, taps, taps_in_z, splitk, atomic, accumulate, c_f32;
+  float alpha;
+};
+
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> { static constexpr int N = 8; typedef bf16x8 type; };
+template <> struct Vec<float> { static constexpr int N = 4; typedef f32x4 type; };
+
+// index map of jen1_gemm_operand: returns the mapped index or -1
+__device__ __forceinline__ long long map_index(const Operand& o, int i, int tap) {
+  const int b = i / o.map_L, t = i - b * o.map_L;
+  int s = t * o.map_mul + tap * o.map_tapmul + o.map_shift;
+  if (s < 0) return -1;
+  if (o.map_div > 1) {
+    const int q = s / o.map_div;
+    if (q * o.map_div != s) return -1;
+    s = q;
+  }
+  if (s >= o.map_Lsrc) return -1;
+  return (long long)b * o.map_Lsrc + s;
+}
+
+// element offset of (row, tap, k) or -1 when it reads as zero
+__device__ __forceinline__ long long elem_offset(const Operand& o, int row, int tap, int k, int K) {
+  if (row >= o.rows || k >= K) return -1;
+  long long r = row, kk = k;
+  if (o.map_axis == 1) { r = map_index(o, row, tap); if (r < 0) return -1; }
+  if (o.map_axis == 2) { kk = map_index(o, k, tap); if (kk < 0) return -1; }
+  return (long long)tap * o.tap_stride + r * o.ld_r + kk * o.ld_k;
+}
+
+template <typename T>
+struct Staged {
+  typename Vec<T>::type v[BM * BK / Vec<T>::N / NT];
+};
+
+// global -> registers for one (tap, k0) step of one operand (64 rows x 32 k)
+template <typename T>
+__device__ __forceinline__ void fetch(Staged<T>& st, const Operand& o, const T* base, int row0, int tap, int k0, int K, int tid) {
+  constexpr int V = Vec<T>::N;
+  constexpr int NV = BM * BK / V / NT;
+  typedef typename Vec<T>::type vec_t;
+  const bool kc = (o.ld_k == 1), rc = (o.ld_r == 1) && !kc;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * NT;
+    vec_t val;
+#pragma unroll
+    for (int j = 0; j < V; ++j) val[j] = (T)0.f;
+    if (!rc) {
+      // vector along k: row = v / (BK / V)
+      const int r = row0 + v / (BK / V), k = k0 + (v % (BK / V)) * V;
+      bool done = false;
+      if (kc && o.map_axis != 2 && k + V <= K) {
+        const long long off = elem_offset(o, r, tap, k, K);
+        if (off < 0) done = true;
+        else if ((((unsigned long long)(base + off)) & 15) == 0) { val = *reinterpret_cast<const vec_t*>(base + off); done = true; }
+      }
+      if (!done) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const long long off = elem_offset(o, r, tap, k + j, K);
+          if (off >= 0) val[j] = base[off];
+        }
+      }
+    } else {
+      // vector along rows at one k: k = v / (BM / V)
+      const int k = k0 + v / (BM / V), r = row0 + (v % (BM / V)) * V;
+      bool done = false;
+      if (o.map_axis != 1 && r + V <= o.rows) {
+        const long long off = elem_offset(o, r, tap, k, K);
+        if (off < 0) done = true;
+        else if ((((unsigned long long)(base + off)) & 15) == 0) { val = *reinterpret_cast<const vec_t*>(base + off); done = true; }
+      }
+      if (!done) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const long long off = elem_offset(o, r + j, tap, k, K);
+          if (off >= 0) val[j] = base[off];
+        }
+      }
+    }
+    st.v[i] = val;
+  }
+}
+
+// registers -> LDS tile [64][PITCH] (k contiguous)
+template <typename T, int PITCH>
+__device__ __forceinline__ void stash(const Staged<T>& st, const Operand& o, T* tile, int tid) {
+  constexpr int V = Vec<T>::N;
+  constexpr int NV = BM * BK / V / NT;
+  typedef typename Vec<T>::type vec_t;
+  const bool rc = (o.ld_r == 1) && (o.ld_k != 1);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * NT;
+    if (!rc) {
+      const int r = v / (BK / V), k = (v % (BK / V)) * V;
+      *reinterpret_cast<vec_t*>(tile + r * PITCH + k) = st.v[i];
+    } else {
+      const int k = v / (BM / V), r = (v % (BM / V)) * V;
+#pragma unroll
+      for (int j = 0; j < V; ++j) tile[(r + j) * PITCH + k] = st.v[i][j];
+    }
+  }
+}
+
+__device__ __forceinline__ void mma8(f32x4& acc, const bf16_t* a, const bf16_t* b) {
+  const bf16x8 fa = *reinterpret_cast<const bf16x8*>(a);
+  const bf16x8 fb = *reinterpret_cast<const bf16x8*>(b);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma8(f32x4& acc, const float* a, const float* b) {
+  float fa[8], fb[8];
+  load8(a, fa);
+  load8(b, fb);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
+  constexpr int PITCH = BK + 16 / (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
+  __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int z = blockIdx.z;
+  const int split = z % g.splitk;
+  z /= g.splitk;
+  int tap_z = 0;
+  if (g.taps_in_z) { tap_z = z % g.taps; z /= g.taps; }
+  const T* abase = reinterpret_cast<const T*>(g.a.p) + (long long)(z / g.a_zdiv) * g.a_zs0 + (long long)(z % g.a_zdiv) * g.a_zs1;
+  const T* bbase = reinterpret_cast<const T*>(g.b.p) + (long long)(z / g.b_zdiv) * g.b_zs0 + (long long)(z % g.b_zdiv) * g.b_zs1;
+
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int ntap = g.taps_in_z ? 1 : g.taps;
+  const int total = ksteps * ntap;
+  const int per = (total + g.splitk - 1) / g.splitk;
+  const int s_begin = split * per, s_end = min(total, s_begin + per);
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  Staged<T> sa, sb;
+  auto fetch_step = [&](int s) {
+    const int tap = g.taps_in_z ? tap_z : s / ksteps;
+    const int k0 = (g.taps_in_z ? s : s % ksteps) * BK;
+    fetch<T>(sa, g.a, abase, m0, tap, k0, g.K, tid);
+    fetch<T>(sb, g.b, bbase, n0, tap, k0, g.K, tid);
+  };
+  if (s_begin < s_end) fetch_step(s_begin);
+  for (int s = s_begin; s < s_end; ++s) {
+    stash<T, PITCH>(sa, g.a, As, tid);
+    stash<T, PITCH>(sb, g.b, Bs, tid);
+    __syncthreads();
+    if (s + 1 < s_end) fetch_step(s + 1);
+    const int kq = (lane >> 4) * 8, rr = lane & 15;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        mma8(acc[mi][ni], As + (wm * 32 + mi * 16 + rr) * PITCH + kq, Bs + (wn * 32 + ni * 16 + rr) * PITCH + kq);
+    __syncthreads();
+  }
+
+  // epilogue: acc[r] <-> (m = 4 * (lane / 16) + r, n = lane % 16) of the 16 x 16 tile
+  char* cb = reinterpret_cast<char*>(g.c);
+  const long long coff = (long long)(z / g.c_zdiv) * g.c_zs0 + (long long)(z % g.c_zdiv) * g.c_zs1 + (long long)tap_z * g.c_tap_stride;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 32 + ni * 16 + (lane & 15);
+      if (n >= g.N) continue;
+      const float bv = (g.bias != nullptr && split == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + mi * 16 + (lane >> 4) * 4 + r;
+        if (m >= g.M) continue;
+        float v = g.alpha * acc[mi][ni][r] + bv;
+        const long long off = coff + (long long)m * g.ldc_m + (long long)n * g.ldc_n;
+        if (g.c_f32) {
+          float* cp = reinterpret_cast<float*>(cb) + off;
+          if (g.atomic) atomicAdd(cp, v);
+          else { if (g.accumulate) v += *cp; *cp = v; }
+        } else {
+          T* cp = reinterpret_cast<T*>(cb) + off;
+          if (g.accumulate) v += (float)*cp;
+          *cp = (T)v;
+        }
+      }
+    }
+}
+
+int check_operand(const jen1_gemm_operand& o, const char* name) {
+  JEN1_CHECK(o.p != nullptr, "train_gemm: operand %s is NULL", name);
+  JEN1_CHECK(o.zdiv >= 1, "train_gemm: operand %s: zdiv must be >= 1", name);
+  JEN1_CHECK(o.map_axis >= 0 && o.map_axis <= 2, "train_gemm: operand %s: map_axis must be 0, 1 or 2", name);
+  if (o.map_axis) {
+    JEN1_CHECK(o.map_L >= 1 && o.map_Lsrc >= 1 && o.map_div >= 1 && o.map_mul >= 1,
+               "train_gemm: operand %s: map_L, map_Lsrc, map_mul and map_div must be >= 1", name);
+  }
+  return 0;
+}
+
+Operand to_dev(const jen1_gemm_operand& o, int rows) {
+  Operand d;
+  d.p = o.p; d.ld_r = o.ld_r; d.ld_k = o.ld_k; d.tap_stride = o.tap_stride;
+  d.map_axis = o.map_axis; d.map_L = o.map_L; d.map_Lsrc = o.map_Lsrc; d.map_mul = o.map_mul;
+  d.map_tapmul = o.map_tapmul; d.map_shift = o.map_shift; d.map_div = o.map_div; d.rows = rows;
+  return d;
+}
+
+}  // namespace
+
+extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
+  JEN1_CHECK(args != nullptr, "train_gemm: args is NULL");
+  const jen1_gemm_args& a = *args;
+  JEN1_CHECK(a.dtype == JEN1_F32 || a.dtype == JEN1_BF16, "train_gemm: dtype must be JEN1_F32 or JEN1_BF16");
+  JEN1_CHECK(a.M >= 1 && a.N >= 1 && a.K >= 1 && a.taps >= 1 && a.batches >= 1, "train_gemm: M, N, K, taps, batches must be >= 1");
+  JEN1_CHECK(a.c != nullptr, "train_gemm: c is NULL");
+  JEN1_CHECK(a.splitk >= 1, "train_gemm: splitk must be >= 1");
+  JEN1_CHECK(a.splitk == 1 || a.atomic, "train_gemm: splitk > 1 needs the atomic epilogue");
+  JEN1_CHECK(!a.atomic || a.c_f32, "train_gemm: the atomic epilogue needs a float32 C");
+  JEN1_CHECK(a.c_zdiv >= 1, "train_gemm: c_zdiv must be >= 1");
+  if (check_operand(a.a, "a") || check_operand(a.b, "b")) return 1;
+  const long long gz = (long long)a.batches * (a.taps_in_z ? a.taps : 1) * a.splitk;
+  JEN1_CHECK(gz <= 65535, "train_gemm: batches * taps * splitk = %lld exceeds the grid limit", gz);
+  const int gy = (a.N + BN - 1) / BN;
+  JEN1_CHECK(gy <= 65535, "train_gemm: N = %d is too large", a.N);
+  GemmDev g;
+  g.a = to_dev(a.a, a.M);
+  g.b = to_dev(a.b, a.N);
+  g.c = a.c; g.bias = reinterpret_cast<const float*>(a.bias);
+  g.ldc_m = a.ldc_m; g.ldc_n = a.ldc_n; g.c_tap_stride = a.c_tap_stride;
+  g.a_zs0 = a.a.zs0; g.a_zs1 = a.a.zs1; g.b_zs0 = a.b.zs0; g.b_zs1 = a.b.zs1; g.c_zs0 = a.c_zs0; g.c_zs1 = a.c_zs1;
+  g.a_zdiv = a.a.zdiv; g.b_zdiv = a.b.zdiv; g.c_zdiv = a.c_zdiv;
+  g.M = a.M; g.N = a.N; g.K = a.K; g.taps = a.taps; g.taps_in_z = a.taps_in_z ? 1 : 0; g.splitk = a.splitk;
+  g.atomic = a.atomic ? 1 : 0; g.accumulate = a.accumulate ? 1 : 0; g.c_f32 = a.c_f32 ? 1 : 0; g.alpha = a.alpha;
+  dim3 grid((a.M + BM - 1) / BM, gy, (unsigned)gz);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a.dtype == JEN1_F32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);
+  else hipLaunchKernelGGL(train_gemm_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,469 @@
+// Normalisation / pointwise / softmax kernels of the training path, forward and backward (include/jen1_train.h).
+// Channel-last rows x[row][c]; consecutive threads take consecutive channels, so every access is coalesced.
+// All of these are HBM-bound streaming kernels: one read of each input, one write of each output, float32 math.
+#include "common.h"
+#include "jen1_train.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p, long long i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void stf(T* p, long long i, float v) { p[i] = (T)v; }
+
+__device__ __forceinline__ float silu_grad(float f) {
+  const float s = 1.0f / (1.0f + expf(-f));
+  return s * (1.0f + f * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// thread layout for per-(b, c) reductions over t: CT channels x (NT / CT) rows per block
+struct RedGeom {
+  int CT, RT;      // channels per block, rows in flight per block
+  int rows_per_block;
+};
+
+// ---------------------------------------------------------------- GroupNorm
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_sums_kernel(const void* x_, float* __restrict__ sums, int L, int C, int ld,
+                                                      int groups, int cpg, int CT, int rows_per_block) {
+  const T* x = reinterpret_cast<const T*>(x_);
+  const int b = blockIdx.z;
+  const int c = blockIdx.y * CT + threadIdx.x % CT;
+  const int ty = threadIdx.x / CT, RT = NT / CT;
+  const int t0 = blockIdx.x * rows_per_block, t1 = min(L, t0 + rows_per_block);
+  float s = 0.f, ss = 0.f;
+  if (c < C) {
+    const T* xp = x + (long long)b * L * ld + c;
+    for (int t = t0 + ty; t < t1; t += RT) {
+      const float v = (float)xp[(long long)t * ld];
+      s += v;
+      ss += v * v;
+    }
+  }
+  __shared__ float acc[64];   // [groups touched by this block][2]; at most 32 groups
+  // groups covered by this block: c range [blockIdx.y*CT, +CT)
+  const int g_lo = (blockIdx.y * CT) / cpg;
+  for (int i = threadIdx.x; i < 64; i += NT) acc[i] = 0.f;
+  __syncthreads();
+  if (c < C) {
+    const int gi = c / cpg - g_lo;
+    if (gi < 32) { atomicAdd(&acc[2 * gi], s); atomicAdd(&acc[2 * gi + 1], ss); }
+    else { atomicAdd(&sums[((long long)b * groups + c / cpg) * 2], s); atomicAdd(&sums[((long long)b * groups + c / cpg) * 2 + 1], ss); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32; i += NT) {
+    const int g = g_lo + i;
+    if (g < groups && (acc[2 * i] != 0.f || acc[2 * i + 1] != 0.f)) {
+      atomicAdd(&sums[((long long)b * groups + g) * 2], acc[2 * i]);
+      atomicAdd(&sums[((long long)b * groups + g) * 2 + 1], acc[2 * i + 1]);
+    }
+  }
+}
+
+struct GnDev {
+  const void* x; const void* dy; const float* sums; const float* gamma; const float* beta; const void* film;
+  void* y; float* P; float* Gm; float* dgamma; float* dbeta; float* dfilm;
+  int B, L, C, ld, groups, cpg, film_ld, flags;
+  float eps, inv_count;
+};
+
+// (mean, rstd) of the group of channel c in batch element b
+__device__ __forceinline__ void gn_moments(const GnDev& g, int b, int c, float& mean, float& rstd) {
+  const float* s = g.sums + ((long long)b * g.groups + c / g.cpg) * 2;
+  mean = s[0] * g.inv_count;
+  const float var = fmaxf(s[1] * g.inv_count - mean * mean, 0.f);
+  rstd = 1.0f / sqrtf(var + g.eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const GnDev g) {
+  const long long total = (long long)g.B * g.L * g.C;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const T* film = reinterpret_cast<const T*>(g.film);
+  T* y = reinterpret_cast<T*>(g.y);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int c = (int)(i % g.C);
+    const long long row = i / g.C;
+    const int b = (int)(row / g.L);
+    float mean, rstd;
+    gn_moments(g, b, c, mean, rstd);
+    float n = ((float)x[row * g.ld + c] - mean) * rstd * g.gamma[c] + g.beta[c];
+    if (film != nullptr) n = n * ((float)film[(long long)b * g.film_ld + c] + 1.0f) + (float)film[(long long)b * g.film_ld + g.C + c];
+    if (g.flags & 1) n = silu_precise(n);
+    y[row * g.ld + c] = (T)n;
+  }
+}
+
+// P[b][c] = (sum dn, sum dn * xhat, sum df * n, sum df) over t
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const GnDev g, int CT, int rows_per_block) {
+  const int b = blockIdx.z;
+  const int c = blockIdx.y * CT + threadIdx.x % CT;
+  const int ty = threadIdx.x / CT, RT = NT / CT;
+  const int t0 = blockIdx.x * rows_per_block, t1 = min(g.L, t0 + rows_per_block);
+  if (c >= g.C) return;
+  const T* x = reinterpret_cast<const T*>(g.x) + (long long)b * g.L * g.ld + c;
+  const T* dy = reinterpret_cast<const T*>(g.dy) + (long long)b * g.L * g.ld + c;
+  const T* film = reinterpret_cast<const T*>(g.film);
+  float mean, rstd;
+  gn_moments(g, b, c, mean, rstd);
+  const float ga = g.gamma[c], be = g.beta[c];
+  float sc1 = 1.0f, sh = 0.f;
+  if (film != nullptr) { sc1 = (float)film[(long long)b * g.film_ld + c] + 1.0f; sh = (float)film[(long long)b * g.film_ld + g.C + c]; }
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  for (int t = t0 + ty; t < t1; t += RT) {
+    const float xh = ((float)x[(long long)t * g.ld] - mean) * rstd;
+    const float n = xh * ga + be;
+    const float f = n * sc1 + sh;
+    float df = (float)dy[(long long)t * g.ld];
+    if (g.flags & 1) df *= silu_grad(f);
+    const float dn = df * sc1;
+    p0 += dn; p1 += dn * xh; p2 += df * n; p3 += df;
+  }
+  float* P = g.P + ((long long)b * g.C + c) * 4;
+  atomicAdd(P + 0, p0); atomicAdd(P + 1, p1); atomicAdd(P + 2, p2); atomicAdd(P + 3, p3);
+}
+
+// group means of d(xhat), parameter gradients, FiLM gradients: one thread per (b, c)
+__global__ __launch_bounds__(NT) void gn_bwd_finish_kernel(const GnDev g) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= g.B * g.C) return;
+  const int b = i / g.C, c = i % g.C;
+  const float* P = g.P + (long long)i * 4;
+  const float ga = g.gamma[c];
+  float* gm = g.Gm + ((long long)b * g.groups + c / g.cpg) * 2;
+  atomicAdd(gm + 0, ga * P[0] * g.inv_count);
+  atomicAdd(gm + 1, ga * P[1] * g.inv_count);
+  atomicAdd(g.dgamma + c, P[1]);
+  atomicAdd(g.dbeta + c, P[0]);
+  if (g.dfilm != nullptr) {
+    g.dfilm[(long long)b * 2 * g.C + c] = P[2];
+    g.dfilm[(long long)b * 2 * g.C + g.C + c] = P[3];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_dx_kernel(const GnDev g, void* dx_) {
+  T* dx = reinterpret_cast<T*>(dx_);
+  const long long total = (long long)g.B * g.L * g.C;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const T* dy = reinterpret_cast<const T*>(g.dy);
+  const T* film = reinterpret_cast<const T*>(g.film);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int c = (int)(i % g.C);
+    const long long row = i / g.C;
+    const int b = (int)(row / g.L);
+    float mean, rstd;
+    gn_moments(g, b, c, mean, rstd);
+    const float ga = g.gamma[c];
+    const float xh = ((float)x[row * g.ld + c] - mean) * rstd;
+    float sc1 = 1.0f, sh = 0.f;
+    if (film != nullptr) { sc1 = (float)film[(long long)b * g.film_ld + c] + 1.0f; sh = (float)film[(long long)b * g.film_ld + g.C + c]; }
+    float df = (float)dy[row * g.ld + c];
+    if (g.flags & 1) df *= silu_grad((xh * ga + g.beta[c]) * sc1 + sh);
+    const float dxh = df * sc1 * ga;
+    const float* gm = g.Gm + ((long long)b * g.groups + c / g.cpg) * 2;
+    dx[row * g.ld + c] = (T)(rstd * (dxh - gm[0] - xh * gm[1]));
+  }
+}
+
+void red_geom(int C, int L, int& CT, int& rows_per_block, int& gx, int& gy) {
+  CT = 256;
+  while (CT > 1 && CT / 2 >= C) CT /= 2;      // smallest power of two >= C, capped at 256
+  const int RT = NT / CT;
+  rows_per_block = RT * 16;                    // each thread walks <= 16 rows
+  if (rows_per_block > L) rows_per_block = (L + RT - 1) / RT * RT;
+  gx = (L + rows_per_block - 1) / rows_per_block;
+  gy = (C + CT - 1) / CT;
+}
+
+int ew_grid(long long total) {
+  long long g = (total + NT - 1) / NT;
+  if (g > 256 * 32) g = 256 * 32;
+  return (int)(g < 1 ? 1 : g);
+}
+
+// ---------------------------------------------------------------- LayerNorm (one wave per row, C <= 64 * 32)
+constexpr int LN_MAXPL = 32;
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(const void* x_, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     void* y_, float* __restrict__ stats, int rows, int C, int ld, float eps) {
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* y = reinterpret_cast<T*>(y_);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (long long)row * ld;
+  float v[LN_MAXPL];
+  float s = 0.f;
+  int n = 0;
+  for (int c = lane; c < C; c += 64, ++n) { v[n] = (float)xr[c]; s += v[n]; }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / C;
+  float q = 0.f;
+  for (int i = 0; i < n; ++i) { const float d = v[i] - mean; q += d * d; }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q / C + eps);
+  T* yr = y + (long long)row * ld;
+  n = 0;
+  for (int c = lane; c < C; c += 64, ++n) yr[c] = (T)((v[n] - mean) * rstd * gamma[c] + beta[c]);
+  if (lane == 0) { stats[2 * (long long)row] = mean; stats[2 * (long long)row + 1] = rstd; }
+}
+
+// each wave walks rows row0, row0 + stride, ... and keeps the column sums of its lanes in registers
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const void* dy_, const void* x_, const float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, void* dx_, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows, int C, int ld) {
+  const T* dy = reinterpret_cast<const T*>(dy_);
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* dx = reinterpret_cast<T*>(dx_);
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  const int nw = gridDim.x * (NT / 64);
+  float ag[LN_MAXPL], ab[LN_MAXPL], gv[LN_MAXPL];
+  int npl = 0;
+  for (int c = lane; c < C; c += 64, ++npl) { ag[npl] = 0.f; ab[npl] = 0.f; gv[npl] = gamma[c]; }
+  for (int row = wid; row < rows; row += nw) {
+    const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
+    const T* xr = x + (long long)row * ld;
+    const T* dr = dy + (long long)row * ld;
+    float xh[LN_MAXPL], dh[LN_MAXPL];
+    float s1 = 0.f, s2 = 0.f;
+    int n = 0;
+    for (int c = lane; c < C; c += 64, ++n) {
+      const float d = (float)dr[c];
+      xh[n] = ((float)xr[c] - mean) * rstd;
+      dh[n] = d * gv[n];
+      s1 += dh[n];
+      s2 += dh[n] * xh[n];
+      ag[n] += d * xh[n];
+      ab[n] += d;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 /= C; s2 /= C;
+    T* xo = dx + (long long)row * ld;
+    n = 0;
+    for (int c = lane; c < C; c += 64, ++n) xo[c] = (T)(rstd * (dh[n] - s1 - xh[n] * s2));
+  }
+  int n = 0;
+  for (int c = lane; c < C; c += 64, ++n) { atomicAdd(dgamma + c, ag[n]); atomicAdd(dbeta + c, ab[n]); }
+}
+
+// ---------------------------------------------------------------- pointwise
+template <typename T>
+__global__ __launch_bounds__(NT) void act_fwd_kernel(const void* x_, void* y_, long long n, int mode) {
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* y = reinterpret_cast<T*>(y_);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+    const float v = (float)x[i];
+    y[i] = (T)(mode == 0 ? gelu_erf(v) : silu_precise(v));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void act_bwd_kernel(const void* dy_, const void* x_, void* dx_, long long n, int mode) {
+  const T* dy = reinterpret_cast<const T*>(dy_);
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* dx = reinterpret_cast<T*>(dx_);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+    const float v = (float)x[i];
+    dx[i] = (T)((float)dy[i] * (mode == 0 ? gelu_grad(v) : silu_grad(v)));
+  }
+}
+
+// ---------------------------------------------------------------- softmax (one wave per row)
+template <typename T>
+__global__ __launch_bounds__(NT) void softmax_fwd_kernel(const float* __restrict__ s, void* p_, int rows, int Nq, int Nk,
+                                                          int ld_s, int ld_p, int causal) {
+  T* p = reinterpret_cast<T*>(p_);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int i = row % Nq;
+  const int lim = causal ? min(Nk, i + (Nk - Nq) + 1) : Nk;     // keys j < lim are kept (blocks.py:315-319)
+  const float* sr = s + (long long)row * ld_s;
+  float m = -3.0e38f;
+  for (int j = lane; j < lim; j += 64) m = fmaxf(m, sr[j]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float z = 0.f;
+  for (int j = lane; j < lim; j += 64) z += expf(sr[j] - m);
+  for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+  const float inv = 1.0f / z;
+  T* pr = p + (long long)row * ld_p;
+  for (int j = lane; j < ld_p; j += 64) pr[j] = (T)(j < lim ? expf(sr[j] - m) * inv : 0.f);
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void softmax_bwd_kernel(const void* p_, const float* __restrict__ dp, void* ds_, int rows,
+                                                          int Nk, int ld_s, int ld_p) {
+  const T* p = reinterpret_cast<const T*>(p_);
+  T* ds = reinterpret_cast<T*>(ds_);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* pr = p + (long long)row * ld_p;
+  const float* dr = dp + (long long)row * ld_s;
+  float d = 0.f;
+  for (int j = lane; j < Nk; j += 64) d += (float)pr[j] * dr[j];
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+  T* so = ds + (long long)row * ld_p;
+  for (int j = lane; j < ld_p; j += 64) so[j] = (T)(j < Nk ? (float)pr[j] * (dr[j] - d) : 0.f);
+}
+
+// ---------------------------------------------------------------- column sums
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_kernel(const void* x_, float* __restrict__ out, int rows, int C, int ld, int CT,
+                                                     int rows_per_block) {
+  const T* x = reinterpret_cast<const T*>(x_);
+  const int c = blockIdx.y * CT + threadIdx.x % CT;
+  const int ty = threadIdx.x / CT, RT = NT / CT;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = r0 + ty; r < r1; r += RT) s += (float)x[(long long)r * ld + c];
+  atomicAdd(out + c, s);
+}
+
+#define DISPATCH(dtype, KERNEL, grid, ...)                                                        \
+  do {                                                                                            \
+    if ((dtype) == JEN1_F32) hipLaunchKernelGGL(KERNEL<float>, grid, dim3(NT), 0, s, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<bf16_t>, grid, dim3(NT), 0, s, __VA_ARGS__);                    \
+    JEN1_HIP(hipGetLastError());                                                                  \
+  } while (0)
+
+int check_dtype(int dtype, const char* who) {
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "%s: dtype must be JEN1_F32 or JEN1_BF16", who);
+  return 0;
+}
+
+int gn_fill(GnDev& g, const char* who, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,
+            int film_ld, int B, int L, int C, int ld, int groups, float eps, int flags) {
+  JEN1_CHECK(x && sums && gamma && beta, "%s: NULL argument", who);
+  JEN1_CHECK(B >= 1 && L >= 1 && C >= 1 && ld >= C, "%s: bad shape B=%d L=%d C=%d ld=%d", who, B, L, C, ld);
+  JEN1_CHECK(groups >= 1 && C % groups == 0, "%s: num_channels must be divisible by num_groups", who);   // torch GroupNorm's check
+  JEN1_CHECK(film == nullptr || film_ld >= 2 * C, "%s: film_ld must be >= 2 C", who);
+  memset(&g, 0, sizeof(g));
+  g.x = x; g.sums = sums; g.gamma = gamma; g.beta = beta; g.film = film; g.film_ld = film_ld;
+  g.B = B; g.L = L; g.C = C; g.ld = ld; g.groups = groups; g.cpg = C / groups; g.eps = eps; g.flags = flags;
+  g.inv_count = 1.0f / ((float)(C / groups) * (float)L);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int ld, int groups, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_gn_sums")) return 1;
+  JEN1_CHECK(x && sums, "jen1_gn_sums: NULL argument");
+  JEN1_CHECK(B >= 1 && L >= 1 && C >= 1 && ld >= C, "jen1_gn_sums: bad shape B=%d L=%d C=%d ld=%d", B, L, C, ld);
+  JEN1_CHECK(groups >= 1 && C % groups == 0, "jen1_gn_sums: num_channels must be divisible by num_groups");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  JEN1_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * B * groups, s));
+  int CT, rpb, gx, gy;
+  red_geom(C, L, CT, rpb, gx, gy);
+  DISPATCH(dtype, gn_sums_kernel, dim3(gx, gy, B), x, sums, L, C, ld, groups, C / groups, CT, rpb);
+  return 0;
+}
+
+extern "C" int jen1_gn_apply(const void* x, const float* sums, const float* gamma, const float* beta, const void* film, int film_ld,
+                             void* y, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_gn_apply")) return 1;
+  GnDev g;
+  if (gn_fill(g, "jen1_gn_apply", x, sums, gamma, beta, film, film_ld, B, L, C, ld, groups, eps, flags)) return 1;
+  JEN1_CHECK(y != nullptr, "jen1_gn_apply: y is NULL");
+  g.y = y;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, gn_apply_kernel, dim3(ew_grid((long long)B * L * C)), g);
+  return 0;
+}
+
+extern "C" int jen1_gn_backward(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta,
+                                const void* film, int film_ld, void* dx, float* dgamma, float* dbeta, float* dfilm, float* P,
+                                float* Gm, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_gn_backward")) return 1;
+  GnDev g;
+  if (gn_fill(g, "jen1_gn_backward", x, sums, gamma, beta, film, film_ld, B, L, C, ld, groups, eps, flags)) return 1;
+  JEN1_CHECK(dy && dx && dgamma && dbeta && P && Gm, "jen1_gn_backward: NULL argument");
+  JEN1_CHECK((film == nullptr) == (dfilm == nullptr), "jen1_gn_backward: dfilm must be given exactly when film is");
+  g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = dfilm;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  JEN1_HIP(hipMemsetAsync(P, 0, sizeof(float) * 4 * B * C, s));
+  JEN1_HIP(hipMemsetAsync(Gm, 0, sizeof(float) * 2 * B * groups, s));
+  int CT, rpb, gx, gy;
+  red_geom(C, L, CT, rpb, gx, gy);
+  DISPATCH(dtype, gn_bwd_sums_kernel, dim3(gx, gy, B), g, CT, rpb);
+  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((B * C + NT - 1) / NT), dim3(NT), 0, s, g);
+  JEN1_HIP(hipGetLastError());
+  DISPATCH(dtype, gn_bwd_dx_kernel, dim3(ew_grid((long long)B * L * C)), g, dx);
+  return 0;
+}
+
+extern "C" int jen1_ln_forward(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, int ld,
+                               float eps, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_ln_forward")) return 1;
+  JEN1_CHECK(x && gamma && beta && y && stats, "jen1_ln_forward: NULL argument");
+  JEN1_CHECK(rows >= 1 && C >= 1 && ld >= C && C <= 64 * LN_MAXPL, "jen1_ln_forward: bad shape rows=%d C=%d ld=%d (C <= %d)", rows, C, ld, 64 * LN_MAXPL);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, ln_fwd_kernel, dim3((rows + 3) / 4), x, gamma, beta, y, stats, rows, C, ld, eps);
+  return 0;
+}
+
+extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* dgamma,
+                                float* dbeta, int rows, int C, int ld, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_ln_backward")) return 1;
+  JEN1_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta, "jen1_ln_backward: NULL argument");
+  JEN1_CHECK(rows >= 1 && C >= 1 && ld >= C && C <= 64 * LN_MAXPL, "jen1_ln_backward: bad shape rows=%d C=%d ld=%d", rows, C, ld);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int blocks = (rows + 3) / 4;
+  if (blocks > 128) blocks = 128;           // each wave keeps column sums over many rows: few atomics
+  DISPATCH(dtype, ln_bwd_kernel, dim3(blocks), dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+  return 0;
+}
+
+extern "C" int jen1_act_forward(const void* x, void* y, int64_t n, int mode, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_act_forward")) return 1;
+  JEN1_CHECK(x && y && n >= 1 && (mode == 0 || mode == 1), "jen1_act_forward: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, act_fwd_kernel, dim3(ew_grid(n)), x, y, (long long)n, mode);
+  return 0;
+}
+
+extern "C" int jen1_act_backward(const void* dy, const void* x, void* dx, int64_t n, int mode, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_act_backward")) return 1;
+  JEN1_CHECK(dy && x && dx && n >= 1 && (mode == 0 || mode == 1), "jen1_act_backward: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, act_bwd_kernel, dim3(ew_grid(n)), dy, x, dx, (long long)n, mode);
+  return 0;
+}
+
+extern "C" int jen1_softmax_forward(const float* sc, void* p, int rows, int Nq, int Nk, int ld_s, int ld_p, int causal, int dtype,
+                                    void* stream) {
+  if (check_dtype(dtype, "jen1_softmax_forward")) return 1;
+  JEN1_CHECK(sc && p && rows >= 1 && Nq >= 1 && Nk >= 1 && ld_s >= Nk && ld_p >= Nk && rows % Nq == 0, "jen1_softmax_forward: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, softmax_fwd_kernel, dim3((rows + 3) / 4), sc, p, rows, Nq, Nk, ld_s, ld_p, causal);
+  return 0;
+}
+
+extern "C" int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, int Nk, int ld_s, int ld_p, int dtype,
+                                     void* stream) {
+  if (check_dtype(dtype, "jen1_softmax_backward")) return 1;
+  JEN1_CHECK(p && dp && ds && rows >= 1 && Nk >= 1 && ld_s >= Nk && ld_p >= Nk, "jen1_softmax_backward: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, softmax_bwd_kernel, dim3((rows + 3) / 4), p, dp, ds, rows, Nk, ld_s, ld_p);
+  return 0;
+}
+
+extern "C" int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_colsum")) return 1;
+  JEN1_CHECK(x && out && rows >= 1 && C >= 1 && ld >= C, "jen1_colsum: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int CT, rpb, gx, gy;
+  red_geom(C, rows, CT, rpb, gx, gy);
+  DISPATCH(dtype, colsum_kernel, dim3(gx, gy), x, out, rows, C, ld, CT, rpb);
+  return 0;
+}

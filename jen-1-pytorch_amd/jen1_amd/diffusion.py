@@ -258,6 +258,8 @@ class GaussianDiffusion(torch.nn.Module):
         if noise is None:
             noise = torch.rand_like(x_start)
         x_t = self.q_sample(x_start, t, noise=noise)
+        if torch.is_grad_enabled() and getattr(model, "training", False) and hasattr(model, "train_graph"):
+            model = model.train_graph()          # the differentiable HIP path (jen1_amd/train.py)
         model_out = self._call(model, x_t, t, conditioning, causal, dropout_rows)
         if self.objective == "noise":
             target = noise

@@ -16,7 +16,8 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip", "optimizer.hip"]
+SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip", "optimizer.hip",
+           "train_gemm.hip", "train_ops.hip"]
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -73,7 +74,23 @@ class NormArgs(C.Structure):
     ]
 
 
-# every symbol include/jen1_hip.h declares: (name, restype, argtypes)
+class GemmOperand(C.Structure):
+    """mirror of ``jen1_gemm_operand`` (include/jen1_train.h)."""
+    _fields_ = [("p", c_void_p), ("zs0", c_int64), ("zs1", c_int64), ("ld_r", c_int64), ("ld_k", c_int64),
+                ("tap_stride", c_int64), ("zdiv", c_int), ("map_axis", c_int), ("map_L", c_int), ("map_Lsrc", c_int),
+                ("map_mul", c_int), ("map_tapmul", c_int), ("map_shift", c_int), ("map_div", c_int)]
+
+
+class GemmArgs(C.Structure):
+    """mirror of ``jen1_gemm_args`` (include/jen1_train.h)."""
+    _fields_ = [("a", GemmOperand), ("b", GemmOperand), ("c", c_void_p), ("bias", c_void_p),
+                ("c_zs0", c_int64), ("c_zs1", c_int64), ("ldc_m", c_int64), ("ldc_n", c_int64), ("c_tap_stride", c_int64),
+                ("c_zdiv", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("taps", c_int), ("batches", c_int),
+                ("taps_in_z", c_int), ("splitk", c_int), ("atomic", c_int), ("accumulate", c_int), ("c_f32", c_int),
+                ("dtype", c_int), ("alpha", c_float), ("reserved", c_int)]
+
+
+# every symbol include/jen1_hip.h and include/jen1_train.h declare: (name, restype, argtypes)
 _P = c_void_p
 SYMBOLS = {
     "jen1_conv_gemm": (c_int, [C.POINTER(ConvArgs), _P]),
@@ -94,6 +111,17 @@ SYMBOLS = {
     "jen1_grad_sqnorm": (c_int, [_P, c_int64, _P, _P]),
     "jen1_adamw_step": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [c_int, _P, c_float, c_int, _P]),
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
+    "jen1_train_gemm": (c_int, [C.POINTER(GemmArgs), _P]),
+    "jen1_gn_sums": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
+    "jen1_gn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),
+    "jen1_gn_backward": (c_int, [_P] * 6 + [c_int] + [_P] * 6 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
+    "jen1_ln_forward": (c_int, [_P] * 5 + [c_int] * 3 + [c_float, c_int, _P]),
+    "jen1_ln_backward": (c_int, [_P] * 7 + [c_int] * 4 + [_P]),
+    "jen1_act_forward": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "jen1_act_backward": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
+    "jen1_softmax_forward": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
+    "jen1_softmax_backward": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
+    "jen1_colsum": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),
@@ -110,7 +138,7 @@ def build(verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into jen1_amd/libjen1_hip.so (hipcc cross-compiles
     without a GPU).  Skips the compile when the library is newer than every source."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h"), os.path.join(INCLUDE, "jen1_train.h")]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

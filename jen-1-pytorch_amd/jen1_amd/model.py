@@ -56,6 +56,7 @@ class UNetCFG1d(nn.Module):
                 v = torch.from_numpy(fill(key, shape, init_seed))
             _register(self, key, v.to(self._device))
         self._engine: Optional[Engine] = None
+        self._train_graph = None
         self._ctx_key = None
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
@@ -63,6 +64,18 @@ class UNetCFG1d(nn.Module):
     def _invalidate(self):
         self._engine = None
         self._ctx_key = None
+        if self._train_graph is not None:
+            self._train_graph.invalidate()
+
+    def train_graph(self, compute_dtype: Optional[str] = None):
+        """The differentiable forward of this module (jen1_amd/train.py): a callable with ``forward``'s signature
+        whose backward fills ``param.grad``.  ``GaussianDiffusion.training_loosses`` picks it up by itself when
+        gradients are enabled and the module is in training mode (trainer.py:194, :204-208)."""
+        from .train import TrainGraph
+        cd = compute_dtype or self.compute_dtype
+        if self._train_graph is None or self._train_graph.compute_dtype != cd:
+            self._train_graph = TrainGraph(self, self.spec, cd, self._device)
+        return self._train_graph
 
     def engine(self) -> Engine:
         if self._engine is None:

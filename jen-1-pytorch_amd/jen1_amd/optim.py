@@ -6,8 +6,8 @@ Host-side mirror of /root/reference/train.py:56-60, :84 and /root/reference/trai
 (train.py:88-89), the mean all-reduce of the gradients.  Parameters, gradients and both moments live in flat float32
 buffers (the model's parameters become views of the flat buffer), so clip + AdamW is two HIP launches over 296.5 M
 elements (jen1_grad_sqnorm, jen1_adamw_step) with no host synchronisation, and the gradient exchange is a few large
-RCCL all-reduces over xGMI instead of 979 small ones.  The backward pass that produces the gradients is NOT part of
-this round: the class works on whatever fills ``flat_grad``.
+RCCL all-reduces over xGMI instead of 979 small ones.  The gradients come from jen1_amd/train.py, whose kernels
+accumulate straight into ``flat_grad`` through the ``p.grad`` views.
 """
 from __future__ import annotations
 
@@ -64,6 +64,7 @@ class FusedAdamW:
         self.max_norm, self.skip_nonfinite = max_norm, skip_nonfinite
         self.step_count = 0
         self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.post_step_hooks = []      # callables run after every step (TrainGraph.invalidate: re-pack the compute weights)
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
@@ -88,6 +89,8 @@ class FusedAdamW:
                                     self.numel, float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                     float(self.weight_decay), self.step_count, gn, float(self.max_norm or 0.0), 1 if self.skip_nonfinite else 0, s),
                 "jen1_adamw_step")
+        for h in self.post_step_hooks:
+            h()
 
     def state_dict(self) -> dict:
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "betas": self.betas,

@@ -1,0 +1,671 @@
+"""Training path of the denoiser: forward with saved activations + backward, every heavy operator in HIP.
+
+The reference trains ``UNetCFG1d`` through torch.autograd (trainer.py:139-150: ``scaler.scale(loss / n).backward()``,
+gdm.py:245-272 ``training_loosses``).  Here every operator of the path that carries FLOPs or bytes -- the 1-D
+convolutions / transposed convolutions / linears (forward, data gradient, weight gradient), GroupNorm+FiLM+SiLU,
+LayerNorm, GELU/SiLU, the attention products and softmax -- is a ``torch.autograd.Function`` whose forward and
+backward are kernels of libjen1_hip.so (include/jen1_train.h).  torch itself only does plumbing on the way:
+concatenation / cropping / residual adds of activations, the 129 Fourier features of the timestep, the CFG
+combine on the [B, 128, T] output and the loss reduction.
+
+Activations are channel-last ``[B, L, C]`` (C padded to a multiple of 8 with zero columns), so the transformer's
+``[B, N, C]`` is the native layout and no permute exists.  Parameters stay in the reference's ``state_dict`` layout
+(float32 master copies, flat-buffer views when ``FusedAdamW`` owns them); compute copies ``[k][C_out][C_in]`` in the
+compute dtype are re-packed once per optimiser step.  Weight gradients are accumulated by the kernels straight into
+``param.grad`` (float32 atomics, reference layout): gradient accumulation over micro-batches costs nothing extra.
+
+There is no fallback: without libjen1_hip.so / a ROCm device every entry point raises.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+from .config import ResSpec, TransformerSpec, UNetSpec
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+class Map:
+    """index map of ``jen1_gemm_operand`` (include/jen1_train.h)"""
+
+    def __init__(self, axis: int, L_idx: int, L_src: int, mul: int = 1, tapmul: int = 0, shift: int = 0, div: int = 1):
+        self.axis, self.L, self.Lsrc, self.mul, self.tapmul, self.shift, self.div = axis, L_idx, L_src, mul, tapmul, shift, div
+
+
+def _operand(ptr: int, ld_r: int, ld_k: int, tap_stride: int = 0, zs0: int = 0, zs1: int = 0, zdiv: int = 1,
+             m: Optional[Map] = None) -> L.GemmOperand:
+    o = L.GemmOperand()
+    o.p, o.zs0, o.zs1, o.ld_r, o.ld_k, o.tap_stride, o.zdiv = ptr, zs0, zs1, ld_r, ld_k, tap_stride, zdiv
+    if m is None:
+        o.map_axis, o.map_L, o.map_Lsrc, o.map_mul, o.map_tapmul, o.map_shift, o.map_div = 0, 1, 1, 1, 0, 0, 1
+    else:
+        o.map_axis, o.map_L, o.map_Lsrc, o.map_mul, o.map_tapmul, o.map_shift, o.map_div = m.axis, m.L, m.Lsrc, m.mul, m.tapmul, m.shift, m.div
+    return o
+
+
+class TrainRuntime:
+    """Handle on the library + the per-optimiser-step cache of packed compute weights."""
+
+    def __init__(self, compute_dtype: str = "bf16", device="cuda"):
+        self.lib = L.load()                      # raises when the HIP extension is missing
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.Jen1HipError("the training path needs a ROCm GPU (device='cuda'); no CPU path exists in this package")
+        assert compute_dtype in ("f32", "bf16")
+        self.dt = L.F32 if compute_dtype == "f32" else L.BF16
+        self.tdtype = torch.float32 if compute_dtype == "f32" else torch.bfloat16
+        self._packed: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.target_wgs = 512
+
+    # ------------------------------------------------------------------ plumbing
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def invalidate(self) -> None:
+        """forget the packed compute weights (call after every optimiser step / parameter load)"""
+        self._packed.clear()
+
+    def dt_of(self, t: torch.Tensor) -> int:
+        if t.dtype == torch.float32:
+            return L.F32
+        if t.dtype == torch.bfloat16:
+            return L.BF16
+        raise L.Jen1HipError(f"unsupported activation dtype {t.dtype}")
+
+    def packed(self, w: torch.Tensor, kind: str, dtype: torch.dtype) -> torch.Tensor:
+        """compute copy [k][C_out][pad8(C_in)] of a Conv1d [Co, Ci, k] / ConvTranspose1d [Ci, Co, k] / Linear [Co, Ci] weight"""
+        key = (id(w), kind, dtype)
+        hit = self._packed.get(key)
+        p = hit[1] if hit is not None and hit[0]() is w else None      # id() of a dead parameter can be reused
+        if p is None:
+            with torch.no_grad():
+                d = w.detach()
+                if kind == "linear":
+                    d = d.unsqueeze(0)                         # [1][Co][Ci]
+                elif kind == "conv":
+                    d = d.permute(2, 0, 1)                     # [k][Co][Ci]
+                else:                                          # ConvTranspose1d
+                    d = d.permute(2, 1, 0)                     # [k][Co][Ci]
+                k, co, ci = d.shape
+                p = torch.zeros((k, co, pad8(ci)), dtype=dtype, device=w.device)
+                p[:, :, :ci].copy_(d)
+            self._packed[key] = (weakref.ref(w), p)
+        return p
+
+    @staticmethod
+    def grad_of(p: torch.Tensor) -> torch.Tensor:
+        """the float32 gradient buffer of a parameter (created zeroed on first use; a flat-buffer view under FusedAdamW)"""
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        assert p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+        return p.grad
+
+    # ------------------------------------------------------------------ the GEMM
+    def gemm(self, a: L.GemmOperand, b: L.GemmOperand, c_ptr: int, M: int, N: int, K: int, *, dtype: int, taps: int = 1,
+             batches: int = 1, taps_in_z: bool = False, ldc_m: int, ldc_n: int = 1, c_tap_stride: int = 0, c_zs0: int = 0,
+             c_zs1: int = 0, c_zdiv: int = 1, bias: Optional[torch.Tensor] = None, splitk: int = 1, atomic: bool = False,
+             accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0) -> None:
+        g = L.GemmArgs()
+        g.a, g.b, g.c, g.bias = a, b, c_ptr, (None if bias is None else bias.data_ptr())
+        g.c_zs0, g.c_zs1, g.ldc_m, g.ldc_n, g.c_tap_stride, g.c_zdiv = c_zs0, c_zs1, ldc_m, ldc_n, c_tap_stride, c_zdiv
+        g.M, g.N, g.K, g.taps, g.batches = M, N, K, taps, batches
+        g.taps_in_z, g.splitk, g.atomic, g.accumulate, g.c_f32, g.dtype = int(taps_in_z), splitk, int(atomic), int(accumulate), int(c_f32), dtype
+        g.alpha = alpha
+        L.check(self.lib.jen1_train_gemm(g, self.stream()), "jen1_train_gemm")
+
+    def pick_splitk(self, M: int, N: int, ksteps: int, z: int = 1) -> int:
+        tiles = ((M + 63) // 64) * ((N + 63) // 64) * z
+        if tiles >= self.target_wgs // 2:
+            return 1
+        s = min(max(1, self.target_wgs // tiles), max(1, ksteps // 4))
+        return max(1, min(s, 65535 // max(1, z)))
+
+
+# =====================================================================================================================
+# convolution family: _Conv1d (blocks.py:34-53), nn.Conv1d / nn.ConvTranspose1d of Upsample1d (blocks.py:69-95), nn.Linear
+# =====================================================================================================================
+class ConvGeom:
+    """static description of one convolution call"""
+
+    def __init__(self, kind: str, taps: int, stride: int, pad: int, L_in: int, L_out: int, ci: int, co: int):
+        self.kind, self.taps, self.stride, self.pad, self.L_in, self.L_out, self.ci, self.co = kind, taps, stride, pad, L_in, L_out, ci, co
+
+    def fwd_map(self, axis: int) -> Optional[Map]:
+        """activation index (b, t_out) [+ tap] -> input row"""
+        if self.kind == "linear":
+            return None
+        if self.kind == "conv":
+            return Map(axis, self.L_out, self.L_in, mul=self.stride, tapmul=1, shift=-self.pad)
+        return Map(axis, self.L_out, self.L_in, mul=1, tapmul=-1, shift=self.pad, div=self.stride)
+
+    def bwd_map(self, axis: int) -> Optional[Map]:
+        """activation index (b, t_in) [+ tap] -> output row"""
+        if self.kind == "linear":
+            return None
+        if self.kind == "conv":
+            return Map(axis, self.L_in, self.L_out, mul=1, tapmul=-1, shift=self.pad, div=self.stride)
+        return Map(axis, self.L_in, self.L_out, mul=self.stride, tapmul=1, shift=-self.pad)
+
+
+def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom) -> torch.Tensor:
+    """x: [..rows.., ldx] channel-last with ldx == wp.shape[2]; returns [B, L_out, pad8(co)]"""
+    dt = rt.dt_of(x)
+    ldx = x.shape[-1]
+    k, co, cip = wp.shape
+    assert ldx == cip and x.is_contiguous() and k == g.taps and co == g.co, (x.shape, wp.shape, g.__dict__)
+    rows_in = x.numel() // ldx
+    B = rows_in // g.L_in
+    M = B * g.L_out
+    ldy = pad8(co)
+    a = _operand(x.data_ptr(), ldx, 1, m=g.fwd_map(1))
+    b = _operand(wp.data_ptr(), cip, 1, tap_stride=co * cip)
+    ksteps = k * ((cip + 31) // 32)
+    sk = rt.pick_splitk(M, co, ksteps)
+    alloc = torch.zeros if (ldy != co or sk > 1) else torch.empty
+    if sk > 1:
+        y32 = torch.zeros((B, g.L_out, ldy), dtype=torch.float32, device=x.device)
+        rt.gemm(a, b, y32.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, splitk=sk, atomic=True, c_f32=True)
+        return y32 if x.dtype == torch.float32 else y32.to(x.dtype)
+    y = alloc((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
+    rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias)
+    return y
+
+
+def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeom) -> torch.Tensor:
+    dt = rt.dt_of(dy)
+    ldy = dy.shape[-1]
+    k, co, cip = wp.shape
+    assert dy.is_contiguous() and ldy == pad8(co)
+    B = dy.numel() // ldy // g.L_out
+    M = B * g.L_in
+    a = _operand(dy.data_ptr(), ldy, 1, m=g.bwd_map(1))
+    b = _operand(wp.data_ptr(), 1, cip, tap_stride=co * cip)
+    ksteps = k * ((co + 31) // 32)
+    sk = rt.pick_splitk(M, cip, ksteps)
+    if sk > 1:
+        dx32 = torch.zeros((B, g.L_in, cip), dtype=torch.float32, device=dy.device)
+        rt.gemm(a, b, dx32.data_ptr(), M, cip, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True)
+        return dx32 if dy.dtype == torch.float32 else dx32.to(dy.dtype)
+    dx = torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
+    rt.gemm(a, b, dx.data_ptr(), M, cip, co, dtype=dt, taps=k, ldc_m=cip)
+    return dx
+
+
+def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.Tensor, g: ConvGeom) -> None:
+    """gw (float32, reference layout) += the weight gradient"""
+    dt = rt.dt_of(x)
+    ldx, ldy = x.shape[-1], dy.shape[-1]
+    k = g.taps
+    if g.kind == "convT":
+        # W[ci][co][k]: rows m = ci from x (K = (b, t_in)), rows n = co from dy at the mapped row
+        K = x.numel() // ldx
+        a = _operand(x.data_ptr(), 1, ldx)
+        b = _operand(dy.data_ptr(), 1, ldy, m=g.bwd_map(2))
+        M, N = g.ci, g.co
+    else:
+        # W[co][ci][k]: rows m = co from dy (K = (b, t_out)), rows n = ci from x at the mapped row
+        K = dy.numel() // ldy
+        a = _operand(dy.data_ptr(), 1, ldy)
+        b = _operand(x.data_ptr(), 1, ldx, m=g.fwd_map(2))
+        M, N = g.co, g.ci
+    sk = rt.pick_splitk(M, N, (K + 31) // 32, z=k)
+    rt.gemm(a, b, gw.data_ptr(), M, N, K, dtype=dt, taps=k, taps_in_z=True, ldc_m=N * k, ldc_n=k, c_tap_stride=1,
+            splitk=sk, atomic=True, c_f32=True)
+
+
+class ConvFn(Function):
+    """y = conv(x, weight) + bias; backward writes the parameter gradients into ``.grad`` itself"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rt: TrainRuntime, g: ConvGeom):
+        wp = rt.packed(weight, g.kind, x.dtype)
+        ctx.rt, ctx.g, ctx.weight, ctx.bias, ctx.wp = rt, g, weight, bias, wp
+        ctx.save_for_backward(x)
+        return _conv_forward(rt, x, wp, None if bias is None else bias.detach(), g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        rt, g = ctx.rt, ctx.g
+        dy = dy.contiguous()
+        _conv_wgrad(rt, x, dy, rt.grad_of(ctx.weight), g)
+        if ctx.bias is not None:
+            ldy = dy.shape[-1]
+            L.check(rt.lib.jen1_colsum(dy.data_ptr(), rt.grad_of(ctx.bias).data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
+                    "jen1_colsum")
+        dx = _conv_dgrad(rt, dy, ctx.wp, g).view(x.shape) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None
+
+
+def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal: bool) -> torch.Tensor:
+    """_Conv1d (blocks.py:34-53): total padding k - 1, all on the left when causal else split evenly."""
+    co, ci, k = weight.shape
+    B, Lin, _ = x.shape
+    pad = (k - 1) if causal else (k - 1) // 2
+    return ConvFn.apply(x, weight, bias, rt, ConvGeom("conv", k, stride, pad, Lin, (Lin - 1) // stride + 1, ci, co))
+
+
+def conv1d_zero_pad(rt: TrainRuntime, x: torch.Tensor, weight, bias, padding: int) -> torch.Tensor:
+    """nn.Conv1d(k, padding=p) (Upsample1d with factor 1, blocks.py:76-79)"""
+    co, ci, k = weight.shape
+    B, Lin, _ = x.shape
+    return ConvFn.apply(x, weight, bias, rt, ConvGeom("conv", k, 1, padding, Lin, Lin + 2 * padding - k + 1, ci, co))
+
+
+def conv_transpose1d(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, padding: int, output_padding: int) -> torch.Tensor:
+    """nn.ConvTranspose1d (Upsample1d, blocks.py:80-88)"""
+    ci, co, k = weight.shape
+    B, Lin, _ = x.shape
+    Lout = (Lin - 1) * stride - 2 * padding + k + output_padding
+    return ConvFn.apply(x, weight, bias, rt, ConvGeom("convT", k, stride, padding, Lin, Lout, ci, co))
+
+
+def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None) -> torch.Tensor:
+    """nn.Linear on the last axis; x [..., pad8(in)] -> [..., pad8(out)]"""
+    co, ci = weight.shape
+    lead = x.shape[:-1]
+    rows = x.numel() // x.shape[-1]
+    y = ConvFn.apply(x.reshape(1, rows, x.shape[-1]), weight, bias, rt, ConvGeom("linear", 1, 1, 0, rows, rows, ci, co))
+    return y.view(*lead, y.shape[-1])
+
+
+# =====================================================================================================================
+# GroupNorm (+FiLM) (+SiLU): ConvBlock1d prologue (blocks.py:137-143), Transformer1d.group_norm (blocks.py:509)
+# =====================================================================================================================
+class GroupNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, film, rt: TrainRuntime, C: int, groups: int, eps: float, silu: bool):
+        B, Lx, ld = x.shape
+        assert x.is_contiguous() and ld >= C
+        dt = rt.dt_of(x)
+        sums = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+        y = (torch.zeros_like if ld != C else torch.empty_like)(x)
+        s = rt.stream()
+        if film is not None:
+            film = film.contiguous()
+            assert film.dtype == x.dtype and film.shape[-1] >= 2 * C
+        L.check(rt.lib.jen1_gn_sums(x.data_ptr(), sums.data_ptr(), B, Lx, C, ld, groups, dt, s), "jen1_gn_sums")
+        L.check(rt.lib.jen1_gn_apply(x.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                     None if film is None else film.data_ptr(), 0 if film is None else film.shape[-1],
+                                     y.data_ptr(), B, Lx, C, ld, groups, float(eps), 1 if silu else 0, dt, s), "jen1_gn_apply")
+        ctx.rt, ctx.C, ctx.groups, ctx.eps, ctx.silu, ctx.gamma, ctx.beta = rt, C, groups, eps, silu, gamma, beta
+        ctx.has_film = film is not None
+        ctx.save_for_backward(x, sums, film if film is not None else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sums, film = ctx.saved_tensors
+        rt, C, groups = ctx.rt, ctx.C, ctx.groups
+        B, Lx, ld = x.shape
+        dy = dy.contiguous()
+        dt = rt.dt_of(x)
+        dx = (torch.zeros_like if ld != C else torch.empty_like)(x)
+        P = torch.empty((B, C, 4), dtype=torch.float32, device=x.device)
+        Gm = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+        dfilm = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device) if ctx.has_film else None
+        L.check(rt.lib.jen1_gn_backward(dy.data_ptr(), x.data_ptr(), sums.data_ptr(), ctx.gamma.data_ptr(), ctx.beta.data_ptr(),
+                                        film.data_ptr() if ctx.has_film else None, film.shape[-1] if ctx.has_film else 0,
+                                        dx.data_ptr(), rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(),
+                                        None if dfilm is None else dfilm.data_ptr(), P.data_ptr(), Gm.data_ptr(), B, Lx, C, ld,
+                                        groups, float(ctx.eps), 1 if ctx.silu else 0, dt, rt.stream()), "jen1_gn_backward")
+        if dfilm is not None:
+            df = torch.zeros((B, film.shape[-1]), dtype=film.dtype, device=x.device) if film.shape[-1] != 2 * C else None
+            if df is None:
+                df = dfilm.to(film.dtype)
+            else:
+                df[:, :2 * C] = dfilm
+        else:
+            df = None
+        return dx, None, None, df, None, None, None, None, None
+
+
+def group_norm(rt, x, gamma, beta, C, groups, eps, film=None, silu=False):
+    return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu)
+
+
+# =====================================================================================================================
+# LayerNorm (blocks.py:400-401), GELU / SiLU
+# =====================================================================================================================
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rt: TrainRuntime, C: int, eps: float):
+        x = x.contiguous()
+        ld = x.shape[-1]
+        rows = x.numel() // ld
+        y = (torch.zeros_like if ld != C else torch.empty_like)(x)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        L.check(rt.lib.jen1_ln_forward(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), rows, C, ld,
+                                       float(eps), rt.dt_of(x), rt.stream()), "jen1_ln_forward")
+        ctx.rt, ctx.C, ctx.gamma, ctx.beta = rt, C, gamma, beta
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        rt, C = ctx.rt, ctx.C
+        dy = dy.contiguous()
+        ld = x.shape[-1]
+        rows = x.numel() // ld
+        dx = (torch.zeros_like if ld != C else torch.empty_like)(x)
+        L.check(rt.lib.jen1_ln_backward(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), ctx.gamma.data_ptr(), dx.data_ptr(),
+                                        rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(), rows, C, ld, rt.dt_of(x),
+                                        rt.stream()), "jen1_ln_backward")
+        return dx, None, None, None, None, None
+
+
+def layer_norm(rt, x, gamma, beta, eps: float = 1e-5):
+    return LayerNormFn.apply(x, gamma, beta, rt, gamma.shape[0], eps)
+
+
+class ActFn(Function):
+    """mode 0: GELU(erf); mode 1: SiLU"""
+
+    @staticmethod
+    def forward(ctx, x, rt: TrainRuntime, mode: int):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(rt.lib.jen1_act_forward(x.data_ptr(), y.data_ptr(), x.numel(), mode, rt.dt_of(x), rt.stream()), "jen1_act_forward")
+        ctx.rt, ctx.mode = rt, mode
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        L.check(ctx.rt.lib.jen1_act_backward(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), ctx.mode, ctx.rt.dt_of(x), ctx.rt.stream()),
+                "jen1_act_backward")
+        return dx, None, None
+
+
+def gelu(rt, x):
+    return ActFn.apply(x, rt, 0)
+
+
+def silu(rt, x):
+    return ActFn.apply(x, rt, 1)
+
+
+# =====================================================================================================================
+# attention core (AttentionBase.forward, math path: blocks.py:355-380)
+# =====================================================================================================================
+def _rows_view(t: torch.Tensor) -> Tuple[int, int]:
+    """(pointer, row pitch) of a [B, N, C] tensor or last-axis slice of one (k / v halves of to_kv's output)"""
+    assert t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), "rows must be uniformly strided"
+    return t.data_ptr(), t.stride(1)
+
+
+class AttentionCoreFn(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, rt: TrainRuntime, heads: int, causal: bool):
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
+        d = C // heads
+        dt = rt.dt_of(q)
+        Z = B * heads
+        ldS = pad8(Nk)
+        qp, ldq = _rows_view(q)
+        kp, ldk = _rows_view(k)
+        vp, ldv = _rows_view(v)
+        scale = d ** -0.5
+        S = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
+        P = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
+        O = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+        rt.gemm(_operand(qp, ldq, 1, zs0=Nq * ldq, zs1=d, zdiv=heads), _operand(kp, ldk, 1, zs0=Nk * ldk, zs1=d, zdiv=heads),
+                S.data_ptr(), Nq, Nk, d, dtype=dt, batches=Z, ldc_m=ldS, c_zs0=Nq * ldS, c_f32=True, alpha=scale)
+        L.check(rt.lib.jen1_softmax_forward(S.data_ptr(), P.data_ptr(), Z * Nq, Nq, Nk, ldS, ldS, 1 if causal else 0, dt, rt.stream()),
+                "jen1_softmax_forward")
+        rt.gemm(_operand(P.data_ptr(), ldS, 1, zs0=Nq * ldS), _operand(vp, 1, ldv, zs0=Nk * ldv, zs1=d, zdiv=heads),
+                O.data_ptr(), Nq, d, Nk, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nq * C, c_zs1=d, c_zdiv=heads)
+        ctx.rt, ctx.heads, ctx.scale = rt, heads, scale
+        ctx.save_for_backward(q, k, v, P)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, P = ctx.saved_tensors
+        rt, heads, scale = ctx.rt, ctx.heads, ctx.scale
+        dO = dO.contiguous()
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
+        d = C // heads
+        dt = rt.dt_of(q)
+        Z = B * heads
+        ldS = P.shape[-1]
+        qp, ldq = _rows_view(q)
+        kp, ldk = _rows_view(k)
+        vp, ldv = _rows_view(v)
+        dP = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
+        dS = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
+        dQ = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+        dK = torch.empty((B, Nk, C), dtype=q.dtype, device=q.device)
+        dV = torch.empty((B, Nk, C), dtype=q.dtype, device=q.device)
+        o_do = lambda ld_r, ld_k: _operand(dO.data_ptr(), ld_r, ld_k, zs0=Nq * C, zs1=d, zdiv=heads)
+        # dP = dO V^T
+        rt.gemm(o_do(C, 1), _operand(vp, ldv, 1, zs0=Nk * ldv, zs1=d, zdiv=heads), dP.data_ptr(), Nq, Nk, d, dtype=dt, batches=Z,
+                ldc_m=ldS, c_zs0=Nq * ldS, c_f32=True)
+        L.check(rt.lib.jen1_softmax_backward(P.data_ptr(), dP.data_ptr(), dS.data_ptr(), Z * Nq, Nk, ldS, ldS, dt, rt.stream()),
+                "jen1_softmax_backward")
+        # dQ = scale dS K ; dK = scale dS^T Q ; dV = P^T dO
+        rt.gemm(_operand(dS.data_ptr(), ldS, 1, zs0=Nq * ldS), _operand(kp, 1, ldk, zs0=Nk * ldk, zs1=d, zdiv=heads),
+                dQ.data_ptr(), Nq, d, Nk, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nq * C, c_zs1=d, c_zdiv=heads, alpha=scale)
+        rt.gemm(_operand(dS.data_ptr(), 1, ldS, zs0=Nq * ldS), _operand(qp, 1, ldq, zs0=Nq * ldq, zs1=d, zdiv=heads),
+                dK.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nk * C, c_zs1=d, c_zdiv=heads, alpha=scale)
+        rt.gemm(_operand(P.data_ptr(), 1, ldS, zs0=Nq * ldS), o_do(1, C),
+                dV.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nk * C, c_zs1=d, c_zdiv=heads)
+        return dQ, dK, dV, None, None, None
+
+
+def attention_core(rt, q, k, v, heads: int, causal: bool):
+    return AttentionCoreFn.apply(q, k, v, rt, heads, causal)
+
+
+# =====================================================================================================================
+# the differentiable UNet (mirrors UNet1d.forward model.py:225-265 and UNetCFG1d.forward model.py:299-376)
+# =====================================================================================================================
+class TrainGraph:
+    """Differentiable forward of a ``UNetCFG1d`` (jen1_amd/model.py) on the HIP training kernels.
+
+    ``module`` supplies the parameters under the reference's ``state_dict`` names; gradients land in ``param.grad``.
+    Call ``invalidate()`` (or let ``FusedAdamW`` do it through ``attach_optimizer``) after every parameter update.
+    """
+
+    def __init__(self, module: torch.nn.Module, spec: UNetSpec, compute_dtype: str = "bf16", device="cuda"):
+        self.rt = TrainRuntime(compute_dtype, device)
+        self.compute_dtype = compute_dtype
+        self.spec = spec
+        self.p: Dict[str, torch.nn.Parameter] = dict(module.named_parameters())
+        missing = [k for k, _ in spec.param_shapes() if k not in self.p]
+        assert not missing, f"module lacks parameters: {missing[:4]}"
+        self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
+
+    def invalidate(self) -> None:
+        self.rt.invalidate()
+
+    def attach_optimizer(self, opt) -> None:
+        """re-pack the compute weights after every ``FusedAdamW.step``"""
+        opt.post_step_hooks.append(self.invalidate)
+
+    # ------------------------------------------------------------------ leaves
+    def _to_rows(self, x_bct: torch.Tensor) -> torch.Tensor:
+        """[B, C, T] float32 -> channel-last [B, T, pad8(C)] in the compute dtype"""
+        B, C, T = x_bct.shape
+        out = torch.zeros((B, T, pad8(C)), dtype=self.rt.tdtype, device=x_bct.device)
+        out[:, :, :C] = x_bct.transpose(1, 2)
+        return out
+
+    def _time_features(self, prefix: str, t: torch.Tensor) -> torch.Tensor:
+        """LearnedPositionalEmbedding + Linear (utils/module.py:58-79) in float32"""
+        w = self.p[f"{prefix}.0.weights"]
+        x = t.to(torch.float32)[:, None]
+        freqs = x * w[None, :] * 2 * math.pi
+        f = torch.cat([x, freqs.sin(), freqs.cos()], dim=-1)
+        fp = torch.zeros((f.shape[0], pad8(f.shape[1])), dtype=torch.float32, device=f.device)
+        fp = torch.cat([f, fp[:, f.shape[1]:]], dim=-1)
+        return linear(self.rt, fp, self.p[f"{prefix}.1.weight"], self.p[f"{prefix}.1.bias"])
+
+    def mapping(self, t: torch.Tensor) -> torch.Tensor:
+        """UNet1d.get_mapping (model.py:204-223, :75-89), float32"""
+        rt, p = self.rt, self.p
+        m = gelu(rt, self._time_features("to_time.0", t))
+        m = gelu(rt, linear(rt, m, p["to_mapping.0.weight"], p["to_mapping.0.bias"]))
+        return gelu(rt, linear(rt, m, p["to_mapping.2.weight"], p["to_mapping.2.bias"]))
+
+    def res_block(self, r: ResSpec, x: torch.Tensor, smap: torch.Tensor, causal: bool) -> torch.Tensor:
+        """ResnetBlock1d.forward (blocks.py:219-231); ``smap`` = SiLU(mapping) in the compute dtype"""
+        rt, p, n = self.rt, self.p, r.name
+        h = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True)
+        h = conv1d_same(rt, h, p[f"{n}.block1.project.conv.weight"], p[f"{n}.block1.project.conv.bias"], 1, causal)
+        film = linear(rt, smap, p[f"{n}.to_scale_shift.to_scale_shift.1.weight"], p[f"{n}.to_scale_shift.to_scale_shift.1.bias"])
+        h = group_norm(rt, h, p[f"{n}.block2.groupnorm.weight"], p[f"{n}.block2.groupnorm.bias"], r.c_out, r.groups, 1e-5, film, True)
+        h = conv1d_same(rt, h, p[f"{n}.block2.project.conv.weight"], p[f"{n}.block2.project.conv.bias"], 1, causal)
+        if r.has_shortcut:
+            x = conv1d_same(rt, x, p[f"{n}.to_out.conv.weight"], p[f"{n}.to_out.conv.bias"], 1, causal)
+        return h + x
+
+    def attention(self, n: str, x: torch.Tensor, context: Optional[torch.Tensor], context_mask: Optional[torch.Tensor],
+                  heads: int, causal: bool) -> torch.Tensor:
+        """Attention.forward (blocks.py:415-437): the padding mask multiplies K and V (:431-434)"""
+        rt, p = self.rt, self.p
+        ctx = x if context is None else context
+        xn = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"])
+        cn = layer_norm(rt, ctx, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"])
+        q = linear(rt, xn, p[f"{n}.to_q.weight"])
+        kv = linear(rt, cn, p[f"{n}.to_kv.weight"])
+        mid = kv.shape[-1] // 2
+        k, v = kv[..., :mid], kv[..., mid:]
+        if context_mask is not None:
+            m = context_mask.to(kv.dtype)[:, :, None]
+            k, v = k * m, v * m
+        o = attention_core(rt, q, k, v, heads, causal)
+        return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"])
+
+    def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool) -> torch.Tensor:
+        """Transformer1d.forward (blocks.py:528-537): the SAME 1x1 conv before and after the blocks"""
+        rt, p, n = self.rt, self.p, t.name
+        w, b = p[f"{n}.conv1d.conv.weight"], p[f"{n}.conv1d.conv.bias"]
+        h = group_norm(rt, x, p[f"{n}.group_norm.weight"], p[f"{n}.group_norm.bias"], t.channels, 32, 1e-6, None, False)
+        h = conv1d_same(rt, h, w, b, 1, causal)
+        for l in range(t.num_layers):
+            bn = f"{n}.blocks.{l}"
+            h = self.attention(f"{bn}.attention", h, None, None, t.heads, causal) + h
+            h = self.attention(f"{bn}.cross_attention", h, embedding, embedding_mask, t.heads, False) + h
+            f = gelu(rt, linear(rt, h, p[f"{bn}.feed_forward.0.weight"], p[f"{bn}.feed_forward.0.bias"]))
+            h = linear(rt, f, p[f"{bn}.feed_forward.2.weight"], p[f"{bn}.feed_forward.2.bias"]) + h
+        return conv1d_same(rt, h, w, b, 1, causal)
+
+    @staticmethod
+    def _crop_pair(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """crop (utils/module.py:186-204) on the length axis of channel-last tensors"""
+        la, lb = a.shape[1], b.shape[1]
+        if la == lb:
+            return a, b
+        if la > lb:
+            d = la - lb
+            return a[:, d // 2: la - (d - d // 2)], b
+        d = lb - la
+        return a, b[:, d // 2: lb - (d - d // 2)]
+
+    # ------------------------------------------------------------------ UNet1d.forward
+    def unet(self, x: torch.Tensor, t: torch.Tensor, embedding: torch.Tensor, embedding_mask, ctx_channels, causal: bool) -> torch.Tensor:
+        """x [B, C, T] float32 (+ ctx_channels [B, 129, T]) -> [B, out_channels, T] float32"""
+        rt, p, sp = self.rt, self.p, self.spec
+        if ctx_channels is not None:
+            x = torch.cat([x, ctx_channels.to(x.dtype)], dim=1)
+        h = self._to_rows(x)
+        mp = self.mapping(t)
+        smap = silu(rt, mp).to(rt.tdtype)
+        h = self.res_block(sp.to_in, h, smap, False)          # Patcher / Unpatcher are never causal (blocks.py:256-259)
+        skips_list: List = [h]
+        for d in sp.downs:
+            h = conv1d_same(rt, h, p[f"{d.name}.downsample.conv.weight"], p[f"{d.name}.downsample.conv.bias"], d.factor, causal)
+            skips = []
+            for r in d.blocks:
+                h = self.res_block(r, h, smap, causal)
+                skips.append(h)
+            if d.transformer:
+                h = self.transformer(d.transformer, h, embedding, embedding_mask, causal)
+                skips.append(h)
+            skips_list.append(skips)
+        h = self.res_block(sp.bott_pre, h, smap, causal)
+        if sp.bott_tr:
+            h = self.transformer(sp.bott_tr, h, embedding, embedding_mask, causal)
+        h = self.res_block(sp.bott_post, h, smap, causal)
+        for u in sp.ups:
+            skips = skips_list.pop()
+            for r in u.blocks:
+                a, sk = self._crop_pair(h, skips.pop())                 # blocks.py:732-734
+                h = torch.cat([a, sk * self.skip_scale], dim=-1)
+                h = self.res_block(r, h, smap, causal)
+            if u.transformer:
+                h = self.transformer(u.transformer, h, embedding, embedding_mask, causal)
+            w, b = p[f"{u.name}.upsample.weight"], p[f"{u.name}.upsample.bias"]
+            f = u.factor
+            if f == 1:
+                h = conv1d_zero_pad(rt, h, w, b, 1)
+            else:
+                h = conv_transpose1d(rt, h, w, b, f, f // 2 + f % 2, f % 2)
+        h = h + skips_list.pop()                                         # model.py:261
+        h = self.res_block(sp.to_out, h, smap, False)
+        return h[:, :, :sp.out_channels].to(torch.float32).transpose(1, 2)
+
+    # ------------------------------------------------------------------ UNetCFG1d.forward
+    def forward(self, x: torch.Tensor, time: torch.Tensor, *, embedding: torch.Tensor, embedding_mask: Optional[torch.Tensor] = None,
+                embedding_scale: float = 1.0, embedding_mask_proba: float = 0.0, batch_cfg: bool = False, scale_cfg: bool = False,
+                scale_phi: float = 0.7, features=None, channels_list: Optional[Sequence[torch.Tensor]] = None,
+                causal: Optional[bool] = False, dropout_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same contract as the reference forward (model.py:299-376), differentiable."""
+        assert features is None, "context_features is unused on the JEN-1 path"
+        rt, p, sp = self.rt, self.p, self.spec
+        causal = bool(causal)
+        B = embedding.shape[0]
+        dev = x.device
+        emb = embedding.to(rt.tdtype)
+        mask = embedding_mask
+        if sp.use_xattn_time:
+            tok = gelu(rt, self._time_features("to_time_embedding.0", time)).to(rt.tdtype)
+            emb = torch.cat([emb, tok[:, None, :]], dim=1)
+            if mask is not None:
+                mask = torch.cat([mask.to(torch.float32), torch.ones((B, 1), device=dev)], dim=1)
+        fixed = p["fixed_embedding.embedding.weight"][: emb.shape[1]].to(rt.tdtype)[None].expand(B, -1, -1)
+        if embedding_mask_proba > 0.0:
+            if dropout_rows is not None:
+                rows = dropout_rows.to(torch.bool)
+            elif embedding_mask_proba >= 1.0:
+                rows = torch.ones(B, dtype=torch.bool, device=dev)
+            else:   # rand_bool (utils/module.py:36-42)
+                rows = torch.bernoulli(torch.full((B,), float(embedding_mask_proba), device=dev)).to(torch.bool)
+            emb = torch.where(rows[:, None, None], fixed, emb)
+        ctx = None
+        if sp.ctx_ch0:
+            assert channels_list is not None and channels_list[0] is not None, "Missing context"     # model.py:189
+            ctx = channels_list[0]
+        if embedding_scale != 1.0:
+            if batch_cfg:
+                out_all = self.unet(torch.cat([x, x], 0), torch.cat([time, time], 0), torch.cat([emb, fixed], 0).contiguous(),
+                                    None if mask is None else torch.cat([mask, mask], 0),
+                                    None if ctx is None else torch.cat([ctx, ctx], 0), causal)
+                out, out_masked = out_all[:B], out_all[B:]
+            else:
+                out = self.unet(x, time, emb.contiguous(), mask, ctx, causal)
+                out_masked = self.unet(x, time, fixed.contiguous(), mask, ctx, causal)
+            out_cfg = out_masked + (out - out_masked) * embedding_scale
+            if scale_cfg:
+                out_std = out.std(dim=1, keepdim=True)
+                out_cfg_std = out_cfg.std(dim=1, keepdim=True)
+                return scale_phi * (out_cfg * (out_std / out_cfg_std)) + (1 - scale_phi) * out_cfg
+            return out_cfg
+        return self.unet(x, time, emb.contiguous(), mask, ctx, causal)
+
+    __call__ = forward

@@ -287,6 +287,7 @@ def gen_tiny_train(model=None):
              "to_out.block.block2.groupnorm.weight", "to_time.0.0.weights", "fixed_embedding.embedding.weight",
              "to_mapping.0.bias"]
     out["grad_names"] = np.array(json.dumps(names))
+    out["grad_names_all"] = np.array(json.dumps([n for n, _ in model.named_parameters()]))
     for task, causal in (("text_guided", False), ("music_inpaint", False), ("music_cont", True)):
         x0 = synth.latents(B, T_, key="clip")
         cond = synth.conditioning(B, T_, task)
@@ -304,6 +305,11 @@ def gen_tiny_train(model=None):
             out[f"loss.{task}.{objective}"] = np.float32(loss.item())
             params = dict(model.named_parameters())
             out[f"gradnorm.{task}.{objective}"] = np.array([params[n].grad.norm().item() for n in names], dtype=np.float32)
+            if objective == "noise":
+                # every parameter's gradient norm + a strided sample of its entries, in named_parameters() order
+                out[f"gradnorm_all.{task}"] = np.array([p_.grad.norm().item() for _, p_ in model.named_parameters()], dtype=np.float32)
+                out[f"gradsample_all.{task}"] = np.concatenate(
+                    [p_.grad.reshape(-1)[:: max(1, p_.numel() // 16)][:16].numpy() for _, p_ in model.named_parameters()]).astype(np.float32)
             if task == "text_guided" and objective == "noise":
                 out["grad.to_time.0.0.weights"] = params["to_time.0.0.weights"].grad.numpy().copy()
                 out["grad.to_out.block.block2.project.conv.bias"] = params["to_out.block.block2.project.conv.bias"].grad.numpy().copy()

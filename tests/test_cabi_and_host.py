@@ -17,7 +17,7 @@ from jen1_amd import lib as L
 from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config
 from oracle import jen1_oracle as O
 
-HEADER = os.path.join(ROOT, "include", "jen1_hip.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("jen1_hip.h", "jen1_train.h")]
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +28,7 @@ def lib():
 
 # ------------------------------------------------------------------ C ABI
 def test_every_declared_symbol_is_exported(lib):
-    src = open(HEADER).read()
+    src = "\n".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     declared = set(re.findall(r"\b(jen1_[a-z0-9_]+)\s*\(", src))
     assert declared, "no declarations parsed"
@@ -50,22 +50,41 @@ def test_struct_layout_matches_header():
 #include <stdio.h>
 #include <stddef.h>
 #include "jen1_hip.h"
+#include "jen1_train.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(jen1_conv_args), offsetof(jen1_conv_args, dtype), offsetof(jen1_conv_args, gn_eps),
          offsetof(jen1_conv_args, cfg), offsetof(jen1_conv_args, zeros), offsetof(jen1_conv_args, ln_fold), sizeof(jen1_norm_args));
   printf("%zu %zu %zu %d\n", offsetof(jen1_conv_args, nseg), offsetof(jen1_conv_args, seg), sizeof(jen1_conv_seg), JEN1_MAX_SEG);
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(jen1_gemm_operand), offsetof(jen1_gemm_operand, zdiv), sizeof(jen1_gemm_args),
+         offsetof(jen1_gemm_args, c), offsetof(jen1_gemm_args, M), offsetof(jen1_gemm_args, alpha));
   return 0;
 }
 '''
     with tempfile.TemporaryDirectory() as d:
         src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
         open(src, "w").write(prog)
-        subprocess.run(["gcc", "-I", os.path.dirname(HEADER), src, "-o", exe], check=True)
+        subprocess.run(["gcc", "-I", os.path.dirname(HEADERS[0]), src, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     a = L.ConvArgs
     want = [C.sizeof(a), a.dtype.offset, a.gn_eps.offset, a.cfg.offset, a.zeros.offset, a.ln_fold.offset, C.sizeof(L.NormArgs),
-            a.nseg.offset, a.seg.offset, C.sizeof(L.ConvSeg), L.MAX_SEG]
+            a.nseg.offset, a.seg.offset, C.sizeof(L.ConvSeg), L.MAX_SEG,
+            C.sizeof(L.GemmOperand), L.GemmOperand.zdiv.offset, C.sizeof(L.GemmArgs), L.GemmArgs.c.offset, L.GemmArgs.M.offset,
+            L.GemmArgs.alpha.offset]
     assert got == want
+
+
+def test_training_ops_validate_arguments_without_a_gpu(lib):
+    g = L.GemmArgs()
+    assert lib.jen1_train_gemm(None, None) != 0 and b"args is NULL" in lib.jen1_last_error()
+    g.dtype, g.M, g.N, g.K, g.taps, g.batches, g.splitk, g.c = L.F32, 4, 4, 4, 1, 1, 2, 16
+    assert lib.jen1_train_gemm(C.byref(g), None) != 0 and b"atomic" in lib.jen1_last_error()
+    g.atomic = 1
+    assert lib.jen1_train_gemm(C.byref(g), None) != 0 and b"float32 C" in lib.jen1_last_error()
+    assert lib.jen1_gn_sums(16, 16, 1, 4, 12, 16, 8, L.F32, None) != 0 and b"divisible" in lib.jen1_last_error()
+    assert lib.jen1_ln_forward(16, 16, 16, 16, 16, 4, 4096, 4096, 1e-5, L.F32, None) != 0 and b"bad shape" in lib.jen1_last_error()
+    assert lib.jen1_act_forward(16, 16, 8, 7, L.F32, None) != 0
+    assert lib.jen1_softmax_forward(16, 16, 7, 2, 4, 4, 4, 0, L.F32, None) != 0     # rows not a multiple of Nq
+    assert lib.jen1_colsum(None, None, 1, 1, 1, L.F32, None) != 0
 
 
 def test_argument_validation_reports_errors_without_a_gpu(lib):

@@ -1,0 +1,390 @@
+"""-m gpu: the training path (jen1_amd/train.py, include/jen1_train.h) -- forward + backward parity.
+
+Per operator: the HIP forward / data gradient / parameter gradients against the same operator in plain PyTorch
+float32 with torch.autograd on the CPU (the floating-point kernel reference this tier keeps).  Whole model: loss and
+the gradient of every parameter of the tiny configuration against tests/golden/tiny_train.npz, which holds what the
+reference's own ``training_loosses(...).backward()`` produced (tests/golden/make_golden.py).
+Tolerances: float32 mode <= 1e-3 of the largest reference entry (BASELINE.json); bf16 mode 5e-2, stated per test.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, rel_err
+from jen1_amd import synth
+from jen1_amd.config import tiny_model_config
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-3
+BF16_TOL = 5e-2
+
+
+@pytest.fixture(scope="module")
+def rts():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.train import TrainRuntime
+    return {"f32": TrainRuntime("f32"), "bf16": TrainRuntime("bf16")}
+
+
+def _rows(x_bcl: torch.Tensor, dtype) -> torch.Tensor:
+    """[B, C, L] float32 (CPU) -> channel-last [B, L, pad8(C)] on the GPU"""
+    from jen1_amd.train import pad8
+    B, C, Lx = x_bcl.shape
+    out = torch.zeros((B, Lx, pad8(C)), dtype=dtype, device="cuda")
+    out[:, :, :C] = x_bcl.transpose(1, 2).to("cuda")
+    return out
+
+
+def _back(y_rows: torch.Tensor, C: int) -> np.ndarray:
+    return y_rows[:, :, :C].float().transpose(1, 2).cpu().numpy()
+
+
+def _param(shape, gen, scale=1.0):
+    return torch.nn.Parameter((torch.randn(shape, generator=gen) * scale))
+
+
+def _tol(mode):
+    return F32_TOL if mode == "f32" else BF16_TOL
+
+
+CONV_CASES = [
+    # kind, B, Ci, Co, L, k, stride, causal
+    ("conv", 2, 16, 24, 37, 3, 1, False),
+    ("conv", 2, 16, 24, 37, 3, 1, True),
+    ("conv", 3, 13, 40, 50, 3, 1, False),      # C_in = 13: padded channel columns (the 257-channel to_in conv)
+    ("conv", 2, 32, 64, 301, 9, 4, False),     # downsample f = 4
+    ("conv", 2, 32, 64, 94, 5, 2, True),       # downsample f = 2, causal
+    ("conv", 2, 64, 64, 1, 3, 1, False),       # bottom level, L = 1
+    ("conv", 16, 128, 128, 6, 3, 1, False),    # split-K forward / data gradient
+    ("conv1x1", 2, 48, 16, 29, 1, 1, False),
+    ("zeropad", 2, 16, 16, 40, 3, 1, False),   # Upsample1d factor 1
+    ("convT", 2, 24, 16, 19, 4, 2, False),     # Upsample1d factor 2
+    ("convT", 2, 16, 8, 23, 8, 4, False),      # Upsample1d factor 4
+]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_conv_family_forward_backward(rts, mode, case):
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    kind, B, Ci, Co, Lx, k, stride, causal = case
+    gen = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int) and not isinstance(v, bool)))
+    x = torch.randn((B, Ci, Lx), generator=gen).requires_grad_()
+    if kind == "convT":
+        w = _param((Ci, Co, k), gen, (Ci * k) ** -0.5)
+    else:
+        w = _param((Co, Ci, k), gen, (Ci * k) ** -0.5)
+    b = _param((Co,), gen, 0.1)
+    # reference: blocks.py:45-50 (pad then conv) / nn.ConvTranspose1d
+    if kind == "convT":
+        f = stride
+        y_ref = F.conv_transpose1d(x, w, b, stride=f, padding=f // 2 + f % 2, output_padding=f % 2)
+    elif kind == "zeropad":
+        y_ref = F.conv1d(x, w, b, padding=1)
+    else:
+        pad = ((k - 1), 0) if causal else ((k - 1) // 2, (k - 1) - (k - 1) // 2)
+        y_ref = F.conv1d(F.pad(x, pad), w, b, stride=stride)
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+    ref = dict(y=y_ref.detach().numpy(), dx=x.grad.numpy(), dw=w.grad.numpy(), db=b.grad.numpy())
+
+    wd = torch.nn.Parameter(w.detach().cuda())
+    bd = torch.nn.Parameter(b.detach().cuda())
+    xr = _rows(x.detach(), rt.tdtype).requires_grad_()
+    if kind == "convT":
+        y = TR.conv_transpose1d(rt, xr, wd, bd, stride, stride // 2 + stride % 2, stride % 2)
+    elif kind == "zeropad":
+        y = TR.conv1d_zero_pad(rt, xr, wd, bd, 1)
+    else:
+        y = TR.conv1d_same(rt, xr, wd, bd, stride, causal)
+    assert y.shape[1] == y_ref.shape[2]
+    y.backward(_rows(dy, rt.tdtype))
+    torch.cuda.synchronize()
+    tol = _tol(mode)
+    assert rel_err(_back(y.detach(), Co), ref["y"]) < tol
+    assert rel_err(_back(xr.grad, Ci), ref["dx"]) < tol
+    assert float(xr.grad[:, :, Ci:].abs().max()) == 0.0 if xr.shape[-1] > Ci else True
+    assert rel_err(wd.grad.cpu().numpy(), ref["dw"]) < tol
+    assert rel_err(bd.grad.cpu().numpy(), ref["db"]) < tol
+    # a second backward accumulates (gradient accumulation over micro-batches, trainer.py:139-143)
+    y2 = TR.conv1d_same(rt, xr, wd, bd, stride, causal) if kind in ("conv", "conv1x1") else None
+    if y2 is not None:
+        y2.backward(_rows(dy, rt.tdtype))
+        torch.cuda.synchronize()
+        assert rel_err(wd.grad.cpu().numpy(), 2 * ref["dw"]) < tol
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("rows,ci,co,bias", [(2, 129, 512, True), (48, 512, 1024, True), (258, 1024, 256, False), (5, 64, 64, True)])
+def test_linear_forward_backward(rts, mode, rows, ci, co, bias):
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator().manual_seed(rows + ci)
+    x = torch.randn((rows, ci), generator=gen).requires_grad_()
+    w = _param((co, ci), gen, ci ** -0.5)
+    b = _param((co,), gen, 0.1) if bias else None
+    y_ref = F.linear(x, w, b)
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+    wd = torch.nn.Parameter(w.detach().cuda())
+    bd = torch.nn.Parameter(b.detach().cuda()) if bias else None
+    xp = torch.zeros((rows, TR.pad8(ci)), dtype=rt.tdtype, device="cuda")
+    xp[:, :ci] = x.detach().cuda()
+    xp.requires_grad_()
+    y = TR.linear(rt, xp, wd, bd)
+    dyp = torch.zeros(y.shape, dtype=rt.tdtype, device="cuda")
+    dyp[:, :co] = dy.cuda()
+    y.backward(dyp)
+    torch.cuda.synchronize()
+    tol = _tol(mode)
+    assert rel_err(y[:, :co].detach().float().cpu().numpy(), y_ref.detach().numpy()) < tol
+    assert rel_err(xp.grad[:, :ci].float().cpu().numpy(), x.grad.numpy()) < tol
+    assert rel_err(wd.grad.cpu().numpy(), w.grad.numpy()) < tol
+    if bias:
+        assert rel_err(bd.grad.cpu().numpy(), b.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,C,Lx,groups,film,silu,eps", [
+    (2, 64, 75, 8, False, True, 1e-5), (2, 64, 75, 8, True, True, 1e-5), (3, 257, 40, 1, False, True, 1e-5),
+    (2, 128, 24, 32, False, False, 1e-6), (16, 1024, 1, 8, True, True, 1e-5), (2, 128, 1500, 8, True, True, 1e-5)])
+def test_group_norm_film_silu_forward_backward(rts, mode, B, C, Lx, groups, film, silu, eps):
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator().manual_seed(C + Lx)
+    x = (torch.randn((B, C, Lx), generator=gen) * 1.5 + 0.3).requires_grad_()
+    ga, be = _param((C,), gen), _param((C,), gen, 0.2)
+    fl = (torch.randn((B, 2 * C), generator=gen) * 0.5).requires_grad_() if film else None
+    h = F.group_norm(x, groups, ga, be, eps)                          # blocks.py:137-143
+    if film:
+        h = h * (fl[:, :C, None] + 1) + fl[:, C:, None]
+    y_ref = F.silu(h) if silu else h
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+    gd, bd = torch.nn.Parameter(ga.detach().cuda()), torch.nn.Parameter(be.detach().cuda())
+    xr = _rows(x.detach(), rt.tdtype).requires_grad_()
+    fd = fl.detach().to("cuda", rt.tdtype).requires_grad_() if film else None
+    y = TR.group_norm(rt, xr, gd, bd, C, groups, eps, fd, silu)
+    y.backward(_rows(dy, rt.tdtype))
+    torch.cuda.synchronize()
+    tol = _tol(mode) * (4 if mode == "bf16" else 1)                   # bf16 storage of x: the group statistics see rounded inputs
+    if Lx * C // groups == 1:
+        return                                                         # degenerate group of one element: y == beta, nothing to compare
+    assert rel_err(_back(y.detach(), C), y_ref.detach().numpy()) < tol
+    assert rel_err(_back(xr.grad, C), x.grad.numpy()) < tol
+    assert rel_err(gd.grad.cpu().numpy(), ga.grad.numpy()) < tol
+    assert rel_err(bd.grad.cpu().numpy(), be.grad.numpy()) < tol
+    if film:
+        assert rel_err(fd.grad.float().cpu().numpy(), fl.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("rows,C", [(48, 512), (258, 1024), (7, 64), (600, 128)])
+def test_layer_norm_forward_backward(rts, mode, rows, C):
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator().manual_seed(rows)
+    x = (torch.randn((2, rows, C), generator=gen) * 2 + 0.5).requires_grad_()
+    ga, be = _param((C,), gen), _param((C,), gen, 0.2)
+    y_ref = F.layer_norm(x, (C,), ga, be, 1e-5)
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+    gd, bd = torch.nn.Parameter(ga.detach().cuda()), torch.nn.Parameter(be.detach().cuda())
+    xd = x.detach().to("cuda", rt.tdtype).requires_grad_()
+    y = TR.layer_norm(rt, xd, gd, bd)
+    y.backward(dy.to("cuda", rt.tdtype))
+    torch.cuda.synchronize()
+    tol = _tol(mode)
+    assert rel_err(y.detach().float().cpu().numpy(), y_ref.detach().numpy()) < tol
+    assert rel_err(xd.grad.float().cpu().numpy(), x.grad.numpy()) < tol
+    assert rel_err(gd.grad.cpu().numpy(), ga.grad.numpy()) < tol
+    assert rel_err(bd.grad.cpu().numpy(), be.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("fn", ["gelu", "silu"])
+def test_activation_forward_backward(rts, mode, fn):
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn((5, 1000), generator=gen) * 3).requires_grad_()
+    y_ref = F.gelu(x) if fn == "gelu" else F.silu(x)
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+    xd = x.detach().to("cuda", rt.tdtype).requires_grad_()
+    y = (TR.gelu if fn == "gelu" else TR.silu)(rt, xd)
+    y.backward(dy.to("cuda", rt.tdtype))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().float().cpu().numpy(), y_ref.detach().numpy()) < _tol(mode)
+    assert rel_err(xd.grad.float().cpu().numpy(), x.grad.numpy()) < _tol(mode)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Nq,Nk,C,heads,causal,strided", [
+    (2, 24, 24, 64, 8, False, True), (2, 24, 24, 64, 8, True, True), (3, 6, 129, 128, 8, False, False),
+    (2, 1, 129, 512, 8, False, True), (2, 150, 150, 64, 8, True, True), (2, 75, 129, 128, 8, False, False)])
+def test_attention_core_forward_backward(rts, mode, B, Nq, Nk, C, heads, causal, strided):
+    """AttentionBase.forward math path (blocks.py:355-380) incl. the causal mask of blocks.py:315-319"""
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator().manual_seed(Nq * Nk)
+    q = torch.randn((B, Nq, C), generator=gen).requires_grad_()
+    kv = torch.randn((B, Nk, 2 * C), generator=gen).requires_grad_()
+    d = C // heads
+
+    def split(t, n):
+        return t.reshape(B, n, heads, d).transpose(1, 2)
+
+    k, v = kv[..., :C], kv[..., C:]
+    sim = torch.einsum("bhnd,bhmd->bhnm", split(q, Nq), split(k, Nk)) * d ** -0.5
+    if causal:
+        keep = ~torch.ones((Nq, Nk), dtype=torch.bool).triu(Nk - Nq + 1)
+        sim = sim.masked_fill(~keep, -torch.finfo(sim.dtype).max)
+    o_ref = torch.einsum("bhnm,bhmd->bhnd", sim.softmax(-1), split(v, Nk)).transpose(1, 2).reshape(B, Nq, C)
+    do = torch.randn(o_ref.shape, generator=gen)
+    o_ref.backward(do)
+    qd = q.detach().to("cuda", rt.tdtype).requires_grad_()
+    kvd = kv.detach().to("cuda", rt.tdtype).requires_grad_()
+    if strided:
+        kd, vd = kvd[..., :C], kvd[..., C:]
+    else:
+        kd, vd = kvd[..., :C] * 1.0, kvd[..., C:] * 1.0
+    o = TR.attention_core(rt, qd, kd, vd, heads, causal)
+    o.backward(do.to("cuda", rt.tdtype))
+    torch.cuda.synchronize()
+    tol = _tol(mode)
+    assert rel_err(o.detach().float().cpu().numpy(), o_ref.detach().numpy()) < tol
+    assert rel_err(qd.grad.float().cpu().numpy(), q.grad.numpy()) < tol
+    assert rel_err(kvd.grad.float().cpu().numpy(), kv.grad.numpy()) < tol
+
+
+# ------------------------------------------------------------------ whole model against the reference's autograd
+@pytest.fixture(scope="module")
+def tiny_model():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _loss_and_grads(model, mode, task, causal, objective):
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.init_fill import fill_uniform
+    B, T = 2, 300
+    betas, _ = get_beta_schedule("linear", 1000)
+    t = torch.tensor([17, 801], dtype=torch.long, device="cuda")
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, task).items()}
+    noise = dev(fill_uniform(f"synth.trainnoise.{task}", (B, 128, T), 3, 0.0, 1.0))
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective=objective, loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    graph = model.train_graph(mode)
+    loss = gd.training_loosses(graph, x0, t, cond, noise=noise, causal=causal)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.detach()), {n: p.grad for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("task,causal", [("text_guided", False), ("music_inpaint", False), ("music_cont", True)])
+def test_tiny_training_gradients_vs_reference_autograd_f32(tiny_model, task, causal):
+    """loss + the gradient of EVERY parameter (norm and a strided sample of entries) against the reference's
+    ``training_loosses(...).backward()`` (gdm.py:245-272, trainer.py:141) on the same inputs and weights."""
+    g = golden("tiny_train")
+    names = json.loads(str(g["grad_names_all"]))
+    loss, grads = _loss_and_grads(tiny_model, "f32", task, causal, "noise")
+    ref_loss = float(g[f"loss.{task}.noise"])
+    assert abs(loss - ref_loss) <= 1e-3 * abs(ref_loss)
+    assert sorted(names) == sorted(grads.keys())
+    ref_norm, ref_samp = g[f"gradnorm_all.{task}"], g[f"gradsample_all.{task}"]
+    gmax = float(ref_norm.max())
+    off = 0
+    worst = 0.0
+    for i, n in enumerate(names):
+        gr = grads[n]
+        assert gr is not None, f"no gradient for {n}"
+        samp = gr.reshape(-1)[:: max(1, gr.numel() // 16)][:16].cpu().numpy()
+        ref = ref_samp[off: off + samp.size]
+        off += samp.size
+        nrm = float(gr.norm())
+        # every tensor's norm within 1e-3 (relative; tiny tensors against the largest norm of the model)
+        assert abs(nrm - ref_norm[i]) <= 1e-3 * max(ref_norm[i], 1e-3 * gmax), (n, nrm, ref_norm[i])
+        scale = max(float(np.abs(ref).max()), ref_norm[i] / np.sqrt(gr.numel()))
+        err = float(np.abs(samp - ref).max() / max(scale, 1e-12))
+        worst = max(worst, err)
+        assert err < 5e-3, (n, err)
+    assert off == ref_samp.size
+    print(f"worst sampled-entry error {worst:.2e}")
+
+
+@pytest.mark.parametrize("objective", ["x0", "v"])
+def test_tiny_training_other_objectives_f32(tiny_model, objective):
+    g = golden("tiny_train")
+    names = json.loads(str(g["grad_names"]))
+    loss, grads = _loss_and_grads(tiny_model, "f32", "music_inpaint", False, objective)
+    ref_loss = float(g[f"loss.music_inpaint.{objective}"])
+    assert abs(loss - ref_loss) <= 1e-3 * abs(ref_loss)
+    ref = g[f"gradnorm.music_inpaint.{objective}"]
+    for i, n in enumerate(names):
+        assert abs(float(grads[n].norm()) - ref[i]) <= 1e-3 * max(ref[i], 1e-3 * float(ref.max())), (n, float(grads[n].norm()), ref[i])
+    full = g["grad.to_time.0.0.weights"]
+    assert full.shape == tuple(grads["to_time.0.0.weights"].shape)
+
+
+def test_tiny_training_gradients_bf16(tiny_model):
+    """bf16 storage / float32 accumulation: gradient norms within 5e-2 of the reference's float32 autograd"""
+    g = golden("tiny_train")
+    names = json.loads(str(g["grad_names_all"]))
+    loss, grads = _loss_and_grads(tiny_model, "bf16", "text_guided", False, "noise")
+    ref_loss = float(g["loss.text_guided.noise"])
+    assert abs(loss - ref_loss) <= BF16_TOL * abs(ref_loss)
+    ref_norm = g["gradnorm_all.text_guided"]
+    gmax = float(ref_norm.max())
+    bad = [(n, float(grads[n].norm()), float(ref_norm[i])) for i, n in enumerate(names)
+           if abs(float(grads[n].norm()) - ref_norm[i]) > BF16_TOL * max(ref_norm[i], 1e-2 * gmax)]
+    assert not bad, bad[:5]
+
+
+def test_training_step_updates_parameters_and_repacks(tiny_model):
+    """one optimiser step through FusedAdamW changes the loss; the packed compute weights follow the parameters"""
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+    opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=0.7)
+    graph = model.train_graph("f32")
+    graph.attach_optimizer(opt)
+    l0, _ = _loss_and_grads_keep(model, graph, opt)
+    opt.step()
+    l1, _ = _loss_and_grads_keep(model, graph, opt)
+    assert l1 != l0 and np.isfinite(l1)
+    assert float(opt.grad_norm()) > 0
+
+
+def _loss_and_grads_keep(model, graph, opt):
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.init_fill import fill_uniform
+    B, T = 2, 300
+    betas, _ = get_beta_schedule("linear", 1000)
+    t = torch.tensor([17, 801], dtype=torch.long, device="cuda")
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, "text_guided").items()}
+    noise = dev(fill_uniform("synth.trainnoise.text_guided", (B, 128, T), 3, 0.0, 1.0))
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    opt.zero_grad()
+    loss = gd.training_loosses(graph, x0, t, cond, noise=noise, causal=False)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.detach()), None
