@@ -1,0 +1,91 @@
+"""``UnifiedMultiTaskTrainer``: the training step of the reference around the HIP training path.
+
+Host-side mirror of /root/reference/trainer.py:126-213 -- ``train(audio_emb, metadata)`` (three equal sub-batches, one
+per task in the fixed order of config.py:93, a fresh mask / timestep draw per sub-batch, the sum of the three losses)
+and the optimiser part of ``train_loop`` (trainer.py:139-150: zero_grad at the start of an accumulation window,
+``(loss / grad_accum_every).backward()``, and every ``grad_accum_every`` micro-batches clip -> AdamW -> LinearLR).
+Same names and argument meaning; what is NOT mirrored: the data loader, logging / tensorboard, evaluation and the
+GradScaler (the HIP path trains in bf16 storage with float32 accumulation and float32 master weights, which needs no
+loss scaling; ``skip_nonfinite`` of FusedAdamW keeps GradScaler's skip-on-overflow behaviour).
+
+Data-parallel training (train.py:88-89): one process per GPU, every rank draws its own masks /
+timesteps / noise, and the mean all-reduce of the flat gradient buffer (``optim.allreduce_gradients``, RCCL over xGMI)
+runs once per optimiser step, right before the clip -- the gradient exchange is the only collective.
+"""
+from __future__ import annotations
+
+import random as _random
+from typing import Callable, Dict, Optional, Sequence, Tuple
+
+import torch
+
+from .optim import FusedAdamW, LinearLR, allreduce_gradients
+from .tasks import get_conditioning, random_mask
+
+TASKS = ("text_guided", "music_inpaint", "music_cont")        # config.py:93
+
+
+class UnifiedMultiTaskTrainer:
+    """``conditioner(metadata, device)`` returns ``{"prompt": (embedding [b, 128, 1024], mask [b, 128])}`` like
+    ``MultiConditioner.forward`` (conditioners.py:182-208); ``model`` is a ``jen1_amd.model.UNetCFG1d``."""
+
+    def __init__(self, model, diffusion, conditioner: Callable, optimizer: FusedAdamW, lr_scheduler: Optional[LinearLR] = None,
+                 grad_accum_every: int = 10, tasks: Sequence[str] = TASKS, device="cuda", process_group=None,
+                 rng=_random, cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
+                 input_concat_ids: Sequence[str] = ("masked_input", "mask"), compute_dtype: Optional[str] = None):
+        self.model, self.diffusion, self.conditioner, self.optimizer, self.lr_scheduler = model, diffusion, conditioner, optimizer, lr_scheduler
+        self.grad_accum_every, self.tasks, self.device, self.group, self.rng = grad_accum_every, tuple(tasks), device, process_group, rng
+        self.cross_attn_cond_ids, self.global_cond_ids, self.input_concat_ids = cross_attn_cond_ids, global_cond_ids, input_concat_ids
+        self.graph = model.train_graph(compute_dtype)
+        self.graph.attach_optimizer(optimizer)
+        self.grad_accum = 0
+        self.global_step = 0
+
+    # trainer.py:215-247 / :249-278
+    def random_mask(self, sequence, max_mask_length, task):
+        return random_mask(sequence, max_mask_length, task, self.rng)
+
+    def get_conditioning(self, cond):
+        return get_conditioning(cond, self.cross_attn_cond_ids, self.global_cond_ids, self.input_concat_ids)
+
+    def train(self, audio_emb: torch.Tensor, metadata) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """trainer.py:183-213.  Returns (sum of the task losses, {task: loss}); the per-task values stay on the device
+        (the reference's ``.item()`` per sub-batch is a host sync the step does not need)."""
+        loss_dict: Dict[str, torch.Tensor] = {}
+        all_loss = torch.zeros((), device=self.device)
+        batch_size = audio_emb.size(0)
+        assert batch_size % len(self.tasks) == 0, "Batch size must be divisible by the number of tasks"
+        sub = batch_size // len(self.tasks)
+        for i, task in enumerate(self.tasks):
+            sub_audio_emb = audio_emb[i * sub:(i + 1) * sub]
+            sub_metadata = metadata[i * sub:(i + 1) * sub]
+            self.model.train()
+            masked_input, mask, causal = self.random_mask(sub_audio_emb, sub_audio_emb.shape[2], task)
+            conditioning = self.conditioner(sub_metadata, self.device)
+            conditioning["masked_input"] = masked_input
+            conditioning["mask"] = mask
+            conditioning = self.get_conditioning(conditioning)
+            t = torch.randint(0, self.diffusion.num_timesteps, (sub,), device=self.device).long()
+            loss = self.diffusion.training_loosses(self.graph, sub_audio_emb, t, conditioning, causal=causal)
+            loss_dict[task] = loss.detach()
+            all_loss = all_loss + loss
+        return all_loss, loss_dict
+
+    def train_step(self, audio_emb: torch.Tensor, metadata) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], bool]:
+        """one iteration of ``train_loop``'s body (trainer.py:134-150).  Returns (loss, per-task losses, whether an
+        optimiser step was taken)."""
+        all_task_loss, loss_dict = self.train(audio_emb, metadata)
+        if self.grad_accum == 0:
+            self.optimizer.zero_grad()
+        (all_task_loss / self.grad_accum_every).backward()
+        self.grad_accum += 1
+        stepped = False
+        if self.grad_accum == self.grad_accum_every:
+            allreduce_gradients(self.optimizer.flat_grad, self.group)          # DDP's exchange (train.py:88-89)
+            self.optimizer.step(None if self.lr_scheduler is None else self.lr_scheduler.get_last_lr())
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step()
+            self.grad_accum = 0
+            stepped = True
+        self.global_step += 1
+        return all_task_loss.detach(), loss_dict, stepped

@@ -388,3 +388,42 @@ def _loss_and_grads_keep(model, graph, opt):
     loss.backward()
     torch.cuda.synchronize()
     return float(loss.detach()), None
+
+
+def test_unified_multitask_trainer_steps(tiny_model):
+    """trainer.py:126-213: three task sub-batches per micro-batch, gradient accumulation, clip + AdamW + LinearLR"""
+    import random
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW, LinearLR
+    from jen1_amd.trainer import UnifiedMultiTaskTrainer
+    model = UNetCFG1d(**tiny_model_config(), compute_dtype="bf16", device="cuda")
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.2, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    sched = LinearLR(1e-3)
+    B, T = 6, 300
+    emb = dev(synth.conditioning(B, T, "text_guided")["cross_attn_cond"])
+    msk = dev(synth.conditioning(B, T, "text_guided")["cross_attn_masks"])
+
+    def conditioner(metadata, device):
+        idx = torch.tensor(metadata, device=device)
+        return {"prompt": (emb[idx], msk[idx])}
+
+    tr = UnifiedMultiTaskTrainer(model, gd, conditioner, opt, sched, grad_accum_every=2, rng=random.Random(0))
+    audio = dev(synth.latents(B, T, key="clip"))
+    p0 = opt.flat_param.clone()
+    torch.manual_seed(0)
+    losses, steps = [], 0
+    for it in range(4):
+        loss, per_task, stepped = tr.train_step(audio, list(range(B)))
+        assert set(per_task) == {"text_guided", "music_inpaint", "music_cont"}
+        assert abs(float(loss) - sum(float(v) for v in per_task.values())) < 1e-3 * abs(float(loss))
+        losses.append(float(loss))
+        steps += int(stepped)
+        assert stepped == (it % 2 == 1)
+    assert steps == 2 and opt.step_count == 2 and sched.last_epoch == 2
+    assert all(np.isfinite(losses))
+    assert float((opt.flat_param - p0).abs().max()) > 0
+    assert tr.global_step == 4 and tr.grad_accum == 0
