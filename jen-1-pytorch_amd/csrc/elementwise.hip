@@ -23,9 +23,22 @@ extern "C" const char* jen1_last_error(void) { return g_jen1_err; }
 extern "C" const char* jen1_build_info(void) { return "libjen1_hip gfx950 (CDNA4) hipcc; abi 1"; }
 extern "C" int jen1_abi_version(void) { return 1; }
 
+// A kernel, not hipMemsetAsync: memset nodes interleaved with kernel nodes in a captured graph were observed to
+// run out of order on ROCm 7.2 (training step), a kernel node never is.
+__global__ __launch_bounds__(256) void memset_zero_kernel(unsigned* __restrict__ p, long long nwords) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (long long)gridDim.x * 256) p[i] = 0u;
+}
+
 extern "C" int jen1_memset_zero(void* p, int64_t bytes, void* stream) {
   JEN1_CHECK(p && bytes >= 0, "memset_zero: bad arguments");
-  JEN1_HIP(hipMemsetAsync(p, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream)));
+  JEN1_CHECK(((uintptr_t)p & 3) == 0 && (bytes & 3) == 0, "memset_zero: pointer and size must be multiples of 4");
+  if (bytes == 0) return 0;
+  const long long nwords = bytes / 4;
+  long long blocks = (nwords + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(memset_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<unsigned*>(p), nwords);
+  JEN1_HIP(hipGetLastError());
   return 0;
 }
 

@@ -172,6 +172,19 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_kernel(const GnDev g, void* dx_)
   }
 }
 
+// scratch reset as a kernel node (one launch zeroes up to two buffers)
+__global__ __launch_bounds__(NT) void zero2_kernel(float* __restrict__ a, int na, float* __restrict__ b, int nb) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i < na) a[i] = 0.f;
+  if (i < nb) b[i] = 0.f;
+}
+int zero2(float* a, int na, float* b, int nb, hipStream_t s) {
+  const int n = na > nb ? na : nb;
+  hipLaunchKernelGGL(zero2_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, s, a, na, b, nb);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
 void red_geom(int C, int L, int& CT, int& rows_per_block, int& gx, int& gy) {
   CT = 256;
   while (CT > 1 && CT / 2 >= C) CT /= 2;      // smallest power of two >= C, capped at 256
@@ -362,7 +375,7 @@ extern "C" int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int
   JEN1_CHECK(B >= 1 && L >= 1 && C >= 1 && ld >= C, "jen1_gn_sums: bad shape B=%d L=%d C=%d ld=%d", B, L, C, ld);
   JEN1_CHECK(groups >= 1 && C % groups == 0, "jen1_gn_sums: num_channels must be divisible by num_groups");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  JEN1_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * B * groups, s));
+  if (zero2(sums, 2 * B * groups, nullptr, 0, s)) return 1;
   int CT, rpb, gx, gy;
   red_geom(C, L, CT, rpb, gx, gy);
   DISPATCH(dtype, gn_sums_kernel, dim3(gx, gy, B), x, sums, L, C, ld, groups, C / groups, CT, rpb);
@@ -391,8 +404,7 @@ extern "C" int jen1_gn_backward(const void* dy, const void* x, const float* sums
   JEN1_CHECK((film == nullptr) == (dfilm == nullptr), "jen1_gn_backward: dfilm must be given exactly when film is");
   g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = dfilm;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  JEN1_HIP(hipMemsetAsync(P, 0, sizeof(float) * 4 * B * C, s));
-  JEN1_HIP(hipMemsetAsync(Gm, 0, sizeof(float) * 2 * B * groups, s));
+  if (zero2(P, 4 * B * C, Gm, 2 * B * groups, s)) return 1;
   int CT, rpb, gx, gy;
   red_geom(C, L, CT, rpb, gx, gy);
   DISPATCH(dtype, gn_bwd_sums_kernel, dim3(gx, gy, B), g, CT, rpb);

@@ -95,8 +95,11 @@ class TrainRuntime:
                 else:                                          # ConvTranspose1d
                     d = d.permute(2, 1, 0)                     # [k][Co][Ci]
                 k, co, ci = d.shape
-                p = torch.zeros((k, co, pad8(ci)), dtype=dtype, device=w.device)
-                p[:, :, :ci].copy_(d)
+                if kind == "linear" and dtype == d.dtype and ci % 8 == 0:
+                    p = d                                      # float32 mode: the parameter itself is the compute copy
+                else:
+                    p = torch.zeros((k, co, pad8(ci)), dtype=dtype, device=w.device)
+                    p[:, :, :ci].copy_(d)
             self._packed[key] = (weakref.ref(w), p)
         return p
 
@@ -489,6 +492,7 @@ class TrainGraph:
         missing = [k for k, _ in spec.param_shapes() if k not in self.p]
         assert not missing, f"module lacks parameters: {missing[:4]}"
         self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
+        self._side: Optional[torch.cuda.Stream] = None
 
     def invalidate(self) -> None:
         self.rt.invalidate()
@@ -668,4 +672,88 @@ class TrainGraph:
             return out_cfg
         return self.unet(x, time, emb.contiguous(), mask, ctx, causal)
 
-    __call__ = forward
+    def __call__(self, *args, **kwargs) -> torch.Tensor:
+        """``forward``; a call from the legacy default stream is moved to a private stream.  A backward pass that ran
+        on the null stream makes a later graph capture of the same parameters crash inside hipStreamEndCapture
+        (ROCm 7.2 / torch 2.10, reproduced in tests/test_gpu_train.py), so the eager path never uses it."""
+        dev = self.rt.device
+        cur = torch.cuda.current_stream(dev)
+        if torch.cuda.is_current_stream_capturing() or cur != torch.cuda.default_stream(dev):
+            return self.forward(*args, **kwargs)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            out = self.forward(*args, **kwargs)
+        cur.wait_stream(self._side)
+        out.record_stream(cur)
+        return out
+
+
+# =====================================================================================================================
+# hipGraph-captured forward + backward
+# =====================================================================================================================
+class GraphedLossStep:
+    """``(training_loosses(...) * scale).backward()`` captured once per (shape, causal) as a HIP graph.
+
+    In eager mode a training micro-batch is ~6000 launches issued from Python at ~20 us each, i.e. host-bound; the
+    replayed graph runs the same kernels back to back.  Inputs are copied into static buffers, the loss comes back in
+    a static scalar, gradients are accumulated into ``param.grad`` exactly as in eager mode (so ``zero_grad`` /
+    the optimiser step stay outside the graph).  Noise and the CFG-dropout rows are drawn inside the graph from
+    torch's graph-safe generator, so every replay sees fresh draws.
+    The scratch resets inside the kernels' entry points are kernel nodes: ``hipMemsetAsync`` nodes interleaved with
+    kernel nodes were observed to replay out of order on ROCm 7.2.
+    """
+
+    def __init__(self, graph: TrainGraph, diffusion, scale: float = 1.0):
+        self.graph, self.diffusion, self.scale = graph, diffusion, scale
+        self._captured: Dict[tuple, tuple] = {}
+
+    def _body(self, static, causal):
+        cond = {"cross_attn_cond": static["emb"], "cross_attn_masks": static["mask"], "global_cond": None,
+                "input_concat_cond": static["concat"]}
+        loss = self.diffusion.training_loosses(self.graph, static["x0"], static["t"], cond, causal=causal)
+        (loss * self.scale).backward()
+        return loss.detach()
+
+    def _capture(self, key, x0, t, conditioning, causal):
+        params = list(self.graph.p.values())
+        static = {"x0": x0.clone(), "t": t.clone(), "emb": conditioning["cross_attn_cond"].clone(),
+                  "mask": None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"].clone(),
+                  "concat": None if conditioning["input_concat_cond"] is None else conditioning["input_concat_cond"].clone()}
+        keep = [None if p.grad is None else p.grad.clone() for p in params]       # the warm-up run must not leak into the gradients
+        side = torch.cuda.Stream(self.graph.rt.device)
+        side.wait_stream(torch.cuda.current_stream(self.graph.rt.device))
+        with torch.cuda.stream(side):
+            self._body(static, causal)
+        torch.cuda.current_stream(self.graph.rt.device).wait_stream(side)
+        for p, k in zip(params, keep):
+            if k is None:
+                p.grad.zero_()
+            else:
+                p.grad.copy_(k)
+        del keep
+        self.graph.invalidate()            # the weight packing becomes part of the graph: replays follow the parameters
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._body(static, causal)
+        self._captured[key] = (g, static, loss)
+        return self._captured[key]
+
+    def __call__(self, x0: torch.Tensor, t: torch.Tensor, conditioning: Dict[str, Optional[torch.Tensor]], causal: bool) -> torch.Tensor:
+        assert conditioning.get("global_cond") is None
+        key = (tuple(x0.shape), bool(causal), conditioning["cross_attn_masks"] is None, conditioning["input_concat_cond"] is None)
+        hit = self._captured.get(key)
+        first = hit is None
+        if first:
+            hit = self._capture(key, x0, t, conditioning, bool(causal))
+        g, static, loss = hit
+        static["x0"].copy_(x0)
+        static["t"].copy_(t)
+        static["emb"].copy_(conditioning["cross_attn_cond"])
+        if static["mask"] is not None:
+            static["mask"].copy_(conditioning["cross_attn_masks"])
+        if static["concat"] is not None:
+            static["concat"].copy_(conditioning["input_concat_cond"])
+        g.replay()
+        return loss.clone()

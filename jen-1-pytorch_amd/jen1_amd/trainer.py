@@ -21,6 +21,7 @@ import torch
 
 from .optim import FusedAdamW, LinearLR, allreduce_gradients
 from .tasks import get_conditioning, random_mask
+from .train import GraphedLossStep
 
 TASKS = ("text_guided", "music_inpaint", "music_cont")        # config.py:93
 
@@ -32,12 +33,16 @@ class UnifiedMultiTaskTrainer:
     def __init__(self, model, diffusion, conditioner: Callable, optimizer: FusedAdamW, lr_scheduler: Optional[LinearLR] = None,
                  grad_accum_every: int = 10, tasks: Sequence[str] = TASKS, device="cuda", process_group=None,
                  rng=_random, cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
-                 input_concat_ids: Sequence[str] = ("masked_input", "mask"), compute_dtype: Optional[str] = None):
+                 input_concat_ids: Sequence[str] = ("masked_input", "mask"), compute_dtype: Optional[str] = None,
+                 use_graph: bool = True):
         self.model, self.diffusion, self.conditioner, self.optimizer, self.lr_scheduler = model, diffusion, conditioner, optimizer, lr_scheduler
         self.grad_accum_every, self.tasks, self.device, self.group, self.rng = grad_accum_every, tuple(tasks), device, process_group, rng
         self.cross_attn_cond_ids, self.global_cond_ids, self.input_concat_ids = cross_attn_cond_ids, global_cond_ids, input_concat_ids
         self.graph = model.train_graph(compute_dtype)
         self.graph.attach_optimizer(optimizer)
+        # forward + backward of one sub-batch replayed as a HIP graph (train.GraphedLossStep); the loss scaling of the
+        # accumulation window (trainer.py:141) is folded into the captured backward
+        self.graphed = GraphedLossStep(self.graph, diffusion, 1.0 / grad_accum_every) if use_graph else None
         self.grad_accum = 0
         self.global_step = 0
 
@@ -66,7 +71,12 @@ class UnifiedMultiTaskTrainer:
             conditioning["mask"] = mask
             conditioning = self.get_conditioning(conditioning)
             t = torch.randint(0, self.diffusion.num_timesteps, (sub,), device=self.device).long()
-            loss = self.diffusion.training_loosses(self.graph, sub_audio_emb, t, conditioning, causal=causal)
+            if self.graphed is not None:
+                if self.grad_accum == 0 and i == 0:
+                    self.optimizer.zero_grad()                 # the captured step already contains the backward
+                loss = self.graphed(sub_audio_emb, t, conditioning, causal)
+            else:
+                loss = self.diffusion.training_loosses(self.graph, sub_audio_emb, t, conditioning, causal=causal)
             loss_dict[task] = loss.detach()
             all_loss = all_loss + loss
         return all_loss, loss_dict
@@ -75,9 +85,10 @@ class UnifiedMultiTaskTrainer:
         """one iteration of ``train_loop``'s body (trainer.py:134-150).  Returns (loss, per-task losses, whether an
         optimiser step was taken)."""
         all_task_loss, loss_dict = self.train(audio_emb, metadata)
-        if self.grad_accum == 0:
-            self.optimizer.zero_grad()
-        (all_task_loss / self.grad_accum_every).backward()
+        if self.graphed is None:
+            if self.grad_accum == 0:
+                self.optimizer.zero_grad()
+            (all_task_loss / self.grad_accum_every).backward()
         self.grad_accum += 1
         stepped = False
         if self.grad_accum == self.grad_accum_every:

@@ -179,7 +179,7 @@ def test_tiny_training_loss_value_vs_golden(tiny_models):
         for objective in ("noise", "x0", "v"):
             gd = GaussianDiffusion(steps=1000, betas=betas, objective=objective, loss_type="l2", device="cuda",
                                    cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
-            loss = float(gd.training_loosses(tiny_models["f32"], x0, t, cond, noise=noise, causal=causal))
+            loss = float(gd.training_loosses(tiny_models["f32"], x0, t, cond, noise=noise, causal=causal).detach())
             ref = float(g[f"loss.{task}.{objective}"])
             assert abs(loss - ref) <= 1e-3 * abs(ref), (task, objective, loss, ref)
 

@@ -390,7 +390,8 @@ def _loss_and_grads_keep(model, graph, opt):
     return float(loss.detach()), None
 
 
-def test_unified_multitask_trainer_steps(tiny_model):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_unified_multitask_trainer_steps(tiny_model, use_graph):
     """trainer.py:126-213: three task sub-batches per micro-batch, gradient accumulation, clip + AdamW + LinearLR"""
     import random
     from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
@@ -411,7 +412,7 @@ def test_unified_multitask_trainer_steps(tiny_model):
         idx = torch.tensor(metadata, device=device)
         return {"prompt": (emb[idx], msk[idx])}
 
-    tr = UnifiedMultiTaskTrainer(model, gd, conditioner, opt, sched, grad_accum_every=2, rng=random.Random(0))
+    tr = UnifiedMultiTaskTrainer(model, gd, conditioner, opt, sched, grad_accum_every=2, rng=random.Random(0), use_graph=use_graph)
     audio = dev(synth.latents(B, T, key="clip"))
     p0 = opt.flat_param.clone()
     torch.manual_seed(0)
@@ -427,3 +428,44 @@ def test_unified_multitask_trainer_steps(tiny_model):
     assert all(np.isfinite(losses))
     assert float((opt.flat_param - p0).abs().max()) > 0
     assert tr.global_step == 4 and tr.grad_accum == 0
+
+
+def test_graphed_step_matches_eager_gradients():
+    """the captured forward + backward (train.GraphedLossStep) accumulates the same gradients as the eager path, replay
+    after replay, also after the parameters moved (the weight packing is part of the graph)"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    from jen1_amd.train import GraphedLossStep
+    model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    graph = model.train_graph("f32")
+    graph.attach_optimizer(opt)
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    B, T = 2, 300
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, "music_cont").items()}
+    t = torch.tensor([17, 801], dtype=torch.long, device="cuda")
+    step = GraphedLossStep(graph, gd, scale=0.5)
+    # eager pass BEFORE the capture, issued from the default stream: TrainGraph moves it to a private stream (a
+    # backward pass on the null stream makes the later capture crash inside hipStreamEndCapture)
+    gd.training_loosses(graph, x0, t, cond, causal=True).backward()
+    step(x0, t, cond, True)                 # capture (its warm-up run draws noise of its own)
+    for rnd in range(2):
+        opt.zero_grad()
+        torch.manual_seed(5 + rnd)
+        le = gd.training_loosses(graph, x0, t, cond, causal=True)
+        (le * 0.5).backward()
+        torch.cuda.synchronize()
+        ge = opt.flat_grad.clone()
+        opt.zero_grad()
+        torch.manual_seed(5 + rnd)
+        lg = step(x0, t, cond, True)
+        torch.cuda.synchronize()
+        gg = opt.flat_grad.clone()
+        le = le.detach()
+        assert abs(float(lg) - float(le)) <= 1e-5 * abs(float(le)), (rnd, float(lg), float(le))
+        assert float((gg - ge).abs().max()) <= 1e-4 * float(ge.abs().max()), rnd
+        opt.step()      # parameters move; the next replay must re-pack
