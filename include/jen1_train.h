@@ -58,6 +58,8 @@ typedef struct jen1_gemm_args {
   int32_t taps_in_z, splitk, atomic, accumulate, c_f32, dtype;
   float alpha;
   int32_t reserved;
+  float* rowsum;           /* taps_in_z only: rowsum[m] += alpha * sum_k A(m, tap 0, k)  (the bias gradient, blocks.py:52
+                              nn.Conv1d bias, riding on the weight gradient); float32 [M] or NULL */
 } jen1_gemm_args;
 
 int jen1_train_gemm(const jen1_gemm_args* args, void* stream);
@@ -68,7 +70,7 @@ int jen1_train_gemm(const jen1_gemm_args* args, void* stream);
 int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int ld, int groups, int dtype, void* stream);
 int jen1_gn_apply(const void* x, const float* sums, const float* gamma, const float* beta, const void* film, int film_ld,
                   void* y, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
-/* backward: P[B][C][4] and Gm[B][G][2] are float32 scratch (zeroed by the call); dgamma/dbeta are ACCUMULATED
+/* backward: P[B][C][4] and Gm[B][G][2] are float32 scratch (P is zeroed by the call); dgamma/dbeta are ACCUMULATED
  * (float32, the parameter's .grad); dfilm [B][2C] float32 is written (NULL when film is NULL). */
 int jen1_gn_backward(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,
                      int film_ld, void* dx, float* dgamma, float* dbeta, float* dfilm, float* P, float* Gm, int B, int L, int C,

@@ -26,6 +26,7 @@ struct GemmDev {
   Operand a, b;
   void* c;
   const float* bias;
+  float* rowsum;     // += sum_k A(m, tap 0, k) for every m (bias gradient riding on the weight gradient), or NULL
   long long ldc_m, ldc_n, c_tap_stride;
   long long a_zs0, a_zs1, b_zs0, b_zs1, c_zs0, c_zs1;
   int a_zdiv, b_zdiv, c_zdiv;
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient: the workgroups of the first N tile and tap 0 also sum their A rows over K
+  const bool do_rowsum = g.rowsum != nullptr && blockIdx.y == 0 && tap_z == 0;
+  float rsum = 0.f;
+
   Staged<T> sa, sb;
   auto fetch_step = [&](int s) {
     const int tap = g.taps_in_z ? tap_z : s / ksteps;
@@ -190,6 +195,10 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
     stash<T, PITCH>(sb, g.b, Bs, tid);
     __syncthreads();
     if (s + 1 < s_end) fetch_step(s + 1);
+    if (do_rowsum && tid < BM) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) rsum += (float)As[tid * PITCH + k];
+    }
     const int kq = (lane >> 4) * 8, rr = lane & 15;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -198,6 +207,8 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
         mma8(acc[mi][ni], As + (wm * 32 + mi * 16 + rr) * PITCH + kq, Bs + (wn * 32 + ni * 16 + rr) * PITCH + kq);
     __syncthreads();
   }
+
+  if (do_rowsum && tid < BM && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, g.alpha * rsum);
 
   // epilogue: acc[r] <-> (m = 4 * (lane / 16) + r, n = lane % 16) of the 16 x 16 tile
   char* cb = reinterpret_cast<char*>(g.c);
@@ -268,6 +279,8 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   g.a = to_dev(a.a, a.M);
   g.b = to_dev(a.b, a.N);
   g.c = a.c; g.bias = reinterpret_cast<const float*>(a.bias);
+  g.rowsum = reinterpret_cast<float*>(a.rowsum);
+  JEN1_CHECK(a.rowsum == nullptr || a.taps_in_z, "train_gemm: rowsum rides on the per-tap (weight gradient) form only");
   g.ldc_m = a.ldc_m; g.ldc_n = a.ldc_n; g.c_tap_stride = a.c_tap_stride;
   g.a_zs0 = a.a.zs0; g.a_zs1 = a.a.zs1; g.b_zs0 = a.b.zs0; g.b_zs1 = a.b.zs1; g.c_zs0 = a.c_zs0; g.c_zs1 = a.c_zs1;
   g.a_zdiv = a.a.zdiv; g.b_zdiv = a.b.zdiv; g.c_zdiv = a.c_zdiv;

@@ -129,22 +129,41 @@ __global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const GnDev g, int CT, 
   atomicAdd(P + 0, p0); atomicAdd(P + 1, p1); atomicAdd(P + 2, p2); atomicAdd(P + 3, p3);
 }
 
-// group means of d(xhat), parameter gradients, FiLM gradients: one thread per (b, c)
-__global__ __launch_bounds__(NT) void gn_bwd_finish_kernel(const GnDev g) {
-  const int i = blockIdx.x * NT + threadIdx.x;
-  if (i >= g.B * g.C) return;
-  const int b = i / g.C, c = i % g.C;
-  const float* P = g.P + (long long)i * 4;
-  const float ga = g.gamma[c];
-  float* gm = g.Gm + ((long long)b * g.groups + c / g.cpg) * 2;
-  atomicAdd(gm + 0, ga * P[0] * g.inv_count);
-  atomicAdd(gm + 1, ga * P[1] * g.inv_count);
-  atomicAdd(g.dgamma + c, P[1]);
-  atomicAdd(g.dbeta + c, P[0]);
-  if (g.dfilm != nullptr) {
-    g.dfilm[(long long)b * 2 * g.C + c] = P[2];
-    g.dfilm[(long long)b * 2 * g.C + g.C + c] = P[3];
+// group means of d(xhat), FiLM gradients, parameter gradients -- no atomics:
+//   blocks [0, B*G): one wave per (b, g) reduces its channels;  blocks [B*G, ..): one thread per channel sums over b
+__global__ __launch_bounds__(64) void gn_bwd_finish_kernel(const GnDev g) {
+  const int nbg = g.B * g.groups;
+  if ((int)blockIdx.x < nbg) {
+    const int b = blockIdx.x / g.groups, grp = blockIdx.x % g.groups;
+    float m1 = 0.f, m2 = 0.f;
+    for (int j = threadIdx.x; j < g.cpg; j += 64) {
+      const int c = grp * g.cpg + j;
+      const float* P = g.P + ((long long)b * g.C + c) * 4;
+      const float ga = g.gamma[c];
+      m1 += ga * P[0];
+      m2 += ga * P[1];
+      if (g.dfilm != nullptr) {
+        g.dfilm[(long long)b * 2 * g.C + c] = P[2];
+        g.dfilm[(long long)b * 2 * g.C + g.C + c] = P[3];
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+    if (threadIdx.x == 0) {
+      g.Gm[2 * (long long)blockIdx.x] = m1 * g.inv_count;
+      g.Gm[2 * (long long)blockIdx.x + 1] = m2 * g.inv_count;
+    }
+    return;
   }
+  const int c = (blockIdx.x - nbg) * 64 + threadIdx.x;
+  if (c >= g.C) return;
+  float dg = 0.f, db = 0.f;
+  for (int b = 0; b < g.B; ++b) {
+    const float* P = g.P + ((long long)b * g.C + c) * 4;
+    dg += P[1];
+    db += P[0];
+  }
+  g.dgamma[c] += dg;       // the only writer of this entry in this launch
+  g.dbeta[c] += db;
 }
 
 template <typename T>
@@ -404,11 +423,11 @@ extern "C" int jen1_gn_backward(const void* dy, const void* x, const float* sums
   JEN1_CHECK((film == nullptr) == (dfilm == nullptr), "jen1_gn_backward: dfilm must be given exactly when film is");
   g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = dfilm;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (zero2(P, 4 * B * C, Gm, 2 * B * groups, s)) return 1;
+  if (zero2(P, 4 * B * C, nullptr, 0, s)) return 1;
   int CT, rpb, gx, gy;
   red_geom(C, L, CT, rpb, gx, gy);
   DISPATCH(dtype, gn_bwd_sums_kernel, dim3(gx, gy, B), g, CT, rpb);
-  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((B * C + NT - 1) / NT), dim3(NT), 0, s, g);
+  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(B * groups + (C + 63) / 64), dim3(64), 0, s, g);
   JEN1_HIP(hipGetLastError());
   DISPATCH(dtype, gn_bwd_dx_kernel, dim3(ew_grid((long long)B * L * C)), g, dx);
   return 0;

@@ -87,7 +87,7 @@ class GemmArgs(C.Structure):
                 ("c_zs0", c_int64), ("c_zs1", c_int64), ("ldc_m", c_int64), ("ldc_n", c_int64), ("c_tap_stride", c_int64),
                 ("c_zdiv", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("taps", c_int), ("batches", c_int),
                 ("taps_in_z", c_int), ("splitk", c_int), ("atomic", c_int), ("accumulate", c_int), ("c_f32", c_int),
-                ("dtype", c_int), ("alpha", c_float), ("reserved", c_int)]
+                ("dtype", c_int), ("alpha", c_float), ("reserved", c_int), ("rowsum", c_void_p)]
 
 
 # every symbol include/jen1_hip.h and include/jen1_train.h declare: (name, restype, argtypes)

@@ -19,6 +19,7 @@ There is no fallback: without libjen1_hip.so / a ROCm device every entry point r
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -63,7 +64,8 @@ class TrainRuntime:
         self.dt = L.F32 if compute_dtype == "f32" else L.BF16
         self.tdtype = torch.float32 if compute_dtype == "f32" else torch.bfloat16
         self._packed: Dict[Tuple[int, str], torch.Tensor] = {}
-        self.target_wgs = 512
+        self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
+        self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
 
     # ------------------------------------------------------------------ plumbing
     def stream(self) -> int:
@@ -115,20 +117,21 @@ class TrainRuntime:
     def gemm(self, a: L.GemmOperand, b: L.GemmOperand, c_ptr: int, M: int, N: int, K: int, *, dtype: int, taps: int = 1,
              batches: int = 1, taps_in_z: bool = False, ldc_m: int, ldc_n: int = 1, c_tap_stride: int = 0, c_zs0: int = 0,
              c_zs1: int = 0, c_zdiv: int = 1, bias: Optional[torch.Tensor] = None, splitk: int = 1, atomic: bool = False,
-             accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0) -> None:
+             accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0, rowsum: Optional[torch.Tensor] = None) -> None:
         g = L.GemmArgs()
         g.a, g.b, g.c, g.bias = a, b, c_ptr, (None if bias is None else bias.data_ptr())
         g.c_zs0, g.c_zs1, g.ldc_m, g.ldc_n, g.c_tap_stride, g.c_zdiv = c_zs0, c_zs1, ldc_m, ldc_n, c_tap_stride, c_zdiv
         g.M, g.N, g.K, g.taps, g.batches = M, N, K, taps, batches
         g.taps_in_z, g.splitk, g.atomic, g.accumulate, g.c_f32, g.dtype = int(taps_in_z), splitk, int(atomic), int(accumulate), int(c_f32), dtype
         g.alpha = alpha
+        g.rowsum = None if rowsum is None else rowsum.data_ptr()
         L.check(self.lib.jen1_train_gemm(g, self.stream()), "jen1_train_gemm")
 
     def pick_splitk(self, M: int, N: int, ksteps: int, z: int = 1) -> int:
         tiles = ((M + 63) // 64) * ((N + 63) // 64) * z
         if tiles >= self.target_wgs // 2:
             return 1
-        s = min(max(1, self.target_wgs // tiles), max(1, ksteps // 4))
+        s = min(max(1, self.target_wgs // tiles), max(1, ksteps // self.min_steps))
         return max(1, min(s, 65535 // max(1, z)))
 
 
@@ -202,8 +205,9 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     return dx
 
 
-def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.Tensor, g: ConvGeom) -> None:
-    """gw (float32, reference layout) += the weight gradient"""
+def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.Tensor, g: ConvGeom, gb: Optional[torch.Tensor] = None) -> bool:
+    """gw (float32, reference layout) += the weight gradient.  ``gb`` (bias gradient) is accumulated by the same launch
+    when dy is the row operand (Conv1d / Linear); returns whether it was."""
     dt = rt.dt_of(x)
     ldx, ldy = x.shape[-1], dy.shape[-1]
     k = g.taps
@@ -220,8 +224,10 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
         b = _operand(x.data_ptr(), 1, ldx, m=g.fwd_map(2))
         M, N = g.co, g.ci
     sk = rt.pick_splitk(M, N, (K + 31) // 32, z=k)
+    fused_bias = gb is not None and g.kind != "convT"
     rt.gemm(a, b, gw.data_ptr(), M, N, K, dtype=dt, taps=k, taps_in_z=True, ldc_m=N * k, ldc_n=k, c_tap_stride=1,
-            splitk=sk, atomic=True, c_f32=True)
+            splitk=sk, atomic=True, c_f32=True, rowsum=gb if fused_bias else None)
+    return fused_bias
 
 
 class ConvFn(Function):
@@ -239,10 +245,10 @@ class ConvFn(Function):
         (x,) = ctx.saved_tensors
         rt, g = ctx.rt, ctx.g
         dy = dy.contiguous()
-        _conv_wgrad(rt, x, dy, rt.grad_of(ctx.weight), g)
-        if ctx.bias is not None:
+        gb = None if ctx.bias is None else rt.grad_of(ctx.bias)
+        if not _conv_wgrad(rt, x, dy, rt.grad_of(ctx.weight), g, gb) and ctx.bias is not None:
             ldy = dy.shape[-1]
-            L.check(rt.lib.jen1_colsum(dy.data_ptr(), rt.grad_of(ctx.bias).data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
+            L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
                     "jen1_colsum")
         dx = _conv_dgrad(rt, dy, ctx.wp, g).view(x.shape) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None
