@@ -163,6 +163,47 @@ def optimizer_step_bench(n_params, device, reps=5):
             "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 
+def train_step_bench(cfg, B, T, dtype, device, reps=5):
+    """BASELINE configs[3] on one GPU (SURVEY.md section 8 rows a14 / a16 / e): one micro-batch of the trainer --
+    ``training_loosses`` forward + backward of B clips through the CFG pair (2B rows, gdm.py:245-272, model.py:332-369)
+    on the HIP training path, replayed as a HIP graph -- and one clip + AdamW step.  Not the headline metric."""
+    from jen1_amd import synth
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    from jen1_amd.train import GraphedLossStep
+    model = UNetCFG1d(**cfg, compute_dtype=dtype, device=device)
+    model.train()
+    opt = FusedAdamW(model.parameters())
+    graph = model.train_graph(dtype)
+    graph.attach_optimizer(opt)
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device=device, cfg_dropout_proba=0.2,
+                           embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    x0 = dev(synth.latents(B, T, key="clip"), device)
+    cond = {k: dev(v, device) for k, v in synth.conditioning(B, T, "music_inpaint").items()}
+    t = torch.randint(0, 1000, (B,), device=device)
+    step = GraphedLossStep(graph, gd, scale=0.1)
+    opt.zero_grad()
+    step(x0, t, cond, False)
+    opt.step()
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    opt.zero_grad()
+    e[0].record()
+    for _ in range(reps):
+        loss = step(x0, t, cond, False)
+    e[1].record()
+    opt.step()
+    e[2].record()
+    torch.cuda.synchronize()
+    fb = e[0].elapsed_time(e[1]) / reps
+    return {"what": f"configs[3] per-GPU shape: forward + backward of {B} clips x 128x{T} through the CFG pair (2B rows), hipGraph replay",
+            "fwd_bwd_ms": round(fb, 2), "clips_per_s": round(B / fb * 1e3, 1), "optimizer_ms": round(e[1].elapsed_time(e[2]), 2),
+            "loss": round(float(loss), 4), "grad_allreduce_bytes": 4 * opt.numel,
+            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+
+
 def cpu_baseline(B, T, tiny):
     """The CPU oracle (numpy port of the reference path) on the host cores: bounded sample."""
     from jen1_amd import synth
@@ -256,6 +297,7 @@ def main():
                             "conv_ms_per_step": r2["conv_ms_per_step"]}
             if not args.tiny:
                 out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
+                out["extra"]["train_step"] = train_step_bench(cfg, B, T, args.dtype, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.tiny)
         print(json.dumps(out))

@@ -63,7 +63,9 @@ class TrainRuntime:
         assert compute_dtype in ("f32", "bf16")
         self.dt = L.F32 if compute_dtype == "f32" else L.BF16
         self.tdtype = torch.float32 if compute_dtype == "f32" else torch.bfloat16
-        self._packed: Dict[Tuple[int, str], torch.Tensor] = {}
+        self._packed: Dict[tuple, list] = {}          # (id, kind, dtype) -> [weakref, buffer, epoch of last refresh, kind]
+        self.epoch = 0
+        self._fresh_epoch = -1
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
 
@@ -72,8 +74,8 @@ class TrainRuntime:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def invalidate(self) -> None:
-        """forget the packed compute weights (call after every optimiser step / parameter load)"""
-        self._packed.clear()
+        """the parameters changed (optimiser step / load): every packed compute copy is stale"""
+        self.epoch += 1
 
     def dt_of(self, t: torch.Tensor) -> int:
         if t.dtype == torch.float32:
@@ -82,28 +84,51 @@ class TrainRuntime:
             return L.BF16
         raise L.Jen1HipError(f"unsupported activation dtype {t.dtype}")
 
+    @staticmethod
+    def _layout(w: torch.Tensor, kind: str) -> torch.Tensor:
+        d = w.detach()
+        if kind == "linear":
+            return d.unsqueeze(0)                          # [1][Co][Ci]
+        if kind == "conv":
+            return d.permute(2, 0, 1)                      # [k][Co][Ci]
+        return d.permute(2, 1, 0)                          # ConvTranspose1d [Ci][Co][k] -> [k][Co][Ci]
+
     def packed(self, w: torch.Tensor, kind: str, dtype: torch.dtype) -> torch.Tensor:
-        """compute copy [k][C_out][pad8(C_in)] of a Conv1d [Co, Ci, k] / ConvTranspose1d [Ci, Co, k] / Linear [Co, Ci] weight"""
+        """compute copy [k][C_out][pad8(C_in)] of a Conv1d [Co, Ci, k] / ConvTranspose1d [Ci, Co, k] / Linear [Co, Ci]
+        weight.  The buffer is allocated once and refreshed IN PLACE when the parameters moved, so a captured graph
+        keeps reading the same address (GraphedLossStep refreshes outside the graph, once per optimiser step)."""
         key = (id(w), kind, dtype)
         hit = self._packed.get(key)
-        p = hit[1] if hit is not None and hit[0]() is w else None      # id() of a dead parameter can be reused
-        if p is None:
+        if hit is not None and hit[0]() is not w:          # id() of a dead parameter can be reused
+            hit = None
+        if hit is None:
             with torch.no_grad():
-                d = w.detach()
-                if kind == "linear":
-                    d = d.unsqueeze(0)                         # [1][Co][Ci]
-                elif kind == "conv":
-                    d = d.permute(2, 0, 1)                     # [k][Co][Ci]
-                else:                                          # ConvTranspose1d
-                    d = d.permute(2, 1, 0)                     # [k][Co][Ci]
+                d = self._layout(w, kind)
                 k, co, ci = d.shape
                 if kind == "linear" and dtype == d.dtype and ci % 8 == 0:
-                    p = d                                      # float32 mode: the parameter itself is the compute copy
+                    hit = [weakref.ref(w), d, -1, kind]    # float32 mode: the parameter itself is the compute copy
                 else:
-                    p = torch.zeros((k, co, pad8(ci)), dtype=dtype, device=w.device)
-                    p[:, :, :ci].copy_(d)
-            self._packed[key] = (weakref.ref(w), p)
-        return p
+                    hit = [weakref.ref(w), torch.zeros((k, co, pad8(ci)), dtype=dtype, device=w.device), -2, kind]
+            self._packed[key] = hit
+        if hit[2] != self.epoch and hit[2] != -1:
+            self._refresh(hit, w)
+        return hit[1]
+
+    def _refresh(self, hit, w) -> None:
+        with torch.no_grad():
+            d = self._layout(w, hit[3])
+            hit[1][:, :, :d.shape[2]].copy_(d)
+        hit[2] = self.epoch
+
+    def refresh_all(self) -> None:
+        """bring every packed copy up to date now (outside any graph capture)"""
+        if self._fresh_epoch == self.epoch:
+            return
+        for hit in self._packed.values():
+            w = hit[0]()
+            if w is not None and hit[2] != self.epoch and hit[2] != -1:
+                self._refresh(hit, w)
+        self._fresh_epoch = self.epoch
 
     @staticmethod
     def grad_of(p: torch.Tensor) -> torch.Tensor:
@@ -739,7 +764,7 @@ class GraphedLossStep:
             else:
                 p.grad.copy_(k)
         del keep
-        self.graph.invalidate()            # the weight packing becomes part of the graph: replays follow the parameters
+        self.graph.rt.refresh_all()        # packed weights are refreshed OUTSIDE the graph (once per optimiser step)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss = self._body(static, causal)
@@ -761,5 +786,6 @@ class GraphedLossStep:
             static["mask"].copy_(conditioning["cross_attn_masks"])
         if static["concat"] is not None:
             static["concat"].copy_(conditioning["input_concat_cond"])
+        self.graph.rt.refresh_all()
         g.replay()
         return loss.clone()
