@@ -354,8 +354,34 @@ def gen_full():
     save("full_unet", **out)
 
 
+def gen_full_train():
+    """full configuration, one clip through the CFG pair: loss + every parameter's gradient from the reference's autograd"""
+    cfg = full_model_config()
+    model, spec = _build(cfg)
+    B, T_ = 1, 1500
+    betas, _ = get_beta_schedule("linear", 1000)
+    out = {"grad_names_all": np.array(json.dumps([n for n, _ in model.named_parameters()]))}
+    x0 = synth.latents(B, T_, key="clip")
+    cond = synth.conditioning(B, T_, "music_cont")
+    cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+    noise = fill_uniform("synth.trainnoise.full", (B, 128, T_), 3, 0.0, 1.0)
+    t = torch.tensor([417], dtype=torch.long)
+    gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective="noise", loss_type="l2", device="cpu",
+                           cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    with torch.enable_grad():
+        model.zero_grad(set_to_none=True)
+        model.train()
+        loss = gd.training_loosses(model, T(x0), t, cond_t, noise=T(noise), causal=True)
+        loss.backward()
+    out["loss"] = np.float32(loss.item())
+    out["gradnorm_all"] = np.array([p_.grad.norm().item() for _, p_ in model.named_parameters()], dtype=np.float32)
+    out["gradsample_all"] = np.concatenate(
+        [p_.grad.reshape(-1)[:: max(1, p_.numel() // 16)][:16].numpy() for _, p_ in model.named_parameters()]).astype(np.float32)
+    save("full_train", **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full"}
+    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fulltrain"}
     model = None
     if "schedule" in which:
         print("schedule"); gen_schedule()
@@ -369,3 +395,5 @@ if __name__ == "__main__":
         print("train"); gen_tiny_train(model)
     if "full" in which:
         print("full"); gen_full()
+    if "fulltrain" in which:
+        print("fulltrain"); gen_full_train()

@@ -469,3 +469,49 @@ def test_graphed_step_matches_eager_gradients():
         assert abs(float(lg) - float(le)) <= 1e-5 * abs(float(le)), (rnd, float(lg), float(le))
         assert float((gg - ge).abs().max()) <= 1e-4 * float(ge.abs().max()), rnd
         opt.step()      # parameters move; the next replay must re-pack
+
+
+def test_full_model_training_gradients_vs_reference_autograd_f32():
+    """BASELINE's full 296.5 M-parameter configuration, one clip x 128x1500 through the CFG pair, causal: loss and the
+    gradient of every one of the 979 tensors against the reference's own autograd (tests/golden/full_train.npz)."""
+    from jen1_amd.config import full_model_config
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.init_fill import fill_uniform
+    from jen1_amd.model import UNetCFG1d
+    g = golden("full_train")
+    names = json.loads(str(g["grad_names_all"]))
+    model = UNetCFG1d(**full_model_config(), compute_dtype="f32", device="cuda")
+    model.train()
+    B, T = 1, 1500
+    betas, _ = get_beta_schedule("linear", 1000)
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, "music_cont").items()}
+    noise = dev(fill_uniform("synth.trainnoise.full", (B, 128, T), 3, 0.0, 1.0))
+    t = torch.tensor([417], dtype=torch.long, device="cuda")
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    loss = gd.training_loosses(model, x0, t, cond, noise=noise, causal=True)       # picks model.train_graph() by itself
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float(g["loss"])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-3 * abs(ref_loss)
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    assert sorted(names) == sorted(grads.keys()) and len(names) == 979
+    ref_norm, ref_samp = g["gradnorm_all"], g["gradsample_all"]
+    gmax = float(ref_norm.max())
+    off, worst_n, worst_s = 0, 0.0, 0.0
+    for i, n in enumerate(names):
+        gr = grads[n]
+        assert gr is not None, f"no gradient for {n}"
+        samp = gr.reshape(-1)[:: max(1, gr.numel() // 16)][:16].cpu().numpy()
+        ref = ref_samp[off: off + samp.size]
+        off += samp.size
+        nrm = float(gr.norm())
+        en = abs(nrm - ref_norm[i]) / max(ref_norm[i], 1e-3 * gmax)
+        scale = max(float(np.abs(ref).max()), ref_norm[i] / np.sqrt(gr.numel()))
+        es = float(np.abs(samp - ref).max() / max(scale, 1e-12))
+        worst_n, worst_s = max(worst_n, en), max(worst_s, es)
+        assert en <= 1e-3, (n, nrm, ref_norm[i])
+        assert es <= 5e-3, (n, es)
+    assert off == ref_samp.size
+    print(f"full model: worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
