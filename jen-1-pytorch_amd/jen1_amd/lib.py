@@ -163,6 +163,9 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` from the repo root. "
             "There is no CPU / eager fallback for the denoiser path.")
+    # torch first: its bundled libamdhip64 must be the HIP runtime of the process.  Loading libjen1_hip.so before torch
+    # pulls in the system runtime instead, and two runtimes in one process fail with "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # raises AttributeError if the symbol is not exported
