@@ -183,8 +183,8 @@ class GaussianDiffusion(torch.nn.Module):
         out = st.x.clone()
         return out if not return_all_timesteps else torch.stack(audios, dim=1)
 
-    def stepper(self, model, shape, conditioning, causal=False, use_graph=True, n_streams=None) -> "DDIMStepper":
-        return DDIMStepper(self, model, shape, conditioning, causal, use_graph, n_streams)
+    def stepper(self, model, shape, conditioning, causal=False, use_graph=True, n_streams=None, plan_slot: int = 0) -> "DDIMStepper":
+        return DDIMStepper(self, model, shape, conditioning, causal, use_graph, n_streams, plan_slot)
 
     def _ddim_generic(self, model, shape, conditioning, return_all_timesteps, causal, init_data, init_noise, step_noises,
                       dropout_rows):
@@ -287,7 +287,7 @@ class DDIMStepper:
     parity-tested; ROCm 7.2 serialises them, so the default is 1)."""
 
     def __init__(self, gd: GaussianDiffusion, model: UNetCFG1d, shape, conditioning, causal=False, use_graph=True,
-                 n_streams: Optional[int] = None):
+                 n_streams: Optional[int] = None, plan_slot: int = 0):
         self.gd, self.model = gd, model
         B, C, T = shape
         self.shape = (B, C, T)
@@ -317,7 +317,8 @@ class DDIMStepper:
         for i, nb in enumerate(sizes):
             slot = used.get(nb, 0)
             used[nb] = slot + 1
-            plan = eng.plan(nb, T, self.nrep, bool(causal), slot=slot, n_t=S)
+            # plan_slot: independent samplers of the same shape that run concurrently (serving) own separate buffers
+            plan = eng.plan(nb, T, self.nrep, bool(causal), slot=slot + 1000 * plan_slot, n_t=S)
             sl = slice(b0, b0 + nb)
             emb = conditioning["cross_attn_cond"][sl]
             msk = None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"][sl]
