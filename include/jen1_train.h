@@ -92,6 +92,10 @@ int jen1_act_backward(const void* dy, const void* x, void* dx, int64_t n, int mo
 int jen1_softmax_forward(const float* s, void* p, int rows, int Nq, int Nk, int ld_s, int ld_p, int causal, int dtype, void* stream);
 int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, int Nk, int ld_s, int ld_p, int dtype, void* stream);
 
+/* dst[i] = (dtype) src[i]; src[i] = 0  for i < n (n a multiple of 4): hands the float32 accumulator of a split-K GEMM
+ * over in the compute dtype and leaves it zeroed for the next launch of the stream. */
+int jen1_convert_clear(float* src, void* dst, int64_t n, int dtype, void* stream);
+
 /* out[c] += sum_rows x[row][c]  (bias gradients), float32 accumulate */
 int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream);
 

@@ -361,6 +361,19 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const void* x_, float* __res
   atomicAdd(out + c, s);
 }
 
+// dst = (T) src, src = 0: hands a float32 split-K accumulator over in the compute dtype and leaves it zero for the
+// next GEMM of the stream (the accumulator is one persistent scratch buffer, so no fill launch is ever needed)
+template <typename T>
+__global__ __launch_bounds__(NT) void convert_clear_kernel(float* __restrict__ src, void* dst_, long long n4) {
+  T* dst = reinterpret_cast<T*>(dst_);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<float4*>(src)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float o[4] = {v.x, v.y, v.z, v.w};
+    store4(dst + 4 * i, o);
+  }
+}
+
 #define DISPATCH(dtype, KERNEL, grid, ...)                                                        \
   do {                                                                                            \
     if ((dtype) == JEN1_F32) hipLaunchKernelGGL(KERNEL<float>, grid, dim3(NT), 0, s, __VA_ARGS__); \
@@ -496,5 +509,13 @@ extern "C" int jen1_colsum(const void* x, float* out, int rows, int C, int ld, i
   int CT, rpb, gx, gy;
   red_geom(C, rows, CT, rpb, gx, gy);
   DISPATCH(dtype, colsum_kernel, dim3(gx, gy), x, out, rows, C, ld, CT, rpb);
+  return 0;
+}
+
+extern "C" int jen1_convert_clear(float* src, void* dst, int64_t n, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_convert_clear")) return 1;
+  JEN1_CHECK(src && dst && n >= 4 && (n & 3) == 0, "jen1_convert_clear: n must be a positive multiple of 4");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, convert_clear_kernel, dim3(ew_grid(n / 4)), src, dst, (long long)(n / 4));
   return 0;
 }

@@ -122,6 +122,7 @@ SYMBOLS = {
     "jen1_softmax_forward": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     "jen1_softmax_backward": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_colsum": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
+    "jen1_convert_clear": (c_int, [_P, _P, c_int64, c_int, _P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),

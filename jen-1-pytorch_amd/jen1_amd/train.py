@@ -66,6 +66,7 @@ class TrainRuntime:
         self._packed: Dict[tuple, list] = {}          # (id, kind, dtype) -> [weakref, buffer, epoch of last refresh, kind]
         self.epoch = 0
         self._fresh_epoch = -1
+        self._acc32: Optional[torch.Tensor] = None        # persistent float32 split-K accumulator, zero at rest
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
 
@@ -152,6 +153,19 @@ class TrainRuntime:
         g.rowsum = None if rowsum is None else rowsum.data_ptr()
         L.check(self.lib.jen1_train_gemm(g, self.stream()), "jen1_train_gemm")
 
+    def split_accumulator(self, n: int) -> torch.Tensor:
+        """the persistent zeroed float32 scratch every split-K forward / data-gradient GEMM of the stream accumulates
+        into; ``hand_over`` converts it into the output and zeroes it again in the same launch"""
+        if self._acc32 is None or self._acc32.numel() < n:
+            assert not torch.cuda.is_current_stream_capturing(), "the split-K accumulator must be sized before graph capture"
+            self._acc32 = torch.zeros(max(n, 1 << 23), dtype=torch.float32, device=self.device)
+        return self._acc32
+
+    def hand_over(self, acc: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        n = out.numel()
+        L.check(self.lib.jen1_convert_clear(acc.data_ptr(), out.data_ptr(), n, self.dt_of(out), self.stream()), "jen1_convert_clear")
+        return out
+
     def pick_splitk(self, M: int, N: int, ksteps: int, z: int = 1) -> int:
         tiles = ((M + 63) // 64) * ((N + 63) // 64) * z
         if tiles >= self.target_wgs // 2:
@@ -202,9 +216,9 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     sk = rt.pick_splitk(M, co, ksteps)
     alloc = torch.zeros if (ldy != co or sk > 1) else torch.empty
     if sk > 1:
-        y32 = torch.zeros((B, g.L_out, ldy), dtype=torch.float32, device=x.device)
-        rt.gemm(a, b, y32.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, splitk=sk, atomic=True, c_f32=True)
-        return y32 if x.dtype == torch.float32 else y32.to(x.dtype)
+        acc = rt.split_accumulator(B * g.L_out * ldy)
+        rt.gemm(a, b, acc.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, splitk=sk, atomic=True, c_f32=True)
+        return rt.hand_over(acc, torch.empty((B, g.L_out, ldy), dtype=x.dtype, device=x.device))
     y = alloc((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
     rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias)
     return y
@@ -222,9 +236,9 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     ksteps = k * ((co + 31) // 32)
     sk = rt.pick_splitk(M, cip, ksteps)
     if sk > 1:
-        dx32 = torch.zeros((B, g.L_in, cip), dtype=torch.float32, device=dy.device)
-        rt.gemm(a, b, dx32.data_ptr(), M, cip, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True)
-        return dx32 if dy.dtype == torch.float32 else dx32.to(dy.dtype)
+        acc = rt.split_accumulator(B * g.L_in * cip)
+        rt.gemm(a, b, acc.data_ptr(), M, cip, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True)
+        return rt.hand_over(acc, torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device))
     dx = torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
     rt.gemm(a, b, dx.data_ptr(), M, cip, co, dtype=dt, taps=k, ldc_m=cip)
     return dx
