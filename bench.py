@@ -326,6 +326,12 @@ def main():
                 out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
                 out["extra"]["train_step"] = train_step_bench(cfg, B, T, args.dtype, device)
                 if not args.no_graph:
+                    # BASELINE configs[4] shape (long-form continuation / inpaint, T ~ 9000), bf16, no fp8 path yet
+                    st5 = build_stepper(model, 1, 9000, device, cfg_pair=True, use_graph=True)
+                    n5 = max(10, args.steps // 5)
+                    dt5 = timed_steps(st5, n5, 3, lambda: None)
+                    out["extra"]["configs[4] long-form B=1 T=9000 CFG pair, steps/s"] = round(n5 / dt5, 2)
+                    del st5
                     out["extra"]["concurrent_batches"] = [concurrent_batches_bench(model, B, T, device, n, max(20, args.steps // 2), 5)
                                                           for n in (2, 4)]
         if world == 1 and not args.no_cpu_baseline:

@@ -85,6 +85,7 @@ def test_training_ops_validate_arguments_without_a_gpu(lib):
     assert lib.jen1_act_forward(16, 16, 8, 7, L.F32, None) != 0
     assert lib.jen1_softmax_forward(16, 16, 7, 2, 4, 4, 4, 0, L.F32, None) != 0     # rows not a multiple of Nq
     assert lib.jen1_colsum(None, None, 1, 1, 1, L.F32, None) != 0
+    assert lib.jen1_convert_clear(16, 16, 6, L.F32, None) != 0 and b"multiple of 4" in lib.jen1_last_error()
 
 
 def test_argument_validation_reports_errors_without_a_gpu(lib):

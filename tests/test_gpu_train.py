@@ -264,6 +264,20 @@ def test_attention_core_forward_backward(rts, mode, B, Nq, Nk, C, heads, causal,
     assert rel_err(kvd.grad.float().cpu().numpy(), kv.grad.numpy()) < tol
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_convert_clear_hands_over_and_zeroes(rts, mode):
+    """jen1_convert_clear: the float32 split-K accumulator becomes the output (compute dtype) and is zero again"""
+    from jen1_amd import lib as L
+    rt = rts[mode]
+    src = torch.randn(4096 + 8, device="cuda")
+    want = src[:4096].to(rt.tdtype).clone()
+    dst = torch.empty(4096, dtype=rt.tdtype, device="cuda")
+    L.check(rt.lib.jen1_convert_clear(src.data_ptr(), dst.data_ptr(), 4096, rt.dt, rt.stream()), "jen1_convert_clear")
+    torch.cuda.synchronize()
+    assert torch.equal(dst, want)
+    assert float(src[:4096].abs().max()) == 0.0 and float(src[4096:].abs().min()) > 0.0      # only n entries are touched
+
+
 # ------------------------------------------------------------------ whole model against the reference's autograd
 @pytest.fixture(scope="module")
 def tiny_model():
