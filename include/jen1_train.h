@@ -37,6 +37,9 @@ typedef struct jen1_gemm_operand {
   int32_t zdiv;
   int32_t map_axis;
   int32_t map_L, map_Lsrc, map_mul, map_tapmul, map_shift, map_div;
+  int32_t map_reflect;     /* 1: out-of-range s is mirrored (s < 0 -> -s, s >= Lsrc -> 2 (Lsrc - 1) - s) instead of reading 0:
+                              F.pad(mode="reflect") of the SEANet convolutions (encodec 0.1.1 modules/conv.py pad1d) */
+  int32_t reserved;
 } jen1_gemm_operand;
 
 /*
@@ -82,7 +85,8 @@ int jen1_ln_forward(const void* x, const float* gamma, const float* beta, void* 
 int jen1_ln_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* dgamma,
                      float* dbeta, int rows, int C, int ld, int dtype, void* stream);
 
-/* --- pointwise activations: mode 0 GELU(erf) (blocks.py:443, model.py:77-89), 1 SiLU (blocks.py:158) --- */
+/* --- pointwise activations: mode 0 GELU(erf) (blocks.py:443, model.py:77-89), 1 SiLU (blocks.py:158),
+ *     2 ELU(alpha = 1) (the SEANet decoder behind generation.py:130) --- */
 int jen1_act_forward(const void* x, void* y, int64_t n, int mode, int dtype, void* stream);
 int jen1_act_backward(const void* dy, const void* x, void* dx, int64_t n, int mode, int dtype, void* stream);
 
@@ -95,6 +99,16 @@ int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, in
 /* dst[i] = (dtype) src[i]; src[i] = 0  for i < n (n a multiple of 4): hands the float32 accumulator of a split-K GEMM
  * over in the compute dtype and leaves it zeroed for the next launch of the stream. */
 int jen1_convert_clear(float* src, void* dst, int64_t n, int dtype, void* stream);
+
+/* --- Encodec pieces either side of the sampler (generation.py:113, :130, :145-150) ---
+ * jen1_rvq_decode: ResidualVectorQuantizer.decode -- out[b][d][t] = sum_q tables[q][codes[q][b][t]][d]
+ *   codes int64 [n_q][B][T], tables float32 [n_q][bins][D], out float32 [B][D][T] (the reference's latent layout).
+ * jen1_lstm_layer: one nn.LSTM layer (gate order i, f, g, o) over T steps for B sequences, as SLSTM uses it:
+ *   gin float32 [B][T][4H] = x W_ih^T + b_ih + b_hh (a jen1_train_gemm), whh_t [H][4H] = W_hh^T in `dtype`,
+ *   y (dtype) [B][T][ld_y] = h_t (+ skip[b][t][j] when skip != NULL: SLSTM's residual), zero initial state. */
+int jen1_rvq_decode(const int64_t* codes, const float* tables, float* out, int n_q, int B, int T, int bins, int D, void* stream);
+int jen1_lstm_layer(const float* gin, const void* whh_t, const void* skip, void* y, int B, int T, int H, int ld_y, int dtype,
+                    void* stream);
 
 /* out[c] += sum_rows x[row][c]  (bias gradients), float32 accumulate */
 int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream);

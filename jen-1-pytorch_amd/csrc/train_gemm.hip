@@ -18,7 +18,7 @@ constexpr int BM = 64, BN = 64, BK = 32, NT = 256;
 struct Operand {
   const void* p;
   long long ld_r, ld_k, tap_stride;
-  int map_axis, map_L, map_Lsrc, map_mul, map_tapmul, map_shift, map_div;
+  int map_axis, map_L, map_Lsrc, map_mul, map_tapmul, map_shift, map_div, map_reflect;
   int rows;   // number of valid rows (M or N)
 };
 
@@ -42,6 +42,10 @@ template <> struct Vec<float> { static constexpr int N = 4; typedef f32x4 type; 
 __device__ __forceinline__ long long map_index(const Operand& o, int i, int tap) {
   const int b = i / o.map_L, t = i - b * o.map_L;
   int s = t * o.map_mul + tap * o.map_tapmul + o.map_shift;
+  if (o.map_reflect) {                       // F.pad(mode="reflect"): ... 2 1 | 0 1 2 ... L-1 | L-2 L-3 ...
+    if (s < 0) s = -s;
+    if (s >= o.map_Lsrc) s = 2 * (o.map_Lsrc - 1) - s;
+  }
   if (s < 0) return -1;
   if (o.map_div > 1) {
     const int q = s / o.map_div;
@@ -254,7 +258,7 @@ Operand to_dev(const jen1_gemm_operand& o, int rows) {
   Operand d;
   d.p = o.p; d.ld_r = o.ld_r; d.ld_k = o.ld_k; d.tap_stride = o.tap_stride;
   d.map_axis = o.map_axis; d.map_L = o.map_L; d.map_Lsrc = o.map_Lsrc; d.map_mul = o.map_mul;
-  d.map_tapmul = o.map_tapmul; d.map_shift = o.map_shift; d.map_div = o.map_div; d.rows = rows;
+  d.map_tapmul = o.map_tapmul; d.map_shift = o.map_shift; d.map_div = o.map_div; d.map_reflect = o.map_reflect ? 1 : 0; d.rows = rows;
   return d;
 }
 

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void act_fwd_kernel(const void* x_, void* y_, l
   T* y = reinterpret_cast<T*>(y_);
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
     const float v = (float)x[i];
-    y[i] = (T)(mode == 0 ? gelu_erf(v) : silu_precise(v));
+    y[i] = (T)(mode == 0 ? gelu_erf(v) : mode == 1 ? silu_precise(v) : (v > 0.f ? v : expm1f(v)));
   }
 }
 template <typename T>
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT) void act_bwd_kernel(const void* dy_, const void
   T* dx = reinterpret_cast<T*>(dx_);
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
     const float v = (float)x[i];
-    dx[i] = (T)((float)dy[i] * (mode == 0 ? gelu_grad(v) : silu_grad(v)));
+    dx[i] = (T)((float)dy[i] * (mode == 0 ? gelu_grad(v) : mode == 1 ? silu_grad(v) : (v > 0.f ? 1.f : expf(v))));
   }
 }
 
@@ -470,7 +470,7 @@ extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stat
 
 extern "C" int jen1_act_forward(const void* x, void* y, int64_t n, int mode, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_act_forward")) return 1;
-  JEN1_CHECK(x && y && n >= 1 && (mode == 0 || mode == 1), "jen1_act_forward: bad argument");
+  JEN1_CHECK(x && y && n >= 1 && mode >= 0 && mode <= 2, "jen1_act_forward: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DISPATCH(dtype, act_fwd_kernel, dim3(ew_grid(n)), x, y, (long long)n, mode);
   return 0;
@@ -478,7 +478,7 @@ extern "C" int jen1_act_forward(const void* x, void* y, int64_t n, int mode, int
 
 extern "C" int jen1_act_backward(const void* dy, const void* x, void* dx, int64_t n, int mode, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_act_backward")) return 1;
-  JEN1_CHECK(dy && x && dx && n >= 1 && (mode == 0 || mode == 1), "jen1_act_backward: bad argument");
+  JEN1_CHECK(dy && x && dx && n >= 1 && mode >= 0 && mode <= 2, "jen1_act_backward: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DISPATCH(dtype, act_bwd_kernel, dim3(ew_grid(n)), dy, x, dx, (long long)n, mode);
   return 0;

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # 
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip", "optimizer.hip",
-           "train_gemm.hip", "train_ops.hip"]
+           "train_gemm.hip", "train_ops.hip", "encodec.hip"]
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -78,7 +78,8 @@ class GemmOperand(C.Structure):
     """mirror of ``jen1_gemm_operand`` (include/jen1_train.h)."""
     _fields_ = [("p", c_void_p), ("zs0", c_int64), ("zs1", c_int64), ("ld_r", c_int64), ("ld_k", c_int64),
                 ("tap_stride", c_int64), ("zdiv", c_int), ("map_axis", c_int), ("map_L", c_int), ("map_Lsrc", c_int),
-                ("map_mul", c_int), ("map_tapmul", c_int), ("map_shift", c_int), ("map_div", c_int)]
+                ("map_mul", c_int), ("map_tapmul", c_int), ("map_shift", c_int), ("map_div", c_int),
+                ("map_reflect", c_int), ("reserved", c_int)]
 
 
 class GemmArgs(C.Structure):
@@ -123,6 +124,8 @@ SYMBOLS = {
     "jen1_softmax_backward": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_colsum": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_convert_clear": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "jen1_rvq_decode": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
+    "jen1_lstm_layer": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),

@@ -37,8 +37,8 @@ def pad8(c: int) -> int:
 class Map:
     """index map of ``jen1_gemm_operand`` (include/jen1_train.h)"""
 
-    def __init__(self, axis: int, L_idx: int, L_src: int, mul: int = 1, tapmul: int = 0, shift: int = 0, div: int = 1):
-        self.axis, self.L, self.Lsrc, self.mul, self.tapmul, self.shift, self.div = axis, L_idx, L_src, mul, tapmul, shift, div
+    def __init__(self, axis: int, L_idx: int, L_src: int, mul: int = 1, tapmul: int = 0, shift: int = 0, div: int = 1, reflect: bool = False):
+        self.axis, self.L, self.Lsrc, self.mul, self.tapmul, self.shift, self.div, self.reflect = axis, L_idx, L_src, mul, tapmul, shift, div, reflect
 
 
 def _operand(ptr: int, ld_r: int, ld_k: int, tap_stride: int = 0, zs0: int = 0, zs1: int = 0, zdiv: int = 1,
@@ -49,6 +49,7 @@ def _operand(ptr: int, ld_r: int, ld_k: int, tap_stride: int = 0, zs0: int = 0, 
         o.map_axis, o.map_L, o.map_Lsrc, o.map_mul, o.map_tapmul, o.map_shift, o.map_div = 0, 1, 1, 1, 0, 0, 1
     else:
         o.map_axis, o.map_L, o.map_Lsrc, o.map_mul, o.map_tapmul, o.map_shift, o.map_div = m.axis, m.L, m.Lsrc, m.mul, m.tapmul, m.shift, m.div
+        o.map_reflect = int(m.reflect)
     return o
 
 
@@ -180,15 +181,16 @@ class TrainRuntime:
 class ConvGeom:
     """static description of one convolution call"""
 
-    def __init__(self, kind: str, taps: int, stride: int, pad: int, L_in: int, L_out: int, ci: int, co: int):
+    def __init__(self, kind: str, taps: int, stride: int, pad: int, L_in: int, L_out: int, ci: int, co: int, reflect: bool = False):
         self.kind, self.taps, self.stride, self.pad, self.L_in, self.L_out, self.ci, self.co = kind, taps, stride, pad, L_in, L_out, ci, co
+        self.reflect = reflect        # forward only: F.pad(mode="reflect") instead of zeros (SEANet convolutions)
 
     def fwd_map(self, axis: int) -> Optional[Map]:
         """activation index (b, t_out) [+ tap] -> input row"""
         if self.kind == "linear":
             return None
         if self.kind == "conv":
-            return Map(axis, self.L_out, self.L_in, mul=self.stride, tapmul=1, shift=-self.pad)
+            return Map(axis, self.L_out, self.L_in, mul=self.stride, tapmul=1, shift=-self.pad, reflect=self.reflect)
         return Map(axis, self.L_out, self.L_in, mul=1, tapmul=-1, shift=self.pad, div=self.stride)
 
     def bwd_map(self, axis: int) -> Optional[Map]:

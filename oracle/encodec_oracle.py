@@ -1,0 +1,97 @@
+"""CPU restatement (numpy) of the Encodec pieces generation.py touches -- TEST INFRASTRUCTURE ONLY.
+
+Nothing under jen-1-pytorch_amd/ may import this module; it is the checker of tests/ and never the thing measured or
+shipped.
+
+The algorithm lives in a third-party dependency that is absent from /root/reference: ``encodec==0.1.1``
+(requirements.txt:5), used at generation.py:34 (``EncodecModel.encodec_model_48khz()``), :130 (``.decoder``) and
+:145-150 (``.quantizer.decode``).  This file restates its published algorithm for the 48 kHz model:
+  * ``quantization/core_vq.py`` ResidualVectorQuantization.decode: sum of embedding look-ups;
+  * ``modules/seanet.py`` SEANetDecoder + ``modules/conv.py`` SConv1d / SConvTranspose1d (norm "time_group_norm" =
+    GroupNorm(1) right after the convolution, reflect padding split right-first, transposed convs trimmed AFTER the norm)
+    + ``modules/lstm.py`` SLSTM (2-layer LSTM + skip).
+PARITY PIN: tests/golden/encodec.npz, produced by tests/golden/make_golden.py from the Hugging Face port of the same
+architecture (``transformers.EncodecModel``, which is installed offline) with synthetic weights from
+``jen1_amd.init_fill``.  Parity against the ``encodec`` package itself and its released checkpoint is UNPINNED: neither
+is available in this environment.
+"""
+from typing import Dict, Sequence
+
+import numpy as np
+
+from oracle.jen1_oracle import _conv1d_valid, conv_transpose1d, group_norm
+
+Array = np.ndarray
+
+
+def rvq_decode(codes: Array, tables: Array) -> Array:
+    """codes int [n_q, B, T], tables [n_q, bins, D] -> [B, D, T]"""
+    out = np.zeros((codes.shape[1], codes.shape[2], tables.shape[2]), dtype=np.float32)
+    for q in range(codes.shape[0]):
+        out = out + tables[q][codes[q]]
+    return out.transpose(0, 2, 1)
+
+
+def elu(x: Array) -> Array:
+    return np.where(x > 0, x, np.expm1(np.minimum(x, 0))).astype(x.dtype)
+
+
+def sconv1d(x: Array, p: Dict[str, Array], name: str) -> Array:
+    w, b = p[f"{name}.conv.weight"], p[f"{name}.conv.bias"]
+    total = w.shape[2] - 1
+    right = total // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (total - right, right)), mode="reflect")
+    y = _conv1d_valid(xp, w, b, 1)
+    return group_norm(y, 1, p[f"{name}.norm.weight"], p[f"{name}.norm.bias"], 1e-5)
+
+
+def sconv_transpose1d(x: Array, p: Dict[str, Array], name: str, stride: int) -> Array:
+    w, b = p[f"{name}.conv.weight"], p[f"{name}.conv.bias"]
+    y = conv_transpose1d(x, w, b, stride, 0, 0)
+    y = group_norm(y, 1, p[f"{name}.norm.weight"], p[f"{name}.norm.bias"], 1e-5)
+    total = w.shape[2] - stride
+    right = total // 2
+    return y[..., total - right: y.shape[-1] - right]
+
+
+def slstm(x: Array, p: Dict[str, Array], name: str, layers: int) -> Array:
+    """x [B, C, T]; torch.nn.LSTM gate order i, f, g, o; zero initial state; + skip"""
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))      # noqa: E731
+    seq = x.transpose(2, 0, 1).astype(np.float32)            # [T, B, C]
+    inp = seq
+    for l in range(layers):
+        wih, whh = p[f"{name}.lstm.weight_ih_l{l}"], p[f"{name}.lstm.weight_hh_l{l}"]
+        bias = p[f"{name}.lstm.bias_ih_l{l}"] + p[f"{name}.lstm.bias_hh_l{l}"]
+        H = whh.shape[1]
+        h = np.zeros((inp.shape[1], H), dtype=np.float32)
+        c = np.zeros_like(h)
+        out = np.empty((inp.shape[0], inp.shape[1], H), dtype=np.float32)
+        for t in range(inp.shape[0]):
+            g = inp[t] @ wih.T + h @ whh.T + bias
+            i, f, gg, o = sig(g[:, :H]), sig(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), sig(g[:, 3 * H:])
+            c = f * c + i * gg
+            h = o * np.tanh(c)
+            out[t] = h
+        inp = out
+    return (inp + seq).transpose(1, 2, 0)
+
+
+def seanet_decoder(p: Dict[str, Array], emb: Array, ratios: Sequence[int] = (8, 5, 4, 2), lstm_layers: int = 2,
+                   n_residual_layers: int = 1, taps: Dict[str, Array] = None) -> Array:
+    """SEANetDecoder.forward with the 48 kHz settings; ``p`` in the key names of the Hugging Face port"""
+    h = sconv1d(emb.astype(np.float32), p, "layers.0")
+    if taps is not None:
+        taps["conv0"] = h
+    h = slstm(h, p, "layers.1", lstm_layers)
+    if taps is not None:
+        taps["lstm"] = h
+    idx = 2
+    for r in ratios:
+        h = sconv_transpose1d(elu(h), p, f"layers.{idx + 1}", r)
+        for j in range(n_residual_layers):
+            n = f"layers.{idx + 2 + j}"
+            y = sconv1d(elu(h), p, f"{n}.block.1")
+            y = sconv1d(elu(y), p, f"{n}.block.3")
+            h = sconv1d(h, p, f"{n}.shortcut") + y
+        idx += 2 + n_residual_layers
+    return sconv1d(elu(h), p, f"layers.{idx + 1}")

@@ -380,8 +380,48 @@ def gen_full_train():
     save("full_train", **out)
 
 
+def encodec_decoder_shapes():
+    """(key, shape) of transformers' EncodecDecoder for the 48 kHz configuration (the names jen1_amd/encodec.py reads)"""
+    from transformers import EncodecConfig, EncodecModel
+    cfg = EncodecConfig(sampling_rate=48000, audio_channels=2, normalize=True, chunk_length_s=1.0, overlap=0.01,
+                        use_causal_conv=False, norm_type="time_group_norm", upsampling_ratios=[8, 5, 4, 2],
+                        target_bandwidths=[3.0, 6.0, 12.0, 24.0])
+    return EncodecModel(cfg), cfg
+
+
+def gen_encodec():
+    """SEANet decoder + RVQ decode of the Hugging Face port of Encodec 48 kHz (architecture oracle; the ``encodec``
+    package the reference imports is not installed), synthetic weights by key name."""
+    model, cfg = encodec_decoder_shapes()
+    dec = model.decoder
+    sd = dec.state_dict()
+    dec.load_state_dict({k: T(fill("encodec.decoder." + k, tuple(v.shape), SEED)) for k, v in sd.items()})
+    dec.eval()
+    out = {"schema": np.array(json.dumps([(k, list(v.shape)) for k, v in sd.items()]))}
+    emb = fill_normal("encodec.emb", (2, 128, 37), 5)
+    taps = {}
+    dec.layers[0].register_forward_hook(lambda m, i, o: taps.__setitem__("conv0", o.numpy().copy()))
+    dec.layers[1].register_forward_hook(lambda m, i, o: taps.__setitem__("lstm", o.numpy().copy()))
+    y = dec(T(emb)).numpy()
+    assert y.shape == (2, 2, 37 * 320), y.shape
+    out["decoder.y"] = y
+    out["decoder.tap.conv0"] = taps["conv0"][:, ::8, :]
+    out["decoder.tap.lstm"] = taps["lstm"][:, ::8, :]
+    # quantizer.decode: 16 codebooks of 1024 x 128
+    q = model.quantizer
+    nq = len(q.layers)
+    for i, layer in enumerate(q.layers):
+        layer.codebook.embed.copy_(T(fill_normal(f"encodec.quantizer.layers.{i}.codebook.embed", (1024, 128), SEED)))
+    g = np.random.Generator(np.random.Philox(key=[77, 0x6A656E31]))
+    codes = g.integers(0, 1024, size=(nq, 2, 53), dtype=np.int64)
+    out["rvq.codes"] = codes
+    out["rvq.y"] = q.decode(T(codes)).numpy()
+    out["rvq.n_q"] = np.int64(nq)
+    save("encodec", **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fulltrain"}
+    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fulltrain", "encodec"}
     model = None
     if "schedule" in which:
         print("schedule"); gen_schedule()
@@ -397,3 +437,5 @@ if __name__ == "__main__":
         print("full"); gen_full()
     if "fulltrain" in which:
         print("fulltrain"); gen_full_train()
+    if "encodec" in which:
+        print("encodec"); gen_encodec()
