@@ -15,7 +15,7 @@ layers, ELU, non-causal, reflect padding, norm "time_group_norm", true skip off)
 convolution -> GroupNorm(1 group) [-> trim for the transposed ones, AFTER the norm], as in ``modules/conv.py``.
 Convolutions run on jen1_train_gemm (the reflect padding is an index map, no padded copy), GroupNorm / ELU on the
 train_ops kernels, the LSTM on jen1_lstm_layer.  Parameters are taken under the key names of the Hugging Face port
-(``transformers.EncodecModel``: ``layers.N.conv.weight`` ...), which is the architecture oracle available offline:
+(``transformers.EncodecModel``: ``layers.N.conv.weight`` ...), which is the implementation of that architecture available offline:
 PARITY IS PINNED AGAINST THAT PORT WITH SYNTHETIC WEIGHTS (tests/golden/encodec.npz); the real checkpoint and the
 ``encodec`` package itself are not available here, so parity against them is unpinned.
 """
