@@ -231,6 +231,25 @@ def train_step_bench(cfg, B, T, dtype, device, reps=5):
             "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
+def encodec_decode_bench(B, T, dtype, device):
+    """SURVEY.md section 8 f1, the step after the sampler (generation.py:130): SEANet decoder of Encodec 48 kHz on the HIP
+    kernels, B latents 128xT -> B x 2 x 320 T samples, synthetic weights (the checkpoint is not available offline)."""
+    from jen1_amd.encodec import SEANetDecoderHIP
+    from jen1_amd.init_fill import fill
+    import json as _json
+    sch = _json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "encodec.npz"))["schema"]))
+    dec = SEANetDecoderHIP({k: torch.from_numpy(fill("encodec.decoder." + k, tuple(sh), 1234)) for k, sh in sch}, compute_dtype=dtype, device=device)
+    emb = torch.randn((B, 128, T), device=device)
+    dec(emb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y = dec(emb)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"what": f"SEANet decoder, {B} x 128x{T} latents -> {tuple(y.shape)} samples", "ms": round(dt * 1e3, 1),
+            "audio_seconds_per_second": round(B * y.shape[-1] / 48000 / dt, 1)}
+
+
 def cpu_baseline(B, T, tiny):
     """The CPU oracle (numpy port of the reference path) on the host cores: bounded sample."""
     from jen1_amd import synth
@@ -325,6 +344,7 @@ def main():
             if not args.tiny:
                 out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
                 out["extra"]["train_step"] = train_step_bench(cfg, B, T, args.dtype, device)
+                out["extra"]["encodec_decode"] = encodec_decode_bench(B, T, args.dtype, device)
                 if not args.no_graph:
                     # BASELINE configs[4] shape (long-form continuation / inpaint, T ~ 9000), bf16, no fp8 path yet
                     st5 = build_stepper(model, 1, 9000, device, cfg_pair=True, use_graph=True)
