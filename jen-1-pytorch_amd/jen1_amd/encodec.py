@@ -6,8 +6,9 @@ not vendored, weights not available offline):
     works on  ->  ``ResidualVectorQuantizerHIP.decode`` (jen1_rvq_decode);
   * ``audio_encoder.decoder(sample_embs)``     (generation.py:130): latents ``[B, 128, T]`` -> stereo audio
     ``[B, 2, 320 T]`` through the SEANet decoder  ->  ``SEANetDecoderHIP``.
-The encoder half (``.encode``: SEANet encoder + nearest-codebook search) is not built yet; ``EncodecHIP.encode`` delegates to
-an encoder the caller supplies or raises.
+  * ``audio_encoder.encode(audio)``            (generation.py:146; dataloader.py:106-114): 1 s segments, RMS normalisation,
+    SEANet encoder, nearest-codebook search  ->  ``EncodecHIP.encode`` (``SEANetEncoderHIP``,
+    ``ResidualVectorQuantizerHIP.encode``).
 
 The decoder restates encodec 0.1.1 ``modules/seanet.py::SEANetDecoder`` with the 48 kHz settings (dimension 128,
 n_filters 32, ratios [8, 5, 4, 2], kernel 7, last kernel 7, residual kernel 3, 1 residual layer, compress 2, 2 LSTM
@@ -39,6 +40,7 @@ class ResidualVectorQuantizerHIP:
         self.lib = L.load()
         self.tables = tables.to(device, torch.float32).contiguous()
         self.device = torch.device(device)
+        self._rt = None
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda") -> "ResidualVectorQuantizerHIP":
@@ -47,6 +49,31 @@ class ResidualVectorQuantizerHIP:
             n += 1
         assert n > 0, "no layers.N.codebook.embed entries"
         return cls(torch.stack([sd[f"layers.{q}.codebook.embed"] for q in range(n)]), device)
+
+    @torch.no_grad()
+    def encode(self, emb: torch.Tensor, n_q: Optional[int] = None) -> torch.Tensor:
+        """ResidualVectorQuantization.encode (core_vq.py): per codebook the nearest entry of the running residual.
+        emb float32 [B, 128, T] -> codes int64 [n_q, B, T].  The distance search -(|x|^2 - 2 x.E + |E|^2) is one float32
+        GEMM per codebook (2 x.E with -|E|^2 as its bias; |x|^2 does not change the argmax)."""
+        from .train import TrainRuntime, _operand
+        if self._rt is None:
+            self._rt = TrainRuntime("f32", self.device)
+            self._neg_sq = (-(self.tables ** 2).sum(-1)).contiguous()          # [n_q][bins]
+        rt = self._rt
+        src = emb.device
+        B, D, T = emb.shape
+        nq = self.tables.shape[0] if n_q is None else n_q
+        bins = self.tables.shape[1]
+        res = emb.to(self.device, torch.float32).transpose(1, 2).reshape(B * T, D).contiguous()
+        scores = torch.empty((B * T, bins), dtype=torch.float32, device=self.device)
+        out = []
+        for q in range(nq):
+            rt.gemm(_operand(res.data_ptr(), D, 1), _operand(self.tables[q].data_ptr(), D, 1), scores.data_ptr(), B * T, bins, D,
+                    dtype=L.F32, ldc_m=bins, bias=self._neg_sq[q], alpha=2.0)
+            idx = scores.argmax(dim=-1)
+            res = res - self.tables[q][idx]
+            out.append(idx.view(B, T))
+        return torch.stack(out).to(src)
 
     @torch.no_grad()
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
@@ -62,34 +89,30 @@ class ResidualVectorQuantizerHIP:
         return out.to(src)
 
 
-class SEANetDecoderHIP:
-    def __init__(self, params: Dict[str, torch.Tensor], ratios: Sequence[int] = (8, 5, 4, 2), n_residual_layers: int = 1,
-                 compute_dtype: str = "bf16", device="cuda"):
+class _SEANetOps:
+    """the building blocks both halves of the SEANet share (encodec modules/conv.py, modules/lstm.py, modules/seanet.py)"""
+
+    def __init__(self, params: Dict[str, torch.Tensor], lstm_name: str, compute_dtype: str, device):
         self.rt = TrainRuntime(compute_dtype, device)
         self.device = self.rt.device
         self.p = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in params.items()}
-        self.ratios, self.n_res = list(ratios), n_residual_layers
         assert "layers.0.norm.weight" in self.p, "only the 48 kHz model's norm='time_group_norm' is built (no weight_norm)"
-        assert "layers.1.lstm.weight_ih_l0" in self.p, "layers.1 must be the LSTM"
+        assert f"{lstm_name}.lstm.weight_ih_l0" in self.p, f"{lstm_name} must be the LSTM"
+        self.lstm_name = lstm_name
         self.n_lstm = 0
-        while f"layers.1.lstm.weight_ih_l{self.n_lstm}" in self.p:
+        while f"{lstm_name}.lstm.weight_ih_l{self.n_lstm}" in self.p:
             self.n_lstm += 1
         dt = self.rt.tdtype
         # LSTM operands: W_ih as a linear weight (packed by the runtime), W_hh transposed [H][4H], the two biases summed
-        self.whh_t = [self.p[f"layers.1.lstm.weight_hh_l{l}"].t().contiguous().to(dt) for l in range(self.n_lstm)]
-        self.lstm_bias = [(self.p[f"layers.1.lstm.bias_ih_l{l}"] + self.p[f"layers.1.lstm.bias_hh_l{l}"]).contiguous() for l in range(self.n_lstm)]
-        idx = 2
-        self.stages: List[tuple] = []
-        for r in self.ratios:
-            self.stages.append((idx + 1, r, [idx + 2 + j for j in range(self.n_res)]))
-            idx += 2 + self.n_res
-        self.last = idx + 1
-        assert f"layers.{self.last}.conv.weight" in self.p, f"expected the output convolution at layers.{self.last}"
+        self.whh_t = [self.p[f"{lstm_name}.lstm.weight_hh_l{l}"].t().contiguous().to(dt) for l in range(self.n_lstm)]
+        self.lstm_bias = [(self.p[f"{lstm_name}.lstm.bias_ih_l{l}"] + self.p[f"{lstm_name}.lstm.bias_hh_l{l}"]).contiguous()
+                          for l in range(self.n_lstm)]
 
-    @classmethod
-    def from_module(cls, decoder: torch.nn.Module, ratios: Sequence[int] = (8, 5, 4, 2), **kw) -> "SEANetDecoderHIP":
-        """from a ``transformers`` EncodecDecoder (its state_dict already uses the key names this class reads)"""
-        return cls({k: v for k, v in decoder.state_dict().items()}, ratios, **kw)
+    def _to_rows(self, x_bct: torch.Tensor) -> torch.Tensor:
+        B, C, T = x_bct.shape
+        h = torch.zeros((B, T, pad8(C)), dtype=self.rt.tdtype, device=self.device)
+        h[:, :, :C] = x_bct.transpose(1, 2)
+        return h
 
     # ------------------------------------------------------------------ building blocks
     def _norm(self, x: torch.Tensor, name: str, C: int) -> torch.Tensor:
@@ -104,15 +127,20 @@ class SEANetDecoderHIP:
                                   None, 0, y.data_ptr(), B, Lx, C, ld, 1, 1e-5, 0, dt, s), "jen1_gn_apply")
         return y
 
-    def _conv(self, x: torch.Tensor, name: str) -> torch.Tensor:
-        """SConv1d, stride 1, non-causal: reflect padding (k - 1 split right-first), conv, GroupNorm(1)"""
+    def _conv(self, x: torch.Tensor, name: str, stride: int = 1) -> torch.Tensor:
+        """SConv1d, non-causal: reflect padding of k - stride (split right-first) plus the extra right padding that
+        makes the frame count whole (modules/conv.py get_extra_padding_for_conv1d), conv, GroupNorm(1)"""
         w, b = self.p[f"{name}.conv.weight"], self.p[f"{name}.conv.bias"]
         co, ci, k = w.shape
         Lx = x.shape[1]
-        total = k - 1
+        total = k - stride
         left = total - total // 2
-        assert Lx > max(left, total // 2), "reflect padding needs more frames than the padding (encodec pad1d's tiny-input case is not built)"
-        g = ConvGeom("conv", k, 1, left, Lx, Lx, ci, co, reflect=True)
+        Lout = -(-(Lx - k + total) // stride) + 1                  # ceil((L - k + total) / stride) + 1
+        right = (Lout - 1) * stride + k - left - Lx                # total // 2 + extra padding
+        if Lx <= max(left, right):
+            raise NotImplementedError(f"{name}: {Lx} frames are not more than the reflect padding ({left}, {right}); encodec's "
+                                      "tiny-input case of pad1d is not built")
+        g = ConvGeom("conv", k, stride, left, Lx, Lout, ci, co, reflect=True)
         y = _conv_forward(self.rt, x, self.rt.packed(w, "conv", x.dtype), b, g)
         return self._norm(y, name, co)
 
@@ -145,7 +173,7 @@ class SEANetDecoderHIP:
         dt = rt.dt_of(x)
         h = x
         for l in range(self.n_lstm):
-            wih = rt.packed(self.p[f"layers.1.lstm.weight_ih_l{l}"], "linear", x.dtype)
+            wih = rt.packed(self.p[f"{self.lstm_name}.lstm.weight_ih_l{l}"], "linear", x.dtype)
             gin = torch.empty((B, T, 4 * H), dtype=torch.float32, device=x.device)
             rt.gemm(_operand(h.data_ptr(), h.shape[-1], 1), _operand(wih.data_ptr(), wih.shape[-1], 1), gin.data_ptr(), B * T, 4 * H, H,
                     dtype=dt, ldc_m=4 * H, bias=self.lstm_bias[l], c_f32=True)
@@ -156,16 +184,33 @@ class SEANetDecoderHIP:
             h = y
         return h
 
+
+
+class SEANetDecoderHIP(_SEANetOps):
+    def __init__(self, params: Dict[str, torch.Tensor], ratios: Sequence[int] = (8, 5, 4, 2), n_residual_layers: int = 1,
+                 compute_dtype: str = "bf16", device="cuda"):
+        super().__init__(params, "layers.1", compute_dtype, device)
+        self.ratios, self.n_res = list(ratios), n_residual_layers
+        idx = 2
+        self.stages: List[tuple] = []
+        for r in self.ratios:
+            self.stages.append((idx + 1, r, [idx + 2 + j for j in range(self.n_res)]))
+            idx += 2 + self.n_res
+        self.last = idx + 1
+        assert f"layers.{self.last}.conv.weight" in self.p, f"expected the output convolution at layers.{self.last}"
+
+    @classmethod
+    def from_module(cls, decoder: torch.nn.Module, ratios: Sequence[int] = (8, 5, 4, 2), **kw) -> "SEANetDecoderHIP":
+        """from a ``transformers`` EncodecDecoder (its state_dict already uses the key names this class reads)"""
+        return cls({k: v for k, v in decoder.state_dict().items()}, ratios, **kw)
+
     # ------------------------------------------------------------------ SEANetDecoder.forward
     @torch.no_grad()
     def __call__(self, emb: torch.Tensor) -> torch.Tensor:
         """latents [B, 128, T] (any device) -> audio float32 [B, channels, hop * T] on the same device"""
         src = emb.device
         x = emb.to(self.device, torch.float32)
-        B, C, T = x.shape
-        h = torch.zeros((B, T, pad8(C)), dtype=self.rt.tdtype, device=self.device)
-        h[:, :, :C] = x.transpose(1, 2)
-        h = self._conv(h, "layers.0")
+        h = self._conv(self._to_rows(x), "layers.0")
         h = self._lstm(h)
         for conv_idx, ratio, res in self.stages:
             h = self._conv_transpose(self._elu(h), f"layers.{conv_idx}", ratio)
@@ -176,16 +221,72 @@ class SEANetDecoderHIP:
         return h[:, :, :ch].to(torch.float32).transpose(1, 2).contiguous().to(src)
 
 
+class SEANetEncoderHIP(_SEANetOps):
+    """encodec modules/seanet.py::SEANetEncoder, 48 kHz settings: conv k7, then per ratio (reversed: 2, 4, 5, 8) a residual
+    block, ELU and a strided conv (k = 2 r); LSTM; ELU; conv k7 to the 128 latent channels"""
+
+    def __init__(self, params: Dict[str, torch.Tensor], ratios: Sequence[int] = (8, 5, 4, 2), n_residual_layers: int = 1,
+                 compute_dtype: str = "bf16", device="cuda"):
+        n_stage = len(ratios) * (n_residual_layers + 2)
+        super().__init__(params, f"layers.{1 + n_stage}", compute_dtype, device)
+        self.ratios, self.n_res = list(reversed(list(ratios))), n_residual_layers
+        self.last = 1 + n_stage + 2
+        assert f"layers.{self.last}.conv.weight" in self.p, f"expected the output convolution at layers.{self.last}"
+
+    @classmethod
+    def from_module(cls, encoder: torch.nn.Module, ratios: Sequence[int] = (8, 5, 4, 2), **kw) -> "SEANetEncoderHIP":
+        return cls({k: v for k, v in encoder.state_dict().items()}, ratios, **kw)
+
+    @torch.no_grad()
+    def __call__(self, audio: torch.Tensor) -> torch.Tensor:
+        """audio [B, channels, L] -> latents float32 [B, 128, ceil(L / 320)] on the same device"""
+        src = audio.device
+        h = self._conv(self._to_rows(audio.to(self.device, torch.float32)), "layers.0")
+        idx = 1
+        for r in self.ratios:
+            for j in range(self.n_res):
+                h = self._resblock(h, f"layers.{idx + j}")
+            idx += self.n_res
+            h = self._conv(self._elu(h), f"layers.{idx + 1}", stride=r)
+            idx += 2
+        h = self._lstm(h)
+        h = self._conv(self._elu(h), f"layers.{self.last}")
+        ch = self.p[f"layers.{self.last}.conv.weight"].shape[0]
+        return h[:, :, :ch].to(torch.float32).transpose(1, 2).contiguous().to(src)
+
+
 class EncodecHIP:
     """the slice of ``EncodecModel`` generation.py touches: ``.channels``, ``.sample_rate``, ``.quantizer.decode``,
     ``.decoder``, ``.encode``"""
 
     def __init__(self, decoder: SEANetDecoderHIP, quantizer: ResidualVectorQuantizerHIP, channels: int = 2, sample_rate: int = 48000,
-                 encode: Optional[Callable] = None):
+                 encode: Optional[Callable] = None, encoder: Optional["SEANetEncoderHIP"] = None, segment: float = 1.0,
+                 overlap: float = 0.01, normalize: bool = True, n_q: Optional[int] = None):
         self.decoder, self.quantizer, self.channels, self.sample_rate, self._encode = decoder, quantizer, channels, sample_rate, encode
+        self.encoder, self.normalize, self.n_q = encoder, normalize, n_q
+        self.segment_length = int(segment * sample_rate)                                   # encodec model.py segment_length
+        self.segment_stride = max(1, int((1 - overlap) * self.segment_length))             # encodec model.py segment_stride
 
+    @torch.no_grad()
     def encode(self, audio: torch.Tensor):
-        if self._encode is None:
-            raise NotImplementedError("the Encodec encoder half (SEANet encoder + codebook search) is not built yet: pass encode=... "
-                                      "(e.g. the reference's EncodecModel.encode)")
-        return self._encode(audio)
+        """``EncodecModel.encode`` of the package (model.py): the audio is cut into 1 s segments with 1 % overlap, every
+        segment is normalised by the RMS of its mono mix, encoded and quantised with ALL codebooks (the reference never
+        sets a target bandwidth) -> ``[(codes [B, n_q, T_seg], scale [B, 1]), ...]``, which is what ``get_emb``
+        concatenates (generation.py:145-150; dataloader.py:106-114)."""
+        if self._encode is not None:
+            return self._encode(audio)
+        if self.encoder is None:
+            raise NotImplementedError("no encoder: construct EncodecHIP with encoder=SEANetEncoderHIP(...) or encode=<callable>")
+        assert audio.dim() == 3 and 0 < audio.shape[1] <= 2
+        frames = []
+        for offset in range(0, audio.shape[-1], self.segment_stride):
+            x = audio[:, :, offset: offset + self.segment_length]
+            scale = None
+            if self.normalize:
+                mono = x.mean(dim=1, keepdim=True)
+                scale = 1e-8 + mono.pow(2).mean(dim=2, keepdim=True).sqrt()
+                x = x / scale
+                scale = scale.view(-1, 1)
+            codes = self.quantizer.encode(self.encoder(x), self.n_q).transpose(0, 1)       # [B, n_q, T]
+            frames.append((codes, scale))
+        return frames

@@ -95,3 +95,66 @@ def seanet_decoder(p: Dict[str, Array], emb: Array, ratios: Sequence[int] = (8, 
             h = sconv1d(h, p, f"{n}.shortcut") + y
         idx += 2 + n_residual_layers
     return sconv1d(elu(h), p, f"layers.{idx + 1}")
+
+
+# ---------------------------------------------------------------------------------------------- encoder half
+def sconv1d_strided(x: Array, p: Dict[str, Array], name: str, stride: int) -> Array:
+    """SConv1d with stride: reflect padding of k - stride (split right-first) + the extra right padding that makes the
+    frame count whole (modules/conv.py get_extra_padding_for_conv1d / pad_for_conv1d)"""
+    w, b = p[f"{name}.conv.weight"], p[f"{name}.conv.bias"]
+    k = w.shape[2]
+    total = k - stride
+    L = x.shape[-1]
+    n_frames = -(-(L - k + total) // stride) + 1
+    extra = (n_frames - 1) * stride + (k - total) - L
+    right = total // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (total - right, right + extra)), mode="reflect")
+    y = _conv1d_valid(xp, w, b, stride)
+    return group_norm(y, 1, p[f"{name}.norm.weight"], p[f"{name}.norm.bias"], 1e-5)
+
+
+def seanet_encoder(p: Dict[str, Array], audio: Array, ratios: Sequence[int] = (8, 5, 4, 2), lstm_layers: int = 2,
+                   n_residual_layers: int = 1) -> Array:
+    """SEANetEncoder.forward with the 48 kHz settings: audio [B, 2, L] -> latents [B, 128, ceil(L / 320)]"""
+    h = sconv1d(audio.astype(np.float32), p, "layers.0")
+    idx = 1
+    for r in reversed(list(ratios)):
+        for j in range(n_residual_layers):
+            n = f"layers.{idx + j}"
+            y = sconv1d(elu(h), p, f"{n}.block.1")
+            y = sconv1d(elu(y), p, f"{n}.block.3")
+            h = sconv1d(h, p, f"{n}.shortcut") + y
+        idx += n_residual_layers
+        h = sconv1d_strided(elu(h), p, f"layers.{idx + 1}", r)
+        idx += 2
+    h = slstm(h, p, f"layers.{idx}", lstm_layers)
+    return sconv1d(elu(h), p, f"layers.{idx + 2}")
+
+
+def rvq_encode(emb: Array, tables: Array) -> Array:
+    """core_vq.py ResidualVectorQuantization.encode: emb [B, D, T] -> codes [n_q, B, T] (nearest entry of the residual)"""
+    B, D, T = emb.shape
+    res = emb.transpose(0, 2, 1).reshape(B * T, D).astype(np.float32)
+    out = []
+    for q in range(tables.shape[0]):
+        e = tables[q]
+        dist = -((res ** 2).sum(1, keepdims=True) - 2 * res @ e.T + (e ** 2).sum(1)[None])
+        idx = dist.argmax(-1)
+        res = res - e[idx]
+        out.append(idx.reshape(B, T))
+    return np.stack(out)
+
+
+def encode_frames(p: Dict[str, Array], tables: Array, audio: Array, sample_rate: int = 48000, segment: float = 1.0,
+                  overlap: float = 0.01):
+    """EncodecModel.encode (model.py): 1 s segments with 1 % overlap, per-segment RMS normalisation, all codebooks"""
+    seg = int(segment * sample_rate)
+    stride = max(1, int((1 - overlap) * seg))
+    frames = []
+    for off in range(0, audio.shape[-1], stride):
+        x = audio[:, :, off: off + seg].astype(np.float32)
+        mono = x.mean(axis=1, keepdims=True)
+        scale = 1e-8 + np.sqrt((mono ** 2).mean(axis=2, keepdims=True))
+        codes = rvq_encode(seanet_encoder(p, x / scale), tables).transpose(1, 0, 2)
+        frames.append((codes, scale.reshape(-1, 1)))
+    return frames

@@ -417,6 +417,17 @@ def gen_encodec():
     out["rvq.codes"] = codes
     out["rvq.y"] = q.decode(T(codes)).numpy()
     out["rvq.n_q"] = np.int64(nq)
+    # encoder half: SEANet encoder on one normalised segment, then the RVQ search with all 16 codebooks (24 kbps)
+    enc = model.encoder
+    esd = enc.state_dict()
+    enc.load_state_dict({k: T(fill("encodec.encoder." + k, tuple(v.shape), SEED)) for k, v in esd.items()})
+    enc.eval()
+    out["enc_schema"] = np.array(json.dumps([(k, list(v.shape)) for k, v in esd.items()]))
+    audio = fill_normal("encodec.audio", (2, 2, 9600 + 123), 5) * 0.3
+    e = enc(T(audio))
+    assert e.shape == (2, 128, -(-(9600 + 123) // 320)), e.shape
+    out["encoder.y"] = e.numpy()
+    out["encoder.codes"] = q.encode(e, 24.0).numpy()
     save("encodec", **out)
 
 

@@ -43,6 +43,68 @@ def test_oracle_rvq_decode_matches_reference_port():
     assert y.shape == g["rvq.y"].shape and rel_err(y, g["rvq.y"]) < 1e-6
 
 
+def _enc_params():
+    g = golden("encodec")
+    return {k: fill("encodec.encoder." + k, tuple(s), SEED) for k, s in json.loads(str(g["enc_schema"]))}
+
+
+def _audio():
+    return fill_normal("encodec.audio", (2, 2, 9600 + 123), 5) * 0.3
+
+
+def test_oracle_seanet_encoder_and_rvq_encode_match_reference_port():
+    from oracle import encodec_oracle as EO
+    g = golden("encodec")
+    e = EO.seanet_encoder(_enc_params(), _audio())
+    assert e.shape == g["encoder.y"].shape == (2, 128, 31)
+    assert rel_err(e, g["encoder.y"]) < 1e-4
+    codes = EO.rvq_encode(g["encoder.y"], _tables(16))
+    assert codes.shape == g["encoder.codes"].shape == (16, 2, 31)
+    assert (codes == g["encoder.codes"]).mean() > 0.999          # nearest-neighbour ties can flip with the summation order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 5e-2)])
+def test_hip_seanet_encoder_vs_reference_port(mode, tol):
+    from jen1_amd.encodec import SEANetEncoderHIP
+    g = golden("encodec")
+    enc = SEANetEncoderHIP({k: torch.from_numpy(v) for k, v in _enc_params().items()}, compute_dtype=mode)
+    e = enc(torch.from_numpy(_audio()))
+    assert e.device.type == "cpu" and tuple(e.shape) == (2, 128, 31)
+    assert rel_err(e.numpy(), g["encoder.y"]) < tol
+
+
+@pytest.mark.gpu
+def test_hip_rvq_encode_and_segmented_encode():
+    """codes of the nearest-neighbour search against the port (same latents in), then EncodecModel.encode's segment
+    loop (1 s segments, 1 % overlap, RMS normalisation, all codebooks) against the numpy restatement"""
+    from jen1_amd.encodec import EncodecHIP, ResidualVectorQuantizerHIP, SEANetDecoderHIP, SEANetEncoderHIP
+    from oracle import encodec_oracle as EO
+    g = golden("encodec")
+    quant = ResidualVectorQuantizerHIP(torch.from_numpy(_tables(16)))
+    codes = quant.encode(torch.from_numpy(g["encoder.y"]))
+    assert tuple(codes.shape) == (16, 2, 31) and codes.dtype == torch.int64
+    assert (codes.numpy() == g["encoder.codes"]).mean() > 0.999
+    # the first codebook's choice really is the nearest entry (float64 check of every frame)
+    x = g["encoder.y"].transpose(0, 2, 1).reshape(-1, 128).astype(np.float64)
+    d = ((x[:, None, :] - _tables(1)[0][None].astype(np.float64)) ** 2).sum(-1)
+    chosen = d[np.arange(x.shape[0]), codes[0].numpy().reshape(-1)]
+    assert np.all(chosen <= d.min(axis=1) * (1 + 1e-6))
+    enc = SEANetEncoderHIP({k: torch.from_numpy(v) for k, v in _enc_params().items()}, compute_dtype="f32")
+    dec = SEANetDecoderHIP({k: torch.from_numpy(v) for k, v in _params().items()}, compute_dtype="f32")
+    model = EncodecHIP(dec, quant, encoder=enc)
+    audio = fill_normal("encodec.audio.long", (1, 2, 48000 + 47520 // 2), 7) * 0.2       # 2 segments, the second one short
+    frames = model.encode(torch.from_numpy(audio))
+    want = EO.encode_frames(_enc_params(), _tables(16), audio)
+    assert len(frames) == len(want) == 2
+    for (c, s), (cw, sw) in zip(frames, want):
+        assert tuple(c.shape) == cw.shape and rel_err(s.numpy(), sw) < 1e-6
+        assert (c.numpy() == cw).mean() > 0.995
+    # get_emb (generation.py:145-150) on top of it
+    emb = quant.decode(torch.cat([f[0] for f in frames], dim=-1).transpose(0, 1))
+    assert tuple(emb.shape) == (1, 128, sum(f[0].shape[-1] for f in frames))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 5e-2)])
 def test_hip_seanet_decoder_vs_reference_port(mode, tol):
