@@ -109,6 +109,12 @@ int jen1_convert_clear(float* src, void* dst, int64_t n, int dtype, void* stream
 int jen1_rvq_decode(const int64_t* codes, const float* tables, float* out, int n_q, int B, int T, int bins, int D, void* stream);
 int jen1_lstm_layer(const float* gin, const void* whh_t, const void* skip, void* y, int B, int T, int H, int ld_y, int dtype,
                     void* stream);
+/* The same layer spread over H / 32 workgroups per group of 8 sequences, the slice of W_hh of every workgroup resident in
+ * registers and one grid barrier per step (needs all workgroups co-resident: nothing else may occupy the GPU's CUs).
+ * whh [4H][H] (NOT transposed) in `dtype`; hbuf: float32 scratch [groups][2][8][H]; counters: uint32 [groups][32], ZERO on
+ * entry; counters[g * 32 + 1] != 0 afterwards reports a barrier time-out (output invalid). */
+int jen1_lstm_layer_multi(const float* gin, const void* whh, const void* skip, void* y, float* hbuf, uint32_t* counters, int B, int T,
+                          int H, int ld_y, int dtype, void* stream);
 
 /* out[c] += sum_rows x[row][c]  (bias gradients), float32 accumulate */
 int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream);

@@ -89,6 +89,102 @@ __global__ __launch_bounds__(1024) void lstm_layer_kernel(const float* __restric
   }
 }
 
+// ---- LSTM layer spread over NW workgroups (the fast path) -----------------------------------------------------------
+// Workgroup w owns UPW = 32 hidden units = 128 gate rows; its slice of W_hh (128 x H) lives in registers for the whole
+// sequence: thread (row r, k slice s) holds W_hh[row r][s * KS .. s * KS + KS).  Up to LB = 8 sequences advance together.
+// Per step: h_t of all sequences is in LDS; every thread forms its partial dot products for the LB sequences (LDS
+// broadcast reads), the k slices are summed through LDS, 32 x LB threads apply the gates, publish h_{t+1} of their
+// units with write-through stores, and one grid barrier (relaxed agent-scope atomics, tools/microbench/gridbar.hip:
+// ~1 us at 16 workgroups) separates the steps.  The spin is bounded: a lost workgroup turns into wrong output plus an
+// error flag, never into a hang.
+constexpr int LSTM_UPW = 32, LSTM_LB = 8, LSTM_NS = 8;
+
+template <typename T, int KS>    // KS = H / LSTM_NS k values per thread
+__global__ __launch_bounds__(1024) void lstm_multi_kernel(const float* __restrict__ gin, const void* whh_, const void* skip_, void* y_,
+                                                          float* hbuf, unsigned* ctr, int B, int Tn, int H, int ld_y) {
+  __shared__ float h_s[LSTM_LB][1024];                 // h_t of the sequences of this group (H <= 1024)
+  __shared__ float red[LSTM_NS][128][LSTM_LB + 1];
+  __shared__ float gates[LSTM_LB][128];
+  const T* whh = reinterpret_cast<const T*>(whh_);
+  const T* skip = reinterpret_cast<const T*>(skip_);
+  T* y = reinterpret_cast<T*>(y_);
+  const int tid = threadIdx.x, NW = gridDim.x, w = blockIdx.x, grp = blockIdx.y;
+  const int b0 = grp * LSTM_LB, nb = min(LSTM_LB, B - b0);
+  const int rl = tid & 127, sl = tid >> 7;            // gate row within the workgroup, k slice
+  const int gate = rl >> 5, u = rl & 31;
+  const int grow = gate * H + w * LSTM_UPW + u;        // row of W_hh / entry of the 4H gate vector
+  float wreg[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) wreg[j] = (float)whh[(long long)grow * H + sl * KS + j];
+  float* hb = hbuf + (long long)grp * 2 * LSTM_LB * H;   // [2][LB][H] ping-pong of the published hidden state
+  unsigned* my_ctr = ctr + grp * 32;
+  unsigned epoch = 0;
+  float c = 0.f;                                         // cell state of (unit u2, sequence b2) for threads < 32 * LB
+  const int u2 = tid & 31, b2 = tid >> 5;
+  for (int i = tid; i < LSTM_LB * 1024; i += 1024) (&h_s[0][0])[i] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < Tn; ++t) {
+    // partial dot products of this thread's k slice for every sequence
+    // the input projection of this step is fetched first: its latency hides behind the dot products
+    const float g_in = (sl < nb) ? gin[((long long)(b0 + sl) * Tn + t) * (4 * H) + grow] : 0.f;
+    float part[LSTM_LB];
+#pragma unroll
+    for (int b = 0; b < LSTM_LB; ++b) part[b] = 0.f;
+#pragma unroll
+    for (int b = 0; b < LSTM_LB; ++b) {
+      if (b < nb) {                                  // uniform: absent sequences cost nothing
+#pragma unroll
+        for (int j = 0; j < KS; j += 4) {
+          const float4 hv = *reinterpret_cast<const float4*>(&h_s[b][sl * KS + j]);
+          part[b] += wreg[j] * hv.x + wreg[j + 1] * hv.y + wreg[j + 2] * hv.z + wreg[j + 3] * hv.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < LSTM_LB; ++b) red[sl][rl][b] = part[b];
+    __syncthreads();
+    {   // thread (rl, b = sl) sums the k slices and adds the input projection
+      const int b = sl;
+      float g = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < LSTM_NS; ++s2) g += red[s2][rl][b];
+      gates[b][rl] = g + g_in;
+    }
+    __syncthreads();
+    float* hnext = hb + (long long)((t + 1) & 1) * LSTM_LB * H;
+    if (tid < 32 * LSTM_LB && b2 < nb) {
+      const float ig = sigmoid_f(gates[b2][u2]), fg = sigmoid_f(gates[b2][32 + u2]), gg = tanhf(gates[b2][64 + u2]), og = sigmoid_f(gates[b2][96 + u2]);
+      c = fg * c + ig * gg;
+      const float hn = og * tanhf(c);
+      const int j = w * LSTM_UPW + u2;
+      __hip_atomic_store(hnext + b2 * H + j, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long o = ((long long)(b0 + b2) * Tn + t) * ld_y + j;
+      y[o] = (T)(hn + (skip != nullptr ? (float)skip[o] : 0.f));
+    }
+    // grid barrier over the NW workgroups of this group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      ++epoch;
+      __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = epoch * NW;
+      int spins = 0;
+      while (__hip_atomic_load(my_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 20)) { __hip_atomic_store(my_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < Tn) {
+      for (int i = tid; i < nb * H; i += 1024) {
+        const int b = i / H, j = i - b * H;
+        h_s[b][j] = __hip_atomic_load(hnext + b * H + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int jen1_rvq_decode(const int64_t* codes, const float* tables, float* out, int n_q, int B, int T, int bins, int D, void* stream) {
@@ -96,6 +192,24 @@ extern "C" int jen1_rvq_decode(const int64_t* codes, const float* tables, float*
   JEN1_CHECK(n_q >= 1 && B >= 1 && T >= 1 && bins >= 1 && D >= 1 && B <= 65535, "jen1_rvq_decode: bad shape");
   hipLaunchKernelGGL(rvq_decode_kernel, dim3((T + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const long long*>(codes), tables, out, n_q, B, T, bins, D);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_lstm_layer_multi(const float* gin, const void* whh, const void* skip, void* y, float* hbuf, uint32_t* counters,
+                                     int B, int T, int H, int ld_y, int dtype, void* stream) {
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "jen1_lstm_layer_multi: dtype must be JEN1_F32 or JEN1_BF16");
+  JEN1_CHECK(gin && whh && y && hbuf && counters, "jen1_lstm_layer_multi: NULL argument");
+  JEN1_CHECK(B >= 1 && T >= 1 && ld_y >= H, "jen1_lstm_layer_multi: bad shape B=%d T=%d H=%d ld_y=%d", B, T, H, ld_y);
+  JEN1_CHECK(H == 256 || H == 512 || H == 1024, "jen1_lstm_layer_multi: H must be 256, 512 or 1024");
+  const int groups = (B + LSTM_LB - 1) / LSTM_LB, nw = H / LSTM_UPW;
+  JEN1_CHECK(groups * nw <= 256, "jen1_lstm_layer_multi: %d workgroups must be co-resident (at most 256)", groups * nw);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(nw, groups);
+#define JEN1_LSTMM(TT, KS) hipLaunchKernelGGL((lstm_multi_kernel<TT, KS>), grid, dim3(1024), 0, s, gin, whh, skip, y, hbuf, counters, B, T, H, ld_y)
+  if (dtype == JEN1_F32) { if (H == 256) JEN1_LSTMM(float, 32); else if (H == 512) JEN1_LSTMM(float, 64); else JEN1_LSTMM(float, 128); }
+  else { if (H == 256) JEN1_LSTMM(bf16_t, 32); else if (H == 512) JEN1_LSTMM(bf16_t, 64); else JEN1_LSTMM(bf16_t, 128); }
+#undef JEN1_LSTMM
   JEN1_HIP(hipGetLastError());
   return 0;
 }

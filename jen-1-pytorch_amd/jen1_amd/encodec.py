@@ -22,6 +22,7 @@ PARITY IS PINNED AGAINST THAT PORT WITH SYNTHETIC WEIGHTS (tests/golden/encodec.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -105,6 +106,10 @@ class _SEANetOps:
         dt = self.rt.tdtype
         # LSTM operands: W_ih as a linear weight (packed by the runtime), W_hh transposed [H][4H], the two biases summed
         self.whh_t = [self.p[f"{lstm_name}.lstm.weight_hh_l{l}"].t().contiguous().to(dt) for l in range(self.n_lstm)]
+        self.whh = [self.p[f"{lstm_name}.lstm.weight_hh_l{l}"].to(dt).contiguous() for l in range(self.n_lstm)]
+        # jen1_lstm_layer_multi (register-resident W_hh over H / 32 workgroups, one grid barrier per step) unless disabled
+        self.lstm_multi = os.environ.get("JEN1_LSTM_MULTI", "1") == "1"
+        self.last_lstm_counters: Optional[torch.Tensor] = None
         self.lstm_bias = [(self.p[f"{lstm_name}.lstm.bias_ih_l{l}"] + self.p[f"{lstm_name}.lstm.bias_hh_l{l}"]).contiguous()
                           for l in range(self.n_lstm)]
 
@@ -179,8 +184,17 @@ class _SEANetOps:
                     dtype=dt, ldc_m=4 * H, bias=self.lstm_bias[l], c_f32=True)
             y = torch.empty_like(x)
             last = l == self.n_lstm - 1
-            L.check(rt.lib.jen1_lstm_layer(gin.data_ptr(), self.whh_t[l].data_ptr(), x.data_ptr() if last else None, y.data_ptr(), B, T, H,
-                                           y.shape[-1], dt, rt.stream()), "jen1_lstm_layer")
+            groups = (B + 7) // 8
+            if self.lstm_multi and groups * (H // 32) <= 256:
+                hbuf = torch.empty((groups, 2, 8, H), dtype=torch.float32, device=x.device)
+                cnt = torch.zeros((groups, 32), dtype=torch.int32, device=x.device)
+                L.check(rt.lib.jen1_lstm_layer_multi(gin.data_ptr(), self.whh[l].data_ptr(), x.data_ptr() if last else None, y.data_ptr(),
+                                                     hbuf.data_ptr(), cnt.data_ptr(), B, T, H, y.shape[-1], dt, rt.stream()),
+                        "jen1_lstm_layer_multi")
+                self.last_lstm_counters = cnt        # cnt[:, 1] != 0 would report a barrier time-out (checked by the tests)
+            else:
+                L.check(rt.lib.jen1_lstm_layer(gin.data_ptr(), self.whh_t[l].data_ptr(), x.data_ptr() if last else None, y.data_ptr(), B, T, H,
+                                               y.shape[-1], dt, rt.stream()), "jen1_lstm_layer")
             h = y
         return h
 

@@ -126,6 +126,7 @@ SYMBOLS = {
     "jen1_convert_clear": (c_int, [_P, _P, c_int64, c_int, _P]),
     "jen1_rvq_decode": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_lstm_layer": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    "jen1_lstm_layer_multi": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),

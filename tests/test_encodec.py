@@ -117,6 +117,26 @@ def test_hip_seanet_decoder_vs_reference_port(mode, tol):
     assert rel_err(y.numpy(), g["decoder.y"]) < tol
     y2 = dec(emb.cuda())
     assert y2.device.type == "cuda" and rel_err(y2.cpu().numpy(), g["decoder.y"]) < tol
+    assert int(dec.last_lstm_counters[:, 1].sum()) == 0           # no grid-barrier time-out in the multi-workgroup LSTM
+    # the single-workgroup LSTM kernel gives the same audio
+    dec.lstm_multi = False
+    assert rel_err(dec(emb).numpy(), g["decoder.y"]) < tol
+
+
+@pytest.mark.gpu
+def test_hip_lstm_multi_many_sequences_and_long():
+    """more sequences than one group of 8 and a long sequence: multi-workgroup LSTM against the single-workgroup kernel"""
+    from jen1_amd.encodec import SEANetDecoderHIP
+    dec = SEANetDecoderHIP({k: torch.from_numpy(v) for k, v in _params().items()}, compute_dtype="f32")
+    for B, T in ((11, 40), (2, 700)):
+        x = torch.randn((B, T, 512), device="cuda") * 0.5
+        dec.lstm_multi = True
+        a = dec._lstm(x)
+        assert int(dec.last_lstm_counters[:, 1].sum()) == 0
+        dec.lstm_multi = False
+        b = dec._lstm(x)
+        torch.cuda.synchronize()
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, (B, T)
 
 
 @pytest.mark.gpu
