@@ -10,6 +10,7 @@
 // LDS, so the MFMA fragments are always 8 consecutive K values of one row.
 #include "common.h"
 #include "jen1_train.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,6 +32,7 @@ struct GemmDev {
   long long a_zs0, a_zs1, b_zs0, b_zs1, c_zs0, c_zs1;
   int a_zdiv, b_zdiv, c_zdiv;
   int M, N, K, taps, taps_in_z, splitk, atomic, accumulate, c_f32;
+  int direct;        // both operands K-contiguous, fragments straight from global memory (no LDS staging)
   float alpha;
 };
 
@@ -70,9 +72,49 @@ struct Staged {
   typename Vec<T>::type v[BM * BK / Vec<T>::N / NT];
 };
 
+// The index map without its division: (b, t) of the mapped index are kept per thread (rows of a k-contiguous
+// operand never change during the K loop; the k index of a row-contiguous one advances by BK per step), so the
+// loop body only does the multiply-add of the map.  Integer divisions per vector per step used to dominate the loop.
+__device__ __forceinline__ long long map_from_bt(const Operand& o, int b, int t, int tap) {
+  int s = t * o.map_mul + tap * o.map_tapmul + o.map_shift;
+  if (o.map_reflect) {
+    if (s < 0) s = -s;
+    if (s >= o.map_Lsrc) s = 2 * (o.map_Lsrc - 1) - s;
+  }
+  if (s < 0) return -1;
+  if (o.map_div > 1) {
+    const int q = s / o.map_div;          // map_div is a small constant per launch; only the strided gradients pay this
+    if (q * o.map_div != s) return -1;
+    s = q;
+  }
+  if (s >= o.map_Lsrc) return -1;
+  return (long long)b * o.map_Lsrc + s;
+}
+
+template <typename T>
+struct Pre {            // per-thread (b, t) of the mapped index of every vector this thread fetches
+  static constexpr int NV = BM * BK / Vec<T>::N / NT;
+  int b[NV], t[NV];
+  bool hoisted;         // false: fall back to map_index (division) every step
+};
+
+template <typename T>
+__device__ __forceinline__ void pre_init(Pre<T>& p, const Operand& o, int row0, int k_first, bool k_monotonic, int tid) {
+  constexpr int V = Vec<T>::N;
+  const bool kc = (o.ld_k == 1), rc = (o.ld_r == 1) && !kc;
+  p.hoisted = (!rc && o.map_axis == 1) || (rc && o.map_axis == 2 && k_monotonic);
+#pragma unroll
+  for (int i = 0; i < Pre<T>::NV; ++i) {
+    const int v = tid + i * NT;
+    const int idx = !rc ? row0 + v / (BK / V) : k_first + v / (BM / V);
+    p.b[i] = p.hoisted ? idx / o.map_L : 0;
+    p.t[i] = p.hoisted ? idx - p.b[i] * o.map_L : 0;
+  }
+}
+
 // global -> registers for one (tap, k0) step of one operand (64 rows x 32 k)
 template <typename T>
-__device__ __forceinline__ void fetch(Staged<T>& st, const Operand& o, const T* base, int row0, int tap, int k0, int K, int tid) {
+__device__ __forceinline__ void fetch(Staged<T>& st, Pre<T>& pre, const Operand& o, const T* base, int row0, int tap, int k0, int K, int tid) {
   constexpr int V = Vec<T>::N;
   constexpr int NV = BM * BK / V / NT;
   typedef typename Vec<T>::type vec_t;
@@ -88,7 +130,14 @@ __device__ __forceinline__ void fetch(Staged<T>& st, const Operand& o, const T* 
       const int r = row0 + v / (BK / V), k = k0 + (v % (BK / V)) * V;
       bool done = false;
       if (kc && o.map_axis != 2 && k + V <= K) {
-        const long long off = elem_offset(o, r, tap, k, K);
+        long long off;
+        if (r >= o.rows) off = -1;
+        else if (o.map_axis == 1 && pre.hoisted) {
+          const long long rr = map_from_bt(o, pre.b[i], pre.t[i], tap);
+          off = rr < 0 ? -1 : (long long)tap * o.tap_stride + rr * o.ld_r + k;
+        } else {
+          off = elem_offset(o, r, tap, k, K);
+        }
         if (off < 0) done = true;
         else if ((((unsigned long long)(base + off)) & 15) == 0) { val = *reinterpret_cast<const vec_t*>(base + off); done = true; }
       }
@@ -104,7 +153,14 @@ __device__ __forceinline__ void fetch(Staged<T>& st, const Operand& o, const T* 
       const int k = k0 + v / (BM / V), r = row0 + (v % (BM / V)) * V;
       bool done = false;
       if (o.map_axis != 1 && r + V <= o.rows) {
-        const long long off = elem_offset(o, r, tap, k, K);
+        long long off;
+        if (k >= K) off = -1;
+        else if (o.map_axis == 2 && pre.hoisted) {
+          const long long kk = map_from_bt(o, pre.b[i], pre.t[i], tap);
+          off = kk < 0 ? -1 : (long long)tap * o.tap_stride + r + kk * o.ld_k;
+        } else {
+          off = elem_offset(o, r, tap, k, K);
+        }
         if (off < 0) done = true;
         else if ((((unsigned long long)(base + off)) & 15) == 0) { val = *reinterpret_cast<const vec_t*>(base + off); done = true; }
       }
@@ -114,6 +170,10 @@ __device__ __forceinline__ void fetch(Staged<T>& st, const Operand& o, const T* 
           const long long off = elem_offset(o, r + j, tap, k, K);
           if (off >= 0) val[j] = base[off];
         }
+      }
+      if (o.map_axis == 2 && pre.hoisted) {        // next step of this K slice: k += BK
+        pre.t[i] += BK;
+        while (pre.t[i] >= o.map_L) { pre.t[i] -= o.map_L; ++pre.b[i]; }
       }
     }
     st.v[i] = val;
@@ -154,11 +214,95 @@ __device__ __forceinline__ void mma8(f32x4& acc, const float* a, const float* b)
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc, 0, 0, 0);
 }
 
+// ---- register-direct path: both operands K-contiguous (forward conv / linear, data gradient over transposed weights) ----
+// A lane's MFMA fragment (row lane % 16, 8 consecutive k at (lane / 16) * 8) IS 16 contiguous bytes of its row, so the
+// fragments come straight from global memory through buffer descriptors (rows in the padding / beyond M, N, K read as
+// zero through an out-of-range offset): no LDS, no barriers in the K loop, PF steps of loads in flight per wave.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned D_OOB = 0x80000000u;
+constexpr int D_RSRC_FLAGS = 0x00020000;
+
+template <typename T> struct DFrag;
+template <> struct DFrag<bf16_t> { typedef bf16x8 type; static constexpr int PF = 4; };
+template <> struct DFrag<float> { typedef f32x8 type; static constexpr int PF = 2; };
+
+__device__ __forceinline__ void dload(bf16x8& f, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  f = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ void dload(f32x8& f, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+  const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(r, voff == D_OOB ? D_OOB : voff + 16u, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = __uint_as_float(lo[j]); f.v[4 + j] = __uint_as_float(hi[j]); }
+}
+__device__ __forceinline__ void dmma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void dmma(f32x4& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, const T* bbase, int m0, int n0, int wm, int wn, int lane,
+                                            int s_begin, int s_end, int ksteps, f32x4 (&acc)[2][2]) {
+  typedef typename DFrag<T>::type Frag;
+  constexpr int PF = DFrag<T>::PF;
+  constexpr unsigned ES = sizeof(T);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(abase), 0, 0x7fffffff, D_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(bbase), 0, 0x7fffffff, D_RSRC_FLAGS);
+  const int li = lane & 15, kq = (lane >> 4) * 8;
+  int a_b[2], a_t[2], a_row[2];
+  bool a_ok[2];
+  unsigned b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = m0 + wm * 32 + i * 16 + li;
+    a_ok[i] = r < g.M;
+    a_row[i] = r;
+    a_b[i] = (g.a.map_axis == 1) ? r / g.a.map_L : 0;
+    a_t[i] = (g.a.map_axis == 1) ? r - a_b[i] * g.a.map_L : 0;
+    const int n = n0 + wn * 32 + i * 16 + li;
+    b_off[i] = n < g.N ? (unsigned)((long long)n * g.b.ld_r) * ES : D_OOB;
+  }
+  Frag fa[PF][2], fb[PF][2];
+  int s_next = s_begin;
+  auto issue = [&](Frag (&xa)[2], Frag (&xb)[2]) {
+    const int s = s_next++;
+    const int tap = s / ksteps, k = (s - tap * ksteps) * BK + kq;
+    const bool live = s < s_end && k < g.K;
+    const unsigned tb = (unsigned)((long long)tap * g.b.tap_stride + k) * ES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      long long row = a_row[i];
+      if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap);
+      const bool ok = live && a_ok[i] && row >= 0;
+      dload(xa[i], ra, ok ? (unsigned)((long long)tap * g.a.tap_stride + row * g.a.ld_r + k) * ES : D_OOB);
+      dload(xb[i], rb, (live && b_off[i] != D_OOB) ? b_off[i] + tb : D_OOB);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u) issue(fa[u], fb[u]);
+  for (int c = s_begin; c < s_end; c += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (c + u < s_end) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) dmma(acc[mi][ni], fa[u][mi], fb[u][ni]);
+      }
+      issue(fa[u], fb[u]);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
   constexpr int PITCH = BK + 16 / (int)sizeof(T);
   __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
   __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
+  jen1_prefetch_kernarg<sizeof(GemmDev)>();      // one batch of scalar loads instead of one round trip per argument line
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -182,16 +326,33 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the bias of this lane's two output columns is requested before the K loop (its latency hides behind it)
+  float bias_v[2] = {0.f, 0.f};
+  if (g.bias != nullptr) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 32 + ni * 16 + (lane & 15);
+      bias_v[ni] = n < g.N ? g.bias[n] : 0.f;
+    }
+  }
+
   // bias gradient: the workgroups of the first N tile and tap 0 also sum their A rows over K
   const bool do_rowsum = g.rowsum != nullptr && blockIdx.y == 0 && tap_z == 0;
   float rsum = 0.f;
 
+  if (g.direct) {
+    direct_loop<T>(g, abase, bbase, m0, n0, wm, wn, lane, s_begin, s_end, ksteps, acc);
+  } else {
   Staged<T> sa, sb;
+  Pre<T> pa, pb;
+  // with one matrix per tap (weight gradient) the steps of this K slice are consecutive in k: s -> k0 = s * BK
+  pre_init<T>(pa, g.a, m0, s_begin * BK, g.taps_in_z != 0, tid);
+  pre_init<T>(pb, g.b, n0, s_begin * BK, g.taps_in_z != 0, tid);
   auto fetch_step = [&](int s) {
     const int tap = g.taps_in_z ? tap_z : s / ksteps;
     const int k0 = (g.taps_in_z ? s : s % ksteps) * BK;
-    fetch<T>(sa, g.a, abase, m0, tap, k0, g.K, tid);
-    fetch<T>(sb, g.b, bbase, n0, tap, k0, g.K, tid);
+    fetch<T>(sa, pa, g.a, abase, m0, tap, k0, g.K, tid);
+    fetch<T>(sb, pb, g.b, bbase, n0, tap, k0, g.K, tid);
   };
   if (s_begin < s_end) fetch_step(s_begin);
   for (int s = s_begin; s < s_end; ++s) {
@@ -211,6 +372,7 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
         mma8(acc[mi][ni], As + (wm * 32 + mi * 16 + rr) * PITCH + kq, Bs + (wn * 32 + ni * 16 + rr) * PITCH + kq);
     __syncthreads();
   }
+  }
 
   if (do_rowsum && tid < BM && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, g.alpha * rsum);
 
@@ -223,7 +385,7 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
     for (int ni = 0; ni < 2; ++ni) {
       const int n = n0 + wn * 32 + ni * 16 + (lane & 15);
       if (n >= g.N) continue;
-      const float bv = (g.bias != nullptr && split == 0) ? g.bias[n] : 0.f;
+      const float bv = split == 0 ? bias_v[ni] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 32 + mi * 16 + (lane >> 4) * 4 + r;
@@ -290,6 +452,22 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   g.a_zdiv = a.a.zdiv; g.b_zdiv = a.b.zdiv; g.c_zdiv = a.c_zdiv;
   g.M = a.M; g.N = a.N; g.K = a.K; g.taps = a.taps; g.taps_in_z = a.taps_in_z ? 1 : 0; g.splitk = a.splitk;
   g.atomic = a.atomic ? 1 : 0; g.accumulate = a.accumulate ? 1 : 0; g.c_f32 = a.c_f32 ? 1 : 0; g.alpha = a.alpha;
+  {
+    // register-direct path: K-contiguous operands whose rows start on 16-byte boundaries and whose extents fit the
+    // 31-bit offsets of a buffer descriptor; the mapped axis of A may only be its rows; B is a plain matrix per tap
+    const long long es = a.dtype == JEN1_F32 ? 4 : 2;
+    const long long vec = 16 / es;
+    auto aligned = [&](const jen1_gemm_operand& o) {
+      return o.ld_k == 1 && o.ld_r % vec == 0 && o.tap_stride % vec == 0 && o.zs0 % vec == 0 && o.zs1 % vec == 0 &&
+             ((uintptr_t)o.p & 15) == 0;
+    };
+    const long long a_rows = a.a.map_axis == 1 ? (long long)((a.M + a.a.map_L - 1) / a.a.map_L) * a.a.map_Lsrc : a.M;
+    const long long a_span = ((long long)(a.taps - 1) * (a.a.tap_stride > 0 ? a.a.tap_stride : 0) + a_rows * a.a.ld_r + a.K) * es;
+    const long long b_span = ((long long)(a.taps - 1) * a.b.tap_stride + (long long)a.N * a.b.ld_r + a.K) * es;
+    g.direct = (!a.taps_in_z && a.rowsum == nullptr && aligned(a.a) && aligned(a.b) && a.a.map_axis != 2 && a.b.map_axis == 0 &&
+                a.K % vec == 0 && a.a.tap_stride >= 0 && a.b.tap_stride >= 0 && a_span < (1ll << 31) && b_span < (1ll << 31) &&
+                getenv("JEN1_TRAIN_GEMM_NO_DIRECT") == nullptr) ? 1 : 0;
+  }
   dim3 grid((a.M + BM - 1) / BM, gy, (unsigned)gz);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a.dtype == JEN1_F32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);

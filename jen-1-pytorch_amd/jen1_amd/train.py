@@ -68,6 +68,8 @@ class TrainRuntime:
         self.epoch = 0
         self._fresh_epoch = -1
         self._acc32: Optional[torch.Tensor] = None        # persistent float32 split-K accumulator, zero at rest
+        # keep a second, transposed compute copy of every weight so that the data gradient is K-contiguous on both operands
+        self.dgrad_copies = os.environ.get("JEN1_TRAIN_DGRAD_COPIES", "1") == "1"
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
 
@@ -93,7 +95,15 @@ class TrainRuntime:
             return d.unsqueeze(0)                          # [1][Co][Ci]
         if kind == "conv":
             return d.permute(2, 0, 1)                      # [k][Co][Ci]
-        return d.permute(2, 1, 0)                          # ConvTranspose1d [Ci][Co][k] -> [k][Co][Ci]
+        if kind == "convT":
+            return d.permute(2, 1, 0)                      # ConvTranspose1d [Ci][Co][k] -> [k][Co][Ci]
+        # the data-gradient copies: rows = input channels, K = output channels contiguous (register-direct GEMM path)
+        if kind == "linearD":
+            return d.t().unsqueeze(0)                      # [1][Ci][Co]
+        if kind == "convD":
+            return d.permute(2, 1, 0)                      # [Co][Ci][k] -> [k][Ci][Co]
+        assert kind == "convTD"
+        return d.permute(2, 0, 1)                          # [Ci][Co][k] -> [k][Ci][Co]
 
     def packed(self, w: torch.Tensor, kind: str, dtype: torch.dtype) -> torch.Tensor:
         """compute copy [k][C_out][pad8(C_in)] of a Conv1d [Co, Ci, k] / ConvTranspose1d [Ci, Co, k] / Linear [Co, Ci]
@@ -226,7 +236,9 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     return y
 
 
-def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeom) -> torch.Tensor:
+def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeom, wd: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``wd``: the data-gradient copy [k][Ci][pad8(Co)] of the weight (both GEMM operands K-contiguous: the register-direct
+    path of jen1_train_gemm); without it the forward copy ``wp`` is read transposed through LDS"""
     dt = rt.dt_of(dy)
     ldy = dy.shape[-1]
     k, co, cip = wp.shape
@@ -234,15 +246,23 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     B = dy.numel() // ldy // g.L_out
     M = B * g.L_in
     a = _operand(dy.data_ptr(), ldy, 1, m=g.bwd_map(1))
-    b = _operand(wp.data_ptr(), 1, cip, tap_stride=co * cip)
+    if wd is not None:
+        assert wd.shape[0] == k and wd.shape[2] == ldy
+        ci_rows = wd.shape[1]
+        b = _operand(wd.data_ptr(), ldy, 1, tap_stride=ci_rows * ldy)
+        co = ldy                                               # K runs over the padded (zero) output channels too
+        cip_n = ci_rows
+    else:
+        b = _operand(wp.data_ptr(), 1, cip, tap_stride=co * cip)
+        cip_n = cip
     ksteps = k * ((co + 31) // 32)
     sk = rt.pick_splitk(M, cip, ksteps)
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_in * cip)
-        rt.gemm(a, b, acc.data_ptr(), M, cip, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True)
+        rt.gemm(a, b, acc.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True)
         return rt.hand_over(acc, torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device))
-    dx = torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
-    rt.gemm(a, b, dx.data_ptr(), M, cip, co, dtype=dt, taps=k, ldc_m=cip)
+    dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
+    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip)
     return dx
 
 
@@ -278,6 +298,7 @@ class ConvFn(Function):
     def forward(ctx, x, weight, bias, rt: TrainRuntime, g: ConvGeom):
         wp = rt.packed(weight, g.kind, x.dtype)
         ctx.rt, ctx.g, ctx.weight, ctx.bias, ctx.wp = rt, g, weight, bias, wp
+        ctx.wd = rt.packed(weight, g.kind + "D", x.dtype) if (ctx.needs_input_grad[0] and rt.dgrad_copies) else None
         ctx.save_for_backward(x)
         return _conv_forward(rt, x, wp, None if bias is None else bias.detach(), g)
 
@@ -291,7 +312,7 @@ class ConvFn(Function):
             ldy = dy.shape[-1]
             L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
                     "jen1_colsum")
-        dx = _conv_dgrad(rt, dy, ctx.wp, g).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd).view(x.shape) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None
 
 
