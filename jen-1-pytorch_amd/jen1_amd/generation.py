@@ -21,6 +21,8 @@ Differences, all deliberate and visible:
   * the reference reads ``flag`` before assignment when ``init_audio`` is given (generation.py:91-120); here
     ``flag`` is False in that case, i.e. the given audio is the ``init_data`` of the sampler, which is what the code
     evidently means;
+  * ``init_audio.size() != 3`` (generation.py:85) compares a ``torch.Size`` with an int and is always true, so the
+    reference repeats even batched audio ``batch_size`` times; here only audio without a batch axis is repeated;
   * ``music_cont`` indexes the mask with ``mask[:, cont_start:]`` on dim 1 (generation.py:106), which is a no-op slice of
     a size-1 axis that only works for cont_start == 0; here the time axis is sliced.
 """
