@@ -95,8 +95,8 @@ __global__ __launch_bounds__(1024) void lstm_layer_kernel(const float* __restric
 // Per step: h_t of all sequences is in LDS; every thread forms its partial dot products for the LB sequences (LDS
 // broadcast reads), the k slices are summed through LDS, 32 x LB threads apply the gates, publish h_{t+1} of their
 // units with write-through stores, and one grid barrier (relaxed agent-scope atomics, tools/microbench/gridbar.hip:
-// ~1 us at 16 workgroups) separates the steps.  The spin is bounded: a lost workgroup turns into wrong output plus an
-// error flag, never into a hang.
+// ~1 us at 16 workgroups) separates the steps.  The spin is bounded (2^26 polls, seconds): a workgroup that never
+// becomes resident turns into an error flag that the host side checks (jen1_amd/encodec.py), never into a hang.
 constexpr int LSTM_UPW = 32, LSTM_LB = 8, LSTM_NS = 8;
 
 template <typename T, int KS>    // KS = H / LSTM_NS k values per thread
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1024) void lstm_multi_kernel(const float* __restric
       int spins = 0;
       while (__hip_atomic_load(my_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) { __hip_atomic_store(my_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (++spins > (1 << 26)) { __hip_atomic_store(my_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
     __syncthreads();

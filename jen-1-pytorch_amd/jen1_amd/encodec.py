@@ -110,8 +110,15 @@ class _SEANetOps:
         # jen1_lstm_layer_multi (register-resident W_hh over H / 32 workgroups, one grid barrier per step) unless disabled
         self.lstm_multi = os.environ.get("JEN1_LSTM_MULTI", "1") == "1"
         self.last_lstm_counters: Optional[torch.Tensor] = None
+        self._lstm_flags: List[torch.Tensor] = []
         self.lstm_bias = [(self.p[f"{lstm_name}.lstm.bias_ih_l{l}"] + self.p[f"{lstm_name}.lstm.bias_hh_l{l}"]).contiguous()
                           for l in range(self.n_lstm)]
+
+    def _check_lstm(self) -> None:
+        """raise if a grid barrier of the multi-workgroup LSTM timed out (its workgroups were not co-resident)"""
+        flags, self._lstm_flags = self._lstm_flags, []
+        if flags and int(torch.stack([f[:, 1].sum() for f in flags]).sum()) != 0:
+            raise L.Jen1HipError("jen1_lstm_layer_multi: grid barrier time-out (workgroups not co-resident); set JEN1_LSTM_MULTI=0")
 
     def _to_rows(self, x_bct: torch.Tensor) -> torch.Tensor:
         B, C, T = x_bct.shape
@@ -191,7 +198,8 @@ class _SEANetOps:
                 L.check(rt.lib.jen1_lstm_layer_multi(gin.data_ptr(), self.whh[l].data_ptr(), x.data_ptr() if last else None, y.data_ptr(),
                                                      hbuf.data_ptr(), cnt.data_ptr(), B, T, H, y.shape[-1], dt, rt.stream()),
                         "jen1_lstm_layer_multi")
-                self.last_lstm_counters = cnt        # cnt[:, 1] != 0 would report a barrier time-out (checked by the tests)
+                self.last_lstm_counters = cnt        # cnt[:, 1] != 0 reports a barrier time-out (checked in _check_lstm)
+                self._lstm_flags.append(cnt)
             else:
                 L.check(rt.lib.jen1_lstm_layer(gin.data_ptr(), self.whh_t[l].data_ptr(), x.data_ptr() if last else None, y.data_ptr(), B, T, H,
                                                y.shape[-1], dt, rt.stream()), "jen1_lstm_layer")
@@ -232,7 +240,9 @@ class SEANetDecoderHIP(_SEANetOps):
                 h = self._resblock(h, f"layers.{r}")
         h = self._conv(self._elu(h), f"layers.{self.last}")
         ch = self.p[f"layers.{self.last}.conv.weight"].shape[0]
-        return h[:, :, :ch].to(torch.float32).transpose(1, 2).contiguous().to(src)
+        out = h[:, :, :ch].to(torch.float32).transpose(1, 2).contiguous().to(src)
+        self._check_lstm()
+        return out
 
 
 class SEANetEncoderHIP(_SEANetOps):
@@ -266,7 +276,9 @@ class SEANetEncoderHIP(_SEANetOps):
         h = self._lstm(h)
         h = self._conv(self._elu(h), f"layers.{self.last}")
         ch = self.p[f"layers.{self.last}.conv.weight"].shape[0]
-        return h[:, :, :ch].to(torch.float32).transpose(1, 2).contiguous().to(src)
+        out = h[:, :, :ch].to(torch.float32).transpose(1, 2).contiguous().to(src)
+        self._check_lstm()
+        return out
 
 
 class EncodecHIP:
