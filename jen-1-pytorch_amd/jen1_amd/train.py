@@ -70,6 +70,7 @@ class TrainRuntime:
         self._acc32: Optional[torch.Tensor] = None        # persistent float32 split-K accumulator, zero at rest
         # keep a second, transposed compute copy of every weight so that the data gradient is K-contiguous on both operands
         self.dgrad_copies = os.environ.get("JEN1_TRAIN_DGRAD_COPIES", "1") == "1"
+        self.wgrad_plain_rmw = os.environ.get("JEN1_TRAIN_WGRAD_RMW", "1") == "1"
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
 
@@ -286,8 +287,11 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
         M, N = g.co, g.ci
     sk = rt.pick_splitk(M, N, (K + 31) // 32, z=k)
     fused_bias = gb is not None and g.kind != "convT"
+    # one K slice: every (tap, tile) of the gradient belongs to exactly one workgroup of this launch and launches are
+    # stream-ordered, so a plain read-modify-write accumulates; float atomics only when the K range is split
+    na = sk == 1 and rt.wgrad_plain_rmw
     rt.gemm(a, b, gw.data_ptr(), M, N, K, dtype=dt, taps=k, taps_in_z=True, ldc_m=N * k, ldc_n=k, c_tap_stride=1,
-            splitk=sk, atomic=True, c_f32=True, rowsum=gb if fused_bias else None)
+            splitk=sk, atomic=not na, accumulate=na, c_f32=True, rowsum=gb if fused_bias else None)
     return fused_bias
 
 
