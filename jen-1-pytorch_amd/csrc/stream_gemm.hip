@@ -154,8 +154,13 @@ __device__ __forceinline__ void bload(f32x8& f, __amdgpu_buffer_rsrc_t r, unsign
 #define JEN1_W_AUX 2      // cache policy of the weight stream: nt (each weight byte is used once per launch; measured +7 % end to end)
 #endif
 
+#ifndef JEN1_STREAM_WAVES
+#define JEN1_STREAM_WAVES 4   // waves per workgroup = in-workgroup split of the K chunks (tuning builds: -DJEN1_STREAM_WAVES=8)
+#endif
+constexpr int SG_NW = JEN1_STREAM_WAVES;
+
 template <typename T, int NF, int PF>
-__global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(64 * SG_NW) void stream_gemm_kernel(const StreamArgs a) {
   typedef typename Frag8<T>::type Frag;
   constexpr bool PRECISE = is_f32<T>::value;
   constexpr unsigned ES = sizeof(T);
@@ -163,8 +168,8 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
   constexpr unsigned CHB = 32 * ES;       // bytes of one 32-channel chunk of an activation row
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* misc = reinterpret_cast<int*>(smem);
-  float* red = smem + 4;                   // [3][NF][256]
-  float* st_lds = red + 3 * NF * 256;      // [nb][ngrp fine groups][2]
+  float* red = smem + 4;                   // [SG_NW - 1][NF][256]
+  float* st_lds = red + (SG_NW - 1) * NF * 256;      // [nb][ngrp fine groups][2]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -278,10 +283,10 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
     for (int nf = 0; nf < NF; ++nf) bload<JEN1_X_AUX>(fb[nf], rx, voff[nf], soffB);
     if (!parked) {
       ++issued;
-      cur_g += 4;
+      cur_g += SG_NW;
       if (cur_g < cur_hi) {
-        soffA += 4u * BLK * (unsigned)h.MT;
-        soffB += 4u * CHB;
+        soffA += (unsigned)SG_NW * BLK * (unsigned)h.MT;
+        soffB += (unsigned)SG_NW * CHB;
       } else if (!advance()) {
         // past the end: the ring keeps issuing (the load count per slot must stay fixed for vmcnt),
         // but with out-of-range offsets -- no memory traffic
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
     e = load_epi_args();
     if (owner) request_epilogue_operands();
     if (e.out_gn_stats) {
-      for (int i = tid; i < h.nb * e.ngrp * 2; i += 256) st_lds[i] = 0.f;
+      for (int i = tid; i < h.nb * e.ngrp * 2; i += 64 * SG_NW) st_lds[i] = 0.f;
     }
     SG_STAMP(2);
     if (any) {
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamArgs a) {
   __syncthreads();
   if (owner) {
 #pragma unroll
-    for (int w2 = 0; w2 < 3; ++w2)
+    for (int w2 = 0; w2 < SG_NW - 1; ++w2)
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         const float4 o = *reinterpret_cast<const float4*>(red + (w2 * NF + nf) * 256 + lane * 4);
@@ -536,8 +541,8 @@ template <typename T, int NF, int PF>
 int launch_stream(const StreamArgs& sa, hipStream_t s) {
   const int tiles_b = (sa.hot.B + sa.hot.nb - 1) / sa.hot.nb;
   dim3 grid(sa.hot.MT, sa.hot.tiles_t * tiles_b, sa.splitk);
-  const size_t lds = (size_t)(4 + 3 * NF * 256 + sa.hot.nb * sa.epi.ngrp * 2) * sizeof(float);
-  hipLaunchKernelGGL((stream_gemm_kernel<T, NF, PF>), grid, dim3(256), lds, s, sa);
+  const size_t lds = (size_t)(4 + (SG_NW - 1) * NF * 256 + sa.hot.nb * sa.epi.ngrp * 2) * sizeof(float);
+  hipLaunchKernelGGL((stream_gemm_kernel<T, NF, PF>), grid, dim3(64 * SG_NW), lds, s, sa);
   JEN1_HIP(hipGetLastError());
   return 0;
 }
