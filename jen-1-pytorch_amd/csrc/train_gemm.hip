@@ -455,6 +455,7 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   {
     // register-direct path: K-contiguous operands whose rows start on 16-byte boundaries and whose extents fit the
     // 31-bit offsets of a buffer descriptor; the mapped axis of A may only be its rows; B is a plain matrix per tap
+    static const bool no_direct = getenv("JEN1_TRAIN_GEMM_NO_DIRECT") != nullptr;     // tuning / A-B switch, read once
     const long long es = a.dtype == JEN1_F32 ? 4 : 2;
     const long long vec = 16 / es;
     auto aligned = [&](const jen1_gemm_operand& o) {
@@ -466,7 +467,7 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
     const long long b_span = ((long long)(a.taps - 1) * a.b.tap_stride + (long long)a.N * a.b.ld_r + a.K) * es;
     g.direct = (!a.taps_in_z && a.rowsum == nullptr && aligned(a.a) && aligned(a.b) && a.a.map_axis != 2 && a.b.map_axis == 0 &&
                 a.K % vec == 0 && a.a.tap_stride >= 0 && a.b.tap_stride >= 0 && a_span < (1ll << 31) && b_span < (1ll << 31) &&
-                getenv("JEN1_TRAIN_GEMM_NO_DIRECT") == nullptr) ? 1 : 0;
+                !no_direct) ? 1 : 0;
   }
   dim3 grid((a.M + BM - 1) / BM, gy, (unsigned)gz);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
