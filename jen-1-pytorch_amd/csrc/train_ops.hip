@@ -204,6 +204,147 @@ int zero2(float* a, int na, float* b, int nb, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------- 8-wide variants (rows without padding, groups of a
+// multiple of 8 channels): every thread moves 8 consecutive channels per access (16 bytes in bf16, 2 x 16 in float32)
+// instead of one element -- these kernels are pure streaming, so bytes per instruction is what sets their speed.
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_sums_vec_kernel(const void* x_, float* __restrict__ sums, int L, int C, int groups, int cpg,
+                                                          int CT, int rows_per_block) {
+  const T* x = reinterpret_cast<const T*>(x_);
+  const int b = blockIdx.z, VPR = C >> 3;
+  const int vc = blockIdx.y * CT + threadIdx.x % CT;          // which 8-channel vector of the row
+  const int ty = threadIdx.x / CT, RT = NT / CT;
+  const int t0 = blockIdx.x * rows_per_block, t1 = min(L, t0 + rows_per_block);
+  float s = 0.f, ss = 0.f;
+  if (vc < VPR) {
+    const T* xp = x + (long long)b * L * C + vc * 8;
+    for (int t = t0 + ty; t < t1; t += RT) {
+      float v[8];
+      load8(xp + (long long)t * C, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s += v[j]; ss += v[j] * v[j]; }
+    }
+  }
+  __shared__ float acc[64];
+  const int g_lo = (blockIdx.y * CT * 8) / cpg;
+  for (int i = threadIdx.x; i < 64; i += NT) acc[i] = 0.f;
+  __syncthreads();
+  if (vc < VPR) {
+    const int g = (vc * 8) / cpg, gi = g - g_lo;
+    if (gi < 32) { atomicAdd(&acc[2 * gi], s); atomicAdd(&acc[2 * gi + 1], ss); }
+    else { atomicAdd(&sums[((long long)b * groups + g) * 2], s); atomicAdd(&sums[((long long)b * groups + g) * 2 + 1], ss); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32; i += NT) {
+    const int g = g_lo + i;
+    if (g < groups && (acc[2 * i] != 0.f || acc[2 * i + 1] != 0.f)) {
+      atomicAdd(&sums[((long long)b * groups + g) * 2], acc[2 * i]);
+      atomicAdd(&sums[((long long)b * groups + g) * 2 + 1], acc[2 * i + 1]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_vec_kernel(const GnDev g) {
+  const int VPR = g.C >> 3;
+  const long long total = (long long)g.B * g.L * VPR;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const T* film = reinterpret_cast<const T*>(g.film);
+  T* y = reinterpret_cast<T*>(g.y);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int c0 = (int)(i % VPR) * 8;
+    const long long row = i / VPR;
+    const int b = (int)(row / g.L);
+    float mean, rstd;
+    gn_moments(g, b, c0, mean, rstd);
+    float v[8], ga[8], be[8];
+    load8(x + row * g.C + c0, v);
+    load8(g.gamma + c0, ga);
+    load8(g.beta + c0, be);
+    float sc[8], sh[8];
+    if (film != nullptr) {
+      load8(film + (long long)b * g.film_ld + c0, sc);
+      load8(film + (long long)b * g.film_ld + g.C + c0, sh);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float n = (v[j] - mean) * rstd * ga[j] + be[j];
+      if (film != nullptr) n = n * (sc[j] + 1.0f) + sh[j];
+      if (g.flags & 1) n = silu_precise(n);
+      v[j] = n;
+    }
+    store8(y + row * g.C + c0, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_dx_vec_kernel(const GnDev g, void* dx_) {
+  T* dx = reinterpret_cast<T*>(dx_);
+  const int VPR = g.C >> 3;
+  const long long total = (long long)g.B * g.L * VPR;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const T* dy = reinterpret_cast<const T*>(g.dy);
+  const T* film = reinterpret_cast<const T*>(g.film);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int c0 = (int)(i % VPR) * 8;
+    const long long row = i / VPR;
+    const int b = (int)(row / g.L);
+    float mean, rstd;
+    gn_moments(g, b, c0, mean, rstd);
+    const float* gm = g.Gm + ((long long)b * g.groups + c0 / g.cpg) * 2;
+    const float m1 = gm[0], m2 = gm[1];
+    float v[8], d[8], ga[8], be[8], sc[8], sh[8];
+    load8(x + row * g.C + c0, v);
+    load8(dy + row * g.C + c0, d);
+    load8(g.gamma + c0, ga);
+    load8(g.beta + c0, be);
+    if (film != nullptr) {
+      load8(film + (long long)b * g.film_ld + c0, sc);
+      load8(film + (long long)b * g.film_ld + g.C + c0, sh);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (v[j] - mean) * rstd;
+      const float s1 = film != nullptr ? sc[j] + 1.0f : 1.0f, s0 = film != nullptr ? sh[j] : 0.f;
+      float df = d[j];
+      if (g.flags & 1) df *= silu_grad((xh * ga[j] + be[j]) * s1 + s0);
+      v[j] = rstd * (df * s1 * ga[j] - m1 - xh * m2);
+    }
+    store8(dx + row * g.C + c0, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void act_fwd_vec_kernel(const void* x_, void* y_, long long n8, int mode) {
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* y = reinterpret_cast<T*>(y_);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n8; i += (long long)gridDim.x * NT) {
+    float v[8];
+    load8(x + 8 * i, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = mode == 0 ? gelu_erf(v[j]) : mode == 1 ? silu_precise(v[j]) : (v[j] > 0.f ? v[j] : expm1f(v[j]));
+    store8(y + 8 * i, v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void act_bwd_vec_kernel(const void* dy_, const void* x_, void* dx_, long long n8, int mode) {
+  const T* dy = reinterpret_cast<const T*>(dy_);
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* dx = reinterpret_cast<T*>(dx_);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n8; i += (long long)gridDim.x * NT) {
+    float v[8], d[8];
+    load8(x + 8 * i, v);
+    load8(dy + 8 * i, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] *= mode == 0 ? gelu_grad(v[j]) : mode == 1 ? silu_grad(v[j]) : (v[j] > 0.f ? 1.f : expf(v[j]));
+    store8(dx + 8 * i, d);
+  }
+}
+
+__host__ bool vec_ok(const void* p0, const void* p1, const void* p2, int C, int ld, int cpg) {
+  return ld == C && (C & 7) == 0 && (cpg & 7) == 0 && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0;
+}
+
 void red_geom(int C, int L, int& CT, int& rows_per_block, int& gx, int& gy) {
   CT = 256;
   while (CT > 1 && CT / 2 >= C) CT /= 2;      // smallest power of two >= C, capped at 256
@@ -409,6 +550,11 @@ extern "C" int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (zero2(sums, 2 * B * groups, nullptr, 0, s)) return 1;
   int CT, rpb, gx, gy;
+  if (vec_ok(x, nullptr, nullptr, C, ld, C / groups)) {
+    red_geom(C / 8, L, CT, rpb, gx, gy);
+    DISPATCH(dtype, gn_sums_vec_kernel, dim3(gx, gy, B), x, sums, L, C, groups, C / groups, CT, rpb);
+    return 0;
+  }
   red_geom(C, L, CT, rpb, gx, gy);
   DISPATCH(dtype, gn_sums_kernel, dim3(gx, gy, B), x, sums, L, C, ld, groups, C / groups, CT, rpb);
   return 0;
@@ -422,6 +568,11 @@ extern "C" int jen1_gn_apply(const void* x, const float* sums, const float* gamm
   JEN1_CHECK(y != nullptr, "jen1_gn_apply: y is NULL");
   g.y = y;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool film_ok = film == nullptr || ((film_ld & 7) == 0 && ((uintptr_t)film & 15) == 0);
+  if (film_ok && vec_ok(x, y, nullptr, C, ld, C / groups) && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
+    DISPATCH(dtype, gn_apply_vec_kernel, dim3(ew_grid((long long)B * L * C / 8)), g);
+    return 0;
+  }
   DISPATCH(dtype, gn_apply_kernel, dim3(ew_grid((long long)B * L * C)), g);
   return 0;
 }
@@ -442,6 +593,11 @@ extern "C" int jen1_gn_backward(const void* dy, const void* x, const float* sums
   DISPATCH(dtype, gn_bwd_sums_kernel, dim3(gx, gy, B), g, CT, rpb);
   hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(B * groups + (C + 63) / 64), dim3(64), 0, s, g);
   JEN1_HIP(hipGetLastError());
+  const bool film_ok = film == nullptr || ((film_ld & 7) == 0 && ((uintptr_t)film & 15) == 0);
+  if (film_ok && vec_ok(x, dy, dx, C, ld, C / groups) && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
+    DISPATCH(dtype, gn_bwd_dx_vec_kernel, dim3(ew_grid((long long)B * L * C / 8)), g, dx);
+    return 0;
+  }
   DISPATCH(dtype, gn_bwd_dx_kernel, dim3(ew_grid((long long)B * L * C)), g, dx);
   return 0;
 }
@@ -472,6 +628,10 @@ extern "C" int jen1_act_forward(const void* x, void* y, int64_t n, int mode, int
   if (check_dtype(dtype, "jen1_act_forward")) return 1;
   JEN1_CHECK(x && y && n >= 1 && mode >= 0 && mode <= 2, "jen1_act_forward: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if ((n & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    DISPATCH(dtype, act_fwd_vec_kernel, dim3(ew_grid(n / 8)), x, y, (long long)(n / 8), mode);
+    return 0;
+  }
   DISPATCH(dtype, act_fwd_kernel, dim3(ew_grid(n)), x, y, (long long)n, mode);
   return 0;
 }
@@ -480,6 +640,10 @@ extern "C" int jen1_act_backward(const void* dy, const void* x, void* dx, int64_
   if (check_dtype(dtype, "jen1_act_backward")) return 1;
   JEN1_CHECK(dy && x && dx && n >= 1 && mode >= 0 && mode <= 2, "jen1_act_backward: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if ((n & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+    DISPATCH(dtype, act_bwd_vec_kernel, dim3(ew_grid(n / 8)), dy, x, dx, (long long)(n / 8), mode);
+    return 0;
+  }
   DISPATCH(dtype, act_bwd_kernel, dim3(ew_grid(n)), dy, x, dx, (long long)n, mode);
   return 0;
 }
