@@ -111,7 +111,8 @@ int jen1_lstm_layer(const float* gin, const void* whh_t, const void* skip, void*
                     void* stream);
 /* The same layer spread over H / 32 workgroups per group of 8 sequences, the slice of W_hh of every workgroup resident in
  * registers and one grid barrier per step (needs all workgroups co-resident: nothing else may occupy the GPU's CUs).
- * whh [4H][H] (NOT transposed) in `dtype`; hbuf: float32 scratch [groups][2][8][H]; counters: uint32 [groups][32], ZERO on
+ * (bf16, H = 512, B > 1: the recurrent product runs on the matrix cores, 16 sequences per group, h split into bf16 high + low.)
+ * whh [4H][H] (NOT transposed) in `dtype`; hbuf: float32 scratch [ceil(B / 8)][2][16][H]; counters: uint32 [ceil(B / 8)][32], ZERO on
  * entry; counters[g * 32 + 1] != 0 afterwards reports a barrier time-out (output invalid). */
 int jen1_lstm_layer_multi(const float* gin, const void* whh, const void* skip, void* y, float* hbuf, uint32_t* counters, int B, int T,
                           int H, int ld_y, int dtype, void* stream);

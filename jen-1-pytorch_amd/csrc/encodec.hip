@@ -185,6 +185,109 @@ __global__ __launch_bounds__(1024) void lstm_multi_kernel(const float* __restric
   }
 }
 
+// ---- the same layer with the recurrent product on the matrix cores (bf16 weights) -----------------------------------
+// Workgroup w owns the same 128 gate rows; wave v holds the MFMA A fragments of row tile v % 8 for the K half v / 8
+// (8 fragments = 32 VGPRs, resident for the whole sequence).  Up to 16 sequences are the 16 MFMA columns.  h_t stays
+// float32 in the exchange buffer and is split into a bf16 high and low part when it is staged into LDS (two MFMAs per
+// fragment), so the recurrence sees h at ~16 mantissa bits while the weights are the bf16 ones of the bf16 mode.
+constexpr int LSTM_MB = 16;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void lstm_multi_mfma_kernel(const float* __restrict__ gin, const bf16_t* __restrict__ whh,
+                                                               const bf16_t* __restrict__ skip, bf16_t* __restrict__ y, float* hbuf,
+                                                               unsigned* ctr, int B, int Tn, int H, int ld_y) {
+  // H == 512 (checked by the launcher): K halves of 256 = 8 MFMA steps of 32
+  __shared__ __attribute__((aligned(16))) bf16_t h_hi[LSTM_MB][512 + 8];
+  __shared__ __attribute__((aligned(16))) bf16_t h_lo[LSTM_MB][512 + 8];
+  __shared__ float part[8][64][4];
+  __shared__ float gates[LSTM_MB][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = gridDim.x, w = blockIdx.x, grp = blockIdx.y;
+  const int b0 = grp * LSTM_MB, nb = min(LSTM_MB, B - b0);
+  const int rt = wave & 7, kh = wave >> 3;
+  // gate rows of tile rt: rl = rt * 16 + i  ->  gate rl / 32, unit rl % 32
+  const int rl_a = rt * 16 + (lane & 15);
+  const int grow_a = (rl_a >> 5) * H + w * LSTM_UPW + (rl_a & 31);
+  bf16x8 wf[8];
+#pragma unroll
+  for (int s2 = 0; s2 < 8; ++s2)
+    wf[s2] = *reinterpret_cast<const bf16x8*>(whh + (long long)grow_a * H + kh * 256 + s2 * 32 + (lane >> 4) * 8);
+  float* hb = hbuf + (long long)grp * 2 * LSTM_MB * H;
+  unsigned* my_ctr = ctr + grp * 32;
+  unsigned epoch = 0;
+  float c = 0.f;
+  const int u2 = tid & 31, b2 = tid >> 5;           // unit / sequence of the update threads (tid < 32 * 16 = 512)
+  for (int i = tid; i < LSTM_MB * (512 + 8); i += 1024) { (&h_hi[0][0])[i] = (bf16_t)0.f; (&h_lo[0][0])[i] = (bf16_t)0.f; }
+  __syncthreads();
+  for (int t = 0; t < Tn; ++t) {
+    // input projection of the 4 gate rows x 1 sequence this lane will own after the reduction (waves 0..7)
+    const int col = lane & 15;
+    const int rl0 = rt * 16 + (lane >> 4) * 4;
+    const int grow0 = (rl0 >> 5) * H + w * LSTM_UPW + (rl0 & 31);
+    float4 g_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kh == 0 && col < nb) g_in = *reinterpret_cast<const float4*>(gin + ((long long)(b0 + col) * Tn + t) * (4 * H) + grow0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const int k = kh * 256 + s2 * 32 + (lane >> 4) * 8;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&h_hi[col][k]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&h_lo[col][k]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2], bl, acc, 0, 0, 0);
+    }
+    if (kh == 1) *reinterpret_cast<float4*>(&part[rt][lane][0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (kh == 0) {
+      const float4 o = *reinterpret_cast<const float4*>(&part[rt][lane][0]);
+      if (col < nb) {
+        gates[col][rl0 + 0] = acc[0] + o.x + g_in.x;
+        gates[col][rl0 + 1] = acc[1] + o.y + g_in.y;
+        gates[col][rl0 + 2] = acc[2] + o.z + g_in.z;
+        gates[col][rl0 + 3] = acc[3] + o.w + g_in.w;
+      }
+    }
+    __syncthreads();
+    float* hnext = hb + (long long)((t + 1) & 1) * LSTM_MB * H;
+    if (tid < 32 * LSTM_MB && b2 < nb) {
+      const float ig = sigmoid_f(gates[b2][u2]), fg = sigmoid_f(gates[b2][32 + u2]), gg = tanhf(gates[b2][64 + u2]), og = sigmoid_f(gates[b2][96 + u2]);
+      c = fg * c + ig * gg;
+      const float hn = og * tanhf(c);
+      const int j = w * LSTM_UPW + u2;
+      __hip_atomic_store(hnext + b2 * H + j, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long o = ((long long)(b0 + b2) * Tn + t) * ld_y + j;
+      y[o] = (bf16_t)(hn + (skip != nullptr ? (float)skip[o] : 0.f));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      ++epoch;
+      __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = epoch * NW;
+      int spins = 0;
+      while (__hip_atomic_load(my_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 26)) { __hip_atomic_store(my_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < Tn) {
+      // restage h_{t+1}: 16-byte sc1 loads (nb * 512 floats = nb * 128 vectors), split into bf16 high + low
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hnext, 0, LSTM_MB * 512 * 4, 0x00020000);
+      for (int i = tid; i < nb * 128; i += 1024) {
+        const int b = i >> 7, j = (i & 127) * 4;
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rh, (unsigned)(b * 512 + j) * 4u, 0, 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float hv = __uint_as_float(q[e]);
+          const bf16_t hi = (bf16_t)hv;
+          h_hi[b][j + e] = hi;
+          h_lo[b][j + e] = (bf16_t)(hv - (float)hi);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int jen1_rvq_decode(const int64_t* codes, const float* tables, float* out, int n_q, int B, int T, int bins, int D, void* stream) {
@@ -202,9 +305,18 @@ extern "C" int jen1_lstm_layer_multi(const float* gin, const void* whh, const vo
   JEN1_CHECK(gin && whh && y && hbuf && counters, "jen1_lstm_layer_multi: NULL argument");
   JEN1_CHECK(B >= 1 && T >= 1 && ld_y >= H, "jen1_lstm_layer_multi: bad shape B=%d T=%d H=%d ld_y=%d", B, T, H, ld_y);
   JEN1_CHECK(H == 256 || H == 512 || H == 1024, "jen1_lstm_layer_multi: H must be 256, 512 or 1024");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == JEN1_BF16 && H == 512 && B > 1) {
+    // matrix-core variant: 16 sequences per group (hbuf / counters are sized for 8 per group by the caller: half as many groups)
+    const int groups16 = (B + LSTM_MB - 1) / LSTM_MB;
+    JEN1_CHECK(groups16 * (H / LSTM_UPW) <= 256, "jen1_lstm_layer_multi: too many workgroups to be co-resident");
+    hipLaunchKernelGGL(lstm_multi_mfma_kernel, dim3(H / LSTM_UPW, groups16), dim3(1024), 0, s, gin, reinterpret_cast<const bf16_t*>(whh),
+                       reinterpret_cast<const bf16_t*>(skip), reinterpret_cast<bf16_t*>(y), hbuf, counters, B, T, H, ld_y);
+    JEN1_HIP(hipGetLastError());
+    return 0;
+  }
   const int groups = (B + LSTM_LB - 1) / LSTM_LB, nw = H / LSTM_UPW;
   JEN1_CHECK(groups * nw <= 256, "jen1_lstm_layer_multi: %d workgroups must be co-resident (at most 256)", groups * nw);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(nw, groups);
 #define JEN1_LSTMM(TT, KS) hipLaunchKernelGGL((lstm_multi_kernel<TT, KS>), grid, dim3(1024), 0, s, gin, whh, skip, y, hbuf, counters, B, T, H, ld_y)
   if (dtype == JEN1_F32) { if (H == 256) JEN1_LSTMM(float, 32); else if (H == 512) JEN1_LSTMM(float, 64); else JEN1_LSTMM(float, 128); }

@@ -193,7 +193,7 @@ class _SEANetOps:
             last = l == self.n_lstm - 1
             groups = (B + 7) // 8
             if self.lstm_multi and groups * (H // 32) <= 256:
-                hbuf = torch.empty((groups, 2, 8, H), dtype=torch.float32, device=x.device)
+                hbuf = torch.empty((groups, 2, 16, H), dtype=torch.float32, device=x.device)
                 cnt = torch.zeros((groups, 32), dtype=torch.int32, device=x.device)
                 L.check(rt.lib.jen1_lstm_layer_multi(gin.data_ptr(), self.whh[l].data_ptr(), x.data_ptr() if last else None, y.data_ptr(),
                                                      hbuf.data_ptr(), cnt.data_ptr(), B, T, H, y.shape[-1], dt, rt.stream()),

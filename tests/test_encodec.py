@@ -137,6 +137,18 @@ def test_hip_lstm_multi_many_sequences_and_long():
         b = dec._lstm(x)
         torch.cuda.synchronize()
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, (B, T)
+    # bf16 mode with more than one sequence: the recurrent product runs on the matrix cores (16 sequences per group,
+    # h split into bf16 high + low); against the float32 single-workgroup kernel on the same (bf16-rounded) input
+    dec16 = SEANetDecoderHIP({k: torch.from_numpy(v) for k, v in _params().items()}, compute_dtype="bf16")
+    for B, T in ((2, 64), (11, 40), (20, 33), (3, 700)):
+        x = (torch.randn((B, T, 512), device="cuda") * 0.5).to(torch.bfloat16)
+        dec16.lstm_multi = True
+        a = dec16._lstm(x)
+        assert int(dec16.last_lstm_counters[:, 1].sum()) == 0
+        dec.lstm_multi = False
+        b = dec._lstm(x.float())
+        torch.cuda.synchronize()
+        assert rel_err(a.float().cpu().numpy(), b.cpu().numpy()) < 2e-2, (B, T)
 
 
 @pytest.mark.gpu
