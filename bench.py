@@ -275,8 +275,30 @@ def encodec_decode_bench(B, T, dtype, device):
     y = dec(emb)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"what": f"SEANet decoder, {B} x 128x{T} latents -> {tuple(y.shape)} samples", "ms": round(dt * 1e3, 1),
-            "audio_seconds_per_second": round(B * y.shape[-1] / 48000 / dt, 1)}
+    out = {"what": f"SEANet decoder, {B} x 128x{T} latents -> {tuple(y.shape)} samples", "ms": round(dt * 1e3, 1),
+           "audio_seconds_per_second": round(B * y.shape[-1] / 48000 / dt, 1)}
+    # the way in (generation.py:146, dataloader.py:106-114): EncodecModel.encode's segment loop + get_emb's RVQ decode
+    from jen1_amd.encodec import EncodecHIP, ResidualVectorQuantizerHIP, SEANetEncoderHIP
+    from jen1_amd.init_fill import fill_normal
+    esch = _json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "encodec.npz"))["enc_schema"]))
+    enc = SEANetEncoderHIP({k: torch.from_numpy(fill("encodec.encoder." + k, tuple(sh), 1234)) for k, sh in esch}, compute_dtype=dtype, device=device)
+    quant = ResidualVectorQuantizerHIP(torch.from_numpy(np.stack([fill_normal(f"encodec.quantizer.layers.{i}.codebook.embed", (1024, 128), 1234)
+                                                                   for i in range(16)])), device=device)
+    model = EncodecHIP(dec, quant, encoder=enc)
+    audio = torch.randn((B, 2, 320 * T), device=device) * 0.1
+
+    def get_emb():
+        frames = model.encode(audio)
+        return quant.decode(torch.cat([f[0] for f in frames], dim=-1).transpose(0, 1))
+    get_emb()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e = get_emb()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["encode"] = {"what": f"encode + quantizer.decode (get_emb), {tuple(audio.shape)} samples -> {tuple(e.shape)} latents, 16 codebooks",
+                     "ms": round(dt * 1e3, 1), "audio_seconds_per_second": round(B * audio.shape[-1] / 48000 / dt, 1)}
+    return out
 
 
 def cpu_baseline(B, T, tiny):
