@@ -33,6 +33,7 @@ struct GemmDev {
   int a_zdiv, b_zdiv, c_zdiv;
   int M, N, K, taps, taps_in_z, splitk, atomic, accumulate, c_f32;
   int direct;        // both operands K-contiguous, fragments straight from global memory (no LDS staging)
+  int tall;          // direct path only: the 4 waves stack along M (tile 128 x 32) because N <= 32
   float alpha;
 };
 
@@ -304,8 +305,8 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
   __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
   jen1_prefetch_kernarg<sizeof(GemmDev)>();      // one batch of scalar loads instead of one round trip per argument line
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wm = g.tall ? wave : wave >> 1, wn = g.tall ? 0 : wave & 1;
+  const int m0 = blockIdx.x * (g.tall ? 2 * BM : BM), n0 = blockIdx.y * (g.tall ? BN / 2 : BN);
   int z = blockIdx.z;
   const int split = z % g.splitk;
   z /= g.splitk;
@@ -469,7 +470,10 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
                 a.K % vec == 0 && a.a.tap_stride >= 0 && a.b.tap_stride >= 0 && a_span < (1ll << 31) && b_span < (1ll << 31) &&
                 !no_direct) ? 1 : 0;
   }
-  dim3 grid((a.M + BM - 1) / BM, gy, (unsigned)gz);
+  // narrow outputs (N <= 32, e.g. the last stages of the SEANet decoder): in the 2 x 2 wave layout half of the waves
+  // would only multiply padding; on the direct path the four waves stack along M instead
+  g.tall = (g.direct && a.N <= 32) ? 1 : 0;
+  dim3 grid(g.tall ? (a.M + 2 * BM - 1) / (2 * BM) : (a.M + BM - 1) / BM, g.tall ? 1 : gy, (unsigned)gz);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a.dtype == JEN1_F32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);
   else hipLaunchKernelGGL(train_gemm_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
