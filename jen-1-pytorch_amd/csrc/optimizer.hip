@@ -3,7 +3,8 @@
 //   (/root/reference/trainer.py:144-149, /root/reference/train.py:56-60: lr 3e-5, betas (0.9, 0.95), weight_decay 0.1,
 //    one parameter group: the decay applies to every parameter).
 // Elementwise over 296.5 M float32 parameters + gradient + two moments: 28 bytes per parameter, purely HBM-bound.
-//   jen1_grad_sqnorm : sum of squares of the flat gradient -> one device float (block partials + one atomic per block)
+//   jen1_grad_sqnorm : sum of squares of the flat gradient -> one device float (block partials, summed in a fixed order by
+//                      the last block to arrive: bit-reproducible, so data-parallel replicas clip identically)
 //   jen1_adamw_step  : reads that device scalar, so clip + AdamW is ONE pass with no host synchronisation:
 //                      g' = g * min(1, max_norm / (||g|| + 1e-6));  p *= 1 - lr wd;  m, v updates;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 //   A non-finite gradient norm skips the step (GradScaler semantics of trainer.py:147 when fp16 is on).
@@ -20,8 +21,16 @@ __device__ __forceinline__ float4 nt_load4(const float4* p) {
 constexpr int OPT_THREADS = 256;
 constexpr int OPT_VEC_PER_THREAD = 4;        // float4 vectors per thread per grid-stride pass
 
+// Deterministic: block partials go to a fixed slot each, the last block to arrive sums the slots in a fixed order.
+// (With one float atomic per block the sum depended on the arrival order, the clip coefficient differed in its last
+// bits from run to run -- and between the ranks of a data-parallel job, whose replicas then drift apart.)
+constexpr int OPT_MAX_BLOCKS = 4096;
+__device__ float g_sq_partials[OPT_MAX_BLOCKS];
+__device__ unsigned g_sq_ticket;
+
 __global__ __launch_bounds__(OPT_THREADS) void grad_sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
   __shared__ float red[OPT_THREADS / 64];
+  __shared__ int last_s;
   const int64_t nv = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(g);
   float s = 0.f;
@@ -48,7 +57,28 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sqnorm_kernel(const float* _
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < OPT_THREADS / 64; ++w) t += red[w];
-    atomicAdd(out, t);
+    __hip_atomic_store(&g_sq_partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(&g_sq_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = (ticket == gridDim.x - 1) ? 1 : 0;
+    if (last_s) __hip_atomic_store(&g_sq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last_s) return;
+  // the last block: fixed-order sum of the gridDim.x partials (thread t takes slots t, t + 256, ...; then a fixed tree)
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += OPT_THREADS)
+    t += __hip_atomic_load(&g_sq_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < OPT_THREADS / 64; ++w) tot += red[w];
+    out[0] += tot;
   }
 }
 

@@ -7,6 +7,7 @@ reference's own ``training_loosses(...).backward()`` produced (tests/golden/make
 Tolerances: float32 mode <= 1e-3 of the largest reference entry (BASELINE.json); bf16 mode 5e-2, stated per test.
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -562,3 +563,75 @@ def test_training_overfits_one_batch():
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     assert min(losses[20:]) < min(losses[:5])
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.init_fill import fill_uniform
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW, allreduce_gradients
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        betas, _ = get_beta_schedule("linear", 1000)
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                               embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+        B, T = 2, 300
+        cond = {k: dev(v) for k, v in synth.conditioning(B, T, "music_inpaint").items()}
+
+        def grads_of(model, opt, r):
+            x0 = dev(synth.latents(B, T, key=f"clip{r}"))
+            noise = dev(fill_uniform(f"synth.trainnoise.ddp{r}", (B, 128, T), 3, 0.0, 1.0))
+            t = torch.tensor([100 + 50 * r, 900 - 70 * r], dtype=torch.long, device="cuda")
+            loss = gd.training_loosses(model.train_graph("f32"), x0, t, cond, noise=noise, causal=False)
+            loss.backward()
+
+        model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+        model.train()
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        opt.zero_grad()
+        grads_of(model, opt, rank)                       # every rank its own clips / timesteps / noise (train.py:88-89)
+        allreduce_gradients(opt.flat_grad)               # the exchange: mean over ranks, once per optimiser step
+        opt.step()
+        torch.cuda.synchronize()
+        mine = opt.flat_param.detach().cpu()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        out = {"same": bool(all(torch.equal(gathered[0], g_) for g_ in gathered))}
+        if rank == 0:                                     # single-process restatement: accumulate both ranks' gradients, halve
+            ref = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+            ref.train()
+            ropt = FusedAdamW(ref.parameters(), lr=1e-3)
+            ropt.zero_grad()
+            for r in range(world):
+                grads_of(ref, ropt, r)
+            ropt.flat_grad.mul_(1.0 / world)
+            ropt.step()
+            torch.cuda.synchronize()
+            d = (ropt.flat_param.detach().cpu() - mine).abs().max().item()
+            out["err"] = d / ropt.flat_param.abs().max().item()
+            out["moved"] = (mine - torch.from_numpy(np.zeros(1, dtype=np.float32))).abs().max().item() > 0
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_gloo():
+    """two processes (gloo; both on this one GPU), each with its own data; after the gradient
+    all-reduce + clip + AdamW both hold bit-identical parameters, equal to a single process that averages the two gradients"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["same"] and res[1]["same"]
+    assert res[0]["err"] < 1e-5, res[0]

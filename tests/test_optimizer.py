@@ -159,3 +159,21 @@ def test_fused_adamw_skips_nonfinite_and_large_buffer():
     v = 0.05 * (g * coef) ** 2
     want = before * (1 - 3e-5 * 0.1) - (3e-5 / (1 - 0.9 ** 2)) * m / (v.sqrt() / (1 - 0.95 ** 2) ** 0.5 + 1e-8)
     assert float((p.detach() - want).abs().max()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_gradient_norm_is_bit_reproducible():
+    """clip_grad_norm_'s norm (jen1_grad_sqnorm) must not depend on the arrival order of the blocks: data-parallel
+    replicas compute it independently and have to clip identically"""
+    from jen1_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.zeros(5_000_003, device="cuda"))
+    opt = FusedAdamW([p], lr=0.0, weight_decay=0.0, max_norm=0.7)
+    p.grad.normal_(0, 1e-2)
+    vals = []
+    for _ in range(6):
+        opt.step()
+        torch.cuda.synchronize()
+        vals.append(opt._gnorm_sq.clone())
+    assert all(torch.equal(vals[0], v) for v in vals)
+    ref = float((p.grad.double() ** 2).sum())
+    assert abs(float(vals[0]) - ref) <= 1e-5 * ref
