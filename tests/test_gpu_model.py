@@ -294,3 +294,40 @@ def test_text_conditioner_tail_projection_and_mask():
         assert m is mask and emb.dtype == torch.float32
         assert rel_err(emb.cpu().numpy(), ref.cpu().numpy()) < tol
         assert float(emb[0, 5:].abs().max()) == 0.0
+
+
+def test_independent_batches_in_flight_match_solo_runs(tiny_models):
+    """serving mode (bench.py extra.concurrent_batches): samplers of the same shape with different ``plan_slot`` own separate
+    buffers, so several batches can be in flight on different streams; each must end exactly where it ends when run alone"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    B, T, S = 2, 300, 6
+    betas, _ = get_beta_schedule("linear", 1000)
+    m = tiny_models["f32"]
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                           embedding_scale=0.8, batch_cfg=True, scale_cfg=True, sampling_timesteps=S)
+    conds = [{k: dev(v) for k, v in synth.conditioning(B, T, task).items()} for task in ("text_guided", "music_inpaint", "music_cont")]
+    inits = [dev(n) for n in synth.noise_list(3, (B, 128, T), seed=21)]
+    noises = [dev(n) for n in synth.noise_list(S, (B, 128, T), seed=22)]
+
+    def solo(i):
+        st = gd.stepper(m, (B, 128, T), conds[i], causal=False, use_graph=True, plan_slot=10 + i)
+        st.reset(inits[i], fresh_noise=False)
+        for k in range(S):
+            st.step(k, noise=noises[k])
+        torch.cuda.synchronize()
+        return st, st.x.clone()
+
+    sts, want = zip(*[solo(i) for i in range(3)])
+    assert sts[0].plan is not sts[1].plan and sts[0].plan.x_in.data_ptr() != sts[1].plan.x_in.data_ptr()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for i, st in enumerate(sts):
+        st.reset(inits[i], fresh_noise=False)
+    torch.cuda.synchronize()
+    for k in range(S):                                   # interleave the three trajectories step by step on three streams
+        for st, s in zip(sts, streams):
+            with torch.cuda.stream(s):
+                st.step(k, noise=noises[k])
+    torch.cuda.synchronize()
+    for i, st in enumerate(sts):
+        assert rel_err(st.x.cpu().numpy(), want[i].cpu().numpy()) < 1e-4, i
+    assert rel_err(want[0].cpu().numpy(), want[1].cpu().numpy()) > 1e-2      # the three really are different trajectories
