@@ -354,6 +354,90 @@ def gen_full():
     save("full_unet", **out)
 
 
+def _hook_taps(model, taps):
+    def hook(name):
+        def f(_m, _i, o):
+            o = o[0] if isinstance(o, tuple) else o
+            taps[name] = np.array([o.norm().item(), o.abs().max().item(), o.shape[-1]], dtype=np.float64)
+        return f
+    hs = [model.to_in.register_forward_hook(hook("to_in"))]
+    for i, d in enumerate(model.downsamples):
+        hs.append(d.register_forward_hook(hook(f"down{i}")))
+    hs.append(model.bottleneck.register_forward_hook(hook("bottleneck")))
+    for i, u in enumerate(model.upsamples):
+        hs.append(u.register_forward_hook(hook(f"up{i}")))
+    return hs
+
+
+def gen_full_bench():
+    """The exact shapes bench.py times (BASELINE configs[1], [2], [4]) through the reference: full model at B=8, T=1500
+    without CFG and with the CFG pair (2B = 16), B=1, T=9000 for the continuation (causal) and inpaint tasks, a 10-step
+    DDIM at the full configuration (B=2) and a 2-step DDIM at B=8 with and without the CFG pair.  Outputs are sub-sampled
+    along T; per-level norms are kept for the forwards."""
+    cfg = full_model_config()
+    model, spec = _build(cfg)
+    out = {}
+    taps = {}
+    _hook_taps(model, taps)
+    # ---- configs[1] / [2]: B = 8, T = 1500 --------------------------------------------------------------------
+    B, T_ = 8, 1500
+    x, cond = _inputs(B, T_)
+    t = torch.tensor([999, 989, 499, 259, 129, 59, 9, 0], dtype=torch.long)
+    out["B8.t"] = t.numpy()
+    kw = dict(embedding=T(cond["cross_attn_cond"]), embedding_mask=T(cond["cross_attn_masks"]), embedding_mask_proba=0.0,
+              channels_list=[T(cond["input_concat_cond"])], features=None)
+    y = model(T(x), t, embedding_scale=1.0, causal=False, **kw)
+    out["B8.y.nocfg"] = y.numpy()[:, :, ::16]
+    for k, v in taps.items():
+        out[f"B8.tap.nocfg.{k}"] = v
+    taps.clear()
+    y = model(T(x), t, embedding_scale=0.8, batch_cfg=True, scale_cfg=True, causal=False, **kw)
+    out["B8.y.cfg"] = y.numpy()[:, :, ::16]
+    for k, v in taps.items():
+        out[f"B8.tap.cfg.{k}"] = v
+    taps.clear()
+    # ---- configs[4]: B = 1, T = 9000, continuation (causal) and inpaint (non-causal) -------------------------------
+    B, T_ = 1, 9000
+    t1 = torch.tensor([499], dtype=torch.long)
+    for task, causal in (("music_cont", True), ("music_inpaint", False)):
+        x, cond = _inputs(B, T_, task)
+        kw = dict(embedding=T(cond["cross_attn_cond"]), embedding_mask=T(cond["cross_attn_masks"]), embedding_mask_proba=0.0,
+                  channels_list=[T(cond["input_concat_cond"])], features=None)
+        y = model(T(x), t1, embedding_scale=0.8, batch_cfg=True, scale_cfg=True, causal=causal, **kw)
+        out[f"T9000.y.{task}"] = y.numpy()[:, :, ::24]
+        out[f"T9000.y.{task}.norm"] = np.array([y.norm().item(), y.abs().max().item()])
+        for k, v in taps.items():
+            out[f"T9000.tap.{task}.{k}"] = v
+        taps.clear()
+    # ---- DDIM through the reference sampler with injected noise ----------------------------------------------------------
+    betas, _ = get_beta_schedule("linear", 1000)
+
+    def ddim(B, T_, S, scale, causal=False, task="text_guided"):
+        _, cond = _inputs(B, T_, task)
+        cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+        shape = (B, 128, T_)
+        init = synth.noise_list(1, shape, seed=7)[0]
+        noises = synth.noise_list(S, shape, seed=11)
+        gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective="noise", loss_type="l2", device="cpu",
+                               cfg_dropout_proba=0.0, embedding_scale=scale, batch_cfg=True, scale_cfg=True,
+                               sampling_timesteps=S)
+        it = iter([T(init)] + [T(n) for n in noises])
+        r_randn, r_randn_like = torch.randn, torch.randn_like
+        torch.randn = lambda *a, **k: next(it).clone()
+        torch.randn_like = lambda *a, **k: next(it).clone()
+        try:
+            y = gd.sample(model, shape, cond_t, causal=causal)
+        finally:
+            torch.randn, torch.randn_like = r_randn, r_randn_like
+        return y.numpy()
+
+    out["ddim10.B2.cfg"] = ddim(2, 1500, 10, 0.8)[:, :, ::8]
+    out["ddim2.B8.cfg"] = ddim(8, 1500, 2, 0.8)[:, :, ::16]
+    out["ddim2.B8.nocfg"] = ddim(8, 1500, 2, 1.0)[:, :, ::16]
+    out["ddim2.T9000.cont"] = ddim(1, 9000, 2, 0.8, causal=True, task="music_cont")[:, :, ::24]
+    save("full_bench", **out)
+
+
 def gen_full_train():
     """full configuration, one clip through the CFG pair: loss + every parameter's gradient from the reference's autograd"""
     cfg = full_model_config()
@@ -432,7 +516,7 @@ def gen_encodec():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fulltrain", "encodec"}
+    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fullbench", "fulltrain", "encodec"}
     model = None
     if "schedule" in which:
         print("schedule"); gen_schedule()
@@ -446,6 +530,8 @@ if __name__ == "__main__":
         print("train"); gen_tiny_train(model)
     if "full" in which:
         print("full"); gen_full()
+    if "fullbench" in which:
+        print("fullbench"); gen_full_bench()
     if "fulltrain" in which:
         print("fulltrain"); gen_full_train()
     if "encodec" in which:

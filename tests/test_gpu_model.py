@@ -236,22 +236,91 @@ def test_full_unet_bf16_reported_error():
     assert e < BF16_TOL
 
 
-def test_full_unet_long_sequence_T9000(full_model_f32):
-    """BASELINE configs[4] shape (B=1, 128x9000: self-attention over 141 positions, 6x the conv work): no golden is
-    committed for it (the reference forward takes minutes here), so this checks size-independent properties: finite
-    output of the right shape, float32 and bf16 modes agree within the bf16 tolerance."""
+@pytest.fixture(scope="module")
+def full_model_bf16():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
     from jen1_amd.model import UNetCFG1d
-    B, T = 1, 9000
+    return UNetCFG1d(**full_model_config(), compute_dtype="bf16", device="cuda")
+
+
+def _check_taps(plan, g, prefix):
+    for k in [k for k in g.files if k.startswith(prefix)]:
+        name = k[len(prefix):]
+        a, ref = plan.taps[name], g[k]
+        if a.L != int(ref[2]) or name == "up8":
+            continue      # up-path taps are stored already cropped / with the final skip add fused (see test_full_unet_vs_golden_f32)
+        n = float(torch.linalg.vector_norm(a.t[:, :, : a.C].double()))
+        assert abs(n - ref[0]) <= 1e-3 * ref[0], (k, n, ref[0])
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_unet_bench_shapes_B8_vs_golden(full_model_f32, full_model_bf16, mode):
+    """BASELINE configs[1] / [2]: the B = 8 (no CFG) and 2B = 16 (CFG pair) launch plans bench.py times, against what the
+    reference produced on the same inputs (tests/golden/full_bench.npz: B=8, T=1500, eight different timesteps)."""
+    g = golden("full_bench")
+    m, tol = (full_model_f32, F32_TOL) if mode == "f32" else (full_model_bf16, BF16_TOL)
+    B, T = 8, 1500
     x, cond = synth.latents(B, T), synth.conditioning(B, T)
+    t = g["B8.t"]
+    y = _fwd(m, x, t, cond, embedding_scale=1.0, causal=False)
+    e = rel_err(y[:, :, ::16], g["B8.y.nocfg"])
+    print(f"full UNet {mode}, B=8 no CFG: max-abs/max-ref = {e:.3e}")
+    assert e < tol
+    if mode == "f32":
+        _check_taps(m.engine().plan(B, T, 1, False), g, "B8.tap.nocfg.")
+    y = _fwd(m, x, t, cond, embedding_scale=0.8, batch_cfg=True, scale_cfg=True, causal=False)
+    e = rel_err(y[:, :, ::16], g["B8.y.cfg"])
+    print(f"full UNet {mode}, B=8 CFG pair (2B=16): max-abs/max-ref = {e:.3e}")
+    assert e < tol
+    if mode == "f32":
+        _check_taps(m.engine().plan(B, T, 2, False), g, "B8.tap.cfg.")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_unet_long_sequence_T9000_vs_golden(full_model_f32, full_model_bf16, mode):
+    """BASELINE configs[4] shape (B=1, 128x9000: self-attention over 141 positions, 6x the conv work), continuation
+    (causal) and inpainting (non-causal) conditioning through the CFG pair, against the reference's output."""
+    g = golden("full_bench")
+    m, tol = (full_model_f32, F32_TOL) if mode == "f32" else (full_model_bf16, BF16_TOL)
+    B, T = 1, 9000
     t = np.array([499], dtype=np.int64)
-    y32 = _fwd(full_model_f32, x, t, cond, embedding_scale=1.0, causal=False)
-    assert np.isfinite(y32).all() and y32.shape == (B, 128, T)
-    mb = UNetCFG1d(**full_model_config(), compute_dtype="bf16", device="cuda")
-    yb = _fwd(mb, x, t, cond, embedding_scale=1.0, causal=False)
-    e = rel_err(yb, y32)
-    print(f"full UNet T=9000: bf16 vs f32 max-abs/max-ref = {e:.3e}")
-    assert e < BF16_TOL
-    del mb
+    for task, causal in (("music_cont", True), ("music_inpaint", False)):
+        x, cond = synth.latents(B, T), synth.conditioning(B, T, task)
+        y = _fwd(m, x, t, cond, embedding_scale=0.8, batch_cfg=True, scale_cfg=True, causal=causal)
+        assert y.shape == (B, 128, T)
+        e = rel_err(y[:, :, ::24], g[f"T9000.y.{task}"])
+        print(f"full UNet {mode}, T=9000 {task}: max-abs/max-ref = {e:.3e}")
+        assert e < tol, (task, e)
+        if mode == "f32":
+            _check_taps(m.engine().plan(B, T, 2, causal), g, f"T9000.tap.{task}.")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_ddim_vs_golden(full_model_f32, full_model_bf16, mode):
+    """The sampler at the full configuration against the reference's own ``GaussianDiffusion.sample`` with injected noise:
+    10 DDIM steps at B=2, and 2 steps at the two bench shapes (B=8 with and without the CFG pair) and at T=9000 (causal),
+    every one as a replayed hipGraph -- the same stepper objects and plans bench.py times."""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    g = golden("full_bench")
+    m, tol = (full_model_f32, F32_TOL) if mode == "f32" else (full_model_bf16, BF16_TOL)
+    betas, _ = get_beta_schedule("linear", 1000)
+    for key, B, T, S, scale, causal, task, sub in (("ddim10.B2.cfg", 2, 1500, 10, 0.8, False, "text_guided", 8),
+                                                  ("ddim2.B8.cfg", 8, 1500, 2, 0.8, False, "text_guided", 16),
+                                                  ("ddim2.B8.nocfg", 8, 1500, 2, 1.0, False, "text_guided", 16),
+                                                  ("ddim2.T9000.cont", 1, 9000, 2, 0.8, True, "music_cont", 24)):
+        cond = {k: dev(v) for k, v in synth.conditioning(B, T, task).items()}
+        shape = (B, 128, T)
+        init = dev(synth.noise_list(1, shape, seed=7)[0])
+        noises = [dev(n) for n in synth.noise_list(S, shape, seed=11)]
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                               embedding_scale=scale, batch_cfg=True, scale_cfg=True, sampling_timesteps=S)
+        y = gd.sample(m, shape, cond, causal=causal, init_noise=init, step_noises=noises, use_graph=True)
+        torch.cuda.synchronize()
+        e = rel_err(y.cpu().numpy()[:, :, ::sub], g[key])
+        print(f"{key} {mode}: max-abs/max-ref = {e:.3e}")
+        # the x0 clamp at t = 999 (x0 = 157 * (...)) amplifies bf16 rounding; 2e-1 of the [-1, 1] range is the stated bf16 bound
+        assert e < (tol if mode == "f32" else 2e-1), (key, e)
 
 
 def test_sampler_full_size_properties(full_model_f32):

@@ -339,3 +339,22 @@ def test_full_unet_matches_reference():
     y = net(x, t, embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=1.0,
             channels_list=[cond["input_concat_cond"]], causal=True)
     assert rel_err(y[:, :, ::16], g["y.nocfg.causal"]) < NET_TOL
+
+
+def test_full_unet_bench_shape_matches_reference():
+    """the oracle at the shape bench.py times (BASELINE configs[1]: B=8, T=1500, no CFG) and at the long-form shape
+    (configs[4]: B=1, T=9000, continuation task, causal, CFG pair) against the reference's output (full_bench.npz)"""
+    cfg = full_model_config()
+    spec = UNetSpec(**cfg)
+    net = O.OracleUNetCFG1d(filled(spec.param_shapes()), **cfg)
+    g = golden("full_bench")
+    B, T = 8, 1500
+    x, cond = synth.latents(B, T), synth.conditioning(B, T)
+    y = net(x, g["B8.t"], embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=1.0,
+            channels_list=[cond["input_concat_cond"]], causal=False)
+    assert rel_err(y[:, :, ::16], g["B8.y.nocfg"]) < NET_TOL
+    B, T = 1, 9000
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "music_cont")
+    y = net(x, np.array([499], dtype=np.int64), embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"],
+            embedding_scale=0.8, batch_cfg=True, scale_cfg=True, channels_list=[cond["input_concat_cond"]], causal=True)
+    assert rel_err(y[:, :, ::24], g["T9000.y.music_cont"]) < NET_TOL
