@@ -1,0 +1,171 @@
+/*
+ * jen1_deep.h -- C ABI of the persistent deep-level kernel of libjen1_hip.so (gfx950).
+ *
+ * The levels of the JEN-1 UNet with T' <= 24 positions (down 3..8, bottleneck, up 0..5:
+ * reference jen1/model/model.py:246-259, jen1/model/blocks.py:540-830) hold 288 M of the
+ * 296 M parameters and are a chain of ~165 tiny dependent layers.  Run as one launch per
+ * layer, every layer pays a kernel boundary, an argument fetch and a cold prefetch ring.
+ * Here the whole chain is ONE launch of `nwg` resident workgroups (one per CU, 512
+ * threads) that walk a device-resident list of *phases*:
+ *
+ *   JEN1_DEEP_GEMM   conv / transposed conv / linear as a K-segment GEMM (same algebra as
+ *                    jen1_conv_gemm's direct mode: _Conv1d blocks.py:34-53, Upsample1d :69-95,
+ *                    ResnetBlock1d :219-231, Attention projections :427-429, FeedForward
+ *                    :440-446) whose prologue -- GroupNorm(+FiLM)(+SiLU), blocks.py:137-145,
+ *                    :509 -- is applied by the consuming workgroup while it stages the (tiny)
+ *                    activation tile in LDS: the group statistics are computed there, in a
+ *                    fixed order (no float atomics, bit-reproducible);
+ *   JEN1_DEEP_ATTN   AttentionBase.forward's math path (blocks.py:355-380) with the deferred
+ *                    LayerNorm finish of jen1_attention_fin; LayerNorm row statistics are
+ *                    recomputed by the consumer from the rows themselves;
+ *   JEN1_DEEP_STATS  GroupNorm fine-group sums of the last tensor of the chain, for the
+ *                    launch-per-layer kernels that consume it after the persistent launch.
+ *
+ * A unit of a phase (16 output rows x the positions of a few batch elements; one
+ * (batch element, head, 32-query chunk)) is done by one workgroup.  Phase p may start when
+ * every unit of phase p-1 has arrived on that phase's sharded counter; results travel through
+ * global memory with write-through (sc1) stores and L1-bypassing (sc1) loads
+ * (cdna_hip_programming.md Guideline 16, R1).  Weight slices are requested BEFORE the
+ * dependency wait, so their HBM latency hides behind the exchange.
+ *
+ * Plain pointers and sizes only; all pointers are device pointers unless noted.
+ */
+#ifndef JEN1_DEEP_H
+#define JEN1_DEEP_H
+
+#include <stdint.h>
+
+#include "jen1_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JEN1_DEEP_GEMM 0
+#define JEN1_DEEP_ATTN 1
+#define JEN1_DEEP_STATS 2
+
+#define JEN1_DEEP_MAX_SRC 4
+#define JEN1_DEEP_MAX_SEG 12
+#ifndef JEN1_DEEP_THREADS
+#define JEN1_DEEP_THREADS 512      /* 8 waves: 256 registers per lane hold the weight ring and the staging vectors */
+#endif
+#define JEN1_DEEP_BLOB_BYTES 4096   /* device image of one phase: descriptor + per-wave K-chunk lists */
+#define JEN1_DEEP_MAX_PHASES 512
+#define JEN1_DEEP_SHARDS 8          /* arrival counters per phase */
+#define JEN1_DEEP_SHARD_WORDS 64    /* uint32 words between two shard counters (256 B apart) */
+
+/* one source tensor of a GEMM phase: channels [coff, coff + C) of the staged tile */
+typedef struct jen1_deep_src {
+  const void* x;              /* [B][L_in][ld] in the launch dtype */
+  int32_t ld;
+  int32_t C;                  /* channels read (multiple of 32) */
+  int32_t coff;               /* first channel of this source in the staged tile */
+  float scale;                /* multiplies the raw values (skip scale of the up path, blocks.py:682,732-734) */
+} jen1_deep_src;
+
+/* one K segment: chunks [gend_prev, gend) of the flat packed weight multiply the staged channels
+ * coff + 32*(g - gend_prev) .. of input row  q*stride + shift  (zero outside [0, L_in)) */
+typedef struct jen1_deep_seg {
+  int32_t coff, shift, gend, reserved;
+} jen1_deep_seg;
+
+typedef struct jen1_deep_phase {
+  /* ---- scheduling ---- */
+  int32_t kind;               /* JEN1_DEEP_* */
+  int32_t n_units;
+  int32_t rot;                /* unit u runs on workgroup (u + rot) % nwg          (set by jen1_deep_link) */
+  int32_t dep;                /* phase whose completion this phase waits for, -1 = none  (jen1_deep_link) */
+  int32_t dep_units;          /* its n_units                                             (jen1_deep_link) */
+  int32_t lds_bytes;          /* dynamic LDS a unit of this phase needs */
+  int32_t dtype;
+  int32_t reserved0;
+  /* ---- GEMM ---- */
+  const void* w;              /* flat packed weight [chunk][M/16][64 lanes][8] */
+  const float* bias;          /* [out_C] or NULL */
+  const void* residual;       /* same row mapping as y, or NULL */
+  void* y;
+  const float* p1;            /* y = xhat * p1[row * p_ld + c] + p2[row * p_ld + c]: GroupNorm gamma / beta (p_ld = 0), or the */
+  const float* p2;            /* GroupNorm-FiLM table  gamma (scale + 1) / beta (scale + 1) + shift  (blocks.py:141-143) */
+  const int32_t* film_row;    /* p_ld > 0: table row of batch element b (NULL: b) ... */
+  const int32_t* film_step;   /* ... or one row for everybody, read from this device scalar */
+  uint32_t w_bytes;
+  int32_t G, MT, mt_split, g_split;
+  int32_t B, L_in, L_out, stride, nb, NF, groups_n;   /* groups_n = ceil(B / nb) */
+  int32_t nsrc, nseg, Ctot, pitch, R;                 /* R = nb * L_in staged rows (+1 zero row) */
+  int32_t pro_mode, norm_C, gn_groups, gn_cpg, gran;
+  float inv_count, gn_eps, inv_vpr, inv_Lin, inv_Lout, inv_groups;
+  int32_t p_ld, reserved2;
+  int32_t out_C, ps_f, ps_off, L_y, y_brows, y_row0, ld_y, ld_res, act, y_f32;
+  int32_t part_off, stat_off, red_off;                /* LDS byte offsets behind the tile */
+  int32_t reserved1;
+  jen1_deep_src src[JEN1_DEEP_MAX_SRC];
+  jen1_deep_seg seg[JEN1_DEEP_MAX_SEG];
+  /* ---- attention ---- */
+  const void* q;              /* [B][Nq][ldq]; LayerNorm statistics are taken over its columns [0, ln_C) */
+  const void* k;
+  const void* v;
+  void* out;
+  const int32_t* kv_row;
+  const void* kv_extra;
+  const int32_t* extra_row;
+  const int32_t* extra_step;
+  const float* ln_u;
+  const float* ln_b;
+  int32_t ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal;
+  int32_t ln_C, fin_q, fin_kv, kv_live, nqc, log2_vpr;   /* kv_live: K/V were produced inside this launch (sc1 loads) */
+  float scale, ln_eps, inv_H, inv_nqc;
+  /* ---- stats ---- */
+  const void* sx;             /* [B][L][ld] */
+  float* sstats;              /* [B][32][2] */
+  int32_t sL, sld, scpf, sgran;
+} jen1_deep_phase;
+
+/* sizeof(jen1_deep_phase), for host bindings that treat it as opaque bytes */
+int jen1_deep_phase_size(void);
+
+/* HOST helpers: fill *out (host memory) for one layer.  Return non-zero (message in jen1_last_error) when the layer does
+ * not fit the persistent kernel (LDS, register-resident staging vectors, unsupported option); the caller then keeps the
+ * level on the launch-per-layer path.
+ *
+ * jen1_deep_phase_conv reads from `a`: x0/x1/c0/c1/ld0/ld1/src1_scale (the normalised or raw main sources), taps / stride /
+ * pad_left, seg[0..nseg) as EXTRA raw K segments appended after the taps, w (flat packed), bias, residual, y and its row
+ * mapping, pro_mode (NONE / GN / GN_SILU) with the gn_* fields (statistics pointers are ignored: the consumer computes
+ * them), act, m_split / k_split, dtype, B / L_in / L_out.  When `film` is set it must be the FUSED GroupNorm-FiLM table
+ * (gamma (scale + 1) at film_off + c, beta (scale + 1) + shift at film_off + film_C + c; rows picked by film_row / film_step
+ * as in jen1_conv_args).  nb_max > 0 caps the batch elements per unit. */
+int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_deep_phase* out);
+
+int jen1_deep_phase_attention(const void* q, const void* k, const void* v, void* out_t, const int32_t* kv_row, const void* kv_extra,
+                              const int32_t* extra_row, const int32_t* extra_step, int ld_extra, int kx_off, int vx_off, int B, int H,
+                              int d, int Nq, int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off, int ldo, int causal,
+                              float scale, const float* ln_u, const float* ln_b, int ln_C, float ln_eps, int finish_q,
+                              int finish_kv, int kv_live, int dtype, jen1_deep_phase* out);
+
+int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, int ld, int dtype, jen1_deep_phase* out);
+
+/* chain the phases (dep = previous phase, rotation of the unit -> workgroup map) and build the device image:
+ * blobs   n_phases * jen1_deep_blob_bytes() bytes (HOST memory): per phase the descriptor followed by the per-wave lists of the
+ *         K chunks that can touch a real input row ({chunk index, staged column | row shift << 16}, dealt round-robin);
+ * headers n_phases * 16 bytes (HOST memory): {n_units, rot, kind, 0} per phase.
+ * Both are then copied to the device by the caller.  Returns the dynamic LDS bytes of the launch, or a negative value. */
+int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, void* blobs, void* headers);
+int jen1_deep_blob_bytes(void);
+
+/* bytes of the synchronisation area (arrival counters + error word); must be zero when the launch starts */
+int64_t jen1_deep_sync_bytes(int n_phases);
+
+/* workgroups the launch should use on the current device (one per CU, all resident) */
+int jen1_deep_num_workgroups(void);
+
+/* enqueue the persistent launch.  blobs_dev / headers_dev: device copies of what jen1_deep_link produced.  sync: zeroed area
+ * of jen1_deep_sync_bytes(n_phases).  After completion sync word jen1_deep_error_word(n_phases) is non-zero if a dependency
+ * wait timed out (1 + phase index). */
+int jen1_deep_run(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, int nwg, int lds_bytes, int dtype,
+                  void* stream);
+int jen1_deep_error_word(int n_phases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JEN1_DEEP_H */

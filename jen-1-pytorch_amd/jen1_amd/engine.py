@@ -117,6 +117,18 @@ class Weights:
             self.film_off[n] = off
             off += 2 * r.c_out
         self.film_ld = off
+        # fused GroupNorm-FiLM table (persistent deep-level kernel): film2 = A * (film[:, partner] + 1) + Bm * film with
+        #   scale positions: A = gamma2, Bm = 0, partner = itself;  shift positions: A = beta2, Bm = 1, partner = its scale
+        fa = torch.zeros(off, dtype=torch.float32, device=device)
+        fb = torch.zeros(off, dtype=torch.float32, device=device)
+        fp = torch.arange(off, dtype=torch.int64, device=device)
+        for r in spec.res_blocks():
+            o, c = self.film_off[r.name], r.c_out
+            fa[o: o + c] = p[f"{r.name}.block2.groupnorm.weight"]
+            fa[o + c: o + 2 * c] = p[f"{r.name}.block2.groupnorm.bias"]
+            fb[o + c: o + 2 * c] = 1.0
+            fp[o + c: o + 2 * c] = torch.arange(o, o + c, dtype=torch.int64, device=device)
+        self.film2_a, self.film2_b, self.film2_partner = fa, fb, fp
         # MappingToScaleShift of all blocks as ONE GEMM on the shared mapping (blocks.py:148-165)
         self.w["film"] = pk(torch.cat(film_w, 0)[None])
         self.v["film.bias"] = torch.cat(film_b, 0).contiguous()
@@ -215,6 +227,85 @@ class Weights:
         return sum(t.numel() * t.element_size() for t in self.w.values())
 
 
+class DeepIneligible(Exception):
+    """a layer does not fit the persistent deep-level kernel (LDS / staging registers / unsupported option)"""
+
+
+class DeepProgram:
+    """Host side of the persistent deep-level launch (include/jen1_deep.h): collects one phase descriptor per layer of the
+    levels with few positions, links them (dependency chain, unit -> workgroup rotation) and copies the array to the device.
+    The descriptors are opaque bytes here; libjen1_hip.so fills and validates them."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.lib = eng.lib
+        self.psize = self.lib.jen1_deep_phase_size()
+        self.bufs: List[C.Array] = []
+        self.labels: List[str] = []
+        self.outs: List[Optional["Act"]] = []
+        self.nwg = self.lib.jen1_deep_num_workgroups()
+        self.dev = None
+        self.lds = 0
+        self.sync = None
+
+    def _new(self):
+        return (C.c_char * self.psize)()
+
+    def _add(self, buf, rc, label, out):
+        if rc != 0:
+            msg = self.lib.jen1_last_error()
+            raise DeepIneligible(f"{label}: {msg.decode() if msg else 'does not fit'}")
+        self.bufs.append(buf)
+        self.labels.append(label)
+        self.outs.append(out)
+
+    def add_conv(self, a: "L.ConvArgs", label: str, out, nb_max: int = 0):
+        buf = self._new()
+        self._add(buf, self.lib.jen1_deep_phase_conv(C.byref(a), nb_max, C.cast(buf, C.c_void_p)), label, out)
+
+    def add_attention(self, args, label: str, out):
+        buf = self._new()
+        self._add(buf, self.lib.jen1_deep_phase_attention(*args, C.cast(buf, C.c_void_p)), label, out)
+
+    def add_stats(self, x: "Act", stats: torch.Tensor, label: str):
+        buf = self._new()
+        self._add(buf, self.lib.jen1_deep_phase_stats(x.t.data_ptr(), stats.data_ptr(), x.B, x.L, x.ld, self.eng.dt,
+                                                      C.cast(buf, C.c_void_p)), label, None)
+
+    def __len__(self):
+        return len(self.bufs)
+
+    def sync_words(self) -> int:
+        return int(self.lib.jen1_deep_sync_bytes(len(self.bufs))) // 4
+
+    def finalize(self, sync: torch.Tensor):
+        """link the phases, build the device image (per-phase blobs + headers) and move it to the device; ``sync``: int32 view
+        of a zeroed-per-step area of sync_words()"""
+        n = len(self.bufs)
+        host = (C.c_char * (self.psize * n))()
+        for i, b in enumerate(self.bufs):
+            C.memmove(C.addressof(host) + i * self.psize, b, self.psize)
+        bb = self.lib.jen1_deep_blob_bytes()
+        blobs = (C.c_char * (bb * n))()
+        hdrs = (C.c_char * (16 * n))()
+        self.lds = self.lib.jen1_deep_link(C.cast(host, C.c_void_p), n, self.nwg, C.cast(blobs, C.c_void_p), C.cast(hdrs, C.c_void_p))
+        if self.lds <= 0 or self.nwg < 1:
+            msg = self.lib.jen1_last_error()
+            raise DeepIneligible(f"jen1_deep_link: {msg.decode() if msg else 'failed'}")
+        self.dev = torch.frombuffer(bytearray(bytes(blobs)), dtype=torch.uint8).to(self.eng.device)
+        self.hdr = torch.frombuffer(bytearray(bytes(hdrs)), dtype=torch.uint8).to(self.eng.device)
+        self.sync = sync
+        self.err_word = self.lib.jen1_deep_error_word(n)
+
+    def launch(self, stream: int):
+        L.check(self.lib.jen1_deep_run(self.dev.data_ptr(), self.hdr.data_ptr(), len(self.bufs), self.sync.data_ptr(), self.nwg, self.lds,
+                                       self.eng.dt, stream), "jen1_deep_run")
+
+    def error(self) -> int:
+        """non-zero after a launch whose dependency wait timed out (1 + phase index); synchronises with the device"""
+        return int(self.sync[self.err_word].item())
+
+
 class KernelCtx:
     """what an OpBuilder needs to know about the device / dtype (Engine provides the same fields)."""
 
@@ -251,6 +342,8 @@ class OpBuilder:
         self._keep: List[object] = []
         self.slab = None
         self.counters = None
+        self.deep: Optional[DeepProgram] = None     # the persistent deep-level program being recorded (Plan._deep_begin)
+        self._deep_on = False
 
     def _empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.eng.tdtype, device=self.eng.device)
@@ -341,6 +434,32 @@ class OpBuilder:
             a.out_gn_stats, a.out_cpf = out.gn.data_ptr(), out.ld // FG
         if out.rs is not None:
             a.out_rowstats = out.rs.data_ptr()
+        if self._deep_on:
+            # persistent deep-level kernel: one phase descriptor instead of a launch (norm_apply + streaming GEMM); the consumer
+            # computes the GroupNorm statistics itself, FiLM comes from the fused GroupNorm-FiLM table
+            if pro == L.PRO_LN or y_f32 or row_scale is not None:
+                raise DeepIneligible(f"{label}: prologue / epilogue option outside the persistent kernel")
+            a.out_gn_stats = a.out_rowstats = None
+            if pro in (L.PRO_GN, L.PRO_GN_SILU) and film is not None:
+                a.film = self.film2.data_ptr()
+            a.nseg = 0
+            if extra_segs:
+                for i, (e, sh) in enumerate(extra_segs):
+                    assert e.B == a.B and e.L == a.L_in and e.t.dtype == eng.tdtype and e.cp == e.C
+                    a.seg[i].x, a.seg[i].ld, a.seg[i].shift, a.seg[i].kch = e.t.data_ptr(), e.ld, sh, e.cp // 32
+                a.nseg = len(extra_segs)
+            if m_split:
+                a.m_split, a.k_split = m_split, k_split
+            self._keep.append((a, src0, src1, w, bias, out, residual, gn, film, extra_segs))
+            self.deep.add_conv(a, f"conv[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} M={a.M}", out,
+                               nb_max=eng.deep_nb_max)
+            es_ = 4 if eng.dt == L.F32 else 2
+            c_real_ = src0.C + (src1.C if src1 is not None else 0)
+            c_extra_ = sum(e.C for e, _ in extra_segs) if extra_segs else 0
+            self.deep_w_bytes += (taps * c_real_ + c_extra_) * a.M * es_
+            self.deep_act_bytes += a.B * a.L_in * (c_real_ + c_extra_) * es_ + a.B * a.L_y * out_C * es_
+            self.deep_flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
+            return out
         tile_ok = (pro in (L.PRO_NONE, L.PRO_GN, L.PRO_GN_SILU, L.PRO_SILU) and act == L.ACT_NONE and row_scale is None and out.rs is None
                    and not extra_segs and not m_split and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] > 1 or src1 is None)
                    and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] == 1 or
@@ -486,6 +605,8 @@ class OpBuilder:
 
     def streams(self, B: int, L_out: int, M: int) -> bool:
         """will a plain conv of this shape run on the streaming kernel (where K-segment fusions pay)?"""
+        if self._deep_on:
+            return True
         if self.eng.use_tile_kernel and B * L_out >= self.eng.tile_min_rows:
             return False
         return self.pick_cfg(B, L_out, M) in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
@@ -561,6 +682,14 @@ class OpBuilder:
         """fin = (rowstats, u, b, ln_C, eps, finish_q, finish_kv): deferred LayerNorm finish (jen1_attention_fin)"""
         eng = self.eng
         rs_, u_, b_, lnC, eps, fq, fkv = fin if fin is not None else (None, None, None, 0, 0.0, 0, 0)
+        if self._deep_on:
+            kv_live = 1 if kv_row is None and kv_extra is None else 0      # self-attention: K / V come from the previous phase
+            dargs = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
+                     _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off,
+                     out.ld, 1 if causal else 0, float(d) ** -0.5, _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, kv_live, eng.dt)
+            self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row, extra_step, fin))
+            self.deep.add_attention(dargs, f"attention B={q.B} H={H} d={d} Nq={q.L} Nk={Nk} causal={causal}", out)
+            return
         args = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
                 _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
                 1 if causal else 0, float(d) ** -0.5, _ptr(rs_), _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, eng.dt)
@@ -575,21 +704,40 @@ class OpBuilder:
 class Plan(OpBuilder):
     """Pre-allocated buffers + prepared launches for one (B, T, nrep, causal) shape."""
 
-    def __init__(self, eng: "Engine", B: int, T: int, nrep: int, causal: bool, n_t: Optional[int] = None):
+    def __init__(self, eng: "Engine", B: int, T: int, nrep: int, causal: bool, n_t: Optional[int] = None, deep: bool = True):
         """n_t = None: one timestep per batch element (the general forward).  n_t = S: *table mode* of a
         sampler -- the timestep-only work (time MLP, FiLM GEMM, time-token K/V GEMM) is evaluated once for
         all S schedule entries (``run_time``) and every kernel of the step indexes the tables through the
-        device-side counter ``step_idx``, so a captured step replays with no host-side update."""
-        super().__init__(eng)
+        device-side counter ``step_idx``, so a captured step replays with no host-side update.
+
+        deep: run the levels with few positions as ONE persistent launch (DeepProgram).  The first level of that launch
+        is the shallowest one whose every layer fits (``deep_level``); levels above it keep one launch per layer."""
         self.B, self.T, self.nrep, self.causal = B, T, nrep, causal
         self.Beff = B * nrep
         self.table_mode = n_t is not None
         self.n_t = n_t if n_t is not None else B
-        self.time_ops: List[Callable[[int], None]] = []
-        self.ctx_ops: List[Callable[[int], None]] = []
-        self.taps: Dict[str, Act] = {}
-        self.n_launch = 0
-        self._build()
+        lens = eng.spec.level_lengths(T)
+        n_lv = len(eng.spec.downs)
+        first = n_lv
+        if deep and eng.use_deep:
+            # candidates: levels whose length is within the persistent kernel's reach, shallowest first
+            first = next((i for i in range(n_lv) if lens[i + 1] <= eng.deep_max_len), n_lv)
+        self.deep_errors: List[str] = []
+        while True:
+            super().__init__(eng)
+            self.time_ops: List[Callable[[int], None]] = []
+            self.ctx_ops: List[Callable[[int], None]] = []
+            self.taps: Dict[str, Act] = {}
+            self.acts: List[Act] = []
+            self.n_launch = 0
+            self.deep_level = first if first < n_lv else None
+            self.deep_w_bytes = self.deep_act_bytes = self.deep_flops = 0
+            try:
+                self._build()
+                break
+            except DeepIneligible as e:
+                self.deep_errors.append(f"level {first}: {e}")
+                first += 1
 
     # ---------------------------------------------------------------- allocation helpers
     def _stats(self, nfloats: int) -> torch.Tensor:
@@ -604,7 +752,29 @@ class Plan(OpBuilder):
             t = torch.zeros((B, L, ld), dtype=dtype or self.eng.tdtype, device=self.eng.device)
         else:
             t = self._empty((B, L, ld), dtype)
-        return Act(t, B, L, C, ld, self._stats(B * 64) if gn else None, self._stats(B * L * 2) if rs else None)
+        a = Act(t, B, L, C, ld, self._stats(B * 64) if gn else None, self._stats(B * L * 2) if rs else None)
+        self.acts.append(a)
+        return a
+
+    # ---------------------------------------------------------------- persistent deep-level launch
+    def _deep_begin(self):
+        self.deep = DeepProgram(self.eng)
+        self._deep_on = True
+
+    def _deep_end(self, last: Act):
+        """close the recorded program: fine-group statistics of its last tensor for the launch-per-layer consumer, the
+        synchronisation area inside the per-step arena (zeroed by the step's first node), ONE launch op"""
+        self.deep.add_stats(last, last.gn, f"stats B={last.B} L={last.L} ld={last.ld}")
+        self._deep_on = False
+        n = self.deep.sync_words()
+        sync = self._stats(n).view(torch.int32)
+        self.deep.finalize(sync)
+        prog = self.deep
+        fn = lambda s, prog=prog: prog.launch(s)
+        fn.kind = "deep"
+        fn.label = f"deep[{len(prog)} phases, {prog.nwg} workgroups, {prog.lds} B LDS]"
+        fn.w_bytes, fn.act_bytes, fn.flops = self.deep_w_bytes, self.deep_act_bytes, self.deep_flops
+        self.ops.append(fn)
 
     # ---------------------------------------------------------------- network blocks
     def resblock(self, r: ResSpec, src0: Act, src1: Optional[Act], causal: bool, gn=True) -> Act:
@@ -709,7 +879,8 @@ class Plan(OpBuilder):
         n_tr = len(spec.transformers())
         lens = spec.level_lengths(T)
         Ltr = max([lens[i + 1] for i, d in enumerate(spec.downs) if d.transformer] + [lens[-1]])
-        self.arena = torch.zeros(600 * Be * 64 + (4 * n_tr + 8) * Be * Ltr * 2 + 4096, dtype=f32, device=dev)
+        deep_sync = (512 * 8 * 64 + 64) if self.deep_level is not None else 0      # arrival counters of <= 512 phases
+        self.arena = torch.zeros(600 * Be * 64 + (4 * n_tr + 8) * Be * Ltr * 2 + 4096 + deep_sync + 64, dtype=f32, device=dev)
         self._arena_used = 0
         ops = self.ops
 
@@ -760,6 +931,13 @@ class Plan(OpBuilder):
         self.film = torch.empty((NT_, W.film_ld), dtype=f32, device=dev)
         film_act = Act(self.film.view(1, NT_, W.film_ld), 1, NT_, W.film_ld, W.film_ld)
         self.conv(tops, src0=map_t, w=W.w["film"], bias=W.v["film.bias"], out=film_act, pro=L.PRO_SILU, y_f32=True)
+        # fused GroupNorm-FiLM table of the persistent kernel: y = xhat * gamma (scale + 1) + beta (scale + 1) + shift
+        # (blocks.py:141-143); timestep-only work like the FiLM GEMM itself
+        self.film2 = torch.empty_like(self.film)
+        if self.deep_level is not None:
+            film, film2, fa, fb, fp = self.film, self.film2, W.film2_a, W.film2_b, W.film2_partner
+            tops.append(lambda s, film=film, film2=film2, fa=fa, fb=fb, fp=fp:
+                        torch.add(fa * (film.index_select(1, fp) + 1.0), fb * film, out=film2))
 
         # ---- 3. time token of the text context -> its K/V row for every cross-attention ------------
         self.kv_ctx: Dict[str, torch.Tensor] = {}
@@ -788,7 +966,10 @@ class Plan(OpBuilder):
         self.taps["to_in"] = x
         skip0 = x
         skips_list: List[List[Act]] = []
+        n_lv = len(spec.downs)
         for i, d in enumerate(spec.downs):
+            if i == self.deep_level:
+                self._deep_begin()        # from this level's downsampling conv on, layers are phases of one launch
             f, k = d.factor, d.kernel
             Lo = (x.L + f - 1) // f
             y = self.new_act(Be, Lo, d.c_out, gn=True)
@@ -835,6 +1016,8 @@ class Plan(OpBuilder):
                           residual=skip0 if last else None)
             x = y
             self.taps[f"up{idx}"] = x
+            if self.deep_level is not None and n_lv - 1 - idx == self.deep_level:
+                self._deep_end(x)         # this level's upsampling conv was the last phase
         out = self.resblock(spec.to_out, x, None, causal=False, gn=False)
         self.net_out = out
         self.taps["out"] = out
@@ -937,6 +1120,11 @@ class Engine:
         self.tile_min_rows = int(os.environ.get("JEN1_TILE_MIN_ROWS", "512"))
         self.tile_target_wgs = int(os.environ.get("JEN1_TILE_TARGET_WGS", "256"))
         self.tile_one_round = os.environ.get("JEN1_TILE_ONE_ROUND", "0") != "0"
+        # persistent deep-level kernel (DeepProgram): levels of at most deep_max_len positions, plans of slot 0 only
+        # (two persistent launches in flight on different streams could each hold CUs the other waits for)
+        self.use_deep = os.environ.get("JEN1_DEEP", "1") != "0"
+        self.deep_max_len = int(os.environ.get("JEN1_DEEP_MAX_LEN", "64"))
+        self.deep_nb_max = int(os.environ.get("JEN1_DEEP_NB_MAX", "0"))
         self.plans: Dict[tuple, Plan] = {}
         self.load_params(params)
 
@@ -974,11 +1162,15 @@ class Engine:
         tmp.run(s)
         torch.cuda.synchronize(dev)
 
-    def plan(self, B: int, T: int, nrep: int, causal: bool, slot: int = 0, n_t: Optional[int] = None) -> Plan:
+    def plan(self, B: int, T: int, nrep: int, causal: bool, slot: int = 0, n_t: Optional[int] = None,
+             deep: Optional[bool] = None) -> Plan:
         """``slot`` distinguishes plans of the same shape that must own separate buffers because
         they run concurrently on different streams (sub-batches of one sampler step); ``n_t`` selects
-        the sampler's table mode (see Plan)."""
-        key = (B, T, nrep, bool(causal), slot, n_t)
+        the sampler's table mode (see Plan).  ``deep``: use the persistent deep-level launch (default: slot 0 only)."""
+        if deep is None:
+            deep = slot == 0
+        deep = bool(deep) and self.use_deep
+        key = (B, T, nrep, bool(causal), slot, n_t, deep)
         if key not in self.plans:
-            self.plans[key] = Plan(self, B, T, nrep, bool(causal), n_t)
+            self.plans[key] = Plan(self, B, T, nrep, bool(causal), n_t, deep=deep)
         return self.plans[key]

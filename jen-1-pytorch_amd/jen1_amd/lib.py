@@ -16,8 +16,8 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "elementwise.hip", "optimizer.hip",
-           "train_gemm.hip", "train_ops.hip", "encodec.hip"]
+SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "deep_kernel.hip", "elementwise.hip",
+           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "encodec.hip"]
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -127,6 +127,18 @@ SYMBOLS = {
     "jen1_rvq_decode": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_lstm_layer": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_lstm_layer_multi": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    # include/jen1_deep.h: the persistent deep-level kernel (phase descriptors are opaque bytes on this side)
+    "jen1_deep_phase_size": (c_int, []),
+    "jen1_deep_phase_conv": (c_int, [C.POINTER(ConvArgs), c_int, _P]),
+    "jen1_deep_phase_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 +
+                                  [c_float, _P, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
+    "jen1_deep_phase_stats": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "jen1_deep_link": (c_int, [_P, c_int, c_int, _P, _P]),
+    "jen1_deep_blob_bytes": (c_int, []),
+    "jen1_deep_sync_bytes": (c_int64, [c_int]),
+    "jen1_deep_num_workgroups": (c_int, []),
+    "jen1_deep_run": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P]),
+    "jen1_deep_error_word": (c_int, [c_int]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),
@@ -143,7 +155,8 @@ def build(verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into jen1_amd/libjen1_hip.so (hipcc cross-compiles
     without a GPU).  Skips the compile when the library is newer than every source."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h"), os.path.join(INCLUDE, "jen1_train.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h"), os.path.join(INCLUDE, "jen1_train.h"),
+                   os.path.join(INCLUDE, "jen1_deep.h")]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

