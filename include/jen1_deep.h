@@ -51,7 +51,7 @@ extern "C" {
 #define JEN1_DEEP_THREADS 512      /* 8 waves: 256 registers per lane hold the weight ring and the staging vectors */
 #endif
 #define JEN1_DEEP_BLOB_BYTES 4096   /* device image of one phase: descriptor + per-wave K-chunk lists */
-#define JEN1_DEEP_MAX_PHASES 512
+#define JEN1_DEEP_MAX_PHASES 256
 #define JEN1_DEEP_SHARDS 8          /* arrival counters per phase */
 #define JEN1_DEEP_SHARD_WORDS 64    /* uint32 words between two shard counters (256 B apart) */
 
@@ -70,7 +70,9 @@ typedef struct jen1_deep_seg {
   int32_t coff, shift, gend, reserved;
 } jen1_deep_seg;
 
-typedef struct jen1_deep_phase {
+/* the part of a phase a GEMM unit reads as ONE batch of scalar loads (384 bytes = 6 x 64): scheduling, GEMM geometry,
+ * prologue / epilogue scalars and the source table.  Field order is ABI. */
+typedef struct jen1_deep_hot {
   /* ---- scheduling ---- */
   int32_t kind;               /* JEN1_DEEP_* */
   int32_t n_units;
@@ -95,11 +97,22 @@ typedef struct jen1_deep_phase {
   int32_t nsrc, nseg, Ctot, pitch, R;                 /* R = nb * L_in staged rows (+1 zero row) */
   int32_t pro_mode, norm_C, gn_groups, gn_cpg, gran;
   float inv_count, gn_eps, inv_vpr, inv_Lin, inv_Lout, inv_groups;
-  int32_t p_ld, reserved2;
+  int32_t p_ld;
+  int32_t lvn, lvr;           /* lvr: log2 of the 8-channel vectors per row of the raw part of the staged tile (lvn unused) */
   int32_t out_C, ps_f, ps_off, L_y, y_brows, y_row0, ld_y, ld_res, act, y_f32;
   int32_t part_off, stat_off, red_off;                /* LDS byte offsets behind the tile */
-  int32_t reserved1;
   jen1_deep_src src[JEN1_DEEP_MAX_SRC];
+  int32_t part_n;             /* unused */
+  /* staged tile: every batch element owns Lp = Hb + L_in + Ha rows (zero halo rows before / after: a conv tap is a plain row
+   * offset), a block of zero rows behind them serves the columns that do not exist (zrow: its centre row) */
+  int32_t Lp, Hb, zrow, Rtot;
+  /* GroupNorm statistics without LDS: each (batch element of the unit, group) pair owns 2^lS consecutive lanes, a lane owns
+   * one 8-channel column of the group (2^lvpg columns per row) */
+  int32_t lS, lvpg, lgroups, pad_hot;
+} jen1_deep_hot;
+
+typedef struct jen1_deep_phase {
+  jen1_deep_hot h;
   jen1_deep_seg seg[JEN1_DEEP_MAX_SEG];
   /* ---- attention ---- */
   const void* q;              /* [B][Nq][ldq]; LayerNorm statistics are taken over its columns [0, ln_C) */

@@ -46,13 +46,18 @@ template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { u64 d[2]; };
 template <> struct Raw8<float> { u64 d[4]; };
 
+#ifdef JEN1_DEEP_EXP_PLAIN        // timing experiment only: plain (L1-cached) loads instead of agent-scope ones
+#define JEN1_LIVE_LOAD(p) (*(p))
+#else
+#define JEN1_LIVE_LOAD(p) __hip_atomic_load(p, RLX_AGENT)
+#endif
 __device__ __forceinline__ void ld_live(Raw8<bf16_t>& r, const bf16_t* p) {
-  r.d[0] = __hip_atomic_load(g64(p), RLX_AGENT);
-  r.d[1] = __hip_atomic_load(g64(p) + 1, RLX_AGENT);
+  r.d[0] = JEN1_LIVE_LOAD(g64(p));
+  r.d[1] = JEN1_LIVE_LOAD(g64(p) + 1);
 }
 __device__ __forceinline__ void ld_live(Raw8<float>& r, const float* p) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r.d[i] = __hip_atomic_load(g64(p) + i, RLX_AGENT);
+  for (int i = 0; i < 4; ++i) r.d[i] = JEN1_LIVE_LOAD(g64(p) + i);
 }
 __device__ __forceinline__ void ld_plain(Raw8<bf16_t>& r, const bf16_t* p) {
   const u32x4 v = *reinterpret_cast<const u32x4*>(p);
@@ -85,6 +90,19 @@ __device__ __forceinline__ void raw_to_float(const Raw8<float>& r, float (&o)[8]
     o[2 * i] = __uint_as_float((unsigned)r.d[i]);
     o[2 * i + 1] = __uint_as_float((unsigned)(r.d[i] >> 32));
   }
+}
+__device__ __forceinline__ void float_to_raw(const float (&x)[8], Raw8<bf16_t>& r) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    bf16x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = (bf16_t)x[4 * i + j];
+    r.d[i] = __builtin_bit_cast(u64, a);
+  }
+}
+__device__ __forceinline__ void float_to_raw(const float (&x)[8], Raw8<float>& r) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = ((u64)__float_as_uint(x[2 * i + 1]) << 32) | __float_as_uint(x[2 * i]);
 }
 // 4 consecutive output channels of one position, write-through
 __device__ __forceinline__ void st_live4(bf16_t* p, const float (&v)[4]) {
@@ -154,6 +172,15 @@ __device__ __forceinline__ void wload(f32x8& f, __amdgpu_buffer_rsrc_t r, unsign
   }
 }
 
+__device__ __forceinline__ void frag_zero_d(bf16x8& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16_t)0.f;
+}
+__device__ __forceinline__ void frag_zero_d(f32x8& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = 0.f;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float ddpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -196,13 +223,16 @@ template <> struct DeepCfg<float> { static constexpr int MAXV = JEN1_DEEP_MAXV_F
 
 // ---- device-resident program: one blob per phase + a header array ----------------------------------------------------
 //   blob  [0, sizeof(jen1_deep_phase))            the descriptor
-//         [TAB_OFF, +32)                          int16 cnt[NW] (K chunks of wave w), int16 cnt_low[NW] (those below g_split)
-//         [TAB_OFF + 32, ...)                     NW lists of MAXE entries {chunk index g, staged column | shift << 16}:
-//                                                 the usable chunks of the flat (segment, chunk) list dealt round-robin
+//         [TAB_OFF, +64)                          int16 cnt[NW] (K chunks of wave w), cnt_low[NW] (those below g_split),
+//                                                 nruns[NW], nruns_low[NW]
+//         [TAB_OFF + 64, ...)                     NW lists of MAXRUN runs {g0, n, col0, shift}: the usable chunks of the flat
+//                                                 (segment, chunk) list dealt round-robin; inside a segment a wave's chunks
+//                                                 are g0, g0 + NW, ... at staged columns col0, col0 + 32 NW, ...
 //   header {n_units, rot, kind, -}                what a workgroup needs to find its next unit without touching the blobs
 constexpr int BLOB = JEN1_DEEP_BLOB_BYTES;
 constexpr int TAB_OFF = 1024;
-constexpr int MAXE = (BLOB - TAB_OFF - 32) / (8 * NW);
+constexpr int MAXRUN = 16;                             // runs (segment pieces) per wave
+static_assert(TAB_OFF + 64 + NW * MAXRUN * 16 <= BLOB, "run tables must fit the blob");
 constexpr int HDR_BYTES = JEN1_DEEP_MAX_PHASES * 16;
 constexpr int WS_OFF = HDR_BYTES + 2 * BLOB;           // LDS: headers | two descriptor slots | unit workspace
 static_assert(sizeof(jen1_deep_phase) <= TAB_OFF, "descriptor must fit ahead of the chunk table");
@@ -218,16 +248,23 @@ struct Sync {
   unsigned* err;       // error word
   bool dead;           // wave 0: a wait timed out somewhere: stop waiting, finish with whatever is there
   int p, wg, nwg;      // current phase / this workgroup
+#ifdef JEN1_DEEP_PROFILE
+  unsigned long long tt[16];
+#endif
 };
 
 // Tuning builds only (-DJEN1_DEEP_PROFILE): thread 0 of every workgroup records the constant-rate 100 MHz counter at the
 // stages of each unit it runs: dbg[(phase * nwg + wg) * 16 + stage]  (jen1_deep_debug_buffer sets the pointer)
 #ifdef JEN1_DEEP_PROFILE
 __device__ unsigned long long* g_deep_dbg = nullptr;
-#define DK_STAMP(sy, i) do { if (threadIdx.x == 0 && g_deep_dbg) \
-    g_deep_dbg[((size_t)(sy).p * (sy).nwg + (sy).wg) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// stamps stay in registers (s_memrealtime is an asynchronous scalar-memory request) and are written once per unit
+#define DK_STAMP(sy, i) do { (sy).tt[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DK_FLUSH(sy) do { if (threadIdx.x == 0 && g_deep_dbg) { \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) g_deep_dbg[((size_t)(sy).p * (sy).nwg + (sy).wg) * 16 + i_] = (sy).tt[i_]; } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) (sy).tt[i_] = 0; } while (0)
 #else
 #define DK_STAMP(sy, i) do { } while (0)
+#define DK_FLUSH(sy) do { } while (0)
 #endif
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -236,6 +273,10 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // `dead` is wave 0's private knowledge (only it ever polls): once set, later waits fall through.
 __device__ __forceinline__ void wait_phase(Sync& sy, int dep, int dep_units, int tid) {
   if (dep < 0) return;
+#ifdef JEN1_DEEP_EXP_NOWAIT      // timing experiment only: results are garbage
+  __syncthreads();
+  return;
+#endif
   if (tid < 64 && !sy.dead) {
     const gu32* c = g32(sy.base + ((size_t)dep * SHARDS + (tid < SHARDS ? tid : 0)) * SHW);
     const gu32* e = g32(sy.err);
@@ -282,52 +323,128 @@ __device__ __forceinline__ bool find_next(const Hdr* hdr, int n_phases, int wg, 
 
 // =====================================================================================================================
 // GEMM unit.  D: the phase's blob in LDS.
+//
+// A wave retires an instruction every ~2 ns here (two waves per SIMD, dependent chains), so a unit is written for few
+// dynamic instructions per wave:
+//   * the staged tile gives every batch element zero halo rows, so a conv tap is a plain row offset: the LDS address of an
+//     activation fragment is (per-lane column base) + (per-chunk SCALAR shift * pitch + channel offset), no validity tests;
+//   * GroupNorm statistics never touch LDS: each (batch element, group) pair owns 2^lS consecutive lanes, a lane sums its own
+//     vectors and a fixed DPP / shuffle tree finishes the pair (bit-reproducible); one barrier per staged tile;
+//   * a thread owns ONE 8-channel column of the normalised part and one of the raw part: source, scale and (gamma, beta) / FiLM
+//     parameters are per-thread constants; every address is computed BEFORE the dependency wait; vectors are processed
+//     branch-free (vectors that do not exist read row 0 and land in a dummy slot);
+//   * the K loop runs whole rounds of the PF ring slots straight-line (slots beyond the wave's chunks hold zero weights).
 // =====================================================================================================================
+struct KRun {                // one run of a wave's K chunks: chunk j is flat chunk g0 + j * NW at staged column col0 + j * NW * 32
+  int g0, n, col0, shift;
+};
+
 template <typename T>
-struct GemmWave {            // what prefill and the K loop share
-  int mt, total;
+struct GemmWave {            // what prefill and the K loop share (all scalar)
+  int mt, total, nruns, MT;
   bool low_m;
+  const KRun* runs;          // this wave's run list in the LDS blob
+  __amdgpu_buffer_rsrc_t rw;
 };
 
 template <typename T>
 __device__ __forceinline__ GemmWave<T> gemm_wave(const unsigned char* D, int u, int wk) {
   const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
-  const int MT = P->MT;
-  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)MT));      // u < 2^20: exact
   GemmWave<T> g;
-  g.mt = u - grp * MT;
-  g.low_m = g.mt < P->mt_split;
+  g.MT = rfl(P->h.MT);
+  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)g.MT));      // u < 2^20: exact
+  g.mt = u - grp * g.MT;
+  g.low_m = g.mt < rfl(P->h.mt_split);
   const short* cnt = reinterpret_cast<const short*>(D + TAB_OFF);
   g.total = rfl(g.low_m ? cnt[NW + wk] : cnt[wk]);
+  g.nruns = rfl(g.low_m ? cnt[3 * NW + wk] : cnt[2 * NW + wk]);
+  g.runs = reinterpret_cast<const KRun*>(D + TAB_OFF + 64) + wk * MAXRUN;
+  const u64 wp = (u64)P->h.w;
+  g.rw = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((u64)(unsigned)rfl((int)(wp >> 32)) << 32) | (unsigned)rfl((int)wp)), 0,
+                                           rfl((int)P->h.w_bytes), RSRC_FLAGS);
   return g;
 }
 
-template <typename T, typename Frag>
-__device__ __forceinline__ void gemm_issue(const unsigned char* D, const GemmWave<T>& g, int wk, int lane, int j, Frag& fa) {
-  constexpr int ES = sizeof(T);
-  constexpr unsigned BLK = 512 * ES;
-  const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
-  const u64 wp = (u64)P->w;
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(((u64)(unsigned)rfl((int)(wp >> 32)) << 32) | (unsigned)rfl((int)wp)), 0, rfl((int)P->w_bytes), RSRC_FLAGS);
-  const uint2 e = reinterpret_cast<const uint2*>(D + TAB_OFF + 32)[wk * MAXE + j];
-  const unsigned voff = (e.x * (unsigned)P->MT + (unsigned)g.mt) * BLK + (unsigned)lane * (8u * ES);
-  wload(fa, rw, voff, 0);
+// scalar cursor over a wave's runs
+struct KCursor {
+  int r, left, g, col, shift;
+};
+__device__ __forceinline__ void kc_load(KCursor& c, const KRun* runs, int r) {
+  c.r = r;
+  c.left = rfl(runs[r].n);
+  c.g = rfl(runs[r].g0);
+  c.col = rfl(runs[r].col0);
+  c.shift = rfl(runs[r].shift);
 }
-
-// fill the ring of the unit (called as early as the descriptor is known: before the previous unit's epilogue, or at unit start)
-template <typename T, typename Frag, int PF>
-__device__ __forceinline__ void gemm_prefill(const unsigned char* D, int u, int wk, int lane, Frag (&ra)[PF]) {
-  const GemmWave<T> g = gemm_wave<T>(D, u, wk);
-#pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    if (i < g.total) gemm_issue<T>(D, g, wk, lane, i, ra[i]);
+__device__ __forceinline__ void kc_start(KCursor& c, const KRun* runs, int nruns) {
+  c.r = 0; c.left = 0; c.g = 0; c.col = 0; c.shift = 0;
+  if (nruns > 0) kc_load(c, runs, 0);
+}
+__device__ __forceinline__ void kc_next(KCursor& c, const KRun* runs, int nruns) {
+  if (--c.left > 0) {
+    c.g += NW;
+    c.col += NW * 32;
+  } else if (c.r + 1 < nruns) {
+    kc_load(c, runs, c.r + 1);
   }
 }
 
-template <typename T, typename Frag, int PF, typename FPub, typename FPre>
+template <typename T, typename Frag>
+__device__ __forceinline__ void gemm_issue(const GemmWave<T>& g, const KCursor& c, int lane, Frag& fa) {
+  constexpr int ES = sizeof(T);
+  constexpr unsigned BLK = 512 * ES;
+#ifdef JEN1_DEEP_EXP_NOW          // timing experiment only: no weight traffic
+  wload(fa, g.rw, OOB, 0);
+#else
+  wload(fa, g.rw, (unsigned)lane * (8u * ES), (unsigned)(c.g * g.MT + g.mt) * BLK);
+#endif
+}
+
+// fill the ring of a unit as early as its descriptor is known (right behind the previous unit's arrival); slots beyond the wave's
+// chunks are zeroed (the K loop runs whole rounds)
+template <typename T, typename Frag, int PF>
+__device__ __forceinline__ void gemm_prefill(const unsigned char* D, int u, int wk, int lane, Frag (&ra)[PF]) {
+  const GemmWave<T> g = gemm_wave<T>(D, u, wk);
+  KCursor ic;
+  kc_start(ic, g.runs, g.nruns);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    if (i < g.total) {
+      gemm_issue<T>(g, ic, lane, ra[i]);
+      kc_next(ic, g.runs, g.nruns);
+    } else {
+      frag_zero_d(ra[i]);
+    }
+  }
+}
+
+// K loop of one round: PF ring slots x NF fragments, straight-line
+template <typename T, int NF, typename Frag, int PF>
+__device__ __forceinline__ void k_round(f32x4 (&acc)[4], const Frag (&ra)[PF], const T* tile, const int (&cbase)[4], const int (&soff)[PF]) {
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    Frag fb[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) dlds(fb[nf], tile + cbase[nf] + soff[i]);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) dmma(acc[nf], ra[i], fb[nf]);
+  }
+}
+
+// sum over the aligned group of 2^lS lanes (3 <= lS <= 6) that holds v, in a fixed order
+__device__ __forceinline__ float lane_set_sum(float v, int lS) {
+  v += ddpp<0xB1>(v);                       // lanes ^ 1
+  v += ddpp<0x4E>(v);                       // lanes ^ 2
+  v += ddpp<0x141>(v);                      // row_half_mirror: the other quad of the 8
+  if (lS >= 4) v += ddpp<0x140>(v);         // row_mirror: the other half of the 16
+  if (lS >= 5) v += __shfl_xor(v, 16);
+  if (lS >= 6) v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <typename T, typename Frag, int PF, typename FPub>
 __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, Frag (&ra)[PF],
-                                          bool prefilled, FPub publish_next, FPre prefill_next, int tid) {
+                                          FPub publish_next, int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool PRECISE = is_f32<T>::value;
   constexpr int MAXV = DeepCfg<T>::MAXV;
@@ -337,70 +454,121 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const int li = lane & 15, lg = lane >> 4;
   DK_STAMP(sy, 0);
   const GemmWave<T> gw = gemm_wave<T>(D, u, wk);
-  if (!prefilled) gemm_prefill<T>(D, u, wk, lane, ra);
-  DK_STAMP(sy, 7);
-
-  // ---- descriptor fields into registers, once ---------------------------------------------------------------------------
-  const int MT = P->MT, nb = P->nb, B = P->B, L_in = P->L_in, L_out = P->L_out, stride = P->stride, NF = P->NF;
-  const int pitch = P->pitch, R = P->R, norm_C = P->norm_C, Ctot = P->Ctot, pro = P->pro_mode;
-  const int gran = P->gran, cpg = P->gn_cpg, groups = P->gn_groups, nsrc = P->nsrc;
-  const float inv_Lin = P->inv_Lin, inv_Lout = P->inv_Lout;
-  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)MT));
+  const int nb = rfl(P->h.nb), B = rfl(P->h.B), L_in = rfl(P->h.L_in), L_out = rfl(P->h.L_out), NF = rfl(P->h.NF);
+  const int pitch = rfl(P->h.pitch), norm_C = rfl(P->h.norm_C), Ctot = rfl(P->h.Ctot), Lp = rfl(P->h.Lp), Hb = rfl(P->h.Hb);
+  const int zrow = rfl(P->h.zrow), Rtot = rfl(P->h.Rtot);
+  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)gw.MT));
   const int mt = gw.mt, b0 = grp * nb;
   const bool low_m = gw.low_m;
-  jen1_deep_src src[JEN1_DEEP_MAX_SRC];
-#pragma unroll
-  for (int k = 0; k < JEN1_DEEP_MAX_SRC; ++k) src[k] = P->src[k];
   unsigned char* ws = smem + WS_OFF;
   T* tile = reinterpret_cast<T*>(ws);
-  float2* part = reinterpret_cast<float2*>(ws + P->part_off);
-  float2* stat = reinterpret_cast<float2*>(ws + P->stat_off);
-  float* red = reinterpret_cast<float*>(ws + P->red_off);
+  float* red = reinterpret_cast<float*>(ws + rfl(P->h.red_off));
+  // per-thread landing place of vectors that do not exist (branch-free stores): the K-reduction scratch, unused while staging
+  const int dummy_tile = rfl(P->h.red_off) / (int)sizeof(T) + tid * 8;
+  const float inv_Lin = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_Lin)));
+  const float inv_Lout = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_Lout)));
 
-  // ---- staging plan: normalised vectors (idx < Vn over the leading norm_C channels) and raw vectors (the rest) -------------
-  const int VPRn = norm_C >> 3, VPRr = (Ctot - norm_C) >> 3;
-  const int Vn = R * VPRn, Vr = R * VPRr;
-  const float inv_vprn = VPRn ? 1.0f / (float)VPRn : 0.f, inv_vprr = VPRr ? 1.0f / (float)VPRr : 0.f;
-  auto locate = [&](int row, int c, const T*& ap, float& sc, int& bl) -> bool {       // tile (row, channel c) -> source address
-    bl = (int)(((float)row + 0.5f) * inv_Lin);
-    const int t = row - bl * L_in;
-    const void* xp = src[0].x;
-    int ld = src[0].ld, coff = 0;
-    sc = src[0].scale;
+  // ---- the normalised part: (batch element, group) pair of this lane set, column of this lane -----------------------------
+  const int lS = rfl(P->h.lS), lvpg = rfl(P->h.lvpg), lgroups = rfl(P->h.lgroups), cpg = rfl(P->h.gn_cpg);
+  const int pair = tid >> lS, wl = tid & ((1 << lS) - 1);
+  const int nbl = pair >> lgroups, ngrp = pair & ((1 << lgroups) - 1);
+  const int cn = ngrp * cpg + (wl & ((1 << lvpg) - 1)) * 8;       // first channel of the lane's column
+  const int nt0 = wl >> lvpg, ntstep = (1 << lS) >> lvpg;           // first position, positions per trip
+  const bool npair_ok = norm_C > 0 && nbl < nb && b0 + nbl < B;
+  const jen1_deep_src s0 = P->h.src[0], s1 = P->h.src[1];
+  const bool in1 = rfl(P->h.nsrc) > 1 && s1.coff < norm_C && cn >= s1.coff;         // second normalised source (the skip)
+  const T* nbase = reinterpret_cast<const T*>(in1 ? s1.x : s0.x) + (cn - (in1 ? s1.coff : 0)) +
+                   (size_t)((unsigned)((npair_ok ? b0 + nbl : b0) * L_in) * (unsigned)(in1 ? s1.ld : s0.ld));
+  const int nld = in1 ? s1.ld : s0.ld;
+  const float nscale = in1 ? s1.scale : s0.scale;
+  float p1[8], p2[8];
 #pragma unroll
-    for (int k = 1; k < JEN1_DEEP_MAX_SRC; ++k) {
-      const bool use = k < nsrc && c >= src[k].coff;
-      xp = use ? src[k].x : xp;
-      ld = use ? src[k].ld : ld;
-      coff = use ? src[k].coff : coff;
-      sc = use ? src[k].scale : sc;
-    }
-    ap = reinterpret_cast<const T*>(xp) + ((size_t)((unsigned)((b0 + bl) * L_in + t) * (unsigned)ld) + (unsigned)(c - coff));
-    return b0 + bl < B;
-  };
-  DK_STAMP(sy, 8);
-  // GroupNorm (* FiLM) parameters of this thread's normalised vectors: requested before the dependency wait
-  float p1[MAXV][8], p2[MAXV][8];
-  int nrow[MAXV], nc[MAXV], nbl[MAXV];
-  bool nokv[MAXV];
+  for (int j = 0; j < 8; ++j) { p1[j] = 0.f; p2[j] = 0.f; }
+  if (norm_C) {
+    // one table row per unit: gamma / beta (p_ld = 0), the sampler's per-step row, or the row of the unit's batch element
+    // (units of a per-element table hold one batch element: jen1_deep_phase_conv)
+    const int p_ld = rfl(P->h.p_ld);
+    const int* fstep = P->h.film_step;
+    const int* frow = P->h.film_row;
+    const int fr = p_ld ? (fstep ? fstep[0] : (frow ? frow[b0] : b0)) : 0;
+    const size_t po = (size_t)((unsigned)fr * (unsigned)p_ld) + (unsigned)(npair_ok ? cn : 0);
+    load8(P->h.p1 + po, p1);
+    load8(P->h.p2 + po, p2);
+  }
   const T* nap[MAXV];
-  float nsc[MAXV];
+  int ntile[MAXV];
+  float nmask[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int idx = tid + i * NT;
-    nrow[i] = (int)(((float)idx + 0.5f) * inv_vprn);
-    nc[i] = (idx - nrow[i] * VPRn) * 8;
-    nokv[i] = idx < Vn && locate(nrow[i], nc[i], nap[i], nsc[i], nbl[i]);
-    if (nokv[i]) {
-      const int b = b0 + nbl[i];
-      const int fr = P->p_ld ? (P->film_step ? P->film_step[0] : (P->film_row ? P->film_row[b] : b)) : 0;
-      const size_t po = (size_t)((unsigned)fr * (unsigned)P->p_ld) + (unsigned)nc[i];
-      load8(P->p1 + po, p1[i]);
-      load8(P->p2 + po, p2[i]);
+    const int t = nt0 + i * ntstep;
+    const bool ok = npair_ok && t < L_in;
+    nap[i] = nbase + (size_t)((unsigned)(ok ? t : 0) * (unsigned)nld);
+    ntile[i] = ok ? (nbl * Lp + Hb + t) * pitch + cn : dummy_tile;
+    nmask[i] = ok ? nscale : 0.f;                                    // scale of the source, 0 for vectors that do not exist
+  }
+  // ---- the raw part: a thread owns one column, rows r0, r0 + rpr, ... of the unit's nb * L_in staged rows ----------------------
+  const int Craw = Ctot - norm_C;
+  const int lvr = rfl(P->h.lvr);
+  const int cr = Craw > 0 ? norm_C + (tid & ((1 << lvr) - 1)) * 8 : 0;      // (no raw part: the dummy loads stay inside source 0)
+  const int rr0 = tid >> lvr, rpr = NT >> lvr;
+  int rows_ok = (B - b0) * L_in;                       // staged rows below this belong to real batch elements
+  rows_ok = rows_ok < nb * L_in ? rows_ok : nb * L_in;
+  rows_ok = Craw > 0 ? rows_ok : 0;
+  const T* rbase;
+  int rld;
+  float rscale;
+  {
+    const void* xp = s0.x;
+    int ld = s0.ld, coff = 0;
+    float sc = s0.scale;
+#pragma unroll
+    for (int k = 1; k < JEN1_DEEP_MAX_SRC; ++k) {
+      const jen1_deep_src sk = P->h.src[k];
+      const bool use = k < rfl(P->h.nsrc) && cr >= sk.coff;
+      xp = use ? sk.x : xp;
+      ld = use ? sk.ld : ld;
+      coff = use ? sk.coff : coff;
+      sc = use ? sk.scale : sc;
+    }
+    rbase = reinterpret_cast<const T*>(xp) + (cr - coff) + (size_t)((unsigned)(b0 * L_in) * (unsigned)ld);
+    rld = ld;
+    rscale = sc;
+  }
+  const int lpx = Lp - L_in;                            // halo rows per batch element
+  const T* wap[MAXV];
+  int wtile[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int rr = rr0 + i * rpr;
+    const bool ok = rr < rows_ok;
+    const int rc = ok ? rr : 0;
+    const int bl = (int)(((float)rc + 0.5f) * inv_Lin);
+    wap[i] = rbase + (size_t)((unsigned)rc * (unsigned)rld);
+    wtile[i] = ok ? (rc + bl * lpx + Hb) * pitch + cr : dummy_tile;
+  }
+  // ---- halo rows and the zero block: nobody else touches them, written before the wait ----------------------------------------
+  {
+    const int vpr = Ctot >> 3;
+    const int hz = nb * lpx;                           // halo rows of the batch elements, then the zero block
+    const int zr = hz + (Rtot - nb * Lp);
+    const float inv_vprf = 1.0f / (float)vpr;
+    const float inv_lpx = lpx ? 1.0f / (float)lpx : 0.f;
+    for (int i = tid; i < zr * vpr; i += NT) {
+      const int z = (int)(((float)i + 0.5f) * inv_vprf);
+      const int c = (i - z * vpr) * 8;
+      int row;
+      if (z < hz) {
+        const int bl = (int)(((float)z + 0.5f) * inv_lpx);
+        const int k = z - bl * lpx;
+        row = bl * Lp + (k < Hb ? k : L_in + k);
+      } else {
+        row = nb * Lp + (z - hz);
+      }
+      const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      store8(tile + (size_t)row * pitch + c, z8);
     }
   }
-  DK_STAMP(sy, 9);
-  // epilogue operands that do not depend on other workgroups
+  // ---- epilogue operands that do not depend on other workgroups ----------------------------------------------------------
   const bool epi = wk < NF;
   const int nfe = wk;                                   // the fragment this wave finishes
   const int m = mt * 16 + lg * 4;
@@ -409,218 +577,166 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   bool okk = false;
   int yrow = 0;
   if (epi) {
-    const int out_C = P->out_C, ps_f = P->ps_f;
+    const int out_C = rfl(P->h.out_C), ps_f = rfl(P->h.ps_f);
     for (int k = 1; k < ps_f; ++k) ph += (m >= k * out_C) ? 1 : 0;
     co = m - ph * out_C;
-    if (P->bias) bias4 = *reinterpret_cast<const f32x4*>(P->bias + co);
+    if (P->h.bias) bias4 = *reinterpret_cast<const f32x4*>(P->h.bias + co);
     const int n = nfe * 16 + li;
     const int ebl = (int)(((float)n + 0.5f) * inv_Lout);
     const int t = n - ebl * L_out;
-    const int ty = t * ps_f + ph - P->ps_off;
-    okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < P->L_y;
-    yrow = okk ? (b0 + ebl) * P->y_brows + P->y_row0 + ty : 0;
+    const int ty = t * ps_f + ph - rfl(P->h.ps_off);
+    okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < rfl(P->h.L_y);
+    yrow = okk ? (b0 + ebl) * rfl(P->h.y_brows) + rfl(P->h.y_row0) + ty : 0;
   }
-  const bool use_res = epi && okk && P->residual && (P->mt_split == 0 || low_m);
-  const T* resp = reinterpret_cast<const T*>(P->residual) + ((size_t)((unsigned)yrow * (unsigned)P->ld_res) + (unsigned)co);
-  const int act = P->act, y_f32 = P->y_f32, ld_y = P->ld_y;
-  void* const yp = P->y;
-  const float inv_count = P->inv_count, gn_eps = P->gn_eps, inv_groups = P->inv_groups;
+  const bool use_res = epi && okk && P->h.residual && (rfl(P->h.mt_split) == 0 || low_m);
+  const T* resp = reinterpret_cast<const T*>(P->h.residual) + ((size_t)((unsigned)yrow * (unsigned)rfl(P->h.ld_res)) + (unsigned)co);
+  // ---- K loop: column base of this lane per fragment; scalar (shift * pitch + channel) offset per ring slot of the first round ---
+  const int total = gw.total;
+  int cbase[4];
+  {
+    const int stride = rfl(P->h.stride);
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int n = nf * 16 + li;
+      const int bl = (int)(((float)n + 0.5f) * inv_Lout);
+      const bool ok = nf < NF && n < nb * L_out && b0 + bl < B;
+      cbase[nf] = (ok ? bl * Lp + Hb + (n - bl * L_out) * stride : zrow) * pitch + lg * 8;
+    }
+  }
+  int soff[PF];
+  KCursor cc;
+  kc_start(cc, gw.runs, gw.nruns);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    soff[i] = cc.shift * pitch + cc.col;
+    if (i + 1 < total) kc_next(cc, gw.runs, gw.nruns);            // slots beyond the last chunk repeat its offset (zero weights)
+  }
 
   // ---- dependency ---------------------------------------------------------------------------------------------------
   DK_STAMP(sy, 1);
   if (need_wait) wait_phase(sy, sy.p - 1, dep_units, tid);
   DK_STAMP(sy, 2);
 
-  // ---- stage the tile: every load first (sc1: another workgroup wrote the data in this launch) ----------------------------
-  Raw8<T> xn[MAXV];
+#ifndef JEN1_DEEP_EXP_NOSTAGE
+  // ---- every load (sc1: another workgroup wrote the data in this launch), no branches ---------------------------------------
+  Raw8<T> xn[MAXV], xw[MAXV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    if (nokv[i]) ld_live(xn[i], nap[i]);
-    else zero_raw(xn[i]);
-  }
+  for (int i = 0; i < MAXV; ++i) ld_live(xn[i], nap[i]);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) ld_live(xw[i], wap[i]);
   float rres[4] = {0.f, 0.f, 0.f, 0.f};
   if (use_res) ld_live4(rres, resp);
-  DK_STAMP(sy, 10);
-  // zero row (conv padding) behind the R staged rows
-  for (int i = tid; i < (Ctot >> 3); i += NT) {
-    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    store8(tile + (size_t)R * pitch + i * 8, z8);
+  // raw vectors: straight into the tile
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (rscale != 1.0f) {
+      float x[8];
+      raw_to_float(xw[i], x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] *= rscale;
+      float_to_raw(x, xw[i]);
+    }
+    *reinterpret_cast<Raw8<T>*>(tile + wtile[i]) = xw[i];
   }
-  // raw vectors: straight into the tile, MAXV per thread in flight (one trip unless the tile is a long raw input, e.g. the
-  // 94 rows a downsampling conv reads)
-  for (int base = 0; base < Vr; base += MAXV * NT) {
-    Raw8<T> xw[MAXV];
-    int wrow[MAXV], wc[MAXV];
-    bool wok[MAXV];
-    float wsc[MAXV];
+  // further trips of a long raw input (e.g. the 94 rows a downsampling conv reads)
+  for (int rbeg = MAXV * rpr; rbeg < rows_ok; rbeg += MAXV * rpr) {
+    Raw8<T> xv[MAXV];
+    int vt[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int idx = base + tid + i * NT;
-      wrow[i] = (int)(((float)idx + 0.5f) * inv_vprr);
-      wc[i] = norm_C + (idx - wrow[i] * VPRr) * 8;
-      const T* ap;
-      int bl;
-      wok[i] = idx < Vr && locate(wrow[i], wc[i], ap, wsc[i], bl);
-      if (wok[i]) ld_live(xw[i], ap);
-      else zero_raw(xw[i]);
+      const int rr = rbeg + rr0 + i * rpr;
+      const bool ok = rr < rows_ok;
+      const int rc = ok ? rr : 0;
+      const int bl = (int)(((float)rc + 0.5f) * inv_Lin);
+      vt[i] = ok ? (rc + bl * lpx + Hb) * pitch + cr : dummy_tile;
+      ld_live(xv[i], rbase + (size_t)((unsigned)rc * (unsigned)rld));
     }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      if (wok[i]) {
-        if (wsc[i] == 1.0f) {
-          *reinterpret_cast<Raw8<T>*>(tile + (size_t)wrow[i] * pitch + wc[i]) = xw[i];
-        } else {
-          float x[8];
-          raw_to_float(xw[i], x);
+      if (rscale != 1.0f) {
+        float x[8];
+        raw_to_float(xv[i], x);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x[j] *= wsc[i];
-          store8(tile + (size_t)wrow[i] * pitch + wc[i], x);
-        }
+        for (int j = 0; j < 8; ++j) x[j] *= rscale;
+        float_to_raw(x, xv[i]);
       }
+      *reinterpret_cast<Raw8<T>*>(tile + vt[i]) = xv[i];
     }
   }
   DK_STAMP(sy, 11);
   if (norm_C) {
-    // per-vector partial sums (granules of 8 / 4 / 2 / 1 channels; narrower than a vector only in tiny configurations)
-    const int gpr = norm_C / gran;
-    const int lg2 = gran >= 8 ? 3 : (gran >= 4 ? 2 : (gran >= 2 ? 1 : 0));
+    // GroupNorm (+FiLM) (+SiLU): the lane sums its own vectors, the lane set finishes the pair, no LDS, no barrier
     float xf[MAXV][8];
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       raw_to_float(xn[i], xf[i]);
-      if (nokv[i]) {
-        if (nsc[i] != 1.0f) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xf[i][j] *= nsc[i];
-        }
-        float es[8], eq[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { es[j] = xf[i][j]; eq[j] = xf[i][j] * xf[i][j]; }
-        if (gran >= 2) {
-#pragma unroll
-          for (int j = 0; j < 8; j += 2) { es[j] += es[j + 1]; eq[j] += eq[j + 1]; }
-        }
-        if (gran >= 4) {
-#pragma unroll
-          for (int j = 0; j < 8; j += 4) { es[j] += es[j + 2]; eq[j] += eq[j + 2]; }
-        }
-        if (gran >= 8) { es[0] += es[4]; eq[0] += eq[4]; }
-        float2* pp = part + (size_t)nrow[i] * gpr + nc[i] / gran;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((j & (gran - 1)) == 0) pp[j >> lg2] = make_float2(es[j], eq[j]);
-        }
-      }
+      for (int j = 0; j < 8; ++j) xf[i][j] *= nmask[i];
+      const float a0 = (xf[i][0] + xf[i][1]) + (xf[i][2] + xf[i][3]), a1 = (xf[i][4] + xf[i][5]) + (xf[i][6] + xf[i][7]);
+      const float c0 = (xf[i][0] * xf[i][0] + xf[i][1] * xf[i][1]) + (xf[i][2] * xf[i][2] + xf[i][3] * xf[i][3]);
+      const float c1 = (xf[i][4] * xf[i][4] + xf[i][5] * xf[i][5]) + (xf[i][6] * xf[i][6] + xf[i][7] * xf[i][7]);
+      s += a0 + a1;
+      q += c0 + c1;
     }
-    __syncthreads();
-    DK_STAMP(sy, 12);
-    // 16 lanes per (batch element of the unit, group): lane j adds elements j, j+16, ... then a DPP tree, fixed order
-    const int pairs = nb * groups;
-    for (int pid = tid >> 4; pid < pairs; pid += NT / 16) {
-      const int bl = (int)(((float)pid + 0.5f) * inv_groups);
-      const int g = pid - bl * groups;
-      const int glo = g * cpg / gran;
-      const int ghi = (g == groups - 1) ? gpr : (g + 1) * cpg / gran;       // the last group also takes padding channels
-      const int ngr = ghi - glo;
-      const int n_el = L_in * ngr;
-      float s = 0.f, q = 0.f;
-      if (b0 + bl < B) {
-        const float inv_ngr = 1.0f / (float)ngr;
-#pragma unroll 4
-        for (int e = li; e < n_el; e += 16) {
-          const int t = (int)(((float)e + 0.5f) * inv_ngr);
-          const int gi = e - t * ngr;
-          const float2 v = part[(size_t)(bl * L_in + t) * gpr + glo + gi];
-          s += v.x;
-          q += v.y;
-        }
-      }
-      s = row16_sum_d(s);
-      q = row16_sum_d(q);
-      if (li == 0) {
-        const float mean = s * inv_count;
-        float var = q * inv_count - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        const float rstd = PRECISE ? 1.0f / sqrtf(var + gn_eps) : rsqrtf(var + gn_eps);
-        stat[pid] = make_float2(mean, rstd);
-      }
-    }
-    __syncthreads();
-    DK_STAMP(sy, 13);
+    s = lane_set_sum(s, lS);
+    q = lane_set_sum(q, lS);
+    const float inv_count = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_count)));
+    const float gn_eps = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.gn_eps)));
+    const float mean = s * inv_count;
+    float var = q * inv_count - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = PRECISE ? 1.0f / sqrtf(var + gn_eps) : rsqrtf(var + gn_eps);
+    const bool silu = rfl(P->h.pro_mode) == JEN1_PRO_GN_SILU;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      if (nokv[i]) {
-        if (cpg >= 8) {
-          int g = nc[i] / cpg;
-          g = g < groups ? g : groups - 1;
-          const float2 st = stat[nbl[i] * groups + g];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xf[i][j] = (xf[i][j] - st.x) * st.y * p1[i][j] + p2[i][j];
-        } else {
+      for (int j = 0; j < 8; ++j) xf[i][j] = (xf[i][j] - mean) * rstd * p1[j] + p2[j];
+      if (silu) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            int g = (nc[i] + j) / cpg;
-            g = g < groups ? g : groups - 1;
-            const float2 st = stat[nbl[i] * groups + g];
-            xf[i][j] = (xf[i][j] - st.x) * st.y * p1[i][j] + p2[i][j];
-          }
-        }
-        if (pro == JEN1_PRO_GN_SILU) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) xf[i][j] = PRECISE ? silu_precise(xf[i][j]) : silu_f(xf[i][j]);
-        }
-        store8(tile + (size_t)nrow[i] * pitch + nc[i], xf[i]);
+        for (int j = 0; j < 8; ++j) xf[i][j] = PRECISE ? silu_precise(xf[i][j]) : silu_f(xf[i][j]);
       }
+      store8(tile + ntile[i], xf[i]);
     }
   }
+#else
+  float rres[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
   __syncthreads();
   DK_STAMP(sy, 3);
 
-  // ---- K loop: weights from the ring, activation fragments from the staged tile ---------------------------------------------
+  // ---- K loop: rounds of the PF ring slots; a slot is refilled behind its use when the wave has more chunks ---------------------
   f32x4 acc[4];
 #pragma unroll
   for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int cbl[4], ct[4];
-  bool cok[4];
+#ifndef JEN1_DEEP_EXP_NOK
+  {
+    KCursor ic = cc;                                   // already behind the first round's chunks when there are more
+    for (int c0 = 0; c0 < total; c0 += PF) {
+      if (NF == 1) k_round<T, 1>(acc, ra, tile, cbase, soff);
+      else if (NF == 2) k_round<T, 2>(acc, ra, tile, cbase, soff);
+      else if (NF == 3) k_round<T, 3>(acc, ra, tile, cbase, soff);
+      else k_round<T, 4>(acc, ra, tile, cbase, soff);
+      if (c0 + PF < total) {
+        // next round: request its chunks (slots beyond the end: zero), note their staged offsets
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf) {
-    const int n = nf * 16 + li;
-    const int bl = (int)(((float)n + 0.5f) * inv_Lout);
-    cbl[nf] = bl * L_in;
-    ct[nf] = (n - bl * L_out) * stride;
-    cok[nf] = nf < NF && n < nb * L_out && b0 + bl < B;
-  }
-  const uint2* ent = reinterpret_cast<const uint2*>(D + TAB_OFF + 32) + wk * MAXE;
-  const int total = gw.total;
-  auto consume = [&](int j, const typename DFrag<T>::type& fa) {
-    const unsigned ey = ent[j].y;
-    const int col = (int)(ey & 0xffffu) + lg * 8;
-    const int sh = (int)(signed char)(ey >> 16);
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      if (nf < NF) {
-        const int tin = ct[nf] + sh;
-        const bool ok = cok[nf] && tin >= 0 && tin < L_in;
-        typename DFrag<T>::type fb;
-        dlds(fb, tile + (size_t)(ok ? cbl[nf] + tin : R) * pitch + col);
-        dmma(acc[nf], fa, fb);
-      }
-    }
-  };
-  for (int c = 0; c < total; c += PF) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int j = c + i;
-      if (j < total) {
-        consume(j, ra[i]);
-        if (j + PF < total) gemm_issue<T>(D, gw, wk, lane, j + PF, ra[i]);
+        for (int i = 0; i < PF; ++i) {
+          if (c0 + PF + i < total) {
+            gemm_issue<T>(gw, ic, lane, ra[i]);
+            soff[i] = ic.shift * pitch + ic.col;
+            if (c0 + PF + i + 1 < total) kc_next(ic, gw.runs, gw.nruns);
+          } else {
+            frag_zero_d(ra[i]);
+          }
+        }
       }
     }
   }
+#endif
   DK_STAMP(sy, 4);
 
   // ---- K reduction across the waves (fixed order), epilogue by the first NF waves; the next unit's descriptor is published
-  // with the partial sums, its weight ring is requested as soon as this unit's stores have drained ------------------------------
+  // with the partial sums ----------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int nf = 0; nf < 4; ++nf) {
     if (nf < NF) *reinterpret_cast<float4*>(red + ((size_t)(wk * NF + nf) * 64 + lane) * 4) = make_float4(acc[nf][0], acc[nf][1], acc[nf][2], acc[nf][3]);
@@ -629,34 +745,40 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   __syncthreads();
   DK_STAMP(sy, 14);
   if (epi) {
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 o[NW];
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) {
-      const float4 o = *reinterpret_cast<const float4*>(red + ((size_t)(w2 * NF + nfe) * 64 + lane) * 4);
-      v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    for (int w2 = 0; w2 < NW; ++w2) o[w2] = *reinterpret_cast<const float4*>(red + ((size_t)(w2 * NF + nfe) * 64 + lane) * 4);
+    float v[4];
+    // fixed order, as a tree: ((0+1)+(2+3)) + ((4+5)+(6+7))
+#pragma unroll
+    for (int st = 1; st < NW; st <<= 1) {
+#pragma unroll
+      for (int w2 = 0; w2 + st < NW; w2 += 2 * st) {
+        o[w2].x += o[w2 + st].x; o[w2].y += o[w2 + st].y; o[w2].z += o[w2 + st].z; o[w2].w += o[w2 + st].w;
+      }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += bias4[r];
-    if (act == JEN1_ACT_GELU && !low_m) {
+    v[0] = o[0].x + bias4[0]; v[1] = o[0].y + bias4[1]; v[2] = o[0].z + bias4[2]; v[3] = o[0].w + bias4[3];
+    if (rfl(P->h.act) == JEN1_ACT_GELU && !low_m) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
+#ifdef JEN1_DEEP_EXP_NOEPI
+    if (okk && v[0] == 1234.5f) {
+#else
     if (okk) {
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += rres[r];
-      const size_t off = (size_t)((unsigned)yrow * (unsigned)ld_y) + (unsigned)co;
-      if (y_f32) st_live4(reinterpret_cast<float*>(yp) + off, v);
-      else st_live4(reinterpret_cast<T*>(yp) + off, v);
+      const size_t off = (size_t)((unsigned)yrow * (unsigned)rfl(P->h.ld_y)) + (unsigned)co;
+      if (rfl(P->h.y_f32)) st_live4(reinterpret_cast<float*>(P->h.y) + off, v);
+      else st_live4(reinterpret_cast<T*>(P->h.y) + off, v);
     }
     DK_STAMP(sy, 15);
     drain_stores();
-  } else {
-    prefill_next();
   }
   __syncthreads();
   DK_STAMP(sy, 5);
   arrive_phase(sy, tid);
-  if (epi) prefill_next();
   DK_STAMP(sy, 6);
 }
 
@@ -664,9 +786,8 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 // attention unit: one (batch element, head, 32-query chunk); attention.hip's structure for 8 waves with the LayerNorm
 // statistics of the deferred finish computed here (blocks.py:355-380, :427-429)
 // =====================================================================================================================
-template <typename T, typename FPub, typename FPre>
-__device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, FPub publish_next,
-                                          FPre prefill_next, int tid) {
+template <typename T, typename FPub>
+__device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, FPub publish_next, int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef typename DFrag<T>::type Frag;
   constexpr bool PRECISE = is_f32<T>::value;
@@ -749,6 +870,11 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   if (need_wait) wait_phase(sy, sy.p - 1, dep_units, tid);
   DK_STAMP(sy, 2);
 
+#ifdef JEN1_DEEP_EXP_NOATTN
+  if (sy.wg == 100000) {
+#else
+  {
+#endif
   // ---- live operands -------------------------------------------------------------------------------------------------
   if (kv_live) {
 #pragma unroll
@@ -948,11 +1074,12 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
     T* op = outp + ((size_t)((unsigned)(b * Nq + q0 + kr0) * (unsigned)ldo) + (unsigned)(hd + kc0));
     st_live8(op, q_s + kr0 * dq + kc0);
   }
+  }
+  publish_next();
   drain_stores();
   __syncthreads();
   DK_STAMP(sy, 5);
   arrive_phase(sy, tid);
-  prefill_next();
   DK_STAMP(sy, 6);
 }
 
@@ -960,9 +1087,8 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
 // statistics unit: GroupNorm fine-group (sum, sumsq) of one batch element of the chain's last tensor, for the
 // launch-per-layer consumer that follows the persistent launch (same layout as jen1_conv_args.gn_stats*)
 // =====================================================================================================================
-template <typename T, typename FPub, typename FPre>
-__device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, FPub publish_next,
-                                           FPre prefill_next, int tid) {
+template <typename T, typename FPub>
+__device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, FPub publish_next, int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
   const int b = u, L = P->sL, ld = P->sld, cpf = P->scpf, gran = P->sgran;
@@ -1029,7 +1155,6 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
   __syncthreads();
   DK_STAMP(sy, 5);
   arrive_phase(sy, tid);
-  prefill_next();
   DK_STAMP(sy, 6);
 }
 
@@ -1051,6 +1176,10 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
   sy.dead = false;
   sy.wg = wg;
   sy.nwg = nwg;
+#ifdef JEN1_DEEP_PROFILE
+#pragma unroll
+  for (int i_ = 0; i_ < 16; ++i_) sy.tt[i_] = 0;
+#endif
   int p = -1, u = 0;
   if (!find_next(hdr, n_phases, wg, nwg, p, u)) return;
   p = rfl(p);
@@ -1059,7 +1188,7 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
   reinterpret_cast<u64*>(smem + HDR_BYTES)[tid] = reinterpret_cast<const u64*>(blobs + (size_t)p * BLOB)[tid];
   __syncthreads();
   Frag ra[PF];
-  bool prefilled = false;
+  if (hdr[p].kind == JEN1_DEEP_GEMM) gemm_prefill<T>(smem + HDR_BYTES, u, wk, lane, ra);
   int waited = -1;
   for (;;) {
     int p2 = p, u2 = u;
@@ -1071,29 +1200,25 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
     if (reload) nx = reinterpret_cast<const u64*>(blobs + (size_t)p2 * BLOB)[tid];       // in flight during the unit
     const unsigned char* D = smem + HDR_BYTES + slot * BLOB;
     unsigned char* Dn = smem + HDR_BYTES + (reload ? slot ^ 1 : slot) * BLOB;
-    const bool next_gemm = more && hdr[p2].kind == JEN1_DEEP_GEMM;
-    bool next_prefilled = false;
-    // called by the unit right before one of its __syncthreads() / after it
+    // called by the unit right before one of its __syncthreads()
     auto publish_next = [&]() { if (reload) reinterpret_cast<u64*>(Dn)[tid] = nx; };
-    auto prefill_next = [&]() {
-      if (next_gemm) {
-        gemm_prefill<T>(Dn, u2, wk, lane, ra);
-        next_prefilled = true;
-      }
-    };
     sy.p = p;
     const bool need_wait = waited != p && p > 0;
     waited = p;
     const int dep_units = p > 0 ? hdr[p - 1].n_units : 0;
     const int kind = hdr[p].kind;
-    if (kind == JEN1_DEEP_GEMM) gemm_unit<T>(D, u, sy, need_wait, dep_units, ra, prefilled, publish_next, prefill_next, tid);
-    else if (kind == JEN1_DEEP_ATTN) attn_unit<T>(D, u, sy, need_wait, dep_units, publish_next, prefill_next, tid);
-    else stats_unit<T>(D, u, sy, need_wait, dep_units, publish_next, prefill_next, tid);
+    if (kind == JEN1_DEEP_GEMM) gemm_unit<T>(D, u, sy, need_wait, dep_units, ra, publish_next, tid);
+    else if (kind == JEN1_DEEP_ATTN) attn_unit<T>(D, u, sy, need_wait, dep_units, publish_next, tid);
+    else stats_unit<T>(D, u, sy, need_wait, dep_units, publish_next, tid);
+    DK_FLUSH(sy);
     if (!more) break;
+    // the next unit's weight ring: requested right behind this unit's arrival, long before its dependency wait ends
+#ifndef JEN1_DEEP_EXP_NOPRE
+    if (hdr[p2].kind == JEN1_DEEP_GEMM) gemm_prefill<T>(Dn, u2, wk, lane, ra);
+#endif
     p = p2;
     u = u2;
     if (reload) slot ^= 1;
-    prefilled = next_prefilled;
   }
 }
 
@@ -1129,16 +1254,16 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   const int maxv = a->dtype == JEN1_F32 ? JEN1_DEEP_MAXV_F : JEN1_DEEP_MAXV_B;
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
-  p.kind = JEN1_DEEP_GEMM;
-  p.dtype = a->dtype;
-  p.dep = -1;
+  p.h.kind = JEN1_DEEP_GEMM;
+  p.h.dtype = a->dtype;
+  p.h.dep = -1;
   // ---- sources and segments ------------------------------------------------------------------------------------------------
   int ns = 0, coff = 0;
-  p.src[ns++] = jen1_deep_src{a->x0, a->ld0, a->c0, 0, 1.0f};
+  p.h.src[ns++] = jen1_deep_src{a->x0, a->ld0, a->c0, 0, 1.0f};
   coff = a->c0;
   if (a->c1) {
     JEN1_CHECK(a->x1, "deep conv: c1 without x1");
-    p.src[ns++] = jen1_deep_src{a->x1, a->ld1, a->c1, coff, a->src1_scale};
+    p.h.src[ns++] = jen1_deep_src{a->x1, a->ld1, a->c1, coff, a->src1_scale};
     coff += a->c1;
   }
   const int cmain = coff;
@@ -1150,81 +1275,120 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   for (int s = 0; s < a->nseg; ++s) {
     const jen1_conv_seg& e = a->seg[s];
     JEN1_CHECK(e.x && e.kch > 0 && e.ld >= 32 * e.kch, "deep conv: bad extra segment %d", s);
-    p.src[ns++] = jen1_deep_src{e.x, e.ld, 32 * e.kch, coff, 1.0f};
+    p.h.src[ns++] = jen1_deep_src{e.x, e.ld, 32 * e.kch, coff, 1.0f};
     G += e.kch;
     p.seg[nseg++] = jen1_deep_seg{coff, e.shift, G, 0};
     coff += 32 * e.kch;
   }
-  p.nsrc = ns; p.nseg = nseg; p.G = G; p.Ctot = coff;
-  p.pitch = coff + 8;
-  p.MT = a->M / 16;
-  const int64_t wb = (int64_t)G * p.MT * 512 * es;
+  p.h.nsrc = ns; p.h.nseg = nseg; p.h.G = G; p.h.Ctot = coff;
+  p.h.pitch = coff + 8;
+  p.h.MT = a->M / 16;
+  const int64_t wb = (int64_t)G * p.h.MT * 512 * es;
   JEN1_CHECK(wb < ((int64_t)1 << 31), "deep conv: packed weight too large for 31-bit offsets");
-  p.w = a->w; p.w_bytes = (uint32_t)wb;
-  p.mt_split = a->m_split / 16;
-  p.g_split = a->m_split ? a->k_split : 0;
-  JEN1_CHECK(a->m_split % 16 == 0 && p.g_split <= G, "deep conv: bad dual-range split");
-  p.B = a->B; p.L_in = a->L_in; p.L_out = a->L_out; p.stride = a->stride;
+  p.h.w = a->w; p.h.w_bytes = (uint32_t)wb;
+  p.h.mt_split = a->m_split / 16;
+  p.h.g_split = a->m_split ? a->k_split : 0;
+  JEN1_CHECK(a->m_split % 16 == 0 && p.h.g_split <= G, "deep conv: bad dual-range split");
+  p.h.B = a->B; p.h.L_in = a->L_in; p.h.L_out = a->L_out; p.h.stride = a->stride;
   // ---- prologue ---------------------------------------------------------------------------------------------------------------
-  p.pro_mode = a->pro_mode;
+  p.h.pro_mode = a->pro_mode;
   if (a->pro_mode != JEN1_PRO_NONE) {
     JEN1_CHECK(a->gn_gamma && a->gn_beta && a->gn_groups >= 1 && a->gn_cpg >= 1 && a->gn_count >= 1, "deep conv: incomplete GroupNorm");
-    p.norm_C = cmain;
-    p.gn_groups = a->gn_groups;
-    p.gn_cpg = a->gn_groups == 1 ? cmain : a->gn_cpg;
-    p.gran = p.gn_cpg >= 8 ? 8 : p.gn_cpg;
-    JEN1_CHECK((p.gn_cpg >= 8 && p.gn_cpg % 8 == 0) || p.gn_cpg == 4 || p.gn_cpg == 2 || p.gn_cpg == 1, "deep conv: group size %d", p.gn_cpg);
-    JEN1_CHECK(a->gn_groups * p.gn_cpg <= cmain, "deep conv: groups exceed the channels");
-    p.inv_count = 1.0f / (float)a->gn_count;
-    p.gn_eps = a->gn_eps;
-    p.inv_groups = 1.0f / (float)a->gn_groups;
+    p.h.norm_C = cmain;
+    p.h.gn_groups = a->gn_groups;
+    p.h.gn_cpg = a->gn_groups == 1 ? cmain : a->gn_cpg;
+    p.h.gran = p.h.gn_cpg >= 8 ? 8 : p.h.gn_cpg;
+    JEN1_CHECK((p.h.gn_cpg >= 8 && p.h.gn_cpg % 8 == 0) || p.h.gn_cpg == 4 || p.h.gn_cpg == 2 || p.h.gn_cpg == 1, "deep conv: group size %d", p.h.gn_cpg);
+    JEN1_CHECK(a->gn_groups * p.h.gn_cpg == cmain, "deep conv: %d groups of %d channels do not tile the %d channels", a->gn_groups, p.h.gn_cpg, cmain);
+    p.h.inv_count = 1.0f / (float)a->gn_count;
+    p.h.gn_eps = a->gn_eps;
+    p.h.inv_groups = 1.0f / (float)a->gn_groups;
     if (a->film) {
       // `film` is the FUSED table here: gamma * (scale + 1) at film_off + c, beta * (scale + 1) + shift at film_off + film_C + c
       JEN1_CHECK(a->film_C == cmain && a->film_ld >= a->film_off + 2 * a->film_C, "deep conv: bad FiLM table geometry");
-      p.p1 = a->film + a->film_off;
-      p.p2 = a->film + a->film_off + a->film_C;
-      p.p_ld = a->film_ld;
-      p.film_row = a->film_row; p.film_step = a->film_step;
+      p.h.p1 = a->film + a->film_off;
+      p.h.p2 = a->film + a->film_off + a->film_C;
+      p.h.p_ld = a->film_ld;
+      p.h.film_row = a->film_row; p.h.film_step = a->film_step;
     } else {
-      p.p1 = a->gn_gamma; p.p2 = a->gn_beta; p.p_ld = 0;
+      p.h.p1 = a->gn_gamma; p.h.p2 = a->gn_beta; p.h.p_ld = 0;
     }
   }
   // ---- epilogue ----------------------------------------------------------------------------------------------------------------
-  p.bias = a->bias; p.residual = a->residual; p.y = a->y;
-  p.out_C = a->out_C; p.ps_f = a->ps_f < 1 ? 1 : a->ps_f; p.ps_off = a->ps_off; p.L_y = a->L_y; p.y_brows = a->y_brows;
-  p.y_row0 = a->y_row0; p.ld_y = a->ld_y; p.ld_res = a->ld_res; p.act = a->act; p.y_f32 = a->y_f32;
+  p.h.bias = a->bias; p.h.residual = a->residual; p.h.y = a->y;
+  p.h.out_C = a->out_C; p.h.ps_f = a->ps_f < 1 ? 1 : a->ps_f; p.h.ps_off = a->ps_off; p.h.L_y = a->L_y; p.h.y_brows = a->y_brows;
+  p.h.y_row0 = a->y_row0; p.h.ld_y = a->ld_y; p.h.ld_res = a->ld_res; p.h.act = a->act; p.h.y_f32 = a->y_f32;
   JEN1_CHECK(a->out_C % 4 == 0 && a->ld_y % 4 == 0 && (!a->residual || a->ld_res % 4 == 0), "deep conv: output channels / pitches must be multiples of 4");
   JEN1_CHECK((int64_t)a->B * a->L_in * (a->ld0 > a->ld1 ? a->ld0 : a->ld1) < ((int64_t)1 << 31) && (int64_t)a->B * a->y_brows * a->ld_y < ((int64_t)1 << 31),
              "deep conv: tensor too large");
-  // ---- unit geometry: as many batch elements per unit as fit (fewer, fatter units re-read the weights less) --------------------------
-  int nb = a->B;
-  if (nb_max > 0 && nb > nb_max) nb = nb_max;
-  for (;; --nb) {
+  // ---- staging geometry -------------------------------------------------------------------------------------------------------
+  // raw part: a thread owns one 8-channel column (vectors per row: a power of two that divides the workgroup)
+  {
+    const int vr = (coff - p.h.norm_C) / 8;
+    JEN1_CHECK((vr & (vr - 1)) == 0 && vr <= JEN1_DEEP_THREADS, "deep conv: %d raw channels: vectors per row must be a power of two <= %d",
+               coff - p.h.norm_C, JEN1_DEEP_THREADS);
+    int l = 0;
+    while ((1 << l) < vr) ++l;
+    p.h.lvr = l;
+  }
+  // halo rows: a tap is a plain row offset in the staged tile
+  int min_sh = 0, max_sh = 0;
+  for (int s = 0; s < nseg; ++s) {
+    min_sh = p.seg[s].shift < min_sh ? p.seg[s].shift : min_sh;
+    max_sh = p.seg[s].shift > max_sh ? p.seg[s].shift : max_sh;
+  }
+  p.h.Hb = -min_sh;
+  int Ha = (a->L_out - 1) * a->stride + max_sh - (a->L_in - 1);
+  Ha = Ha < 0 ? 0 : Ha;
+  p.h.Lp = p.h.Hb + a->L_in + Ha;
+  // normalised part: (batch element, group) pairs own 2^lS consecutive lanes, a lane owns one column of the group
+  int lvpg = 0, lgroups = 0;
+  if (p.h.norm_C) {
+    const int vpg = p.h.gn_cpg / 8;
+    JEN1_CHECK(p.h.gn_cpg % 8 == 0 && (vpg & (vpg - 1)) == 0 && (a->gn_groups & (a->gn_groups - 1)) == 0 && vpg <= 64,
+               "deep conv: %d groups of %d channels: the persistent kernel needs power-of-two groups of at least 8 channels", a->gn_groups, p.h.gn_cpg);
+    while ((1 << lvpg) < vpg) ++lvpg;
+    while ((1 << lgroups) < a->gn_groups) ++lgroups;
+  }
+  p.h.lvpg = lvpg; p.h.lgroups = lgroups;
+  // ---- unit geometry: as many batch elements per unit as fit (a power of two; fewer, fatter units re-read the weights less) -----------
+  int nb = 1;
+  while (nb * 2 <= a->B) nb *= 2;
+  if (nb_max > 0) while (nb > nb_max) nb /= 2;
+  if (p.h.p_ld && !p.h.film_step) nb = 1;      // a per-element FiLM table: one table row per unit
+  for (;; nb /= 2) {
     JEN1_CHECK(nb >= 1, "deep conv: one batch element (%d rows x %d channels) does not fit a unit", a->L_in, coff);
     const int cols = nb * a->L_out;
     const int NF = ceil_div(cols, 16);
-    const int R = nb * a->L_in;
     if (NF > 4) continue;
-    if ((int64_t)R * (p.norm_C / 8) > (int64_t)maxv * JEN1_DEEP_THREADS) continue;       // normalised vectors per thread
-    const int tile_b = align16i((R + 1) * p.pitch * es);
-    const int part_b = p.norm_C ? align16i(R * (p.norm_C / p.gran) * 8) : 0;
-    const int stat_b = p.norm_C ? align16i(nb * p.gn_groups * 8) : 0;
-    const int red_b = (JEN1_DEEP_THREADS / 64) * NF * 1024;
-    const int tot = tile_b + stat_b + (part_b > red_b ? part_b : red_b);
+    int lS = 6;
+    if (p.h.norm_C) {
+      const int pairs = nb * a->gn_groups;
+      if (pairs > JEN1_DEEP_THREADS / 8) continue;                       // at least 8 lanes per pair
+      int S = JEN1_DEEP_THREADS / pairs;
+      S = S > 64 ? 64 : S;
+      lS = 0;
+      while ((1 << lS) < S) ++lS;
+      if ((1 << lvpg) > S) continue;                                      // a lane owns a column
+      if (ceil_div(a->L_in << lvpg, S) > maxv) continue;                  // vectors per lane
+    }
+    const int Rtot = nb * p.h.Lp + (p.h.Hb + Ha + 1);
+    const int tile_b = align16i(Rtot * p.h.pitch * es);
+    int red_b = (JEN1_DEEP_THREADS / 64) * NF * 1024;                    // K-reduction scratch, also the per-thread dummy vector slots
+    red_b = red_b > JEN1_DEEP_THREADS * 8 * es ? red_b : JEN1_DEEP_THREADS * 8 * es;
+    const int tot = tile_b + red_b;
     if (tot > LDS_BUDGET) continue;
-    p.nb = nb; p.NF = NF; p.R = R;
-    p.stat_off = tile_b;
-    p.part_off = tile_b + stat_b;
-    p.red_off = tile_b + stat_b;        // the partial sums are dead when the K reduction starts
-    p.lds_bytes = tot;
+    p.h.nb = nb; p.h.NF = NF; p.h.R = nb * a->L_in; p.h.Rtot = Rtot; p.h.zrow = nb * p.h.Lp + p.h.Hb; p.h.lS = lS;
+    p.h.red_off = tile_b;
+    p.h.lds_bytes = tot;
     break;
   }
-  p.groups_n = ceil_div(a->B, p.nb);
-  p.n_units = p.MT * p.groups_n;
-  JEN1_CHECK(p.n_units < (1 << 20), "deep conv: too many units");
-  p.inv_vpr = 1.0f / (float)(coff / 8);
-  p.inv_Lin = 1.0f / (float)a->L_in;
-  p.inv_Lout = 1.0f / (float)a->L_out;
+  p.h.groups_n = ceil_div(a->B, p.h.nb);
+  p.h.n_units = p.h.MT * p.h.groups_n;
+  JEN1_CHECK(p.h.n_units < (1 << 20), "deep conv: too many units");
+  p.h.inv_vpr = 1.0f / (float)(coff / 8);
+  p.h.inv_Lin = 1.0f / (float)a->L_in;
+  p.h.inv_Lout = 1.0f / (float)a->L_out;
   return 0;
 }
 
@@ -1254,13 +1418,13 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
   JEN1_CHECK(lds <= LDS_BUDGET, "deep attention: Nk=%d d=%d needs %lld B of LDS", Nk, d, (long long)lds);
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
-  p.kind = JEN1_DEEP_ATTN;
-  p.dtype = dtype;
-  p.dep = -1;
-  p.lds_bytes = align16i((int)lds);
+  p.h.kind = JEN1_DEEP_ATTN;
+  p.h.dtype = dtype;
+  p.h.dep = -1;
+  p.h.lds_bytes = align16i((int)lds);
   p.q = q; p.k = k; p.v = v; p.out = out_t; p.kv_row = kv_row; p.kv_extra = kv_extra; p.extra_row = extra_row; p.extra_step = extra_step;
   p.ln_u = ln_u; p.ln_b = ln_b;
-  p.ld_extra = ld_extra; p.kx_off = kx_off; p.vx_off = vx_off; p.B = B; p.H = H; p.d = d; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.q_off = q_off;
+  p.ld_extra = ld_extra; p.kx_off = kx_off; p.vx_off = vx_off; p.h.B = B; p.H = H; p.d = d; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.q_off = q_off;
   p.ldkv = ldkv; p.k_off = k_off; p.v_off = v_off; p.ldo = ldo; p.causal = causal;
   p.ln_C = ln_C; p.fin_q = finish_q; p.fin_kv = finish_kv; p.kv_live = kv_live;
   p.nqc = ceil_div(Nq, QCHUNK);
@@ -1268,8 +1432,8 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
   while ((8 << l2) < d) ++l2;
   p.log2_vpr = l2;
   p.scale = scale; p.ln_eps = ln_eps; p.inv_H = 1.0f / (float)H; p.inv_nqc = 1.0f / (float)p.nqc;
-  p.n_units = B * H * p.nqc;
-  JEN1_CHECK(p.n_units < (1 << 20), "deep attention: too many units");
+  p.h.n_units = B * H * p.nqc;
+  JEN1_CHECK(p.h.n_units < (1 << 20), "deep attention: too many units");
   return 0;
 }
 
@@ -1279,16 +1443,16 @@ extern "C" int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, 
   JEN1_CHECK(ld >= 32 && (ld & (ld - 1)) == 0 && ld / 8 <= JEN1_DEEP_THREADS, "deep stats: row pitch %d must be a power of two in [32, 8192]", ld);
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
-  p.kind = JEN1_DEEP_STATS;
-  p.dtype = dtype;
-  p.dep = -1;
+  p.h.kind = JEN1_DEEP_STATS;
+  p.h.dtype = dtype;
+  p.h.dep = -1;
   p.sx = x; p.sstats = stats; p.sL = L; p.sld = ld;
   p.scpf = ld / JEN1_FINE_GROUPS;
   p.sgran = p.scpf >= 8 ? 8 : p.scpf;
-  p.B = B;
-  p.n_units = B;
+  p.h.B = B;
+  p.h.n_units = B;
   const int vpr = ld / 8, sub = 8 / p.sgran;
-  p.lds_bytes = align16i((JEN1_DEEP_THREADS / vpr) * vpr * sub * 8);
+  p.h.lds_bytes = align16i((JEN1_DEEP_THREADS / vpr) * vpr * sub * 8);
   return 0;
 }
 
@@ -1301,40 +1465,45 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
   memset(bl, 0, (size_t)n_phases * BLOB);
   for (int p = 0; p < n_phases; ++p) {
     jen1_deep_phase& P = phases[p];
-    P.dep = p - 1;
-    P.dep_units = p ? phases[p - 1].n_units : 0;
+    P.h.dep = p - 1;
+    P.h.dep_units = p ? phases[p - 1].h.n_units : 0;
     // successive phases start their units on successive workgroups (multiples of 8 keep a unit's XCD = its M tile mod 8):
     // a workgroup that just finished a unit is rarely the one the next phase waits for, so it has the time of a few
     // phases to pull the weight slice of its next unit, and the weight streams spread over all CUs
-    P.rot = rot % nwg;
-    rot += ((P.n_units + 7) / 8) * 8;
-    lds = P.lds_bytes > lds ? P.lds_bytes : lds;
+    P.h.rot = rot % nwg;
+    rot += ((P.h.n_units + 7) / 8) * 8;
+    lds = P.h.lds_bytes > lds ? P.h.lds_bytes : lds;
     unsigned char* b = bl + (size_t)p * BLOB;
     memcpy(b, &P, sizeof(P));
-    hd[4 * p + 0] = P.n_units; hd[4 * p + 1] = P.rot; hd[4 * p + 2] = P.kind; hd[4 * p + 3] = 0;
-    if (P.kind != JEN1_DEEP_GEMM) continue;
+    hd[4 * p + 0] = P.h.n_units; hd[4 * p + 1] = P.h.rot; hd[4 * p + 2] = P.h.kind; hd[4 * p + 3] = 0;
+    if (P.h.kind != JEN1_DEEP_GEMM) continue;
     // K chunks that can touch a real input row (a segment whose every row is conv padding for every position is skipped
-    // together with its weights: exact), dealt round-robin to the waves
+    // together with its weights: exact), dealt round-robin to the waves; per wave and segment that is one run
     int16_t* cnt = reinterpret_cast<int16_t*>(b + TAB_OFF);
-    uint32_t* ent = reinterpret_cast<uint32_t*>(b + TAB_OFF + 32);
-    const int tmax = (P.L_out - 1) * P.stride;
-    int k = 0;
-    for (int s = 0; s < P.nseg; ++s) {
+    int32_t* runs = reinterpret_cast<int32_t*>(b + TAB_OFF + 64);
+    const int tmax = (P.h.L_out - 1) * P.h.stride;
+    int k0 = 0;
+    for (int s = 0; s < P.h.nseg; ++s) {
       const int sb = s ? P.seg[s - 1].gend : 0, se = P.seg[s].gend, sh = P.seg[s].shift;
-      if (!(tmax + sh >= 0 && sh < P.L_in)) continue;
-      JEN1_CHECK(sh >= -128 && sh <= 127, "deep link: shift %d out of range", sh);
-      for (int g = sb; g < se; ++g, ++k) {
-        const int w = k % NW, j = k / NW;
-        JEN1_CHECK(j < MAXE, "deep link: phase %d has more than %d K chunks per wave", p, MAXE);
-        const int col = P.seg[s].coff + (g - sb) * 32;
-        JEN1_CHECK(col < 65536, "deep link: staged column %d out of range", col);
-        ent[(w * MAXE + j) * 2 + 0] = (uint32_t)g;
-        ent[(w * MAXE + j) * 2 + 1] = (uint32_t)col | ((uint32_t)(uint8_t)(int8_t)sh << 16);
-        cnt[w] = (int16_t)(j + 1);
-        if (P.mt_split && g < P.g_split) cnt[NW + w] = (int16_t)(j + 1);
+      if (!(tmax + sh >= 0 && sh < P.h.L_in)) continue;
+      const bool low = P.h.mt_split && sb < P.h.g_split;
+      JEN1_CHECK(!low || se <= P.h.g_split, "deep link: phase %d: the dual-range split must fall on a segment boundary", p);
+      const int Ls = se - sb;
+      for (int w = 0; w < NW; ++w) {
+        const int i0 = ((w - k0) % NW + NW) % NW;
+        if (i0 >= Ls) continue;
+        const int n = (Ls - i0 + NW - 1) / NW;
+        const int r = cnt[2 * NW + w];
+        JEN1_CHECK(r < MAXRUN, "deep link: phase %d has more than %d runs per wave", p, MAXRUN);
+        int32_t* e = runs + ((size_t)w * MAXRUN + r) * 4;
+        e[0] = sb + i0; e[1] = n; e[2] = P.seg[s].coff + i0 * 32; e[3] = sh;
+        cnt[w] = (int16_t)(cnt[w] + n);
+        cnt[2 * NW + w] = (int16_t)(r + 1);
+        if (low) { cnt[NW + w] = cnt[w]; cnt[3 * NW + w] = cnt[2 * NW + w]; }
       }
+      k0 += Ls;
     }
-    if (!P.mt_split) for (int w = 0; w < NW; ++w) cnt[NW + w] = cnt[w];
+    if (!P.h.mt_split) for (int w = 0; w < NW; ++w) { cnt[NW + w] = cnt[w]; cnt[3 * NW + w] = cnt[2 * NW + w]; }
   }
   return lds + WS_OFF;
 }

@@ -298,7 +298,10 @@ class DeepProgram:
         self.err_word = self.lib.jen1_deep_error_word(n)
 
     def launch(self, stream: int):
-        L.check(self.lib.jen1_deep_run(self.dev.data_ptr(), self.hdr.data_ptr(), len(self.bufs), self.sync.data_ptr(), self.nwg, self.lds,
+        n = len(self.bufs)
+        if os.environ.get("JEN1_DEEP_RUN_PHASES"):          # debugging: run only the first phases of the program
+            n = min(n, int(os.environ["JEN1_DEEP_RUN_PHASES"]))
+        L.check(self.lib.jen1_deep_run(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.nwg, self.lds,
                                        self.eng.dt, stream), "jen1_deep_run")
 
     def error(self) -> int:
@@ -879,7 +882,7 @@ class Plan(OpBuilder):
         n_tr = len(spec.transformers())
         lens = spec.level_lengths(T)
         Ltr = max([lens[i + 1] for i, d in enumerate(spec.downs) if d.transformer] + [lens[-1]])
-        deep_sync = (512 * 8 * 64 + 64) if self.deep_level is not None else 0      # arrival counters of <= 512 phases
+        deep_sync = (256 * 8 * 64 + 64) if self.deep_level is not None else 0      # arrival counters of <= 256 phases
         self.arena = torch.zeros(600 * Be * 64 + (4 * n_tr + 8) * Be * Ltr * 2 + 4096 + deep_sync + 64, dtype=f32, device=dev)
         self._arena_used = 0
         ops = self.ops

@@ -336,11 +336,10 @@ def test_deep_phase_planner_host_side(lib):
     lds = lib.jen1_deep_link(C.cast(host, C.c_void_p), n, 256, C.cast(blobs, C.c_void_p), C.cast(hdrs, C.c_void_p))
     assert 0 < lds <= 160 * 1024
     assert [hdrs[4 * i + 2] for i in range(n)] == [0] * n and hdrs[0] > 0 and hdrs[1] == 0 and hdrs[5] == (hdrs[0] + 7) // 8 * 8 % 256
-    # per-wave K-chunk lists of the first phase (T' = 1, non-causal k = 3 over 2048 channels): only the centre tap can touch a
-    # real row, so 64 of the 192 chunks are listed, 8 per wave, chunk indices 64 + wave + 8 j
-    cnt = (C.c_int16 * 16).from_buffer(blobs, 1024)
-    assert list(cnt) == [8] * 16
-    ent = (C.c_uint32 * 4).from_buffer(blobs, 1024 + 32)
-    assert ent[0] == 64 and ent[1] == 0 and ent[2] == 72 and ent[3] == 8 * 32
-    assert lib.jen1_deep_sync_bytes(n) == (n * 8 * 64 + 64) * 4
-    assert lib.jen1_deep_error_word(n) == n * 8 * 64
+    # per-wave K-chunk runs of the first phase (T' = 1, non-causal k = 3 over 2048 channels): only the centre tap can touch a
+    # real row, so 64 of the 192 chunks are listed: one run of 8 chunks per wave, chunks 64 + wave + 8 j at columns 32 (wave + 8 j)
+    cnt = (C.c_int16 * 32).from_buffer(blobs, 1024)
+    assert list(cnt) == [8] * 16 + [1] * 16
+    run0 = (C.c_int32 * 4).from_buffer(blobs, 1024 + 64)
+    run1 = (C.c_int32 * 4).from_buffer(blobs, 1024 + 64 + 16 * 16)
+    assert list(run0) == [64, 8, 0, 0] and list(run1) == [65, 8, 32, 0]
