@@ -418,17 +418,24 @@ __device__ __forceinline__ void gemm_prefill(const unsigned char* D, int u, int 
   }
 }
 
-// K loop of one round: PF ring slots x NF fragments, straight-line
-template <typename T, int NF, typename Frag, int PF>
+// K loop of one round: the first NS ring slots x NF fragments, straight-line
+template <typename T, int NF, int NS, typename Frag, int PF>
 __device__ __forceinline__ void k_round(f32x4 (&acc)[4], const Frag (&ra)[PF], const T* tile, const int (&cbase)[4], const int (&soff)[PF]) {
 #pragma unroll
-  for (int i = 0; i < PF; ++i) {
+  for (int i = 0; i < (NS < PF ? NS : PF); ++i) {
     Frag fb[NF];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) dlds(fb[nf], tile + cbase[nf] + soff[i]);
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) dmma(acc[nf], ra[i], fb[nf]);
   }
+}
+// a round of `left` chunks (slots beyond them hold zero weights: rounded up to 4 slots)
+template <typename T, int NF, typename Frag, int PF>
+__device__ __forceinline__ void k_round_n(f32x4 (&acc)[4], const Frag (&ra)[PF], const T* tile, const int (&cbase)[4], const int (&soff)[PF], int left) {
+  if (left <= 4) k_round<T, NF, 4>(acc, ra, tile, cbase, soff);
+  else if (left <= 8) k_round<T, NF, 8>(acc, ra, tile, cbase, soff);
+  else k_round<T, NF, PF>(acc, ra, tile, cbase, soff);
 }
 
 // sum over the aligned group of 2^lS lanes (3 <= lS <= 6) that holds v, in a fixed order
@@ -713,10 +720,11 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   {
     KCursor ic = cc;                                   // already behind the first round's chunks when there are more
     for (int c0 = 0; c0 < total; c0 += PF) {
-      if (NF == 1) k_round<T, 1>(acc, ra, tile, cbase, soff);
-      else if (NF == 2) k_round<T, 2>(acc, ra, tile, cbase, soff);
-      else if (NF == 3) k_round<T, 3>(acc, ra, tile, cbase, soff);
-      else k_round<T, 4>(acc, ra, tile, cbase, soff);
+      const int left = total - c0;
+      if (NF == 1) k_round_n<T, 1>(acc, ra, tile, cbase, soff, left);
+      else if (NF == 2) k_round_n<T, 2>(acc, ra, tile, cbase, soff, left);
+      else if (NF == 3) k_round_n<T, 3>(acc, ra, tile, cbase, soff, left);
+      else k_round_n<T, 4>(acc, ra, tile, cbase, soff, left);
       if (c0 + PF < total) {
         // next round: request its chunks (slots beyond the end: zero), note their staged offsets
 #pragma unroll

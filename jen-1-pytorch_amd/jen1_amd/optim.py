@@ -102,6 +102,89 @@ class FusedAdamW:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
 
+class GradExchange:
+    """DDP's bucketed gradient exchange overlapped with the backward pass (train.py:88-89: ``DDP(model)`` all-reduces a
+    bucket as soon as autograd has finished the gradients in it).
+
+    The flat gradient buffer is laid out in forward order (to_mapping, to_time, to_in, downsamples.0 .. 8, bottleneck,
+    upsamples.0 .. 8, to_out, to_time_embedding, fixed_embedding), the backward pass finishes it from the back.  A *region* is
+    the slice of one top-level block; ``TrainGraph`` hooks the activation that enters each block, and when the gradient with
+    respect to that activation exists every parameter gradient of the block is complete (``region_ready``).  A region is
+    reduced in chunks of at most ``bucket_bytes`` on a communication stream (few large RCCL messages: xGMI rings are per-link
+    bound) while the rest of the backward pass runs; regions that only finish with the pass (the head: time MLPs and to_in; the
+    tail: the tiny global embeddings) go out in ``finish``.  Mean over ranks; the result is bit-identical to one blocking
+    all-reduce of the whole buffer chunked the same way (same chunks, same reduction)."""
+
+    def __init__(self, opt: "FusedAdamW", names: List[str], group=None, bucket_bytes: int = 128 << 20):
+        import torch.distributed as dist
+        self.opt, self.group, self.bucket = opt, group, max(1, bucket_bytes // 4)
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        assert len(names) == len(opt.params)
+        self.regions: "dict[str, tuple[int, int]]" = {}
+        for n, p, o in zip(names, opt.params, opt.offsets):
+            r = ".".join(n.split(".")[:2]) if n.startswith(("downsamples.", "upsamples.")) else n.split(".")[0]
+            lo, hi = self.regions.get(r, (o, o))
+            self.regions[r] = (min(lo, o), max(hi, o + (p.numel() + 3) // 4 * 4))
+        self.active = False
+        self._comm = None
+        self._works, self._expect, self._sent = [], {}, set()
+
+    def begin(self) -> None:
+        """arm the exchange for the backward pass(es) that follow (the last micro-batch of an accumulation window)"""
+        self.active = self.world > 1
+        self._works, self._expect, self._sent = [], {}, set()
+        g = self.opt.flat_grad
+        if self.active and g.is_cuda and self._comm is None:
+            self._comm = torch.cuda.Stream(g.device)
+
+    def expect(self, region: str) -> None:
+        """a forward pass registered one more hook for ``region`` (several sub-batches share one backward pass)"""
+        self._expect[region] = self._expect.get(region, 0) + 1
+
+    def region_ready(self, region: str) -> None:
+        if not self.active or region not in self.regions or region in self._sent:
+            return
+        left = self._expect.get(region, 1) - 1
+        self._expect[region] = left
+        if left > 0:
+            return
+        self._send(region)
+
+    def _send(self, region: str) -> None:
+        import torch.distributed as dist
+        self._sent.add(region)
+        lo, hi = self.regions[region]
+        g = self.opt.flat_grad
+        if g.is_cuda:
+            self._comm.wait_stream(torch.cuda.current_stream(g.device))      # the gradients of the region are enqueued before this point
+            with torch.cuda.stream(self._comm):
+                for o in range(lo, hi, self.bucket):
+                    self._works.append(dist.all_reduce(g[o:min(hi, o + self.bucket)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for o in range(lo, hi, self.bucket):
+                self._works.append(dist.all_reduce(g[o:min(hi, o + self.bucket)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        """after the backward pass: send what is left (in reverse order), wait, turn the sums into means"""
+        if not self.active:
+            return
+        for region in reversed(list(self.regions)):
+            if region not in self._sent:
+                self._send(region)
+        for w in self._works:
+            w.wait()
+        g = self.opt.flat_grad
+        if g.is_cuda:
+            torch.cuda.current_stream(g.device).wait_stream(self._comm)
+        g.mul_(1.0 / self.world)
+        self.active = False
+
+    def blocking(self) -> None:
+        """the same exchange with no overlap (graph-replayed backward passes): every region, reverse order, then wait"""
+        self.begin()
+        self.finish()
+
+
 def allreduce_gradients(flat_grad: torch.Tensor, group=None, bucket_bytes: int = 256 << 20) -> None:
     """DDP gradient exchange (train.py:88-89): mean over ranks, in place, in a few large buckets (xGMI rings are
     per-link bound: big messages, not 979 small ones).  ``backend="nccl"`` is RCCL on ROCm; gloo on CPU for tests."""

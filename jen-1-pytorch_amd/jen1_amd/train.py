@@ -565,6 +565,16 @@ class TrainGraph:
         assert not missing, f"module lacks parameters: {missing[:4]}"
         self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
         self._side: Optional[torch.cuda.Stream] = None
+        self.exchange = None        # optim.GradExchange: told when the gradients of a top-level block are complete
+
+    def _mark(self, h: torch.Tensor, region: str) -> torch.Tensor:
+        """``h`` enters the top-level block ``region``: once the gradient with respect to ``h`` exists, every parameter
+        gradient of the block has been enqueued (autograd runs a block's backward nodes before it reaches its input)"""
+        ex = self.exchange
+        if ex is not None and ex.active and h.requires_grad:
+            ex.expect(region)
+            h.register_hook(lambda g, ex=ex, region=region: ex.region_ready(region))
+        return h
 
     def invalidate(self) -> None:
         self.rt.invalidate()
@@ -665,6 +675,7 @@ class TrainGraph:
         h = self.res_block(sp.to_in, h, smap, False)          # Patcher / Unpatcher are never causal (blocks.py:256-259)
         skips_list: List = [h]
         for d in sp.downs:
+            h = self._mark(h, d.name)
             h = conv1d_same(rt, h, p[f"{d.name}.downsample.conv.weight"], p[f"{d.name}.downsample.conv.bias"], d.factor, causal)
             skips = []
             for r in d.blocks:
@@ -674,11 +685,13 @@ class TrainGraph:
                 h = self.transformer(d.transformer, h, embedding, embedding_mask, causal)
                 skips.append(h)
             skips_list.append(skips)
+        h = self._mark(h, "bottleneck")
         h = self.res_block(sp.bott_pre, h, smap, causal)
         if sp.bott_tr:
             h = self.transformer(sp.bott_tr, h, embedding, embedding_mask, causal)
         h = self.res_block(sp.bott_post, h, smap, causal)
         for u in sp.ups:
+            h = self._mark(h, u.name)
             skips = skips_list.pop()
             for r in u.blocks:
                 a, sk = self._crop_pair(h, skips.pop())                 # blocks.py:732-734
@@ -693,6 +706,7 @@ class TrainGraph:
             else:
                 h = conv_transpose1d(rt, h, w, b, f, f // 2 + f % 2, f % 2)
         h = h + skips_list.pop()                                         # model.py:261
+        h = self._mark(h, "to_out")
         h = self.res_block(sp.to_out, h, smap, False)
         return h[:, :, :sp.out_channels].to(torch.float32).transpose(1, 2)
 

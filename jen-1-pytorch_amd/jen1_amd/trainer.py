@@ -19,7 +19,7 @@ from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
 
-from .optim import FusedAdamW, LinearLR, allreduce_gradients
+from .optim import FusedAdamW, GradExchange, LinearLR
 from .tasks import get_conditioning, random_mask
 from .train import GraphedLossStep
 
@@ -34,7 +34,7 @@ class UnifiedMultiTaskTrainer:
                  grad_accum_every: int = 10, tasks: Sequence[str] = TASKS, device="cuda", process_group=None,
                  rng=_random, cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
                  input_concat_ids: Sequence[str] = ("masked_input", "mask"), compute_dtype: Optional[str] = None,
-                 use_graph: bool = True):
+                 use_graph: bool = True, allow_uneven_tasks: bool = False, bucket_bytes: int = 128 << 20):
         self.model, self.diffusion, self.conditioner, self.optimizer, self.lr_scheduler = model, diffusion, conditioner, optimizer, lr_scheduler
         self.grad_accum_every, self.tasks, self.device, self.group, self.rng = grad_accum_every, tuple(tasks), device, process_group, rng
         self.cross_attn_cond_ids, self.global_cond_ids, self.input_concat_ids = cross_attn_cond_ids, global_cond_ids, input_concat_ids
@@ -45,6 +45,12 @@ class UnifiedMultiTaskTrainer:
         self.graphed = GraphedLossStep(self.graph, diffusion, 1.0 / grad_accum_every) if use_graph else None
         self.grad_accum = 0
         self.global_step = 0
+        self.allow_uneven_tasks = allow_uneven_tasks
+        # DDP's gradient exchange (train.py:88-89): buckets in reverse execution order; in eager mode each bucket leaves as soon
+        # as the backward pass has finished it, behind a replayed graph the buckets leave together right after the replay
+        names = [n for n, _ in model.named_parameters()]
+        self.exchange = GradExchange(optimizer, names, process_group, bucket_bytes)
+        self.graph.exchange = self.exchange
 
     # trainer.py:215-247 / :249-278
     def random_mask(self, sequence, max_mask_length, task):
@@ -59,11 +65,20 @@ class UnifiedMultiTaskTrainer:
         loss_dict: Dict[str, torch.Tensor] = {}
         all_loss = torch.zeros((), device=self.device)
         batch_size = audio_emb.size(0)
-        assert batch_size % len(self.tasks) == 0, "Batch size must be divisible by the number of tasks"
-        sub = batch_size // len(self.tasks)
+        nt = len(self.tasks)
+        if not self.allow_uneven_tasks:
+            assert batch_size % nt == 0, "Batch size must be divisible by the number of tasks"       # trainer.py:187
+        # BASELINE configs[3] puts 8 clips on a GPU (64 / 8), which three tasks do not divide: the first ``batch_size % 3``
+        # tasks take one clip more (8 -> 3 / 3 / 2), task order as in config.py:93
+        sizes = [batch_size // nt + (1 if i < batch_size % nt else 0) for i in range(nt)]
+        start = 0
         for i, task in enumerate(self.tasks):
-            sub_audio_emb = audio_emb[i * sub:(i + 1) * sub]
-            sub_metadata = metadata[i * sub:(i + 1) * sub]
+            sub = sizes[i]
+            if sub == 0:
+                continue
+            sub_audio_emb = audio_emb[start:start + sub]
+            sub_metadata = metadata[start:start + sub]
+            start += sub
             self.model.train()
             masked_input, mask, causal = self.random_mask(sub_audio_emb, sub_audio_emb.shape[2], task)
             conditioning = self.conditioner(sub_metadata, self.device)
@@ -84,6 +99,9 @@ class UnifiedMultiTaskTrainer:
     def train_step(self, audio_emb: torch.Tensor, metadata) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], bool]:
         """one iteration of ``train_loop``'s body (trainer.py:134-150).  Returns (loss, per-task losses, whether an
         optimiser step was taken)."""
+        last = self.grad_accum + 1 == self.grad_accum_every
+        if self.graphed is None and last:
+            self.exchange.begin()          # the backward pass of the window's last micro-batch releases the buckets
         all_task_loss, loss_dict = self.train(audio_emb, metadata)
         if self.graphed is None:
             if self.grad_accum == 0:
@@ -92,7 +110,10 @@ class UnifiedMultiTaskTrainer:
         self.grad_accum += 1
         stepped = False
         if self.grad_accum == self.grad_accum_every:
-            allreduce_gradients(self.optimizer.flat_grad, self.group)          # DDP's exchange (train.py:88-89)
+            if self.graphed is None:
+                self.exchange.finish()                                         # DDP's exchange (train.py:88-89), overlapped
+            else:
+                self.exchange.blocking()                                       # behind the replayed graphs
             self.optimizer.step(None if self.lr_scheduler is None else self.lr_scheduler.get_last_lr())
             if self.lr_scheduler is not None:
                 self.lr_scheduler.step()

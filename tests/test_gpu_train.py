@@ -572,7 +572,7 @@ def _ddp_worker(rank, world, port, q):
     from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
     from jen1_amd.init_fill import fill_uniform
     from jen1_amd.model import UNetCFG1d
-    from jen1_amd.optim import FusedAdamW, allreduce_gradients
+    from jen1_amd.optim import FusedAdamW, GradExchange, allreduce_gradients
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
@@ -593,14 +593,30 @@ def _ddp_worker(rank, world, port, q):
         model.train()
         opt = FusedAdamW(model.parameters(), lr=1e-3)
         opt.zero_grad()
-        grads_of(model, opt, rank)                       # every rank its own clips / timesteps / noise (train.py:88-89)
-        allreduce_gradients(opt.flat_grad)               # the exchange: mean over ranks, once per optimiser step
+        # the exchange overlapped with the backward pass (DDP's buckets, train.py:88-89): TrainGraph's hooks release a block's
+        # slice of the flat gradient as soon as the pass has finished it
+        ex = GradExchange(opt, [n for n, _ in model.named_parameters()], bucket_bytes=64 << 10)
+        model.train_graph("f32").exchange = ex
+        ex.begin()
+        grads_of(model, opt, rank)                       # every rank its own clips / timesteps / noise
+        sent_during_backward = len(ex._sent)
+        ex.finish()
+        overlapped = opt.flat_grad.clone()
+        # the same gradients through the blocking exchange: bit for bit the same mean
+        model.train_graph("f32").exchange = None
+        opt.zero_grad()
+        grads_of(model, opt, rank)
+        allreduce_gradients(opt.flat_grad, bucket_bytes=64 << 10)
+        torch.cuda.synchronize()
+        same_as_blocking = bool(torch.allclose(overlapped, opt.flat_grad, rtol=0, atol=2e-6 * float(opt.flat_grad.abs().max())))
+        opt.flat_grad.copy_(overlapped)
         opt.step()
         torch.cuda.synchronize()
         mine = opt.flat_param.detach().cpu()
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
-        out = {"same": bool(all(torch.equal(gathered[0], g_) for g_ in gathered))}
+        out = {"same": bool(all(torch.equal(gathered[0], g_) for g_ in gathered)), "same_as_blocking": same_as_blocking,
+               "sent_during_backward": sent_during_backward}
         if rank == 0:                                     # single-process restatement: accumulate both ranks' gradients, halve
             ref = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
             ref.train()
@@ -634,4 +650,6 @@ def test_data_parallel_step_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0]["same"] and res[1]["same"]
+    assert res[0]["same_as_blocking"] and res[1]["same_as_blocking"]
+    assert res[0]["sent_during_backward"] >= 4, res[0]       # down / bottleneck / up blocks + to_out left during the pass
     assert res[0]["err"] < 1e-5, res[0]

@@ -13,7 +13,7 @@ from helpers import ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import jen1_oracle as O  # noqa: E402  (the checker, tests only)
-from jen1_amd.optim import FusedAdamW, LinearLR, allreduce_gradients  # noqa: E402
+from jen1_amd.optim import FusedAdamW, GradExchange, LinearLR, allreduce_gradients  # noqa: E402
 
 SHAPES = [(37, 5, 3), (128,), (64, 33), (1,), (19, 7)]
 
@@ -177,3 +177,75 @@ def test_gradient_norm_is_bit_reproducible():
     assert all(torch.equal(vals[0], v) for v in vals)
     ref = float((p.grad.double() ** 2).sum())
     assert abs(float(vals[0]) - ref) <= 1e-5 * ref
+
+
+class _FlatOpt:
+    """the part of FusedAdamW that GradExchange reads (flat buffer + per-parameter offsets), on CPU"""
+
+    def __init__(self, shapes):
+        self.params, self.offsets, n = [], [], 0
+        for sh in shapes:
+            p = torch.nn.Parameter(torch.zeros(sh))
+            self.params.append(p)
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.flat_grad = torch.zeros(n)
+
+
+_EX_NAMES = ["to_mapping.0.weight", "to_time.0.0.weights", "to_in.block.a", "downsamples.0.x", "downsamples.0.y", "downsamples.1.x",
+             "bottleneck.a", "upsamples.0.a", "upsamples.1.a", "upsamples.1.b", "to_out.block.a", "to_time_embedding.0.1.weight",
+             "fixed_embedding.embedding.weight"]
+_EX_SHAPES = [(7, 5), (6,), (33,), (100, 3), (17,), (64, 9), (300,), (1000,), (13, 13), (5,), (77,), (4, 129), (129, 16)]
+
+
+def _exchange_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    opt = _FlatOpt(_EX_SHAPES)
+    g0 = torch.randn(opt.flat_grad.numel(), generator=torch.Generator().manual_seed(100 + rank))
+    ex = GradExchange(opt, _EX_NAMES, bucket_bytes=512)                # several chunks per region
+    # overlapped: the backward pass releases the regions from the back, two sub-batches share the pass (two hooks per region)
+    opt.flat_grad.copy_(g0)
+    ex.begin()
+    order = ["to_out", "upsamples.1", "upsamples.0", "bottleneck", "downsamples.1", "downsamples.0"]
+    for r in order:
+        ex.expect(r)
+        ex.expect(r)
+    for r in order:
+        ex.region_ready(r)
+        assert r not in ex._sent
+        ex.region_ready(r)
+        assert r in ex._sent
+    ex.finish()                                                          # head (to_mapping, to_time, to_in) and tail regions
+    overlapped = opt.flat_grad.clone()
+    opt.flat_grad.copy_(g0)
+    ex.blocking()
+    q.put((rank, overlapped.numpy().copy(), opt.flat_grad.numpy().copy(), g0.numpy().copy(), dict(ex.regions)))
+    dist.destroy_process_group()
+
+
+def test_grad_exchange_overlapped_equals_blocking_gloo_world2():
+    """DDP's bucketed exchange (optim.GradExchange): regions released during the backward pass give bit-for-bit what the
+    blocking exchange gives, both equal the mean over ranks, and the regions tile the flat buffer in forward order"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 2000
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = {r: rest for r, *rest in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    mean = (outs[0][2] + outs[1][2]) / 2
+    for r in range(2):
+        ov, bl, _, regions = outs[r]
+        assert np.array_equal(ov, bl)
+        assert np.array_equal(ov, mean.astype(np.float32))
+    regions = outs[0][3]
+    names = list(regions)
+    assert names == ["to_mapping", "to_time", "to_in", "downsamples.0", "downsamples.1", "bottleneck", "upsamples.0", "upsamples.1",
+                     "to_out", "to_time_embedding", "fixed_embedding"]
+    assert regions[names[0]][0] == 0 and all(regions[a][1] == regions[b][0] for a, b in zip(names[:-1], names[1:]))

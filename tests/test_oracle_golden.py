@@ -358,3 +358,27 @@ def test_full_unet_bench_shape_matches_reference():
     y = net(x, np.array([499], dtype=np.int64), embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"],
             embedding_scale=0.8, batch_cfg=True, scale_cfg=True, channels_list=[cond["input_concat_cond"]], causal=True)
     assert rel_err(y[:, :, ::24], g["T9000.y.music_cont"]) < NET_TOL
+
+
+def test_torch_cpu_restatement_matches_reference():
+    """oracle/jen1_oracle_torch.py (the multi-threaded CPU restatement bench.py times as cpu_baseline) against the reference's
+    outputs: every CFG / causal branch of the tiny configuration, and the full model at the bench shape (B=8, no CFG)"""
+    from oracle import jen1_oracle_torch as OT
+    cfg = tiny_model_config()
+    net = OT.TorchOracleUNetCFG1d(filled(UNetSpec(**cfg).param_shapes()), **cfg)
+    g = golden("tiny_unet")
+    x, cond = synth.latents(2, 300), synth.conditioning(2, 300)
+    t = np.array([999, 499], dtype=np.int64)
+    for key in [k for k in g.files if k.startswith("y.s")]:
+        scale_s, rest = key[3:].split(".b")
+        b, r, c = rest[0] == "1", rest[3] == "1", rest[6] == "1"
+        y = net(x, t, embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=float(scale_s),
+                batch_cfg=b, scale_cfg=r, channels_list=[cond["input_concat_cond"]], causal=c)
+        assert rel_err(y[:, :, ::3], g[key]) < NET_TOL, key
+    cfg = full_model_config()
+    net = OT.TorchOracleUNetCFG1d(filled(UNetSpec(**cfg).param_shapes()), **cfg)
+    g = golden("full_bench")
+    x, cond = synth.latents(8, 1500), synth.conditioning(8, 1500)
+    y = net(x, g["B8.t"], embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=1.0,
+            channels_list=[cond["input_concat_cond"]], causal=False)
+    assert rel_err(y[:, :, ::16], g["B8.y.nocfg"]) < NET_TOL

@@ -23,6 +23,7 @@ ap.add_argument("--length", type=int, default=1500)
 ap.add_argument("--cfg", action="store_true")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--general", action="store_true", help="one timestep per batch element (model.forward) instead of the sampler's table mode")
 ap.add_argument("--defs", default="", help="extra -D flags for the tuning build, space separated")
 args = ap.parse_args()
 
@@ -48,16 +49,20 @@ dev = "cuda"
 model = UNetCFG1d(**full_model_config(), compute_dtype=args.dtype, device=dev)
 B, T = args.batch, args.length
 nrep = 2 if args.cfg else 1
-plan = model.engine().plan(B, T, nrep, False)
+plan = model.engine().plan(B, T, nrep, False, n_t=None if args.general else 100)
 assert plan.deep_level is not None, plan.deep_errors
 x, cond = synth.latents(B, T), synth.conditioning(B, T)
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+t = np.array([(131 * i + 7) % 1000 for i in range(plan.n_t)], dtype=np.int64)
+if plan.table_mode:
+    plan.t_in.copy_(tt(t))
 model._prepare(plan, tt(x), tt(t), tt(cond["cross_attn_cond"]), tt(cond["cross_attn_masks"]), [tt(cond["input_concat_cond"])], None)
 prog = plan.deep
 n, nwg = len(prog), prog.nwg
 dbg = torch.zeros((n, nwg, 16), dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
+if plan.table_mode:
+    plan.run_time(s)
 for rep in range(args.reps):
     plan.run(s)
 torch.cuda.synchronize()
