@@ -11,13 +11,26 @@ BASELINE.json configs[1]: full JEN-1 1D-UNet (296.5 M parameters, random init), 
 Encodec latents 128x1500, 100-step DDIM schedule, bf16 storage / fp32 accumulate.  With N>1 every
 rank runs its own B=8 batch (independent samples, no data-path collective): weak scaling.
 
+Inside the timed region: the time-embedding / FiLM tables were computed once for the whole schedule
+and the DDIM noise is eta=0 (none); CFG dropout is off (sampling).  Nothing else is hoisted.
+
 The JSON line also carries
-  roofline      -- fused conv-GEMM kernel family (the dominant kernel): algorithmic HBM bytes per
-                   launch / measured average launch duration (HIP events on the launch stream)
-                   against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md;
-  cpu_baseline  -- the numpy oracle (a port of the reference's CPU path) timed on this box's host
-                   cores on a bounded sample of the same workload (rank 0, N=1 only);
-  extra         -- configs[2] (CFG pair, effective batch 16) measured the same way.
+  roofline      -- the dominant kernel of the step, ``deep_kernel`` (the persistent launch that
+                   runs every level below T'=64 as one phase list): algorithmic HBM bytes of its
+                   phases / its measured launch duration (HIP events on the launch stream, the
+                   launch replayed alone in a HIP graph) against the 8 TB/s HBM3E peak of
+                   MI355X_MICROARCH.md; ``long_levels`` holds the same figure for the fused
+                   conv-GEMM launches of the levels above it;
+  cpu_baseline  -- the torch-CPU oracle (oracle/jen1_oracle_torch.py, a restatement of the
+                   reference's CPU path, all physical host cores) on a bounded sample of the same
+                   workload (rank 0, N=1 only);
+  extra         -- configs[2] (CFG pair, effective batch 16) measured the same way, and the other
+                   rows of SURVEY.md section 8.
+
+    python bench.py --mode train --gpus N     (torchrun as above)
+measures BASELINE configs[3]'s per-GPU shape instead: one optimiser step of the multi-task trainer
+(8 clips per GPU as 3/3/2 sub-batches through the CFG pair, gradient exchange over RCCL overlapped
+with the backward pass, clip + AdamW), reported in clips/s.
 """
 import argparse
 import json
@@ -48,6 +61,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="configs[0] tiny UNet (plumbing check)")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"])
+    ap.add_argument("--eager-train", action="store_true", help="--mode train: eager backward (overlapped exchange) only")
     return ap.parse_args()
 
 
@@ -108,6 +123,76 @@ def concurrent_batches_bench(model, B, T, device, n, steps, warmup):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"batches_in_flight": n, "steps_per_s_aggregate": round(n * steps / dt, 1), "ms_per_step_per_batch": round(dt / steps * 1e3, 3)}
+
+
+def pmc_entry(name):
+    """HBM bytes / MFMA-busy of the committed rocprofv3 --pmc passes of this command (profiles/r02_pmc.json, produced by
+    tools/pmc_summary.py from the per-pass CSVs; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))["kernels"].get(name)
+    except Exception:
+        return None
+
+
+def graph_time_ms(fn, R=20):
+    """average duration of ``fn`` (launches on the current stream) replayed R times as a HIP graph between two HIP events"""
+    stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(stream)
+    with torch.cuda.stream(side):
+        fn(side.cuda_stream)
+    stream.wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn(torch.cuda.current_stream().cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(R):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / R
+
+
+def deep_roofline(st, dtype):
+    """The persistent deep-level launch on its own: [zero its arrival counters, launch] replayed as a HIP graph minus the
+    zeroing replayed alone.  Algorithmic bytes = every phase's weights once + its input and output activations once
+    (DESIGN.md section 5); inputs are whatever the last step left in the plan's buffers (no data-dependent control flow)."""
+    plan = st.plan
+    deep = [op for op in plan.ops if getattr(op, "kind", "") == "deep"]
+    if not deep:
+        return None
+    op = deep[0]
+    prog = plan.deep
+    sync = prog.sync
+
+    def zero(s):
+        sync.zero_()
+
+    def both(s):
+        sync.zero_()
+        op(s)
+    t_zero = graph_time_ms(zero)
+    t_both = graph_time_ms(both)
+    ms = t_both - t_zero
+    assert prog.error() == 0, "deep kernel: dependency wait timed out"
+    alg = op.w_bytes + op.act_bytes
+    achieved = alg / (ms * 1e-3) / 1e9
+    pm = pmc_entry("deep_kernel") or {}
+    n_ph = len(prog)
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pm.get("hbm_bytes_per_launch"),
+        "kernel": "deep_kernel<%s> (persistent: %d dependent phases in one launch, levels %d..bottom)" % (
+            dtype, n_ph, plan.deep_level),
+        "launches_per_step": 1, "avg_launch_us": round(ms * 1e3, 1), "phases": n_ph, "us_per_phase": round(ms * 1e3 / n_ph, 2),
+        "alg_bytes_per_launch": int(alg), "alg_weight_bytes": int(op.w_bytes), "alg_act_bytes": int(op.act_bytes),
+        "executed_gflop_per_launch": round(op.flops / 1e9, 2), "mfma_busy_pct": pm.get("mfma_busy_pct"),
+        "pmc_source": pm.get("source"),
+    }
 
 
 def conv_roofline(st, reps=3):
@@ -177,13 +262,8 @@ def conv_roofline(st, reps=3):
         with open(os.environ["JEN1_BENCH_OPS"], "w") as f:
             for i in range(n):
                 f.write(f"{per_op[i] * 1e3:8.1f} us  w={convs[i].w_bytes / 1e6:7.2f}MB act={convs[i].act_bytes / 1e6:6.2f}MB  {convs[i].label}\n")
-    traffic = None
-    try:   # HBM bytes per launch from the committed PMC run of this same command (profiles/, rocprofv3 --pmc)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pm.get("launches_per_step") == n:
-            traffic = pm["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    pm = pmc_entry("conv_family") or {}
+    traffic = pm.get("hbm_bytes_per_launch") if pm.get("launches_per_step") == n else None
     return {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -301,33 +381,127 @@ def encodec_decode_bench(B, T, dtype, device):
     return out
 
 
+def physical_cores():
+    """physical cores this process may run on (SMT siblings counted once): (physical id, core id) pairs of /proc/cpuinfo
+    restricted to the affinity mask"""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except Exception:
+        allowed = set(range(os.cpu_count() or 1))
+    cores, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+    except Exception:
+        pass
+    return max(1, len(cores)) if cores else max(1, len(allowed))
+
+
 def cpu_baseline(B, T, tiny):
-    """The CPU oracle (numpy port of the reference path) on the host cores: bounded sample."""
+    """The CPU oracle on the host cores: oracle/jen1_oracle_torch.py (restatement of the reference's CPU path on torch's CPU
+    tensor library, pinned against the reference's outputs by tests/test_oracle_golden.py), one thread per physical core,
+    3 warm-up forwards + at least 5 timed ones on the bench shape."""
     from jen1_amd import synth
     from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config
     from jen1_amd.init_fill import fill
-    from oracle import jen1_oracle as O
+    from oracle import jen1_oracle_torch as OT
+    cores = physical_cores()
+    torch.set_num_threads(cores)
     cfg = tiny_model_config() if tiny else full_model_config()
     spec = UNetSpec(**cfg)
-    net = O.OracleUNetCFG1d({k: fill(k, s, 1234) for k, s in spec.param_shapes()}, **cfg)
+    net = OT.TorchOracleUNetCFG1d({k: fill(k, s, 1234) for k, s in spec.param_shapes()}, **cfg)
     x, cond = synth.latents(B, T), synth.conditioning(B, T)
     t = np.full((B,), 999, dtype=np.int64)
     kw = dict(embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=1.0,
               channels_list=[cond["input_concat_cond"]], causal=False)
-    net(x, t, **kw)                                    # warm-up
+    for _ in range(3):
+        net(x, t, **kw)                                # warm-up (allocator, thread pool, oneDNN primitive cache)
     times = []
     t_start = time.perf_counter()
-    while len(times) < 3 or (time.perf_counter() - t_start < 12.0 and len(times) < 10):
+    while len(times) < 5 or (time.perf_counter() - t_start < 15.0 and len(times) < 40):
         t0 = time.perf_counter()
         net(x, t, **kw)
         times.append(time.perf_counter() - t0)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count()
     return {"value": round(1.0 / float(np.median(times)), 4), "unit": "denoiser steps/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} UNetCFG1d forwards (no CFG) at B={B}, T={T} with the numpy oracle, median; "
+            "sample": f"3 warm-up + {len(times)} timed UNetCFG1d forwards (no CFG) at B={B}, T={T}, float32, torch CPU oracle with "
+                      f"torch.set_num_threads({cores}) (physical cores; {os.cpu_count()} logical), median; "
                       f"min {min(times):.3f}s max {max(times):.3f}s"}
+
+
+def train_mode(args, world, rank, device, dist, barrier):
+    """BASELINE configs[3]'s per-GPU shape: one optimiser step of the multi-task trainer (trainer.py:126-213 + train.py:88-89)
+    = 8 clips of 128x1500 latents per GPU as 3 / 3 / 2 task sub-batches through the CFG pair (forward + backward on the HIP
+    training path), the gradient exchange (mean all-reduce of the 296.5 M float32 gradients over RCCL), clip + AdamW + LinearLR.
+    Conditioner outputs are synthetic T5-shaped embeddings resident in HBM; masks, timesteps, noise and CFG-dropout rows are
+    drawn inside the timed region as the reference draws them."""
+    import random
+    from jen1_amd import synth
+    from jen1_amd.config import full_model_config, tiny_model_config
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW, LinearLR
+    from jen1_amd.trainer import UnifiedMultiTaskTrainer
+    cfg = tiny_model_config() if args.tiny else full_model_config()
+    B, T = args.batch, args.length
+    model = UNetCFG1d(**cfg, compute_dtype=args.dtype, device=device)
+    model.train()
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device=device, cfg_dropout_proba=0.2,
+                           embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    opt = FusedAdamW(model.parameters(), lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1, max_norm=0.7)
+    sched = LinearLR(3e-5)
+    c = synth.conditioning(B, T, "text_guided", seed=rank)
+    emb, msk = dev(c["cross_attn_cond"], device), dev(c["cross_attn_masks"], device)
+
+    def conditioner(metadata, device_):
+        idx = torch.tensor(metadata, device=device_)
+        return {"prompt": (emb[idx], msk[idx])}
+    tr = UnifiedMultiTaskTrainer(model, gd, conditioner, opt, sched, grad_accum_every=1, rng=random.Random(rank), device=device,
+                                 use_graph=not args.eager_train, allow_uneven_tasks=True)
+    audio = dev(synth.latents(B, T, key="clip", seed=rank), device)
+    meta = list(range(B))
+    torch.manual_seed(rank)
+    for _ in range(max(args.warmup, 3)):      # >= 3: every (sub-batch size, causal) graph is captured before the timed region
+        loss, _, _ = tr.train_step(audio, meta)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _, _ = tr.train_step(audio, meta)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    dt, steps_per_s = aggregate(dist, dt, args.steps, world, device)
+    out = {
+        "metric": "training clips/sec (multi-task DDP step, 8 clips x 128x1500 latents per GPU)", "value": round(steps_per_s * B, 2),
+        "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3),
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[3] full JEN-1 1D-UNet (296.5M params)")
+                   + f", {B} clips per GPU (3/3/2 over text_guided / music_inpaint / music_cont), latents 128x{T}, CFG pair, "
+                   + ("eager backward with the exchange overlapped" if args.eager_train else "hipGraph-replayed forward+backward, exchange after the replays")
+                   + ", clip 0.7 + AdamW + LinearLR", "global_batch": B * world, "seq_len": T, "parallelism": f"ddp x{world}"},
+        "loss": round(float(loss), 4),
+    }
+    if world > 1:
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tr.exchange.blocking()
+        torch.cuda.synchronize()
+        out["exchange_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        out["exchange_bytes"] = 4 * opt.numel
+    out["peak_mem_GiB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def init_dist(world, rank, device, backend="nccl"):
@@ -363,6 +537,13 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.mode == "train":
+        train_mode(args, world, rank, device, dist, barrier)
+        barrier()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     from jen1_amd.config import full_model_config, tiny_model_config
     from jen1_amd.model import UNetCFG1d
     cfg = tiny_model_config() if args.tiny else full_model_config()
@@ -377,11 +558,18 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[1] full JEN-1 1D-UNet (296.5M params)")
-                   + f", B={B} per GPU, latents 128x{T}, 100-step DDIM schedule, no CFG, hipGraph-replayed step",
+                   + f", B={B} per GPU, latents 128x{T}, 100-step DDIM schedule (eta=0), no CFG (CFG dropout off: sampling), "
+                     "hipGraph-replayed step; the time-embedding / FiLM tables of the schedule are computed once outside the timed region",
                    "global_batch": B * world, "seq_len": T, "parallelism": f"replicas x{world} (independent samples)"},
     }
     if rank == 0:
-        out["roofline"] = conv_roofline(st)
+        long_levels = conv_roofline(st)
+        deep = deep_roofline(st, args.dtype)
+        if deep is not None:
+            out["roofline"] = deep                       # the dominant kernel of the step
+            out["roofline"]["long_levels"] = long_levels  # the fused conv-GEMM launches of the levels above the deep launch
+        else:
+            out["roofline"] = long_levels
         out["launches_per_step"] = st.plan.n_launch + 1
         if not args.no_extra:
             st2 = build_stepper(model, B, T, device, cfg_pair=True, use_graph=not args.no_graph)

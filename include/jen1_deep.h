@@ -102,13 +102,16 @@ typedef struct jen1_deep_hot {
   int32_t out_C, ps_f, ps_off, L_y, y_brows, y_row0, ld_y, ld_res, act, y_f32;
   int32_t part_off, stat_off, red_off;                /* LDS byte offsets behind the tile */
   jen1_deep_src src[JEN1_DEEP_MAX_SRC];
-  int32_t part_n;             /* unused */
+  int32_t red_bytes;          /* size of one K-reduction scratch at red_off (a second one follows it when mrep > 1) */
   /* staged tile: every batch element owns Lp = Hb + L_in + Ha rows (zero halo rows before / after: a conv tap is a plain row
    * offset), a block of zero rows behind them serves the columns that do not exist (zrow: its centre row) */
   int32_t Lp, Hb, zrow, Rtot;
   /* GroupNorm statistics without LDS: each (batch element of the unit, group) pair owns 2^lS consecutive lanes, a lane owns
    * one 8-channel column of the group (2^lvpg columns per row) */
-  int32_t lS, lvpg, lgroups, pad_hot;
+  int32_t lS, lvpg, lgroups;
+  /* a unit finishes mrep consecutive 16-row M tiles from ONE staged tile (jen1_deep_link: phases with more units than
+   * workgroups; divides MT and mt_split): n_units = (MT / mrep) * groups_n */
+  int32_t mrep;
 } jen1_deep_hot;
 
 typedef struct jen1_deep_phase {

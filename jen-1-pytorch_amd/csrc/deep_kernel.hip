@@ -19,6 +19,7 @@
 // stores, every storing wave drains (asm s_waitcnt vmcnt(0)), one lane arrives with a relaxed agent-scope
 // atomic; consumers poll relaxed, then read with sc1 (L1-bypassing) loads.  Every spin is bounded: a time-out
 // raises the error word and releases every other waiter.
+#include <cstdlib>
 #include "common.h"
 #include "jen1_deep.h"
 
@@ -341,7 +342,7 @@ struct KRun {                // one run of a wave's K chunks: chunk j is flat ch
 
 template <typename T>
 struct GemmWave {            // what prefill and the K loop share (all scalar)
-  int mt, total, nruns, MT;
+  int mt, total, nruns, MT, grp;
   bool low_m;
   const KRun* runs;          // this wave's run list in the LDS blob
   __amdgpu_buffer_rsrc_t rw;
@@ -352,8 +353,11 @@ __device__ __forceinline__ GemmWave<T> gemm_wave(const unsigned char* D, int u, 
   const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
   GemmWave<T> g;
   g.MT = rfl(P->h.MT);
-  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)g.MT));      // u < 2^20: exact
-  g.mt = u - grp * g.MT;
+  const int mrep = rfl(P->h.mrep);
+  const int MTg = g.MT >> (mrep > 4 ? 3 : (mrep > 2 ? 2 : (mrep > 1 ? 1 : 0)));      // units per batch group (mrep: 1, 2, 4, 8)
+  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)MTg));      // u < 2^20: exact
+  g.mt = (u - grp * MTg) * mrep;                                        // the unit's first M tile
+  g.grp = grp;
   g.low_m = g.mt < rfl(P->h.mt_split);
   const short* cnt = reinterpret_cast<const short*>(D + TAB_OFF);
   g.total = rfl(g.low_m ? cnt[NW + wk] : cnt[wk]);
@@ -460,12 +464,12 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const int wk = rfl(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   DK_STAMP(sy, 0);
-  const GemmWave<T> gw = gemm_wave<T>(D, u, wk);
+  GemmWave<T> gw = gemm_wave<T>(D, u, wk);
   const int nb = rfl(P->h.nb), B = rfl(P->h.B), L_in = rfl(P->h.L_in), L_out = rfl(P->h.L_out), NF = rfl(P->h.NF);
   const int pitch = rfl(P->h.pitch), norm_C = rfl(P->h.norm_C), Ctot = rfl(P->h.Ctot), Lp = rfl(P->h.Lp), Hb = rfl(P->h.Hb);
   const int zrow = rfl(P->h.zrow), Rtot = rfl(P->h.Rtot);
-  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)gw.MT));
-  const int mt = gw.mt, b0 = grp * nb;
+  const int mrep = rfl(P->h.mrep);                       // the unit finishes mrep M tiles from one staged tile
+  const int b0 = gw.grp * nb;
   const bool low_m = gw.low_m;
   unsigned char* ws = smem + WS_OFF;
   T* tile = reinterpret_cast<T*>(ws);
@@ -504,14 +508,12 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   }
   const T* nap[MAXV];
   int ntile[MAXV];
-  float nmask[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int t = nt0 + i * ntstep;
     const bool ok = npair_ok && t < L_in;
     nap[i] = nbase + (size_t)((unsigned)(ok ? t : 0) * (unsigned)nld);
     ntile[i] = ok ? (nbl * Lp + Hb + t) * pitch + cn : dummy_tile;
-    nmask[i] = ok ? nscale : 0.f;                                    // scale of the source, 0 for vectors that do not exist
   }
   // ---- the raw part: a thread owns one column, rows r0, r0 + rpr, ... of the unit's nb * L_in staged rows ----------------------
   const int Craw = Ctot - norm_C;
@@ -575,28 +577,33 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       store8(tile + (size_t)row * pitch + c, z8);
     }
   }
-  // ---- epilogue operands that do not depend on other workgroups ----------------------------------------------------------
+  // ---- epilogue operands that do not depend on other workgroups (per M tile of the unit) ------------------------------------
   const bool epi = wk < NF;
   const int nfe = wk;                                   // the fragment this wave finishes
-  const int m = mt * 16 + lg * 4;
-  int ph = 0, co = m;
+  int co = 0, yrow = 0;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  bool okk = false;
-  int yrow = 0;
-  if (epi) {
-    const int out_C = rfl(P->h.out_C), ps_f = rfl(P->h.ps_f);
-    for (int k = 1; k < ps_f; ++k) ph += (m >= k * out_C) ? 1 : 0;
-    co = m - ph * out_C;
-    if (P->h.bias) bias4 = *reinterpret_cast<const f32x4*>(P->h.bias + co);
-    const int n = nfe * 16 + li;
-    const int ebl = (int)(((float)n + 0.5f) * inv_Lout);
-    const int t = n - ebl * L_out;
-    const int ty = t * ps_f + ph - rfl(P->h.ps_off);
-    okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < rfl(P->h.L_y);
-    yrow = okk ? (b0 + ebl) * rfl(P->h.y_brows) + rfl(P->h.y_row0) + ty : 0;
-  }
-  const bool use_res = epi && okk && P->h.residual && (rfl(P->h.mt_split) == 0 || low_m);
-  const T* resp = reinterpret_cast<const T*>(P->h.residual) + ((size_t)((unsigned)yrow * (unsigned)rfl(P->h.ld_res)) + (unsigned)co);
+  bool okk = false, use_res = false;
+  const T* resp = nullptr;
+  auto epi_operands = [&](int mt) {
+    const int m = mt * 16 + lg * 4;
+    int ph = 0;
+    co = m;
+    if (epi) {
+      const int out_C = rfl(P->h.out_C), ps_f = rfl(P->h.ps_f);
+      for (int k = 1; k < ps_f; ++k) ph += (m >= k * out_C) ? 1 : 0;
+      co = m - ph * out_C;
+      if (P->h.bias) bias4 = *reinterpret_cast<const f32x4*>(P->h.bias + co);
+      const int n = nfe * 16 + li;
+      const int ebl = (int)(((float)n + 0.5f) * inv_Lout);
+      const int t = n - ebl * L_out;
+      const int ty = t * ps_f + ph - rfl(P->h.ps_off);
+      okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < rfl(P->h.L_y);
+      yrow = okk ? (b0 + ebl) * rfl(P->h.y_brows) + rfl(P->h.y_row0) + ty : 0;
+    }
+    use_res = epi && okk && P->h.residual && (rfl(P->h.mt_split) == 0 || low_m);
+    resp = reinterpret_cast<const T*>(P->h.residual) + ((size_t)((unsigned)yrow * (unsigned)rfl(P->h.ld_res)) + (unsigned)co);
+  };
+  epi_operands(gw.mt);
   // ---- K loop: column base of this lane per fragment; scalar (shift * pitch + channel) offset per ring slot of the first round ---
   const int total = gw.total;
   int cbase[4];
@@ -678,8 +685,9 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       raw_to_float(xn[i], xf[i]);
+      const float nm = ntile[i] != dummy_tile ? nscale : 0.f;           // scale of the source, 0 for vectors that do not exist
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xf[i][j] *= nmask[i];
+      for (int j = 0; j < 8; ++j) xf[i][j] *= nm;
       const float a0 = (xf[i][0] + xf[i][1]) + (xf[i][2] + xf[i][3]), a1 = (xf[i][4] + xf[i][5]) + (xf[i][6] + xf[i][7]);
       const float c0 = (xf[i][0] * xf[i][0] + xf[i][1] * xf[i][1]) + (xf[i][2] * xf[i][2] + xf[i][3] * xf[i][3]);
       const float c1 = (xf[i][4] * xf[i][4] + xf[i][5] * xf[i][5]) + (xf[i][6] * xf[i][6] + xf[i][7] * xf[i][7]);
@@ -712,12 +720,14 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   __syncthreads();
   DK_STAMP(sy, 3);
 
-  // ---- K loop: rounds of the PF ring slots; a slot is refilled behind its use when the wave has more chunks ---------------------
-  f32x4 acc[4];
+  // ---- per M tile of the unit: K loop, K reduction across the waves, epilogue.  The first tile is the straight path; further
+  // tiles (mrep > 1: phases with more M tiles x batch groups than workgroups) reuse the staged tile -----------------------------
+  const int red_floats = rfl(P->h.red_bytes) >> 2;
+  // K loop: rounds of the PF ring slots; a slot is refilled behind its use when the wave has more chunks
+  auto k_loop = [&](f32x4 (&acc)[4]) __attribute__((always_inline)) {
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifndef JEN1_DEEP_EXP_NOK
-  {
     KCursor ic = cc;                                   // already behind the first round's chunks when there are more
     for (int c0 = 0; c0 < total; c0 += PF) {
       const int left = total - c0;
@@ -739,25 +749,38 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
         }
       }
     }
-  }
 #endif
-  DK_STAMP(sy, 4);
-
-  // ---- K reduction across the waves (fixed order), epilogue by the first NF waves; the next unit's descriptor is published
-  // with the partial sums ----------------------------------------------------------------------------------------------------
+  };
+  // the next tile of the unit: the same chunks, the next 1 KiB fragment of each; requested behind a K loop
+  auto ring_next_tile = [&]() __attribute__((always_inline)) {
+    gw.mt += 1;
+    KCursor ic;
+    kc_start(ic, gw.runs, gw.nruns);
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf) {
-    if (nf < NF) *reinterpret_cast<float4*>(red + ((size_t)(wk * NF + nf) * 64 + lane) * 4) = make_float4(acc[nf][0], acc[nf][1], acc[nf][2], acc[nf][3]);
-  }
-  publish_next();
-  __syncthreads();
-  DK_STAMP(sy, 14);
-  if (epi) {
+    for (int i = 0; i < PF; ++i) {
+      if (i < total) {
+        gemm_issue<T>(gw, ic, lane, ra[i]);
+        soff[i] = ic.shift * pitch + ic.col;
+        if (i + 1 < total) kc_next(ic, gw.runs, gw.nruns);
+      } else {
+        frag_zero_d(ra[i]);
+      }
+    }
+    cc = ic;
+  };
+  auto put_partial = [&](const f32x4 (&acc)[4], float* redj) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      if (nf < NF) *reinterpret_cast<float4*>(redj + ((size_t)(wk * NF + nf) * 64 + lane) * 4) = make_float4(acc[nf][0], acc[nf][1], acc[nf][2], acc[nf][3]);
+    }
+  };
+  // K reduction across the waves in a fixed order, epilogue by the first NF waves
+  auto epilogue = [&](const float* redj) __attribute__((always_inline)) {
     float4 o[NW];
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) o[w2] = *reinterpret_cast<const float4*>(red + ((size_t)(w2 * NF + nfe) * 64 + lane) * 4);
+    for (int w2 = 0; w2 < NW; ++w2) o[w2] = *reinterpret_cast<const float4*>(redj + ((size_t)(w2 * NF + nfe) * 64 + lane) * 4);
     float v[4];
-    // fixed order, as a tree: ((0+1)+(2+3)) + ((4+5)+(6+7))
+    // as a tree: ((0+1)+(2+3)) + ((4+5)+(6+7))
 #pragma unroll
     for (int st = 1; st < NW; st <<= 1) {
 #pragma unroll
@@ -781,6 +804,33 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       if (rfl(P->h.y_f32)) st_live4(reinterpret_cast<float*>(P->h.y) + off, v);
       else st_live4(reinterpret_cast<T*>(P->h.y) + off, v);
     }
+  };
+  {
+    f32x4 acc[4];
+    k_loop(acc);
+    if (mrep > 1) ring_next_tile();
+    DK_STAMP(sy, 4);
+    put_partial(acc, red);
+    publish_next();                                      // the next unit's descriptor rides on this barrier
+    __syncthreads();
+    DK_STAMP(sy, 14);
+    if (epi) epilogue(red);
+  }
+  for (int j = 1; j < mrep; ++j) {
+    // consecutive tiles alternate between two scratch areas: one barrier per tile
+    epi_operands(gw.mt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rres[r] = 0.f;
+    if (use_res) ld_live4(rres, resp);
+    f32x4 acc[4];
+    k_loop(acc);
+    if (j + 1 < mrep) ring_next_tile();
+    float* redj = red + (j & 1) * red_floats;
+    put_partial(acc, redj);
+    __syncthreads();
+    if (epi) epilogue(redj);
+  }
+  if (epi) {
     DK_STAMP(sy, 15);
     drain_stores();
   }
@@ -1388,10 +1438,12 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
     if (tot > LDS_BUDGET) continue;
     p.h.nb = nb; p.h.NF = NF; p.h.R = nb * a->L_in; p.h.Rtot = Rtot; p.h.zrow = nb * p.h.Lp + p.h.Hb; p.h.lS = lS;
     p.h.red_off = tile_b;
+    p.h.red_bytes = red_b;
     p.h.lds_bytes = tot;
     break;
   }
   p.h.groups_n = ceil_div(a->B, p.h.nb);
+  p.h.mrep = 1;
   p.h.n_units = p.h.MT * p.h.groups_n;
   JEN1_CHECK(p.h.n_units < (1 << 20), "deep conv: too many units");
   p.h.inv_vpr = 1.0f / (float)(coff / 8);
@@ -1473,6 +1525,17 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
   memset(bl, 0, (size_t)n_phases * BLOB);
   for (int p = 0; p < n_phases; ++p) {
     jen1_deep_phase& P = phases[p];
+    if (P.h.kind == JEN1_DEEP_GEMM && P.h.mrep == 1 && !getenv("JEN1_DEEP_NO_MREP")) {
+      // more units than workgroups: a unit finishes several M tiles from one staged tile instead of the workgroup staging the
+      // same rows once per tile (second K-reduction scratch behind the first)
+      int mrep = 1;
+      while (mrep < 8 && (P.h.MT / mrep) * P.h.groups_n > nwg && P.h.MT % (2 * mrep) == 0 && P.h.mt_split % (2 * mrep) == 0) mrep *= 2;
+      if (mrep > 1 && P.h.lds_bytes + P.h.red_bytes <= LDS_BUDGET) {
+        P.h.mrep = mrep;
+        P.h.n_units = (P.h.MT / mrep) * P.h.groups_n;
+        P.h.lds_bytes += P.h.red_bytes;
+      }
+    }
     P.h.dep = p - 1;
     P.h.dep_units = p ? phases[p - 1].h.n_units : 0;
     // successive phases start their units on successive workgroups (multiples of 8 keep a unit's XCD = its M tile mod 8):

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Per-kernel-family PMC totals of one replayed denoiser step -> profiles/r02_pmc.json (read by bench.py's roofline block).
+
+usage: pmc_summary.py OUT.json  COUNTER=results.db [COUNTER=results.db ...]  [--step 3]
+Each results.db is one rocprofv3 --pmc pass (rocpd format) of `python bench.py --steps 8 --warmup 3 --no-extra
+--no-cpu-baseline`; counters are collected in separate passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do
+not fit one pass).  Corrections applied here and recorded in the output:
+  FETCH_SIZE (KiB)  x 2   -- gfx950 reports half of the bytes of wide coalesced streaming reads (the guide's HBM section);
+  WRITE_SIZE (KiB)  x 1   -- uncalibrated, taken as is;
+  MFMA busy = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4)   (rocprofiler-sdk's MfmaUtil expression).
+"""
+import collections
+import json
+import sqlite3
+import sys
+
+
+def family(n):
+    if "deep_kernel" in n:
+        return "deep_kernel"
+    if "conv_gemm" in n or "stream_gemm" in n or "tile_gemm" in n or "TileArgs" in n:
+        return "conv_family"
+    if "norm_apply" in n:
+        return "norm_apply"
+    if "attention" in n:
+        return "attention"
+    return n.split("(")[0][-40:]
+
+
+def per_step(db, counter, which):
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    T = lambda p: [t for t in tabs if t.startswith(p)][0]
+    kd, ks, pe, ip = T("rocpd_kernel_dispatch"), T("rocpd_info_kernel_symbol"), T("rocpd_pmc_event"), T("rocpd_info_pmc")
+    ipcols = [r[1] for r in c.execute(f"pragma table_info({ip})")]
+    namecol = "name" if "name" in ipcols else ipcols[8]
+    ids = [r[0] for r in c.execute(f"select id from {ip} where {namecol}=?", (counter,))]
+    scols = [r[1] for r in c.execute(f"pragma table_info({ks})")]
+    name_col = "display_name" if "display_name" in scols else "kernel_name"
+    q = f"""select s.{name_col}, d.start, sum(p.value) from {kd} d join {ks} s on d.kernel_id = s.id
+            join {pe} p on p.event_id = d.event_id where p.pmc_id in ({','.join(str(i) for i in ids)})
+            group by d.id order by d.start"""
+    rows = list(c.execute(q))
+    idx = [i for i, r in enumerate(rows) if "pack_input" in r[0]]
+    a = idx[which]
+    b = idx[which + 1] if which + 1 < len(idx) else len(rows)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for n, _, v in rows[a:b]:
+        f = family(n)
+        agg[f][0] += 1
+        agg[f][1] += v
+    return agg, b - a
+
+
+def main():
+    out = sys.argv[1]
+    which = 3
+    passes = {}
+    args = sys.argv[2:]
+    while args:
+        a = args.pop(0)
+        if a == "--step":
+            which = int(args.pop(0))
+        else:
+            k, v = a.split("=", 1)
+            passes[k] = v
+    data = {k: per_step(v, k, which) for k, v in passes.items()}
+    fams = sorted({f for agg, _ in data.values() for f in agg})
+    res = {"source": "rocprofv3 --kernel-trace --pmc <one counter set per pass>, `python bench.py --steps 8 --warmup 3 --no-extra "
+                     "--no-cpu-baseline`, one replayed step (tools/profile_round.sh, tools/pmc_summary.py)",
+           "corrections": {"FETCH_SIZE": "KiB x 2 (gfx950 wide streaming reads are tallied at half)", "WRITE_SIZE": "KiB as reported"},
+           "dispatches_per_step": {k: n for k, (_, n) in data.items()}, "kernels": {}}
+    for f in fams:
+        e = {}
+        n = max((data[k][0][f][0] for k in data if f in data[k][0]), default=0)
+        e["launches_per_step"] = n
+        if "FETCH_SIZE" in data and f in data["FETCH_SIZE"][0]:
+            e["fetch_kib_raw"] = round(data["FETCH_SIZE"][0][f][1], 1)
+        if "WRITE_SIZE" in data and f in data["WRITE_SIZE"][0]:
+            e["write_kib_raw"] = round(data["WRITE_SIZE"][0][f][1], 1)
+        if "fetch_kib_raw" in e or "write_kib_raw" in e:
+            e["hbm_bytes_per_launch"] = int((2.0 * e.get("fetch_kib_raw", 0.0) + e.get("write_kib_raw", 0.0)) * 1024 / max(n, 1))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in data and "GRBM_GUI_ACTIVE" in data and f in data["GRBM_GUI_ACTIVE"][0]:
+            busy = data["SQ_VALU_MFMA_BUSY_CYCLES"][0][f][1]
+            act = data["GRBM_GUI_ACTIVE"][0][f][1]
+            e["mfma_busy_cycles"] = int(busy)
+            e["gui_active_cycles"] = int(act)
+            e["mfma_busy_pct"] = round(100.0 * busy / (act * 256 * 4), 3) if act else None
+        e["source"] = "profiles/r02_pmc.txt"
+        res["kernels"][f] = e
+    json.dump(res, open(out, "w"), indent=1)
+    for f, e in sorted(res["kernels"].items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0) * kv[1]["launches_per_step"]):
+        print(f"{f:42s} n={e['launches_per_step']:4d}  fetch {e.get('fetch_kib_raw', 0) / 1024:9.1f} MiB raw  write {e.get('write_kib_raw', 0) / 1024:8.1f} MiB"
+              f"  hbm/launch {e.get('hbm_bytes_per_launch', 0) / 1e6:8.3f} MB  mfma_busy {e.get('mfma_busy_pct')}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,13 +1,20 @@
+# round profile: kernel stats + per-step breakdown + PMC passes (HBM traffic, MFMA busy) of the default bench command.
+# run on the GPU box:  bash tools/profile_round.sh [tag]     outputs under gpurun_out/profile (copy the summaries to profiles/)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+TAG=${1:-r02}
 O=gpurun_out/profile; mkdir -p $O
-JEN1_BENCH_NO_CPU=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format rocpd -- python bench.py --steps 20 --warmup 5 --no-extra > $O/trace.log 2>&1
-python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --top 24 > $O/kernel_stats.txt 2>&1
-python tools/rocpd_step.py $(find $O/trace -name "*.db" | head -1) 12 40 > $O/step_breakdown.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  JEN1_BENCH_NO_CPU=1 timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format rocpd -- python bench.py --steps 8 --warmup 3 --no-extra > $O/pmc_$c.log 2>&1
-  python tools/rocpd_pmc.py $(find $O/pmc_$c -name "*.db" | head -1) $c 3 >> $O/pmc.txt 2>&1
+B="python bench.py --no-extra --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format rocpd -- $B --steps 20 --warmup 5 > $O/trace.log 2>&1
+python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --top 24 > $O/${TAG}_kernel_stats_bf16_B8_T1500.txt 2>&1
+python tools/rocpd_step.py $(find $O/trace -name "*.db" | head -1) 12 40 > $O/${TAG}_step_breakdown_bf16_B8_T1500.txt 2>&1
+ARGS=""
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  d=$O/pmc_$(echo $c | cut -d' ' -f1)
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format rocpd -- $B --steps 8 --warmup 3 > $d.log 2>&1
+  db=$(find $d -name "*.db" | head -1)
+  for n in $c; do ARGS="$ARGS $n=$db"; done
 done
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-tail -1 $O/bench.json | cut -c1-400
-cat $O/pmc.txt | head -30
-rm -rf $O/trace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+python tools/pmc_summary.py $O/${TAG}_pmc.json $ARGS > $O/${TAG}_pmc.txt 2>&1
+cat $O/${TAG}_pmc.txt | head -12
+head -30 $O/${TAG}_kernel_stats_bf16_B8_T1500.txt
+rm -rf $O/trace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES
