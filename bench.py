@@ -412,7 +412,6 @@ def cpu_baseline(B, T, tiny):
     from jen1_amd.init_fill import fill
     from oracle import jen1_oracle_torch as OT
     cores = physical_cores()
-    torch.set_num_threads(cores)
     cfg = tiny_model_config() if tiny else full_model_config()
     spec = UNetSpec(**cfg)
     net = OT.TorchOracleUNetCFG1d({k: fill(k, s, 1234) for k, s in spec.param_shapes()}, **cfg)
@@ -420,18 +419,34 @@ def cpu_baseline(B, T, tiny):
     t = np.full((B,), 999, dtype=np.int64)
     kw = dict(embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=1.0,
               channels_list=[cond["input_concat_cond"]], causal=False)
+    # thread count: one per physical core is the starting point; these layers are small enough that a 128-thread pool spends
+    # its time in fork / join, so the count is halved while that is faster (2 forwards each) and the best one is timed
+    tried = {}
+    n = cores
+    while n >= 1:
+        torch.set_num_threads(n)
+        net(x, t, **kw)
+        t0 = time.perf_counter()
+        net(x, t, **kw)
+        tried[n] = time.perf_counter() - t0
+        if len(tried) >= 2 and tried[n] > 1.15 * min(tried.values()) or n <= 4:
+            break
+        n //= 2
+    threads = min(tried, key=tried.get)
+    torch.set_num_threads(threads)
     for _ in range(3):
         net(x, t, **kw)                                # warm-up (allocator, thread pool, oneDNN primitive cache)
     times = []
     t_start = time.perf_counter()
-    while len(times) < 5 or (time.perf_counter() - t_start < 15.0 and len(times) < 40):
+    while len(times) < 5 or (time.perf_counter() - t_start < 12.0 and len(times) < 40):
         t0 = time.perf_counter()
         net(x, t, **kw)
         times.append(time.perf_counter() - t0)
-    return {"value": round(1.0 / float(np.median(times)), 4), "unit": "denoiser steps/s", "cores": cores, "kind": "port",
-            "sample": f"3 warm-up + {len(times)} timed UNetCFG1d forwards (no CFG) at B={B}, T={T}, float32, torch CPU oracle with "
-                      f"torch.set_num_threads({cores}) (physical cores; {os.cpu_count()} logical), median; "
-                      f"min {min(times):.3f}s max {max(times):.3f}s"}
+    return {"value": round(1.0 / float(np.median(times)), 4), "unit": "denoiser steps/s", "cores": threads, "kind": "port",
+            "sample": f"3 warm-up + {len(times)} timed UNetCFG1d forwards (no CFG) at B={B}, T={T}, float32, torch CPU oracle "
+                      f"(oracle/jen1_oracle_torch.py) with torch.set_num_threads({threads}), the fastest of "
+                      f"{ {k: round(v, 3) for k, v in tried.items()} } s per forward tried from the {cores} physical cores down "
+                      f"({os.cpu_count()} logical); median; min {min(times):.3f}s max {max(times):.3f}s"}
 
 
 def train_mode(args, world, rank, device, dist, barrier):
