@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
         eps = (sr * xv[k] - x0) / srm1;
       }
       float xn;
-      if (last != 0.f) xn = x0;
+      if (last == 1.f) xn = x0;                                            // DDIM's final step (gdm.py:207-209)
+      else if (last == 2.f) xn = x0 * sa_n + cc * xv[k] + sg * nv[k];      // DDPM row: posterior mean + sd * noise (gdm.py:144-163)
       else xn = x0 * sa_n + cc * eps + sg * nv[k];
       x_out[idx] = xn;
       if (eps_out) eps_out[idx] = eps;

@@ -150,18 +150,28 @@ class GaussianDiffusion(torch.nn.Module):
         return (torch.tensor(rows, dtype=torch.float32, device=self.device),
                 torch.tensor(ts, dtype=torch.int64, device=self.device))
 
-    @torch.no_grad()
-    def ddim_sample(self, model, shape, conditioning, return_all_timesteps=False, causal=False, init_data=None, *,
-                    init_noise=None, step_noises: Optional[Sequence[torch.Tensor]] = None,
-                    dropout_rows: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True):
-        """gdm.py:181-225.  The keyword-only extras inject the RNG draws (parity tests);
-        by default they come from torch's device generator like the reference's."""
-        cfg = self.embedding_scale != 1.0
-        if not isinstance(model, UNetCFG1d) or (cfg and not self.batch_cfg):
-            return self._ddim_generic(model, shape, conditioning, return_all_timesteps, causal, init_data,
-                                      init_noise, step_noises, dropout_rows)
+    def ddpm_coeff_table(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The same 8-float rows for ancestral sampling (gdm.py:144-163), t = T-1 .. 0: {sqrt_recip, sqrt_recipm1,
+        posterior_mean_coef1, posterior_mean_coef2, exp(0.5 posterior_log_variance_clipped) (0 at t = 0: no noise there),
+        2 (row kind: x_next = coef1 x0 + coef2 x_t + sd noise), sqrt_alpha_t, sqrt(1-alpha_t)}"""
+        h = self._host
+        rows, ts = [], []
+        for t in reversed(range(self.num_timesteps)):
+            sd = (0.5 * h["posterior_log_variance_clipped"][t]).exp().item() if t > 0 else 0.0
+            rows.append([h["sqrt_recip_alphas_cumprod"][t].item(), h["sqrt_recipm1_alphas_cumprod"][t].item(),
+                         h["posterior_mean_coef1"][t].item(), h["posterior_mean_coef2"][t].item(), sd, 2.0,
+                         h["sqrt_alphas_cumprod"][t].item(), h["sqrt_one_minus_alphas_cumprod"][t].item()])
+            ts.append(t)
+        return (torch.tensor(rows, dtype=torch.float32, device=self.device), torch.tensor(ts, dtype=torch.int64, device=self.device))
+
+    def _fused_ok(self, model) -> bool:
+        """the fused stepper covers UNetCFG1d with the CFG pair batched (or no CFG at all)"""
+        return isinstance(model, UNetCFG1d) and not (self.embedding_scale != 1.0 and not self.batch_cfg)
+
+    def _fused_loop(self, st: "DDIMStepper", shape, return_all_timesteps, init_data, init_noise, step_noises, dropout_rows):
+        """drive a stepper through its whole schedule (both samplers): start noise (+ init_data), per-step CFG-dropout rows as
+        the reference draws them at sampling time too (gdm.py:121 -> model.py:323-328), optional injected draws"""
         B = shape[0]
-        st = self.stepper(model, shape, conditioning, causal=causal, use_graph=use_graph)
         audio = torch.randn(shape, device=self.device) if init_noise is None else init_noise.to(self.device, torch.float32).reshape(shape)
         if init_data is not None:
             audio = audio + init_data
@@ -174,17 +184,32 @@ class GaussianDiffusion(torch.nn.Module):
                     drop = torch.as_tensor(dropout_rows[i])
                 elif self.cfg_dropout_proba >= 1.0:
                     drop = torch.ones(B, dtype=torch.bool)
-                else:   # rand_bool at sampling time too (gdm.py:121 -> model.py:323-328)
+                else:
                     drop = torch.bernoulli(torch.full((B,), float(self.cfg_dropout_proba), device=self.device)).to(torch.bool)
-            if return_all_timesteps:
-                audios.append(st.x.clone())
+            if return_all_timesteps and st.mode == "ddim":
+                audios.append(st.x.clone())                  # ddim_sample records the INPUT of each step (gdm.py:205)
             st.step(i, noise=None if step_noises is None or i >= len(step_noises) else step_noises[i], drop_rows=drop,
                     set_rows=self.cfg_dropout_proba > 0.0)
+            if return_all_timesteps and st.mode == "ddpm":
+                audios.append(st.x.clone())                  # p_sample_loop records the OUTPUT of each step (gdm.py:176)
         out = st.x.clone()
         return out if not return_all_timesteps else torch.stack(audios, dim=1)
 
-    def stepper(self, model, shape, conditioning, causal=False, use_graph=True, n_streams=None, plan_slot: int = 0) -> "DDIMStepper":
-        return DDIMStepper(self, model, shape, conditioning, causal, use_graph, n_streams, plan_slot)
+    @torch.no_grad()
+    def ddim_sample(self, model, shape, conditioning, return_all_timesteps=False, causal=False, init_data=None, *,
+                    init_noise=None, step_noises: Optional[Sequence[torch.Tensor]] = None,
+                    dropout_rows: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True):
+        """gdm.py:181-225.  The keyword-only extras inject the RNG draws (parity tests);
+        by default they come from torch's device generator like the reference's."""
+        if not self._fused_ok(model):
+            return self._ddim_generic(model, shape, conditioning, return_all_timesteps, causal, init_data,
+                                      init_noise, step_noises, dropout_rows)
+        st = self.stepper(model, shape, conditioning, causal=causal, use_graph=use_graph)
+        return self._fused_loop(st, shape, return_all_timesteps, init_data, init_noise, step_noises, dropout_rows)
+
+    def stepper(self, model, shape, conditioning, causal=False, use_graph=True, n_streams=None, plan_slot: int = 0,
+                mode: str = "ddim") -> "DDIMStepper":
+        return DDIMStepper(self, model, shape, conditioning, causal, use_graph, n_streams, plan_slot, mode)
 
     def _ddim_generic(self, model, shape, conditioning, return_all_timesteps, causal, init_data, init_noise, step_noises,
                       dropout_rows):
@@ -227,7 +252,13 @@ class GaussianDiffusion(torch.nn.Module):
 
     @torch.no_grad()
     def p_sample_loop(self, model, shape, conditioning, return_all_timesteps=False, init_data=None, *, init_noise=None,
-                      step_noises=None):
+                      step_noises=None, dropout_rows=None, use_graph: bool = True, fused: bool = True):
+        """gdm.py:165-179.  On the HIP denoiser the loop is the same fused stepper as DDIM with ancestral-sampling rows
+        (``ddpm_coeff_table``): one replayed graph per step, uniform per-step noise as the reference draws it (gdm.py:161);
+        ``fused=False`` (or any other callable) runs the literal loop below."""
+        if fused and self._fused_ok(model):
+            st = self.stepper(model, shape, conditioning, causal=False, use_graph=use_graph, mode="ddpm")   # causal is not forwarded (gdm.py:145)
+            return self._fused_loop(st, shape, return_all_timesteps, init_data, init_noise, step_noises, dropout_rows)
         audio = torch.randn(shape, device=self.device) if init_noise is None else init_noise.to(self.device, torch.float32)
         if init_data is not None:
             audio = audio + init_data
@@ -239,7 +270,8 @@ class GaussianDiffusion(torch.nn.Module):
 
     @torch.no_grad()
     def sample(self, model, shape, conditioning, return_all_timesteps=False, causal=False, init_data=None, **kw):
-        """gdm.py:227-230."""
+        """gdm.py:227-230.  (The reference passes ``causal=`` to ``p_sample_loop`` as well, which does not take it: its non-DDIM
+        ``sample()`` raises TypeError and ancestral sampling only runs through ``p_sample_loop`` directly; here both work.)"""
         if not self.is_ddim_sampling:
             return self.p_sample_loop(model, shape, conditioning, return_all_timesteps=return_all_timesteps, init_data=init_data, **kw)
         return self.ddim_sample(model, shape, conditioning, return_all_timesteps=return_all_timesteps, causal=causal,
@@ -287,8 +319,9 @@ class DDIMStepper:
     parity-tested; ROCm 7.2 serialises them, so the default is 1)."""
 
     def __init__(self, gd: GaussianDiffusion, model: UNetCFG1d, shape, conditioning, causal=False, use_graph=True,
-                 n_streams: Optional[int] = None, plan_slot: int = 0):
-        self.gd, self.model = gd, model
+                 n_streams: Optional[int] = None, plan_slot: int = 0, mode: str = "ddim"):
+        assert mode in ("ddim", "ddpm")
+        self.gd, self.model, self.mode = gd, model, mode
         B, C, T = shape
         self.shape = (B, C, T)
         dev = gd.device
@@ -301,7 +334,7 @@ class DDIMStepper:
             n_streams = int(os.environ.get("JEN1_STREAMS", "1"))
         n_streams = max(1, min(n_streams, B))
         sizes = [B // n_streams + (1 if i < B % n_streams else 0) for i in range(n_streams)]
-        self.coef, self.times = gd.ddim_coeff_table()
+        self.coef, self.times = gd.ddim_coeff_table() if mode == "ddim" else gd.ddpm_coeff_table()
         S = self.num_steps = int(self.times.numel())
         self.coef = self.coef.contiguous()
         # per-step noise table [S][B][C][T] (614 MB at B=8, T=1500: nothing against 288 GB of HBM)
@@ -404,7 +437,10 @@ class DDIMStepper:
         for sl, plan, _, _ in self.parts:
             plan.x_in.copy_(x0[sl])
         if fresh_noise:
-            self.noise_all.normal_()
+            if self.mode == "ddim":
+                self.noise_all.normal_()
+            else:
+                self.noise_all.uniform_()          # p_sample draws rand_like, as written (gdm.py:161)
             self._push_noise(None)
         self._set_step(0)
 

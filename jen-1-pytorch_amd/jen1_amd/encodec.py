@@ -290,6 +290,7 @@ class EncodecHIP:
                  overlap: float = 0.01, normalize: bool = True, n_q: Optional[int] = None):
         self.decoder, self.quantizer, self.channels, self.sample_rate, self._encode = decoder, quantizer, channels, sample_rate, encode
         self.encoder, self.normalize, self.n_q = encoder, normalize, n_q
+        self.decoder_device = decoder.device       # Jen1.generate hands the sampled latents over where they are (no host round trip)
         self.segment_length = int(segment * sample_rate)                                   # encodec model.py segment_length
         self.segment_stride = max(1, int((1 - overlap) * self.segment_length))             # encodec model.py segment_stride
 

@@ -23,13 +23,17 @@ Differences, all deliberate and visible:
     evidently means;
   * ``init_audio.size() != 3`` (generation.py:85) compares a ``torch.Size`` with an int and is always true, so the
     reference repeats even batched audio ``batch_size`` times; here only audio without a batch axis is repeated;
-  * ``music_cont`` indexes the mask with ``mask[:, cont_start:]`` on dim 1 (generation.py:106), which is a no-op slice of
-    a size-1 axis that only works for cont_start == 0; here the time axis is sliced.
+  * ``music_cont`` appends ``randn * mask[:, cont_start:]`` to the prefix (generation.py:105-107; the slice is on the
+    size-1 channel axis); the mask is 0 over the whole extension and the extension is multiplied by the mask again before it
+    reaches the network, so zeros are appended here (no noise draw: the sampler's own draws start at the same generator state
+    only if the reference's draw is skipped too -- the test compares against the hand-built call, not a bit-stream);
+  * the decoder gets the latents on its own device (``audio_encoder.decoder_device``, default "cpu" as in
+    generation.py:129): with ``EncodecHIP`` they never leave HBM.
 """
 from __future__ import annotations
 
 import math
-from typing import Callable, Optional, Sequence
+from typing import Callable, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -77,65 +81,81 @@ class Jen1:
             self._model = model.eval()
         return diffusion, self._model
 
-    # generation.py:76-132
+    # ------------------------------------------------------------------ generate (generation.py:76-132)
+    #
+    # A request is planned in three independent pieces and only then touches the device:
+    #   _task_window   which seconds are to be generated (the mask is 0 there) and whether the denoiser runs causally
+    #   _known_audio   the waveform whose latents are "known": silence, the given audio, or the given prefix + placeholder
+    #   _sample        latents of the known audio -> conditioning dict -> DDIM loop on the HIP path -> decoder
+    def _task_window(self, task: str, seconds: float, inpainting_scope, prefix_samples: int) -> Tuple[float, float, bool]:
+        """(start_s, end_s, causal): text_guided generates everything, music_inpaint the given scope, music_cont everything
+        behind the given prefix with the causal network (generation.py:96-110)"""
+        if task == "text_guided":
+            return 0.0, float(seconds), False
+        if task == "music_inpaint":
+            if inpainting_scope is None or len(inpainting_scope) != 2:
+                raise ValueError("music_inpaint needs inpainting_scope=(start_s, end_s)")
+            return float(inpainting_scope[0]), float(inpainting_scope[1]), False
+        if task == "music_cont":
+            return prefix_samples / self.sample_rate, float(seconds), True
+        raise ValueError(f"unknown task {task!r}")
+
+    def _known_audio(self, task: str, init_audio: Optional[torch.Tensor], init_audio_sr: Optional[int], batch_size: int,
+                     total_samples: int) -> Tuple[torch.Tensor, bool]:
+        """([B, channels, n] waveform in the model's sample rate / channel count, whether it is only a placeholder).
+        Without ``init_audio`` the known audio is silence and the sampler starts from noise; audio without a batch axis is
+        repeated over the batch; for music_cont the prefix is extended to the full length (the extension is masked out, its
+        content never reaches the network)."""
+        channels = self.audio_encoder.channels
+        if init_audio is None:
+            return torch.zeros((batch_size, channels, total_samples)), True
+        if init_audio.dim() == 2:
+            init_audio = init_audio.unsqueeze(0).expand(batch_size, -1, -1)
+        wav = self.convert_audio(init_audio, init_audio_sr, self.sample_rate, channels)
+        if task == "music_cont":
+            missing = total_samples - wav.shape[2]
+            if missing < 0:
+                raise ValueError("music_cont: init_audio is longer than the requested duration")
+            # the reference appends noise * mask here (generation.py:105-107); the mask is 0 over the whole extension
+            wav = torch.cat([wav, wav.new_zeros((wav.shape[0], wav.shape[1], missing))], dim=2)
+        return wav, False
+
     def generate(self, prompt, seed: int = -1, steps: int = 100, batch_size: int = 1, seconds: int = 30, use_gdm: bool = False,
                  task: str = "text_guided", init_audio: Optional[torch.Tensor] = None, init_audio_sr: Optional[int] = None,
                  inpainting_scope=None) -> torch.Tensor:
-        seed = seed if seed != -1 else int(np.random.randint(0, 2 ** 32 - 1))
-        torch.manual_seed(seed)
+        torch.manual_seed(seed if seed != -1 else int(np.random.randint(0, 2 ** 32 - 1)))
         self.batch_size = batch_size
         diffusion, model = self.get_model_and_diffusion(steps, use_gdm)
-        channels = self.audio_encoder.channels
-        sample_length = seconds * self.sample_rate
-        flag = False
-        if init_audio is not None and init_audio.dim() != 3:
-            init_audio = init_audio.repeat(batch_size, 1, 1)
-        if init_audio is None:
-            flag = True
-            init_audio = torch.zeros((batch_size, channels, sample_length))
-            init_audio_sr = self.sample_rate
-        init_audio = self.convert_audio(init_audio, init_audio_sr, self.sample_rate, channels)
-        if task == "text_guided":
-            mask = self.get_mask(sample_length, 0, seconds, batch_size)
-            causal = False
-        elif task == "music_inpaint":
-            mask = self.get_mask(sample_length, inpainting_scope[0], inpainting_scope[1], batch_size)
-            causal = False
-        elif task == "music_cont":
-            cont_length = sample_length - init_audio.size(2)
-            cont_start = init_audio.size(2)
-            mask = self.get_mask(sample_length, cont_start / self.sample_rate, seconds, batch_size)
-            cont_audio = torch.randn(batch_size, channels, cont_length, device=init_audio.device)
-            cont_audio = cont_audio * mask[:, :, cont_start:].to(cont_audio.device)
-            init_audio = torch.cat([init_audio, cont_audio], dim=2)
-            causal = True
-        else:
-            raise ValueError(f"unknown task {task!r}")
-        with torch.no_grad():
-            init_emb = self.get_emb(init_audio.to(self.device)).to(self.device)
-            emb_shape = init_emb.shape
-            mask = torch.nn.functional.interpolate(mask.to(self.device), size=(emb_shape[2]))
-            masked_emb = init_emb * mask
-            if flag:
-                init_emb = None
-            batch_metadata = [{"prompt": prompt} for _ in range(batch_size)]
-            conditioning = self.conditioner(batch_metadata, self.device)
-            conditioning["masked_input"] = masked_emb
-            conditioning["mask"] = mask
-            conditioning = self.get_conditioning(conditioning)
-            sample_embs = diffusion.sample(model, tuple(emb_shape), conditioning, causal=causal, init_data=init_emb)
-            samples = self.audio_encoder.decoder(sample_embs.to("cpu"))
-        return samples
+        total = int(seconds * self.sample_rate)
+        prefix = 0 if init_audio is None else int(init_audio.shape[-1])
+        start_s, end_s, causal = self._task_window(task, seconds, inpainting_scope, prefix)
+        wav, placeholder = self._known_audio(task, init_audio, init_audio_sr, batch_size, total)
+        keep = self.get_mask(total, start_s, end_s, batch_size)                 # 1 = keep the known audio, 0 = generate
+        return self._sample(diffusion, model, prompt, wav, keep, causal, seed_with_audio=not placeholder)
+
+    @torch.no_grad()
+    def _sample(self, diffusion, model, prompt, wav: torch.Tensor, keep: torch.Tensor, causal: bool, seed_with_audio: bool) -> torch.Tensor:
+        B = wav.shape[0]
+        known = self.get_emb(wav.to(self.device)).to(self.device)               # [B, 128, T']
+        keep = torch.nn.functional.interpolate(keep.to(self.device), size=known.shape[2])
+        cond = self.conditioner([{"prompt": prompt}] * B, self.device)
+        cond["masked_input"] = known * keep
+        cond["mask"] = keep
+        cond = self.get_conditioning(cond)
+        z = diffusion.sample(model, tuple(known.shape), cond, causal=causal, init_data=known if seed_with_audio else None)
+        # the reference hands the latents to its CPU decoder (generation.py:129-130); a decoder that lives on a device says so
+        # (EncodecHIP.decoder_device) and gets them where they are
+        return self.audio_encoder.decoder(z.to(getattr(self.audio_encoder, "decoder_device", "cpu")))
 
     # generation.py:134-150
     def get_mask(self, sample_size: int, start: float, end: float, batch_size: int) -> torch.Tensor:
         return get_mask(sample_size, start, end, batch_size, self.sample_rate)
 
     def get_emb(self, audio: torch.Tensor) -> torch.Tensor:
-        encoded_frames = self.audio_encoder.encode(audio)
-        codes = torch.cat([encoded[0] for encoded in encoded_frames], dim=-1)
-        codes = codes.transpose(0, 1)
-        return self.audio_encoder.quantizer.decode(codes)
+        """waveform -> continuous latents [B, 128, T']: the codes of every encoded segment side by side in time, summed
+        codebook vectors (generation.py:145-150)"""
+        per_segment = [codes for codes, _scale in self.audio_encoder.encode(audio)]          # each [B, n_q, T_seg]
+        return self.audio_encoder.quantizer.decode(torch.cat(per_segment, dim=-1).permute(1, 0, 2))
 
     # generation.py:152-192
     def get_conditioning(self, cond):

@@ -61,11 +61,20 @@ class UNetCFG1d(nn.Module):
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     # ------------------------------------------------------------------ plumbing
-    def _invalidate(self):
+    def _invalidate_engine(self):
+        """the parameters changed in place (an optimiser step): the inference engine's packed weights, its plans and their
+        captured graphs are stale; the next ``engine()`` call packs again"""
         self._engine = None
         self._ctx_key = None
+
+    def _invalidate(self):
+        self._invalidate_engine()
         if self._train_graph is not None:
             self._train_graph.invalidate()
+
+    def attach_optimizer(self, opt) -> None:
+        """for optimisers driven outside ``TrainGraph`` / the trainer: every ``FusedAdamW.step`` invalidates the packed weights"""
+        opt.post_step_hooks.append(self._invalidate)
 
     def train_graph(self, compute_dtype: Optional[str] = None):
         """The differentiable forward of this module (jen1_amd/train.py): a callable with ``forward``'s signature

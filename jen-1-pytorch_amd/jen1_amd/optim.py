@@ -93,13 +93,60 @@ class FusedAdamW:
             h()
 
     def state_dict(self) -> dict:
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "betas": self.betas,
-                "eps": self.eps, "weight_decay": self.weight_decay}
+        """``torch.optim.AdamW.state_dict()``'s schema (what script_util.py:79-90 saves with the reference's optimiser): per-parameter
+        ``state[i] = {"step", "exp_avg", "exp_avg_sq"}`` cut out of the flat buffers, ONE entry of ``param_groups`` with the
+        hyper-parameters and ``params = [0 .. n-1]`` in ``model.parameters()`` order.  A file written here loads into
+        ``torch.optim.AdamW`` over the same parameters and the other way round."""
+        proto = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=self.lr, betas=tuple(self.betas), eps=self.eps,
+                                  weight_decay=self.weight_decay).state_dict()["param_groups"][0]
+        group = dict(proto)
+        group["params"] = list(range(len(self.params)))
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd: dict) -> None:
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """accepts the torch AdamW schema (see ``state_dict``; checkpoints of the reference) and the flat format this class
+        wrote before (``{"step", "exp_avg", "exp_avg_sq", ...}`` over the padded flat layout)"""
+        if "param_groups" not in sd:                               # flat format of earlier checkpoints
+            if sd["exp_avg"].numel() != self.numel or sd["exp_avg_sq"].numel() != self.numel:
+                raise ValueError(f"flat optimiser state of {sd['exp_avg'].numel()} elements does not fit this model ({self.numel})")
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        groups = sd["param_groups"]
+        if len(groups) != 1:
+            raise ValueError(f"{len(groups)} parameter groups in the checkpoint; the trainer uses one (train.py:56-60)")
+        ids = list(groups[0]["params"])
+        if len(ids) != len(self.params):
+            raise ValueError(f"the checkpoint's optimiser covers {len(ids)} parameters, this model has {len(self.params)}")
+        g = groups[0]
+        self.lr = float(g.get("lr", self.lr))
+        self.betas = tuple(g.get("betas", self.betas))
+        self.eps = float(g.get("eps", self.eps))
+        self.weight_decay = float(g.get("weight_decay", self.weight_decay))
+        state = sd.get("state", {})
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for pos, (p, o) in enumerate(zip(self.params, self.offsets)):
+            st = state.get(ids[pos], state.get(str(ids[pos])))
+            if st is None:
+                continue
+            for name, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                v = st[name]
+                if tuple(v.shape) != tuple(p.shape):
+                    raise ValueError(f"optimiser state {name} of parameter {pos} has shape {tuple(v.shape)}, the parameter {tuple(p.shape)}")
+                flat[o:o + p.numel()].copy_(v.reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"parameters at different optimiser steps {sorted(steps)}: one fused step counter cannot represent that")
+        self.step_count = steps.pop() if steps else 0
 
 
 class GradExchange:

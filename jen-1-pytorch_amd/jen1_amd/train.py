@@ -565,6 +565,7 @@ class TrainGraph:
         assert not missing, f"module lacks parameters: {missing[:4]}"
         self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
         self._side: Optional[torch.cuda.Stream] = None
+        self._module = weakref.ref(module)
         self.exchange = None        # optim.GradExchange: told when the gradients of a top-level block are complete
 
     def _mark(self, h: torch.Tensor, region: str) -> torch.Tensor:
@@ -580,8 +581,13 @@ class TrainGraph:
         self.rt.invalidate()
 
     def attach_optimizer(self, opt) -> None:
-        """re-pack the compute weights after every ``FusedAdamW.step``"""
+        """after every ``FusedAdamW.step``: re-pack the compute weights of the training path AND drop the inference engine's
+        packed copy (``model(x, ...)`` / ``diffusion.sample`` between optimiser steps -- the reference's periodic evaluation
+        under no_grad -- must see the new weights)"""
         opt.post_step_hooks.append(self.invalidate)
+        m = self._module()
+        if m is not None and hasattr(m, "_invalidate_engine"):
+            opt.post_step_hooks.append(m._invalidate_engine)
 
     # ------------------------------------------------------------------ leaves
     def _to_rows(self, x_bct: torch.Tensor) -> torch.Tensor:

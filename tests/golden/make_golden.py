@@ -515,8 +515,174 @@ def gen_encodec():
     save("encodec", **out)
 
 
+def gen_ddpm(model=None):
+    """ancestral sampling (gdm.py:144-179) of the reference: GaussianDiffusion(steps=20).p_sample_loop called directly (sample()
+    passes causal= to it and raises TypeError, gdm.py:229-230); start noise (randn) and the per-step noise (rand_like: UNIFORM, as
+    written) are injected"""
+    cfg = tiny_model_config()
+    if model is None:
+        model, _ = _build(cfg)
+    B, T_, S = 2, 300, 20
+    _, cond = _inputs(B, T_)
+    cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+    betas = torch.linspace(1e-3, 0.35, S, dtype=torch.float32)       # (the 'linear' schedule reaches beta = 1 at 20 steps: 1 / alphas_cumprod = inf)
+    shape = (B, 128, T_)
+    init = synth.noise_list(1, shape, seed=17)[0]
+    noises = synth.noise_list(S, shape, seed=19, uniform=True)
+    out = {"betas": betas.numpy()}
+
+    def run(scale, batch_cfg, scale_cfg, all_steps=False):
+        gd = GaussianDiffusion(steps=S, betas=betas, objective="noise", loss_type="l2", device="cpu", cfg_dropout_proba=0.0,
+                               embedding_scale=scale, batch_cfg=batch_cfg, scale_cfg=scale_cfg)
+        assert not gd.is_ddim_sampling
+        it = iter([T(n) for n in noises])
+        r_randn, r_rand_like = torch.randn, torch.rand_like
+        torch.randn = lambda *a, **k: T(init).clone()
+        torch.rand_like = lambda *a, **k: next(it).clone()
+        try:
+            try:
+                gd.sample(model, shape, cond_t)
+                raise AssertionError("the reference's sample() was expected to fail for non-DDIM sampling")
+            except TypeError:
+                pass
+            y = gd.p_sample_loop(model, shape, cond_t, return_all_timesteps=all_steps)
+        finally:
+            torch.randn, torch.rand_like = r_randn, r_rand_like
+        return y.numpy()
+
+    out["ddpm20.cfg"] = run(0.8, True, True)
+    out["ddpm20.nocfg"] = run(1.0, False, False)[:, :, ::3]
+    traj = run(0.8, True, True, all_steps=True)
+    assert traj.shape == (B, S + 1, 128, T_)
+    out["ddpm20.cfg.traj"] = traj[:, :, ::8, ::15]
+    save("tiny_ddpm", **out)
+
+
+def gen_host():
+    """The host functions either side of the denoiser, from the reference's own trainer.py / generation.py (imported with stand-ins
+    for the absent ``encodec`` package; called unbound on a namespace that carries the attributes they read):
+      trainer.py:215-247 random_mask (the ``random`` module seeded per case), :249-278 get_conditioning,
+      generation.py:134-143 get_mask, :152-192 get_conditioning,
+    and the checkpoint format (script_util.py:79-124): the reference's save_checkpoint writes a tiny-config file with its
+    model + torch AdamW, the build's load_checkpoint reads it; the build's save_checkpoint writes one, the reference's
+    load_checkpoint reads it.  Stored: the key list, per-tensor checksums and the outcomes -- no weights."""
+    import hashlib
+    import logging
+    import random
+    import tempfile
+    enc = types.ModuleType("encodec")
+    enc.EncodecModel = type("EncodecModel", (), {})
+    encu = types.ModuleType("encodec.utils")
+    encu.convert_audio = lambda wav, sr, target_sr, target_channels: wav
+    sys.modules.setdefault("encodec", enc)
+    sys.modules.setdefault("encodec.utils", encu)
+    import trainer as rtr
+    import generation as rgen
+    from utils import script_util as rsu
+    out = {}
+    # ---- random_mask ---------------------------------------------------------------------------------------------
+    cases = []
+    for L_ in (1500, 375, 300):
+        seq = T(synth.latents(3, L_, key="clip"))
+        for task in ("text_guided", "music_inpaint", "music_cont"):
+            for seed in (0, 1, 2, 3, 4, 5, 6):
+                random.seed(seed)
+                try:
+                    masked, mask, causal = rtr.UnifiedMultiTaskTrainer.random_mask(None, seq, L_, task)
+                except Exception as e:      # non-integral float bounds: random.randint refuses them on this Python
+                    cases.append([L_, task, seed, type(e).__name__])
+                    continue
+                assert torch.equal(masked, seq * mask) and mask.shape == (3, 1, L_) and bool((mask[0] == mask[2]).all())
+                k = f"mask.{L_}.{task}.{seed}"
+                out[k] = mask[0, 0].numpy().astype(np.uint8)
+                out[k + ".causal"] = np.bool_(causal)
+                cases.append([L_, task, seed, "ok"])
+    out["mask.cases"] = np.array(json.dumps(cases))
+    # ---- get_conditioning (trainer form and generation form) ---------------------------------------------------------
+    B, T_ = 3, 40
+    g = np.random.Generator(np.random.Philox(key=[5, 0x6A656E31]))
+    emb = g.standard_normal((B, 16, 24)).astype(np.float32)
+    emb2 = g.standard_normal((B, 4, 24)).astype(np.float32)
+    msk = (g.random((B, 16)) > 0.3)
+    msk2 = (g.random((B, 4)) > 0.3)
+    glob = g.standard_normal((B, 1, 12)).astype(np.float32)
+    masked_in = g.standard_normal((B, 8, T_)).astype(np.float32)
+    keep = (g.random((B, 1, T_)) > 0.5).astype(np.float32)
+    for k, v in (("emb", emb), ("emb2", emb2), ("msk", msk), ("msk2", msk2), ("glob", glob), ("masked_in", masked_in), ("keep", keep)):
+        out["cond.in." + k] = v
+    cond = {"prompt": (T(emb), T(msk)), "style": (T(emb2), T(msk2)), "g": (T(glob), None), "masked_input": T(masked_in), "mask": T(keep)}
+    ns = types.SimpleNamespace(cross_attn_cond_ids=["prompt", "style"], global_cond_ids=["g"], input_concat_ids=["masked_input", "mask"])
+    r = rtr.UnifiedMultiTaskTrainer.get_conditioning(ns, cond)
+    for k, v in r.items():
+        out["cond.trainer." + k] = v.numpy()
+    ns.batch_size = B
+    r = rgen.Jen1.get_conditioning(ns, cond)
+    for k, v in r.items():
+        out["cond.generation." + k] = v.numpy()
+    # ---- get_mask ----------------------------------------------------------------------------------------------------
+    ns = types.SimpleNamespace(sample_rate=48000)
+    gm = []
+    for n, a, b, bs in ((96000, 0.0, 2.0, 2), (96000, 0.5, 1.5, 1), (48000, 0.33333, 0.77777, 3), (1000, 0.0101, 0.0199, 1)):
+        m = rgen.Jen1.get_mask(ns, n, a, b, bs)
+        assert m.shape == (bs, 1, n)
+        z = np.flatnonzero(m[0, 0].numpy() == 0)
+        gm.append([n, a, b, bs, int(z[0]) if len(z) else -1, int(z[-1]) if len(z) else -1, int(len(z))])
+    out["get_mask.cases"] = np.array(json.dumps(gm))
+    # ---- checkpoint format, both directions ----------------------------------------------------------------------------
+    from jen1_amd import checkpoint as mck
+    from jen1_amd.model import UNetCFG1d as MyUNet
+    from jen1_amd.optim import FusedAdamW
+    cfg = tiny_model_config()
+    rmodel, spec = _build(cfg)
+    rmodel.train()
+    params = list(rmodel.parameters())
+    ropt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1)
+    with torch.enable_grad():
+        for it in range(2):
+            ropt.zero_grad()
+            for i, p_ in enumerate(params):
+                p_.grad = T(fill_normal(f"ckpt.grad.{it}.{i}", tuple(p_.shape), 3)) * 1e-2
+            ropt.step()
+    digest = lambda t: hashlib.sha256(np.ascontiguousarray(t.detach().numpy()).tobytes()).hexdigest()[:16]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "G_2.pth")
+        rsu.save_checkpoint(rmodel, ropt, 3e-5, 2, path, logging.getLogger("golden"))
+        # the reference's file into the build
+        mine = MyUNet(**cfg, compute_dtype="f32", device="cpu", init_seed=None)
+        mopt = FusedAdamW(mine.parameters())
+        _, _, lr, epoch = mck.load_checkpoint(path, mine, optimizer=mopt)
+        rsd = rmodel.state_dict()
+        assert lr == 3e-5 and epoch == 2 and mopt.step_count == 2
+        assert all(torch.equal(v, rsd[k]) for k, v in mine.state_dict().items()) and list(mine.state_dict()) == list(rsd)
+        rst = ropt.state_dict()["state"]
+        for i, (p_, o) in enumerate(zip(mopt.params, mopt.offsets)):
+            assert torch.equal(mopt.exp_avg[o:o + p_.numel()].view_as(p_), rst[i]["exp_avg"])
+            assert torch.equal(mopt.exp_avg_sq[o:o + p_.numel()].view_as(p_), rst[i]["exp_avg_sq"])
+        out["ckpt.keys"] = np.array(json.dumps(list(rsd)))
+        out["ckpt.file_keys"] = np.array(json.dumps(sorted(torch.load(path, map_location="cpu", weights_only=False))))
+        out["ckpt.opt_group_keys"] = np.array(json.dumps(sorted(k for k in ropt.state_dict()["param_groups"][0])))
+        out["ckpt.param_digest"] = np.array(json.dumps({k: digest(v) for k, v in rsd.items()}))
+        out["ckpt.exp_avg_digest"] = np.array(json.dumps([digest(rst[i]["exp_avg"]) for i in range(len(params))]))
+        out["ckpt.exp_avg_sq_digest"] = np.array(json.dumps([digest(rst[i]["exp_avg_sq"]) for i in range(len(params))]))
+        # the build's file into the reference
+        path2 = os.path.join(d, "G_3.pth")
+        mck.save_checkpoint(mine, mopt, 1e-5, 3, path2)
+        r2, _ = _build(cfg)
+        for p_ in r2.parameters():
+            p_.data.zero_()
+        ropt2 = torch.optim.AdamW(r2.parameters(), lr=1.0)
+        _, _, lr2, epoch2 = rsu.load_checkpoint(path2, r2, logger=None, optimizer=ropt2)
+        assert lr2 == 1e-5 and epoch2 == 3
+        assert all(torch.equal(v, rsd[k]) for k, v in r2.state_dict().items())
+        st2 = ropt2.state_dict()
+        assert all(torch.equal(st2["state"][i]["exp_avg"], rst[i]["exp_avg"]) and float(st2["state"][i]["step"]) == 2.0 for i in range(len(params)))
+        assert st2["param_groups"][0]["lr"] == 3e-5 and st2["param_groups"][0]["betas"] == (0.9, 0.95)
+        out["ckpt.cross_load"] = np.array(json.dumps({"reference_file_into_build": True, "build_file_into_reference": True}))
+    save("host_pins", **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fullbench", "fulltrain", "encodec"}
+    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fullbench", "fulltrain", "encodec", "ddpm", "host"}
     model = None
     if "schedule" in which:
         print("schedule"); gen_schedule()
@@ -536,3 +702,7 @@ if __name__ == "__main__":
         print("fulltrain"); gen_full_train()
     if "encodec" in which:
         print("encodec"); gen_encodec()
+    if "ddpm" in which:
+        print("ddpm"); gen_ddpm(model)
+    if "host" in which:
+        print("host"); gen_host()

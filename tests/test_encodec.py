@@ -202,3 +202,10 @@ def test_jen1_generate_with_hip_encodec_halves():
              model_config=tiny_model_config(), diffusion_config=GDMConfig(), compute_dtype="bf16")
     wav = j.generate("strings", seed=2, steps=3, batch_size=2, seconds=1, use_gdm=True)
     assert tuple(wav.shape) == (2, 2, 48000) and torch.isfinite(wav).all() and float(wav.abs().max()) > 0
+    # the sampled latents go to the HIP decoder where they are: no host round trip (EncodecHIP.decoder_device)
+    assert enc.decoder_device.type == "cuda" and wav.device.type == "cuda"
+    seen = []
+    inner = enc.decoder
+    enc.decoder = lambda z: (seen.append(z.device.type), inner(z))[1]
+    j.generate("strings", seed=2, steps=2, batch_size=2, seconds=1, use_gdm=True)
+    assert seen == ["cuda"]

@@ -164,6 +164,38 @@ def test_tiny_ddim_sampler_vs_golden(tiny_models, use_graph):
     assert rel_err(run(0.0, 0.8, True, True, False, objective="v")[:, :, ::3], g["ddim10.v"]) < F32_TOL
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_tiny_ddpm_sampler_vs_golden(tiny_models, use_graph):
+    """ancestral sampling (gdm.py:144-179) on the fused stepper against the reference's p_sample_loop with
+    GaussianDiffusion(steps=20): final latents with and without CFG, the whole trajectory, and the literal (unfused) loop"""
+    from jen1_amd.diffusion import GaussianDiffusion
+    g = golden("tiny_ddpm")
+    B, T, S = 2, 300, 20
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+    shape = (B, 128, T)
+    init = dev(synth.noise_list(1, shape, seed=17)[0])
+    noises = [dev(n) for n in synth.noise_list(S, shape, seed=19, uniform=True)]
+    betas = torch.from_numpy(g["betas"])
+    m = tiny_models["f32"]
+
+    def run(scale, bcfg, rcfg, **kw):
+        gd = GaussianDiffusion(steps=S, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                               embedding_scale=scale, batch_cfg=bcfg, scale_cfg=rcfg)
+        assert not gd.is_ddim_sampling
+        y = gd.sample(m, shape, cond, init_noise=init, step_noises=noises, use_graph=use_graph, **kw)
+        torch.cuda.synchronize()
+        return y.cpu().numpy()
+
+    # 20 chained steps with clamping: 1e-3 (north_star's gate)
+    assert rel_err(run(0.8, True, True), g["ddpm20.cfg"]) < 1e-3
+    assert rel_err(run(1.0, False, False)[:, :, ::3], g["ddpm20.nocfg"]) < 1e-3
+    traj = run(0.8, True, True, return_all_timesteps=True)
+    assert traj.shape == (B, S + 1, 128, T)
+    assert rel_err(traj[:, :, ::8, ::15], g["ddpm20.cfg.traj"]) < 1e-3
+    if not use_graph:
+        assert rel_err(run(0.8, True, True, fused=False), g["ddpm20.cfg"]) < 1e-3
+
+
 def test_tiny_training_loss_value_vs_golden(tiny_models):
     """forward value of ``training_loosses`` (gdm.py:245-272) for the three tasks x objectives."""
     from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule

@@ -653,3 +653,37 @@ def test_data_parallel_step_two_ranks_gloo():
     assert res[0]["same_as_blocking"] and res[1]["same_as_blocking"]
     assert res[0]["sent_during_backward"] >= 4, res[0]       # down / bottleneck / up blocks + to_out left during the pass
     assert res[0]["err"] < 1e-5, res[0]
+
+
+def test_inference_engine_follows_optimizer_steps():
+    """model(x, ...) between optimiser steps (the reference evaluates under no_grad every eval_interval, trainer.py:152-160)
+    runs on the CURRENT weights: forward, train step, forward differs and equals a model freshly built from the new state_dict"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    cfg = tiny_model_config()
+    model = UNetCFG1d(**cfg, compute_dtype="f32", device="cuda")
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                           embedding_scale=1.0, batch_cfg=False, scale_cfg=False)
+    B, T = 2, 300
+    x = dev(synth.latents(B, T))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+    t = torch.tensor([999, 499], device="cuda")
+    kw = dict(embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], channels_list=[cond["input_concat_cond"]])
+    y0 = model(x, t, **kw).clone()                      # builds the inference engine (packed weights)
+    opt = FusedAdamW(model.parameters(), lr=1e-2)
+    graph = model.train_graph("f32")
+    graph.attach_optimizer(opt)
+    model.train()
+    opt.zero_grad()
+    loss = gd.training_loosses(graph, x, t, cond, causal=False)
+    loss.backward()
+    opt.step()
+    model.eval()
+    y1 = model(x, t, **kw).clone()
+    assert float((y1 - y0).abs().max()) > 1e-4          # the step moved the weights and the engine saw it
+    fresh = UNetCFG1d(**cfg, compute_dtype="f32", device="cuda")
+    fresh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    y2 = fresh(x, t, **kw)
+    assert float((y1 - y2).abs().max()) <= 1e-5 * float(y2.abs().max())

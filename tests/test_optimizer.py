@@ -249,3 +249,49 @@ def test_grad_exchange_overlapped_equals_blocking_gloo_world2():
     assert names == ["to_mapping", "to_time", "to_in", "downsamples.0", "downsamples.1", "bottleneck", "upsamples.0", "upsamples.1",
                      "to_out", "to_time_embedding", "fixed_embedding"]
     assert regions[names[0]][0] == 0 and all(regions[a][1] == regions[b][0] for a, b in zip(names[:-1], names[1:]))
+
+
+def test_optimizer_state_is_torch_adamw_schema_both_ways():
+    """FusedAdamW.state_dict() / load_state_dict() speak torch.optim.AdamW's format (script_util.py:79-124 saves and loads the
+    optimiser with it): a state written here loads into torch's AdamW over the same parameters, a state written by torch's AdamW
+    (the reference's optimiser, train.py:56-60) loads here, shapes / counts are validated, the earlier flat format still loads"""
+    shapes = [(5, 3), (7,), (2, 3, 4), (1,)]
+    g = torch.Generator().manual_seed(3)
+    mine = [torch.nn.Parameter(torch.randn(sh, generator=g)) for sh in shapes]
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    ref = torch.optim.AdamW(theirs, lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1)
+    for it in range(3):
+        for p in theirs:
+            p.grad = torch.randn(p.shape, generator=g)
+        ref.step()
+    opt = FusedAdamW(mine, lr=1e-3)
+    opt.load_state_dict(ref.state_dict())                                    # reference -> here
+    assert opt.step_count == 3 and opt.lr == 3e-5 and tuple(opt.betas) == (0.9, 0.95) and opt.weight_decay == 0.1
+    for i, (p, o) in enumerate(zip(opt.params, opt.offsets)):
+        st = ref.state_dict()["state"][i]
+        assert torch.equal(opt.exp_avg[o:o + p.numel()].view_as(p), st["exp_avg"])
+        assert torch.equal(opt.exp_avg_sq[o:o + p.numel()].view_as(p), st["exp_avg_sq"])
+    sd = opt.state_dict()                                                    # here -> reference
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == [0, 1, 2, 3]
+    assert set(sd["param_groups"][0]) == set(ref.state_dict()["param_groups"][0])
+    other = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(sh)) for sh in shapes], lr=1.0)
+    other.load_state_dict(sd)
+    back = other.state_dict()
+    for i in range(4):
+        assert float(back["state"][i]["step"]) == 3.0
+        assert torch.equal(back["state"][i]["exp_avg"], ref.state_dict()["state"][i]["exp_avg"])
+        assert torch.equal(back["state"][i]["exp_avg_sq"], ref.state_dict()["state"][i]["exp_avg_sq"])
+    assert back["param_groups"][0]["lr"] == 3e-5 and back["param_groups"][0]["weight_decay"] == 0.1
+    # a fresh optimiser (no step yet) has an empty state, like torch's
+    assert FusedAdamW([torch.nn.Parameter(torch.zeros(3))]).state_dict()["state"] == {}
+    # refusals: wrong parameter count, wrong shape
+    with pytest.raises(ValueError):
+        FusedAdamW([torch.nn.Parameter(torch.zeros(3))]).load_state_dict(sd)
+    bad = ref.state_dict()
+    bad["state"][1]["exp_avg"] = torch.zeros(8)
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
+    # the flat format of round-1 checkpoints
+    flat = {"step": 7, "exp_avg": torch.arange(opt.numel, dtype=torch.float32), "exp_avg_sq": torch.ones(opt.numel)}
+    opt.load_state_dict(flat)
+    assert opt.step_count == 7 and float(opt.exp_avg[5]) == 5.0

@@ -298,6 +298,22 @@ def test_tiny_ddim_sampler(tiny_net):
     assert rel_err(run(0.0, 0.8, True, True, False, objective="v")[:, :, ::3], g["ddim10.v"]) < 5e-4
 
 
+def test_tiny_ddpm_sampler(tiny_net):
+    """the oracle's p_sample_loop against the reference's (GaussianDiffusion(steps=20), uniform per-step noise as written)"""
+    net, _ = tiny_net
+    g = golden("tiny_ddpm")
+    B, T, S = 2, 300, 20
+    cond = synth.conditioning(B, T)
+    shape = (B, 128, T)
+    init = synth.noise_list(1, shape, seed=17)[0]
+    noises = synth.noise_list(S, shape, seed=19, uniform=True)
+    for key, scale, bcfg, rcfg, sub in (("ddpm20.cfg", 0.8, True, True, 1), ("ddpm20.nocfg", 1.0, False, False, 3)):
+        gd = O.OracleGaussianDiffusion(steps=S, betas=g["betas"].astype(np.float64), objective="noise", cfg_dropout_proba=0.0,
+                                       embedding_scale=scale, batch_cfg=bcfg, scale_cfg=rcfg)
+        y = gd.p_sample_loop(net, shape, cond, init_noise=init, step_noises=noises)
+        assert rel_err(y[:, :, ::sub], g[key]) < 5e-4, key
+
+
 def test_tiny_training_loss(tiny_net):
     net, _ = tiny_net
     g = golden("tiny_train")

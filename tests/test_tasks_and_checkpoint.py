@@ -93,3 +93,37 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
     m4 = UNetCFG1d(**tiny_model_config(), device="cpu", init_seed=4)
     load_model_diffsize(path, m4)
     assert torch.equal(m4.state_dict()[keys[5]], m1.state_dict()[keys[5]])
+
+
+def test_generate_request_planning_host_side():
+    """Jen1's request planning (generation.py:84-110) without a device: the window each task generates, the causal flag, the
+    known waveform (silence / given audio / prefix extended to the full length), batch handling and refusals"""
+    import pytest
+    from jen1_amd.generation import Jen1
+
+    class Enc:
+        channels = 2
+    j = Jen1(None, device="cpu", audio_encoder=Enc(), conditioner=lambda md, dev: {}, model_config=tiny_model_config())
+    sr = j.sample_rate
+    assert j._task_window("text_guided", 3, None, 0) == (0.0, 3.0, False)
+    assert j._task_window("music_inpaint", 3, (0.5, 1.25), 0) == (0.5, 1.25, False)
+    assert j._task_window("music_cont", 3, None, sr) == (1.0, 3.0, True)
+    with pytest.raises(ValueError):
+        j._task_window("music_inpaint", 3, None, 0)
+    with pytest.raises(ValueError):
+        j._task_window("remix", 3, None, 0)
+    wav, placeholder = j._known_audio("text_guided", None, None, 3, 2 * sr)
+    assert placeholder and wav.shape == (3, 2, 2 * sr) and float(wav.abs().max()) == 0
+    clip = torch.randn((2, sr))                                     # no batch axis: repeated over the batch
+    wav, placeholder = j._known_audio("music_inpaint", clip, sr, 3, sr)
+    assert not placeholder and wav.shape == (3, 2, sr) and torch.equal(wav[2], clip)
+    batched = torch.randn((3, 2, sr))                               # batched audio is used as it is
+    wav, _ = j._known_audio("music_inpaint", batched, sr, 3, sr)
+    assert torch.equal(wav, batched)
+    wav, placeholder = j._known_audio("music_cont", clip, sr, 2, 3 * sr)
+    assert not placeholder and wav.shape == (2, 2, 3 * sr) and torch.equal(wav[0, :, :sr], clip) and float(wav[:, :, sr:].abs().max()) == 0
+    with pytest.raises(ValueError):
+        j._known_audio("music_cont", torch.randn((2, 4 * sr)), sr, 2, 3 * sr)
+    # the mask of a continuation keeps exactly the prefix
+    keep = j.get_mask(3 * sr, *j._task_window("music_cont", 3, None, sr)[:2], 2)
+    assert keep.shape == (2, 1, 3 * sr) and float(keep[:, :, :sr].min()) == 1 and float(keep[:, :, sr:].max()) == 0
