@@ -793,9 +793,11 @@ static int validate(const jen1_conv_args& a) {
   JEN1_CHECK(a.dtype == JEN1_F32 || a.dtype == JEN1_BF16, "conv_gemm: bad dtype %d", a.dtype);
   JEN1_CHECK(a.w && a.y, "conv_gemm: null w/y");
   JEN1_CHECK(a.nseg >= 0 && a.nseg <= JEN1_MAX_SEG, "conv_gemm: bad nseg %d", a.nseg);
-  JEN1_CHECK(a.nseg == 0 || a.direct, "conv_gemm: explicit K segments need direct mode");
+  // (for the T* tile configurations ``seg`` lists only raw EXTRA segments behind the taps: checked by jen1_tile_gemm_launch)
+  const bool tile_extras = is_tile_cfg(a.cfg) && a.nseg > 0;
+  JEN1_CHECK(a.nseg == 0 || a.direct || tile_extras, "conv_gemm: explicit K segments need direct mode");
   int kch = 0;       // 32-channel chunks the K split operates on
-  if (a.nseg > 0) {
+  if (a.nseg > 0 && !tile_extras) {
     for (int s = 0; s < a.nseg; ++s) {
       const jen1_conv_seg& g = a.seg[s];
       JEN1_CHECK(g.x && g.kch >= 1 && g.ld >= 32 * g.kch && g.ld % 8 == 0, "conv_gemm: bad K segment %d (kch=%d ld=%d)", s, g.kch, g.ld);

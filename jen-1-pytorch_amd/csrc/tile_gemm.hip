@@ -49,24 +49,44 @@ struct TileEpi {                 // 32 dwords: read while the first loads are in
   uint32_t res_bytes, bias_bytes;
   int32_t M, out_C, ps_f, ps_off, L_y, y_brows, y_row0, ld_y, ld_res, y_f32, out_cpf;
   float inv_out_cpf;
-  int32_t pad[10];
+  int32_t pad[2];
+  // raw extra K segments behind the taps (a 1x1 shortcut over the block's input riding on its second conv, blocks.py:229-231):
+  // channels [c0 + c1, +c2) of the staged tile come from x2, the next c3 from x3, both at row shift 0.  These 8 dwords sit at
+  // kernarg offset 0x120 and are read with the hot block (TileExtra), the rest of this block only before the epilogue.
+  const void* x2;
+  const void* x3;
+  int32_t ld2, c2, ld3, c3;
+};
+struct TileExtra {
+  const void* x2;
+  const void* x3;
+  int32_t ld2, c2, ld3, c3;
 };
 struct TileArgs {
   TileHot hot;
   TileEpi epi;
 };
 static_assert(sizeof(TileHot) == 192 && sizeof(TileEpi) == 128 && offsetof(TileArgs, epi) == 192, "kernarg blocks are read with fixed-size scalar loads");
+static_assert(offsetof(TileArgs, epi) + offsetof(TileEpi, x2) == 0x120 && sizeof(TileExtra) == 32, "the extra-segment block is read at a fixed kernarg offset");
 
-__device__ __forceinline__ TileHot load_tile_hot() {
+// the hot block and the extra-segment block in ONE batch of scalar loads (one wait)
+__device__ __forceinline__ TileHot load_tile_hot(TileExtra& ex) {
   const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
   u32x16 k0, k1, k2;
+  u32x8 k3;
   unsigned t0, t1;
-  asm volatile("s_load_dwordx16 %0, %5, 0x0\n\ts_load_dwordx16 %1, %5, 0x40\n\ts_load_dwordx16 %2, %5, 0x80\n\t"
-               "s_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(t0), "=&s"(t1) : "s"(kp) : "memory");
+  asm volatile("s_load_dwordx16 %0, %6, 0x0\n\ts_load_dwordx16 %1, %6, 0x40\n\ts_load_dwordx16 %2, %6, 0x80\n\t"
+               "s_load_dwordx8 %5, %6, 0x120\n\t"
+               "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(t0), "=&s"(t1), "=&s"(k3) : "s"(kp) : "memory");
   struct Raw { unsigned d[48]; } raw;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { raw.d[i] = k0[i]; raw.d[16 + i] = k1[i]; raw.d[32 + i] = k2[i]; }
+  struct RawX { unsigned d[8]; } rx;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rx.d[i] = k3[i];
+  ex = __builtin_bit_cast(TileExtra, rx);
   return __builtin_bit_cast(TileHot, raw);
 }
 __device__ __forceinline__ TileEpi load_tile_epi() {
@@ -132,7 +152,16 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 constexpr int VB = 4;          // staging vectors (8 channels) per thread per batch
 
-template <typename T, int MF, int NF, int PF>
+// Tuning builds only (-DJEN1_TILE_PROFILE): thread 0 of every workgroup records the 100 MHz counter at the stages of the kernel:
+// dbg[workgroup * 8 + stage]  (jen1_tile_debug_buffer sets the pointer)
+#ifdef JEN1_TILE_PROFILE
+__device__ unsigned long long* g_tile_dbg = nullptr;
+#define TK_STAMP(i) do { tk_t[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TK_STAMP(i) do { } while (0)
+#endif
+
+template <typename T, int MF, int NF, int PF, bool XS>      // XS: raw extra K segments behind the taps
 __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused) {
   typedef typename Frag8<T>::type Frag;
   typedef typename VecOf<T>::type Vec;
@@ -145,19 +174,28 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const TileHot h = load_tile_hot();
+#ifdef JEN1_TILE_PROFILE
+  unsigned long long tk_t[8];
+#pragma unroll
+  for (int i_ = 0; i_ < 8; ++i_) tk_t[i_] = 0;
+#endif
+  TK_STAMP(0);
+  TileExtra ex;
+  const TileHot h = load_tile_hot(ex);
+  TK_STAMP(1);
 
   // ---- tile coordinates ---------------------------------------------------------------------------
   const int by = blockIdx.y;
   const int b = (int)(((float)by + 0.5f) * h.inv_tiles_t), tt = by - b * h.tiles_t;
   const int t0 = tt * h.tb;
-  const int ctot = h.c0 + h.c1;
+  const int ctot = h.c0 + h.c1;                                // normalised / main channels
+  const int call = XS ? ctot + ex.c2 + ex.c3 : ctot;           // + the raw extra segments
   const int kch = ctot >> 5;
-  const int vpr = ctot >> 3;
-  const int ldsld = ctot + 8;
+  const int vpr = call >> 3;
+  const int ldsld = call + 8;
   const int rows_in = (h.tb - 1) * h.stride + h.taps;
   const int tin0 = t0 * h.stride - h.pad_left;
-  const int KS = h.taps * kch;                                 // k-steps: (tap, 32-channel chunk)
+  const int KS = h.taps * kch + (XS ? (ex.c2 + ex.c3) >> 5 : 0);   // k-steps: (tap, 32-channel chunk), then the extra chunks
   const int mt0 = (blockIdx.x * 4 + wv) * MF;                   // this wave's first 16-row tile of M
 
   T* tile = reinterpret_cast<T*>(smem);
@@ -200,11 +238,17 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
       const bool ok = v < nvec && tin >= 0 && tin < h.L_in;
       const unsigned grow = (unsigned)(b * h.L_in + (ok ? tin : 0));
       const T* p = (c < h.c0) ? x0p + (size_t)(grow * (unsigned)h.ld0 + (unsigned)c) : x1p + (size_t)(grow * (unsigned)h.ld1 + (unsigned)(c - h.c0));
+      if (XS && c >= ctot) {
+        const int cx = c - ctot;
+        p = (cx < ex.c2) ? reinterpret_cast<const T*>(ex.x2) + (size_t)(grow * (unsigned)ex.ld2 + (unsigned)cx)
+                         : reinterpret_cast<const T*>(ex.x3) + (size_t)(grow * (unsigned)ex.ld3 + (unsigned)(cx - ex.c2));
+      }
       bt.x[u] = *reinterpret_cast<const Vec*>(p);
     }
   };
   Batch cur;
   load_batch(cur, 0);
+  TK_STAMP(2);
 
   // ---- (3) affine tables of the prologue: y = silu?(A[c] x + S[c]) ---------------------------------------
   const bool gn = h.pro_mode == JEN1_PRO_GN || h.pro_mode == JEN1_PRO_GN_SILU;
@@ -261,6 +305,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
   if (e.out_gn_stats) {
     for (int i = tid; i < 2 * (64 * MF / 2 + 2); i += 256) st_lds[i] = 0.f;
   }
+  TK_STAMP(3);
   __syncthreads();
 
   // ---- (4) stage the tile: prologue applied once, zero padding applied after it ------------------------------
@@ -277,7 +322,9 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
       float x[8];
       vec_to_float(cur.x[u], x);
       if (tin >= 0 && tin < h.L_in) {
-        if (gn) {
+        if (XS && c >= ctot) {
+          // raw extra segment: staged as it is
+        } else if (gn) {
           const float4 a0 = *reinterpret_cast<const float4*>(tabA + c), a1 = *reinterpret_cast<const float4*>(tabA + c + 4);
           const float4 s0 = *reinterpret_cast<const float4*>(tabS + c), s1 = *reinterpret_cast<const float4*>(tabS + c + 4);
           x[0] = x[0] * a0.x + s0.x; x[1] = x[1] * a0.y + s0.y; x[2] = x[2] * a0.z + s0.z; x[3] = x[3] * a0.w + s0.w;
@@ -286,7 +333,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
 #pragma unroll
           for (int j = 0; j < 8; ++j) x[j] *= h.src1_scale;
         }
-        if (do_silu) {
+        if (do_silu && (!XS || c < ctot)) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
         }
@@ -299,8 +346,36 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
     if (more) cur = nxt;
   }
   __syncthreads();
+  TK_STAMP(4);
 
   // ---- (5) MFMA loop: weights from the ring, activations from row-shifted views of the LDS tile -------------
+  // the residual of the epilogue is requested first: its round trip hides behind the loop
+  float rres[MF][NF][4];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rres[mf][nf][r] = 0.f;
+  if (e.residual) {
+    const T* res0 = reinterpret_cast<const T*>(e.residual);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int m = (mt0 + mf) * 16 + lg * 4;
+      if (mt0 + mf >= h.MT) continue;
+      int ph = 0;
+      for (int k = 1; k < e.ps_f; ++k) ph += (m >= k * e.out_C) ? 1 : 0;
+      const int co = m - ph * e.out_C;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int n = nf * 16 + li;
+        const int q = t0 + n;
+        const int ty = q * e.ps_f + ph - e.ps_off;
+        const bool ok = n < h.tb && q < h.L_out && ty >= 0 && ty < e.L_y;
+        if (ok) load4(res0 + (size_t)((unsigned)(b * e.y_brows + e.y_row0 + ty) * (unsigned)e.ld_res + (unsigned)co), rres[mf][nf]);
+      }
+    }
+  }
   f32x4 acc[MF][NF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
@@ -313,6 +388,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
     ldsrow[nf] = ((n < h.tb ? n : 0) * h.stride) * ldsld + lg * 8;
   }
   int c_tap = 0, c_kc = 0;
+  bool in_extra = false;
   for (int ks = 0; ks < KS; ks += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -325,16 +401,20 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) mma(acc[mf][nf], ring[u][mf], bfr[nf]);
-        if (++c_kc == kch) { c_kc = 0; ++c_tap; }
+        // (tap, chunk) order; behind the last tap the extra chunks follow at the centre row, columns ctot + 32 j
+        if (++c_kc == kch && !in_extra) {
+          c_kc = 0;
+          if (++c_tap == h.taps && XS) { in_extra = true; c_tap = h.pad_left; c_kc = kch; }
+        }
       }
       issueA(ring[u]);
     }
   }
 
+  TK_STAMP(5);
   // ---- (6) epilogue: bias, residual, sub-pixel row mapping, store, statistics of the next GroupNorm -----------
   T* yT = reinterpret_cast<T*>(e.y);
   float* yF = reinterpret_cast<float*>(e.y);
-  const T* res = reinterpret_cast<const T*>(e.residual);
   const int m_wg0 = blockIdx.x * 64 * MF;                       // first GEMM row of the workgroup
   int phw = 0;
   for (int k = 1; k < e.ps_f; ++k) phw += (m_wg0 >= k * e.out_C) ? 1 : 0;
@@ -358,12 +438,8 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
       if (ok) {
         const unsigned yrow = (unsigned)(b * e.y_brows + e.y_row0 + ty);
         float v[4] = {acc[mf][nf][0] + bb.x, acc[mf][nf][1] + bb.y, acc[mf][nf][2] + bb.z, acc[mf][nf][3] + bb.w};
-        if (res) {
-          float rr[4];
-          load4(res + (size_t)(yrow * (unsigned)e.ld_res + (unsigned)co), rr);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += rr[r];
-        }
+        for (int r = 0; r < 4; ++r) v[r] += rres[mf][nf][r];
         const size_t off = (size_t)(yrow * (unsigned)e.ld_y + (unsigned)co);
         if (e.y_f32) store4(yF + off, v);
         else store4(yT + off, v);
@@ -384,6 +460,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
       }
     }
   }
+  TK_STAMP(6);
   if (e.out_gn_stats) {
     __syncthreads();
     const int nrel = 64 * MF / 2 + 2;
@@ -393,15 +470,24 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const TileArgs a_unused)
       if (v != 0.f && fg < JEN1_FINE_GROUPS) unsafeAtomicAdd(e.out_gn_stats + (size_t)b * 64 + fg * 2 + (i & 1), v);
     }
   }
+#ifdef JEN1_TILE_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TK_STAMP(7);
+  if (tid == 0 && g_tile_dbg) {
+    unsigned long long* d = g_tile_dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+    for (int i_ = 0; i_ < 8; ++i_) d[i_] = tk_t[i_];
+  }
+#endif
 }
 
-template <typename T, int MF, int NF, int PF>
-int launch_tile(const TileArgs& ta, int rows_in, hipStream_t s) {
+template <typename T, int MF, int NF, int PF, bool XS>
+int launch_tile_x(const TileArgs& ta, int rows_in, hipStream_t s) {
   const int ctot = ta.hot.c0 + ta.hot.c1;
-  const size_t tile_bytes = ((size_t)rows_in * (ctot + 8) * sizeof(T) + 15) & ~(size_t)15;
+  const size_t tile_bytes = ((size_t)rows_in * (ctot + ta.epi.c2 + ta.epi.c3 + 8) * sizeof(T) + 15) & ~(size_t)15;
   const size_t lds = tile_bytes + (size_t)(2 * ctot + 2 * (64 * MF / 2 + 2)) * sizeof(float);
   JEN1_CHECK(lds <= 160 * 1024, "conv_gemm: tile kernel LDS request %zu B exceeds 160 KiB", lds);
-  auto kern = tile_gemm_kernel<T, MF, NF, PF>;
+  auto kern = tile_gemm_kernel<T, MF, NF, PF, XS>;
   static bool attr_set = false;
   if (!attr_set) {
     JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -413,7 +499,18 @@ int launch_tile(const TileArgs& ta, int rows_in, hipStream_t s) {
   return 0;
 }
 
+template <typename T, int MF, int NF, int PF>
+int launch_tile(const TileArgs& ta, int rows_in, hipStream_t s) {
+  return (ta.epi.c2 + ta.epi.c3) ? launch_tile_x<T, MF, NF, PF, true>(ta, rows_in, s) : launch_tile_x<T, MF, NF, PF, false>(ta, rows_in, s);
+}
+
 }  // namespace
+
+#ifdef JEN1_TILE_PROFILE
+extern "C" int jen1_tile_debug_buffer(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_dbg), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 #ifndef JEN1_TILE_PF
 #define JEN1_TILE_PF 4
@@ -427,13 +524,21 @@ int jen1_tile_gemm_launch(const jen1_conv_args& a, void* stream) {
   TileEpi& e = ta.epi;
   const int es = a.dtype == JEN1_F32 ? 4 : 2;
   const bool gn = a.pro_mode == JEN1_PRO_GN || a.pro_mode == JEN1_PRO_GN_SILU;
-  JEN1_CHECK(a.nb == 1 && a.splitk == 1 && !a.ln_fold && !a.row_scale && !a.out_rowstats && a.act == JEN1_ACT_NONE && a.nseg == 0 && a.m_split == 0 &&
+  JEN1_CHECK(a.nb == 1 && a.splitk == 1 && !a.ln_fold && !a.row_scale && !a.out_rowstats && a.act == JEN1_ACT_NONE && a.nseg >= 0 && a.nseg <= 2 && a.m_split == 0 &&
              (gn || a.pro_mode == JEN1_PRO_NONE || a.pro_mode == JEN1_PRO_SILU),
              "conv_gemm: the T* tile configurations take GroupNorm / SiLU / no prologue, one batch element per tile, no split-K, no LayerNorm");
   JEN1_CHECK(!a.out_gn_stats || a.out_cpf >= 2, "conv_gemm: bad out_cpf");
   const int ctot = a.c0 + a.c1;
   h.x0 = a.x0; h.x1 = a.x1; h.w = a.w;
-  const int64_t wb = (int64_t)a.taps * (ctot / 32) * (a.M / 16) * 512 * es;
+  // for the T* tiles ``seg`` lists only the raw EXTRA K segments behind the taps (row shift 0)
+  int kx = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    JEN1_CHECK(a.seg[i].x && a.seg[i].shift == 0 && a.seg[i].kch >= 1 && a.seg[i].ld >= 32 * a.seg[i].kch, "conv_gemm: bad extra K segment %d for a T* tile", i);
+    kx += a.seg[i].kch;
+  }
+  if (a.nseg >= 1) { e.x2 = a.seg[0].x; e.ld2 = a.seg[0].ld; e.c2 = 32 * a.seg[0].kch; }
+  if (a.nseg >= 2) { e.x3 = a.seg[1].x; e.ld3 = a.seg[1].ld; e.c3 = 32 * a.seg[1].kch; }
+  const int64_t wb = ((int64_t)a.taps * (ctot / 32) + kx) * (a.M / 16) * 512 * es;
   JEN1_CHECK(wb < (int64_t)OOB, "conv_gemm: packed weight too large for 31-bit offsets");
   h.w_bytes = (uint32_t)wb;
   h.B = a.B; h.L_in = a.L_in; h.L_out = a.L_out; h.c0 = a.c0; h.c1 = a.c1; h.ld0 = a.ld0; h.ld1 = a.ld1;
@@ -468,6 +573,9 @@ int jen1_tile_gemm_launch(const jen1_conv_args& a, void* stream) {
   e.inv_out_cpf = a.out_gn_stats ? 1.0f / (float)a.out_cpf : 1.0f;
   const int rows_in = (a.tb - 1) * a.stride + a.taps;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // ring depth 4: measured on the bench shapes, a ring that covers every k-step (12) costs ~0.7 us more issue time per workgroup and the
+  // MFMA loop does not get shorter -- every workgroup re-reads the whole packed weight from L2 (98 KB at C = 128, k = 3), which is a
+  // throughput cost, not a latency one (tools/tile_profile.py)
   constexpr int PF = JEN1_TILE_PF;
   if (a.dtype == JEN1_F32) {
     switch (a.cfg) {

@@ -463,13 +463,25 @@ class OpBuilder:
             self.deep_act_bytes += a.B * a.L_in * (c_real_ + c_extra_) * es_ + a.B * a.L_y * out_C * es_
             self.deep_flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
             return out
+        # the tile kernel takes up to two raw extra K segments at row shift 0 (a 1x1 shortcut riding on the block's second conv)
+        extras_tile = not extra_segs or (len(extra_segs) <= 2 and all(sh == 0 and e.cp == e.C and e.cp % 32 == 0 for e, sh in extra_segs))
         tile_ok = (pro in (L.PRO_NONE, L.PRO_GN, L.PRO_GN_SILU, L.PRO_SILU) and act == L.ACT_NONE and row_scale is None and out.rs is None
-                   and not extra_segs and not m_split and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] > 1 or src1 is None)
+                   and extras_tile and not m_split and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] > 1 or src1 is None)
                    and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] == 1 or
                         (a.gn_cpg % (a.c0 // FG) == 0 and (a.c1 == 0 or a.gn_cpg % (a.c1 // FG) == 0))))
         self._choose_tiles(a, force, k_extra=(sum(e.cp for e, _ in extra_segs) // 32 if extra_segs else 0), tile_ok=tile_ok)
         lib = eng.lib
         streaming = a.cfg in (L.CFG_S16x64, L.CFG_S16x32, L.CFG_S16x16)
+        tiled = a.cfg in self.TILE_CFGS
+        if extra_segs and tiled and not eng.fuse_shortcut_tiles:
+            return None
+        if extra_segs and not streaming and not tiled:
+            return None           # (a wide W* tile: the caller falls back to separate launches)
+        if extra_segs and tiled:
+            for i, (e, sh) in enumerate(extra_segs):
+                assert e.B == a.B and e.L == a.L_in and e.t.dtype == eng.tdtype
+                a.seg[i].x, a.seg[i].ld, a.seg[i].shift, a.seg[i].kch = e.t.data_ptr(), e.ld, 0, e.cp // 32
+            a.nseg = len(extra_segs)
         want_direct = streaming and (force is None or force.get("direct", True))
         if want_direct and pro == L.PRO_LN and ln_u is not None and a.ln_gamma is None and taps == 1 and stride == 1 \
                 and src1 is None and (force is None or force.get("ln_fold", True)):
@@ -517,7 +529,7 @@ class OpBuilder:
         if m_split:
             assert a.direct, "a dual-range GEMM needs the streaming (direct) mode"
             a.m_split, a.k_split = m_split, k_split
-        if extra_segs:
+        if extra_segs and not tiled:
             assert a.direct, "extra K segments need the streaming (direct) mode"
             segs = []
             for tap in range(taps):
@@ -634,7 +646,7 @@ class OpBuilder:
         def tile_lds_ok(cfg, tb):
             rows_in = (tb - 1) * a.stride + a.taps
             ctot = a.c0 + a.c1
-            return rows_in * (ctot + 8) * es + 8 * ctot + 8 * (lib.jen1_cfg_bm(cfg) // 2 + 2) + 64 <= 150 * 1024
+            return rows_in * (ctot + 32 * k_extra + 8) * es + 8 * ctot + 8 * (lib.jen1_cfg_bm(cfg) // 2 + 2) + 64 <= 150 * 1024
 
         if force is not None and "cfg" in force:
             cfg = force["cfg"]
@@ -794,12 +806,13 @@ class Plan(OpBuilder):
         gn2 = (r.groups, r.c_out, W.v[f"{n}.gn2.g"], W.v[f"{n}.gn2.b"], 1e-5)
         film = (self.film, self.film_row, W.film_off[n], r.c_out, self.step_idx if self.table_mode else None)
         srcs_raw = [src0] + ([src1] if src1 is not None else [])
-        if r.has_shortcut and self.eng.fuse_shortcut and self.streams(src0.B, src0.L, r.c_out) \
+        if r.has_shortcut and self.eng.fuse_shortcut and f"{n}.conv2s" in W.w \
                 and all(s_.cp == s_.C for s_ in srcs_raw) and 3 + len(srcs_raw) <= L.MAX_SEG:
-            # streaming level: the 1x1 shortcut is two more K segments of the second conv
-            self.conv(ops, src0=h, w=W.w[f"{n}.conv2s"], bias=W.v[f"{n}.conv2s.bias"], out=y, taps=3, pad_left=pad,
-                      pro=L.PRO_GN_SILU, gn=gn2, film=film, extra_segs=[(s_, 0) for s_ in srcs_raw])
-            return y
+            # the 1x1 shortcut is one or two more K segments of the second conv (streaming levels, the persistent kernel and the
+            # tiled long levels; a wide-tile launch declines and the separate shortcut launch below is used)
+            if self.conv(ops, src0=h, w=W.w[f"{n}.conv2s"], bias=W.v[f"{n}.conv2s.bias"], out=y, taps=3, pad_left=pad,
+                         pro=L.PRO_GN_SILU, gn=gn2, film=film, extra_segs=[(s_, 0) for s_ in srcs_raw]) is not None:
+                return y
         if r.has_shortcut:
             res = self.new_act(src0.B, src0.L, r.c_out)
             self.conv(ops, src0=src0, src1=src1, src1_scale=1.0, w=W.w[f"{n}.short"], bias=W.v[f"{n}.short.bias"], out=res)
@@ -1116,6 +1129,7 @@ class Engine:
         self.stream_bn = int(os.environ.get("JEN1_STREAM_BN", "64"))
         self.stream_max_wgs = int(os.environ.get("JEN1_STREAM_MAX_WGS", "768"))
         self.fuse_shortcut = os.environ.get("JEN1_FUSE_SHORTCUT", "1") != "0"
+        self.fuse_shortcut_tiles = os.environ.get("JEN1_FUSE_SHORTCUT_TILES", "1") != "0"      # ... also on the tiled long levels
         self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
         self.fuse_o2_ff1 = os.environ.get("JEN1_FUSE_O2_FF1", "1") != "0"
         self.fuse_ln_proj = os.environ.get("JEN1_FUSE_LN_PROJ", "1") != "0"
