@@ -595,6 +595,15 @@ def main():
                             "ms_per_step": round(dt2 / n2 * 1e3, 4),
                             "roofline_frac": r2["frac"], "alg_bytes_per_step": r2["alg_bytes_per_step"],
                             "conv_ms_per_step": r2["conv_ms_per_step"]}
+            # fixed-order statistics (Plan(deterministic=True)): what bit-reproducibility costs on the same workload
+            model.deterministic = True
+            st_d = build_stepper(model, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
+            n_d = max(10, args.steps // 2)
+            dt_d = timed_steps(st_d, n_d, max(3, args.warmup // 2), lambda: None)
+            out["extra"]["deterministic statistics mode, steps/s"] = round(n_d / dt_d, 2)
+            out["extra"]["deterministic statistics mode, launches_per_step"] = st_d.plan.n_launch + 1
+            del st_d
+            model.deterministic = False
             if not args.tiny:
                 out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
                 out["extra"]["train_step"] = train_step_bench(cfg, B, T, args.dtype, device)

@@ -235,6 +235,12 @@ int jen1_unpack_output(const void* y, float* out, int B, int C, int T, int ld, i
  * text context, blocks.py:401,427). */
 int jen1_row_stats(const void* x, float* stats, int rows, int C, int ld, int dtype, void* stream);
 
+/* Fine-group GroupNorm statistics of x[B][L][ld] in a FIXED summation order: stats[b][fg] = (sum, sumsq) over the L rows and the
+ * ld / 32 channels of fine group fg -- what the conv epilogues accumulate with float atomics (out_gn_stats), written instead of
+ * accumulated.  The deterministic mode of the engine (Plan(deterministic=True)) runs it behind every producer of a normalised
+ * tensor (blocks.py:141: GroupNorm statistics of the block input). */
+int jen1_gn_stats(const void* x, float* stats, int B, int L, int ld, int dtype, void* stream);
+
 /*
  * Time features + MLP in float32: LearnedPositionalEmbedding -> Linear -> GELU
  * (utils/module.py:58-79, model.py:84-89 / :286-291).  t: [n] int64 raw timesteps,

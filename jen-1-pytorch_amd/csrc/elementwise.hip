@@ -140,6 +140,40 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x,
   }
 }
 
+// fine-group GroupNorm statistics in a fixed order: one workgroup per (fine group, batch element); a thread sums elements
+// tid, tid + 256, ... of the group's L x cpf block, then a fixed shuffle / LDS tree
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int L, int ld) {
+  __shared__ float red[8];
+  const int fg = blockIdx.x, b = blockIdx.y;
+  const int cpf = ld / JEN1_FINE_GROUPS;
+  const T* p = x + (size_t)b * L * ld + fg * cpf;
+  const int n = L * cpf;
+  const float inv_cpf = 1.0f / (float)cpf;
+  float s = 0.f, q = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int r = (int)(((float)e + 0.5f) * inv_cpf), c = e - r * cpf;
+    const float v = (float)p[(size_t)r * ld + c];
+    s += v;
+    q += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * wave] = s;
+    red[2 * wave + 1] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[(size_t)b * 64 + fg * 2] = (red[0] + red[2]) + (red[4] + red[6]);
+    stats[(size_t)b * 64 + fg * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+  }
+}
+
 // LearnedPositionalEmbedding + Linear + GELU (utils/module.py:58-79; model.py:84-89, :286-291).
 // The phase is ((t * w) * 2) * pi evaluated left to right in float32 exactly like the reference:
 // at t = 999 the argument is ~2e4 rad, one float32 ulp there is 2e-3 rad.
@@ -366,6 +400,18 @@ extern "C" int jen1_row_stats(const void* x, float* stats, int rows, int C, int 
   if (dtype == JEN1_F32) hipLaunchKernelGGL(row_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, rows, C, ld);
   else if (dtype == JEN1_BF16) hipLaunchKernelGGL(row_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, stats, rows, C, ld);
   else return jen1_set_error("row_stats: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_gn_stats(const void* x, float* stats, int B, int L, int ld, int dtype, void* stream) {
+  JEN1_CHECK(x && stats && B >= 1 && L >= 1 && ld >= JEN1_FINE_GROUPS && ld % JEN1_FINE_GROUPS == 0, "gn_stats: bad arguments (ld=%d)", ld);
+  JEN1_CHECK((int64_t)L * (ld / JEN1_FINE_GROUPS) < (1 << 23), "gn_stats: %d rows are too many for the float index arithmetic", L);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(JEN1_FINE_GROUPS, B);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, L, ld);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, stats, L, ld);
+  else return jen1_set_error("gn_stats: bad dtype");
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -345,6 +345,7 @@ class OpBuilder:
         self._keep: List[object] = []
         self.slab = None
         self.counters = None
+        self.det = getattr(self, "det", False)      # fixed-order statistics launches instead of epilogue atomics (Plan)
         self.deep: Optional[DeepProgram] = None     # the persistent deep-level program being recorded (Plan._deep_begin)
         self._deep_on = False
 
@@ -465,7 +466,11 @@ class OpBuilder:
             return out
         # the tile kernel takes up to two raw extra K segments at row shift 0 (a 1x1 shortcut riding on the block's second conv)
         extras_tile = not extra_segs or (len(extra_segs) <= 2 and all(sh == 0 and e.cp == e.C and e.cp % 32 == 0 for e, sh in extra_segs))
-        tile_ok = (pro in (L.PRO_NONE, L.PRO_GN, L.PRO_GN_SILU, L.PRO_SILU) and act == L.ACT_NONE and row_scale is None and out.rs is None
+        det_gn = det_rs = False
+        if self.det:
+            det_gn, det_rs = bool(a.out_gn_stats), bool(a.out_rowstats)
+            a.out_gn_stats = a.out_rowstats = None
+        tile_ok = (pro in (L.PRO_NONE, L.PRO_GN, L.PRO_GN_SILU, L.PRO_SILU) and act == L.ACT_NONE and row_scale is None and (out.rs is None or det_rs)
                    and extras_tile and not m_split and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] > 1 or src1 is None)
                    and (pro not in (L.PRO_GN, L.PRO_GN_SILU) or gn[0] == 1 or
                         (a.gn_cpg % (a.c0 // FG) == 0 and (a.c1 == 0 or a.gn_cpg % (a.c1 // FG) == 0))))
@@ -561,7 +566,32 @@ class OpBuilder:
                     f"ps={a.ps_f}/{a.ps_off} Ly={a.L_y} pro={a.pro_mode} cfg={a.cfg} tb={a.tb} nb={a.nb} kst={a.kc_stage} sk={a.splitk} "
                     f"direct={a.direct}")
         ops.append(fn)
+        if det_gn:
+            self.stats_launch(ops, out)
+        if det_rs:
+            self.rowstats_launch(ops, out, m_split if m_split else out_C)
         return out
+
+    # ---------------------------------------------------------------- deterministic statistics (Plan(deterministic=True))
+    def stats_launch(self, ops, x: Act):
+        """fine-group GroupNorm statistics of ``x`` in a fixed summation order (jen1_gn_stats: written, not accumulated)"""
+        lib = self.eng.lib
+        a = (x.t.data_ptr(), x.gn.data_ptr(), x.B, x.L, x.ld, self.eng.dt)
+        fn = lambda s, a=a, lib=lib: L.check(lib.jen1_gn_stats(*a, s), "jen1_gn_stats")
+        fn.kind = "stats"
+        fn.label = f"gn_stats[B={x.B} L={x.L} ld={x.ld}]"
+        self._keep.append(x)
+        ops.append(fn)
+
+    def rowstats_launch(self, ops, x: Act, C: int):
+        """per-row LayerNorm sums over the first ``C`` columns of ``x`` (jen1_row_stats: one wave per row, fixed order)"""
+        lib = self.eng.lib
+        a = (x.t.data_ptr(), x.rs.data_ptr(), x.B * x.L, C, x.ld, self.eng.dt)
+        fn = lambda s, a=a, lib=lib: L.check(lib.jen1_row_stats(*a, s), "jen1_row_stats")
+        fn.kind = "stats"
+        fn.label = f"row_stats[rows={x.B * x.L} C={C}]"
+        self._keep.append(x)
+        ops.append(fn)
 
     @staticmethod
     def tile_geometry(B: int, L_out: int, BN: int):
@@ -719,14 +749,20 @@ class OpBuilder:
 class Plan(OpBuilder):
     """Pre-allocated buffers + prepared launches for one (B, T, nrep, causal) shape."""
 
-    def __init__(self, eng: "Engine", B: int, T: int, nrep: int, causal: bool, n_t: Optional[int] = None, deep: bool = True):
+    def __init__(self, eng: "Engine", B: int, T: int, nrep: int, causal: bool, n_t: Optional[int] = None, deep: bool = True,
+                 deterministic: bool = False):
         """n_t = None: one timestep per batch element (the general forward).  n_t = S: *table mode* of a
         sampler -- the timestep-only work (time MLP, FiLM GEMM, time-token K/V GEMM) is evaluated once for
         all S schedule entries (``run_time``) and every kernel of the step indexes the tables through the
         device-side counter ``step_idx``, so a captured step replays with no host-side update.
 
         deep: run the levels with few positions as ONE persistent launch (DeepProgram).  The first level of that launch
-        is the shallowest one whose every layer fits (``deep_level``); levels above it keep one launch per layer."""
+        is the shallowest one whose every layer fits (``deep_level``); levels above it keep one launch per layer.
+
+        deterministic: GroupNorm / LayerNorm statistics of the launch-per-layer levels are summed in a fixed order by a statistics
+        launch behind each producer (instead of float atomics in the producers' epilogues): two runs are bit-identical, the step
+        is slower by those launches.  The persistent deep-level launch is deterministic either way."""
+        self.det = bool(deterministic)
         self.B, self.T, self.nrep, self.causal = B, T, nrep, causal
         self.Beff = B * nrep
         self.table_mode = n_t is not None
@@ -922,9 +958,11 @@ class Plan(OpBuilder):
 
         # ---- 1. pack [B,C,T] + context channels -> channel-last, CFG pair replicated -------------
         X0 = self.new_act(Be, T, Cx + Cc, gn=True)
-        a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), X0.gn.data_ptr(), B, Cx, Cc, T,
+        a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), None if self.det else X0.gn.data_ptr(), B, Cx, Cc, T,
              X0.ld, self.nrep, eng.dt)
         ops.append(lambda s, a=a: L.check(lib.jen1_pack_input(*a, s), "jen1_pack_input"))
+        if self.det:
+            self.stats_launch(ops, X0)
 
         # ---- 2. time -> mapping -> FiLM scale/shift of all ResBlocks (model.py:204-223) -------------
         # (timestep-only work: ``time_ops``; one row per batch element, or per schedule entry in table mode)
@@ -1140,6 +1178,7 @@ class Engine:
         # persistent deep-level kernel (DeepProgram): levels of at most deep_max_len positions, plans of slot 0 only
         # (two persistent launches in flight on different streams could each hold CUs the other waits for)
         self.use_deep = os.environ.get("JEN1_DEEP", "1") != "0"
+        self.deterministic = os.environ.get("JEN1_DETERMINISTIC", "0") != "0"
         self.deep_max_len = int(os.environ.get("JEN1_DEEP_MAX_LEN", "64"))
         self.deep_nb_max = int(os.environ.get("JEN1_DEEP_NB_MAX", "0"))
         self.plans: Dict[tuple, Plan] = {}
@@ -1180,14 +1219,16 @@ class Engine:
         torch.cuda.synchronize(dev)
 
     def plan(self, B: int, T: int, nrep: int, causal: bool, slot: int = 0, n_t: Optional[int] = None,
-             deep: Optional[bool] = None) -> Plan:
+             deep: Optional[bool] = None, deterministic: Optional[bool] = None) -> Plan:
         """``slot`` distinguishes plans of the same shape that must own separate buffers because
         they run concurrently on different streams (sub-batches of one sampler step); ``n_t`` selects
-        the sampler's table mode (see Plan).  ``deep``: use the persistent deep-level launch (default: slot 0 only)."""
+        the sampler's table mode (see Plan).  ``deep``: use the persistent deep-level launch (default: slot 0 only).
+        ``deterministic``: fixed-order statistics (see Plan; default: ``self.deterministic``, env JEN1_DETERMINISTIC)."""
         if deep is None:
             deep = slot == 0
         deep = bool(deep) and self.use_deep
-        key = (B, T, nrep, bool(causal), slot, n_t, deep)
+        det = self.deterministic if deterministic is None else bool(deterministic)
+        key = (B, T, nrep, bool(causal), slot, n_t, deep, det)
         if key not in self.plans:
-            self.plans[key] = Plan(self, B, T, nrep, bool(causal), n_t, deep=deep)
+            self.plans[key] = Plan(self, B, T, nrep, bool(causal), n_t, deep=deep, deterministic=det)
         return self.plans[key]

@@ -104,6 +104,7 @@ SYMBOLS = {
     "jen1_pack_input": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "jen1_unpack_output": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     "jen1_row_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
+    "jen1_gn_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_time_features": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "jen1_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_cfg_ddim_step": (c_int, [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),

@@ -56,6 +56,7 @@ class UNetCFG1d(nn.Module):
                 v = torch.from_numpy(fill(key, shape, init_seed))
             _register(self, key, v.to(self._device))
         self._engine: Optional[Engine] = None
+        self._deterministic: Optional[bool] = None     # None: the engine's default (env JEN1_DETERMINISTIC)
         self._train_graph = None
         self._ctx_key = None
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
@@ -92,7 +93,21 @@ class UNetCFG1d(nn.Module):
             if self._device.type != "cuda":
                 raise L.Jen1HipError("UNetCFG1d needs a ROCm GPU (device='cuda'); no CPU path exists in this package")
             self._engine = Engine(self.spec, {k: v for k, v in self.state_dict().items()}, self.compute_dtype, self._device)
+            if self._deterministic is not None:
+                self._engine.deterministic = self._deterministic
         return self._engine
+
+    @property
+    def deterministic(self) -> bool:
+        """fixed-order GroupNorm / LayerNorm statistics in every plan built from now on (Plan(deterministic=True)): two runs of
+        the same inputs are bit-identical; the launch-per-layer levels pay one statistics launch per normalised tensor"""
+        return bool(self._deterministic) if self._engine is None else self._engine.deterministic
+
+    @deterministic.setter
+    def deterministic(self, on: bool) -> None:
+        self._deterministic = bool(on)
+        if self._engine is not None:
+            self._engine.deterministic = bool(on)
 
     def repack(self):
         """Re-pack weights after an optimiser step / in-place parameter change."""

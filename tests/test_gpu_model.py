@@ -385,9 +385,46 @@ def test_sampler_full_size_properties(full_model_f32):
         assert float(y.abs().max()) <= 1.0 + 1e-6
         outs.append(y.cpu().numpy())
     # graph replay vs eager: same kernels, same order.  A single forward repeats to ~4e-7 (float atomics reorder
-    # the GroupNorm/LayerNorm sums); four steps from t=999, where x0 = 157*(...) is clamped, amplify that to
-    # ~1e-4 run to run (eager vs eager shows the same spread), so the check uses the 1e-3 parity gate.
+    # the GroupNorm/LayerNorm sums of the launch-per-layer levels); four steps from t=999, where x0 = 157*(...) is clamped,
+    # amplify that to ~1e-4 run to run (eager vs eager shows the same spread), so the check uses the 1e-3 parity gate.
+    # With fixed-order statistics the two are bit-identical: test_deterministic_statistics_mode_is_bit_reproducible.
     assert rel_err(outs[1], outs[0]) < F32_TOL
+
+
+def test_deterministic_statistics_mode_is_bit_reproducible(full_model_f32, tiny_models):
+    """Plan(deterministic=True): the GroupNorm / LayerNorm sums of the launch-per-layer levels come from fixed-order statistics
+    launches (jen1_gn_stats, jen1_row_stats) instead of float atomics.  Two 100-step DDIM runs of the full model from the same
+    inputs are bit-identical (graph replay and eager), and the mode changes nothing beyond the summation order (1e-5 against the
+    default plan after one forward).  The tiny configuration covers attention on the launch path (row statistics)."""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    betas, _ = get_beta_schedule("linear", 1000)
+    for m, (B, T, S) in ((full_model_f32, (2, 1500, 100)), (tiny_models["f32"], (2, 300, 20))):
+        cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+        shape = (B, 128, T)
+        init = dev(synth.noise_list(1, shape, seed=7)[0])
+        x = dev(synth.latents(B, T))
+        t = torch.tensor([999, 499], device="cuda")
+        kw = dict(embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], channels_list=[cond["input_concat_cond"]],
+                  embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+        y_default = m(x, t, **kw).clone()
+        m.deterministic = True
+        try:
+            y_det = [m(x, t, **kw).clone() for _ in range(2)]
+            assert torch.equal(y_det[0], y_det[1])
+            assert rel_err(y_det[0].cpu().numpy(), y_default.cpu().numpy()) < 1e-5
+            plan = m.engine().plan(B, T, 2, False)
+            assert plan.det and any(getattr(op, "kind", "") == "stats" for op in plan.ops)
+            outs = []
+            for use_graph in (True, False, True):
+                gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                                       embedding_scale=0.8, batch_cfg=True, scale_cfg=True, sampling_timesteps=S, ddim_sampling_eta=0.0)
+                y = gd.sample(m, shape, cond, init_noise=init, use_graph=use_graph)
+                torch.cuda.synchronize()
+                assert torch.isfinite(y).all()
+                outs.append(y.clone())
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        finally:
+            m.deterministic = False
 
 
 def test_text_conditioner_tail_projection_and_mask():
