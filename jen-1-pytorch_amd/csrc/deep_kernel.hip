@@ -951,14 +951,22 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
     for (int r = tid >> 4; r < rsn; r += NT / 16) {
       const T* rowp = qp + (size_t)((unsigned)(b * Nq + rs0 + r) * (unsigned)ldq);
       float s = 0.f, q2 = 0.f;
-#pragma unroll 4
-      for (int vv = li; vv < nvec; vv += 16) {
-        Raw8<T> x;
-        ld_live(x, rowp + vv * 8);
-        float f[8];
-        raw_to_float(x, f);
+      // LNB vectors per lane requested together (bf16: a 1024-column row in one round trip; f32 keeps 2: registers)
+      constexpr int LNB = sizeof(T) == 2 ? 8 : 2;
+      for (int v0 = li; v0 < nvec; v0 += 16 * LNB) {
+        Raw8<T> x[LNB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s += f[j]; q2 += f[j] * f[j]; }
+        for (int k = 0; k < LNB; ++k) {
+          if (v0 + 16 * k < nvec) ld_live(x[k], rowp + (v0 + 16 * k) * 8);
+          else zero_raw(x[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < LNB; ++k) {
+          float f[8];
+          raw_to_float(x[k], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s += f[j]; q2 += f[j] * f[j]; }
+        }
       }
       s = row16_sum_d(s);
       q2 = row16_sum_d(q2);
