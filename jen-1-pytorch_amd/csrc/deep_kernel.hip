@@ -442,11 +442,11 @@ __device__ __forceinline__ void k_round_n(f32x4 (&acc)[4], const Frag (&ra)[PF],
   else k_round<T, NF, PF>(acc, ra, tile, cbase, soff);
 }
 
-// sum over the aligned group of 2^lS lanes (3 <= lS <= 6) that holds v, in a fixed order
+// sum over the aligned group of 2^lS lanes (1 <= lS <= 6) that holds v, in a fixed order
 __device__ __forceinline__ float lane_set_sum(float v, int lS) {
   v += ddpp<0xB1>(v);                       // lanes ^ 1
-  v += ddpp<0x4E>(v);                       // lanes ^ 2
-  v += ddpp<0x141>(v);                      // row_half_mirror: the other quad of the 8
+  if (lS >= 2) v += ddpp<0x4E>(v);          // lanes ^ 2
+  if (lS >= 3) v += ddpp<0x141>(v);         // row_half_mirror: the other quad of the 8
   if (lS >= 4) v += ddpp<0x140>(v);         // row_mirror: the other half of the 16
   if (lS >= 5) v += __shfl_xor(v, 16);
   if (lS >= 6) v += __shfl_xor(v, 32);
@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   } else {
     for (int i = tid; i < d * 32; i += NT) {
       const int c = i >> 5, j = Nk + (i & 31);
-      if (j < NKP) kv_s[c * vt + j] = (T)0.f;
+      if (j < NKP) kv_s[c * vt + (j ^ (((c >> 3) & 3) << 3))] = (T)0.f;
     }
   }
 #pragma unroll
@@ -1066,8 +1066,11 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
       float x[8];
       raw_to_float(vraw[i], x);
       if (i == 0 && fin_kv) finish(x, st_s[r], uv, bv);
+      // the 8-key blocks of a row are permuted by the row's channel block (XOR inside each 32-key group): the 16 channel blocks a
+      // wave transposes at once would otherwise land on two LDS banks
+      const int rs = r ^ (((c >> 3) & 3) << 3);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + r] = (T)x[e];
+      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + rs] = (T)x[e];
     }
   }
   // ---- softmax in float32 (blocks.py:367-371): 16 lanes per row, 32 rows per pass over the 8 waves ---------------------------------
@@ -1123,7 +1126,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
       for (int j = 0; j < NKP; j += 32) {
         Frag pa, vb;
         dlds(pa, p_s + (qt * 16 + li) * vt + j + lg * 8);
-        dlds(vb, kv_s + (ct * 16 + li) * vt + j + lg * 8);
+        dlds(vb, kv_s + (ct * 16 + li) * vt + ((j + lg * 8) ^ ((((ct * 16 + li) >> 3) & 3) << 3)));
         dmma(acc, pa, vb);
       }
 #pragma unroll
@@ -1430,7 +1433,7 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
     int lS = 6;
     if (p.h.norm_C) {
       const int pairs = nb * a->gn_groups;
-      if (pairs > JEN1_DEEP_THREADS / 8) continue;                       // at least 8 lanes per pair
+      if (pairs > JEN1_DEEP_THREADS / 2) continue;                       // at least 2 lanes per pair
       int S = JEN1_DEEP_THREADS / pairs;
       S = S > 64 ? 64 : S;
       lS = 0;
