@@ -229,11 +229,19 @@ template <> struct DeepCfg<float> { static constexpr int MAXV = JEN1_DEEP_MAXV_F
 //         [TAB_OFF + 64, ...)                     NW lists of MAXRUN runs {g0, n, col0, shift}: the usable chunks of the flat
 //                                                 (segment, chunk) list dealt round-robin; inside a segment a wave's chunks
 //                                                 are g0, g0 + NW, ... at staged columns col0, col0 + 32 NW, ...
+//         [SLOT_OFF, ...)                         per wave: the flat chunk index g[SLOTS] and the staged offset (shift * pitch + column)
+//                                                 off[SLOTS] of its first SLOTS chunks (the first round of the weight ring: no cursor
+//                                                 walk in the unit or in the prefill), then per wave the cursor {run, left, g, col,
+//                                                 shift} behind the ring's first round (CUR_OFF; PF chunks in, for layers with more)
 //   header {n_units, rot, kind, -}                what a workgroup needs to find its next unit without touching the blobs
 constexpr int BLOB = JEN1_DEEP_BLOB_BYTES;
 constexpr int TAB_OFF = 1024;
-constexpr int MAXRUN = 16;                             // runs (segment pieces) per wave
-static_assert(TAB_OFF + 64 + NW * MAXRUN * 16 <= BLOB, "run tables must fit the blob");
+constexpr int MAXRUN = 12;                             // runs (segment pieces) per wave
+constexpr int SLOTS = 12;                              // ring slots tabulated per wave (>= PF of either dtype)
+constexpr int SLOT_OFF = TAB_OFF + 64 + NW * MAXRUN * 16;
+constexpr int CUR_OFF = SLOT_OFF + NW * SLOTS * 8;
+static_assert(CUR_OFF + NW * 32 <= BLOB, "run / slot / cursor tables must fit the blob");
+static_assert(JEN1_DEEP_PF_B <= SLOTS && JEN1_DEEP_PF_F <= SLOTS, "the slot table covers the ring");
 constexpr int HDR_BYTES = JEN1_DEEP_MAX_PHASES * 16;
 constexpr int WS_OFF = HDR_BYTES + 2 * BLOB;           // LDS: headers | two descriptor slots | unit workspace
 static_assert(sizeof(jen1_deep_phase) <= TAB_OFF, "descriptor must fit ahead of the chunk table");
@@ -406,19 +414,39 @@ __device__ __forceinline__ void gemm_issue(const GemmWave<T>& g, const KCursor& 
 
 // fill the ring of a unit as early as its descriptor is known (right behind the previous unit's arrival); slots beyond the wave's
 // chunks are zeroed (the K loop runs whole rounds)
+// the wave's tabulated first round: lane i < SLOTS holds chunk index / staged offset of slot i
+struct SlotTab {
+  int g, off;
+};
+__device__ __forceinline__ SlotTab slot_tab(const unsigned char* D, int wk, int lane) {
+  const int* t = reinterpret_cast<const int*>(D + SLOT_OFF) + wk * (2 * SLOTS);
+  SlotTab r;
+  const int l = lane < SLOTS ? lane : 0;
+  r.g = t[l];
+  r.off = t[SLOTS + l];
+  return r;
+}
+template <typename T, typename Frag>
+__device__ __forceinline__ void gemm_issue_g(const GemmWave<T>& g, int chunk, int lane, Frag& fa) {
+  constexpr int ES = sizeof(T);
+  constexpr unsigned BLK = 512 * ES;
+#ifdef JEN1_DEEP_EXP_NOW
+  wload(fa, g.rw, OOB, 0);
+#else
+  wload(fa, g.rw, (unsigned)lane * (8u * ES), (unsigned)(chunk * g.MT + g.mt) * BLK);
+#endif
+}
+
+// fill the ring of a unit as early as its descriptor is known (right behind the previous unit's arrival); slots beyond the wave's
+// chunks are zeroed (the K loop runs whole rounds)
 template <typename T, typename Frag, int PF>
 __device__ __forceinline__ void gemm_prefill(const unsigned char* D, int u, int wk, int lane, Frag (&ra)[PF]) {
   const GemmWave<T> g = gemm_wave<T>(D, u, wk);
-  KCursor ic;
-  kc_start(ic, g.runs, g.nruns);
+  const SlotTab st = slot_tab(D, wk, lane);
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
-    if (i < g.total) {
-      gemm_issue<T>(g, ic, lane, ra[i]);
-      kc_next(ic, g.runs, g.nruns);
-    } else {
-      frag_zero_d(ra[i]);
-    }
+    if (i < g.total) gemm_issue_g<T>(g, __builtin_amdgcn_readlane(st.g, i), lane, ra[i]);
+    else frag_zero_d(ra[i]);
   }
 }
 
@@ -479,6 +507,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const float inv_Lin = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_Lin)));
   const float inv_Lout = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_Lout)));
 
+  DK_STAMP(sy, 7);
   // ---- the normalised part: (batch element, group) pair of this lane set, column of this lane -----------------------------
   const int lS = rfl(P->h.lS), lvpg = rfl(P->h.lvpg), lgroups = rfl(P->h.lgroups), cpg = rfl(P->h.gn_cpg);
   const int pair = tid >> lS, wl = tid & ((1 << lS) - 1);
@@ -515,6 +544,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     nap[i] = nbase + (size_t)((unsigned)(ok ? t : 0) * (unsigned)nld);
     ntile[i] = ok ? (nbl * Lp + Hb + t) * pitch + cn : dummy_tile;
   }
+  DK_STAMP(sy, 8);
   // ---- the raw part: a thread owns one column, rows r0, r0 + rpr, ... of the unit's nb * L_in staged rows ----------------------
   const int Craw = Ctot - norm_C;
   const int lvr = rfl(P->h.lvr);
@@ -555,6 +585,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     wap[i] = rbase + (size_t)((unsigned)rc * (unsigned)rld);
     wtile[i] = ok ? (rc + bl * lpx + Hb) * pitch + cr : dummy_tile;
   }
+  DK_STAMP(sy, 9);
   // ---- halo rows and the zero block: nobody else touches them, written before the wait ----------------------------------------
   {
     const int vpr = Ctot >> 3;
@@ -577,6 +608,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       store8(tile + (size_t)row * pitch + c, z8);
     }
   }
+  DK_STAMP(sy, 10);
   // ---- epilogue operands that do not depend on other workgroups (per M tile of the unit) ------------------------------------
   const bool epi = wk < NF;
   const int nfe = wk;                                   // the fragment this wave finishes
@@ -604,6 +636,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     resp = reinterpret_cast<const T*>(P->h.residual) + ((size_t)((unsigned)yrow * (unsigned)rfl(P->h.ld_res)) + (unsigned)co);
   };
   epi_operands(gw.mt);
+  DK_STAMP(sy, 12);
   // ---- K loop: column base of this lane per fragment; scalar (shift * pitch + channel) offset per ring slot of the first round ---
   const int total = gw.total;
   int cbase[4];
@@ -618,12 +651,13 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     }
   }
   int soff[PF];
-  KCursor cc;
-  kc_start(cc, gw.runs, gw.nruns);
+  const SlotTab stab = slot_tab(D, wk, lane);
 #pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    soff[i] = cc.shift * pitch + cc.col;
-    if (i + 1 < total) kc_next(cc, gw.runs, gw.nruns);            // slots beyond the last chunk repeat its offset (zero weights)
+  for (int i = 0; i < PF; ++i) soff[i] = __builtin_amdgcn_readlane(stab.off, i);      // (slots beyond the last chunk hold zero weights)
+  KCursor cc;                                          // behind the first round's chunks (used by layers with more than PF per wave)
+  {
+    const int* ct = reinterpret_cast<const int*>(D + CUR_OFF) + wk * 8;
+    cc.r = rfl(ct[0]); cc.left = rfl(ct[1]); cc.g = rfl(ct[2]); cc.col = rfl(ct[3]); cc.shift = rfl(ct[4]);
   }
 
   // ---- dependency ---------------------------------------------------------------------------------------------------
@@ -754,19 +788,15 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   // the next tile of the unit: the same chunks, the next 1 KiB fragment of each; requested behind a K loop
   auto ring_next_tile = [&]() __attribute__((always_inline)) {
     gw.mt += 1;
-    KCursor ic;
-    kc_start(ic, gw.runs, gw.nruns);
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       if (i < total) {
-        gemm_issue<T>(gw, ic, lane, ra[i]);
-        soff[i] = ic.shift * pitch + ic.col;
-        if (i + 1 < total) kc_next(ic, gw.runs, gw.nruns);
+        gemm_issue_g<T>(gw, __builtin_amdgcn_readlane(stab.g, i), lane, ra[i]);
+        soff[i] = __builtin_amdgcn_readlane(stab.off, i);
       } else {
         frag_zero_d(ra[i]);
       }
     }
-    cc = ic;
   };
   auto put_partial = [&](const f32x4 (&acc)[4], float* redj) __attribute__((always_inline)) {
 #pragma unroll
@@ -1586,6 +1616,32 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
       k0 += Ls;
     }
     if (!P.h.mt_split) for (int w = 0; w < NW; ++w) { cnt[NW + w] = cnt[w]; cnt[3 * NW + w] = cnt[2 * NW + w]; }
+    // the first ring round of every wave, tabulated (chunk index, staged offset), and the cursor behind it
+    const int pf = P.h.dtype == JEN1_F32 ? JEN1_DEEP_PF_F : JEN1_DEEP_PF_B;
+    int32_t* slots = reinterpret_cast<int32_t*>(b + SLOT_OFF);
+    int32_t* curs = reinterpret_cast<int32_t*>(b + CUR_OFF);
+    for (int w = 0; w < NW; ++w) {
+      const int32_t* rw = runs + (size_t)w * MAXRUN * 4;
+      const int nr = cnt[2 * NW + w], tot = cnt[w];
+      int r = 0, left = nr ? rw[1] : 0, g = nr ? rw[0] : 0, col = nr ? rw[2] : 0, sh = nr ? rw[3] : 0;
+      auto next = [&]() {
+        if (--left > 0) { g += NW; col += NW * 32; }
+        else if (r + 1 < nr) { ++r; left = rw[r * 4 + 1]; g = rw[r * 4]; col = rw[r * 4 + 2]; sh = rw[r * 4 + 3]; }
+      };
+      for (int i = 0; i < SLOTS; ++i) {
+        slots[w * 2 * SLOTS + i] = g;
+        slots[w * 2 * SLOTS + SLOTS + i] = sh * P.h.pitch + col;
+        if (i + 1 == pf) {                 // the device cursor state after the ring's first round (kc_next semantics)
+          int r2 = r, l2 = left, g2 = g, c2 = col, s2 = sh;
+          if (i + 1 < tot) {
+            if (--l2 > 0) { g2 += NW; c2 += NW * 32; }
+            else if (r2 + 1 < nr) { ++r2; l2 = rw[r2 * 4 + 1]; g2 = rw[r2 * 4]; c2 = rw[r2 * 4 + 2]; s2 = rw[r2 * 4 + 3]; }
+          }
+          curs[w * 8 + 0] = r2; curs[w * 8 + 1] = l2; curs[w * 8 + 2] = g2; curs[w * 8 + 3] = c2; curs[w * 8 + 4] = s2;
+        }
+        if (i + 1 < tot) next();           // slots beyond the last chunk repeat its offset (zero weights)
+      }
+    }
   }
   return lds + WS_OFF;
 }

@@ -341,5 +341,10 @@ def test_deep_phase_planner_host_side(lib):
     cnt = (C.c_int16 * 32).from_buffer(blobs, 1024)
     assert list(cnt) == [8] * 16 + [1] * 16
     run0 = (C.c_int32 * 4).from_buffer(blobs, 1024 + 64)
-    run1 = (C.c_int32 * 4).from_buffer(blobs, 1024 + 64 + 16 * 16)
+    run1 = (C.c_int32 * 4).from_buffer(blobs, 1024 + 64 + 12 * 16)
     assert list(run0) == [64, 8, 0, 0] and list(run1) == [65, 8, 32, 0]
+    # the tabulated first ring round of wave 1 (12 slots: chunk index, staged offset = shift * pitch + column) behind the 8 x 12 runs:
+    # its 8 chunks 65, 73, ... at columns 32, 288, ..., the four slots beyond them repeat the last one
+    slot1 = (C.c_int32 * 24).from_buffer(blobs, 1024 + 64 + 8 * 12 * 16 + 1 * 96)
+    assert list(slot1)[:12] == [65 + 8 * j for j in range(8)] + [121] * 4
+    assert list(slot1)[12:] == [32 + 256 * j for j in range(8)] + [32 + 256 * 7] * 4

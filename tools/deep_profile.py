@@ -94,18 +94,14 @@ raw = dbg.cpu().numpy().astype(np.float64)
 mm = (raw[:, :, 7] > 0) & (raw[:, :, 8] > 0) & (raw[:, :, 6] > raw[:, :, 0])
 fr = (raw[:, :, 8] - raw[:, :, 7])[mm] / ((raw[:, :, 6] - raw[:, :, 0])[mm] * 0.01)
 print(f"# shader clock during the GEMM units (s_memtime ticks per us): median {np.median(fr):.0f} MHz, 10th / 90th percentile {np.percentile(fr, 10):.0f} / {np.percentile(fr, 90):.0f}")
-# finer stamps of the GEMM units (mean over the workgroups of a phase): setup 0->7 ring, 7->8 fields, 8->9 parameter requests,
-# 9->1 epilogue operands; staging 2->10 loads issued, 10->11 raw stores, 11->12 partial sums + sync, 12->13 statistics + sync,
-# 13->3 normalise + sync; 3->4 K loop; 4->14 reduction sync, 14->15 epilogue math + stores, 15->5 drain + sync, 5->6 arrive (+ prefill)
-order = [0, 1, 2, 11, 12, 13, 3, 4, 14, 15, 5, 6]
-print("# fine: " + " ".join(f"{a}>{b}" for a, b in zip(order[:-1], order[1:])))
+# pre-wait setup of the GEMM units (mean over the workgroups of a phase): 0->7 wave / geometry scalars, 7->8 normalised-part
+# addresses + parameter requests, 8->9 raw-part addresses, 9->10 halo rows zeroed, 10->12 epilogue operands, 12->1 K-loop offsets
+order = [0, 7, 8, 9, 10, 12, 1]
+print("# setup: " + " ".join(f"{a}>{b}" for a, b in zip(order[:-1], order[1:])))
 for p in range(n):
-    m = (d[p, :, 0] > 0) & (d[p, :, 14] > 0)
+    m = (d[p, :, 0] > 0) & (d[p, :, 7] > 0)
     if not m.any():
         continue
     st = d[p, m]
-    vals = []
-    for a, b in zip(order[:-1], order[1:]):
-        ok = (st[:, a] > 0) & (st[:, b] > 0)
-        vals.append(np.mean(st[ok, b] - st[ok, a]) if ok.any() else float("nan"))
-    print(f"{p:3d} " + " ".join(f"{v:5.2f}" for v in vals) + "  " + prog.labels[p][:60])
+    vals = [np.mean(st[:, b] - st[:, a]) for a, b in zip(order[:-1], order[1:])]
+    print(f"{p:3d} " + " ".join(f"{v:5.2f}" for v in vals) + "  " + prog.labels[p][:70])
