@@ -344,6 +344,47 @@ __device__ __forceinline__ bool find_next(const Hdr* hdr, int n_phases, int wg, 
 //     branch-free (vectors that do not exist read row 0 and land in a dummy slot);
 //   * the K loop runs whole rounds of the PF ring slots straight-line (slots beyond the wave's chunks hold zero weights).
 // =====================================================================================================================
+// ---- descriptor fields without LDS round trips: lane i of two registers holds dwords i and 64 + i of the phase blob; a field is a
+// v_readlane (scalar result), a pointer two of them.  (One ds_read pair per unit instead of one dependent LDS read per field.)
+struct HotRegs {
+  unsigned a, b;
+};
+static_assert(sizeof(jen1_deep_hot) <= 512, "the hot block must fit two dwords per lane");
+__device__ __forceinline__ HotRegs hot_regs(const unsigned char* D, int lane) {
+  const unsigned* w = reinterpret_cast<const unsigned*>(D);
+  HotRegs r;
+  r.a = w[lane];
+  r.b = w[64 + lane];
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ int hot_i32(const HotRegs& r) {
+  static_assert(OFF % 4 == 0 && OFF >= 0 && OFF < 512, "field offset");
+  return OFF < 256 ? __builtin_amdgcn_readlane((int)r.a, (OFF / 4) & 63) : __builtin_amdgcn_readlane((int)r.b, (OFF / 4 - 64) & 63);
+}
+template <int OFF>
+__device__ __forceinline__ float hot_f32(const HotRegs& r) { return __builtin_bit_cast(float, hot_i32<OFF>(r)); }
+template <int OFF, typename PT>
+__device__ __forceinline__ PT hot_ptr(const HotRegs& r) {
+  const u64 v = (u64)(unsigned)hot_i32<OFF>(r) | ((u64)(unsigned)hot_i32<OFF + 4>(r) << 32);
+  return reinterpret_cast<PT>(v);
+}
+#define HI(f) hot_i32<offsetof(jen1_deep_hot, f)>(hr)
+#define HF(f) hot_f32<offsetof(jen1_deep_hot, f)>(hr)
+#define HP(f, type) hot_ptr<offsetof(jen1_deep_hot, f), type>(hr)
+#define HSRC_OFF(k, f) (offsetof(jen1_deep_hot, src) + (k) * sizeof(jen1_deep_src) + offsetof(jen1_deep_src, f))
+// source k of the table as scalars
+template <int K>
+__device__ __forceinline__ jen1_deep_src hot_src(const HotRegs& hr) {
+  jen1_deep_src s;
+  s.x = hot_ptr<HSRC_OFF(K, x), const void*>(hr);
+  s.ld = hot_i32<HSRC_OFF(K, ld)>(hr);
+  s.C = hot_i32<HSRC_OFF(K, C)>(hr);
+  s.coff = hot_i32<HSRC_OFF(K, coff)>(hr);
+  s.scale = hot_f32<HSRC_OFF(K, scale)>(hr);
+  return s;
+}
+
 struct KRun {                // one run of a wave's K chunks: chunk j is flat chunk g0 + j * NW at staged column col0 + j * NW * 32
   int g0, n, col0, shift;
 };
@@ -357,23 +398,20 @@ struct GemmWave {            // what prefill and the K loop share (all scalar)
 };
 
 template <typename T>
-__device__ __forceinline__ GemmWave<T> gemm_wave(const unsigned char* D, int u, int wk) {
-  const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
+__device__ __forceinline__ GemmWave<T> gemm_wave(const unsigned char* D, const HotRegs& hr, int u, int wk) {
   GemmWave<T> g;
-  g.MT = rfl(P->h.MT);
-  const int mrep = rfl(P->h.mrep);
+  g.MT = HI(MT);
+  const int mrep = HI(mrep);
   const int MTg = g.MT >> (mrep > 4 ? 3 : (mrep > 2 ? 2 : (mrep > 1 ? 1 : 0)));      // units per batch group (mrep: 1, 2, 4, 8)
   const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)MTg));      // u < 2^20: exact
   g.mt = (u - grp * MTg) * mrep;                                        // the unit's first M tile
   g.grp = grp;
-  g.low_m = g.mt < rfl(P->h.mt_split);
+  g.low_m = g.mt < HI(mt_split);
   const short* cnt = reinterpret_cast<const short*>(D + TAB_OFF);
   g.total = rfl(g.low_m ? cnt[NW + wk] : cnt[wk]);
   g.nruns = rfl(g.low_m ? cnt[3 * NW + wk] : cnt[2 * NW + wk]);
   g.runs = reinterpret_cast<const KRun*>(D + TAB_OFF + 64) + wk * MAXRUN;
-  const u64 wp = (u64)P->h.w;
-  g.rw = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((u64)(unsigned)rfl((int)(wp >> 32)) << 32) | (unsigned)rfl((int)wp)), 0,
-                                           rfl((int)P->h.w_bytes), RSRC_FLAGS);
+  g.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HP(w, const void*)), 0, HI(w_bytes), RSRC_FLAGS);
   return g;
 }
 
@@ -441,7 +479,8 @@ __device__ __forceinline__ void gemm_issue_g(const GemmWave<T>& g, int chunk, in
 // chunks are zeroed (the K loop runs whole rounds)
 template <typename T, typename Frag, int PF>
 __device__ __forceinline__ void gemm_prefill(const unsigned char* D, int u, int wk, int lane, Frag (&ra)[PF]) {
-  const GemmWave<T> g = gemm_wave<T>(D, u, wk);
+  const HotRegs hr = hot_regs(D, lane);
+  const GemmWave<T> g = gemm_wave<T>(D, hr, u, wk);
   const SlotTab st = slot_tab(D, wk, lane);
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
@@ -492,31 +531,32 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const int wk = rfl(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   DK_STAMP(sy, 0);
-  GemmWave<T> gw = gemm_wave<T>(D, u, wk);
-  const int nb = rfl(P->h.nb), B = rfl(P->h.B), L_in = rfl(P->h.L_in), L_out = rfl(P->h.L_out), NF = rfl(P->h.NF);
-  const int pitch = rfl(P->h.pitch), norm_C = rfl(P->h.norm_C), Ctot = rfl(P->h.Ctot), Lp = rfl(P->h.Lp), Hb = rfl(P->h.Hb);
-  const int zrow = rfl(P->h.zrow), Rtot = rfl(P->h.Rtot);
-  const int mrep = rfl(P->h.mrep);                       // the unit finishes mrep M tiles from one staged tile
+  const HotRegs hr = hot_regs(D, lane);
+  GemmWave<T> gw = gemm_wave<T>(D, hr, u, wk);
+  const int nb = HI(nb), B = HI(B), L_in = HI(L_in), L_out = HI(L_out), NF = HI(NF);
+  const int pitch = HI(pitch), norm_C = HI(norm_C), Ctot = HI(Ctot), Lp = HI(Lp), Hb = HI(Hb);
+  const int zrow = HI(zrow), Rtot = HI(Rtot);
+  const int mrep = HI(mrep);                       // the unit finishes mrep M tiles from one staged tile
   const int b0 = gw.grp * nb;
   const bool low_m = gw.low_m;
   unsigned char* ws = smem + WS_OFF;
   T* tile = reinterpret_cast<T*>(ws);
-  float* red = reinterpret_cast<float*>(ws + rfl(P->h.red_off));
+  float* red = reinterpret_cast<float*>(ws + HI(red_off));
   // per-thread landing place of vectors that do not exist (branch-free stores): the K-reduction scratch, unused while staging
-  const int dummy_tile = rfl(P->h.red_off) / (int)sizeof(T) + tid * 8;
-  const float inv_Lin = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_Lin)));
-  const float inv_Lout = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_Lout)));
+  const int dummy_tile = HI(red_off) / (int)sizeof(T) + tid * 8;
+  const float inv_Lin = HF(inv_Lin);
+  const float inv_Lout = HF(inv_Lout);
 
   DK_STAMP(sy, 7);
   // ---- the normalised part: (batch element, group) pair of this lane set, column of this lane -----------------------------
-  const int lS = rfl(P->h.lS), lvpg = rfl(P->h.lvpg), lgroups = rfl(P->h.lgroups), cpg = rfl(P->h.gn_cpg);
+  const int lS = HI(lS), lvpg = HI(lvpg), lgroups = HI(lgroups), cpg = HI(gn_cpg);
   const int pair = tid >> lS, wl = tid & ((1 << lS) - 1);
   const int nbl = pair >> lgroups, ngrp = pair & ((1 << lgroups) - 1);
   const int cn = ngrp * cpg + (wl & ((1 << lvpg) - 1)) * 8;       // first channel of the lane's column
   const int nt0 = wl >> lvpg, ntstep = (1 << lS) >> lvpg;           // first position, positions per trip
   const bool npair_ok = norm_C > 0 && nbl < nb && b0 + nbl < B;
-  const jen1_deep_src s0 = P->h.src[0], s1 = P->h.src[1];
-  const bool in1 = rfl(P->h.nsrc) > 1 && s1.coff < norm_C && cn >= s1.coff;         // second normalised source (the skip)
+  const jen1_deep_src s0 = hot_src<0>(hr), s1 = hot_src<1>(hr);
+  const bool in1 = HI(nsrc) > 1 && s1.coff < norm_C && cn >= s1.coff;         // second normalised source (the skip)
   const T* nbase = reinterpret_cast<const T*>(in1 ? s1.x : s0.x) + (cn - (in1 ? s1.coff : 0)) +
                    (size_t)((unsigned)((npair_ok ? b0 + nbl : b0) * L_in) * (unsigned)(in1 ? s1.ld : s0.ld));
   const int nld = in1 ? s1.ld : s0.ld;
@@ -527,13 +567,13 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   if (norm_C) {
     // one table row per unit: gamma / beta (p_ld = 0), the sampler's per-step row, or the row of the unit's batch element
     // (units of a per-element table hold one batch element: jen1_deep_phase_conv)
-    const int p_ld = rfl(P->h.p_ld);
-    const int* fstep = P->h.film_step;
-    const int* frow = P->h.film_row;
+    const int p_ld = HI(p_ld);
+    const int* fstep = HP(film_step, const int*);
+    const int* frow = HP(film_row, const int*);
     const int fr = p_ld ? (fstep ? fstep[0] : (frow ? frow[b0] : b0)) : 0;
     const size_t po = (size_t)((unsigned)fr * (unsigned)p_ld) + (unsigned)(npair_ok ? cn : 0);
-    load8(P->h.p1 + po, p1);
-    load8(P->h.p2 + po, p2);
+    load8(HP(p1, const float*) + po, p1);
+    load8(HP(p2, const float*) + po, p2);
   }
   const T* nap[MAXV];
   int ntile[MAXV];
@@ -547,7 +587,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   DK_STAMP(sy, 8);
   // ---- the raw part: a thread owns one column, rows r0, r0 + rpr, ... of the unit's nb * L_in staged rows ----------------------
   const int Craw = Ctot - norm_C;
-  const int lvr = rfl(P->h.lvr);
+  const int lvr = HI(lvr);
   const int cr = Craw > 0 ? norm_C + (tid & ((1 << lvr) - 1)) * 8 : 0;      // (no raw part: the dummy loads stay inside source 0)
   const int rr0 = tid >> lvr, rpr = NT >> lvr;
   int rows_ok = (B - b0) * L_in;                       // staged rows below this belong to real batch elements
@@ -560,15 +600,18 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     const void* xp = s0.x;
     int ld = s0.ld, coff = 0;
     float sc = s0.scale;
-#pragma unroll
-    for (int k = 1; k < JEN1_DEEP_MAX_SRC; ++k) {
-      const jen1_deep_src sk = P->h.src[k];
-      const bool use = k < rfl(P->h.nsrc) && cr >= sk.coff;
+    static_assert(JEN1_DEEP_MAX_SRC == 4, "the source scan below is written out for four sources");
+    const int nsrc = HI(nsrc);
+    auto pick = [&](const jen1_deep_src sk, int k) __attribute__((always_inline)) {
+      const bool use = k < nsrc && cr >= sk.coff;
       xp = use ? sk.x : xp;
       ld = use ? sk.ld : ld;
       coff = use ? sk.coff : coff;
       sc = use ? sk.scale : sc;
-    }
+    };
+    pick(s1, 1);
+    pick(hot_src<2>(hr), 2);
+    pick(hot_src<3>(hr), 3);
     rbase = reinterpret_cast<const T*>(xp) + (cr - coff) + (size_t)((unsigned)(b0 * L_in) * (unsigned)ld);
     rld = ld;
     rscale = sc;
@@ -621,19 +664,21 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     int ph = 0;
     co = m;
     if (epi) {
-      const int out_C = rfl(P->h.out_C), ps_f = rfl(P->h.ps_f);
+      const int out_C = HI(out_C), ps_f = HI(ps_f);
       for (int k = 1; k < ps_f; ++k) ph += (m >= k * out_C) ? 1 : 0;
       co = m - ph * out_C;
-      if (P->h.bias) bias4 = *reinterpret_cast<const f32x4*>(P->h.bias + co);
+      const float* biasp = HP(bias, const float*);
+      if (biasp) bias4 = *reinterpret_cast<const f32x4*>(biasp + co);
       const int n = nfe * 16 + li;
       const int ebl = (int)(((float)n + 0.5f) * inv_Lout);
       const int t = n - ebl * L_out;
-      const int ty = t * ps_f + ph - rfl(P->h.ps_off);
-      okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < rfl(P->h.L_y);
-      yrow = okk ? (b0 + ebl) * rfl(P->h.y_brows) + rfl(P->h.y_row0) + ty : 0;
+      const int ty = t * ps_f + ph - HI(ps_off);
+      okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < HI(L_y);
+      yrow = okk ? (b0 + ebl) * HI(y_brows) + HI(y_row0) + ty : 0;
     }
-    use_res = epi && okk && P->h.residual && (rfl(P->h.mt_split) == 0 || low_m);
-    resp = reinterpret_cast<const T*>(P->h.residual) + ((size_t)((unsigned)yrow * (unsigned)rfl(P->h.ld_res)) + (unsigned)co);
+    const T* resb = HP(residual, const T*);
+    use_res = epi && okk && resb && (HI(mt_split) == 0 || low_m);
+    resp = resb + ((size_t)((unsigned)yrow * (unsigned)HI(ld_res)) + (unsigned)co);
   };
   epi_operands(gw.mt);
   DK_STAMP(sy, 12);
@@ -641,7 +686,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const int total = gw.total;
   int cbase[4];
   {
-    const int stride = rfl(P->h.stride);
+    const int stride = HI(stride);
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
       const int n = nf * 16 + li;
@@ -730,13 +775,13 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     }
     s = lane_set_sum(s, lS);
     q = lane_set_sum(q, lS);
-    const float inv_count = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.inv_count)));
-    const float gn_eps = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, P->h.gn_eps)));
+    const float inv_count = HF(inv_count);
+    const float gn_eps = HF(gn_eps);
     const float mean = s * inv_count;
     float var = q * inv_count - mean * mean;
     var = var < 0.f ? 0.f : var;
     const float rstd = PRECISE ? 1.0f / sqrtf(var + gn_eps) : rsqrtf(var + gn_eps);
-    const bool silu = rfl(P->h.pro_mode) == JEN1_PRO_GN_SILU;
+    const bool silu = HI(pro_mode) == JEN1_PRO_GN_SILU;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
 #pragma unroll
@@ -756,7 +801,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 
   // ---- per M tile of the unit: K loop, K reduction across the waves, epilogue.  The first tile is the straight path; further
   // tiles (mrep > 1: phases with more M tiles x batch groups than workgroups) reuse the staged tile -----------------------------
-  const int red_floats = rfl(P->h.red_bytes) >> 2;
+  const int red_floats = HI(red_bytes) >> 2;
   // K loop: rounds of the PF ring slots; a slot is refilled behind its use when the wave has more chunks
   auto k_loop = [&](f32x4 (&acc)[4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -819,7 +864,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       }
     }
     v[0] = o[0].x + bias4[0]; v[1] = o[0].y + bias4[1]; v[2] = o[0].z + bias4[2]; v[3] = o[0].w + bias4[3];
-    if (rfl(P->h.act) == JEN1_ACT_GELU && !low_m) {
+    if (HI(act) == JEN1_ACT_GELU && !low_m) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
@@ -830,9 +875,9 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 #endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += rres[r];
-      const size_t off = (size_t)((unsigned)yrow * (unsigned)rfl(P->h.ld_y)) + (unsigned)co;
-      if (rfl(P->h.y_f32)) st_live4(reinterpret_cast<float*>(P->h.y) + off, v);
-      else st_live4(reinterpret_cast<T*>(P->h.y) + off, v);
+      const size_t off = (size_t)((unsigned)yrow * (unsigned)HI(ld_y)) + (unsigned)co;
+      if (HI(y_f32)) st_live4(HP(y, float*) + off, v);
+      else st_live4(HP(y, T*) + off, v);
     }
   };
   {
