@@ -385,6 +385,34 @@ __device__ __forceinline__ jen1_deep_src hot_src(const HotRegs& hr) {
   return s;
 }
 
+// the same for any field of the phase (attention / statistics units): four registers cover the 1 KiB descriptor
+struct PhaseRegs {
+  unsigned w[4];
+};
+static_assert(sizeof(jen1_deep_phase) <= 1024, "the descriptor must fit four dwords per lane");
+__device__ __forceinline__ PhaseRegs phase_regs(const unsigned char* D, int lane) {
+  const unsigned* w = reinterpret_cast<const unsigned*>(D);
+  PhaseRegs r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.w[k] = w[64 * k + lane];
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ int ph_i32(const PhaseRegs& r) {
+  static_assert(OFF % 4 == 0 && OFF >= 0 && OFF < 1024, "field offset");
+  return __builtin_amdgcn_readlane((int)r.w[OFF / 256], (OFF / 4) & 63);
+}
+template <int OFF>
+__device__ __forceinline__ float ph_f32(const PhaseRegs& r) { return __builtin_bit_cast(float, ph_i32<OFF>(r)); }
+template <int OFF, typename PT>
+__device__ __forceinline__ PT ph_ptr(const PhaseRegs& r) {
+  const u64 v = (u64)(unsigned)ph_i32<OFF>(r) | ((u64)(unsigned)ph_i32<OFF + 4>(r) << 32);
+  return reinterpret_cast<PT>(v);
+}
+#define AI(f) ph_i32<offsetof(jen1_deep_phase, f)>(pr)
+#define AF(f) ph_f32<offsetof(jen1_deep_phase, f)>(pr)
+#define AP(f, type) ph_ptr<offsetof(jen1_deep_phase, f), type>(pr)
+
 struct KRun {                // one run of a wave's K chunks: chunk j is flat chunk g0 + j * NW at staged column col0 + j * NW * 32
   int g0, n, col0, shift;
 };
@@ -930,10 +958,11 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   const int wave = rfl(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   DK_STAMP(sy, 0);
-  const int H = P->H, d = P->d, Nq = P->Nq, Nk = P->Nk, nqc = P->nqc;
-  const int bh = (int)(((float)u + 0.5f) * P->inv_nqc);
+  const PhaseRegs pr = phase_regs(D, lane);
+  const int H = AI(H), d = AI(d), Nq = AI(Nq), Nk = AI(Nk), nqc = AI(nqc);
+  const int bh = (int)(((float)u + 0.5f) * AF(inv_nqc));
   const int qc = u - bh * nqc;
-  const int b = (int)(((float)bh + 0.5f) * P->inv_H), h = bh - b * H;
+  const int b = (int)(((float)bh + 0.5f) * AF(inv_H)), h = bh - b * H;
   const int q0 = qc * QCHUNK;
   const int nq = (Nq - q0 < QCHUNK) ? (Nq - q0) : QCHUNK;
   const int NKP = (Nk + 31) & ~31;
@@ -947,29 +976,29 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   T* p_s = reinterpret_cast<T*>(s_s + ((QCHUNK * sp + 3) & ~3));      // [32][vt]
   float2* st_s = reinterpret_cast<float2*>(p_s + ((QCHUNK * vt + 7) & ~7));   // [max(Nk, 32)] LayerNorm (mean, rstd) per row
 
-  const int ldq = P->ldq, ldkv = P->ldkv, log2_vpr = P->log2_vpr, ldo = P->ldo, ln_C = P->ln_C;
+  const int ldq = AI(ldq), ldkv = AI(ldkv), log2_vpr = AI(log2_vpr), ldo = AI(ldo), ln_C = AI(ln_C);
   const int vpr = 1 << log2_vpr;
   const int nkv = Nk * vpr, nqv = nq * vpr;
   const int hd = h * d;
-  const T* qp = reinterpret_cast<const T*>(P->q);
-  const T* kp_ = reinterpret_cast<const T*>(P->k);
-  const T* vp_ = reinterpret_cast<const T*>(P->v);
-  const T* xp_ = reinterpret_cast<const T*>(P->kv_extra);
-  T* const outp = reinterpret_cast<T*>(P->out);
-  const int fin_q = P->fin_q, fin_kv = P->fin_kv, kv_live = P->kv_live, causal = P->causal;
-  const float scale = P->scale, ln_eps = P->ln_eps;
-  const int q_off = P->q_off;
+  const T* qp = reinterpret_cast<const T*>(AP(q, const void*));
+  const T* kp_ = reinterpret_cast<const T*>(AP(k, const void*));
+  const T* vp_ = reinterpret_cast<const T*>(AP(v, const void*));
+  const T* xp_ = reinterpret_cast<const T*>(AP(kv_extra, const void*));
+  T* const outp = reinterpret_cast<T*>(AP(out, void*));
+  const int fin_q = AI(fin_q), fin_kv = AI(fin_kv), kv_live = AI(kv_live), causal = AI(causal);
+  const float scale = AF(scale), ln_eps = AF(ln_eps);
+  const int q_off = AI(q_off);
 
   // ---- operands that do not depend on other workgroups: cached text K/V, the finish vectors u / b ----------------------
-  const int kvbase = (P->kv_row ? P->kv_row[b] : b) * Nk;
-  int xr = (P->kv_extra && P->extra_row) ? P->extra_row[b] : -1;
-  if (xr >= 0 && P->extra_step) xr = P->extra_step[0];
+  const int kvbase = (AP(kv_row, const int32_t*) ? AP(kv_row, const int32_t*)[b] : b) * Nk;
+  int xr = (AP(kv_extra, const void*) && AP(extra_row, const int32_t*)) ? AP(extra_row, const int32_t*)[b] : -1;
+  if (xr >= 0 && AP(extra_step, const int32_t*)) xr = AP(extra_step, const int32_t*)[0];
   Raw8<T> kraw[MAXVA], vraw[MAXVA], qraw;
   const T* kadr[MAXVA];
   const T* vadr[MAXVA];
   bool kvok[MAXVA];
   {
-    const int ld_extra = P->ld_extra, kx_off = P->kx_off, vx_off = P->vx_off, k_off = P->k_off, v_off = P->v_off;
+    const int ld_extra = AI(ld_extra), kx_off = AI(kx_off), vx_off = AI(vx_off), k_off = AI(k_off), v_off = AI(v_off);
 #pragma unroll
     for (int i = 0; i < MAXVA; ++i) {
       const int idx = tid + i * NT;
@@ -989,14 +1018,14 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   float uk[8], bk[8], uv[8], bv[8], uq[8], bq[8];
   const int kr0 = tid >> log2_vpr, kc0 = (tid & (vpr - 1)) * 8;            // vector 0 of this thread (the only one with a K/V finish)
   if (fin_kv && tid < nkv) {
-    load8(P->ln_u + P->k_off + hd + kc0, uk);
-    load8(P->ln_b + P->k_off + hd + kc0, bk);
-    load8(P->ln_u + P->v_off + hd + kc0, uv);
-    load8(P->ln_b + P->v_off + hd + kc0, bv);
+    load8(AP(ln_u, const float*) + AI(k_off) + hd + kc0, uk);
+    load8(AP(ln_b, const float*) + AI(k_off) + hd + kc0, bk);
+    load8(AP(ln_u, const float*) + AI(v_off) + hd + kc0, uv);
+    load8(AP(ln_b, const float*) + AI(v_off) + hd + kc0, bv);
   }
   if (fin_q && tid < nqv) {
-    load8(P->ln_u + q_off + hd + kc0, uq);
-    load8(P->ln_b + q_off + hd + kc0, bq);
+    load8(AP(ln_u, const float*) + q_off + hd + kc0, uq);
+    load8(AP(ln_b, const float*) + q_off + hd + kc0, bq);
   }
 
   DK_STAMP(sy, 1);
