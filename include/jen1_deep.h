@@ -81,7 +81,7 @@ typedef struct jen1_deep_hot {
   int32_t dep_units;          /* its n_units                                             (jen1_deep_link) */
   int32_t lds_bytes;          /* dynamic LDS a unit of this phase needs */
   int32_t dtype;
-  int32_t reserved0;
+  int32_t ntrips;             /* GEMM: trips of JEN1_DEEP_MAXV vectors per lane that stage the normalised part (1 for short rows) */
   /* ---- GEMM ---- */
   const void* w;              /* flat packed weight [chunk][M/16][64 lanes][8] */
   const float* bias;          /* [out_C] or NULL */

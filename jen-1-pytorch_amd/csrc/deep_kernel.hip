@@ -801,6 +801,29 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       s += a0 + a1;
       q += c0 + c1;
     }
+    // long rows (more than MAXV vectors per lane: e.g. 36 positions x 512 channels of one batch element): the further trips are
+    // summed here and read again below for the normalisation (their second read is an L2 hit)
+    const int ntrips = HI(ntrips);
+    for (int trip = 1; trip < ntrips; ++trip) {
+      Raw8<T> xt[MAXV];
+      float mt_[MAXV];
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int t = nt0 + (trip * MAXV + i) * ntstep;
+        const bool ok = npair_ok && t < L_in;
+        mt_[i] = ok ? nscale : 0.f;
+        ld_live(xt[i], nbase + (size_t)((unsigned)(ok ? t : 0) * (unsigned)nld));
+      }
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        float x[8];
+        raw_to_float(xt[i], x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] *= mt_[i];
+        s += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+        q += ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
+      }
+    }
     s = lane_set_sum(s, lS);
     q = lane_set_sum(q, lS);
     const float inv_count = HF(inv_count);
@@ -819,6 +842,31 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
         for (int j = 0; j < 8; ++j) xf[i][j] = PRECISE ? silu_precise(xf[i][j]) : silu_f(xf[i][j]);
       }
       store8(tile + ntile[i], xf[i]);
+    }
+    for (int trip = 1; trip < ntrips; ++trip) {
+      Raw8<T> xt[MAXV];
+      int tt[MAXV];
+      float mt_[MAXV];
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int t = nt0 + (trip * MAXV + i) * ntstep;
+        const bool ok = npair_ok && t < L_in;
+        mt_[i] = ok ? nscale : 0.f;
+        tt[i] = ok ? (nbl * Lp + Hb + t) * pitch + cn : dummy_tile;
+        ld_live(xt[i], nbase + (size_t)((unsigned)(ok ? t : 0) * (unsigned)nld));
+      }
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        float x[8];
+        raw_to_float(xt[i], x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (x[j] * mt_[i] - mean) * rstd * p1[j] + p2[j];
+        if (silu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
+        }
+        store8(tile + tt[i], x);
+      }
     }
   }
 #else
@@ -1398,6 +1446,7 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int align16i(int x) { return (x + 15) & ~15; }
 constexpr int LDS_TOTAL = 160 * 1024;
+constexpr int MAX_TRIPS = 4;                        // staging trips of the normalised part of a unit (long rows)
 constexpr int LDS_BUDGET = LDS_TOTAL - WS_OFF;      // what a unit may use behind the headers and the two descriptor slots
 
 }  // namespace
@@ -1525,16 +1574,20 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   }
   p.h.lvpg = lvpg; p.h.lgroups = lgroups;
   // ---- unit geometry: as many batch elements per unit as fit (a power of two; fewer, fatter units re-read the weights less) -----------
-  int nb = 1;
-  while (nb * 2 <= a->B) nb *= 2;
-  if (nb_max > 0) while (nb > nb_max) nb /= 2;
-  if (p.h.p_ld && !p.h.film_step) nb = 1;      // a per-element FiLM table: one table row per unit
+  int nb0 = 1;
+  while (nb0 * 2 <= a->B) nb0 *= 2;
+  if (nb_max > 0) while (nb0 > nb_max) nb0 /= 2;
+  if (p.h.p_ld && !p.h.film_step) nb0 = 1;     // a per-element FiLM table: one table row per unit
+  // staging in ONE trip is preferred (a further trip is a further memory round trip); several trips only when not even one batch
+  // element fits otherwise (long rows: e.g. 36 positions x 512 channels)
+  int max_trips = 1, nb = nb0;
   for (;; nb /= 2) {
+    if (nb < 1 && max_trips == 1) { max_trips = MAX_TRIPS; nb = nb0; }
     JEN1_CHECK(nb >= 1, "deep conv: one batch element (%d rows x %d channels) does not fit a unit", a->L_in, coff);
     const int cols = nb * a->L_out;
     const int NF = ceil_div(cols, 16);
     if (NF > 4) continue;
-    int lS = 6;
+    int lS = 6, ntrips = 1;
     if (p.h.norm_C) {
       const int pairs = nb * a->gn_groups;
       if (pairs > JEN1_DEEP_THREADS / 2) continue;                       // at least 2 lanes per pair
@@ -1543,7 +1596,8 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
       lS = 0;
       while ((1 << lS) < S) ++lS;
       if ((1 << lvpg) > S) continue;                                      // a lane owns a column
-      if (ceil_div(a->L_in << lvpg, S) > maxv) continue;                  // vectors per lane
+      if (ceil_div(a->L_in << lvpg, S) > maxv * max_trips) continue;      // vectors per lane (in trips of maxv)
+      ntrips = ceil_div(ceil_div(a->L_in << lvpg, S), maxv);
     }
     const int Rtot = nb * p.h.Lp + (p.h.Hb + Ha + 1);
     const int tile_b = align16i(Rtot * p.h.pitch * es);
@@ -1551,6 +1605,7 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
     red_b = red_b > JEN1_DEEP_THREADS * 8 * es ? red_b : JEN1_DEEP_THREADS * 8 * es;
     const int tot = tile_b + red_b;
     if (tot > LDS_BUDGET) continue;
+    p.h.ntrips = ntrips;
     p.h.nb = nb; p.h.NF = NF; p.h.R = nb * a->L_in; p.h.Rtot = Rtot; p.h.zrow = nb * p.h.Lp + p.h.Hb; p.h.lS = lS;
     p.h.red_off = tile_b;
     p.h.red_bytes = red_b;
