@@ -1699,7 +1699,9 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
       // more units than workgroups: a unit finishes several M tiles from one staged tile instead of the workgroup staging the
       // same rows once per tile (second K-reduction scratch behind the first)
       int mrep = 1;
-      while (mrep < 8 && (P.h.MT / mrep) * P.h.groups_n > nwg && P.h.MT % (2 * mrep) == 0 && P.h.mt_split % (2 * mrep) == 0) mrep *= 2;
+      const char* cap_s = getenv("JEN1_DEEP_UNIT_CAP");          // tuning: at most this many units per phase (default: one per workgroup)
+      const int cap = cap_s ? atoi(cap_s) : nwg;
+      while (mrep < 8 && (P.h.MT / mrep) * P.h.groups_n > cap && P.h.MT % (2 * mrep) == 0 && P.h.mt_split % (2 * mrep) == 0) mrep *= 2;
       if (mrep > 1 && P.h.lds_bytes + P.h.red_bytes <= LDS_BUDGET) {
         P.h.mrep = mrep;
         P.h.n_units = (P.h.MT / mrep) * P.h.groups_n;
