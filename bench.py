@@ -614,6 +614,16 @@ def main():
                     n5 = max(10, args.steps // 5)
                     dt5 = timed_steps(st5, n5, 3, lambda: None)
                     out["extra"]["configs[4] long-form B=1 T=9000 CFG pair, steps/s"] = round(n5 / dt5, 2)
+                    # per-kernel figures of that plan: the tiled conv launches of its long levels (T' = 9000 ... 71) and its
+                    # persistent launch (levels 5..8)
+                    r5 = conv_roofline(st5)
+                    d5 = deep_roofline(st5, args.dtype)
+                    out["extra"]["configs[4] kernels"] = {
+                        "launches_per_step": st5.plan.n_launch + 1,
+                        "long_levels": {k: r5[k] for k in ("launches_per_step", "avg_launch_us", "conv_ms_per_step", "alg_bytes_per_step", "achieved",
+                                                           "frac", "executed_gflop_per_step", "slowest_launches_us")},
+                        "deep_kernel": None if d5 is None else {k: d5[k] for k in ("phases", "avg_launch_us", "us_per_phase", "alg_bytes_per_launch",
+                                                                                   "achieved", "frac")}}
                     del st5
                     out["extra"]["concurrent_batches"] = [concurrent_batches_bench(model, B, T, device, n, max(20, args.steps // 2), 5)
                                                           for n in (2, 4)]

@@ -384,15 +384,13 @@ extern "C" int jen1_attention_fin(const void* q, const void* k, const void* v, v
   while ((8 << log2_vpr) < d) ++log2_vpr;
   if (dtype == JEN1_F32) {
     auto kern = attention_kernel<float>;
-    static bool set = false;
-    if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out,
                        kv_row, (const float*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale,
                        ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv, inv_H, log2_vpr);
   } else {
     auto kern = attention_kernel<bf16_t>;
-    static bool set = false;
-    if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (bf16_t*)out, kv_row, (const bf16_t*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale,
                        ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv, inv_H, log2_vpr);

@@ -34,6 +34,20 @@ int jen1_tile_gemm_launch(const jen1_conv_args& a, void* stream);
     if (e_ != hipSuccess) return jen1_set_error("%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set once per (kernel, device ordinal).  ``mask``
+// is a function-local static of the caller (one bit per device, ordinals >= 64 set it every time); launches are issued from one
+// host thread per process in this library, so the mask needs no lock.
+#define JEN1_MAX_LDS_ONCE(kern, bytes)                                                                      \
+  do {                                                                                                      \
+    static unsigned long long lds_mask_ = 0ull;                                                             \
+    int dev_ = 0;                                                                                           \
+    JEN1_HIP(hipGetDevice(&dev_));                                                                          \
+    if (dev_ >= 64 || !((lds_mask_ >> dev_) & 1ull)) {                                                      \
+      JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+      if (dev_ < 64) lds_mask_ |= 1ull << dev_;                                                             \
+    }                                                                                                       \
+  } while (0)
+
 // ---- 8-element fragments -------------------------------------------------------------------
 struct f32x8 {
   float v[8];

@@ -751,11 +751,7 @@ int launch(const jen1_conv_args& a, hipStream_t s) {
   constexpr int BM = 16 * MF * WM;
   const Layout L = make_layout(a, (int)sizeof(T), red_floats<MF, NF, WM, WK>());
   auto kern = conv_gemm_kernel<T, MF, NF, WM, WK, PF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
   const int tiles_t = (a.L_out + a.tb - 1) / a.tb;
   const int tiles_b = (a.B + a.nb - 1) / a.nb;
   dim3 grid((a.M + BM - 1) / BM, tiles_t * tiles_b, a.splitk);

@@ -448,13 +448,11 @@ static int launch_cfg(const void* net, const float* x, const float* noise, const
   const size_t lds = sizeof(float) * (size_t)C * 33;
   if (dtype == JEN1_F32) {
     auto kern = cfg_step_kernel<float, DDIM>;
-    static bool set = false;
-    if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
   } else if (dtype == JEN1_BF16) {
     auto kern = cfg_step_kernel<bf16_t, DDIM>;
-    static bool set = false;
-    if (!set) { JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
   } else {
     return jen1_set_error("cfg step: bad dtype");

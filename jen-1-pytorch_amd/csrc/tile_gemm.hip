@@ -488,11 +488,7 @@ int launch_tile_x(const TileArgs& ta, int rows_in, hipStream_t s) {
   const size_t lds = tile_bytes + (size_t)(2 * ctot + 2 * (64 * MF / 2 + 2)) * sizeof(float);
   JEN1_CHECK(lds <= 160 * 1024, "conv_gemm: tile kernel LDS request %zu B exceeds 160 KiB", lds);
   auto kern = tile_gemm_kernel<T, MF, NF, PF, XS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    JEN1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
   dim3 grid((ta.hot.MT * 16 + 64 * MF - 1) / (64 * MF), ta.hot.tiles_t * ta.hot.B);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, ta);
   JEN1_HIP(hipGetLastError());
