@@ -285,8 +285,9 @@ class GaussianDiffusion(torch.nn.Module):
         assert noise.shape == x_start.shape
         return extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start + extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise
 
-    def training_loosses(self, model, x_start, t, conditioning, noise=None, causal=False, dropout_rows=None):
-        """gdm.py:245-272: mean over (C, T), then over the batch."""
+    def training_loosses(self, model, x_start, t, conditioning, noise=None, causal=False, dropout_rows=None, reduction: str = "mean"):
+        """gdm.py:245-272: mean over (C, T), then over the batch.  ``reduction="none"`` returns the per-sample means [B] instead (the
+        trainer merges task sub-batches that share the causal flag into one pass and weights the samples itself)."""
         if noise is None:
             noise = torch.rand_like(x_start)
         x_t = self.q_sample(x_start, t, noise=noise)
@@ -302,7 +303,8 @@ class GaussianDiffusion(torch.nn.Module):
         else:
             raise ValueError(f"unknown objective {self.objective}")
         loss = self.loss_fn(model_out, target, reduction="none")
-        return loss.reshape(loss.shape[0], -1).mean(dim=1).mean()
+        per_sample = loss.reshape(loss.shape[0], -1).mean(dim=1)
+        return per_sample if reduction == "none" else per_sample.mean()
 
 
 class DDIMStepper:

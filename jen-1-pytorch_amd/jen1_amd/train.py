@@ -804,15 +804,22 @@ class GraphedLossStep:
     def _body(self, static, causal):
         cond = {"cross_attn_cond": static["emb"], "cross_attn_masks": static["mask"], "global_cond": None,
                 "input_concat_cond": static["concat"]}
-        loss = self.diffusion.training_loosses(self.graph, static["x0"], static["t"], cond, causal=causal)
-        (loss * self.scale).backward()
-        return loss.detach()
+        if static["w"] is None:
+            loss = self.diffusion.training_loosses(self.graph, static["x0"], static["t"], cond, causal=causal)
+            (loss * self.scale).backward()
+            return loss.detach()
+        # merged task sub-batches: the objective is sum_i w_i * loss_i (w_i = 1 / size of the sample's own sub-batch, i.e. the
+        # sum of the per-task means of trainer.py:205-211); the per-sample losses come back for the per-task report
+        per_sample = self.diffusion.training_loosses(self.graph, static["x0"], static["t"], cond, causal=causal, reduction="none")
+        ((per_sample * static["w"]).sum() * self.scale).backward()
+        return per_sample.detach()
 
-    def _capture(self, key, x0, t, conditioning, causal):
+    def _capture(self, key, x0, t, conditioning, causal, weights=None):
         params = list(self.graph.p.values())
         static = {"x0": x0.clone(), "t": t.clone(), "emb": conditioning["cross_attn_cond"].clone(),
                   "mask": None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"].clone(),
-                  "concat": None if conditioning["input_concat_cond"] is None else conditioning["input_concat_cond"].clone()}
+                  "concat": None if conditioning["input_concat_cond"] is None else conditioning["input_concat_cond"].clone(),
+                  "w": None if weights is None else weights.to(torch.float32).clone()}
         keep = [None if p.grad is None else p.grad.clone() for p in params]       # the warm-up run must not leak into the gradients
         side = torch.cuda.Stream(self.graph.rt.device)
         side.wait_stream(torch.cuda.current_stream(self.graph.rt.device))
@@ -832,14 +839,20 @@ class GraphedLossStep:
         self._captured[key] = (g, static, loss)
         return self._captured[key]
 
-    def __call__(self, x0: torch.Tensor, t: torch.Tensor, conditioning: Dict[str, Optional[torch.Tensor]], causal: bool) -> torch.Tensor:
+    def __call__(self, x0: torch.Tensor, t: torch.Tensor, conditioning: Dict[str, Optional[torch.Tensor]], causal: bool,
+                 sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """replay (capture on first use) forward + backward of one pass; returns the loss, or with ``sample_weights`` [B] the
+        per-sample losses [B] of the pass whose objective is their weighted sum"""
         assert conditioning.get("global_cond") is None
-        key = (tuple(x0.shape), bool(causal), conditioning["cross_attn_masks"] is None, conditioning["input_concat_cond"] is None)
+        key = (tuple(x0.shape), bool(causal), conditioning["cross_attn_masks"] is None, conditioning["input_concat_cond"] is None,
+               sample_weights is None)
         hit = self._captured.get(key)
         first = hit is None
         if first:
-            hit = self._capture(key, x0, t, conditioning, bool(causal))
+            hit = self._capture(key, x0, t, conditioning, bool(causal), sample_weights)
         g, static, loss = hit
+        if sample_weights is not None:
+            static["w"].copy_(sample_weights)
         static["x0"].copy_(x0)
         static["t"].copy_(t)
         static["emb"].copy_(conditioning["cross_attn_cond"])

@@ -34,7 +34,7 @@ class UnifiedMultiTaskTrainer:
                  grad_accum_every: int = 10, tasks: Sequence[str] = TASKS, device="cuda", process_group=None,
                  rng=_random, cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
                  input_concat_ids: Sequence[str] = ("masked_input", "mask"), compute_dtype: Optional[str] = None,
-                 use_graph: bool = True, allow_uneven_tasks: bool = False, bucket_bytes: int = 128 << 20):
+                 use_graph: bool = True, allow_uneven_tasks: bool = False, bucket_bytes: int = 128 << 20, merge_tasks: bool = True):
         self.model, self.diffusion, self.conditioner, self.optimizer, self.lr_scheduler = model, diffusion, conditioner, optimizer, lr_scheduler
         self.grad_accum_every, self.tasks, self.device, self.group, self.rng = grad_accum_every, tuple(tasks), device, process_group, rng
         self.cross_attn_cond_ids, self.global_cond_ids, self.input_concat_ids = cross_attn_cond_ids, global_cond_ids, input_concat_ids
@@ -46,6 +46,9 @@ class UnifiedMultiTaskTrainer:
         self.grad_accum = 0
         self.global_step = 0
         self.allow_uneven_tasks = allow_uneven_tasks
+        # task sub-batches that drew the same ``causal`` flag run as ONE pass through the network (same loss: the sum of the
+        # per-task means, each sample weighted 1 / its sub-batch size); False = the reference's literal one pass per task
+        self.merge_tasks = merge_tasks
         # DDP's gradient exchange (train.py:88-89): buckets in reverse execution order; in eager mode each bucket leaves as soon
         # as the backward pass has finished it, behind a replayed graph the buckets leave together right after the replay
         names = [n for n, _ in model.named_parameters()]
@@ -72,6 +75,7 @@ class UnifiedMultiTaskTrainer:
         # tasks take one clip more (8 -> 3 / 3 / 2), task order as in config.py:93
         sizes = [batch_size // nt + (1 if i < batch_size % nt else 0) for i in range(nt)]
         start = 0
+        parts = []                      # per task: what one pass of the reference's loop prepares (trainer.py:190-203)
         for i, task in enumerate(self.tasks):
             sub = sizes[i]
             if sub == 0:
@@ -86,14 +90,44 @@ class UnifiedMultiTaskTrainer:
             conditioning["mask"] = mask
             conditioning = self.get_conditioning(conditioning)
             t = torch.randint(0, self.diffusion.num_timesteps, (sub,), device=self.device).long()
+            parts.append((task, sub_audio_emb, t, conditioning, bool(causal)))
+        first = True
+        if not self.merge_tasks:
+            for task, x, t, conditioning, causal in parts:
+                if self.graphed is not None:
+                    if self.grad_accum == 0 and first:
+                        self.optimizer.zero_grad()             # the captured step already contains the backward
+                    loss = self.graphed(x, t, conditioning, causal)
+                else:
+                    loss = self.diffusion.training_loosses(self.graph, x, t, conditioning, causal=causal)
+                first = False
+                loss_dict[task] = loss.detach()
+                all_loss = all_loss + loss
+            return all_loss, loss_dict
+        for flag in (False, True):
+            group = [p for p in parts if p[4] == flag]
+            if not group:
+                continue
+            cat = lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)        # noqa: E731
+            x = cat([p[1] for p in group])
+            t = cat([p[2] for p in group])
+            keys = group[0][3].keys()
+            conditioning = {k: (None if group[0][3][k] is None else cat([p[3][k] for p in group])) for k in keys}
+            w = torch.cat([torch.full((p[1].shape[0],), 1.0 / p[1].shape[0], device=self.device) for p in group])
             if self.graphed is not None:
-                if self.grad_accum == 0 and i == 0:
-                    self.optimizer.zero_grad()                 # the captured step already contains the backward
-                loss = self.graphed(sub_audio_emb, t, conditioning, causal)
+                if self.grad_accum == 0 and first:
+                    self.optimizer.zero_grad()
+                per_sample = self.graphed(x, t, conditioning, flag, sample_weights=w)
+                group_loss = (per_sample * w).sum()
             else:
-                loss = self.diffusion.training_loosses(self.graph, sub_audio_emb, t, conditioning, causal=causal)
-            loss_dict[task] = loss.detach()
-            all_loss = all_loss + loss
+                per_sample = self.diffusion.training_loosses(self.graph, x, t, conditioning, causal=flag, reduction="none")
+                group_loss = (per_sample * w).sum()
+            first = False
+            all_loss = all_loss + group_loss
+            o = 0
+            for task, xs, *_ in group:
+                loss_dict[task] = per_sample[o:o + xs.shape[0]].detach().mean()
+                o += xs.shape[0]
         return all_loss, loss_dict
 
     def train_step(self, audio_emb: torch.Tensor, metadata) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], bool]:

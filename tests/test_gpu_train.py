@@ -687,3 +687,43 @@ def test_inference_engine_follows_optimizer_steps():
     fresh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
     y2 = fresh(x, t, **kw)
     assert float((y1 - y2).abs().max()) <= 1e-5 * float(y2.abs().max())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_merged_task_passes_equal_one_pass_per_task(use_graph, monkeypatch):
+    """UnifiedMultiTaskTrainer(merge_tasks=True): sub-batches that drew the same causal flag share one pass through the network
+    with per-sample weights 1 / sub-batch size -- the same objective as the reference's one pass per task (trainer.py:189-211: the
+    sum of the three per-task means), so the same per-task losses and the same gradients; 8 clips split 3 / 3 / 2"""
+    import random
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    from jen1_amd.trainer import UnifiedMultiTaskTrainer
+    # the diffusion noise as a function of the clip itself, so that a sample gets the same noise however it is batched
+    monkeypatch.setattr(torch, "rand_like", lambda x, **kw: torch.sin(x * 997.0) * 0.5 + 0.5)
+    B, T = 8, 300
+    emb = dev(synth.conditioning(B, T, "text_guided")["cross_attn_cond"])
+    msk = dev(synth.conditioning(B, T, "text_guided")["cross_attn_masks"])
+    audio = dev(synth.latents(B, T, key="clip"))
+    betas, _ = get_beta_schedule("linear", 1000)
+    res = {}
+    for merge in (False, True):
+        model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                               embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        tr = UnifiedMultiTaskTrainer(model, gd, lambda md, device: {"prompt": (emb[torch.tensor(md, device=device)], msk[torch.tensor(md, device=device)])},
+                                     opt, None, grad_accum_every=2, rng=random.Random(5), use_graph=use_graph, allow_uneven_tasks=True,
+                                     merge_tasks=merge)
+        torch.manual_seed(11)
+        loss, per_task, stepped = tr.train_step(audio, list(range(B)))
+        torch.cuda.synchronize()
+        assert not stepped
+        res[merge] = (float(loss), {k: float(v) for k, v in per_task.items()}, opt.flat_grad.clone())
+    l0, p0, g0 = res[False]
+    l1, p1, g1 = res[True]
+    assert set(p0) == set(p1) == {"text_guided", "music_inpaint", "music_cont"}
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    for k in p0:
+        assert abs(p0[k] - p1[k]) <= 1e-5 * abs(p0[k]), k
+    assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
