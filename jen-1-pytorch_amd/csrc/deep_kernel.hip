@@ -1200,6 +1200,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
     }
   }
   __syncthreads();
+  DK_STAMP(sy, 10);
   // ---- V replaces K in LDS, transposed: V^T [d][keys] is the B operand of P V ---------------------------------------------------
   if (d < 16) {
     for (int i = tid; i < DC * vt; i += NT) kv_s[i] = (T)0.f;
@@ -1225,6 +1226,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
       for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + rs] = (T)x[e];
     }
   }
+  DK_STAMP(sy, 11);
   // ---- softmax in float32 (blocks.py:367-371): 16 lanes per row, 32 rows per pass over the 8 waves ---------------------------------
   {
     const int rsel = lane >> 4;
@@ -1268,6 +1270,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
     }
   }
   __syncthreads();
+  DK_STAMP(sy, 12);
   // ---- out = P V on the matrix cores; the tile goes through LDS (Q's place) so that it leaves as 16-byte write-through stores ----
   {
     const int nqt = (nq + 15) >> 4;

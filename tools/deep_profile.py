@@ -105,3 +105,17 @@ for p in range(n):
     st = d[p, m]
     vals = [np.mean(st[:, b] - st[:, a]) for a, b in zip(order[:-1], order[1:])]
     print(f"{p:3d} " + " ".join(f"{v:5.2f}" for v in vals) + "  " + prog.labels[p][:70])
+
+# attention units: 2->3 operands -> LDS (+ LayerNorm statistics), 3->10 scores (+ barrier), 10->11 V^T into LDS, 11->12 softmax (+ barrier),
+# 12->4 P V (+ barrier), 4->5 store + drain
+order = [2, 3, 10, 11, 12, 4, 5]
+print("# attention: " + " ".join(f"{a}>{b}" for a, b in zip(order[:-1], order[1:])))
+for p in range(n):
+    if not prog.labels[p].startswith("attention"):
+        continue
+    m = (d[p, :, 0] > 0) & (d[p, :, 10] > 0)
+    if not m.any():
+        continue
+    st = d[p, m]
+    vals = [np.mean(st[:, b] - st[:, a]) for a, b in zip(order[:-1], order[1:])]
+    print(f"{p:3d} " + " ".join(f"{v:5.2f}" for v in vals) + "  " + prog.labels[p][:70])
