@@ -206,6 +206,9 @@ __device__ __forceinline__ float row16_max_d(float v) {
   return v;
 }
 
+#ifndef JEN1_DEEP_POLL_SLEEP
+#define JEN1_DEEP_POLL_SLEEP 8       // (0 / 1 / 3 / 8 / 20: 1136 / 1125 / 1119 / 1114 / 1126 us per launch) measured: several polls in flight per workgroup (LDS-DMA polls, 2 / 3 / 4 deep) slow the launch by
+#endif                               // 4 / 9 / 12 % -- 256 pollers on the counter lines are in the producers' way; see DESIGN.md 4a
 template <typename T> struct DeepCfg;
 #ifndef JEN1_DEEP_MAXV_B
 #define JEN1_DEEP_MAXV_B 3        // 8-channel vectors per thread of the normalised part and of the raw part of a staged tile (bf16)
@@ -304,7 +307,9 @@ __device__ __forceinline__ void wait_phase(Sync& sy, int dep, int dep_units, int
         sy.dead = true;
         break;
       }
-      __builtin_amdgcn_s_sleep(1);
+#if JEN1_DEEP_POLL_SLEEP > 0
+      __builtin_amdgcn_s_sleep(JEN1_DEEP_POLL_SLEEP);     // (units of 64 clocks) between polls
+#endif
     }
   }
   __syncthreads();
