@@ -52,8 +52,12 @@ extern "C" {
 #endif
 #define JEN1_DEEP_BLOB_BYTES 4096   /* device image of one phase: descriptor + per-wave K-chunk lists */
 #define JEN1_DEEP_MAX_PHASES 256
-#define JEN1_DEEP_SHARDS 8          /* arrival counters per phase */
-#define JEN1_DEEP_SHARD_WORDS 64    /* uint32 words between two shard counters (256 B apart) */
+#ifndef JEN1_DEEP_SHARDS
+#define JEN1_DEEP_SHARDS 32         /* arrival counters per phase (<= 63: one wave polls them; 8 / 16 / 32 / 48: 1113 / 1070 / 1039 / 1037 us) */
+#endif
+#ifndef JEN1_DEEP_SHARD_WORDS
+#define JEN1_DEEP_SHARD_WORDS 32    /* uint32 words between two shard counters (128 B apart: one line each; 64 B apart is slower) */
+#endif
 
 /* one source tensor of a GEMM phase: channels [coff, coff + C) of the staged tile */
 typedef struct jen1_deep_src {

@@ -34,6 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = JEN1_DEEP_THREADS;
 constexpr int NW = NT / 64;
 constexpr int SHARDS = JEN1_DEEP_SHARDS;
+static_assert(SHARDS >= 1 && SHARDS <= 63, "one wave polls the shards and the error word");
 constexpr int SHW = JEN1_DEEP_SHARD_WORDS;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int RSRC_FLAGS = 0x00020000;
@@ -297,7 +298,9 @@ __device__ __forceinline__ void wait_phase(Sync& sy, int dep, int dep_units, int
       unsigned v = 0, ev = 0;
       if (tid < SHARDS) v = __hip_atomic_load(c, RLX_AGENT);
       if (tid == SHARDS) ev = __hip_atomic_load(e, RLX_AGENT);
-      const float tot = row16_sum_d((float)v);          // counts are small integers: exact in float
+      float tot = row16_sum_d((float)v);                // counts are small integers: exact in float
+      if (SHARDS > 16) tot += __shfl_xor(tot, 16);      // (lanes beyond the shards hold 0)
+      if (SHARDS > 32) tot += __shfl_xor(tot, 32);
       const int total = __builtin_amdgcn_readfirstlane((int)tot);
       const int errv = __builtin_amdgcn_readlane((int)ev, SHARDS);
       if (total >= dep_units) break;

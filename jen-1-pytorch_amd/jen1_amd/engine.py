@@ -931,7 +931,7 @@ class Plan(OpBuilder):
         n_tr = len(spec.transformers())
         lens = spec.level_lengths(T)
         Ltr = max([lens[i + 1] for i, d in enumerate(spec.downs) if d.transformer] + [lens[-1]])
-        deep_sync = (256 * 8 * 64 + 64) if self.deep_level is not None else 0      # arrival counters of <= 256 phases
+        deep_sync = (int(eng.lib.jen1_deep_sync_bytes(256)) // 4) if self.deep_level is not None else 0    # arrival counters of <= 256 phases
         self.arena = torch.zeros(600 * Be * 64 + (4 * n_tr + 8) * Be * Ltr * 2 + 4096 + deep_sync + 64, dtype=f32, device=dev)
         self._arena_used = 0
         ops = self.ops
