@@ -261,6 +261,7 @@ struct Sync {
   unsigned* err;       // error word
   bool dead;           // wave 0: a wait timed out somewhere: stop waiting, finish with whatever is there
   int p, wg, nwg;      // current phase / this workgroup
+  int dep_rot;         // first workgroup of the phase waited for (its units run on dep_rot, dep_rot + 1, ... mod nwg)
 #ifdef JEN1_DEEP_PROFILE
   unsigned long long tt[16];
 #endif
@@ -293,12 +294,20 @@ __device__ __forceinline__ void wait_phase(Sync& sy, int dep, int dep_units, int
   if (tid < 64 && !sy.dead) {
     const gu32* c = g32(sy.base + ((size_t)dep * SHARDS + (tid < SHARDS ? tid : 0)) * SHW);
     const gu32* e = g32(sy.err);
-    unsigned spins = 0;
+    // arrivals this lane's shard will see: units u = 0 .. dep_units - 1 run on workgroup (u + rot) % nwg and arrive on shard
+    // workgroup % SHARDS.  A shard that has reached its count is not read again, so towards the end of a phase only the shards
+    // with stragglers are polled and the last arrivals do not queue behind hundreds of reads of their line.
+    unsigned target = 0xFFFFFFFFu;                     // (unknown: keep polling the shard)
+    if ((sy.nwg % SHARDS) == 0 && tid < SHARDS) {
+      const int u0 = ((tid - sy.dep_rot) % SHARDS + SHARDS) % SHARDS;
+      target = u0 < dep_units ? (unsigned)((dep_units - u0 + SHARDS - 1) / SHARDS) : 0u;
+    }
+    unsigned v = 0, spins = 0;
     for (;;) {
-      unsigned v = 0, ev = 0;
-      if (tid < SHARDS) v = __hip_atomic_load(c, RLX_AGENT);
+      unsigned ev = 0;
+      if (tid < SHARDS && v < target) v = __hip_atomic_load(c, RLX_AGENT);
       if (tid == SHARDS) ev = __hip_atomic_load(e, RLX_AGENT);
-      float tot = row16_sum_d((float)v);                // counts are small integers: exact in float
+      float tot = row16_sum_d(tid < SHARDS ? (float)v : 0.f);      // counts are small integers: exact in float
       if (SHARDS > 16) tot += __shfl_xor(tot, 16);      // (lanes beyond the shards hold 0)
       if (SHARDS > 32) tot += __shfl_xor(tot, 32);
       const int total = __builtin_amdgcn_readfirstlane((int)tot);
@@ -1435,6 +1444,7 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
     // called by the unit right before one of its __syncthreads()
     auto publish_next = [&]() { if (reload) reinterpret_cast<u64*>(Dn)[tid] = nx; };
     sy.p = p;
+    sy.dep_rot = p > 0 ? hdr[p - 1].rot : 0;
     const bool need_wait = waited != p && p > 0;
     waited = p;
     const int dep_units = p > 0 ? hdr[p - 1].n_units : 0;
