@@ -306,7 +306,7 @@ __device__ __forceinline__ void wait_phase(Sync& sy, int dep, int dep_units, int
     for (;;) {
       unsigned ev = 0;
       if (tid < SHARDS && v < target) v = __hip_atomic_load(c, RLX_AGENT);
-      if (tid == SHARDS) ev = __hip_atomic_load(e, RLX_AGENT);
+      if (tid == SHARDS && (spins & 7u) == 7u) ev = __hip_atomic_load(e, RLX_AGENT);      // the error word: every 8th poll
       float tot = row16_sum_d(tid < SHARDS ? (float)v : 0.f);      // counts are small integers: exact in float
       if (SHARDS > 16) tot += __shfl_xor(tot, 16);      // (lanes beyond the shards hold 0)
       if (SHARDS > 32) tot += __shfl_xor(tot, 32);
