@@ -321,6 +321,7 @@ class KernelCtx:
         self.splitk_target_wgs = 512
         self.splitk_min_bytes = 1 << 20
         self.fuse_shortcut = True
+        self.fuse_shortcut_tiles = True
         self.fuse_ff_out = True
         self.fuse_o2_ff1 = True
         self.use_tile_kernel = True

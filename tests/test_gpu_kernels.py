@@ -597,3 +597,83 @@ def test_cfg_ddim_step(ctx, objective, last):
     L.check(lib.jen1_cfg_combine(net.data_ptr(), g.data_ptr(), B, Cc, T, Cc, 0.8, 1, 0.7, kc.dt, s))
     torch.cuda.synchronize()
     assert rel_err(g.cpu().numpy(), o.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [5, 6, 7, 10])
+@pytest.mark.parametrize("two_extra", [False, True])
+def test_tile_kernel_raw_extra_segments_fused_shortcut(ctx, cfg, two_extra):
+    """ResnetBlock1d second half on a tiled long level: conv k=3 over GroupNorm + FiLM + SiLU(h) plus the 1x1 shortcut over the raw
+    block input [x, skip] as extra K segments staged behind the normalised channels of the same tile (blocks.py:219-231, :732-734)"""
+    from jen1_amd import lib as L
+    from jen1_amd.engine import OpBuilder
+    from jen1_amd.packing import conv_weight_to_gemm, pack_gemm_weight
+    kc, mode = ctx
+    torch.manual_seed(31 + cfg)
+    B, Ch, C0, C1, Co, G, Ln = 2, 128, 128, 64 if two_extra else 0, 128, 8, 150
+    h = torch.randn(B, Ch, Ln, device="cuda") * 1.3 + 0.2
+    x0 = torch.randn(B, C0, Ln, device="cuda")
+    x1 = torch.randn(B, C1, Ln, device="cuda") if two_extra else None
+    gam, bet = torch.rand(Ch, device="cuda") + 0.5, torch.randn(Ch, device="cuda") * 0.1
+    ftab = torch.randn(3, 2 * Ch + 5, device="cuda") * 0.3
+    frow = torch.tensor([2, 0], dtype=torch.int32, device="cuda")
+    w2 = torch.randn(Co, Ch, 3, device="cuda") / (Ch * 3) ** 0.5
+    ws = torch.randn(Co, C0 + C1, 1, device="cuda") / (C0 + C1) ** 0.5
+    b2, bs = torch.randn(Co, device="cuda") * 0.1, torch.randn(Co, device="cuda") * 0.1
+    hn = F.group_norm(h, G, gam, bet, 1e-5)
+    hn = hn * (ftab[frow.long()][:, 5: 5 + Ch, None] + 1) + ftab[frow.long()][:, 5 + Ch: 5 + 2 * Ch, None]
+    xin = x0 if not two_extra else torch.cat([x0, x1], 1)
+    ref = F.conv1d(F.pad(F.silu(hn), (1, 1)), w2, b2) + F.conv1d(xin, ws, bs)
+    wf = torch.cat([pack_gemm_weight(conv_weight_to_gemm(w2), kc.tdtype).flatten(0, 1),
+                    pack_gemm_weight(conv_weight_to_gemm(ws), kc.tdtype).flatten(0, 1)], 0).contiguous()
+    ob = OpBuilder(kc)
+    out = new_out(kc, B, Ln, Co, gn=True)
+    extras = [(to_cl(x0, kc), 0)] + ([(to_cl(x1, kc), 0)] if two_extra else [])
+    r = ob.conv(ob.ops, src0=to_cl(h, kc), w=wf, bias=b2 + bs, out=out, taps=3, pad_left=1, pro=L.PRO_GN_SILU,
+                gn=(G, Ch, gam, bet, 1e-5), film=(ftab, frow, 5, Ch), extra_segs=extras, force={"cfg": cfg})
+    assert r is out
+    run(ob)
+    y = from_cl(out)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TOL[mode]
+    assert rel_err(out.gn.cpu().numpy(), to_cl(y, kc).gn.cpu().numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("B,Ln,ld", [(2, 77, 288), (3, 1500, 128), (1, 5, 1024), (4, 94, 32)])
+def test_gn_stats_fixed_order(ctx, B, Ln, ld):
+    """jen1_gn_stats: fine-group (sum, sumsq) of a channel-last tensor, written (not accumulated) and bit-reproducible"""
+    from jen1_amd import lib as L
+    kc, mode = ctx
+    torch.manual_seed(B * 1000 + Ln)
+    x = (torch.randn(B, Ln, ld, device="cuda") * 1.7 + 0.4).to(kc.tdtype)
+    st = torch.full((B * 64,), 123.0, device="cuda")                       # stale contents must not survive
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(kc.lib.jen1_gn_stats(x.data_ptr(), st.data_ptr(), B, Ln, ld, kc.dt, s))
+    st2 = torch.zeros(B * 64, device="cuda")
+    L.check(kc.lib.jen1_gn_stats(x.data_ptr(), st2.data_ptr(), B, Ln, ld, kc.dt, s))
+    torch.cuda.synchronize()
+    assert torch.equal(st, st2)
+    g = x.double().reshape(B, Ln, 32, ld // 32)
+    exp = torch.stack([g.sum((1, 3)), (g * g).sum((1, 3))], -1).reshape(B * 64)
+    assert rel_err(st.cpu().numpy(), exp.float().cpu().numpy()) < 2e-6
+    with pytest.raises(L.Jen1HipError):
+        L.check(kc.lib.jen1_gn_stats(x.data_ptr(), st.data_ptr(), B, Ln, 48, kc.dt, s))
+
+
+def test_cfg_step_ddpm_row(ctx):
+    """row kind 2 of jen1_cfg_ddim_step: ancestral sampling x_next = coef1 x0 + coef2 x_t + sd noise (gdm.py:144-163)"""
+    from jen1_amd import lib as L
+    kc, mode = ctx
+    torch.manual_seed(4)
+    B, Cc, T = 2, 128, 50
+    net = torch.randn(B, T, Cc, device="cuda").to(kc.tdtype)
+    x = torch.randn(B, Cc, T, device="cuda")
+    noise = torch.rand(B, Cc, T, device="cuda")
+    coef = torch.tensor([1.4, 0.9, 0.35, 0.6, 0.2, 2.0, 0.0, 0.0], device="cuda")
+    xo, x0o = torch.zeros(B, Cc, T, device="cuda"), torch.zeros(B, Cc, T, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(kc.lib.jen1_cfg_ddim_step(net.data_ptr(), x.data_ptr(), noise.data_ptr(), coef.data_ptr(), xo.data_ptr(), None, x0o.data_ptr(),
+                                      None, B, Cc, T, Cc, 1, 1.0, 0, 0.7, 0, 1, kc.dt, s))
+    torch.cuda.synchronize()
+    eps = net.float().permute(0, 2, 1)
+    x0 = (1.4 * x - 0.9 * eps).clamp(-1, 1)
+    assert rel_err(x0o.cpu().numpy(), x0.cpu().numpy()) < 2e-5
+    assert rel_err(xo.cpu().numpy(), (0.35 * x0 + 0.6 * x + 0.2 * noise).cpu().numpy()) < 2e-5
