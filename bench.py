@@ -308,7 +308,7 @@ def train_step_bench(cfg, B, T, dtype, device, reps=5):
     from jen1_amd.model import UNetCFG1d
     from jen1_amd.optim import FusedAdamW
     from jen1_amd.train import GraphedLossStep
-    model = UNetCFG1d(**cfg, compute_dtype=dtype, device=device)
+    model = UNetCFG1d(**cfg, init_seed=1234, compute_dtype=dtype, device=device)
     model.train()
     opt = FusedAdamW(model.parameters())
     graph = model.train_graph(dtype)
@@ -464,7 +464,7 @@ def train_mode(args, world, rank, device, dist, barrier):
     from jen1_amd.trainer import UnifiedMultiTaskTrainer
     cfg = tiny_model_config() if args.tiny else full_model_config()
     B, T = args.batch, args.length
-    model = UNetCFG1d(**cfg, compute_dtype=args.dtype, device=device)
+    model = UNetCFG1d(**cfg, init_seed=1234, compute_dtype=args.dtype, device=device)
     model.train()
     betas, _ = get_beta_schedule("linear", 1000)
     gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device=device, cfg_dropout_proba=0.2,
@@ -565,7 +565,7 @@ def main():
     from jen1_amd.model import UNetCFG1d
     cfg = tiny_model_config() if args.tiny else full_model_config()
     B, T = args.batch, args.length
-    model = UNetCFG1d(**cfg, compute_dtype=args.dtype, device=device)
+    model = UNetCFG1d(**cfg, init_seed=1234, compute_dtype=args.dtype, device=device)
     st = build_stepper(model, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
     dt = timed_steps(st, args.steps, args.warmup, barrier)
     dt, value = aggregate(dist, dt, args.steps, world, device)

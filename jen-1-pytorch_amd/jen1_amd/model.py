@@ -37,21 +37,56 @@ def _register(root: nn.Module, key: str, value: torch.Tensor):
     m.register_parameter(parts[-1], nn.Parameter(value, requires_grad=True))
 
 
+def _torch_default_init(key: str, shape, shapes) -> torch.Tensor:
+    """what the reference's freshly constructed modules hold for this parameter (torch defaults): nn.Conv1d / ConvTranspose1d / Linear
+    weight kaiming_uniform_(a = sqrt 5) = U(+-1 / sqrt(fan_in)) with fan_in = shape[1] * kernel, their bias U(+-1 / sqrt(fan_in));
+    GroupNorm / LayerNorm weight 1, bias 0; nn.Embedding and the learned Fourier frequencies N(0, 1)"""
+    if key.endswith(".weights") or key.endswith("embedding.weight"):
+        return torch.randn(shape)
+    if key.endswith(".weight"):
+        if len(shape) == 1:
+            return torch.ones(shape)
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        bound = 1.0 / fan_in ** 0.5
+        return torch.empty(shape).uniform_(-bound, bound)
+    if key.endswith(".bias"):
+        w = shapes.get(key[:-4] + "weight")
+        if w is None or len(w) == 1:
+            return torch.zeros(shape)
+        fan_in = 1
+        for d in w[1:]:
+            fan_in *= d
+        bound = 1.0 / fan_in ** 0.5
+        return torch.empty(shape).uniform_(-bound, bound)
+    return torch.randn(shape)
+
+
 class UNetCFG1d(nn.Module):
     """UNet1d with classifier-free guidance on MI355X (reference model.py:268)."""
 
     def __init__(self, context_embedding_max_length: int, context_embedding_features: int,
                  use_xattn_time: bool = False, *, compute_dtype: str = "bf16", device="cuda",
-                 init_seed: Optional[int] = 1234, **kwargs):
+                 init_seed="torch", **kwargs):
+        """``init_seed``: "torch" (default) = the distributions torch's own modules start from in the reference (model.py builds
+        nn.Conv1d / nn.Linear / nn.GroupNorm / nn.LayerNorm / nn.Embedding: kaiming-uniform weights and fan-in-bounded biases, unit
+        norm weights and zero norm biases, N(0, 1) embeddings), drawn from torch's global generator; an int = the deterministic
+        test filler ``init_fill.fill(key, shape, seed)`` (perturbed norm affines: what the parity tests, the oracle and bench.py
+        use); None = zeros (a shell for ``load_state_dict``)."""
         super().__init__()
         self.spec = UNetSpec(context_embedding_max_length=context_embedding_max_length,
                              context_embedding_features=context_embedding_features,
                              use_xattn_time=use_xattn_time, **kwargs)
         self.compute_dtype = compute_dtype
         self._device = torch.device(device)
+        shapes = dict(self.spec.param_shapes())
         for key, shape in self.spec.param_shapes():
             if init_seed is None:
                 v = torch.zeros(shape, dtype=torch.float32)
+            elif isinstance(init_seed, str):
+                assert init_seed == "torch", init_seed
+                v = _torch_default_init(key, tuple(shape), shapes)
             else:
                 v = torch.from_numpy(fill(key, shape, init_seed))
             _register(self, key, v.to(self._device))

@@ -120,7 +120,7 @@ def test_argument_validation_reports_errors_without_a_gpu(lib):
 def test_product_path_fails_loudly_without_gpu_or_library():
     from jen1_amd.model import UNetCFG1d
     if not torch.cuda.is_available():
-        m = UNetCFG1d(**tiny_model_config(), device="cpu")
+        m = UNetCFG1d(**tiny_model_config(), init_seed=1234, device="cpu")
         with pytest.raises(L.Jen1HipError):
             m.engine()
     # a missing shared library is an error, never a fallback

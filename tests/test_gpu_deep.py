@@ -27,7 +27,7 @@ def tiny_f32():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from jen1_amd.model import UNetCFG1d
-    return UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+    return UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +35,7 @@ def tiny_bf16():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from jen1_amd.model import UNetCFG1d
-    return UNetCFG1d(**tiny_model_config(), compute_dtype="bf16", device="cuda")
+    return UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +43,7 @@ def full_f32():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from jen1_amd.model import UNetCFG1d
-    return UNetCFG1d(**full_model_config(), compute_dtype="f32", device="cuda")
+    return UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +51,7 @@ def full_bf16():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from jen1_amd.model import UNetCFG1d
-    return UNetCFG1d(**full_model_config(), compute_dtype="bf16", device="cuda")
+    return UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
 
 
 def run_plan(model, plan, x, t, cond, drop=None):

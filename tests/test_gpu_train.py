@@ -285,7 +285,7 @@ def tiny_model():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from jen1_amd.model import UNetCFG1d
-    return UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+    return UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
 
 
 def dev(a):
@@ -376,7 +376,7 @@ def test_training_step_updates_parameters_and_repacks(tiny_model):
     """one optimiser step through FusedAdamW changes the loss; the packed compute weights follow the parameters"""
     from jen1_amd.model import UNetCFG1d
     from jen1_amd.optim import FusedAdamW
-    model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
     opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=0.7)
     graph = model.train_graph("f32")
     graph.attach_optimizer(opt)
@@ -413,7 +413,7 @@ def test_unified_multitask_trainer_steps(tiny_model, use_graph):
     from jen1_amd.model import UNetCFG1d
     from jen1_amd.optim import FusedAdamW, LinearLR
     from jen1_amd.trainer import UnifiedMultiTaskTrainer
-    model = UNetCFG1d(**tiny_model_config(), compute_dtype="bf16", device="cuda")
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
     betas, _ = get_beta_schedule("linear", 1000)
     gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
                            cfg_dropout_proba=0.2, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
@@ -452,7 +452,7 @@ def test_graphed_step_matches_eager_gradients():
     from jen1_amd.model import UNetCFG1d
     from jen1_amd.optim import FusedAdamW
     from jen1_amd.train import GraphedLossStep
-    model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
     opt = FusedAdamW(model.parameters(), lr=1e-3)
     graph = model.train_graph("f32")
     graph.attach_optimizer(opt)
@@ -495,7 +495,7 @@ def test_full_model_training_gradients_vs_reference_autograd_f32():
     from jen1_amd.model import UNetCFG1d
     g = golden("full_train")
     names = json.loads(str(g["grad_names_all"]))
-    model = UNetCFG1d(**full_model_config(), compute_dtype="f32", device="cuda")
+    model = UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
     model.train()
     B, T = 1, 1500
     betas, _ = get_beta_schedule("linear", 1000)
@@ -540,7 +540,7 @@ def test_training_overfits_one_batch():
     from jen1_amd.model import UNetCFG1d
     from jen1_amd.optim import FusedAdamW
     from jen1_amd.train import GraphedLossStep
-    model = UNetCFG1d(**tiny_model_config(), compute_dtype="bf16", device="cuda")
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
     model.train()
     opt = FusedAdamW(model.parameters(), lr=2e-3, weight_decay=0.0, max_norm=1.0)
     graph = model.train_graph("bf16")
@@ -589,7 +589,7 @@ def _ddp_worker(rank, world, port, q):
             loss = gd.training_loosses(model.train_graph("f32"), x0, t, cond, noise=noise, causal=False)
             loss.backward()
 
-        model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+        model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
         model.train()
         opt = FusedAdamW(model.parameters(), lr=1e-3)
         opt.zero_grad()
@@ -618,7 +618,7 @@ def _ddp_worker(rank, world, port, q):
         out = {"same": bool(all(torch.equal(gathered[0], g_) for g_ in gathered)), "same_as_blocking": same_as_blocking,
                "sent_during_backward": sent_during_backward}
         if rank == 0:                                     # single-process restatement: accumulate both ranks' gradients, halve
-            ref = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+            ref = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
             ref.train()
             ropt = FusedAdamW(ref.parameters(), lr=1e-3)
             ropt.zero_grad()
@@ -662,7 +662,7 @@ def test_inference_engine_follows_optimizer_steps():
     from jen1_amd.model import UNetCFG1d
     from jen1_amd.optim import FusedAdamW
     cfg = tiny_model_config()
-    model = UNetCFG1d(**cfg, compute_dtype="f32", device="cuda")
+    model = UNetCFG1d(**cfg, init_seed=1234, compute_dtype="f32", device="cuda")
     betas, _ = get_beta_schedule("linear", 1000)
     gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
                            embedding_scale=1.0, batch_cfg=False, scale_cfg=False)
@@ -683,7 +683,7 @@ def test_inference_engine_follows_optimizer_steps():
     model.eval()
     y1 = model(x, t, **kw).clone()
     assert float((y1 - y0).abs().max()) > 1e-4          # the step moved the weights and the engine saw it
-    fresh = UNetCFG1d(**cfg, compute_dtype="f32", device="cuda")
+    fresh = UNetCFG1d(**cfg, init_seed=1234, compute_dtype="f32", device="cuda")
     fresh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
     y2 = fresh(x, t, **kw)
     assert float((y1 - y2).abs().max()) <= 1e-5 * float(y2.abs().max())
@@ -708,7 +708,7 @@ def test_merged_task_passes_equal_one_pass_per_task(use_graph, monkeypatch):
     betas, _ = get_beta_schedule("linear", 1000)
     res = {}
     for merge in (False, True):
-        model = UNetCFG1d(**tiny_model_config(), compute_dtype="f32", device="cuda")
+        model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
         gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
                                embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
         opt = FusedAdamW(model.parameters(), lr=1e-3)

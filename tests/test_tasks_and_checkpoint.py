@@ -127,3 +127,37 @@ def test_generate_request_planning_host_side():
     # the mask of a continuation keeps exactly the prefix
     keep = j.get_mask(3 * sr, *j._task_window("music_cont", 3, None, sr)[:2], 2)
     assert keep.shape == (2, 1, 3 * sr) and float(keep[:, :, :sr].min()) == 1 and float(keep[:, :, sr:].max()) == 0
+
+
+def test_default_initialisation_mirrors_torch_modules():
+    """UNetCFG1d() without a checkpoint starts from the distributions the reference's freshly built torch modules have (model.py:
+    nn.Conv1d / nn.Linear kaiming-uniform, norm weight 1 / bias 0, N(0, 1) embeddings), seeded by torch's generator -- not from the
+    perturbed test filler (``init_seed=<int>``), which the parity tests and bench.py ask for explicitly"""
+    from jen1_amd.model import UNetCFG1d
+    cfg = tiny_model_config()
+    torch.manual_seed(0)
+    a = UNetCFG1d(**cfg, device="cpu")
+    torch.manual_seed(0)
+    b = UNetCFG1d(**cfg, device="cpu")
+    torch.manual_seed(1)
+    c = UNetCFG1d(**cfg, device="cpu")
+    sa, sb, sc = a.state_dict(), b.state_dict(), c.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)                       # torch's generator decides
+    assert any(not torch.equal(sa[k], sc[k]) for k in sa)
+    shapes = {k: tuple(v.shape) for k, v in sa.items()}
+    n_norm = n_lin = 0
+    for k, v in sa.items():
+        if k.endswith(".weight") and v.dim() == 1:                          # GroupNorm / LayerNorm
+            assert torch.equal(v, torch.ones_like(v)) and torch.equal(sa[k[:-6] + "bias"], torch.zeros_like(v)), k
+            n_norm += 1
+        elif k.endswith(".weight") and v.dim() >= 2 and not k.endswith("embedding.weight"):
+            fan_in = int(np.prod(shapes[k][1:]))
+            bound = 1.0 / fan_in ** 0.5
+            assert float(v.abs().max()) <= bound and float(v.abs().max()) > 0.5 * bound, k
+            if k[:-6] + "bias" in sa:
+                assert float(sa[k[:-6] + "bias"].abs().max()) <= bound, k
+            n_lin += 1
+    assert n_norm > 10 and n_lin > 30
+    filled = UNetCFG1d(**cfg, device="cpu", init_seed=1234).state_dict()
+    k0 = next(k for k in filled if k.endswith(".weight") and filled[k].dim() == 1)
+    assert not torch.equal(filled[k0], torch.ones_like(filled[k0]))          # the filler perturbs the norm affines on purpose

@@ -4,7 +4,7 @@ import numpy as np, torch
 from jen1_amd import synth
 from jen1_amd.config import full_model_config
 from jen1_amd.model import UNetCFG1d
-m = UNetCFG1d(**full_model_config(), compute_dtype=sys.argv[1], device="cuda")
+m = UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype=sys.argv[1], device="cuda")
 B, T, nrep = int(sys.argv[2]), 1500, int(sys.argv[3])
 plan = m.engine().plan(B, T, nrep, False, deep=True)
 print("deep level", plan.deep_level, len(plan.deep), "phases; limit", os.environ.get("JEN1_DEEP_RUN_PHASES"), flush=True)

@@ -46,7 +46,7 @@ lib = L.load()
 lib.jen1_deep_debug_buffer.restype = C.c_int
 lib.jen1_deep_debug_buffer.argtypes = [C.c_void_p]
 dev = "cuda"
-model = UNetCFG1d(**full_model_config(), compute_dtype=args.dtype, device=dev)
+model = UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype=args.dtype, device=dev)
 B, T = args.batch, args.length
 nrep = 2 if args.cfg else 1
 plan = model.engine().plan(B, T, nrep, False, n_t=None if args.general else 100)

@@ -13,7 +13,7 @@ args = ap.parse_args()
 import torch
 from jen1_amd.config import full_model_config
 from jen1_amd.model import UNetCFG1d
-model = UNetCFG1d(**full_model_config(), compute_dtype=args.dtype, device="cuda")
+model = UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype=args.dtype, device="cuda")
 plan = model.engine().plan(args.batch, args.length, 2 if args.cfg else 1, False, n_t=100)
 print("deep_level", plan.deep_level, plan.deep_errors)
 prog = plan.deep

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--eager", action="store_true")
     a = ap.parse_args()
     dev = lambda v: None if v is None else torch.from_numpy(np.ascontiguousarray(v)).cuda()   # noqa: E731
-    model = UNetCFG1d(**(tiny_model_config() if a.tiny else full_model_config()), compute_dtype=a.dtype, device="cuda")
+    model = UNetCFG1d(**(tiny_model_config() if a.tiny else full_model_config()), init_seed=1234, compute_dtype=a.dtype, device="cuda")
     model.train()
     opt = FusedAdamW(model.parameters())
     graph = model.train_graph(a.dtype)
