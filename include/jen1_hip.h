@@ -287,6 +287,11 @@ int jen1_memset_zero(void* p, int64_t bytes, void* stream);
  * gnorm_sq is read on the device, so clip + update needs no host synchronisation.
  */
 int jen1_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
+/* the same with caller-owned scratch (jen1_grad_sqnorm_scratch_bytes() bytes, 16-byte aligned, zeroed ONCE by the caller; the kernel
+ * leaves it ready for the next call): one scratch per optimiser, so optimisers on different streams never share block partials or
+ * the arrival ticket.  jen1_grad_sqnorm itself uses one scratch per device: one call at a time. */
+int64_t jen1_grad_sqnorm_scratch_bytes(void);
+int jen1_grad_sqnorm_ws(const float* g, int64_t n, float* out, void* scratch, void* stream);
 int jen1_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, const float* gnorm_sq, float max_norm, int skip_nonfinite, void* stream);
 

@@ -28,7 +28,10 @@ constexpr int OPT_MAX_BLOCKS = 4096;
 __device__ float g_sq_partials[OPT_MAX_BLOCKS];
 __device__ unsigned g_sq_ticket;
 
-__global__ __launch_bounds__(OPT_THREADS) void grad_sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// `partials` (OPT_MAX_BLOCKS floats) and `ticket` are the caller's scratch (jen1_grad_sqnorm_ws: one per optimiser, so that two
+// optimisers / streams never share them) or the library's own (jen1_grad_sqnorm: one call at a time per device)
+__global__ __launch_bounds__(OPT_THREADS) void grad_sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out,
+                                                                   float* __restrict__ partials, unsigned* __restrict__ ticket_p) {
   __shared__ float red[OPT_THREADS / 64];
   __shared__ int last_s;
   const int64_t nv = n >> 2;
@@ -57,18 +60,18 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sqnorm_kernel(const float* _
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < OPT_THREADS / 64; ++w) t += red[w];
-    __hip_atomic_store(&g_sq_partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through
+    __hip_atomic_store(&partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(&g_sq_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = __hip_atomic_fetch_add(ticket_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_s = (ticket == gridDim.x - 1) ? 1 : 0;
-    if (last_s) __hip_atomic_store(&g_sq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last_s) __hip_atomic_store(ticket_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (!last_s) return;
   // the last block: fixed-order sum of the gridDim.x partials (thread t takes slots t, t + 256, ...; then a fixed tree)
   float t = 0.f;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += OPT_THREADS)
-    t += __hip_atomic_load(&g_sq_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
   __syncthreads();
@@ -139,15 +142,31 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(const AdamArgs a) {
 
 }  // namespace
 
-extern "C" int jen1_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
+static int launch_sqnorm(const float* g, int64_t n, float* out, float* partials, unsigned* ticket, void* stream) {
   JEN1_CHECK(g && out && n > 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "grad_sqnorm: null / unaligned pointer or empty tensor");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t nv = n >> 2;
   int64_t blocks = (nv + OPT_THREADS * OPT_VEC_PER_THREAD - 1) / (OPT_THREADS * OPT_VEC_PER_THREAD);
-  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, g, n, out);
+  blocks = blocks < 1 ? 1 : (blocks > OPT_MAX_BLOCKS ? OPT_MAX_BLOCKS : blocks);
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, g, n, out, partials, ticket);
   JEN1_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int jen1_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
+  float* partials = nullptr;
+  unsigned* ticket = nullptr;
+  JEN1_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&partials), HIP_SYMBOL(g_sq_partials)));
+  JEN1_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ticket), HIP_SYMBOL(g_sq_ticket)));
+  return launch_sqnorm(g, n, out, partials, ticket, stream);
+}
+
+extern "C" int64_t jen1_grad_sqnorm_scratch_bytes(void) { return (int64_t)(OPT_MAX_BLOCKS + 64) * 4; }
+
+extern "C" int jen1_grad_sqnorm_ws(const float* g, int64_t n, float* out, void* scratch, void* stream) {
+  JEN1_CHECK(scratch && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "grad_sqnorm_ws: null / unaligned scratch");
+  float* partials = reinterpret_cast<float*>(scratch);
+  return launch_sqnorm(g, n, out, partials, reinterpret_cast<unsigned*>(partials + OPT_MAX_BLOCKS), stream);
 }
 
 extern "C" int jen1_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

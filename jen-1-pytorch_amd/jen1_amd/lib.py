@@ -111,6 +111,8 @@ SYMBOLS = {
     "jen1_step_advance": (c_int, [_P, _P]),
     "jen1_cfg_combine": (c_int, [_P, _P] + [c_int] * 4 + [c_float, c_int, c_float, c_int, _P]),
     "jen1_grad_sqnorm": (c_int, [_P, c_int64, _P, _P]),
+    "jen1_grad_sqnorm_scratch_bytes": (c_int64, []),
+    "jen1_grad_sqnorm_ws": (c_int, [_P, c_int64, _P, _P, _P]),
     "jen1_adamw_step": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [c_int, _P, c_float, c_int, _P]),
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
     "jen1_train_gemm": (c_int, [C.POINTER(GemmArgs), _P]),

@@ -61,9 +61,12 @@ class FusedAdamW:
             p.data = self.flat_param[o:o + p.numel()].view_as(p)
             p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # (skip_nonfinite: the kernel leaves p / m / v untouched when the norm is not finite, but ``step_count`` -- which the bias
+        # correction is computed from on the host -- still advances; GradScaler would not count the skipped step)
         self.max_norm, self.skip_nonfinite = max_norm, skip_nonfinite
         self.step_count = 0
         self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sq_scratch: Optional[torch.Tensor] = None       # block partials + arrival ticket of the norm, owned by this optimiser
         self.post_step_hooks = []      # callables run after every step (TrainGraph.invalidate: re-pack the compute weights)
 
     def zero_grad(self) -> None:
@@ -83,7 +86,10 @@ class FusedAdamW:
         gn = None
         if self.max_norm is not None or self.skip_nonfinite:
             self._gnorm_sq.zero_()
-            L.check(lib.jen1_grad_sqnorm(self.flat_grad.data_ptr(), self.numel, self._gnorm_sq.data_ptr(), s), "jen1_grad_sqnorm")
+            if self._sq_scratch is None:
+                self._sq_scratch = torch.zeros(int(lib.jen1_grad_sqnorm_scratch_bytes()) // 4, dtype=torch.float32, device=self.flat_param.device)
+            L.check(lib.jen1_grad_sqnorm_ws(self.flat_grad.data_ptr(), self.numel, self._gnorm_sq.data_ptr(), self._sq_scratch.data_ptr(), s),
+                    "jen1_grad_sqnorm_ws")
             gn = self._gnorm_sq.data_ptr()
         L.check(lib.jen1_adamw_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                     self.numel, float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
