@@ -183,6 +183,11 @@ int jen1_deep_num_workgroups(void);
  * wait timed out (1 + phase index). */
 int jen1_deep_run(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, int nwg, int lds_bytes, int dtype,
                   void* stream);
+/* the same with the error word outside the synchronisation area: `sync` is zeroed before every launch, `err` (one uint32, zeroed
+ * once by the caller) keeps the first time-out of ANY launch since then, so a host that replays the launch many times (a sampling
+ * run) checks it once at the end */
+int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes,
+                      int dtype, void* stream);
 int jen1_deep_error_word(int n_phases);
 
 #ifdef __cplusplus

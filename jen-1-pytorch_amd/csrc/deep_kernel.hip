@@ -1401,7 +1401,7 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
 
 template <typename T>
 __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restrict__ blobs, const int4* __restrict__ hdr_g, int n_phases,
-                                                  unsigned* sync, int err_word) {
+                                                  unsigned* sync, unsigned* err) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef typename DFrag<T>::type Frag;
   constexpr int PF = DeepCfg<T>::PF;
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
   __syncthreads();
   Sync sy;
   sy.base = sync;
-  sy.err = sync + err_word;
+  sy.err = err;
   sy.dead = false;
   sy.wg = wg;
   sy.nwg = nwg;
@@ -1809,9 +1809,17 @@ extern "C" int jen1_deep_num_workgroups(void) {
   return cus;
 }
 
+extern "C" int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
+                                 int lds_bytes, int dtype, void* stream);
 extern "C" int jen1_deep_run(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, int nwg, int lds_bytes, int dtype,
                              void* stream) {
-  JEN1_CHECK(blobs_dev && headers_dev && sync && n_phases >= 1 && n_phases <= JEN1_DEEP_MAX_PHASES && nwg >= 1, "deep run: bad arguments");
+  JEN1_CHECK(sync, "deep run: bad arguments");
+  return jen1_deep_run_err(blobs_dev, headers_dev, n_phases, sync, sync + jen1_deep_error_word(n_phases), nwg, lds_bytes, dtype, stream);
+}
+
+extern "C" int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
+                                 int lds_bytes, int dtype, void* stream) {
+  JEN1_CHECK(blobs_dev && headers_dev && sync && err && n_phases >= 1 && n_phases <= JEN1_DEEP_MAX_PHASES && nwg >= 1, "deep run: bad arguments");
   JEN1_CHECK(lds_bytes >= WS_OFF && lds_bytes <= LDS_TOTAL, "deep run: %d B of LDS", lds_bytes);
   JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "deep run: bad dtype");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1823,11 +1831,10 @@ extern "C" int jen1_deep_run(const void* blobs_dev, const void* headers_dev, int
     JEN1_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     if (dev < 64) attr_set[dtype == JEN1_F32 ? 0 : 1] |= 1ull << dev;
   }
-  const int err_word = jen1_deep_error_word(n_phases);
   const unsigned char* bl = reinterpret_cast<const unsigned char*>(blobs_dev);
   const int4* hd = reinterpret_cast<const int4*>(headers_dev);
-  if (dtype == JEN1_F32) hipLaunchKernelGGL(deep_kernel<float>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err_word);
-  else hipLaunchKernelGGL(deep_kernel<bf16_t>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err_word);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(deep_kernel<float>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
+  else hipLaunchKernelGGL(deep_kernel<bf16_t>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -193,6 +193,7 @@ class GaussianDiffusion(torch.nn.Module):
             if return_all_timesteps and st.mode == "ddpm":
                 audios.append(st.x.clone())                  # p_sample_loop records the OUTPUT of each step (gdm.py:176)
         out = st.x.clone()
+        st.check()
         return out if not return_all_timesteps else torch.stack(audios, dim=1)
 
     @torch.no_grad()
@@ -426,6 +427,14 @@ class DDIMStepper:
         if len(self.parts) == 1:
             return self.parts[0][1].x_in
         return torch.cat([p.x_in for _, p, _, _ in self.parts], dim=0)
+
+    def check(self) -> None:
+        """once per sampling run (one host sync): a dependency wait of the persistent deep-level launch that timed out leaves an
+        error word behind instead of hanging the GPU; results are garbage then and must not be returned silently"""
+        for _, plan, _, _ in self.parts:
+            if getattr(plan, "deep_level", None) is not None and plan.deep.error() != 0:
+                raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {plan.deep.error() - 1} timed out "
+                                     "(another persistent launch on the same GPU?)")
 
     def _set_step(self, i: int):
         for _, plan, _, _ in self.parts:

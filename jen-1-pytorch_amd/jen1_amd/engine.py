@@ -295,18 +295,19 @@ class DeepProgram:
         self.dev = torch.frombuffer(bytearray(bytes(blobs)), dtype=torch.uint8).to(self.eng.device)
         self.hdr = torch.frombuffer(bytearray(bytes(hdrs)), dtype=torch.uint8).to(self.eng.device)
         self.sync = sync
-        self.err_word = self.lib.jen1_deep_error_word(n)
+        # the error word lives outside the per-step zeroed area: the first time-out of any replay stays visible (error())
+        self.err = torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
 
     def launch(self, stream: int):
         n = len(self.bufs)
         if os.environ.get("JEN1_DEEP_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_DEEP_RUN_PHASES"]))
-        L.check(self.lib.jen1_deep_run(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.nwg, self.lds,
-                                       self.eng.dt, stream), "jen1_deep_run")
+        L.check(self.lib.jen1_deep_run_err(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.err.data_ptr(), self.nwg,
+                                           self.lds, self.eng.dt, stream), "jen1_deep_run_err")
 
     def error(self) -> int:
         """non-zero after a launch whose dependency wait timed out (1 + phase index); synchronises with the device"""
-        return int(self.sync[self.err_word].item())
+        return int(self.err[0].item())
 
 
 class KernelCtx:
