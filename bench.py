@@ -264,9 +264,12 @@ def conv_roofline(st, reps=3):
                 f.write(f"{per_op[i] * 1e3:8.1f} us  w={convs[i].w_bytes / 1e6:7.2f}MB act={convs[i].act_bytes / 1e6:6.2f}MB  {convs[i].label}\n")
     pm = pmc_entry("conv_family") or {}
     traffic = pm.get("hbm_bytes_per_launch") if pm.get("launches_per_step") == n else None
+    mfma_busy = pm.get("mfma_busy_pct") if pm.get("launches_per_step") == n else None
     return {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_busy_pct": mfma_busy,
+        "mfma": {"bound": "mfma", "achieved": round(flops / (conv_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                 "frac": round(flops / (conv_ms * 1e-3) / 1e12 / 2500.0, 5)},
         "kernel": "jen1_conv_gemm family: stream_gemm_kernel<*> + conv_gemm_kernel<*> (fused norm + conv/linear implicit GEMM)",
         "launches_per_step": n, "avg_launch_us": round(conv_ms * 1e3 / n, 2), "conv_ms_per_step": round(conv_ms, 4),
         "conv_ms_per_step_eager_with_event_pairs": round(eager_ms, 4),
@@ -299,7 +302,7 @@ def optimizer_step_bench(n_params, device, reps=5):
             "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 
-def train_step_bench(cfg, B, T, dtype, device, reps=5):
+def train_step_bench(cfg, B, T, dtype, device, reps=5, fwd_flops=None):
     """BASELINE configs[3] on one GPU (SURVEY.md section 8 rows a14 / a16 / e): one micro-batch of the trainer --
     ``training_loosses`` forward + backward of B clips through the CFG pair (2B rows, gdm.py:245-272, model.py:332-369)
     on the HIP training path, replayed as a HIP graph -- and one clip + AdamW step.  Not the headline metric."""
@@ -334,8 +337,21 @@ def train_step_bench(cfg, B, T, dtype, device, reps=5):
     e[2].record()
     torch.cuda.synchronize()
     fb = e[0].elapsed_time(e[1]) / reps
+    mfma = None
+    if fwd_flops:
+        # GEMM work of the pass: the forward of 2B rows (the CFG pair) + data and weight gradients = 3 x 2 x the B-row forward that the
+        # sampling plan counts; against the dense bf16 MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s; f32 mode is not priced)
+        tf = 6.0 * fwd_flops / (fb * 1e-3) / 1e12
+        busy = None
+        try:
+            busy = json.load(open(os.path.join(ROOT, "profiles", "r02_train_pmc.json")))["kernels"]["train_gemm"]["mfma_busy_pct"]
+        except Exception:
+            pass
+        mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
+                "kernel": "train_gemm_kernel<bf16> (forward, data-gradient and weight-gradient GEMMs of the pass)",
+                "executed_gflop_per_pass": round(6.0 * fwd_flops / 1e9, 1), "mfma_busy_pct": busy, "pmc_source": "profiles/r02_train_pmc.json"}
     return {"what": f"configs[3] per-GPU shape: forward + backward of {B} clips x 128x{T} through the CFG pair (2B rows), hipGraph replay",
-            "fwd_bwd_ms": round(fb, 2), "clips_per_s": round(B / fb * 1e3, 1), "optimizer_ms": round(e[1].elapsed_time(e[2]), 2),
+            "fwd_bwd_ms": round(fb, 2), "roofline_mfma": mfma, "clips_per_s": round(B / fb * 1e3, 1), "optimizer_ms": round(e[1].elapsed_time(e[2]), 2),
             "loss": round(float(loss), 4), "grad_allreduce_bytes": 4 * opt.numel,
             "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
@@ -608,7 +624,8 @@ def main():
             model.deterministic = False
             if not args.tiny:
                 out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
-                out["extra"]["train_step"] = train_step_bench(cfg, B, T, args.dtype, device)
+                fwd_flops = sum(getattr(op, "flops", 0) for op in st.plan.ops)
+                out["extra"]["train_step"] = train_step_bench(cfg, B, T, args.dtype, device, fwd_flops=fwd_flops if args.dtype == "bf16" else None)
                 out["extra"]["encodec_decode"] = encodec_decode_bench(B, T, args.dtype, device)
                 if not args.no_graph:
                     # BASELINE configs[4] shape (long-form continuation / inpaint, T ~ 9000), bf16, no fp8 path yet
