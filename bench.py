@@ -129,7 +129,11 @@ def pmc_entry(name):
     """HBM bytes / MFMA-busy of the committed rocprofv3 --pmc passes of this command (profiles/r02_pmc.json, produced by
     tools/pmc_summary.py from the per-pass CSVs; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)"""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))["kernels"].get(name)
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        e = d["kernels"].get(name)
+        if e is not None:
+            e = dict(e, collected_at=d.get("collected_at"))      # commit + bench.py hash + command of the PMC run
+        return e
     except Exception:
         return None
 
@@ -191,7 +195,7 @@ def deep_roofline(st, dtype):
         "launches_per_step": 1, "avg_launch_us": round(ms * 1e3, 1), "phases": n_ph, "us_per_phase": round(ms * 1e3 / n_ph, 2),
         "alg_bytes_per_launch": int(alg), "alg_weight_bytes": int(op.w_bytes), "alg_act_bytes": int(op.act_bytes),
         "executed_gflop_per_launch": round(op.flops / 1e9, 2), "mfma_busy_pct": pm.get("mfma_busy_pct"),
-        "pmc_source": pm.get("source"),
+        "pmc_source": pm.get("source"), "pmc_collected_at": pm.get("collected_at"),
     }
 
 
