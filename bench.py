@@ -497,7 +497,7 @@ def train_mode(args, world, rank, device, dist, barrier):
     def conditioner(metadata, device_):
         idx = torch.tensor(metadata, device=device_)
         return {"prompt": (emb[idx], msk[idx])}
-    tr = UnifiedMultiTaskTrainer(model, gd, conditioner, opt, sched, grad_accum_every=1, rng=random.Random(rank), device=device,
+    tr = UnifiedMultiTaskTrainer.build(model, gd, conditioner, opt, sched, grad_accum_every=1, rng=random.Random(rank), device=device,
                                  use_graph=not args.eager_train, allow_uneven_tasks=True)
     audio = dev(synth.latents(B, T, key="clip", seed=rank), device)
     meta = list(range(B))

@@ -248,6 +248,10 @@ int jen1_gn_stats(const void* x, float* stats, int B, int L, int ld, int dtype, 
  */
 int jen1_time_features(const int64_t* t, const float* freq, const float* w, const float* bias, float* out,
                        int n, int half, int out_features, void* stream);
+/* the same for float32 times (VDM's continuous t in [0, 1], vdm/vdm.py:44, :98; the reference model promotes any dtype with
+ * the same arithmetic, utils/module.py:66-70) */
+int jen1_time_features_f32(const float* t, const float* freq, const float* w, const float* bias, float* out,
+                           int n, int half, int out_features, void* stream);
 
 /* y[n][out] = act(x[n][in] @ w[out][in]^T + bias), float32 (to_mapping, model.py:75-80). */
 int jen1_linear_f32(const float* x, const float* w, const float* bias, float* y, int n, int in_features,
@@ -261,6 +265,9 @@ int jen1_linear_f32(const float* x, const float* w, const float* bias, float* y,
  *   coef: device float[8] = {sqrt_recip, sqrt_recipm1, sqrt_alpha_next, c, sigma, last_step, -, -}
  *   x_out: [B][C][T] float32 next latents;  eps_out / x0_out optional [B][C][T] float32.
  * With nrep = 1 the CFG part is skipped (embedding_scale == 1).
+ * coef[5] selects the row kind: 0 DDIM, 1 DDIM's last step (x_next = x0), 2 DDPM posterior row (gdm.py:144-163:
+ * {.., coef1, coef2, sd, 2}), 3 VDM row {alpha_t, sigma_t, alpha_next, sigma_next, -, 3} (vdm/vdm.py:52-55: v-prediction,
+ * x_pred = alpha x - sigma v, noise_pred = sigma x + alpha v, x_next = alpha' x_pred + sigma' noise_pred; no clamp).
  */
 int jen1_cfg_ddim_step(const void* net, const float* x, const float* noise, const float* coef, float* x_out,
                        float* eps_out, float* x0_out, const int32_t* step_idx, int B, int C, int T, int ld, int nrep,
@@ -294,6 +301,13 @@ int64_t jen1_grad_sqnorm_scratch_bytes(void);
 int jen1_grad_sqnorm_ws(const float* g, int64_t n, float* out, void* scratch, void* stream);
 int jen1_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, const float* gnorm_sq, float max_norm, int skip_nonfinite, void* stream);
+/* the same with the step number kept on the device: step_counter[0] = steps TAKEN so far (zeroed by the caller once); the bias
+ * corrections use step_counter[0] + 1 and a one-thread node behind the update increments it -- unless skip_nonfinite dropped the
+ * step, so a skipped step does not advance the bias correction (torch AdamW under GradScaler.step, trainer.py:146).  No host
+ * synchronisation, capturable. */
+int jen1_adamw_step_counted(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t* step_counter, const float* gnorm_sq, float max_norm, int skip_nonfinite,
+                            void* stream);
 
 const char* jen1_last_error(void);
 /* "gfx950" build tag + ABI version, for the loader's sanity check */

@@ -149,10 +149,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   const int cpf = ld / JEN1_FINE_GROUPS;
   const T* p = x + (size_t)b * L * ld + fg * cpf;
   const int n = L * cpf;
-  const float inv_cpf = 1.0f / (float)cpf;
   float s = 0.f, q = 0.f;
   for (int e = threadIdx.x; e < n; e += 256) {
-    const int r = (int)(((float)e + 0.5f) * inv_cpf), c = e - r * cpf;
+    const int r = e / cpf, c = e - r * cpf;      // (integer division: a rounded float reciprocal picks the wrong row beyond ~2.8 M elements)
     const float v = (float)p[(size_t)r * ld + c];
     s += v;
     q += v * v;
@@ -177,7 +176,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 // LearnedPositionalEmbedding + Linear + GELU (utils/module.py:58-79; model.py:84-89, :286-291).
 // The phase is ((t * w) * 2) * pi evaluated left to right in float32 exactly like the reference:
 // at t = 999 the argument is ~2e4 rad, one float32 ulp there is 2e-3 rad.
-__global__ __launch_bounds__(256) void time_features_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
+template <typename TT>
+__global__ __launch_bounds__(256) void time_features_kernel(const TT* __restrict__ t, const float* __restrict__ freq,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ out, int half, int out_features) {
   extern __shared__ float feat[];   // [2*half + 1]
@@ -357,7 +357,13 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
         eps = (sr * xv[k] - x0) / srm1;
       }
       float xn;
-      if (last == 1.f) xn = x0;                                            // DDIM's final step (gdm.py:207-209)
+      if (last == 3.f) {
+        // VDM row {alpha_t, sigma_t, alpha_next, sigma_next} (vdm/vdm.py:52-55, v objective, no clamp), evaluated as written:
+        // x_pred = alpha x - sigma v; noise_pred = sigma x + alpha v; x = alpha' x_pred + sigma' noise_pred
+        x0 = sr * xv[k] - srm1 * o;
+        eps = srm1 * xv[k] + sr * o;
+        xn = sa_n * x0 + cc * eps;
+      } else if (last == 1.f) xn = x0;                                     // DDIM's final step (gdm.py:207-209)
       else if (last == 2.f) xn = x0 * sa_n + cc * xv[k] + sg * nv[k];      // DDPM row: posterior mean + sd * noise (gdm.py:144-163)
       else xn = x0 * sa_n + cc * eps + sg * nv[k];
       x_out[idx] = xn;
@@ -406,7 +412,7 @@ extern "C" int jen1_row_stats(const void* x, float* stats, int rows, int C, int 
 
 extern "C" int jen1_gn_stats(const void* x, float* stats, int B, int L, int ld, int dtype, void* stream) {
   JEN1_CHECK(x && stats && B >= 1 && L >= 1 && ld >= JEN1_FINE_GROUPS && ld % JEN1_FINE_GROUPS == 0, "gn_stats: bad arguments (ld=%d)", ld);
-  JEN1_CHECK((int64_t)L * (ld / JEN1_FINE_GROUPS) < (1 << 23), "gn_stats: %d rows are too many for the float index arithmetic", L);
+  JEN1_CHECK((int64_t)L * (ld / JEN1_FINE_GROUPS) < ((int64_t)1 << 31), "gn_stats: %d rows are too many for 32-bit element indices", L);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(JEN1_FINE_GROUPS, B);
   if (dtype == JEN1_F32) hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, L, ld);
@@ -422,7 +428,18 @@ extern "C" int jen1_time_features(const int64_t* t, const float* freq, const flo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int gy = (out_features + 3) / 4;
   if (gy > 64) gy = 64;
-  hipLaunchKernelGGL(time_features_kernel, dim3(n, gy), dim3(256), sizeof(float) * (2 * half + 1), s, t, freq, w, bias, out, half, out_features);
+  hipLaunchKernelGGL(time_features_kernel<int64_t>, dim3(n, gy), dim3(256), sizeof(float) * (2 * half + 1), s, t, freq, w, bias, out, half, out_features);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_time_features_f32(const float* t, const float* freq, const float* w, const float* bias, float* out,
+                                      int n, int half, int out_features, void* stream) {
+  JEN1_CHECK(t && freq && w && bias && out && n >= 1 && half >= 1 && out_features >= 1, "time_features_f32: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int gy = (out_features + 3) / 4;
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(time_features_kernel<float>, dim3(n, gy), dim3(256), sizeof(float) * (2 * half + 1), s, t, freq, w, bias, out, half, out_features);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

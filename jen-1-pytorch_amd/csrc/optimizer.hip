@@ -94,6 +94,7 @@ struct AdamArgs {
   int64_t n;
   float lr, beta1, beta2, eps, weight_decay, max_norm, bc1, inv_sqrt_bc2;
   int32_t skip_nonfinite;
+  const int32_t* step_counter;      // device-side count of the steps TAKEN so far (nullptr: bc1 / inv_sqrt_bc2 come from the host)
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float coef) {
@@ -105,8 +106,15 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
   p -= (a.lr / a.bc1) * (m / denom);
 }
 
-__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(const AdamArgs a) {
+__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(AdamArgs a) {
   float coef = 1.0f;
+  if (a.step_counter) {
+    // bias corrections of step (taken so far + 1), in double like the host form; a skipped step (skip_nonfinite) does not count,
+    // which is what GradScaler.step does with torch's AdamW (trainer.py:146)
+    const double t = (double)(a.step_counter[0] + 1);
+    a.bc1 = (float)(1.0 - pow((double)a.beta1, t));
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, t)));
+  }
   if (a.gnorm_sq) {
     const float nrm = sqrtf(a.gnorm_sq[0]);
     if (a.skip_nonfinite && !(nrm <= 3.0e38f)) return;          // inf / nan gradients: leave parameters and moments untouched
@@ -140,6 +148,12 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(const AdamArgs a) {
   }
 }
 
+// behind adamw_kernel on the same stream: count the step unless it was skipped
+__global__ void adamw_advance_kernel(int32_t* step_counter, const float* gnorm_sq, int skip_nonfinite) {
+  if (skip_nonfinite && gnorm_sq && !(sqrtf(gnorm_sq[0]) <= 3.0e38f)) return;
+  step_counter[0] += 1;
+}
+
 }  // namespace
 
 static int launch_sqnorm(const float* g, int64_t n, float* out, float* partials, unsigned* ticket, void* stream) {
@@ -169,13 +183,32 @@ extern "C" int jen1_grad_sqnorm_ws(const float* g, int64_t n, float* out, void* 
   return launch_sqnorm(g, n, out, partials, reinterpret_cast<unsigned*>(partials + OPT_MAX_BLOCKS), stream);
 }
 
+static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, int32_t* step_counter, const float* gnorm_sq, float max_norm, int skip_nonfinite,
+                        void* stream);
+
 extern "C" int jen1_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int step, const float* gnorm_sq, float max_norm, int skip_nonfinite, void* stream) {
+  JEN1_CHECK(step >= 1, "adamw_step: bad step");
+  return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, gnorm_sq, max_norm, skip_nonfinite, stream);
+}
+
+extern "C" int jen1_adamw_step_counted(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                       float eps, float weight_decay, int32_t* step_counter, const float* gnorm_sq, float max_norm,
+                                       int skip_nonfinite, void* stream) {
+  JEN1_CHECK(step_counter, "adamw_step_counted: null step counter");
+  return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, 1, step_counter, gnorm_sq, max_norm, skip_nonfinite, stream);
+}
+
+static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, int32_t* step_counter, const float* gnorm_sq, float max_norm, int skip_nonfinite,
+                        void* stream) {
   JEN1_CHECK(p && g && m && v && n > 0, "adamw_step: null pointer or empty tensor");
   JEN1_CHECK(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0,
              "adamw_step: buffers must be 16-byte aligned");
-  JEN1_CHECK(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adamw_step: bad step / betas");
+  JEN1_CHECK(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adamw_step: bad betas");
   AdamArgs a;
+  a.step_counter = step_counter;
   a.p = p; a.g = g; a.m = m; a.v = v; a.gnorm_sq = gnorm_sq; a.n = n;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.max_norm = max_norm;
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
@@ -186,6 +219,7 @@ extern "C" int jen1_adamw_step(float* p, const float* g, float* m, float* v, int
   int64_t blocks = (nv + OPT_THREADS - 1) / OPT_THREADS;
   blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, a);
+  if (step_counter) hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, s, step_counter, gnorm_sq, skip_nonfinite);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

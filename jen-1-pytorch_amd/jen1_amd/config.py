@@ -100,6 +100,16 @@ class GDMConfig:
 
 
 @dataclass
+class VDMConfig:
+    """reference utils/config.py:35-42."""
+    loss_type: str = "l2"
+    cfg_dropout_proba: float = 0.2
+    embedding_scale: float = 0.8
+    batch_cfg: bool = True
+    scale_cfg: bool = True
+
+
+@dataclass
 class OptimizerConfig:
     """reference utils/config.py:76-82, :96."""
     lr: float = 3e-5
@@ -108,6 +118,20 @@ class OptimizerConfig:
     weight_decay: float = 0.1
     grad_clip: float = 0.7
     grad_accum_every: int = 10
+
+
+@dataclass
+class TrainConfig:
+    """the fields of reference utils/config.py:84-100 (``Config``) that the trainer reads."""
+    save_dir: str = ""
+    use_fp16: bool = False
+    tasks: List[str] = field(default_factory=lambda: ["text_guided", "music_inpaint", "music_cont"])
+    num_epoch: int = 100
+    eval_interval: int = 30
+    grad_accum_every: int = 10
+    device: str = "cuda"
+    diffusion_type: str = "gdm"
+    optimizer_config: OptimizerConfig = field(default_factory=OptimizerConfig)
 
 
 @dataclass

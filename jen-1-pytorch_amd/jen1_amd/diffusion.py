@@ -323,7 +323,7 @@ class DDIMStepper:
 
     def __init__(self, gd: GaussianDiffusion, model: UNetCFG1d, shape, conditioning, causal=False, use_graph=True,
                  n_streams: Optional[int] = None, plan_slot: int = 0, mode: str = "ddim"):
-        assert mode in ("ddim", "ddpm")
+        assert mode in ("ddim", "ddpm", "vdm")
         self.gd, self.model, self.mode = gd, model, mode
         B, C, T = shape
         self.shape = (B, C, T)
@@ -337,11 +337,12 @@ class DDIMStepper:
             n_streams = int(os.environ.get("JEN1_STREAMS", "1"))
         n_streams = max(1, min(n_streams, B))
         sizes = [B // n_streams + (1 if i < B % n_streams else 0) for i in range(n_streams)]
-        self.coef, self.times = gd.ddim_coeff_table() if mode == "ddim" else gd.ddpm_coeff_table()
+        # "vdm": ``gd`` is a jen1_amd.vdm.VDM -- rows {alpha_t, sigma_t, alpha_next, sigma_next} and continuous float times
+        self.coef, self.times = gd.ddim_coeff_table() if mode == "ddim" else (gd.ddpm_coeff_table() if mode == "ddpm" else gd.coeff_table())
         S = self.num_steps = int(self.times.numel())
         self.coef = self.coef.contiguous()
-        # per-step noise table [S][B][C][T] (614 MB at B=8, T=1500: nothing against 288 GB of HBM)
-        self.noise_all = torch.zeros((S,) + tuple(shape), dtype=torch.float32, device=dev)
+        # per-step noise table [S][B][C][T] (614 MB at B=8, T=1500: nothing against 288 GB of HBM); VDM's update draws none
+        self.noise_all = torch.zeros(((S,) + tuple(shape)) if mode != "vdm" else (1, 1, 1, 1), dtype=torch.float32, device=dev)
         self._noise_fresh = False
         self._cond = conditioning                     # keep the conditioning tensors alive
         Co = model.spec.out_channels
@@ -361,15 +362,16 @@ class DDIMStepper:
             cc = conditioning["input_concat_cond"]
             model._prepare(plan, plan.x_in, None, emb, msk, [None if cc is None else cc[sl]], None)
             plan._cond_refs = (emb, msk)              # the K/V cache key holds weakrefs: keep the slices alive
-            plan.t_in.copy_(self.times)
+            plan.set_times(self.times)
             plan.run_time(s0)                         # FiLM / time-token K/V tables for all S timesteps
             net = plan.net_out
             # noise table slice of this sub-batch: row stride is the full batch, so give each part its own
             # contiguous table when the batch is split
-            ntab = self.noise_all if len(sizes) == 1 else torch.zeros((S, nb, C, T), dtype=torch.float32, device=dev)
-            args = (net.t.data_ptr(), plan.x_in.data_ptr(), ntab.data_ptr(), self.coef.data_ptr(),
+            ntab = self.noise_all if (len(sizes) == 1 or mode == "vdm") else torch.zeros((S, nb, C, T), dtype=torch.float32, device=dev)
+            args = (net.t.data_ptr(), plan.x_in.data_ptr(), ntab.data_ptr() if mode != "vdm" else None, self.coef.data_ptr(),
                     plan.x_in.data_ptr(), None, None, plan.step_idx.data_ptr(), nb, Co, T, net.ld, self.nrep,
-                    float(gd.embedding_scale), 1 if (cfg and gd.scale_cfg) else 0, 0.7, _OBJ[gd.objective], 1, eng.dt)
+                    float(gd.embedding_scale), 1 if (cfg and gd.scale_cfg) else 0, 0.7, _OBJ[getattr(gd, "objective", "v")],
+                    0 if mode == "vdm" else 1, eng.dt)
             sp = plan.step_idx.data_ptr()
 
             def run(s, plan=plan, args=args, sp=sp):
@@ -432,9 +434,11 @@ class DDIMStepper:
         """once per sampling run (one host sync): a dependency wait of the persistent deep-level launch that timed out leaves an
         error word behind instead of hanging the GPU; results are garbage then and must not be returned silently"""
         for _, plan, _, _ in self.parts:
-            if getattr(plan, "deep_level", None) is not None and plan.deep.error() != 0:
-                raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {plan.deep.error() - 1} timed out "
-                                     "(another persistent launch on the same GPU?)")
+            if getattr(plan, "deep_level", None) is not None:
+                e = plan.deep.take_error()
+                if e:
+                    raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {e - 1} timed out "
+                                         "(another persistent launch on the same GPU?); the error word was cleared")
 
     def _set_step(self, i: int):
         for _, plan, _, _ in self.parts:
@@ -447,7 +451,7 @@ class DDIMStepper:
         x0 = x0.to(torch.float32)
         for sl, plan, _, _ in self.parts:
             plan.x_in.copy_(x0[sl])
-        if fresh_noise:
+        if fresh_noise and self.mode != "vdm":
             if self.mode == "ddim":
                 self.noise_all.normal_()
             else:
@@ -456,7 +460,7 @@ class DDIMStepper:
         self._set_step(0)
 
     def _push_noise(self, i):
-        if len(self.parts) == 1:
+        if len(self.parts) == 1 or self.mode == "vdm":
             return
         for sl, _, _, ntab in self.parts:
             if i is None:
@@ -470,7 +474,7 @@ class DDIMStepper:
         if set_rows:
             for sl, plan, _, _ in self.parts:
                 plan.set_rows(None if drop_rows is None else torch.as_tensor(drop_rows)[sl])
-        if noise is not None and i < self.num_steps - 1:
+        if noise is not None and i < self.num_steps - 1 and self.mode != "vdm":
             self.noise_all[i].copy_(noise.to(self.noise_all.device, torch.float32))
             self._push_noise(i)
         if self.graphs is not None:

@@ -20,6 +20,7 @@ Design notes (DESIGN.md has the long form):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import os
@@ -308,6 +309,14 @@ class DeepProgram:
     def error(self) -> int:
         """non-zero after a launch whose dependency wait timed out (1 + phase index); synchronises with the device"""
         return int(self.err[0].item())
+
+    def take_error(self) -> int:
+        """``error()``, and the word is cleared when it was set: one transient time-out must not leave the cached plan 'dead'
+        (every later launch would fall through its waits on the stale word)"""
+        e = self.error()
+        if e:
+            self.err.zero_()
+        return e
 
 
 class KernelCtx:
@@ -944,6 +953,9 @@ class Plan(OpBuilder):
         self.ctx_in = torch.zeros((B, max(Cc, 1), T), dtype=f32, device=dev)
         NT_ = self.n_t
         self.t_in = torch.zeros((NT_,), dtype=torch.int64, device=dev)
+        # continuous times (VDM: t in [0, 1], vdm/vdm.py:44): ``t_float`` switches the two time-feature launches to this buffer
+        self.t_in_f = torch.zeros((NT_,), dtype=torch.float32, device=dev)
+        self.t_float = False
         self.step_idx = torch.zeros((1,), dtype=torch.int32, device=dev)
         F, NL = spec.ctx_features, spec.ctx_max_length
         self.emb_in = torch.zeros((B, NL, F), dtype=f32, device=dev)
@@ -975,9 +987,8 @@ class Plan(OpBuilder):
         self.mapping = torch.empty((NT_, mf), dtype=f32, device=dev)
         self._keep += [tf, m1]          # referenced by raw pointer below
         v = W.v
-        a = (self.t_in.data_ptr(), v["to_time.0.0.weights"].data_ptr(), v["to_time.0.1.weight"].data_ptr(),
-             v["to_time.0.1.bias"].data_ptr(), tf.data_ptr(), NT_, half, mf)
-        tops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
+        a = (v["to_time.0.0.weights"].data_ptr(), v["to_time.0.1.weight"].data_ptr(), v["to_time.0.1.bias"].data_ptr(), tf.data_ptr(), NT_, half, mf)
+        tops.append(lambda s, a=a: self._time_features(a, s))
         a = (tf.data_ptr(), v["to_mapping.0.weight"].data_ptr(), v["to_mapping.0.bias"].data_ptr(), m1.data_ptr(), NT_, mf, mf, L.ACT_GELU)
         tops.append(lambda s, a=a: L.check(lib.jen1_linear_f32(*a, s), "jen1_linear_f32"))
         a = (m1.data_ptr(), v["to_mapping.2.weight"].data_ptr(), v["to_mapping.2.bias"].data_ptr(), self.mapping.data_ptr(), NT_, mf, mf, L.ACT_GELU)
@@ -992,8 +1003,18 @@ class Plan(OpBuilder):
         self.film2 = torch.empty_like(self.film)
         if self.deep_level is not None:
             film, film2, fa, fb, fp = self.film, self.film2, W.film2_a, W.film2_b, W.film2_partner
-            tops.append(lambda s, film=film, film2=film2, fa=fa, fb=fb, fp=fp:
-                        torch.add(fa * (film.index_select(1, fp) + 1.0), fb * film, out=film2))
+            tmp_a, tmp_b = torch.empty_like(film), torch.empty_like(film)
+
+            def film2_op(s, film=film, film2=film2, fa=fa, fb=fb, fp=fp, tmp_a=tmp_a, tmp_b=tmp_b, dev=dev):
+                # torch elementwise plumbing on the stream the other time ops were given (not necessarily torch's current one)
+                cur = torch.cuda.current_stream(dev)
+                ctx = torch.cuda.stream(torch.cuda.ExternalStream(s, device=dev)) if s != cur.cuda_stream else contextlib.nullcontext()
+                with ctx:
+                    torch.index_select(film, 1, fp, out=tmp_a)
+                    tmp_a.add_(1.0).mul_(fa)
+                    torch.mul(film, fb, out=tmp_b)
+                    torch.add(tmp_a, tmp_b, out=film2)
+            tops.append(film2_op)
 
         # ---- 3. time token of the text context -> its K/V row for every cross-attention ------------
         self.kv_ctx: Dict[str, torch.Tensor] = {}
@@ -1005,9 +1026,9 @@ class Plan(OpBuilder):
         if spec.use_xattn_time and n_tr:
             tok = torch.empty((NT_, F), dtype=f32, device=dev)
             self._keep.append(tok)
-            a = (self.t_in.data_ptr(), v["to_time_embedding.0.0.weights"].data_ptr(), v["to_time_embedding.0.1.weight"].data_ptr(),
+            a = (v["to_time_embedding.0.0.weights"].data_ptr(), v["to_time_embedding.0.1.weight"].data_ptr(),
                  v["to_time_embedding.0.1.bias"].data_ptr(), tok.data_ptr(), NT_, half, F)
-            tops.append(lambda s, a=a: L.check(lib.jen1_time_features(*a, s), "jen1_time_features"))
+            tops.append(lambda s, a=a: self._time_features(a, s))
             tok_rs = torch.zeros((NT_ * 2,), dtype=f32, device=dev)     # outside the per-step arena
             tok_t = Act(self._empty((1, NT_, F)), 1, NT_, F, F, rs=tok_rs)
             self._add_cast(tops, tok, tok_t.t)
@@ -1098,6 +1119,22 @@ class Plan(OpBuilder):
         # ---- split-K workspace shared by all launches of the plan (stream-ordered reuse) -----------
         self.finalize_workspace()
         self.n_launch = len(self.ops) + (0 if self.table_mode else len(self.time_ops))
+
+    def _time_features(self, a, s):
+        lib = self.eng.lib
+        if self.t_float:
+            L.check(lib.jen1_time_features_f32(self.t_in_f.data_ptr(), *a, s), "jen1_time_features_f32")
+        else:
+            L.check(lib.jen1_time_features(self.t_in.data_ptr(), *a, s), "jen1_time_features")
+
+    def set_times(self, time: torch.Tensor):
+        """raw int64 timesteps (GaussianDiffusion) or continuous float times (VDM) of the next ``run`` / ``run_time``"""
+        if time.is_floating_point():
+            self.t_in_f.copy_(time.to(torch.float32))
+            self.t_float = True
+        else:
+            self.t_in.copy_(time.to(torch.int64))
+            self.t_float = False
 
     def run_time(self, stream: Optional[int] = None):
         """timestep-only work (time MLP -> FiLM table, time token -> K/V rows) for every entry of t_in"""

@@ -106,6 +106,7 @@ SYMBOLS = {
     "jen1_row_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_gn_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_time_features": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "jen1_time_features_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "jen1_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_cfg_ddim_step": (c_int, [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
     "jen1_step_advance": (c_int, [_P, _P]),
@@ -114,6 +115,7 @@ SYMBOLS = {
     "jen1_grad_sqnorm_scratch_bytes": (c_int64, []),
     "jen1_grad_sqnorm_ws": (c_int, [_P, c_int64, _P, _P, _P]),
     "jen1_adamw_step": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [c_int, _P, c_float, c_int, _P]),
+    "jen1_adamw_step_counted": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [_P, _P, c_float, c_int, _P]),
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
     "jen1_train_gemm": (c_int, [C.POINTER(GemmArgs), _P]),
     "jen1_gn_sums": (c_int, [_P, _P] + [c_int] * 6 + [_P]),

@@ -154,7 +154,7 @@ class UNetCFG1d(nn.Module):
     def _prepare(self, plan: Plan, x, time, embedding, embedding_mask, channels_list, drop_rows, uncond_only=False):
         plan.x_in.copy_(x.to(torch.float32))
         if not plan.table_mode:
-            plan.t_in.copy_(time.to(torch.int64))
+            plan.set_times(time)
         if self.spec.ctx_ch0:
             assert channels_list is not None and channels_list[0] is not None, "Missing context"   # model.py:189
             ch = channels_list[0]
@@ -171,6 +171,17 @@ class UNetCFG1d(nn.Module):
                              None if embedding_mask is None else weakref.ref(embedding_mask),
                              None if embedding_mask is None else embedding_mask._version)
         plan.set_rows(drop_rows, uncond_only)
+
+    def _check_deep(self, plan: Plan) -> None:
+        """the persistent deep-level launch replaces a hang by an error word (a dependency wait that timed out: its workgroups
+        were not all resident, e.g. another persistent launch held CUs); the results are garbage then and ``forward`` must not
+        return them.  One host sync per call -- ``forward`` returns a tensor the caller reads next anyway; the fused sampler
+        checks once per sampling run instead (DDIMStepper.check)."""
+        if getattr(plan, "deep_level", None) is not None:
+            e = plan.deep.take_error()
+            if e:
+                raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {e - 1} timed out (another persistent "
+                                     "launch on the same GPU?); the error word was cleared, the call can be repeated")
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -204,6 +215,7 @@ class UNetCFG1d(nn.Module):
                 self._prepare(plan, x, time, embedding, embedding_mask, channels_list, drop)
                 plan.run(s)
                 net = plan.net_out
+                self._check_deep(plan)
             else:
                 plan = eng.plan(B, T, 1, causal)
                 both = torch.empty((2 * B, T, plan.net_out.ld), dtype=eng.tdtype, device=self._device)
@@ -213,6 +225,7 @@ class UNetCFG1d(nn.Module):
                 plan.set_rows(None, uncond_only=True)
                 plan.run(s)
                 both[B:].copy_(plan.net_out.t)
+                self._check_deep(plan)
                 net = type(plan.net_out)(both, 2 * B, T, Co, plan.net_out.ld)
             L.check(lib.jen1_cfg_combine(net.t.data_ptr(), out.data_ptr(), B, Co, T, net.ld, float(embedding_scale),
                                          1 if scale_cfg else 0, float(scale_phi), eng.dt, s), "jen1_cfg_combine")
@@ -222,4 +235,5 @@ class UNetCFG1d(nn.Module):
         plan.run(s)
         L.check(lib.jen1_unpack_output(plan.net_out.t.data_ptr(), out.data_ptr(), B, Co, T, plan.net_out.ld, eng.dt, s),
                 "jen1_unpack_output")
+        self._check_deep(plan)
         return out

@@ -61,13 +61,22 @@ class FusedAdamW:
             p.data = self.flat_param[o:o + p.numel()].view_as(p)
             p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        # (skip_nonfinite: the kernel leaves p / m / v untouched when the norm is not finite, but ``step_count`` -- which the bias
-        # correction is computed from on the host -- still advances; GradScaler would not count the skipped step)
         self.max_norm, self.skip_nonfinite = max_norm, skip_nonfinite
-        self.step_count = 0
+        # the number of steps TAKEN lives on the device (jen1_adamw_step_counted): the kernel derives the bias corrections from it
+        # and a step dropped by ``skip_nonfinite`` does not advance it -- GradScaler.step semantics (trainer.py:146)
+        self._steps = torch.zeros(1, dtype=torch.int32, device=dev)
         self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sq_scratch: Optional[torch.Tensor] = None       # block partials + arrival ticket of the norm, owned by this optimiser
         self.post_step_hooks = []      # callables run after every step (TrainGraph.invalidate: re-pack the compute weights)
+
+    @property
+    def step_count(self) -> int:
+        """optimiser steps taken so far (one host sync; checkpoints and tests read it, the training loop does not)"""
+        return int(self._steps.item())
+
+    @step_count.setter
+    def step_count(self, n: int) -> None:
+        self._steps.fill_(int(n))
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
@@ -82,7 +91,6 @@ class FusedAdamW:
         if self.flat_param.device.type != "cuda":
             raise L.Jen1HipError("FusedAdamW.step needs a ROCm GPU; no CPU path exists in this package")
         s = torch.cuda.current_stream(self.flat_param.device).cuda_stream
-        self.step_count += 1
         gn = None
         if self.max_norm is not None or self.skip_nonfinite:
             self._gnorm_sq.zero_()
@@ -91,10 +99,11 @@ class FusedAdamW:
             L.check(lib.jen1_grad_sqnorm_ws(self.flat_grad.data_ptr(), self.numel, self._gnorm_sq.data_ptr(), self._sq_scratch.data_ptr(), s),
                     "jen1_grad_sqnorm_ws")
             gn = self._gnorm_sq.data_ptr()
-        L.check(lib.jen1_adamw_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                    self.numel, float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                    float(self.weight_decay), self.step_count, gn, float(self.max_norm or 0.0), 1 if self.skip_nonfinite else 0, s),
-                "jen1_adamw_step")
+        L.check(lib.jen1_adamw_step_counted(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                            self.exp_avg_sq.data_ptr(), self.numel, float(self.lr if lr is None else lr), float(self.betas[0]),
+                                            float(self.betas[1]), float(self.eps), float(self.weight_decay), self._steps.data_ptr(), gn,
+                                            float(self.max_norm or 0.0), 1 if self.skip_nonfinite else 0, s),
+                "jen1_adamw_step_counted")
         for h in self.post_step_hooks:
             h()
 
@@ -108,10 +117,11 @@ class FusedAdamW:
         group = dict(proto)
         group["params"] = list(range(len(self.params)))
         state = {}
-        if self.step_count > 0:
+        step_count = self.step_count
+        if step_count > 0:
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
-                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
+                state[i] = {"step": torch.tensor(float(step_count)), "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
                             "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
         return {"state": state, "param_groups": [group]}
 
@@ -168,27 +178,57 @@ class GradExchange:
     tail: the tiny global embeddings) go out in ``finish``.  Mean over ranks; the result is bit-identical to one blocking
     all-reduce of the whole buffer chunked the same way (same chunks, same reduction)."""
 
-    def __init__(self, opt: "FusedAdamW", names: List[str], group=None, bucket_bytes: int = 128 << 20):
+    def __init__(self, opt: "FusedAdamW", names: List[str], group=None, bucket_bytes: int = 128 << 20, params: Optional[dict] = None,
+                 grad_dtype: str = "f32"):
+        """``params``: ``dict(model.named_parameters())`` -- checked against the optimiser's parameter list by identity (an
+        optimiser built over a re-ordered or filtered list would mis-assign regions).  ``grad_dtype="bf16"``: every chunk is
+        rounded to bfloat16 for the wire and widened again (half the xGMI bytes, two extra passes over the chunk in HBM; the mean
+        is then only bf16-accurate) -- off by default, like torch DDP's bf16 compression hook."""
         import torch.distributed as dist
+        assert grad_dtype in ("f32", "bf16")
         self.opt, self.group, self.bucket = opt, group, max(1, bucket_bytes // 4)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_available() and dist.is_initialized() else None
         assert len(names) == len(opt.params)
+        if params is not None:
+            for n, p in zip(names, opt.params):
+                assert params[n] is p, f"optimiser parameter order differs from the model's at {n!r}"
         self.regions: "dict[str, tuple[int, int]]" = {}
         for n, p, o in zip(names, opt.params, opt.offsets):
             r = ".".join(n.split(".")[:2]) if n.startswith(("downsamples.", "upsamples.")) else n.split(".")[0]
             lo, hi = self.regions.get(r, (o, o))
             self.regions[r] = (min(lo, o), max(hi, o + (p.numel() + 3) // 4 * 4))
+        # regions are contiguous slices of the flat buffer: disjoint, and together they cover it (each is reduced exactly once)
+        spans = sorted(self.regions.values())
+        assert spans[0][0] == 0 and spans[-1][1] == opt.numel and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), \
+            "parameter regions must tile the flat gradient buffer"
+        self.bf16 = grad_dtype == "bf16"
+        self._wire: Optional[torch.Tensor] = None
         self.active = False
+        # debugging aid for one step: instead of sending a region when its hook fires, keep a copy of it; ``finish`` checks that
+        # no gradient landed in the region afterwards (the ordering assumption the overlap rests on), then sends everything
+        self.debug_check = False
+        self._snap: "dict[str, torch.Tensor]" = {}
         self._comm = None
         self._works, self._expect, self._sent = [], {}, set()
+        self.sent_during_pass = 0         # regions that left before finish() (what the overlap test and the bench report)
+
+    @property
+    def capturable(self) -> bool:
+        """RCCL collectives on device buffers can be recorded into the replayed backward pass; gloo / CPU cannot"""
+        return self.world > 1 and self.backend == "nccl" and self.opt.flat_grad.is_cuda
 
     def begin(self) -> None:
         """arm the exchange for the backward pass(es) that follow (the last micro-batch of an accumulation window)"""
         self.active = self.world > 1
         self._works, self._expect, self._sent = [], {}, set()
+        self.sent_during_pass = 0
         g = self.opt.flat_grad
         if self.active and g.is_cuda and self._comm is None:
             self._comm = torch.cuda.Stream(g.device)
+        if self.active and self.bf16 and self._wire is None:
+            self._wire = torch.empty(min(self.bucket, g.numel()), dtype=torch.bfloat16, device=g.device)
+        self._snap = {}
 
     def expect(self, region: str) -> None:
         """a forward pass registered one more hook for ``region`` (several sub-batches share one backward pass)"""
@@ -201,39 +241,70 @@ class GradExchange:
         self._expect[region] = left
         if left > 0:
             return
+        self.sent_during_pass += 1
+        if self.debug_check:
+            lo, hi = self.regions[region]
+            self._snap[region] = self.opt.flat_grad[lo:hi].clone()
+            return
         self._send(region)
 
-    def _send(self, region: str) -> None:
+    def _reduce(self, chunk: torch.Tensor, sync: bool) -> None:
         import torch.distributed as dist
+        if self.bf16:
+            w = self._wire[:chunk.numel()]
+            w.copy_(chunk)
+            dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)       # (the wire buffer is reused: stream-ordered, not async)
+            chunk.copy_(w)
+        elif sync:
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _send(self, region: str) -> None:
         self._sent.add(region)
         lo, hi = self.regions[region]
         g = self.opt.flat_grad
         if g.is_cuda:
-            self._comm.wait_stream(torch.cuda.current_stream(g.device))      # the gradients of the region are enqueued before this point
+            cur = torch.cuda.current_stream(g.device)
+            capturing = torch.cuda.is_current_stream_capturing()
+            self._comm.wait_stream(cur)      # the gradients of the region are enqueued before this point
             with torch.cuda.stream(self._comm):
                 for o in range(lo, hi, self.bucket):
-                    self._works.append(dist.all_reduce(g[o:min(hi, o + self.bucket)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    # while a graph is being recorded the collective is a node of it: issued in stream order on the communication
+                    # stream (forked from the capturing stream above, joined in ``finish``), no Work handle to wait on
+                    self._reduce(g[o:min(hi, o + self.bucket)], sync=capturing)
         else:
             for o in range(lo, hi, self.bucket):
-                self._works.append(dist.all_reduce(g[o:min(hi, o + self.bucket)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce(g[o:min(hi, o + self.bucket)], sync=False)
 
     def finish(self) -> None:
-        """after the backward pass: send what is left (in reverse order), wait, turn the sums into means"""
+        """after the backward pass: send what is left (in reverse order), wait, turn the sums into means.  Called while a graph is
+        being recorded (``GraphedLossStep``) it records the same: the replay then carries the whole exchange."""
         if not self.active:
             return
+        for region, snap in self._snap.items():
+            lo, hi = self.regions[region]
+            if not torch.equal(snap, self.opt.flat_grad[lo:hi]):
+                raise RuntimeError(f"GradExchange: gradients of region {region!r} changed after its hook fired")
+        self._snap = {}
         for region in reversed(list(self.regions)):
             if region not in self._sent:
                 self._send(region)
         for w in self._works:
             w.wait()
+        self._works = []
         g = self.opt.flat_grad
         if g.is_cuda:
             torch.cuda.current_stream(g.device).wait_stream(self._comm)
         g.mul_(1.0 / self.world)
         self.active = False
 
+    def done_in_graph(self) -> None:
+        """a replayed graph that carries the exchange has been enqueued: nothing is left for ``finish``"""
+        self.active = False
+
     def blocking(self) -> None:
-        """the same exchange with no overlap (graph-replayed backward passes): every region, reverse order, then wait"""
+        """the same exchange with no overlap: every region, reverse order, then wait"""
         self.begin()
         self.finish()
 

@@ -68,3 +68,25 @@ def noise_list(n: int, shape, seed: int = 0, uniform: bool = False):
     if uniform:
         return [fill_uniform(f"synth.noise.{i}", shape, seed, 0.0, 1.0) for i in range(n)]
     return [fill_normal(f"synth.noise.{i}", shape, seed) for i in range(n)]
+
+
+TRAIN8_TASKS = (("text_guided", 3, False), ("music_inpaint", 3, False), ("music_cont", 2, True))
+
+
+def train8_inputs(T: int = 1500):
+    """BASELINE configs[3] per-GPU shape: 8 clips as the 3 / 3 / 2 task sub-batches of one micro-batch (reference
+    trainer.py:183-213), every sub-batch with its own text conditioning, its task's mask applied to ITS clips
+    (trainer.py:197-203), timesteps and uniform noise (gdm.py:247).  -> [(task, x0, t, conditioning, noise, causal)];
+    shared by the golden generator (tests/golden/make_golden.py fulltrain8) and the tests."""
+    x_all = latents(8, T, key="clip8")
+    tt = np.array([17, 801, 417, 999, 0, 250, 640, 93], dtype=np.int64)
+    parts, o = [], 0
+    for task, b, causal in TRAIN8_TASKS:
+        x0 = x_all[o:o + b]
+        cond = conditioning(b, T, task)
+        keep = cond["input_concat_cond"][:, 128:129] if task != "text_guided" else np.zeros((b, 1, T), dtype=np.float32)
+        cond["input_concat_cond"] = np.concatenate([x0 * keep, np.broadcast_to(keep, (b, 1, T))], axis=1).astype(np.float32)
+        noise = fill_uniform(f"synth.trainnoise8.{task}", (b, 128, T), 3, 0.0, 1.0)
+        parts.append((task, x0, tt[o:o + b], cond, noise, causal))
+        o += b
+    return parts

@@ -800,6 +800,12 @@ class GraphedLossStep:
     def __init__(self, graph: TrainGraph, diffusion, scale: float = 1.0):
         self.graph, self.diffusion, self.scale = graph, diffusion, scale
         self._captured: Dict[tuple, tuple] = {}
+        # an armed optim.GradExchange (the trainer sets it for the LAST pass of an accumulation window): with RCCL the per-region
+        # all-reduces are recorded into a second variant of the captured pass -- TrainGraph's hooks fire while the backward is
+        # being recorded, each region's collective becomes a graph node on the communication stream behind the kernels that
+        # complete the region, and the replay overlaps the exchange with the rest of the backward pass exactly like the eager
+        # hooks do (DDP, train.py:88-89).  Backends that cannot be recorded (gloo) get the blocking exchange behind the replay.
+        self.exchange = None
 
     def _body(self, static, causal):
         cond = {"cross_attn_cond": static["emb"], "cross_attn_masks": static["mask"], "global_cond": None,
@@ -814,13 +820,14 @@ class GraphedLossStep:
         ((per_sample * static["w"]).sum() * self.scale).backward()
         return per_sample.detach()
 
-    def _capture(self, key, x0, t, conditioning, causal, weights=None):
+    def _capture(self, key, x0, t, conditioning, causal, weights=None, exchange=None):
         params = list(self.graph.p.values())
         static = {"x0": x0.clone(), "t": t.clone(), "emb": conditioning["cross_attn_cond"].clone(),
                   "mask": None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"].clone(),
                   "concat": None if conditioning["input_concat_cond"] is None else conditioning["input_concat_cond"].clone(),
                   "w": None if weights is None else weights.to(torch.float32).clone()}
         keep = [None if p.grad is None else p.grad.clone() for p in params]       # the warm-up run must not leak into the gradients
+        saved_ex, self.graph.exchange = self.graph.exchange, None                 # (no collectives in the warm-up run)
         side = torch.cuda.Stream(self.graph.rt.device)
         side.wait_stream(torch.cuda.current_stream(self.graph.rt.device))
         with torch.cuda.stream(side):
@@ -834,8 +841,16 @@ class GraphedLossStep:
         del keep
         self.graph.rt.refresh_all()        # packed weights are refreshed OUTSIDE the graph (once per optimiser step)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss = self._body(static, causal)
+        self.graph.exchange = exchange
+        try:
+            if exchange is not None:
+                exchange.begin()
+            with torch.cuda.graph(g):
+                loss = self._body(static, causal)
+                if exchange is not None:
+                    exchange.finish()      # recorded: the leftover regions, the join of the communication stream, the 1 / world scale
+        finally:
+            self.graph.exchange = saved_ex
         self._captured[key] = (g, static, loss)
         return self._captured[key]
 
@@ -844,12 +859,15 @@ class GraphedLossStep:
         """replay (capture on first use) forward + backward of one pass; returns the loss, or with ``sample_weights`` [B] the
         per-sample losses [B] of the pass whose objective is their weighted sum"""
         assert conditioning.get("global_cond") is None
+        ex = self.exchange if (self.exchange is not None and self.exchange.active and self.exchange.capturable) else None
         key = (tuple(x0.shape), bool(causal), conditioning["cross_attn_masks"] is None, conditioning["input_concat_cond"] is None,
-               sample_weights is None)
+               sample_weights is None, ex is not None)
         hit = self._captured.get(key)
         first = hit is None
         if first:
-            hit = self._capture(key, x0, t, conditioning, bool(causal), sample_weights)
+            hit = self._capture(key, x0, t, conditioning, bool(causal), sample_weights, ex)
+            if ex is not None:
+                ex.begin()                 # (recording the exchange consumed the armed state; the replay below is the real pass)
         g, static, loss = hit
         if sample_weights is not None:
             static["w"].copy_(sample_weights)
@@ -862,4 +880,6 @@ class GraphedLossStep:
             static["concat"].copy_(conditioning["input_concat_cond"])
         self.graph.rt.refresh_all()
         g.replay()
+        if ex is not None:
+            ex.done_in_graph()
         return loss.clone()

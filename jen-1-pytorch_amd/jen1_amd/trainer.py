@@ -15,7 +15,7 @@ runs once per optimiser step, right before the clip -- the gradient exchange is 
 from __future__ import annotations
 
 import random as _random
-from typing import Callable, Dict, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -27,33 +27,95 @@ TASKS = ("text_guided", "music_inpaint", "music_cont")        # config.py:93
 
 
 class UnifiedMultiTaskTrainer:
-    """``conditioner(metadata, device)`` returns ``{"prompt": (embedding [b, 128, 1024], mask [b, 128])}`` like
-    ``MultiConditioner.forward`` (conditioners.py:182-208); ``model`` is a ``jen1_amd.model.UNetCFG1d``."""
+    """The reference's constructor (trainer.py:17-36), positional argument for positional argument, so the call site of
+    train.py:110-125 works unchanged:
 
-    def __init__(self, model, diffusion, conditioner: Callable, optimizer: FusedAdamW, lr_scheduler: Optional[LinearLR] = None,
-                 grad_accum_every: int = 10, tasks: Sequence[str] = TASKS, device="cuda", process_group=None,
-                 rng=_random, cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
-                 input_concat_ids: Sequence[str] = ("masked_input", "mask"), compute_dtype: Optional[str] = None,
-                 use_graph: bool = True, allow_uneven_tasks: bool = False, bucket_bytes: int = 128 << 20, merge_tasks: bool = True):
-        self.model, self.diffusion, self.conditioner, self.optimizer, self.lr_scheduler = model, diffusion, conditioner, optimizer, lr_scheduler
-        self.grad_accum_every, self.tasks, self.device, self.group, self.rng = grad_accum_every, tuple(tasks), device, process_group, rng
+        UnifiedMultiTaskTrainer(config, rank, epoch_str, global_step, model, diffusion, conditioner, dls, optimizer,
+                                lr_scheduler, scaler, logger, writers, grad_clip, grad_accum_every,
+                                cross_attn_cond_ids=['prompt'], global_cond_ids=[], input_concat_ids=['masked_input', 'mask'])
+
+    What each argument means here:
+      config        read for ``tasks``, ``device``, ``num_epoch``, ``eval_interval``, ``save_dir``, ``diffusion_type`` and
+                    ``optimizer_config.lr`` (utils/config.py:84-100; ``jen1_amd.config.TrainConfig`` has the same fields)
+      rank          rank 0 logs and writes scalars (trainer.py:151)
+      epoch_str / global_step   where ``train_loop`` resumes
+      model         ``jen1_amd.model.UNetCFG1d`` (a ``.module`` wrapper, as DDP adds one, is unwrapped: the gradient exchange is
+                    ``optim.GradExchange`` over ``process_group``, not a module wrapper)
+      diffusion     ``GaussianDiffusion`` (``diffusion_type == 'gdm'``) or ``VDM``
+      conditioner   ``conditioner(metadata, device) -> {"prompt": (embedding [b, 128, 1024], mask [b, 128])}``
+                    (MultiConditioner.forward, conditioners.py:182-208)
+      dls           (train_dl, valid_dl): iterables of ``(audio_emb, metadata)``
+      optimizer     ``FusedAdamW``, or a ``torch.optim.AdamW`` whose hyper-parameters (one group: train.py:56-60) are taken over
+                    into a ``FusedAdamW`` on the same parameters
+      lr_scheduler  ``optim.LinearLR``, or torch's ``LinearLR`` (start / end factor and total_iters are taken over), or None
+      scaler        accepted and NOT used: bf16 storage with float32 accumulation and master weights needs no loss scaling; its
+                    skip-on-overflow behaviour is ``FusedAdamW(skip_nonfinite=True)``, switched on when an enabled scaler is passed
+      logger / writers   ``logger.info`` lines and ``writer.add_scalar`` as in trainer.py:151-172 when given (None: silent)
+      grad_clip     the clip norm of the fused optimiser step (nn.utils.clip_grad_norm_, trainer.py:145)
+      grad_accum_every   micro-batches per optimiser step (trainer.py:139-149)
+    Keyword-only extras (not in the reference): ``process_group``, ``rng``, ``compute_dtype``, ``use_graph``,
+    ``allow_uneven_tasks``, ``bucket_bytes``, ``merge_tasks``.  ``UnifiedMultiTaskTrainer.build(model, diffusion, conditioner,
+    optimizer, ...)`` is the short form for code that has no config object."""
+
+    def __init__(self, config, rank: int, epoch_str: int, global_step: int, model, diffusion, conditioner: Callable, dls, optimizer,
+                 lr_scheduler, scaler, logger, writers, grad_clip, grad_accum_every: int,
+                 cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
+                 input_concat_ids: Sequence[str] = ("masked_input", "mask"), *, process_group=None, rng=_random,
+                 compute_dtype: Optional[str] = None, use_graph: bool = True, allow_uneven_tasks: bool = False,
+                 bucket_bytes: int = 128 << 20, merge_tasks: bool = True):
+        self.config = config
+        self.tasks = tuple(getattr(config, "tasks", TASKS))
+        self.device = getattr(config, "device", "cuda")
+        self.rank, self.epoch_str, self.global_step = rank, int(epoch_str), int(global_step)
+        model = model.module if hasattr(model, "module") else model
+        self.model, self.diffusion, self.conditioner = model, diffusion, conditioner
+        self.train_dl, self.valid_dl = dls if dls is not None else (None, None)
+        self.grad_clip, self.grad_accum_every = grad_clip, int(grad_accum_every)
+        self.scaler, self.logger = scaler, logger
+        self.writer, self.writer_val = writers if writers is not None else (None, None)
         self.cross_attn_cond_ids, self.global_cond_ids, self.input_concat_ids = cross_attn_cond_ids, global_cond_ids, input_concat_ids
+        self.best_avg_total_loss = float("inf")
+        self.group, self.rng = process_group, rng
+        self.is_gdm = getattr(config, "diffusion_type", "gdm") == "gdm"
+        scaling = bool(scaler is not None and getattr(scaler, "is_enabled", lambda: False)())
+        if isinstance(optimizer, torch.optim.Optimizer):
+            g = optimizer.param_groups
+            assert len(g) == 1, "the trainer optimises one parameter group (train.py:56-60)"
+            optimizer = FusedAdamW(list(model.parameters()), lr=g[0]["lr"], betas=tuple(g[0]["betas"]), eps=g[0]["eps"],
+                                   weight_decay=g[0]["weight_decay"], max_norm=grad_clip, skip_nonfinite=scaling)
+        else:
+            optimizer.max_norm = grad_clip if grad_clip is not None else optimizer.max_norm
+            optimizer.skip_nonfinite = optimizer.skip_nonfinite or scaling
+        if lr_scheduler is not None and not isinstance(lr_scheduler, LinearLR):
+            ls = lr_scheduler                # torch.optim.lr_scheduler.LinearLR (train.py:84)
+            lr_scheduler = LinearLR(optimizer.lr, getattr(ls, "start_factor", 1.0 / 3), getattr(ls, "end_factor", 1.0),
+                                    getattr(ls, "total_iters", 5), last_epoch=getattr(ls, "last_epoch", 0) - 1)
+        self.optimizer, self.lr_scheduler = optimizer, lr_scheduler
         self.graph = model.train_graph(compute_dtype)
         self.graph.attach_optimizer(optimizer)
         # forward + backward of one sub-batch replayed as a HIP graph (train.GraphedLossStep); the loss scaling of the
         # accumulation window (trainer.py:141) is folded into the captured backward
-        self.graphed = GraphedLossStep(self.graph, diffusion, 1.0 / grad_accum_every) if use_graph else None
+        self.graphed = GraphedLossStep(self.graph, diffusion, 1.0 / self.grad_accum_every) if (use_graph and self.is_gdm) else None
         self.grad_accum = 0
-        self.global_step = 0
         self.allow_uneven_tasks = allow_uneven_tasks
         # task sub-batches that drew the same ``causal`` flag run as ONE pass through the network (same loss: the sum of the
         # per-task means, each sample weighted 1 / its sub-batch size); False = the reference's literal one pass per task
-        self.merge_tasks = merge_tasks
+        self.merge_tasks = merge_tasks and self.is_gdm
         # DDP's gradient exchange (train.py:88-89): buckets in reverse execution order; in eager mode each bucket leaves as soon
-        # as the backward pass has finished it, behind a replayed graph the buckets leave together right after the replay
+        # as the backward pass has finished it, behind a replayed graph the regions leave between the segments of the replay
         names = [n for n, _ in model.named_parameters()]
-        self.exchange = GradExchange(optimizer, names, process_group, bucket_bytes)
+        self.exchange = GradExchange(optimizer, names, process_group, bucket_bytes, params=dict(model.named_parameters()))
         self.graph.exchange = self.exchange
+
+    @classmethod
+    def build(cls, model, diffusion, conditioner: Callable, optimizer: FusedAdamW, lr_scheduler: Optional[LinearLR] = None,
+              grad_accum_every: int = 10, tasks: Sequence[str] = TASKS, device="cuda", cross_attn_cond_ids: Sequence[str] = ("prompt",),
+              global_cond_ids: Sequence[str] = (), input_concat_ids: Sequence[str] = ("masked_input", "mask"), dls=None, **extras):
+        """the trainer without a config object / logger / writers (tests, bench.py): same object, short argument list"""
+        from .config import TrainConfig
+        cfg = TrainConfig(tasks=list(tasks), device=device, grad_accum_every=grad_accum_every)
+        return cls(cfg, 0, 0, 0, model, diffusion, conditioner, dls, optimizer, lr_scheduler, None, None, None, optimizer.max_norm,
+                   grad_accum_every, cross_attn_cond_ids, global_cond_ids, input_concat_ids, **extras)
 
     # trainer.py:215-247 / :249-278
     def random_mask(self, sequence, max_mask_length, task):
@@ -62,11 +124,9 @@ class UnifiedMultiTaskTrainer:
     def get_conditioning(self, cond):
         return get_conditioning(cond, self.cross_attn_cond_ids, self.global_cond_ids, self.input_concat_ids)
 
-    def train(self, audio_emb: torch.Tensor, metadata) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-        """trainer.py:183-213.  Returns (sum of the task losses, {task: loss}); the per-task values stay on the device
-        (the reference's ``.item()`` per sub-batch is a host sync the step does not need)."""
-        loss_dict: Dict[str, torch.Tensor] = {}
-        all_loss = torch.zeros((), device=self.device)
+    def prepare_parts(self, audio_emb: torch.Tensor, metadata) -> List[tuple]:
+        """what one pass of the reference's task loop prepares (trainer.py:190-203): per task
+        ``(task, sub_audio_emb, t, conditioning, causal)`` with a fresh mask / timestep draw per sub-batch"""
         batch_size = audio_emb.size(0)
         nt = len(self.tasks)
         if not self.allow_uneven_tasks:
@@ -75,7 +135,7 @@ class UnifiedMultiTaskTrainer:
         # tasks take one clip more (8 -> 3 / 3 / 2), task order as in config.py:93
         sizes = [batch_size // nt + (1 if i < batch_size % nt else 0) for i in range(nt)]
         start = 0
-        parts = []                      # per task: what one pass of the reference's loop prepares (trainer.py:190-203)
+        parts = []
         for i, task in enumerate(self.tasks):
             sub = sizes[i]
             if sub == 0:
@@ -83,31 +143,50 @@ class UnifiedMultiTaskTrainer:
             sub_audio_emb = audio_emb[start:start + sub]
             sub_metadata = metadata[start:start + sub]
             start += sub
-            self.model.train()
             masked_input, mask, causal = self.random_mask(sub_audio_emb, sub_audio_emb.shape[2], task)
             conditioning = self.conditioner(sub_metadata, self.device)
             conditioning["masked_input"] = masked_input
             conditioning["mask"] = mask
             conditioning = self.get_conditioning(conditioning)
-            t = torch.randint(0, self.diffusion.num_timesteps, (sub,), device=self.device).long()
+            t = torch.randint(0, self.diffusion.num_timesteps, (sub,), device=self.device).long() if self.is_gdm else None
             parts.append((task, sub_audio_emb, t, conditioning, bool(causal)))
+        return parts
+
+    def train(self, audio_emb: torch.Tensor, metadata) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """trainer.py:183-213.  Returns (sum of the task losses, {task: loss}); the per-task values stay on the device
+        (the reference's ``.item()`` per sub-batch is a host sync the step does not need)."""
+        self.model.train()
+        return self.run_parts(self.prepare_parts(audio_emb, metadata))
+
+    def run_parts(self, parts: List[tuple], noises: Optional[Dict[str, torch.Tensor]] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """the loss of prepared task sub-batches (and, with a replayed graph, its backward).  ``noises`` {task: noise} injects the
+        diffusion noise (parity tests against the reference's autograd; eager mode only -- the graph draws its own)."""
+        loss_dict: Dict[str, torch.Tensor] = {}
+        all_loss = torch.zeros((), device=self.device)
+        assert noises is None or self.graphed is None, "injected noise needs use_graph=False"
         first = True
+        armed = getattr(self, "_armed", False)                 # train_step: this micro-batch closes an accumulation window
         if not self.merge_tasks:
-            for task, x, t, conditioning, causal in parts:
+            for i, (task, x, t, conditioning, causal) in enumerate(parts):
                 if self.graphed is not None:
                     if self.grad_accum == 0 and first:
                         self.optimizer.zero_grad()             # the captured step already contains the backward
+                    # the replayed pass that completes the window's gradients carries the exchange (GraphedLossStep.exchange)
+                    self.graphed.exchange = self.exchange if (armed and i == len(parts) - 1) else None
                     loss = self.graphed(x, t, conditioning, causal)
-                else:
-                    loss = self.diffusion.training_loosses(self.graph, x, t, conditioning, causal=causal)
+                elif self.is_gdm:
+                    loss = self.diffusion.training_loosses(self.graph, x, t, conditioning, causal=causal,
+                                                           noise=None if noises is None else noises[task])
+                else:                                          # VDM draws its own continuous times (trainer.py:209-211)
+                    loss = self.diffusion.training_loosses(self.graph, x, conditioning, causal=causal,
+                                                           noise=None if noises is None else noises[task])
                 first = False
                 loss_dict[task] = loss.detach()
                 all_loss = all_loss + loss
             return all_loss, loss_dict
-        for flag in (False, True):
+        flags = [f for f in (False, True) if any(p[4] == f for p in parts)]
+        for flag in flags:
             group = [p for p in parts if p[4] == flag]
-            if not group:
-                continue
             cat = lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)        # noqa: E731
             x = cat([p[1] for p in group])
             t = cat([p[2] for p in group])
@@ -117,10 +196,12 @@ class UnifiedMultiTaskTrainer:
             if self.graphed is not None:
                 if self.grad_accum == 0 and first:
                     self.optimizer.zero_grad()
+                self.graphed.exchange = self.exchange if (armed and flag == flags[-1]) else None
                 per_sample = self.graphed(x, t, conditioning, flag, sample_weights=w)
                 group_loss = (per_sample * w).sum()
             else:
-                per_sample = self.diffusion.training_loosses(self.graph, x, t, conditioning, causal=flag, reduction="none")
+                noise = None if noises is None else cat([noises[p[0]] for p in group])
+                per_sample = self.diffusion.training_loosses(self.graph, x, t, conditioning, causal=flag, reduction="none", noise=noise)
                 group_loss = (per_sample * w).sum()
             first = False
             all_loss = all_loss + group_loss
@@ -134,9 +215,15 @@ class UnifiedMultiTaskTrainer:
         """one iteration of ``train_loop``'s body (trainer.py:134-150).  Returns (loss, per-task losses, whether an
         optimiser step was taken)."""
         last = self.grad_accum + 1 == self.grad_accum_every
-        if self.graphed is None and last:
-            self.exchange.begin()          # the backward pass of the window's last micro-batch releases the buckets
-        all_task_loss, loss_dict = self.train(audio_emb, metadata)
+        if last:
+            self.exchange.begin()          # the backward pass of the window's last micro-batch releases the regions
+        self._armed = last
+        try:
+            all_task_loss, loss_dict = self.train(audio_emb, metadata)
+        finally:
+            self._armed = False
+            if self.graphed is not None:
+                self.graphed.exchange = None
         if self.graphed is None:
             if self.grad_accum == 0:
                 self.optimizer.zero_grad()
@@ -144,10 +231,7 @@ class UnifiedMultiTaskTrainer:
         self.grad_accum += 1
         stepped = False
         if self.grad_accum == self.grad_accum_every:
-            if self.graphed is None:
-                self.exchange.finish()                                         # DDP's exchange (train.py:88-89), overlapped
-            else:
-                self.exchange.blocking()                                       # behind the replayed graphs
+            self.exchange.finish()                                             # DDP's exchange (train.py:88-89): what is still out
             self.optimizer.step(None if self.lr_scheduler is None else self.lr_scheduler.get_last_lr())
             if self.lr_scheduler is not None:
                 self.lr_scheduler.step()
@@ -155,3 +239,94 @@ class UnifiedMultiTaskTrainer:
             stepped = True
         self.global_step += 1
         return all_task_loss.detach(), loss_dict, stepped
+
+    # ------------------------------------------------------------------ trainer.py:126-181
+    def train_loop(self, max_steps: Optional[int] = None) -> None:
+        """``train_loop`` (trainer.py:126-181) over ``self.train_dl``: micro-batches accumulate, every ``grad_accum_every`` of them
+        clip + AdamW + LinearLR run (one fused optimiser step), rank 0 logs the window's losses and writes the scalars, every
+        ``config.eval_interval`` steps (and at the end) the validation pass runs.  ``max_steps`` (not in the reference) bounds the
+        number of micro-batches, for tests and benchmarks."""
+        cfg = self.config
+        num_epoch = int(getattr(cfg, "num_epoch", 1))
+        eval_interval = int(getattr(cfg, "eval_interval", 0) or 0)
+        all_loss = torch.zeros((), device=self.device)
+        loss_dict = {task: torch.zeros((), device=self.device) for task in self.tasks}
+        done = 0
+        epoch = self.epoch_str
+        for epoch in range(self.epoch_str, int(self.epoch_str + num_epoch + 1)):
+            for batch_idx, (audio_emb, metadata) in enumerate(self.train_dl):
+                step_before = self.global_step
+                all_task_loss, all_loss_dict, stepped = self.train_step(audio_emb.to(self.device), metadata)
+                all_loss = all_loss + all_task_loss / self.grad_accum_every
+                for task in all_loss_dict:
+                    loss_dict[task] = loss_dict[task] + all_loss_dict[task] / self.grad_accum_every
+                if stepped:
+                    if self.rank == 0 and (self.logger is not None or self.writer is not None):
+                        vals = {k: float(v) for k, v in loss_dict.items()}          # the window's only host sync
+                        total = float(all_loss)
+                        lr = self.optimizer.lr if self.lr_scheduler is None else self.lr_scheduler.get_last_lr()
+                        if self.logger is not None:
+                            n = len(self.train_dl) if hasattr(self.train_dl, "__len__") else 0
+                            self.logger.info("Train Epoch: {}, [{:.0f}%]".format(epoch, 100.0 * batch_idx / n if n else 0.0))
+                            self.logger.info(f"loss: {total} " + " ".join(f"loss_{k}: {v}" for k, v in vals.items()) +
+                                             f" global_step: {step_before}, lr:{lr}")
+                        self._summarize(self.writer, step_before, {"loss/train": total, **{f"loss_{k}/train": v for k, v in vals.items()}})
+                    all_loss = torch.zeros((), device=self.device)
+                    loss_dict = {task: torch.zeros((), device=self.device) for task in self.tasks}
+                if eval_interval and step_before % eval_interval == 0 and step_before != 0 and self.valid_dl is not None:
+                    self.eval_all_tasks(epoch=epoch)
+                done += 1
+                if max_steps is not None and done >= max_steps:
+                    return
+        if self.valid_dl is not None:
+            self.eval_all_tasks(epoch=epoch)
+
+    @staticmethod
+    def _summarize(writer, global_step: int, scalars: Dict[str, float]) -> None:
+        """utils/logger.py summarize(): scalars only"""
+        if writer is not None:
+            for k, v in scalars.items():
+                writer.add_scalar(k, v, global_step)
+
+    @torch.no_grad()
+    def eval(self) -> Tuple[Dict[str, float], int]:
+        """trainer.py:90-124: the per-task losses over the validation loader through the inference engine (no gradients)"""
+        self.model.eval()
+        loss_dict = {task: 0.0 for task in self.tasks}
+        count = 0
+        for audio_emb, metadata in self.valid_dl:
+            for task, x, t, conditioning, causal in self.prepare_parts(audio_emb.to(self.device), metadata):
+                if self.is_gdm:
+                    loss = self.diffusion.training_loosses(self.model, x, t, conditioning, causal=causal)
+                else:
+                    loss = self.diffusion.training_loosses(self.model, x, conditioning, causal=causal)
+                loss_dict[task] += float(loss)
+            count += 1
+        return loss_dict, count
+
+    def eval_all_tasks(self, epoch: int) -> float:
+        """trainer.py:61-88: average validation loss per task, best-so-far checkpoint in the reference's wire format"""
+        import os
+        from .checkpoint import save_checkpoint
+        all_task_loss_dict, task_count = self.eval()
+        avg_total_loss = 0.0
+        for task in self.tasks:
+            avg_loss = all_task_loss_dict[task] / task_count if task_count > 0 else 0
+            avg_total_loss += avg_loss
+            if self.logger is not None:
+                self.logger.info(f"Average validation loss for task {task}: {avg_loss}")
+            if self.rank == 0:
+                self._summarize(self.writer, self.global_step, {f"loss/val_{task}": avg_loss})
+        if self.logger is not None:
+            self.logger.info(f"Average total validation loss: {avg_total_loss}")
+        if avg_total_loss < self.best_avg_total_loss:
+            self.best_avg_total_loss = avg_total_loss
+            save_dir = getattr(self.config, "save_dir", "")
+            if save_dir and self.rank == 0:
+                lr = getattr(getattr(self.config, "optimizer_config", None), "lr", self.optimizer.lr)
+                save_checkpoint(model=self.model, optimizer=self.optimizer, lr=lr, iteration=epoch, logger=self.logger,
+                                checkpoint_path=os.path.join(save_dir, f"Jen1_step_{self.global_step}_loss_{self.best_avg_total_loss}.pth"))
+        if self.rank == 0:
+            self._summarize(self.writer, self.global_step, {"loss/val_total": avg_total_loss})
+        self.model.train()
+        return avg_total_loss

@@ -510,6 +510,52 @@ class OracleGaussianDiffusion:
         return per.reshape(per.shape[0], -1).mean(axis=1).mean()
 
 
+class OracleVDM:
+    """``VDM`` (/root/reference/jen1/diffusion/vdm/vdm.py:12-110) with the repairs of SURVEY.md Appendix A-3 / A-4 that
+    jen1_amd/vdm.py documents (the shipped class cannot run): the model gets a batch vector of the step's continuous time,
+    alphas / sigmas are read by step index, the loss broadcasts them as [B, 1, 1].  Pinned by tests/golden/tiny_vdm.npz, which
+    make_golden.py produces from a subclass of the reference's own class with the same three repairs."""
+
+    def __init__(self, *, loss_type: str = "l2", cfg_dropout_proba: float = 0.1, embedding_scale: float = 0.8,
+                 batch_cfg: bool = False, scale_cfg: bool = False):
+        self.loss_type, self.cfg_dropout_proba, self.embedding_scale = loss_type, cfg_dropout_proba, embedding_scale
+        self.batch_cfg, self.scale_cfg = batch_cfg, scale_cfg
+
+    _model_call = OracleGaussianDiffusion._model_call
+
+    def sample(self, model, shape, conditioning, *, step: int, init_noise: Array, causal=False, init_data=None,
+               return_all_timesteps=False, dropout_rows=None):
+        """vdm.py:42-79 (repaired): x_pred = alpha x - sigma v; noise_pred = sigma x + alpha v; x = alpha' x_pred + sigma' noise_pred"""
+        f = np.float32
+        audio = np.asarray(init_noise, dtype=f).reshape(shape)
+        if init_data is not None:
+            audio = audio + init_data
+        steps = linspace_f32(1.0, 0.0, step + 1)
+        al = np.cos(steps * f(math.pi / 2)).astype(f)
+        sg = np.sin(steps * f(math.pi / 2)).astype(f)
+        audios = [audio]
+        for i in range(step):
+            t = np.full((shape[0],), steps[i], dtype=f)
+            v = self._model_call(model, audio, t, conditioning, causal, None if dropout_rows is None else dropout_rows[i])
+            x_pred = al[i] * audio - sg[i] * v
+            noise_pred = sg[i] * audio + al[i] * v
+            audio = (al[i + 1] * x_pred + sg[i + 1] * noise_pred).astype(f)
+            audios.append(audio)
+        return audio if not return_all_timesteps else np.stack(audios, axis=1)
+
+    def training_losses(self, model, x_start, conditioning, noise, times, causal=False, dropout_rows=None):
+        """vdm.py:81-110 (repaired); the target uses x_t as written (vdm.py:106)"""
+        f = np.float32
+        times = np.asarray(times, dtype=f)
+        al = np.cos(times * f(math.pi / 2)).astype(f).reshape(-1, 1, 1)
+        sg = np.sin(times * f(math.pi / 2)).astype(f).reshape(-1, 1, 1)
+        x_t = (x_start * al + noise * sg).astype(f)
+        out = self._model_call(model, x_t, times, conditioning, causal, dropout_rows)
+        d = out - (noise * al - x_t * sg)
+        per = (d * d) if self.loss_type == "l2" else np.abs(d)
+        return per.reshape(per.shape[0], -1).mean(axis=1).mean()
+
+
 # ----------------------------------------------------------------------------
 # host-side helpers restated from files that cannot be imported here
 # (trainer.py / generation.py need encodec + tensorboard)

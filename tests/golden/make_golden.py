@@ -464,6 +464,97 @@ def gen_full_train():
     save("full_train", **out)
 
 
+
+def _ref_ddim(model, B, T_, S, scale, eta=1.0, causal=False, task="text_guided", init_eps=0.0, all_steps=False):
+    """the reference's GaussianDiffusion.sample (DDIM) on the full model with injected start / per-step noise"""
+    betas, _ = get_beta_schedule("linear", 1000)
+    _, cond = _inputs(B, T_, task)
+    cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+    shape = (B, 128, T_)
+    init = synth.noise_list(1, shape, seed=7)[0]
+    if init_eps:
+        init = (init * np.float32(1.0 + init_eps)).astype(np.float32)
+    noises = synth.noise_list(S, shape, seed=11)
+    gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective="noise", loss_type="l2", device="cpu",
+                           cfg_dropout_proba=0.0, embedding_scale=scale, batch_cfg=True, scale_cfg=True,
+                           sampling_timesteps=S, ddim_sampling_eta=eta)
+    it = iter([T(init)] + [T(n) for n in noises])
+    r_randn, r_randn_like = torch.randn, torch.randn_like
+    torch.randn = lambda *a, **k: next(it).clone()
+    torch.randn_like = lambda *a, **k: next(it).clone()
+    try:
+        y = gd.sample(model, shape, cond_t, return_all_timesteps=all_steps, causal=causal)
+    finally:
+        torch.randn, torch.randn_like = r_randn, r_randn_like
+    return y.numpy()
+
+
+def gen_ddim100():
+    """BASELINE configs[1] / [2] at their own schedule length: the reference's 100-step DDIM of the full model.
+      ddim100.B2.cfg[.stepK]   B = 2, CFG pair (scale 0.8, rescale), eta = 1 with injected noise; the trajectory at K = 10/25/50/75
+      ddim100.B8.nocfg[.stepK] B = 8, no CFG, eta = 0 -- exactly what bench.py times
+      *.sens[.stepK]           the REFERENCE's own response to a start noise scaled by (1 + 1e-6), as (max-abs, max-ref, rel-L2):
+                               the x0 clamp makes the 100-step chain amplify rounding-level differences, so the final latents are
+                               pinned only as tightly as the reference pins itself; the early trajectory is pinned tightly
+    Outputs sub-sampled along T."""
+    import time as _time
+    cfg = full_model_config()
+    model, _ = _build(cfg)
+    out = {}
+    taps = (10, 25, 50, 75)
+
+    def sens(a, b):
+        return np.array([np.abs(a - b).max(), np.abs(b).max(), np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum())])
+
+    for key, B, scale, eta, sub in (("ddim100.B2.cfg", 2, 0.8, 1.0, 8), ("ddim100.B8.nocfg", 8, 1.0, 0.0, 16)):
+        t0 = _time.time()
+        traj = _ref_ddim(model, B, 1500, 100, scale, eta=eta, all_steps=True)          # [B, S + 1, C, T]; entry k = input of step k
+        print(f"  {key}: {_time.time() - t0:.0f} s")
+        pert = _ref_ddim(model, B, 1500, 100, scale, eta=eta, init_eps=1e-6, all_steps=True)
+        # gd.sample(return_all_timesteps=True) stacks the INPUT of every step (gdm.py:205) and never the final output; run the
+        # last entry again without the stack for the final latents
+        fin = _ref_ddim(model, B, 1500, 100, scale, eta=eta)
+        fin_p = _ref_ddim(model, B, 1500, 100, scale, eta=eta, init_eps=1e-6)
+        out[key] = fin[:, :, ::sub]
+        out[key + ".sens"] = sens(fin_p, fin)
+        print("   final sensitivity (max-abs, max-ref, rel-L2):", out[key + ".sens"])
+        for k in taps:
+            out[f"{key}.step{k}"] = traj[:, k, :, ::sub]
+            out[f"{key}.sens.step{k}"] = sens(pert[:, k], traj[:, k])
+            print(f"   step {k} sensitivity:", out[f"{key}.sens.step{k}"])
+        del traj, pert
+    save("full_ddim100", **out)
+
+
+TRAIN8_TASKS = synth.TRAIN8_TASKS
+train8_inputs = synth.train8_inputs
+
+
+def gen_full_train8():
+    """full configuration, 8 clips as the 3 / 3 / 2 task sub-batches of one micro-batch: per-task losses, the summed loss
+    and every parameter's gradient of ``sum(task losses).backward()`` from the reference's autograd"""
+    cfg = full_model_config()
+    model, spec = _build(cfg)
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas.float(), objective="noise", loss_type="l2", device="cpu",
+                           cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    out = {"grad_names_all": np.array(json.dumps([n for n, _ in model.named_parameters()]))}
+    with torch.enable_grad():
+        model.zero_grad(set_to_none=True)
+        model.train()
+        for task, x0, t, cond, noise, causal in train8_inputs():
+            cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+            loss = gd.training_loosses(model, T(x0), T(t), cond_t, noise=T(noise), causal=causal)
+            loss.backward()                                            # gradients of the three tasks accumulate (trainer.py:141)
+            out[f"loss.{task}"] = np.float32(loss.item())
+            print("  ", task, loss.item())
+    out["loss"] = np.float32(sum(float(out[f"loss.{t}"]) for t, _, _ in TRAIN8_TASKS))
+    out["gradnorm_all"] = np.array([p_.grad.norm().item() for _, p_ in model.named_parameters()], dtype=np.float32)
+    out["gradsample_all"] = np.concatenate(
+        [p_.grad.reshape(-1)[:: max(1, p_.numel() // 16)][:16].numpy() for _, p_ in model.named_parameters()]).astype(np.float32)
+    save("full_train8", **out)
+
+
 def encodec_decoder_shapes():
     """(key, shape) of transformers' EncodecDecoder for the 48 kHz configuration (the names jen1_amd/encodec.py reads)"""
     from transformers import EncodecConfig, EncodecModel
@@ -556,6 +647,105 @@ def gen_ddpm(model=None):
     assert traj.shape == (B, S + 1, 128, T_)
     out["ddpm20.cfg.traj"] = traj[:, :, ::8, ::15]
     save("tiny_ddpm", **out)
+
+
+def gen_vdm(model=None):
+    """The reference's VDM (jen1/diffusion/vdm/vdm.py) cannot run as shipped (both failures are
+    asserted below).  The fixture pins the REPAIRED form: a subclass of the reference's own class that overrides the two broken
+    methods with the same formulas and the three repairs jen1_amd/vdm.py documents -- the model gets ``time.expand(B)``,
+    ``alphas`` / ``sigmas`` are read by step index, and the loss reshapes them to [B, 1, 1].  Tiny configuration: sampling with
+    10 and 4 steps (CFG pair; no CFG + causal), the whole trajectory of the 10-step run, the loss and every gradient norm."""
+    import math
+    from jen1.diffusion.vdm.vdm import VDM
+    cfg = tiny_model_config()
+    if model is None:
+        model, _ = _build(cfg)
+    B, T_ = 2, 300
+    _, cond = _inputs(B, T_)
+    cond_t = {k: (None if v is None else T(v)) for k, v in cond.items()}
+    shape = (B, 128, T_)
+    init = synth.noise_list(1, shape, seed=23)[0]
+
+    # ---- the reference as shipped fails (A-3, A-4) --------------------------------------------------------------------------
+    ref = VDM(loss_type="l2", device="cpu", cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    for what, fn in (("sample", lambda: ref.sample(model, shape, cond_t, step=2)),
+                     ("training_loosses", lambda: ref.training_loosses(model, T(synth.latents(B, T_, key="clip")), cond_t))):
+        try:
+            fn()
+            raise AssertionError(f"the reference's VDM.{what} was expected to fail")
+        except AssertionError:
+            raise
+        except Exception as e:                                        # noqa: BLE001
+            print(f"  reference VDM.{what} fails as documented: {type(e).__name__}")
+
+    class RepairedVDM(VDM):
+        def p_sample_i(self, x, i, model, conditioning, causal):
+            time = self.steps[i].expand(x.shape[0])                    # repair: a batch vector of the step's time
+            v_pred = model(x, time, embedding=conditioning['cross_attn_cond'], embedding_mask=conditioning['cross_attn_masks'],
+                           embedding_scale=self.embedding_scale, embedding_mask_proba=self.cfg_dropout_proba,
+                           features=conditioning['global_cond'], channels_list=[conditioning['input_concat_cond']],
+                           batch_cfg=self.batch_cfg, scale_cfg=self.scale_cfg, causal=causal)
+            x_pred = self.alphas[i] * x - self.sigmas[i] * v_pred      # repair: indexed by the step, not by its float time
+            noise_pred = self.sigmas[i] * x + self.alphas[i] * v_pred
+            return self.alphas[i + 1] * x_pred + self.sigmas[i + 1] * noise_pred
+
+        def p_sample_loop(self, model, shape, conditioning, step=1000, return_all_timesteps=False, init_data=None, causal=False):
+            audio = torch.randn(shape, device=self.device)
+            if init_data is not None:
+                audio = audio + init_data
+            audios = [audio]
+            self.steps = torch.linspace(1., 0., step + 1, device=self.device)
+            self.get_alpha_sigma(self.steps)
+            for i in range(step):
+                audio = self.p_sample_i(audio, i, model, conditioning, causal)
+                audios.append(audio)
+            return audio if not return_all_timesteps else torch.stack(audios, dim=1)
+
+        def training_loosses(self, model, x_start, conditioning, noise=None, causal=False, times=None):
+            if noise is None:
+                noise = torch.rand_like(x_start)
+            if times is None:
+                times = torch.rand(x_start.shape[0])
+            x_t, alphas, sigmas = self.q_sample(x_start, times.reshape(-1, 1, 1), noise=noise)       # repair: [B, 1, 1]
+            model_out = model(x_t, times, embedding=conditioning['cross_attn_cond'], embedding_mask=conditioning['cross_attn_masks'],
+                              embedding_scale=self.embedding_scale, embedding_mask_proba=self.cfg_dropout_proba,
+                              features=conditioning['global_cond'], channels_list=[conditioning['input_concat_cond']],
+                              batch_cfg=self.batch_cfg, scale_cfg=self.scale_cfg, causal=causal)
+            target = noise * alphas - x_t * sigmas
+            loss = self.loss_fn(model_out, target, reduction='none')
+            return loss.reshape(loss.shape[0], -1).mean(dim=1).mean()
+
+    out = {}
+
+    def run(scale, step, causal=False, all_steps=False):
+        vd = RepairedVDM(loss_type="l2", device="cpu", cfg_dropout_proba=0.0, embedding_scale=scale, batch_cfg=True, scale_cfg=True)
+        r_randn = torch.randn
+        torch.randn = lambda *a, **k: T(init).clone()
+        try:
+            y = vd.sample(model, shape, cond_t, step=step, return_all_timesteps=all_steps, causal=causal)
+        finally:
+            torch.randn = r_randn
+        return y.numpy()
+
+    out["vdm10.cfg"] = run(0.8, 10)
+    out["vdm10.cfg.traj"] = run(0.8, 10, all_steps=True)[:, :, ::8, ::15]
+    out["vdm4.nocfg.causal"] = run(1.0, 4, causal=True)[:, :, ::3]
+    # ---- loss + gradients ----------------------------------------------------------------------------------------------------
+    x0 = synth.latents(B, T_, key="clip")
+    noise = fill_uniform("synth.trainnoise.vdm", (B, 128, T_), 3, 0.0, 1.0)
+    times = torch.tensor([0.137, 0.803], dtype=torch.float32)
+    out["times"] = times.numpy()
+    vd = RepairedVDM(loss_type="l2", device="cpu", cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    with torch.enable_grad():
+        model.zero_grad(set_to_none=True)
+        model.train()
+        loss = vd.training_loosses(model, T(x0), cond_t, noise=T(noise), causal=False, times=times)
+        loss.backward()
+    out["loss"] = np.float32(loss.item())
+    out["grad_names_all"] = np.array(json.dumps([n for n, _ in model.named_parameters()]))
+    out["gradnorm_all"] = np.array([p_.grad.norm().item() for _, p_ in model.named_parameters()], dtype=np.float32)
+    model.eval()
+    save("tiny_vdm", **out)
 
 
 def gen_host():
@@ -682,7 +872,7 @@ def gen_host():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fullbench", "fulltrain", "encodec", "ddpm", "host"}
+    which = set(sys.argv[1:]) or {"schedule", "units", "tiny", "sampler", "train", "full", "fullbench", "fulltrain", "encodec", "ddpm", "host", "ddim100", "fulltrain8", "vdm"}
     model = None
     if "schedule" in which:
         print("schedule"); gen_schedule()
@@ -700,9 +890,15 @@ if __name__ == "__main__":
         print("fullbench"); gen_full_bench()
     if "fulltrain" in which:
         print("fulltrain"); gen_full_train()
+    if "ddim100" in which:
+        print("ddim100"); gen_ddim100()
+    if "fulltrain8" in which:
+        print("fulltrain8"); gen_full_train8()
     if "encodec" in which:
         print("encodec"); gen_encodec()
     if "ddpm" in which:
         print("ddpm"); gen_ddpm(model)
+    if "vdm" in which:
+        print("vdm"); gen_vdm(model)
     if "host" in which:
         print("host"); gen_host()

@@ -365,6 +365,68 @@ def test_full_ddim_vs_golden(full_model_f32, full_model_bf16, mode):
             assert l2 < 1e-1, (key, l2, e)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_ddim100_vs_golden(full_model_f32, full_model_bf16, mode):
+    """BASELINE configs[1] / [2] at their own schedule length: 100 DDIM steps of the full model as a replayed hipGraph against
+    the reference's ``GaussianDiffusion.sample`` (tests/golden/make_golden.py ddim100): B = 2 through the CFG pair with eta = 1
+    and injected per-step noise, and B = 8 without CFG at eta = 0 -- the exact plan bench.py times.  The trajectory is compared
+    at steps 10 / 25 / 50 / 75 and at the end.  The reference's own response to a 1e-6 relative change of the start noise is
+    stored next to every tap (<= 1.8e-4 of the value range at the end, <= 1.5e-5 up to step 25), so float32 is held to the
+    1e-3 parity gate everywhere; bf16 storage is gated on the relative L2 error of the whole sample."""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    g = golden("full_ddim100")
+    m = full_model_f32 if mode == "f32" else full_model_bf16
+    betas, _ = get_beta_schedule("linear", 1000)
+    for key, B, scale, eta, sub in (("ddim100.B2.cfg", 2, 0.8, 1.0, 8), ("ddim100.B8.nocfg", 8, 1.0, 0.0, 16)):
+        T, S = 1500, 100
+        cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+        shape = (B, 128, T)
+        init = dev(synth.noise_list(1, shape, seed=7)[0])
+        noises = [dev(n) for n in synth.noise_list(S, shape, seed=11)] if eta else None
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                               embedding_scale=scale, batch_cfg=True, scale_cfg=True, sampling_timesteps=S, ddim_sampling_eta=eta)
+        traj = gd.sample(m, shape, cond, return_all_timesteps=True, init_noise=init, step_noises=noises, use_graph=True)
+        assert traj.shape == (B, S + 1, 128, T)
+        fin = gd.sample(m, shape, cond, init_noise=init, step_noises=noises, use_graph=True)
+        torch.cuda.synchronize()
+        for name, got in [(f"{key}.step{k}", traj[:, k]) for k in (10, 25, 50, 75)] + [(key, fin)]:
+            got, ref = got.cpu().numpy()[:, :, ::sub].astype(np.float64), g[name].astype(np.float64)
+            e = rel_err(got, ref)
+            l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            sens = g[name.replace(key, key + ".sens")]
+            print(f"{name} {mode}: max-abs/max-ref = {e:.3e}, relative L2 = {l2:.3e}   (reference's own 1e-6 sensitivity: {sens[0] / sens[1]:.1e})")
+            if mode == "f32":
+                assert e < F32_TOL, (name, e)
+            else:
+                assert l2 < 1e-1, (name, l2, e)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_vdm_sampler_vs_repaired_reference(tiny_models, mode):
+    """``VDM`` (jen1_amd/vdm.py: the reference's vdm.py with the A-3 / A-4 repairs) on the fused stepper (row kind 3 of
+    jen1_cfg_ddim_step, continuous times through jen1_time_features_f32), eager and as a replayed graph, and through the literal
+    loop over ``model(...)``, against the fixture made from the reference's own class with the same repairs."""
+    from jen1_amd.vdm import VDM
+    g = golden("tiny_vdm")
+    m, tol = (tiny_models["f32"], F32_TOL) if mode == "f32" else (tiny_models["bf16"], BF16_TOL)
+    B, T = 2, 300
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+    shape = (B, 128, T)
+    init = dev(synth.noise_list(1, shape, seed=23)[0])
+    vd = VDM(loss_type="l2", device="cuda", cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    for kw in (dict(use_graph=True), dict(use_graph=False), dict(fused=False)):
+        traj = vd.sample(m, shape, cond, step=10, return_all_timesteps=True, init_noise=init, **kw)
+        torch.cuda.synchronize()
+        assert traj.shape == (B, 11, 128, T)
+        e = rel_err(traj[:, -1].cpu().numpy(), g["vdm10.cfg"])
+        et = rel_err(traj.cpu().numpy()[:, :, ::8, ::15], g["vdm10.cfg.traj"])
+        print(f"VDM 10 steps {mode} {kw}: final {e:.3e}, trajectory {et:.3e}")
+        assert e < tol and et < tol, (kw, e, et)
+    vd1 = VDM(loss_type="l2", device="cuda", cfg_dropout_proba=0.0, embedding_scale=1.0, batch_cfg=True, scale_cfg=True)
+    y = vd1.sample(m, shape, cond, step=4, causal=True, init_noise=init)
+    assert rel_err(y.cpu().numpy()[:, :, ::3], g["vdm4.nocfg.causal"]) < tol
+
+
 def test_sampler_full_size_properties(full_model_f32):
     """size-independent properties at BASELINE size (B=2 to stay in memory/time): every x0 prediction is
     clamped to [-1, 1] so the final DDIM sample is; graph replay == eager; finite everywhere."""

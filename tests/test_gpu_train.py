@@ -372,6 +372,34 @@ def test_tiny_training_gradients_bf16(tiny_model):
     assert not bad, bad[:5]
 
 
+def test_vdm_training_loss_and_gradients_vs_repaired_reference_f32(tiny_model):
+    """``VDM.training_loosses`` (vdm.py:89-110 with the A-4 repair) through the differentiable HIP path: loss and every
+    parameter's gradient norm against the reference's autograd on its own class with the same repair (tiny_vdm.npz)."""
+    from jen1_amd.init_fill import fill_uniform
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.vdm import VDM
+    g = golden("tiny_vdm")
+    names = json.loads(str(g["grad_names_all"]))
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
+    model.train()
+    B, T = 2, 300
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+    noise = dev(fill_uniform("synth.trainnoise.vdm", (B, 128, T), 3, 0.0, 1.0))
+    vd = VDM(loss_type="l2", device="cuda", cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    loss = vd.training_loosses(model, x0, cond, noise=noise, causal=False, times=dev(g["times"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = float(g["loss"])
+    assert abs(float(loss.detach()) - ref) <= 1e-3 * abs(ref)
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    ref_norm = g["gradnorm_all"]
+    gmax = float(ref_norm.max())
+    for i, n in enumerate(names):
+        nrm = float(grads[n].norm())
+        assert abs(nrm - ref_norm[i]) <= 1e-3 * max(ref_norm[i], 1e-3 * gmax), (n, nrm, ref_norm[i])
+
+
 def test_training_step_updates_parameters_and_repacks(tiny_model):
     """one optimiser step through FusedAdamW changes the loss; the packed compute weights follow the parameters"""
     from jen1_amd.model import UNetCFG1d
@@ -427,7 +455,7 @@ def test_unified_multitask_trainer_steps(tiny_model, use_graph):
         idx = torch.tensor(metadata, device=device)
         return {"prompt": (emb[idx], msk[idx])}
 
-    tr = UnifiedMultiTaskTrainer(model, gd, conditioner, opt, sched, grad_accum_every=2, rng=random.Random(0), use_graph=use_graph)
+    tr = UnifiedMultiTaskTrainer.build(model, gd, conditioner, opt, sched, grad_accum_every=2, rng=random.Random(0), use_graph=use_graph)
     audio = dev(synth.latents(B, T, key="clip"))
     p0 = opt.flat_param.clone()
     torch.manual_seed(0)
@@ -530,6 +558,60 @@ def test_full_model_training_gradients_vs_reference_autograd_f32():
         assert es <= 5e-3, (n, es)
     assert off == ref_samp.size
     print(f"full model: worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
+
+
+def test_configs3_micro_batch_merged_passes_vs_reference_autograd_f32():
+    """BASELINE configs[3] at its per-GPU shape: the full model, 8 clips as the 3 / 3 / 2 task sub-batches (text_guided,
+    music_inpaint, music_cont with their masks) of one micro-batch.  The reference runs one pass per task and sums the three
+    mean losses (trainer.py:183-213); the trainer here merges the sub-batches that share the causal flag into one pass with
+    per-sample weights.  Per-task losses, the summed loss and the gradient of every one of the 979 tensors against the
+    reference's own autograd (tests/golden/full_train8.npz, make_golden.py fulltrain8)."""
+    from jen1_amd.config import full_model_config
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    from jen1_amd.trainer import UnifiedMultiTaskTrainer
+    g = golden("full_train8")
+    names = json.loads(str(g["grad_names_all"]))
+    model = UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
+    model.train()
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    opt = FusedAdamW(model.parameters(), lr=0.0, max_norm=None)
+    tr = UnifiedMultiTaskTrainer.build(model, gd, None, opt, None, grad_accum_every=1, use_graph=False, allow_uneven_tasks=True,
+                                       merge_tasks=True, compute_dtype="f32")
+    parts, noises = [], {}
+    for task, x0, t, cond, noise, causal in synth.train8_inputs():
+        parts.append((task, dev(x0), torch.from_numpy(t).cuda(), {k: (None if v is None else dev(v)) for k, v in cond.items()}, causal))
+        noises[task] = dev(noise)
+    opt.zero_grad()
+    loss, per_task = tr.run_parts(parts, noises)
+    loss.backward()
+    torch.cuda.synchronize()
+    for task in per_task:
+        ref = float(g[f"loss.{task}"])
+        assert abs(float(per_task[task]) - ref) <= 1e-3 * abs(ref), (task, float(per_task[task]), ref)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    assert sorted(names) == sorted(grads.keys()) and len(names) == 979
+    ref_norm, ref_samp = g["gradnorm_all"], g["gradsample_all"]
+    gmax = float(ref_norm.max())
+    off, worst_n, worst_s = 0, 0.0, 0.0
+    for i, n in enumerate(names):
+        gr = grads[n]
+        samp = gr.reshape(-1)[:: max(1, gr.numel() // 16)][:16].cpu().numpy()
+        ref = ref_samp[off: off + samp.size]
+        off += samp.size
+        nrm = float(gr.norm())
+        en = abs(nrm - ref_norm[i]) / max(ref_norm[i], 1e-3 * gmax)
+        scale = max(float(np.abs(ref).max()), ref_norm[i] / np.sqrt(gr.numel()))
+        es = float(np.abs(samp - ref).max() / max(scale, 1e-12))
+        worst_n, worst_s = max(worst_n, en), max(worst_s, es)
+        assert en <= 1e-3, (n, nrm, ref_norm[i])
+        assert es <= 5e-3, (n, es)
+    assert off == ref_samp.size
+    print(f"configs[3] micro-batch (3/3/2 merged): worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
 
 
 def test_training_overfits_one_batch():
@@ -712,9 +794,9 @@ def test_merged_task_passes_equal_one_pass_per_task(use_graph, monkeypatch):
         gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
                                embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
         opt = FusedAdamW(model.parameters(), lr=1e-3)
-        tr = UnifiedMultiTaskTrainer(model, gd, lambda md, device: {"prompt": (emb[torch.tensor(md, device=device)], msk[torch.tensor(md, device=device)])},
-                                     opt, None, grad_accum_every=2, rng=random.Random(5), use_graph=use_graph, allow_uneven_tasks=True,
-                                     merge_tasks=merge)
+        tr = UnifiedMultiTaskTrainer.build(model, gd, lambda md, device: {"prompt": (emb[torch.tensor(md, device=device)], msk[torch.tensor(md, device=device)])},
+                                           opt, None, grad_accum_every=2, rng=random.Random(5), use_graph=use_graph, allow_uneven_tasks=True,
+                                           merge_tasks=merge)
         torch.manual_seed(11)
         loss, per_task, stepped = tr.train_step(audio, list(range(B)))
         torch.cuda.synchronize()

@@ -149,6 +149,7 @@ def test_fused_adamw_skips_nonfinite_and_large_buffer():
     opt.step()
     torch.cuda.synchronize()
     assert torch.equal(p.detach(), before) and float(opt.exp_avg.abs().sum()) == 0.0
+    assert opt.step_count == 0          # a skipped step is not counted (GradScaler.step + torch AdamW: trainer.py:146)
     p.grad.normal_()
     g = p.grad.clone()
     opt.step()
@@ -157,8 +158,10 @@ def test_fused_adamw_skips_nonfinite_and_large_buffer():
     coef = min(1.0, 0.7 / (total + 1e-6))
     m = 0.1 * g * coef
     v = 0.05 * (g * coef) ** 2
-    want = before * (1 - 3e-5 * 0.1) - (3e-5 / (1 - 0.9 ** 2)) * m / (v.sqrt() / (1 - 0.95 ** 2) ** 0.5 + 1e-8)
+    # ... so the first step TAKEN uses the bias corrections of step 1
+    want = before * (1 - 3e-5 * 0.1) - (3e-5 / (1 - 0.9)) * m / (v.sqrt() / (1 - 0.95) ** 0.5 + 1e-8)
     assert float((p.detach() - want).abs().max()) < 1e-6
+    assert opt.step_count == 1
 
 
 @pytest.mark.gpu

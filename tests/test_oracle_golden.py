@@ -332,6 +332,27 @@ def test_tiny_training_loss(tiny_net):
             assert abs(loss - ref) <= 2e-4 * abs(ref), (task, objective, loss, ref)
 
 
+def test_tiny_vdm_sampler_and_loss(tiny_net):
+    """the oracle's repaired VDM against the fixture made from the reference's own class with the same three repairs
+    (make_golden.py vdm)"""
+    net, _ = tiny_net
+    g = golden("tiny_vdm")
+    B, T = 2, 300
+    cond = synth.conditioning(B, T)
+    shape = (B, 128, T)
+    init = synth.noise_list(1, shape, seed=23)[0]
+    vd = O.OracleVDM(cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    traj = vd.sample(net, shape, cond, step=10, init_noise=init, return_all_timesteps=True)
+    assert rel_err(traj[:, -1], g["vdm10.cfg"]) < 5e-4
+    assert rel_err(traj[:, :, ::8, ::15], g["vdm10.cfg.traj"]) < 5e-4
+    vd1 = O.OracleVDM(cfg_dropout_proba=0.0, embedding_scale=1.0, batch_cfg=True, scale_cfg=True)
+    assert rel_err(vd1.sample(net, shape, cond, step=4, init_noise=init, causal=True)[:, :, ::3], g["vdm4.nocfg.causal"]) < 5e-4
+    x0 = synth.latents(B, T, key="clip")
+    noise = fill_uniform("synth.trainnoise.vdm", (B, 128, T), 3, 0.0, 1.0)
+    loss = vd.training_losses(net, x0, cond, noise, g["times"], causal=False)
+    assert abs(loss - float(g["loss"])) <= 2e-4 * abs(float(g["loss"]))
+
+
 # ------------------------------------------------------------------ full config
 def test_full_unet_matches_reference():
     cfg = full_model_config()

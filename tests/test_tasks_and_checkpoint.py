@@ -112,21 +112,33 @@ def test_generate_request_planning_host_side():
         j._task_window("music_inpaint", 3, None, 0)
     with pytest.raises(ValueError):
         j._task_window("remix", 3, None, 0)
-    wav, placeholder = j._known_audio("text_guided", None, None, 3, 2 * sr)
+    wav, placeholder, prefix = j._known_audio("text_guided", None, None, 3, 2 * sr)
+    assert prefix == 0
     assert placeholder and wav.shape == (3, 2, 2 * sr) and float(wav.abs().max()) == 0
     clip = torch.randn((2, sr))                                     # no batch axis: repeated over the batch
-    wav, placeholder = j._known_audio("music_inpaint", clip, sr, 3, sr)
+    wav, placeholder, _ = j._known_audio("music_inpaint", clip, sr, 3, sr)
     assert not placeholder and wav.shape == (3, 2, sr) and torch.equal(wav[2], clip)
     batched = torch.randn((3, 2, sr))                               # batched audio is used as it is
-    wav, _ = j._known_audio("music_inpaint", batched, sr, 3, sr)
+    wav, _, _ = j._known_audio("music_inpaint", batched, sr, 3, sr)
     assert torch.equal(wav, batched)
-    wav, placeholder = j._known_audio("music_cont", clip, sr, 2, 3 * sr)
+    wav, placeholder, prefix = j._known_audio("music_cont", clip, sr, 2, 3 * sr)
+    assert prefix == sr
     assert not placeholder and wav.shape == (2, 2, 3 * sr) and torch.equal(wav[0, :, :sr], clip) and float(wav[:, :, sr:].abs().max()) == 0
     with pytest.raises(ValueError):
         j._known_audio("music_cont", torch.randn((2, 4 * sr)), sr, 2, 3 * sr)
     # the mask of a continuation keeps exactly the prefix
     keep = j.get_mask(3 * sr, *j._task_window("music_cont", 3, None, sr)[:2], 2)
     assert keep.shape == (2, 1, 3 * sr) and float(keep[:, :, :sr].min()) == 1 and float(keep[:, :, sr:].max()) == 0
+    # init_audio at another sample rate: the prefix is measured AFTER convert_audio (generation.py:95, :103), so the keep-mask
+    # boundary falls where the resampled prefix ends
+    half = sr // 2
+    j2 = Jen1(None, device="cpu", audio_encoder=Enc(), conditioner=lambda md, dev: {}, model_config=tiny_model_config(),
+              convert_audio=lambda wav, s_in, s_out, ch: torch.nn.functional.interpolate(wav, scale_factor=s_out / s_in, mode="nearest"))
+    lo = torch.randn((2, half))                                     # 1 s at sr / 2
+    wav, placeholder, prefix = j2._known_audio("music_cont", lo, half, 2, 3 * sr)
+    assert prefix == sr and wav.shape == (2, 2, 3 * sr) and float(wav[:, :, sr:].abs().max()) == 0
+    start_s, end_s, causal = j2._task_window("music_cont", 3, None, prefix)
+    assert (start_s, end_s, causal) == (1.0, 3.0, True)
 
 
 def test_default_initialisation_mirrors_torch_modules():
