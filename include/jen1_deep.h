@@ -116,6 +116,8 @@ typedef struct jen1_deep_hot {
   /* a unit finishes mrep consecutive 16-row M tiles from ONE staged tile (jen1_deep_link: phases with more units than
    * workgroups; divides MT and mt_split): n_units = (MT / mrep) * groups_n */
   int32_t mrep;
+  int32_t pad0_;
+  const float* wscale;        /* JEN1_FP8: [M] scale of the e4m3 weight rows (jen1_conv_args.w_scale), else NULL */
 } jen1_deep_hot;
 
 typedef struct jen1_deep_phase {

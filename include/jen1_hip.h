@@ -29,6 +29,9 @@ extern "C" {
 
 #define JEN1_F32 0
 #define JEN1_BF16 1
+/* OCP e4m3 operands for the matrix cores of the persistent deep-level launch (jen1_deep.h) and of jen1_attention_fin: activations
+ * stay JEN1_BF16 in memory, packed weights are one byte per element with a float32 scale per output row */
+#define JEN1_FP8 2
 
 /* prologue applied to the GEMM's activation operand while it is staged in LDS */
 #define JEN1_PRO_NONE 0
@@ -153,6 +156,8 @@ typedef struct jen1_conv_args {
                                 chunks of K, take the residual and feed out_rowstats; rows >= m_split sum all of K
                                 and take `act`.  Multiple of 16. */
   int32_t k_split;           /* 32-channel chunks of K summed by the rows below m_split */
+  const float* w_scale;      /* JEN1_FP8 (jen1_deep_phase_conv only): [M] float32, the scale of output row m -- `w` holds e4m3
+                                bytes q with W[m][k] = w_scale[m] * q[m][k] in the same fragment order (8 bytes per lane and chunk) */
 } jen1_conv_args;
 
 int jen1_conv_gemm(const jen1_conv_args* args, void* stream);

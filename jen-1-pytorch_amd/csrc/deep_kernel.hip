@@ -43,6 +43,40 @@ constexpr int QCHUNK = 32;
 __device__ __forceinline__ gu64* g64(const void* p) { return (gu64*)(u64)p; }
 __device__ __forceinline__ gu32* g32(const void* p) { return (gu32*)(u64)p; }
 
+// ---- JEN1_FP8 mode (BASELINE configs[4]: "fp8 MFMA attention path"; blocks.py:355-380, :402-407, :440-446) -------------
+// Activations stay bf16 in HBM; what the matrix cores read is OCP e4m3 (gfx950's fp8): the packed weights (one float32 scale
+// per output row, applied in the epilogue), the staged activation tile, and Q / K / P / V^T of the attention unit
+// (v_mfma_f32_16x16x32_fp8_fp8: 8 bytes of K per lane and operand, same lane -> element map as the bf16 form).
+struct fp8_t {
+  unsigned char v;
+};
+static_assert(sizeof(fp8_t) == 1, "one byte per element");
+template <typename T> struct Mode { typedef T G; };            // G: element type of activations in global memory
+template <> struct Mode<fp8_t> { typedef bf16_t G; };
+constexpr float FP8_MAX = 448.0f;
+constexpr float P_SCALE = 256.0f;                              // softmax probabilities (<= 1) are stored as 256 p: 1 / Nk would be a denormal
+// two floats -> two e4m3 bytes (saturating: |x| > 448 would turn into NaN)
+__device__ __forceinline__ unsigned pk_fp8(float a, float b, unsigned old, bool hi) {
+  a = __builtin_amdgcn_fmed3f(a, -FP8_MAX, FP8_MAX);
+  b = __builtin_amdgcn_fmed3f(b, -FP8_MAX, FP8_MAX);
+  return hi ? (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
+}
+using ::store8;
+__device__ __forceinline__ void store8(fp8_t* p, const float (&o)[8]) {
+  unsigned lo = 0, hi = 0;
+  lo = pk_fp8(o[0], o[1], lo, false);
+  lo = pk_fp8(o[2], o[3], lo, true);
+  hi = pk_fp8(o[4], o[5], hi, false);
+  hi = pk_fp8(o[6], o[7], hi, true);
+  *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
+}
+template <typename T> __device__ __forceinline__ T to_elem(float x) { return (T)x; }
+template <> __device__ __forceinline__ fp8_t to_elem<fp8_t>(float x) {
+  fp8_t r;
+  r.v = (unsigned char)(pk_fp8(x, x, 0u, false) & 0xffu);
+  return r;
+}
+
 // ---- 8-element vectors through agent-scope (sc1) accesses: data another workgroup produced in THIS launch --------
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { u64 d[2]; };
@@ -106,6 +140,14 @@ __device__ __forceinline__ void float_to_raw(const float (&x)[8], Raw8<float>& r
 #pragma unroll
   for (int i = 0; i < 4; ++i) r.d[i] = ((u64)__float_as_uint(x[2 * i + 1]) << 32) | __float_as_uint(x[2 * i]);
 }
+// a raw vector into the staged tile: a copy when the tile has the activations' type, a conversion in JEN1_FP8 mode
+__device__ __forceinline__ void stage_raw(bf16_t* dst, const Raw8<bf16_t>& r) { *reinterpret_cast<Raw8<bf16_t>*>(dst) = r; }
+__device__ __forceinline__ void stage_raw(float* dst, const Raw8<float>& r) { *reinterpret_cast<Raw8<float>*>(dst) = r; }
+__device__ __forceinline__ void stage_raw(fp8_t* dst, const Raw8<bf16_t>& r) {
+  float x[8];
+  raw_to_float(r, x);
+  store8(dst, x);
+}
 // 4 consecutive output channels of one position, write-through
 __device__ __forceinline__ void st_live4(bf16_t* p, const float (&v)[4]) {
   bf16x4 a;
@@ -146,6 +188,7 @@ __device__ __forceinline__ void st_live8(float* p, const float* s) {
 template <typename T> struct DFrag;
 template <> struct DFrag<bf16_t> { typedef bf16x8 type; };
 template <> struct DFrag<float> { typedef f32x8 type; };
+template <> struct DFrag<fp8_t> { typedef long type; };
 __device__ __forceinline__ void dmma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
@@ -153,6 +196,10 @@ __device__ __forceinline__ void dmma(f32x4& acc, const f32x8& a, const f32x8& b)
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
+__device__ __forceinline__ void dmma(f32x4& acc, const long& a, const long& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void dlds(long& f, const fp8_t* p) { f = *reinterpret_cast<const long*>(p); }
 __device__ __forceinline__ void dlds(bf16x8& f, const bf16_t* p) { f = *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ void dlds(f32x8& f, const float* p) {
   const float4 a = *reinterpret_cast<const float4*>(p);
@@ -174,6 +221,11 @@ __device__ __forceinline__ void wload(f32x8& f, __amdgpu_buffer_rsrc_t r, unsign
   }
 }
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wload(long& f, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  f = __builtin_bit_cast(long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2));
+}
+__device__ __forceinline__ void frag_zero_d(long& f) { f = 0; }
 __device__ __forceinline__ void frag_zero_d(bf16x8& f) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = (bf16_t)0.f;
@@ -225,6 +277,7 @@ template <typename T> struct DeepCfg;
 #endif
 template <> struct DeepCfg<bf16_t> { static constexpr int MAXV = JEN1_DEEP_MAXV_B, PF = JEN1_DEEP_PF_B; };
 template <> struct DeepCfg<float> { static constexpr int MAXV = JEN1_DEEP_MAXV_F, PF = JEN1_DEEP_PF_F; };
+template <> struct DeepCfg<fp8_t> { static constexpr int MAXV = JEN1_DEEP_MAXV_B, PF = JEN1_DEEP_PF_B; };
 
 // ---- device-resident program: one blob per phase + a header array ----------------------------------------------------
 //   blob  [0, sizeof(jen1_deep_phase))            the descriptor
@@ -571,6 +624,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool PRECISE = is_f32<T>::value;
   constexpr int MAXV = DeepCfg<T>::MAXV;
+  typedef typename Mode<T>::G GT;                     // activations in global memory (T itself, bf16 in JEN1_FP8 mode)
   const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
   const int lane = tid & 63;
   const int wk = rfl(tid >> 6);
@@ -602,7 +656,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const bool npair_ok = norm_C > 0 && nbl < nb && b0 + nbl < B;
   const jen1_deep_src s0 = hot_src<0>(hr), s1 = hot_src<1>(hr);
   const bool in1 = HI(nsrc) > 1 && s1.coff < norm_C && cn >= s1.coff;         // second normalised source (the skip)
-  const T* nbase = reinterpret_cast<const T*>(in1 ? s1.x : s0.x) + (cn - (in1 ? s1.coff : 0)) +
+  const GT* nbase = reinterpret_cast<const GT*>(in1 ? s1.x : s0.x) + (cn - (in1 ? s1.coff : 0)) +
                    (size_t)((unsigned)((npair_ok ? b0 + nbl : b0) * L_in) * (unsigned)(in1 ? s1.ld : s0.ld));
   const int nld = in1 ? s1.ld : s0.ld;
   const float nscale = in1 ? s1.scale : s0.scale;
@@ -620,7 +674,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     load8(HP(p1, const float*) + po, p1);
     load8(HP(p2, const float*) + po, p2);
   }
-  const T* nap[MAXV];
+  const GT* nap[MAXV];
   int ntile[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -638,7 +692,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   int rows_ok = (B - b0) * L_in;                       // staged rows below this belong to real batch elements
   rows_ok = rows_ok < nb * L_in ? rows_ok : nb * L_in;
   rows_ok = Craw > 0 ? rows_ok : 0;
-  const T* rbase;
+  const GT* rbase;
   int rld;
   float rscale;
   {
@@ -657,12 +711,12 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     pick(s1, 1);
     pick(hot_src<2>(hr), 2);
     pick(hot_src<3>(hr), 3);
-    rbase = reinterpret_cast<const T*>(xp) + (cr - coff) + (size_t)((unsigned)(b0 * L_in) * (unsigned)ld);
+    rbase = reinterpret_cast<const GT*>(xp) + (cr - coff) + (size_t)((unsigned)(b0 * L_in) * (unsigned)ld);
     rld = ld;
     rscale = sc;
   }
   const int lpx = Lp - L_in;                            // halo rows per batch element
-  const T* wap[MAXV];
+  const GT* wap[MAXV];
   int wtile[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -702,8 +756,9 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const int nfe = wk;                                   // the fragment this wave finishes
   int co = 0, yrow = 0;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 wsc4 = {1.f, 1.f, 1.f, 1.f};                  // JEN1_FP8: the scale of the tile's four output rows of this lane
   bool okk = false, use_res = false;
-  const T* resp = nullptr;
+  const GT* resp = nullptr;
   auto epi_operands = [&](int mt) {
     const int m = mt * 16 + lg * 4;
     int ph = 0;
@@ -714,6 +769,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       co = m - ph * out_C;
       const float* biasp = HP(bias, const float*);
       if (biasp) bias4 = *reinterpret_cast<const f32x4*>(biasp + co);
+      if (sizeof(T) == 1) wsc4 = *reinterpret_cast<const f32x4*>(HP(wscale, const float*) + m);
       const int n = nfe * 16 + li;
       const int ebl = (int)(((float)n + 0.5f) * inv_Lout);
       const int t = n - ebl * L_out;
@@ -721,7 +777,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < HI(L_y);
       yrow = okk ? (b0 + ebl) * HI(y_brows) + HI(y_row0) + ty : 0;
     }
-    const T* resb = HP(residual, const T*);
+    const GT* resb = HP(residual, const GT*);
     use_res = epi && okk && resb && (HI(mt_split) == 0 || low_m);
     resp = resb + ((size_t)((unsigned)yrow * (unsigned)HI(ld_res)) + (unsigned)co);
   };
@@ -757,7 +813,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 
 #ifndef JEN1_DEEP_EXP_NOSTAGE
   // ---- every load (sc1: another workgroup wrote the data in this launch), no branches ---------------------------------------
-  Raw8<T> xn[MAXV], xw[MAXV];
+  Raw8<GT> xn[MAXV], xw[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) ld_live(xn[i], nap[i]);
 #pragma unroll
@@ -774,11 +830,11 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       for (int j = 0; j < 8; ++j) x[j] *= rscale;
       float_to_raw(x, xw[i]);
     }
-    *reinterpret_cast<Raw8<T>*>(tile + wtile[i]) = xw[i];
+    stage_raw(tile + wtile[i], xw[i]);
   }
   // further trips of a long raw input (e.g. the 94 rows a downsampling conv reads)
   for (int rbeg = MAXV * rpr; rbeg < rows_ok; rbeg += MAXV * rpr) {
-    Raw8<T> xv[MAXV];
+    Raw8<GT> xv[MAXV];
     int vt[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -798,7 +854,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
         for (int j = 0; j < 8; ++j) x[j] *= rscale;
         float_to_raw(x, xv[i]);
       }
-      *reinterpret_cast<Raw8<T>*>(tile + vt[i]) = xv[i];
+      stage_raw(tile + vt[i], xv[i]);
     }
   }
   DK_STAMP(sy, 11);
@@ -822,7 +878,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     // summed here and read again below for the normalisation (their second read is an L2 hit)
     const int ntrips = HI(ntrips);
     for (int trip = 1; trip < ntrips; ++trip) {
-      Raw8<T> xt[MAXV];
+      Raw8<GT> xt[MAXV];
       float mt_[MAXV];
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) {
@@ -861,7 +917,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       store8(tile + ntile[i], xf[i]);
     }
     for (int trip = 1; trip < ntrips; ++trip) {
-      Raw8<T> xt[MAXV];
+      Raw8<GT> xt[MAXV];
       int tt[MAXV];
       float mt_[MAXV];
 #pragma unroll
@@ -956,6 +1012,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
         o[w2].x += o[w2 + st].x; o[w2].y += o[w2 + st].y; o[w2].z += o[w2 + st].z; o[w2].w += o[w2 + st].w;
       }
     }
+    if (sizeof(T) == 1) { o[0].x *= wsc4[0]; o[0].y *= wsc4[1]; o[0].z *= wsc4[2]; o[0].w *= wsc4[3]; }
     v[0] = o[0].x + bias4[0]; v[1] = o[0].y + bias4[1]; v[2] = o[0].z + bias4[2]; v[3] = o[0].w + bias4[3];
     if (HI(act) == JEN1_ACT_GELU && !low_m) {
 #pragma unroll
@@ -970,7 +1027,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       for (int r = 0; r < 4; ++r) v[r] += rres[r];
       const size_t off = (size_t)((unsigned)yrow * (unsigned)HI(ld_y)) + (unsigned)co;
       if (HI(y_f32)) st_live4(HP(y, float*) + off, v);
-      else st_live4(HP(y, T*) + off, v);
+      else st_live4(HP(y, GT*) + off, v);
     }
   };
   {
@@ -1016,7 +1073,10 @@ template <typename T, typename FPub>
 __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, FPub publish_next, int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef typename DFrag<T>::type Frag;
+  typedef typename Mode<T>::G GT;                      // q / k / v / out in global memory (bf16 in JEN1_FP8 mode)
   constexpr bool PRECISE = is_f32<T>::value;
+  constexpr bool F8 = sizeof(T) == 1;
+  constexpr float PS = F8 ? P_SCALE : 1.0f;            // the probabilities are stored as PS * p (see P_SCALE)
   constexpr int MAXVA = (141 * 16 + NT - 1) / NT;      // K / V vectors per thread at the longest supported context
   const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
   const int lane = tid & 63;
@@ -1034,10 +1094,11 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   const int DP = d < 32 ? 32 : d;
   const int DC = d < 16 ? 16 : d;
   const int dq = DP + 8, vt = NKP + 8, sp = NKP + 4;
-  T* q_s = reinterpret_cast<T*>(smem + WS_OFF);                      // [32][dq]  (later the output tile)
-  T* kv_s = q_s + QCHUNK * dq;                                      // K [NKP][dq], later V^T [DC][vt]
+  T* q_s = reinterpret_cast<T*>(smem + WS_OFF);                      // [32][dq]  (later the output tile, in the activations' type)
+  GT* o_s = reinterpret_cast<GT*>(smem + WS_OFF);
+  T* kv_s = reinterpret_cast<T*>(o_s + QCHUNK * dq);                // K [NKP][dq], later V^T [DC][vt]
   const int kv_elems = (NKP * dq > DC * vt) ? NKP * dq : DC * vt;
-  float* s_s = reinterpret_cast<float*>(kv_s + ((kv_elems + 7) & ~7));   // [32][sp]
+  float* s_s = reinterpret_cast<float*>(kv_s + ((kv_elems + 15) & ~15));   // [32][sp]
   T* p_s = reinterpret_cast<T*>(s_s + ((QCHUNK * sp + 3) & ~3));      // [32][vt]
   float2* st_s = reinterpret_cast<float2*>(p_s + ((QCHUNK * vt + 7) & ~7));   // [max(Nk, 32)] LayerNorm (mean, rstd) per row
 
@@ -1045,11 +1106,11 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   const int vpr = 1 << log2_vpr;
   const int nkv = Nk * vpr, nqv = nq * vpr;
   const int hd = h * d;
-  const T* qp = reinterpret_cast<const T*>(AP(q, const void*));
-  const T* kp_ = reinterpret_cast<const T*>(AP(k, const void*));
-  const T* vp_ = reinterpret_cast<const T*>(AP(v, const void*));
-  const T* xp_ = reinterpret_cast<const T*>(AP(kv_extra, const void*));
-  T* const outp = reinterpret_cast<T*>(AP(out, void*));
+  const GT* qp = reinterpret_cast<const GT*>(AP(q, const void*));
+  const GT* kp_ = reinterpret_cast<const GT*>(AP(k, const void*));
+  const GT* vp_ = reinterpret_cast<const GT*>(AP(v, const void*));
+  const GT* xp_ = reinterpret_cast<const GT*>(AP(kv_extra, const void*));
+  GT* const outp = reinterpret_cast<GT*>(AP(out, void*));
   const int fin_q = AI(fin_q), fin_kv = AI(fin_kv), kv_live = AI(kv_live), causal = AI(causal);
   const float scale = AF(scale), ln_eps = AF(ln_eps);
   const int q_off = AI(q_off);
@@ -1058,9 +1119,9 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   const int kvbase = (AP(kv_row, const int32_t*) ? AP(kv_row, const int32_t*)[b] : b) * Nk;
   int xr = (AP(kv_extra, const void*) && AP(extra_row, const int32_t*)) ? AP(extra_row, const int32_t*)[b] : -1;
   if (xr >= 0 && AP(extra_step, const int32_t*)) xr = AP(extra_step, const int32_t*)[0];
-  Raw8<T> kraw[MAXVA], vraw[MAXVA], qraw;
-  const T* kadr[MAXVA];
-  const T* vadr[MAXVA];
+  Raw8<GT> kraw[MAXVA], vraw[MAXVA], qraw;
+  const GT* kadr[MAXVA];
+  const GT* vadr[MAXVA];
   bool kvok[MAXVA];
   {
     const int ld_extra = AI(ld_extra), kx_off = AI(kx_off), vx_off = AI(vx_off), k_off = AI(k_off), v_off = AI(v_off);
@@ -1118,12 +1179,12 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
     const int nvec = ln_C >> 3;
     const float inv_c = 1.0f / (float)ln_C;
     for (int r = tid >> 4; r < rsn; r += NT / 16) {
-      const T* rowp = qp + (size_t)((unsigned)(b * Nq + rs0 + r) * (unsigned)ldq);
+      const GT* rowp = qp + (size_t)((unsigned)(b * Nq + rs0 + r) * (unsigned)ldq);
       float s = 0.f, q2 = 0.f;
       // LNB vectors per lane requested together (bf16: a 1024-column row in one round trip; f32 keeps 2: registers)
-      constexpr int LNB = sizeof(T) == 2 ? 8 : 2;
+      constexpr int LNB = sizeof(GT) == 2 ? 8 : 2;
       for (int v0 = li; v0 < nvec; v0 += 16 * LNB) {
-        Raw8<T> x[LNB];
+        Raw8<GT> x[LNB];
 #pragma unroll
         for (int k = 0; k < LNB; ++k) {
           if (v0 + 16 * k < nvec) ld_live(x[k], rowp + (v0 + 16 * k) * 8);
@@ -1220,12 +1281,12 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   DK_STAMP(sy, 10);
   // ---- V replaces K in LDS, transposed: V^T [d][keys] is the B operand of P V ---------------------------------------------------
   if (d < 16) {
-    for (int i = tid; i < DC * vt; i += NT) kv_s[i] = (T)0.f;
+    for (int i = tid; i < DC * vt; i += NT) kv_s[i] = to_elem<T>(0.f);
     __syncthreads();
   } else {
     for (int i = tid; i < d * 32; i += NT) {
       const int c = i >> 5, j = Nk + (i & 31);
-      if (j < NKP) kv_s[c * vt + (j ^ (((c >> 3) & 3) << 3))] = (T)0.f;
+      if (j < NKP) kv_s[c * vt + (j ^ (((c >> 3) & 3) << 3))] = to_elem<T>(0.f);
     }
   }
 #pragma unroll
@@ -1240,7 +1301,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
       // wave transposes at once would otherwise land on two LDS banks
       const int rs = r ^ (((c >> 3) & 3) << 3);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + rs] = (T)x[e];
+      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + rs] = to_elem<T>(x[e]);
     }
   }
   DK_STAMP(sy, 11);
@@ -1253,7 +1314,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
     if (r < QCHUNK) {
       T* pr = p_s + r * vt;
       if (r >= nq) {
-        for (int j = li; j < NKP; j += 16) pr[j] = (T)0.f;
+        for (int j = li; j < NKP; j += 16) pr[j] = to_elem<T>(0.f);
       } else {
         const float* sr = s_s + r * sp + j0;
         float4 x[3];
@@ -1278,10 +1339,10 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
           sum += e[t];
         }
         sum = row16_sum_d(sum);
-        const float inv = PRECISE ? 1.0f / sum : __builtin_amdgcn_rcpf(sum);
+        const float inv = (PRECISE ? 1.0f / sum : __builtin_amdgcn_rcpf(sum)) * PS;
 #pragma unroll
         for (int t = 0; t < 12; ++t) {
-          if (t < kpl && j0 + t < NKP) pr[j0 + t] = (T)(e[t] * inv);
+          if (t < kpl && j0 + t < NKP) pr[j0 + t] = to_elem<T>(e[t] * inv);
         }
       }
     }
@@ -1304,7 +1365,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = qt * 16 + lg * 4 + r;
-        q_s[qi * dq + ct * 16 + li] = (T)acc[r];
+        o_s[qi * dq + ct * 16 + li] = (GT)(F8 ? acc[r] * (1.0f / P_SCALE) : acc[r]);
       }
     }
   }
@@ -1312,8 +1373,8 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   __syncthreads();
   DK_STAMP(sy, 4);
   if (tid < nqv) {
-    T* op = outp + ((size_t)((unsigned)(b * Nq + q0 + kr0) * (unsigned)ldo) + (unsigned)(hd + kc0));
-    st_live8(op, q_s + kr0 * dq + kc0);
+    GT* op = outp + ((size_t)((unsigned)(b * Nq + q0 + kr0) * (unsigned)ldo) + (unsigned)(hd + kc0));
+    st_live8(op, o_s + kr0 * dq + kc0);
   }
   }
   publish_next();
@@ -1333,7 +1394,8 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
   const int b = u, L = P->sL, ld = P->sld, cpf = P->scpf, gran = P->sgran;
-  const T* sx = reinterpret_cast<const T*>(P->sx);
+  typedef typename Mode<T>::G GT;
+  const GT* sx = reinterpret_cast<const GT*>(P->sx);
   float* const sstats = P->sstats;
   DK_STAMP(sy, 0);
   DK_STAMP(sy, 1);
@@ -1345,9 +1407,9 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
   float s[8], q[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
-  const T* xp = sx + (size_t)b * L * ld + vc * 8;
+  const GT* xp = sx + (size_t)b * L * ld + vc * 8;
   for (int r = r0; r < L; r += rstep) {
-    Raw8<T> x;
+    Raw8<GT> x;
     ld_live(x, xp + (size_t)r * ld);
     float f[8];
     raw_to_float(x, f);
@@ -1484,7 +1546,8 @@ extern "C" int jen1_deep_debug_buffer(void* p) {
 
 extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_deep_phase* out) {
   JEN1_CHECK(a && out, "deep conv: null pointer");
-  JEN1_CHECK(a->dtype == JEN1_F32 || a->dtype == JEN1_BF16, "deep conv: bad dtype");
+  JEN1_CHECK(a->dtype == JEN1_F32 || a->dtype == JEN1_BF16 || a->dtype == JEN1_FP8, "deep conv: bad dtype");
+  JEN1_CHECK(a->dtype != JEN1_FP8 || (a->w_scale && !a->y_f32), "deep conv: JEN1_FP8 needs the per-row weight scales (w_scale) and a bf16 output");
   JEN1_CHECK(a->x0 && a->w && a->y, "deep conv: null tensor");
   JEN1_CHECK(a->pro_mode == JEN1_PRO_NONE || a->pro_mode == JEN1_PRO_GN || a->pro_mode == JEN1_PRO_GN_SILU,
              "deep conv: prologue %d is not supported by the persistent kernel", a->pro_mode);
@@ -1493,10 +1556,11 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   JEN1_CHECK(a->taps >= 1 && a->stride >= 1 && a->B >= 1 && a->L_in >= 1 && a->L_out >= 1, "deep conv: bad geometry");
   JEN1_CHECK(a->nseg >= 0 && a->nseg <= JEN1_DEEP_MAX_SRC - 2, "deep conv: at most %d extra K segments", JEN1_DEEP_MAX_SRC - 2);
   JEN1_CHECK(a->taps + a->nseg <= JEN1_DEEP_MAX_SEG, "deep conv: too many K segments");
-  const int es = a->dtype == JEN1_F32 ? 4 : 2;
+  const int es = a->dtype == JEN1_F32 ? 4 : (a->dtype == JEN1_FP8 ? 1 : 2);      // staged tile / packed weights
   const int maxv = a->dtype == JEN1_F32 ? JEN1_DEEP_MAXV_F : JEN1_DEEP_MAXV_B;
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
+  p.h.wscale = a->dtype == JEN1_FP8 ? a->w_scale : nullptr;
   p.h.kind = JEN1_DEEP_GEMM;
   p.h.dtype = a->dtype;
   p.h.dep = -1;
@@ -1649,7 +1713,7 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
                                          int causal, float scale, const float* ln_u, const float* ln_b, int ln_C, float ln_eps,
                                          int finish_q, int finish_kv, int kv_live, int dtype, jen1_deep_phase* out) {
   JEN1_CHECK(q && k && v && out_t && out, "deep attention: null pointer");
-  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "deep attention: bad dtype");
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "deep attention: bad dtype");
   JEN1_CHECK(B >= 1 && H >= 1 && Nq >= 1 && Nk >= 1, "deep attention: bad sizes");
   JEN1_CHECK(d == 8 || d == 16 || d == 32 || d == 64 || d == 128, "deep attention: head dim %d must be 8, 16, 32, 64 or 128", d);
   JEN1_CHECK(Nk <= 192 && Nk * (d / 8) <= ((141 * 16 + JEN1_DEEP_THREADS - 1) / JEN1_DEEP_THREADS) * JEN1_DEEP_THREADS, "deep attention: Nk=%d d=%d outside the kernel's range", Nk, d);
@@ -1659,13 +1723,13 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
   JEN1_CHECK(!fin || (ln_u && ln_b && ln_C >= 8 && ln_C % 8 == 0), "deep attention: a LayerNorm finish needs u, bias and ln_C");
   JEN1_CHECK(!finish_kv || (!kv_row && !kv_extra && Nk * (d / 8) <= JEN1_DEEP_THREADS && Nq == Nk && kv_live),
              "deep attention: the K/V finish is for self-attention over at most %d vectors", JEN1_DEEP_THREADS);
-  const int es = dtype == JEN1_F32 ? 4 : 2;
+  const int es = dtype == JEN1_F32 ? 4 : 2;      // (JEN1_FP8: sized like bf16 -- the output tile is bf16, the fp8 operands need less)
   const int DP = d < 32 ? 32 : d, DC = d < 16 ? 16 : d;
   const int NKP = (Nk + 31) & ~31, dq = DP + 8, vt = NKP + 8, sp = NKP + 4;
   const int64_t kv_elems = (NKP * dq > DC * vt) ? NKP * dq : DC * vt;
   const int st_rows = Nk > QCHUNK ? Nk : QCHUNK;
   const int64_t lds = (int64_t)es * QCHUNK * dq + es * ((kv_elems + 7) & ~(int64_t)7) + 4 * (((int64_t)QCHUNK * sp + 3) & ~(int64_t)3) +
-                      es * (((int64_t)QCHUNK * vt + 7) & ~(int64_t)7) + 8 * st_rows;
+                      es * (((int64_t)QCHUNK * vt + 7) & ~(int64_t)7) + 8 * st_rows + 32;
   JEN1_CHECK(lds <= LDS_BUDGET, "deep attention: Nk=%d d=%d needs %lld B of LDS", Nk, d, (long long)lds);
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
@@ -1690,7 +1754,7 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
 
 extern "C" int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, int ld, int dtype, jen1_deep_phase* out) {
   JEN1_CHECK(x && stats && out && B >= 1 && L >= 1, "deep stats: bad arguments");
-  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "deep stats: bad dtype");
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "deep stats: bad dtype");
   JEN1_CHECK(ld >= 32 && (ld & (ld - 1)) == 0 && ld / 8 <= JEN1_DEEP_THREADS, "deep stats: row pitch %d must be a power of two in [32, 8192]", ld);
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
@@ -1769,7 +1833,7 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
     }
     if (!P.h.mt_split) for (int w = 0; w < NW; ++w) { cnt[NW + w] = cnt[w]; cnt[3 * NW + w] = cnt[2 * NW + w]; }
     // the first ring round of every wave, tabulated (chunk index, staged offset), and the cursor behind it
-    const int pf = P.h.dtype == JEN1_F32 ? JEN1_DEEP_PF_F : JEN1_DEEP_PF_B;
+    const int pf = P.h.dtype == JEN1_F32 ? JEN1_DEEP_PF_F : JEN1_DEEP_PF_B;      // (JEN1_FP8: DeepCfg<fp8_t>::PF = PF_B)
     int32_t* slots = reinterpret_cast<int32_t*>(b + SLOT_OFF);
     int32_t* curs = reinterpret_cast<int32_t*>(b + CUR_OFF);
     for (int w = 0; w < NW; ++w) {
@@ -1821,19 +1885,21 @@ extern "C" int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev,
                                  int lds_bytes, int dtype, void* stream) {
   JEN1_CHECK(blobs_dev && headers_dev && sync && err && n_phases >= 1 && n_phases <= JEN1_DEEP_MAX_PHASES && nwg >= 1, "deep run: bad arguments");
   JEN1_CHECK(lds_bytes >= WS_OFF && lds_bytes <= LDS_TOTAL, "deep run: %d B of LDS", lds_bytes);
-  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "deep run: bad dtype");
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "deep run: bad dtype");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int dev = 0;
   JEN1_HIP(hipGetDevice(&dev));
-  static unsigned long long attr_set[2] = {0ull, 0ull};       // per dtype, one bit per device ordinal
-  const void* fn = dtype == JEN1_F32 ? reinterpret_cast<const void*>(deep_kernel<float>) : reinterpret_cast<const void*>(deep_kernel<bf16_t>);
-  if (dev >= 64 || !(attr_set[dtype == JEN1_F32 ? 0 : 1] >> dev & 1ull)) {
+  static unsigned long long attr_set[3] = {0ull, 0ull, 0ull};       // per dtype, one bit per device ordinal
+  const void* fn = dtype == JEN1_F32 ? reinterpret_cast<const void*>(deep_kernel<float>)
+                 : dtype == JEN1_FP8 ? reinterpret_cast<const void*>(deep_kernel<fp8_t>) : reinterpret_cast<const void*>(deep_kernel<bf16_t>);
+  if (dev >= 64 || !(attr_set[dtype] >> dev & 1ull)) {
     JEN1_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    if (dev < 64) attr_set[dtype == JEN1_F32 ? 0 : 1] |= 1ull << dev;
+    if (dev < 64) attr_set[dtype] |= 1ull << dev;
   }
   const unsigned char* bl = reinterpret_cast<const unsigned char*>(blobs_dev);
   const int4* hd = reinterpret_cast<const int4*>(headers_dev);
   if (dtype == JEN1_F32) hipLaunchKernelGGL(deep_kernel<float>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
+  else if (dtype == JEN1_FP8) hipLaunchKernelGGL(deep_kernel<fp8_t>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
   else hipLaunchKernelGGL(deep_kernel<bf16_t>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
   JEN1_HIP(hipGetLastError());
   return 0;

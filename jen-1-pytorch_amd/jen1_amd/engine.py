@@ -68,6 +68,7 @@ class Weights:
         p = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in params.items()}
         self.w: Dict[str, torch.Tensor] = {}
         self.v: Dict[str, torch.Tensor] = {}
+        self._fp8: Dict[int, tuple] = {}
         pk = lambda w_tmk: pack_gemm_weight(w_tmk, dtype)
         f32 = lambda t: t.contiguous()
 
@@ -227,6 +228,23 @@ class Weights:
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.w.values())
 
+    def fp8(self, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """JEN1_FP8 form of a packed weight ([..][M/16][64 lanes][8], any leading block dims): OCP e4m3 bytes in the same
+        fragment order + one float32 scale per output row m = 16 mt + (lane & 15), chosen so that the row's largest magnitude
+        maps to 448 (the e4m3 maximum).  Cached per packed tensor; built when a plan first puts the layer into the persistent
+        launch (the launch-per-layer levels keep the bf16 copy)."""
+        hit = self._fp8.get(id(w))
+        if hit is not None and hit[0] is w:
+            return hit[1], hit[2]
+        MT = w.shape[-3]
+        wf = w.reshape(-1, MT, 4, 16, 8).to(torch.float32)                   # [chunk, mt, g, i, j]
+        amax = wf.abs().amax(dim=(0, 2, 4))                                  # [mt, i]
+        scale = (amax / 448.0).clamp_min(1e-20)
+        q = (wf / scale[None, :, None, :, None]).to(torch.float8_e4m3fn).view(torch.uint8).reshape(-1, MT, 64, 8).contiguous()
+        scale = scale.reshape(-1).contiguous()
+        self._fp8[id(w)] = (w, q, scale)
+        return q, scale
+
 
 class DeepIneligible(Exception):
     """a layer does not fit the persistent deep-level kernel (LDS / staging registers / unsupported option)"""
@@ -270,7 +288,7 @@ class DeepProgram:
 
     def add_stats(self, x: "Act", stats: torch.Tensor, label: str):
         buf = self._new()
-        self._add(buf, self.lib.jen1_deep_phase_stats(x.t.data_ptr(), stats.data_ptr(), x.B, x.L, x.ld, self.eng.dt,
+        self._add(buf, self.lib.jen1_deep_phase_stats(x.t.data_ptr(), stats.data_ptr(), x.B, x.L, x.ld, self.eng.deep_dt,
                                                       C.cast(buf, C.c_void_p)), label, None)
 
     def __len__(self):
@@ -304,7 +322,7 @@ class DeepProgram:
         if os.environ.get("JEN1_DEEP_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_DEEP_RUN_PHASES"]))
         L.check(self.lib.jen1_deep_run_err(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.err.data_ptr(), self.nwg,
-                                           self.lds, self.eng.dt, stream), "jen1_deep_run_err")
+                                           self.lds, self.eng.deep_dt, stream), "jen1_deep_run_err")
 
     def error(self) -> int:
         """non-zero after a launch whose dependency wait timed out (1 + phase index); synchronises with the device"""
@@ -327,6 +345,7 @@ class KernelCtx:
         self.device = torch.device(device)
         self.dt = L.F32 if dtype == "f32" else L.BF16
         self.tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.deep_dt = self.dt
         self.target_wgs = target_wgs
         self.splitk_target_wgs = 512
         self.splitk_min_bytes = 1 << 20
@@ -455,6 +474,11 @@ class OpBuilder:
             if pro == L.PRO_LN or y_f32 or row_scale is not None:
                 raise DeepIneligible(f"{label}: prologue / epilogue option outside the persistent kernel")
             a.out_gn_stats = a.out_rowstats = None
+            w8 = None
+            if eng.deep_dt == L.FP8:
+                # JEN1_FP8: e4m3 weights + per-row scales feed the fp8 matrix-core path of the unit; activations stay bf16 in HBM
+                w8 = eng.W.fp8(w)
+                a.dtype, a.w, a.w_scale = L.FP8, w8[0].data_ptr(), w8[1].data_ptr()
             if pro in (L.PRO_GN, L.PRO_GN_SILU) and film is not None:
                 a.film = self.film2.data_ptr()
             a.nseg = 0
@@ -465,13 +489,13 @@ class OpBuilder:
                 a.nseg = len(extra_segs)
             if m_split:
                 a.m_split, a.k_split = m_split, k_split
-            self._keep.append((a, src0, src1, w, bias, out, residual, gn, film, extra_segs))
+            self._keep.append((a, src0, src1, w, w8, bias, out, residual, gn, film, extra_segs))
             self.deep.add_conv(a, f"conv[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} M={a.M}", out,
                                nb_max=eng.deep_nb_max)
             es_ = 4 if eng.dt == L.F32 else 2
             c_real_ = src0.C + (src1.C if src1 is not None else 0)
             c_extra_ = sum(e.C for e, _ in extra_segs) if extra_segs else 0
-            self.deep_w_bytes += (taps * c_real_ + c_extra_) * a.M * es_
+            self.deep_w_bytes += (taps * c_real_ + c_extra_) * a.M * (1 if w8 is not None else es_) + (4 * a.M if w8 is not None else 0)
             self.deep_act_bytes += a.B * a.L_in * (c_real_ + c_extra_) * es_ + a.B * a.L_y * out_C * es_
             self.deep_flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
             return out
@@ -742,7 +766,7 @@ class OpBuilder:
             kv_live = 1 if kv_row is None and kv_extra is None else 0      # self-attention: K / V come from the previous phase
             dargs = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
                      _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off,
-                     out.ld, 1 if causal else 0, float(d) ** -0.5, _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, kv_live, eng.dt)
+                     out.ld, 1 if causal else 0, float(d) ** -0.5, _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, kv_live, eng.deep_dt)
             self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row, extra_step, fin))
             self.deep.add_attention(dargs, f"attention B={q.B} H={H} d={d} Nq={q.L} Nk={Nk} causal={causal}", out)
             return
@@ -1193,12 +1217,15 @@ class Plan(OpBuilder):
 
 class Engine:
     def __init__(self, spec: UNetSpec, params: Dict[str, torch.Tensor], dtype: str = "bf16", device="cuda"):
-        assert dtype in ("f32", "bf16")
+        assert dtype in ("f32", "bf16", "fp8")
         self.lib = L.load()
         self.spec = spec
         self.device = torch.device(device)
         self.dt = L.F32 if dtype == "f32" else L.BF16
         self.tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        # "fp8" (BASELINE configs[4]): activations and the launch-per-layer levels as in "bf16"; the persistent deep-level launch --
+        # 94 % of the weights at T = 1500, 87 % at T = 9000 -- runs its GEMM and attention units on OCP e4m3 operands
+        self.deep_dt = L.FP8 if dtype == "fp8" else self.dt
         self.skip_scale = 2 ** -0.5 if spec.use_skip_scale else 1.0
         self.target_wgs = 256
         self.splitk_target_wgs = int(os.environ.get("JEN1_SPLITK_WGS", "128"))

@@ -19,7 +19,7 @@ INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "deep_kernel.hip", "elementwise.hip",
            "optimizer.hip", "train_gemm.hip", "train_ops.hip", "encodec.hip"]
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU = 0, 1
 CFG_W64x64, CFG_W128x64, CFG_S16x64, CFG_S16x32, CFG_S16x16 = 0, 1, 2, 3, 4
@@ -58,7 +58,7 @@ class ConvArgs(C.Structure):
         ("kc_stage", c_int), ("splitk", c_int), ("cfg", c_int), ("direct", c_int),
         ("zeros", c_void_p), ("tiles_t", c_int), ("inv_tiles_t", c_float), ("inv_tb", c_float),
         ("film_step", c_void_p), ("ln_u", c_void_p), ("ln_fold", c_int), ("nseg", c_int),
-        ("seg", ConvSeg * MAX_SEG), ("m_split", c_int), ("k_split", c_int),
+        ("seg", ConvSeg * MAX_SEG), ("m_split", c_int), ("k_split", c_int), ("w_scale", c_void_p),
     ]
 
 

@@ -118,6 +118,7 @@ class UNetCFG1d(nn.Module):
         gradients are enabled and the module is in training mode (trainer.py:194, :204-208)."""
         from .train import TrainGraph
         cd = compute_dtype or self.compute_dtype
+        cd = "bf16" if cd == "fp8" else cd          # (JEN1_FP8 is a sampling mode; training computes in bf16 / float32 master weights)
         if self._train_graph is None or self._train_graph.compute_dtype != cd:
             self._train_graph = TrainGraph(self, self.spec, cd, self._device)
         return self._train_graph

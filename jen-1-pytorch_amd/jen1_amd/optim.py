@@ -200,7 +200,7 @@ class GradExchange:
             self.regions[r] = (min(lo, o), max(hi, o + (p.numel() + 3) // 4 * 4))
         # regions are contiguous slices of the flat buffer: disjoint, and together they cover it (each is reduced exactly once)
         spans = sorted(self.regions.values())
-        assert spans[0][0] == 0 and spans[-1][1] == opt.numel and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), \
+        assert spans[0][0] == 0 and spans[-1][1] == opt.flat_grad.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), \
             "parameter regions must tile the flat gradient buffer"
         self.bf16 = grad_dtype == "bf16"
         self._wire: Optional[torch.Tensor] = None

@@ -54,6 +54,14 @@ def full_bf16():
     return UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
 
 
+@pytest.fixture(scope="module")
+def full_fp8():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="fp8", device="cuda")
+
+
 def run_plan(model, plan, x, t, cond, drop=None):
     s = torch.cuda.current_stream().cuda_stream
     model._prepare(plan, dev(x), dev(t), dev(cond["cross_attn_cond"]), dev(cond["cross_attn_masks"]), [dev(cond["input_concat_cond"])], drop)
@@ -183,3 +191,109 @@ def test_deep_sampler_graph_replay_matches_eager(tiny_f32):
         torch.cuda.synchronize()
         outs.append(y.cpu().numpy())
     assert rel_err(outs[1], outs[0]) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# JEN1_FP8 (BASELINE configs[4] "fp8 MFMA attention path"): OCP e4m3 operands on the matrix cores of the persistent launch
+# ---------------------------------------------------------------------------------------------------------------------------
+FP8_TOL = 1.5e-1       # max-abs / max-ref of the denoiser output against the reference's float32 output (3 mantissa bits per operand)
+FP8_L2 = 1.0e-1        # relative L2 of the same
+
+
+def _golden(name):
+    from helpers import golden
+    return golden(name)
+
+
+def test_fp8_weights_are_e4m3_with_row_scales(full_fp8):
+    """packing: the e4m3 bytes times the row scale reproduce the bf16 weight to e4m3 precision (2^-4 relative per element), the
+    row maximum maps to 448 exactly, and only layers inside the persistent launch own an fp8 copy"""
+    eng = full_fp8.engine()
+    plan = eng.plan(1, 9000, 2, True)
+    assert plan.deep_level is not None and eng.deep_dt == 2 and eng.tdtype == torch.bfloat16
+    W = eng.W
+    assert len(W._fp8) > 50
+    w = W.w["bottleneck.pre_block.conv1"]
+    q, sc = W.fp8(w)
+    assert q.dtype == torch.uint8 and q.numel() == w.numel() and sc.numel() == w.shape[-3] * 16
+    MT = w.shape[-3]
+    deq = q.view(torch.float8_e4m3fn).float().reshape(-1, MT, 4, 16, 8) * sc.reshape(MT, 16)[None, :, None, :, None]
+    ref = w.float().reshape(-1, MT, 4, 16, 8)
+    rowmax = ref.abs().amax(dim=(0, 2, 4))
+    assert float(((deq - ref).abs() / rowmax[None, :, None, :, None]).max()) <= 2.0 ** -4
+    assert float(q.view(torch.float8_e4m3fn).float().abs().amax()) == 448.0
+    assert not any(id(W.w[k]) in W._fp8 for k in W.w if k.startswith("to_in.") or k.startswith("downsamples.0."))
+
+
+@pytest.mark.parametrize("B,T,nrep,causal", [(8, 1500, 1, False), (1, 9000, 2, True)])
+def test_fp8_deep_activations_track_the_bf16_path(full_fp8, B, T, nrep, causal):
+    """every activation of the fp8 persistent launch against the launch-per-layer plan of the same engine (bf16 everywhere):
+    e4m3 operands cost ~3 % per GEMM; the error must stay at that level through the whole chain (a wrong fragment layout, scale
+    or P scaling would be O(1))"""
+    pd, worst = compare_paths(full_fp8, B, T, nrep, causal, task="music_cont" if causal else "text_guided", tol=3.5e-1)
+    assert pd.deep_level is not None, pd.deep_errors
+    print(f"fp8 B={B} T={T}: deep from level {pd.deep_level}, {len(pd.deep)} phases, worst activation difference to the bf16 path {worst:.2e}")
+
+
+def test_fp8_long_form_vs_golden(full_fp8, full_bf16):
+    """BASELINE configs[4] as named: B = 1, T = 9000, CFG pair, continuation (causal) and inpainting, in JEN1_FP8 mode against the
+    reference's float32 output (tests/golden/full_bench.npz); bf16 is printed next to it.  Stated tolerance: FP8_TOL / FP8_L2."""
+    g = _golden("full_bench")
+    B, T = 1, 9000
+    t = np.array([499], dtype=np.int64)
+    for task, causal in (("music_cont", True), ("music_inpaint", False)):
+        x, cond = synth.latents(B, T), synth.conditioning(B, T, task)
+        res = {}
+        for name, m in (("fp8", full_fp8), ("bf16", full_bf16)):
+            y = m(dev(x), dev(t), embedding=dev(cond["cross_attn_cond"]), embedding_mask=dev(cond["cross_attn_masks"]), embedding_scale=0.8,
+                  batch_cfg=True, scale_cfg=True, channels_list=[dev(cond["input_concat_cond"])], causal=causal)
+            torch.cuda.synchronize()
+            got, ref = y.cpu().numpy()[:, :, ::24].astype(np.float64), g[f"T9000.y.{task}"].astype(np.float64)
+            res[name] = (rel_err(got, ref), float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+        print(f"T=9000 {task}: fp8 max-abs/max-ref {res['fp8'][0]:.3e} rel-L2 {res['fp8'][1]:.3e} | bf16 {res['bf16'][0]:.3e} / {res['bf16'][1]:.3e}")
+        assert res["fp8"][0] < FP8_TOL and res["fp8"][1] < FP8_L2, (task, res)
+        plan = full_fp8.engine().plan(B, T, 2, causal)
+        assert plan.deep_level is not None and plan.deep.error() == 0
+
+
+def test_fp8_long_form_ddim_vs_golden(full_fp8):
+    """the 2-step T = 9000 continuation DDIM golden (make_golden.py fullbench) through the fp8 plan as a replayed graph: gated on
+    the relative L2 of the sample like bf16 (the x0 clamp turns single-entry errors into tenths of the range)"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    g = _golden("full_bench")
+    betas, _ = get_beta_schedule("linear", 1000)
+    B, T, S = 1, 9000, 2
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, "music_cont").items()}
+    shape = (B, 128, T)
+    init = dev(synth.noise_list(1, shape, seed=7)[0])
+    noises = [dev(n) for n in synth.noise_list(S, shape, seed=11)]
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                           embedding_scale=0.8, batch_cfg=True, scale_cfg=True, sampling_timesteps=S)
+    y = gd.sample(full_fp8, shape, cond, causal=True, init_noise=init, step_noises=noises, use_graph=True)
+    torch.cuda.synchronize()
+    got, ref = y.cpu().numpy()[:, :, ::24].astype(np.float64), g["ddim2.T9000.cont"].astype(np.float64)
+    l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    print(f"ddim2.T9000.cont fp8: max-abs/max-ref {rel_err(got, ref):.3e}, relative L2 {l2:.3e}")
+    assert l2 < 2.5e-1
+
+
+def test_fp8_launch_replays_bit_identically(full_fp8):
+    B, T = 1, 9000
+    plan = full_fp8.engine().plan(B, T, 2, True, deep=True)
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "music_cont")
+    run_plan(full_fp8, plan, x, np.array([499], dtype=np.int64), cond)
+    prog = plan.deep
+    assert prog.error() == 0
+    outs = [a for a in prog.outs if a is not None]
+    watch = [outs[-1], outs[len(outs) // 2]]
+    want = [a.t.clone() for a in watch]
+    s = torch.cuda.current_stream().cuda_stream
+    for rep in range(50):
+        for a in watch:
+            a.t.fill_(float("nan"))
+        prog.sync.zero_()
+        prog.launch(s)
+        torch.cuda.synchronize()
+        assert prog.error() == 0
+        for a, w in zip(watch, want):
+            assert torch.equal(a.t, w), f"replay {rep}: output of the fp8 persistent launch changed"

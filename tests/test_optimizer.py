@@ -224,7 +224,33 @@ def _exchange_worker(rank, world, port, q):
     overlapped = opt.flat_grad.clone()
     opt.flat_grad.copy_(g0)
     ex.blocking()
-    q.put((rank, overlapped.numpy().copy(), opt.flat_grad.numpy().copy(), g0.numpy().copy(), dict(ex.regions)))
+    blocking = opt.flat_grad.clone()
+    # the ordering check (debug_check): a region whose gradient changes after its hook fired is reported, a quiet pass is not
+    opt.flat_grad.copy_(g0)
+    ex.debug_check = True
+    ex.begin()
+    ex.region_ready("to_out")
+    ex.finish()
+    assert torch.equal(opt.flat_grad, blocking)
+    opt.flat_grad.copy_(g0)
+    ex.begin()
+    ex.region_ready("to_out")
+    lo, hi = ex.regions["to_out"]
+    opt.flat_grad[lo] += 1.0
+    try:
+        ex.finish()
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised
+    ex.debug_check = False
+    # bf16 on the wire: same chunks, the mean is bf16-accurate
+    exb = GradExchange(opt, _EX_NAMES, bucket_bytes=512, grad_dtype="bf16")
+    opt.flat_grad.copy_(g0)
+    exb.blocking()
+    assert float((opt.flat_grad - blocking).abs().max()) <= 2e-2 * float(blocking.abs().max())
+    assert not exb.capturable                  # gloo / CPU buffers cannot be recorded into a graph
+    q.put((rank, overlapped.numpy().copy(), blocking.numpy().copy(), g0.numpy().copy(), dict(ex.regions)))
     dist.destroy_process_group()
 
 
