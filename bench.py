@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--length", type=int, default=1500)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -648,6 +648,26 @@ def main():
                         "deep_kernel": None if d5 is None else {k: d5[k] for k in ("phases", "avg_launch_us", "us_per_phase", "alg_bytes_per_launch",
                                                                                    "achieved", "frac")}}
                     del st5
+                    # configs[4] as named: the JEN1_FP8 mode (e4m3 weights + fp8 matrix-core GEMM / attention units of the persistent
+                    # launch, fp8 attention on the launch-per-layer levels; activations and the long levels stay bf16)
+                    if args.dtype == "bf16":
+                        m8 = UNetCFG1d(**cfg, init_seed=1234, compute_dtype="fp8", device=device)
+                        st8 = build_stepper(m8, 1, 9000, device, cfg_pair=True, use_graph=True)
+                        dt8 = timed_steps(st8, n5, 3, lambda: None)
+                        d8 = deep_roofline(st8, "fp8")
+                        e8 = {"what": "configs[4]: B=1, T=9000, CFG pair, JEN1_FP8 mode (e4m3 operands in the persistent launch and in attention)",
+                              "steps_per_s": round(n5 / dt8, 2), "ms_per_step": round(dt8 / n5 * 1e3, 4),
+                              "roofline": None if d8 is None else {k: d8[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "phases", "avg_launch_us",
+                                                                                      "us_per_phase", "alg_bytes_per_launch", "alg_weight_bytes", "alg_act_bytes")}}
+                        del st8
+                        st8 = build_stepper(m8, B, T, device, cfg_pair=False, use_graph=True)
+                        dt8 = timed_steps(st8, max(10, args.steps // 2), 3, lambda: None)
+                        e8["configs[1] shape (B=8, T=1500) in JEN1_FP8 mode, steps/s"] = round(max(10, args.steps // 2) / dt8, 2)
+                        d8 = deep_roofline(st8, "fp8")
+                        if d8 is not None:
+                            e8["configs[1] shape deep_kernel<fp8>"] = {k: d8[k] for k in ("avg_launch_us", "us_per_phase", "alg_bytes_per_launch", "achieved", "frac")}
+                        out["extra"]["configs[4] fp8"] = e8
+                        del st8, m8
                     out["extra"]["concurrent_batches"] = [concurrent_batches_bench(model, B, T, device, n, max(20, args.steps // 2), 5)
                                                           for n in (2, 4)]
         if world == 1 and not args.no_cpu_baseline:

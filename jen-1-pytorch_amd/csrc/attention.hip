@@ -31,6 +31,19 @@ constexpr int MAXV = 9;        // 8-element vectors per thread for one K or V ti
 template <typename T> struct AFrag;
 template <> struct AFrag<bf16_t> { typedef bf16x8 type; };
 template <> struct AFrag<float> { typedef f32x8 type; };
+template <> struct AFrag<fp8_t> { typedef long type; };
+__device__ __forceinline__ void amma(f32x4& acc, const long& a, const long& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void lds_frag(long& f, const fp8_t* p) { f = *reinterpret_cast<const long*>(p); }
+// a raw Q / K vector into its LDS tile: a copy when the tile has the tensors' type, a conversion in JEN1_FP8 mode
+__device__ __forceinline__ void stage_vec(bf16_t* dst, const bf16x8& v) { *reinterpret_cast<bf16x8*>(dst) = v; }
+__device__ __forceinline__ void stage_vec(float* dst, const f32x8& v) { *reinterpret_cast<f32x8*>(dst) = v; }
+__device__ __forceinline__ void stage_vec(fp8_t* dst, const bf16x8& v) {
+  float x[8];
+  vec_to_float(v, x);
+  store8(dst, x);
+}
 __device__ __forceinline__ void amma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
@@ -72,7 +85,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 //   * Q K^T and P V run on the matrix cores (v_mfma_f32_16x16x32_bf16, or 16x16x4_f32 in the float32 parity mode:
 //     exact fp32 products) from LDS tiles: Q [32][d], K [Nk][d], then V transposed [d][Nk] in K's place;
 //   * softmax in float32, one wavefront per row, 64-lane __shfl_xor max / sum (blocks.py:367-371).
-template <typename T>
+// ST: what the matrix cores read from LDS (T itself; fp8_t in JEN1_FP8 mode: Q K^T and P V on e4m3 operands, float32 softmax kept --
+// blocks.py:355-380 -- with the probabilities stored as 256 p and the factor taken out of the accumulator)
+template <typename T, typename ST>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ v, T* __restrict__ out,
                                                          const int32_t* __restrict__ kv_row,
@@ -85,9 +100,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
                                                          const float* __restrict__ fin_stats, const float* __restrict__ fin_u,
                                                          const float* __restrict__ fin_b, float fin_inv_c, float fin_eps,
                                                          int fin_q, int fin_kv, float inv_H, int log2_vpr) {
-  typedef typename AFrag<T>::type Frag;
+  typedef typename AFrag<ST>::type Frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool PRECISE = is_f32<T>::value;
+  constexpr bool F8 = sizeof(ST) == 1;
+  constexpr float PS = F8 ? JEN1_FP8_P_SCALE : 1.0f;
   jen1_prefetch_kernarg<184>();
   AT_STAMP(0);
   const int bh = blockIdx.x;
@@ -103,11 +120,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
   const int dq = DP + 8;                         // row pitch of Q / K (elements): 16-byte rows, banks spread
   const int vt = NKP + 8;                        // row pitch of V^T and P
   const int sp = NKP + 4;                        // row pitch of the float32 scores (float4 reads in the softmax)
-  T* q_s = reinterpret_cast<T*>(smem);                               // [32][dq]
-  T* kv_s = q_s + QCHUNK * dq;                                      // K [NKP][dq], later V^T [d][vt]
+  ST* q_s = reinterpret_cast<ST*>(smem);                             // [32][dq]
+  ST* kv_s = q_s + QCHUNK * dq;                                     // K [NKP][dq], later V^T [d][vt]
   const int kv_elems = (NKP * dq > DC * vt) ? NKP * dq : DC * vt;
-  float* s_s = reinterpret_cast<float*>(kv_s + ((kv_elems + 7) & ~7));   // [32][sp]
-  T* p_s = reinterpret_cast<T*>(s_s + ((QCHUNK * sp + 3) & ~3));      // [32][vt]
+  float* s_s = reinterpret_cast<float*>(kv_s + ((kv_elems + 15) & ~15));   // [32][sp]
+  ST* p_s = reinterpret_cast<ST*>(s_s + ((QCHUNK * sp + 3) & ~3));    // [32][vt]
 
   const int kvbase = (kv_row ? kv_row[b] : b) * Nk;
   // optional per-step last key row (the time token of the text context, model.py:315-316)
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
           raw_copy = false;
         }
       }
-      if (raw_copy) *reinterpret_cast<Vec*>(kv_s + r * dq + c) = kraw[u];
+      if (raw_copy) stage_vec(kv_s + r * dq + c, kraw[u]);
     }
   }
 #pragma unroll
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
         finish(x, qst[u], uq[u], bq[u]);
         store8(q_s + r * dq + c, x);
       } else {
-        *reinterpret_cast<Vec*>(q_s + r * dq + c) = qraw[u];
+        stage_vec(q_s + r * dq + c, qraw[u]);
       }
     }
   }
@@ -257,12 +274,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
   // ---- V (already in registers) replaces K in LDS, transposed: V^T [d][keys] is the B operand of P V ------------
   {
     if (d < 16) {
-      for (int i = tid; i < DC * vt; i += 256) kv_s[i] = (T)0.f;
+      for (int i = tid; i < DC * vt; i += 256) kv_s[i] = to_elem<ST>(0.f);
       __syncthreads();
     } else {
       for (int i = tid; i < d * 32; i += 256) {                    // keys >= Nk contribute nothing (NKP - Nk < 32)
         const int c = i >> 5, j = Nk + (i & 31);
-        if (j < NKP) kv_s[c * vt + j] = (T)0.f;
+        if (j < NKP) kv_s[c * vt + j] = to_elem<ST>(0.f);
       }
     }
   }
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
         if (fin_kv) finish(vv, kst[u], uv[u], bv[u]);
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + r] = (T)vv[e];
+      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + r] = to_elem<ST>(vv[e]);
     }
   }
   AT_STAMP(7);
@@ -291,9 +308,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 #pragma unroll 1
     for (int it = 0; it < QCHUNK / 16; ++it) {
       const int r = it * 16 + wave * 4 + rsel;
-      T* pr = p_s + r * vt;
+      ST* pr = p_s + r * vt;
       if (r >= nq) {                                              // padding rows of the query tiles
-        for (int j = sub; j < NKP; j += 16) pr[j] = (T)0.f;
+        for (int j = sub; j < NKP; j += 16) pr[j] = to_elem<ST>(0.f);
       } else {
         const float* sr = s_s + r * sp + j0;
         float4 x[3];
@@ -318,10 +335,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
           sum += e[t];
         }
         sum = row16_sum(sum);
-        const float inv = PRECISE ? 1.0f / sum : __builtin_amdgcn_rcpf(sum);
+        const float inv = (PRECISE ? 1.0f / sum : __builtin_amdgcn_rcpf(sum)) * PS;
 #pragma unroll
         for (int t = 0; t < 12; ++t) {
-          if (t < kpl && j0 + t < NKP) pr[j0 + t] = (T)(e[t] * inv);
+          if (t < kpl && j0 + t < NKP) pr[j0 + t] = to_elem<ST>(e[t] * inv);
         }
       }
     }
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = qt * 16 + lg * 4 + r;
-        if (qi < nq && ct * 16 + li < d) out[(size_t)((unsigned)(b * Nq + q0 + qi) * (unsigned)ldo + (unsigned)(hd + ct * 16 + li))] = (T)acc[r];
+        if (qi < nq && ct * 16 + li < d) out[(size_t)((unsigned)(b * Nq + q0 + qi) * (unsigned)ldo + (unsigned)(hd + ct * 16 + li))] = (T)(F8 ? acc[r] * (1.0f / JEN1_FP8_P_SCALE) : acc[r]);
       }
     }
   }
@@ -364,17 +381,17 @@ extern "C" int jen1_attention_fin(const void* q, const void* k, const void* v, v
   JEN1_CHECK(B >= 1 && H >= 1 && d >= 8 && d % 8 == 0 && Nq >= 1 && Nk >= 1, "attention: bad sizes (head dim must be a multiple of 8)");
   JEN1_CHECK(Nk <= 192 && (Nk * (d / 8) + 255) / 256 <= 9 && d <= 128, "attention: Nk=%d d=%d outside the small-N kernel's range", Nk, d);
   JEN1_CHECK(ldq % 8 == 0 && ldkv % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && (!kv_extra || (ld_extra % 8 == 0 && kx_off % 8 == 0 && vx_off % 8 == 0)), "attention: offsets / strides must be multiples of 8 elements");
-  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "attention: bad dtype");
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "attention: bad dtype");
   const bool fin = finish_q || finish_kv;
   JEN1_CHECK(!fin || (ln_rowstats && ln_u && ln_b && ln_C >= 1), "attention: a deferred LayerNorm finish needs rowstats, u, bias and ln_C");
   JEN1_CHECK(!finish_kv || (!kv_row && !kv_extra && Nk * (d / 8) <= 256 * FMAX && Nq == Nk),
              "attention: the K/V finish is for self-attention over at most %d vectors", 256 * FMAX);
   JEN1_CHECK(d == 8 || d == 16 || d == 32 || d == 64 || d == 128, "attention: head dim %d must be 8, 16, 32, 64 or 128", d);
-  const size_t es = dtype == JEN1_F32 ? 4 : 2;
+  const size_t es = dtype == JEN1_F32 ? 4 : (dtype == JEN1_FP8 ? 1 : 2);      // LDS tiles (JEN1_FP8: q / k / v / out are bf16 in memory)
   const int DP = d < 32 ? 32 : d, DC = d < 16 ? 16 : d;
   const int NKP = (Nk + 31) & ~31, dq = DP + 8, vt = NKP + 8, sp = NKP + 4;
   const size_t kv_elems = (size_t)((NKP * dq > DC * vt) ? NKP * dq : DC * vt);
-  const size_t lds = es * (size_t)QCHUNK * dq + es * ((kv_elems + 7) & ~(size_t)7) + sizeof(float) * (((size_t)QCHUNK * sp + 3) & ~(size_t)3) + es * (size_t)QCHUNK * vt;
+  const size_t lds = es * (size_t)QCHUNK * dq + es * ((kv_elems + 15) & ~(size_t)15) + sizeof(float) * (((size_t)QCHUNK * sp + 3) & ~(size_t)3) + es * (size_t)QCHUNK * vt;
   JEN1_CHECK(lds <= 160 * 1024, "attention: Nk=%d d=%d needs %zu B of LDS (> 160 KiB)", Nk, d, lds);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(B * H, (Nq + QCHUNK - 1) / QCHUNK);
@@ -383,13 +400,19 @@ extern "C" int jen1_attention_fin(const void* q, const void* k, const void* v, v
   int log2_vpr = 0;
   while ((8 << log2_vpr) < d) ++log2_vpr;
   if (dtype == JEN1_F32) {
-    auto kern = attention_kernel<float>;
+    auto kern = attention_kernel<float, float>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out,
                        kv_row, (const float*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale,
                        ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv, inv_H, log2_vpr);
+  } else if (dtype == JEN1_FP8) {
+    auto kern = attention_kernel<bf16_t, fp8_t>;
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (bf16_t*)out, kv_row, (const bf16_t*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale,
+                       ln_rowstats, ln_u, ln_b, inv_c, ln_eps, finish_q, finish_kv, inv_H, log2_vpr);
   } else {
-    auto kern = attention_kernel<bf16_t>;
+    auto kern = attention_kernel<bf16_t, bf16_t>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (bf16_t*)out, kv_row, (const bf16_t*)kv_extra, extra_row, extra_step, ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal, scale,

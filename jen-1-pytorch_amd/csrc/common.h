@@ -93,6 +93,36 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&o)[4]) {
   *reinterpret_cast<bf16x4*>(p) = a;
 }
 
+// ---- JEN1_FP8: OCP e4m3 operands of the matrix cores (gfx950's fp8; v_mfma_f32_16x16x32_fp8_fp8 reads 8 bytes of K per lane and
+// operand with the same lane -> element map as the bf16 form).  Activations stay bf16 in memory; what is staged in LDS for the
+// matrix cores -- activation tiles, Q / K / P / V^T -- is one byte per element.
+struct fp8_t {
+  unsigned char v;
+};
+static_assert(sizeof(fp8_t) == 1, "one byte per element");
+#define JEN1_FP8_MAX 448.0f
+#define JEN1_FP8_P_SCALE 256.0f      // softmax probabilities (<= 1) are stored as 256 p: 1 / Nk would be an e4m3 denormal
+// two floats -> two e4m3 bytes in the low / high half of `old` (saturating: |x| > 448 would turn into NaN)
+__device__ __forceinline__ unsigned jen1_pk_fp8(float a, float b, unsigned old, bool hi) {
+  a = __builtin_amdgcn_fmed3f(a, -JEN1_FP8_MAX, JEN1_FP8_MAX);
+  b = __builtin_amdgcn_fmed3f(b, -JEN1_FP8_MAX, JEN1_FP8_MAX);
+  return hi ? (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
+}
+__device__ __forceinline__ void store8(fp8_t* p, const float (&o)[8]) {
+  unsigned lo = 0, hi = 0;
+  lo = jen1_pk_fp8(o[0], o[1], lo, false);
+  lo = jen1_pk_fp8(o[2], o[3], lo, true);
+  hi = jen1_pk_fp8(o[4], o[5], hi, false);
+  hi = jen1_pk_fp8(o[6], o[7], hi, true);
+  *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
+}
+template <typename T> __device__ __forceinline__ T to_elem(float x) { return (T)x; }
+template <> __device__ __forceinline__ fp8_t to_elem<fp8_t>(float x) {
+  fp8_t r;
+  r.v = (unsigned char)(jen1_pk_fp8(x, x, 0u, false) & 0xffu);
+  return r;
+}
+
 template <typename T>
 struct VecOf;
 template <>

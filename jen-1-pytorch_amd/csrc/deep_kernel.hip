@@ -47,35 +47,9 @@ __device__ __forceinline__ gu32* g32(const void* p) { return (gu32*)(u64)p; }
 // Activations stay bf16 in HBM; what the matrix cores read is OCP e4m3 (gfx950's fp8): the packed weights (one float32 scale
 // per output row, applied in the epilogue), the staged activation tile, and Q / K / P / V^T of the attention unit
 // (v_mfma_f32_16x16x32_fp8_fp8: 8 bytes of K per lane and operand, same lane -> element map as the bf16 form).
-struct fp8_t {
-  unsigned char v;
-};
-static_assert(sizeof(fp8_t) == 1, "one byte per element");
 template <typename T> struct Mode { typedef T G; };            // G: element type of activations in global memory
 template <> struct Mode<fp8_t> { typedef bf16_t G; };
-constexpr float FP8_MAX = 448.0f;
-constexpr float P_SCALE = 256.0f;                              // softmax probabilities (<= 1) are stored as 256 p: 1 / Nk would be a denormal
-// two floats -> two e4m3 bytes (saturating: |x| > 448 would turn into NaN)
-__device__ __forceinline__ unsigned pk_fp8(float a, float b, unsigned old, bool hi) {
-  a = __builtin_amdgcn_fmed3f(a, -FP8_MAX, FP8_MAX);
-  b = __builtin_amdgcn_fmed3f(b, -FP8_MAX, FP8_MAX);
-  return hi ? (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
-}
-using ::store8;
-__device__ __forceinline__ void store8(fp8_t* p, const float (&o)[8]) {
-  unsigned lo = 0, hi = 0;
-  lo = pk_fp8(o[0], o[1], lo, false);
-  lo = pk_fp8(o[2], o[3], lo, true);
-  hi = pk_fp8(o[4], o[5], hi, false);
-  hi = pk_fp8(o[6], o[7], hi, true);
-  *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
-}
-template <typename T> __device__ __forceinline__ T to_elem(float x) { return (T)x; }
-template <> __device__ __forceinline__ fp8_t to_elem<fp8_t>(float x) {
-  fp8_t r;
-  r.v = (unsigned char)(pk_fp8(x, x, 0u, false) & 0xffu);
-  return r;
-}
+constexpr float P_SCALE = JEN1_FP8_P_SCALE;
 
 // ---- 8-element vectors through agent-scope (sc1) accesses: data another workgroup produced in THIS launch --------
 template <typename T> struct Raw8;

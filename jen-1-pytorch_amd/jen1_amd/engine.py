@@ -772,7 +772,7 @@ class OpBuilder:
             return
         args = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
                 _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
-                1 if causal else 0, float(d) ** -0.5, _ptr(rs_), _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, eng.dt)
+                1 if causal else 0, float(d) ** -0.5, _ptr(rs_), _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, eng.deep_dt)
         lib = eng.lib
         self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row, extra_step, fin))
         fn = lambda s, args=args, lib=lib: L.check(lib.jen1_attention_fin(*args, s), "jen1_attention")

@@ -196,8 +196,12 @@ def test_deep_sampler_graph_replay_matches_eager(tiny_f32):
 # ---------------------------------------------------------------------------------------------------------------------------
 # JEN1_FP8 (BASELINE configs[4] "fp8 MFMA attention path"): OCP e4m3 operands on the matrix cores of the persistent launch
 # ---------------------------------------------------------------------------------------------------------------------------
-FP8_TOL = 1.5e-1       # max-abs / max-ref of the denoiser output against the reference's float32 output (3 mantissa bits per operand)
-FP8_L2 = 1.0e-1        # relative L2 of the same
+# Stated tolerance of the JEN1_FP8 mode, denoiser output against the reference's float32 output.  Measured at T = 9000: 6.9e-3
+# max-abs / max-ref and 5.7e-3 relative L2 -- the same as bf16 (6.8e-3 / 5.7e-3): the e4m3 operands live in the levels with few
+# positions, whose contribution to the output is small; INSIDE those levels single activations differ from the bf16 path by up to
+# 0.3 of their range (test_fp8_deep_activations_track_the_bf16_path), so the gate leaves room for other weights / inputs.
+FP8_TOL = 3e-2
+FP8_L2 = 3e-2
 
 
 def _golden(name):
@@ -274,7 +278,7 @@ def test_fp8_long_form_ddim_vs_golden(full_fp8):
     got, ref = y.cpu().numpy()[:, :, ::24].astype(np.float64), g["ddim2.T9000.cont"].astype(np.float64)
     l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
     print(f"ddim2.T9000.cont fp8: max-abs/max-ref {rel_err(got, ref):.3e}, relative L2 {l2:.3e}")
-    assert l2 < 2.5e-1
+    assert l2 < 1e-1
 
 
 def test_fp8_launch_replays_bit_identically(full_fp8):

@@ -444,6 +444,42 @@ def test_attention_core(ctx, d, Nq, Nk, causal):
     assert rel_err(out.t.float().cpu().numpy(), ref.cpu().numpy()) < (1e-5 if mode == "f32" else 1e-2)
 
 
+@pytest.mark.parametrize("d,Nq,Nk,causal", [(32, 141, 141, True), (64, 71, 129, False), (128, 5, 129, False), (32, 24, 24, False)])
+def test_attention_core_fp8_operands(d, Nq, Nk, causal):
+    """JEN1_FP8 mode of jen1_attention_fin (BASELINE configs[4] "fp8 MFMA attention path", blocks.py:355-380): Q K^T and P V on
+    e4m3 operands (v_mfma_f32_16x16x32_fp8_fp8), float32 softmax, probabilities stored as 256 p.  q / k / v / out stay bf16 in
+    memory.  Against float32 attention on the same bf16 inputs; stated tolerance 6e-2 of the largest output (3 mantissa bits per
+    operand), a layout or scaling mistake would be O(1)."""
+    from jen1_amd import lib as L
+    from jen1_amd.engine import Act, KernelCtx, OpBuilder
+    kc = KernelCtx("bf16", "cuda")
+    kc.deep_dt = L.FP8
+    torch.manual_seed(d + Nq)
+    B, H = 2, 8
+    mid = H * d
+    q = torch.randn(B, Nq, mid, device="cuda").to(torch.bfloat16)
+    kv = torch.randn(B, Nk, 2 * mid, device="cuda").to(torch.bfloat16)
+    qh = q.float().view(B, Nq, H, d).transpose(1, 2)
+    kh = kv.float()[:, :, :mid].reshape(B, Nk, H, d).transpose(1, 2)
+    vh = kv.float()[:, :, mid:].reshape(B, Nk, H, d).transpose(1, 2)
+    sim = qh @ kh.transpose(-1, -2) * d ** -0.5
+    if causal:
+        keep = ~torch.ones(Nq, Nk, dtype=torch.bool, device="cuda").triu(Nk - Nq + 1)
+        sim = sim.masked_fill(~keep, -torch.finfo(torch.float32).max)
+    ref = (sim.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, mid)
+    outs = {}
+    for name, dt in (("fp8", L.FP8), ("bf16", L.BF16)):
+        kc.deep_dt = dt
+        ob = OpBuilder(kc)
+        out = Act(torch.zeros((B, Nq, mid), dtype=torch.bfloat16, device="cuda"), B, Nq, mid, mid)
+        ob.attention(ob.ops, q=Act(q.contiguous(), B, Nq, mid, mid), q_off=0, kv_t=kv.contiguous(), ldkv=2 * mid, k_off=0, v_off=mid,
+                     out=out, H=H, d=d, Nk=Nk, causal=causal)
+        run(ob)
+        outs[name] = rel_err(out.t.float().cpu().numpy(), ref.cpu().numpy())
+    print(f"attention d={d} Nq={Nq} Nk={Nk}: fp8 {outs['fp8']:.3e}, bf16 {outs['bf16']:.3e}")
+    assert outs["fp8"] < 6e-2 and outs["bf16"] < 1e-2
+
+
 @pytest.mark.parametrize("N,causal", [(1, False), (6, True), (24, False)])
 def test_attention_deferred_layernorm_finish(ctx, N, causal):
     """jen1_attention_fin: Q / K / V arrive as raw = W' x of a LayerNorm-folded projection; the kernel applies
