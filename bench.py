@@ -162,8 +162,8 @@ def graph_time_ms(fn, R=20):
 
 
 def deep_roofline(st, dtype):
-    """The persistent deep-level launch on its own: [zero its arrival counters, launch] replayed as a HIP graph minus the
-    zeroing replayed alone.  Algorithmic bytes = every phase's weights once + its input and output activations once
+    """The persistent deep-level launch on its own: [poison its tensors, launch] replayed as a HIP graph minus the
+    poisoning replayed alone.  Algorithmic bytes = every phase's weights once + its input and output activations once
     (DESIGN.md section 5); inputs are whatever the last step left in the plan's buffers (no data-dependent control flow)."""
     plan = st.plan
     deep = [op for op in plan.ops if getattr(op, "kind", "") == "deep"]
@@ -171,13 +171,12 @@ def deep_roofline(st, dtype):
         return None
     op = deep[0]
     prog = plan.deep
-    sync = prog.sync
 
     def zero(s):
-        sync.zero_()
+        prog.poison(s)
 
     def both(s):
-        sync.zero_()
+        prog.poison(s)
         op(s)
     t_zero = graph_time_ms(zero)
     t_both = graph_time_ms(both)

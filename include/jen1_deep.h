@@ -22,11 +22,14 @@
  *                    launch-per-layer kernels that consume it after the persistent launch.
  *
  * A unit of a phase (16 output rows x the positions of a few batch elements; one
- * (batch element, head, 32-query chunk)) is done by one workgroup.  Phase p may start when
- * every unit of phase p-1 has arrived on that phase's sharded counter; results travel through
- * global memory with write-through (sc1) stores and L1-bypassing (sc1) loads
- * (cdna_hip_programming.md Guideline 16, R1).  Weight slices are requested BEFORE the
- * dependency wait, so their HBM latency hides behind the exchange.
+ * (batch element, head, 32-query chunk)) is done by one workgroup.  Results travel through
+ * global memory as 8-byte write-through (sc1) words; the tensors a phase produces are
+ * POISONED (all bytes 0xFF, jen1_deep_poison) before the launch, and a consumer wave repeats
+ * its L1-bypassing (sc1) loads until no word is the sentinel: the data is its own arrival
+ * flag, there is no counter, no drain and no barrier between producer and consumer
+ * (1.2 - 1.35 us per all-to-all stage on 256 workgroups against 3.05 us for the counter
+ * protocol of round 2: tools/microbench/flagchain.hip).  Weight slices are requested BEFORE
+ * the dependency wait, so their HBM latency hides behind the exchange.
  *
  * Plain pointers and sizes only; all pointers are device pointers unless noted.
  */
@@ -116,7 +119,7 @@ typedef struct jen1_deep_hot {
   /* a unit finishes mrep consecutive 16-row M tiles from ONE staged tile (jen1_deep_link: phases with more units than
    * workgroups; divides MT and mt_split): n_units = (MT / mrep) * groups_n */
   int32_t mrep;
-  int32_t pad0_;
+  int32_t live_mask;          /* bit k: source k was produced inside this launch, bit 8: the residual (jen1_conv_args.live_mask) */
   const float* wscale;        /* JEN1_FP8: [M] scale of the e4m3 weight rows (jen1_conv_args.w_scale), else NULL */
 } jen1_deep_hot;
 
@@ -162,7 +165,7 @@ int jen1_deep_phase_attention(const void* q, const void* k, const void* v, void*
                               const int32_t* extra_row, const int32_t* extra_step, int ld_extra, int kx_off, int vx_off, int B, int H,
                               int d, int Nq, int Nk, int ldq, int q_off, int ldkv, int k_off, int v_off, int ldo, int causal,
                               float scale, const float* ln_u, const float* ln_b, int ln_C, float ln_eps, int finish_q,
-                              int finish_kv, int kv_live, int dtype, jen1_deep_phase* out);
+                              int finish_kv, int kv_live /* bit 0: k / v, bit 1: q produced inside this launch */, int dtype, jen1_deep_phase* out);
 
 int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, int ld, int dtype, jen1_deep_phase* out);
 
@@ -174,7 +177,12 @@ int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, int ld, int
 int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, void* blobs, void* headers);
 int jen1_deep_blob_bytes(void);
 
-/* bytes of the synchronisation area (arrival counters + error word); must be zero when the launch starts */
+/* Poison the tensors the launch produces: table_dev = n device entries {uint64 pointer, uint64 bytes (multiple of 16)}, one per
+ * tensor written by a phase (the caller collects them while it records the phases).  Must run after the previous launch's last
+ * reader and complete before the launch starts (same stream: the first node of the step).  Capturable. */
+int jen1_deep_poison(const void* table_dev, int n, void* stream);
+
+/* (round 2's arrival counters; the area is no longer used by the kernel -- kept so that callers of jen1_deep_run need not change) */
 int64_t jen1_deep_sync_bytes(int n_phases);
 
 /* workgroups the launch should use on the current device (one per CU, all resident) */

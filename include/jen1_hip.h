@@ -158,6 +158,10 @@ typedef struct jen1_conv_args {
   int32_t k_split;           /* 32-channel chunks of K summed by the rows below m_split */
   const float* w_scale;      /* JEN1_FP8 (jen1_deep_phase_conv only): [M] float32, the scale of output row m -- `w` holds e4m3
                                 bytes q with W[m][k] = w_scale[m] * q[m][k] in the same fragment order (8 bytes per lane and chunk) */
+  int32_t live_mask;         /* jen1_deep_phase_conv only: which operands were produced by EARLIER PHASES OF THE SAME persistent
+                                launch (they start poisoned and are polled, jen1_deep.h): bit 0 x0, bit 1 x1 (or seg[0] when c1 = 0),
+                                following bits the extra segments in source order, bit 8 the residual */
+  int32_t reserved_;
 } jen1_conv_args;
 
 int jen1_conv_gemm(const jen1_conv_args* args, void* stream);

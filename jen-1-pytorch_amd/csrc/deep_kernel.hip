@@ -234,7 +234,7 @@ __device__ __forceinline__ float row16_max_d(float v) {
 }
 
 #ifndef JEN1_DEEP_POLL_SLEEP
-#define JEN1_DEEP_POLL_SLEEP 8       // (0 / 1 / 3 / 8 / 20: 1136 / 1125 / 1119 / 1114 / 1126 us per launch) measured: several polls in flight per workgroup (LDS-DMA polls, 2 / 3 / 4 deep) slow the launch by
+#define JEN1_DEEP_POLL_SLEEP 2       // (0 / 1 / 3 / 8 / 20: 1136 / 1125 / 1119 / 1114 / 1126 us per launch) measured: several polls in flight per workgroup (LDS-DMA polls, 2 / 3 / 4 deep) slow the launch by
 #endif                               // 4 / 9 / 12 % -- 256 pollers on the counter lines are in the producers' way; see DESIGN.md 4a
 template <typename T> struct DeepCfg;
 #ifndef JEN1_DEEP_MAXV_B
@@ -282,13 +282,19 @@ struct Hdr {
   int n_units, rot, kind, pad;
 };
 
-// ---- synchronisation -------------------------------------------------------------------------------------------------
+// ---- synchronisation: the data is its own flag ------------------------------------------------------------------------
+// Every tensor a phase of the launch produces is POISONED before the launch (all bytes 0xFF: jen1_deep_poison, a node of the
+// step's graph well ahead of the launch).  A producer stores its results as 8-byte single-copy-atomic write-through words and does
+// nothing else: no drain, no arrival counter.  A consumer WAVE loads the vectors it needs with agent-scope (L1-bypassing) loads
+// and repeats the loads until none of their 8-byte words is the sentinel: the load that finds the data complete is the load that
+// delivers it.  (A finite activation never encodes as four bf16 / two float32 NaNs with all mantissa bits set.)  Measured on
+// 256 workgroups (tools/microbench/flagchain.hip): 1.2 - 1.35 us per all-to-all stage against 3.05 us for
+// stores -> drain -> counter -> poll -> barrier -> load, the protocol of round 2.  Every spin is bounded: a wave that gives up
+// raises the error word (1 + phase), which releases every other waiter; results are garbage then and the host raises.
 struct Sync {
-  unsigned* base;      // counters: phase p, shard s at base[(p * SHARDS + s) * SHW]
   unsigned* err;       // error word
-  bool dead;           // wave 0: a wait timed out somewhere: stop waiting, finish with whatever is there
+  bool dead;           // this wave: a wait timed out somewhere: stop waiting, finish with whatever is there
   int p, wg, nwg;      // current phase / this workgroup
-  int dep_rot;         // first workgroup of the phase waited for (its units run on dep_rot, dep_rot + 1, ... mod nwg)
 #ifdef JEN1_DEEP_PROFILE
   unsigned long long tt[16];
 #endif
@@ -310,55 +316,57 @@ __device__ unsigned long long* g_deep_dbg = nullptr;
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// every thread of the workgroup calls this; wave 0 polls (lanes 0..7 one shard each, lane 8 the error word).
-// `dead` is wave 0's private knowledge (only it ever polls): once set, later waits fall through.
-__device__ __forceinline__ void wait_phase(Sync& sy, int dep, int dep_units, int tid) {
-  if (dep < 0) return;
-#ifdef JEN1_DEEP_EXP_NOWAIT      // timing experiment only: results are garbage
-  __syncthreads();
-  return;
+constexpr u64 POISON = ~0ull;
+#ifndef JEN1_DEEP_POLL_LIMIT
+#define JEN1_DEEP_POLL_LIMIT (1u << 15)      // failed polls of one wait before the wave gives up (~1.3 us each: ~40 ms)
 #endif
-  if (tid < 64 && !sy.dead) {
-    const gu32* c = g32(sy.base + ((size_t)dep * SHARDS + (tid < SHARDS ? tid : 0)) * SHW);
-    const gu32* e = g32(sy.err);
-    // arrivals this lane's shard will see: units u = 0 .. dep_units - 1 run on workgroup (u + rot) % nwg and arrive on shard
-    // workgroup % SHARDS.  A shard that has reached its count is not read again, so towards the end of a phase only the shards
-    // with stragglers are polled and the last arrivals do not queue behind hundreds of reads of their line.
-    unsigned target = 0xFFFFFFFFu;                     // (unknown: keep polling the shard)
-    if ((sy.nwg % SHARDS) == 0 && tid < SHARDS) {
-      const int u0 = ((tid - sy.dep_rot) % SHARDS + SHARDS) % SHARDS;
-      target = u0 < dep_units ? (unsigned)((dep_units - u0 + SHARDS - 1) / SHARDS) : 0u;
-    }
-    unsigned v = 0, spins = 0;
-    for (;;) {
-      unsigned ev = 0;
-      if (tid < SHARDS && v < target) v = __hip_atomic_load(c, RLX_AGENT);
-      if (tid == SHARDS && (spins & 7u) == 7u) ev = __hip_atomic_load(e, RLX_AGENT);      // the error word: every 8th poll
-      float tot = row16_sum_d(tid < SHARDS ? (float)v : 0.f);      // counts are small integers: exact in float
-      if (SHARDS > 16) tot += __shfl_xor(tot, 16);      // (lanes beyond the shards hold 0)
-      if (SHARDS > 32) tot += __shfl_xor(tot, 32);
-      const int total = __builtin_amdgcn_readfirstlane((int)tot);
-      const int errv = __builtin_amdgcn_readlane((int)ev, SHARDS);
-      if (total >= dep_units) break;
-      if (errv != 0) { sy.dead = true; break; }
-      if (++spins > (1u << 22)) {
-        if (tid == 0) __hip_atomic_store(g32(sy.err), (unsigned)(dep + 1), RLX_AGENT);
-        sy.dead = true;
-        break;
-      }
-#if JEN1_DEEP_POLL_SLEEP > 0
-      __builtin_amdgcn_s_sleep(JEN1_DEEP_POLL_SLEEP);     // (units of 64 clocks) between polls
-#endif
-    }
-  }
-  __syncthreads();
+__device__ __forceinline__ bool raw_bad(const Raw8<bf16_t>& r) { return (r.d[0] == POISON) | (r.d[1] == POISON); }
+__device__ __forceinline__ bool raw_bad(const Raw8<float>& r) {
+  return (r.d[0] == POISON) | (r.d[1] == POISON) | (r.d[2] == POISON) | (r.d[3] == POISON);
+}
+// 4 consecutive channels (a residual operand) as raw words
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> { u64 d[1]; };
+template <> struct Raw4<float> { u64 d[2]; };
+__device__ __forceinline__ void ld_live4r(Raw4<bf16_t>& r, const bf16_t* p) { r.d[0] = __hip_atomic_load(g64(p), RLX_AGENT); }
+__device__ __forceinline__ void ld_live4r(Raw4<float>& r, const float* p) {
+  r.d[0] = __hip_atomic_load(g64(p), RLX_AGENT);
+  r.d[1] = __hip_atomic_load(g64(p) + 1, RLX_AGENT);
+}
+__device__ __forceinline__ bool raw_bad(const Raw4<bf16_t>& r) { return r.d[0] == POISON; }
+__device__ __forceinline__ bool raw_bad(const Raw4<float>& r) { return (r.d[0] == POISON) | (r.d[1] == POISON); }
+__device__ __forceinline__ void raw4_to_float(const Raw4<bf16_t>& r, float (&o)[4]) {
+  const unsigned lo = (unsigned)r.d[0], hi = (unsigned)(r.d[0] >> 32);
+  o[0] = __uint_as_float(lo << 16); o[1] = __uint_as_float(lo & 0xffff0000u);
+  o[2] = __uint_as_float(hi << 16); o[3] = __uint_as_float(hi & 0xffff0000u);
+}
+__device__ __forceinline__ void raw4_to_float(const Raw4<float>& r, float (&o)[4]) {
+  o[0] = __uint_as_float((unsigned)r.d[0]); o[1] = __uint_as_float((unsigned)(r.d[0] >> 32));
+  o[2] = __uint_as_float((unsigned)r.d[1]); o[3] = __uint_as_float((unsigned)(r.d[1] >> 32));
 }
 
-// called after a __syncthreads() that follows every storing wave's drain
-__device__ __forceinline__ void arrive_phase(const Sync& sy, int tid) {
-  if (tid == 0) __hip_atomic_fetch_add(g32(sy.base + ((size_t)sy.p * SHARDS + (sy.wg % SHARDS)) * SHW), 1u, RLX_AGENT);
+// behind a round of loads of one wave: `bad` = this lane saw a sentinel word.  Returns true when the wave has to load again.
+// (wave-uniform; the error word is looked at every 64th failed poll)
+__device__ __forceinline__ bool poll_again(Sync& sy, bool bad, unsigned& spins) {
+#ifdef JEN1_DEEP_EXP_NOWAIT      // timing experiment only: results are garbage
+  return false;
+#endif
+  if (!__builtin_amdgcn_ballot_w64(bad) || sy.dead) return false;
+  ++spins;
+  if ((spins & 63u) == 0u) {
+    const unsigned ev = __hip_atomic_load(g32(sy.err), RLX_AGENT);
+    if (rfl((int)ev) != 0) { sy.dead = true; return false; }
+  }
+  if (spins > JEN1_DEEP_POLL_LIMIT) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(g32(sy.err), (unsigned)(sy.p + 1), RLX_AGENT);
+    sy.dead = true;
+    return false;
+  }
+#if JEN1_DEEP_POLL_SLEEP > 0
+  __builtin_amdgcn_s_sleep(JEN1_DEEP_POLL_SLEEP);     // (units of 64 clocks) between polls
+#endif
+  return true;
 }
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // next unit of this workgroup after (p, u): the same phase first (more units than workgroups), then later phases
 __device__ __forceinline__ bool find_next(const Hdr* hdr, int n_phases, int wg, int nwg, int& p, int& u) {
@@ -593,8 +601,7 @@ __device__ __forceinline__ float lane_set_sum(float v, int lS) {
 }
 
 template <typename T, typename Frag, int PF, typename FPub>
-__device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, Frag (&ra)[PF],
-                                          FPub publish_next, int tid) {
+__device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& sy, Frag (&ra)[PF], FPub publish_next, int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool PRECISE = is_f32<T>::value;
   constexpr int MAXV = DeepCfg<T>::MAXV;
@@ -667,16 +674,18 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   rows_ok = rows_ok < nb * L_in ? rows_ok : nb * L_in;
   rows_ok = Craw > 0 ? rows_ok : 0;
   const GT* rbase;
-  int rld;
+  int rld, rsrc;
   float rscale;
   {
     const void* xp = s0.x;
     int ld = s0.ld, coff = 0;
     float sc = s0.scale;
+    rsrc = 0;
     static_assert(JEN1_DEEP_MAX_SRC == 4, "the source scan below is written out for four sources");
     const int nsrc = HI(nsrc);
     auto pick = [&](const jen1_deep_src sk, int k) __attribute__((always_inline)) {
       const bool use = k < nsrc && cr >= sk.coff;
+      rsrc = use ? k : rsrc;
       xp = use ? sk.x : xp;
       ld = use ? sk.ld : ld;
       coff = use ? sk.coff : coff;
@@ -782,18 +791,37 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 
   // ---- dependency ---------------------------------------------------------------------------------------------------
   DK_STAMP(sy, 1);
-  if (need_wait) wait_phase(sy, sy.p - 1, dep_units, tid);
-  DK_STAMP(sy, 2);
+  // which of this lane's loads read tensors produced inside the launch (bit k: source k, bit 8: the residual): those are repeated
+  // until no word is the sentinel; tensors of earlier launches (the first phase's input) are plain data
+  const int live = HI(live_mask);
+  const bool nlive = norm_C > 0 && ((live >> (in1 ? 1 : 0)) & 1);
+  const bool rlive = Craw > 0 && ((live >> rsrc) & 1);
+  const bool reslive = use_res && ((live >> 8) & 1);
 
 #ifndef JEN1_DEEP_EXP_NOSTAGE
-  // ---- every load (sc1: another workgroup wrote the data in this launch), no branches ---------------------------------------
+  // ---- every load (sc1: another workgroup wrote the data in this launch), no branches; the wave repeats them until complete ---
   Raw8<GT> xn[MAXV], xw[MAXV];
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) ld_live(xn[i], nap[i]);
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) ld_live(xw[i], wap[i]);
   float rres[4] = {0.f, 0.f, 0.f, 0.f};
-  if (use_res) ld_live4(rres, resp);
+  {
+    Raw4<GT> rr;
+    unsigned spins = 0;
+    bool bad;
+    do {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) ld_live(xn[i], nap[i]);
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) ld_live(xw[i], wap[i]);
+      if (use_res) ld_live4r(rr, resp);
+      bad = false;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) bad |= nlive && raw_bad(xn[i]);
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) bad |= rlive && raw_bad(xw[i]);
+      if (use_res) bad |= reslive && raw_bad(rr);
+    } while (poll_again(sy, bad, spins));
+    if (use_res) raw4_to_float(rr, rres);
+  }
+  DK_STAMP(sy, 2);
   // raw vectors: straight into the tile
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -810,15 +838,22 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   for (int rbeg = MAXV * rpr; rbeg < rows_ok; rbeg += MAXV * rpr) {
     Raw8<GT> xv[MAXV];
     int vt[MAXV];
+    unsigned spins = 0;
+    bool bad;
+    do {
+      bad = false;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int rr = rbeg + rr0 + i * rpr;
-      const bool ok = rr < rows_ok;
-      const int rc = ok ? rr : 0;
-      const int bl = (int)(((float)rc + 0.5f) * inv_Lin);
-      vt[i] = ok ? (rc + bl * lpx + Hb) * pitch + cr : dummy_tile;
-      ld_live(xv[i], rbase + (size_t)((unsigned)rc * (unsigned)rld));
-    }
+      for (int i = 0; i < MAXV; ++i) {
+        const int rr = rbeg + rr0 + i * rpr;
+        const bool ok = rr < rows_ok;
+        const int rc = ok ? rr : 0;
+        const int bl = (int)(((float)rc + 0.5f) * inv_Lin);
+        vt[i] = ok ? (rc + bl * lpx + Hb) * pitch + cr : dummy_tile;
+        ld_live(xv[i], rbase + (size_t)((unsigned)rc * (unsigned)rld));
+      }
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) bad |= rlive && raw_bad(xv[i]);
+    } while (poll_again(sy, bad, spins));
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       if (rscale != 1.0f) {
@@ -854,13 +889,20 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     for (int trip = 1; trip < ntrips; ++trip) {
       Raw8<GT> xt[MAXV];
       float mt_[MAXV];
+      unsigned spins = 0;
+      bool bad;
+      do {
+        bad = false;
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const int t = nt0 + (trip * MAXV + i) * ntstep;
-        const bool ok = npair_ok && t < L_in;
-        mt_[i] = ok ? nscale : 0.f;
-        ld_live(xt[i], nbase + (size_t)((unsigned)(ok ? t : 0) * (unsigned)nld));
-      }
+        for (int i = 0; i < MAXV; ++i) {
+          const int t = nt0 + (trip * MAXV + i) * ntstep;
+          const bool ok = npair_ok && t < L_in;
+          mt_[i] = ok ? nscale : 0.f;
+          ld_live(xt[i], nbase + (size_t)((unsigned)(ok ? t : 0) * (unsigned)nld));
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) bad |= nlive && raw_bad(xt[i]);
+      } while (poll_again(sy, bad, spins));      // (the second read of these rows below finds them complete)
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) {
         float x[8];
@@ -1020,7 +1062,14 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     epi_operands(gw.mt);
 #pragma unroll
     for (int r = 0; r < 4; ++r) rres[r] = 0.f;
-    if (use_res) ld_live4(rres, resp);
+    if (use_res) {
+      Raw4<GT> rr;
+      unsigned spins = 0;
+      do {
+        ld_live4r(rr, resp);
+      } while (poll_again(sy, ((live >> 8) & 1) && raw_bad(rr), spins));
+      raw4_to_float(rr, rres);
+    }
     f32x4 acc[4];
     k_loop(acc);
     if (j + 1 < mrep) ring_next_tile();
@@ -1029,13 +1078,9 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     __syncthreads();
     if (epi) epilogue(redj);
   }
-  if (epi) {
-    DK_STAMP(sy, 15);
-    drain_stores();
-  }
-  __syncthreads();
+  DK_STAMP(sy, 15);
+  __syncthreads();          // (LDS: the next unit stages over this one's tile and reduction scratch; the stores need no drain)
   DK_STAMP(sy, 5);
-  arrive_phase(sy, tid);
   DK_STAMP(sy, 6);
 }
 
@@ -1044,7 +1089,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 // statistics of the deferred finish computed here (blocks.py:355-380, :427-429)
 // =====================================================================================================================
 template <typename T, typename FPub>
-__device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, FPub publish_next, int tid) {
+__device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& sy, FPub publish_next, int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef typename DFrag<T>::type Frag;
   typedef typename Mode<T>::G GT;                      // q / k / v / out in global memory (bf16 in JEN1_FP8 mode)
@@ -1085,7 +1130,9 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   const GT* vp_ = reinterpret_cast<const GT*>(AP(v, const void*));
   const GT* xp_ = reinterpret_cast<const GT*>(AP(kv_extra, const void*));
   GT* const outp = reinterpret_cast<GT*>(AP(out, void*));
-  const int fin_q = AI(fin_q), fin_kv = AI(fin_kv), kv_live = AI(kv_live), causal = AI(causal);
+  const int fin_q = AI(fin_q), fin_kv = AI(fin_kv), causal = AI(causal);
+  const int kv_live = AI(kv_live) & 1;                 // K / V were produced inside this launch (self-attention)
+  const bool q_live = (AI(kv_live) >> 1) & 1;          // ... and so was q's tensor (always, unless the unit is the first phase)
   const float scale = AF(scale), ln_eps = AF(ln_eps);
   const int q_off = AI(q_off);
 
@@ -1129,24 +1176,33 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   }
 
   DK_STAMP(sy, 1);
-  if (need_wait) wait_phase(sy, sy.p - 1, dep_units, tid);
-  DK_STAMP(sy, 2);
 
 #ifdef JEN1_DEEP_EXP_NOATTN
   if (sy.wg == 100000) {
 #else
   {
 #endif
-  // ---- live operands -------------------------------------------------------------------------------------------------
-  if (kv_live) {
+  // ---- live operands: repeated by the wave until no word is the sentinel ---------------------------------------------------------
+  {
+    unsigned spins = 0;
+    bool bad;
+    do {
+      bad = false;
+      if (kv_live) {
 #pragma unroll
-    for (int i = 0; i < MAXVA; ++i) {
-      if (kvok[i]) { ld_live(kraw[i], kadr[i]); ld_live(vraw[i], vadr[i]); }
-      else { zero_raw(kraw[i]); zero_raw(vraw[i]); }
-    }
+        for (int i = 0; i < MAXVA; ++i) {
+          if (kvok[i]) { ld_live(kraw[i], kadr[i]); ld_live(vraw[i], vadr[i]); }
+          else { zero_raw(kraw[i]); zero_raw(vraw[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXVA; ++i) bad |= raw_bad(kraw[i]) | raw_bad(vraw[i]);
+      }
+      if (tid < nqv) ld_live(qraw, qp + ((size_t)((unsigned)(b * Nq + q0 + kr0) * (unsigned)ldq) + (unsigned)(q_off + hd + kc0)));
+      else zero_raw(qraw);
+      bad |= q_live && raw_bad(qraw);
+    } while (poll_again(sy, bad, spins));
   }
-  if (tid < nqv) ld_live(qraw, qp + ((size_t)((unsigned)(b * Nq + q0 + kr0) * (unsigned)ldq) + (unsigned)(q_off + hd + kc0)));
-  else zero_raw(qraw);
+  DK_STAMP(sy, 2);
   // LayerNorm statistics of the rows the finish needs: 16 lanes per row over the ln_C leading columns of q's tensor
   if (fin_q || fin_kv) {
     const int rs0 = fin_kv ? 0 : q0, rsn = fin_kv ? Nk : nq;
@@ -1159,11 +1215,18 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
       constexpr int LNB = sizeof(GT) == 2 ? 8 : 2;
       for (int v0 = li; v0 < nvec; v0 += 16 * LNB) {
         Raw8<GT> x[LNB];
+        unsigned spins = 0;
+        bool bad;
+        do {
+          bad = false;
 #pragma unroll
-        for (int k = 0; k < LNB; ++k) {
-          if (v0 + 16 * k < nvec) ld_live(x[k], rowp + (v0 + 16 * k) * 8);
-          else zero_raw(x[k]);
-        }
+          for (int k = 0; k < LNB; ++k) {
+            if (v0 + 16 * k < nvec) ld_live(x[k], rowp + (v0 + 16 * k) * 8);
+            else zero_raw(x[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < LNB; ++k) bad |= q_live && raw_bad(x[k]);
+        } while (poll_again(sy, bad, spins));
 #pragma unroll
         for (int k = 0; k < LNB; ++k) {
           float f[8];
@@ -1352,10 +1415,8 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   }
   }
   publish_next();
-  drain_stores();
   __syncthreads();
   DK_STAMP(sy, 5);
-  arrive_phase(sy, tid);
   DK_STAMP(sy, 6);
 }
 
@@ -1364,7 +1425,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
 // launch-per-layer consumer that follows the persistent launch (same layout as jen1_conv_args.gn_stats*)
 // =====================================================================================================================
 template <typename T, typename FPub>
-__device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& sy, bool need_wait, int dep_units, FPub publish_next, int tid) {
+__device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& sy, FPub publish_next, int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const jen1_deep_phase* P = reinterpret_cast<const jen1_deep_phase*>(D);
   const int b = u, L = P->sL, ld = P->sld, cpf = P->scpf, gran = P->sgran;
@@ -1373,7 +1434,6 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
   float* const sstats = P->sstats;
   DK_STAMP(sy, 0);
   DK_STAMP(sy, 1);
-  if (need_wait) wait_phase(sy, sy.p - 1, dep_units, tid);
   DK_STAMP(sy, 2);
   const int VPR = ld >> 3;                       // power of two <= NT (checked on the host)
   const int vc = tid & (VPR - 1), r0 = tid / VPR, rstep = NT / VPR;
@@ -1384,7 +1444,10 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
   const GT* xp = sx + (size_t)b * L * ld + vc * 8;
   for (int r = r0; r < L; r += rstep) {
     Raw8<GT> x;
-    ld_live(x, xp + (size_t)r * ld);
+    unsigned spins = 0;
+    do {
+      ld_live(x, xp + (size_t)r * ld);
+    } while (poll_again(sy, raw_bad(x), spins));      // (the chain's last tensor: always produced inside the launch)
     float f[8];
     raw_to_float(x, f);
 #pragma unroll
@@ -1428,10 +1491,8 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
     }
   }
   DK_STAMP(sy, 4);
-  drain_stores();
   __syncthreads();
   DK_STAMP(sy, 5);
-  arrive_phase(sy, tid);
   DK_STAMP(sy, 6);
 }
 
@@ -1448,7 +1509,7 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
   if (tid < n_phases) reinterpret_cast<int4*>(smem)[tid] = hdr_g[tid];
   __syncthreads();
   Sync sy;
-  sy.base = sync;
+  (void)sync;
   sy.err = err;
   sy.dead = false;
   sy.wg = wg;
@@ -1466,7 +1527,6 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
   __syncthreads();
   Frag ra[PF];
   if (hdr[p].kind == JEN1_DEEP_GEMM) gemm_prefill<T>(smem + HDR_BYTES, u, wk, lane, ra);
-  int waited = -1;
   for (;;) {
     int p2 = p, u2 = u;
     const bool more = find_next(hdr, n_phases, wg, nwg, p2, u2);
@@ -1480,14 +1540,10 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
     // called by the unit right before one of its __syncthreads()
     auto publish_next = [&]() { if (reload) reinterpret_cast<u64*>(Dn)[tid] = nx; };
     sy.p = p;
-    sy.dep_rot = p > 0 ? hdr[p - 1].rot : 0;
-    const bool need_wait = waited != p && p > 0;
-    waited = p;
-    const int dep_units = p > 0 ? hdr[p - 1].n_units : 0;
     const int kind = hdr[p].kind;
-    if (kind == JEN1_DEEP_GEMM) gemm_unit<T>(D, u, sy, need_wait, dep_units, ra, publish_next, tid);
-    else if (kind == JEN1_DEEP_ATTN) attn_unit<T>(D, u, sy, need_wait, dep_units, publish_next, tid);
-    else stats_unit<T>(D, u, sy, need_wait, dep_units, publish_next, tid);
+    if (kind == JEN1_DEEP_GEMM) gemm_unit<T>(D, u, sy, ra, publish_next, tid);
+    else if (kind == JEN1_DEEP_ATTN) attn_unit<T>(D, u, sy, publish_next, tid);
+    else stats_unit<T>(D, u, sy, publish_next, tid);
     DK_FLUSH(sy);
     if (!more) break;
     // the next unit's weight ring: requested right behind this unit's arrival, long before its dependency wait ends
@@ -1535,6 +1591,7 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
   p.h.wscale = a->dtype == JEN1_FP8 ? a->w_scale : nullptr;
+  p.h.live_mask = a->live_mask;
   p.h.kind = JEN1_DEEP_GEMM;
   p.h.dtype = a->dtype;
   p.h.dep = -1;
@@ -1695,7 +1752,7 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
              (!kv_extra || (ld_extra % 8 == 0 && kx_off % 8 == 0 && vx_off % 8 == 0)), "deep attention: offsets / strides must be multiples of 8 elements");
   const bool fin = finish_q || finish_kv;
   JEN1_CHECK(!fin || (ln_u && ln_b && ln_C >= 8 && ln_C % 8 == 0), "deep attention: a LayerNorm finish needs u, bias and ln_C");
-  JEN1_CHECK(!finish_kv || (!kv_row && !kv_extra && Nk * (d / 8) <= JEN1_DEEP_THREADS && Nq == Nk && kv_live),
+  JEN1_CHECK(!finish_kv || (!kv_row && !kv_extra && Nk * (d / 8) <= JEN1_DEEP_THREADS && Nq == Nk && (kv_live & 1)),
              "deep attention: the K/V finish is for self-attention over at most %d vectors", JEN1_DEEP_THREADS);
   const int es = dtype == JEN1_F32 ? 4 : 2;      // (JEN1_FP8: sized like bf16 -- the output tile is bf16, the fp8 operands need less)
   const int DP = d < 32 ? 32 : d, DC = d < 16 ? 16 : d;
@@ -1834,6 +1891,27 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
     }
   }
   return lds + WS_OFF;
+}
+
+// ---- the sentinel every in-launch tensor starts from (see "synchronisation") ------------------------------------------------------
+namespace {
+struct PoisonEntry {
+  unsigned long long ptr, bytes;          // bytes: a multiple of 16
+};
+__global__ __launch_bounds__(256) void poison_kernel(const PoisonEntry* __restrict__ tab) {
+  const PoisonEntry e = tab[blockIdx.y];
+  uint4* p = reinterpret_cast<uint4*>(e.ptr);
+  const size_t n = e.bytes >> 4;
+  const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = ones;
+}
+}  // namespace
+
+extern "C" int jen1_deep_poison(const void* table_dev, int n, void* stream) {
+  JEN1_CHECK(table_dev && n >= 1 && n <= 65535, "deep poison: bad table");
+  hipLaunchKernelGGL(poison_kernel, dim3(8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const PoisonEntry*>(table_dev));
+  JEN1_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int64_t jen1_deep_sync_bytes(int n_phases) { return ((int64_t)n_phases * SHARDS * SHW + SHW) * 4; }

@@ -266,6 +266,16 @@ class DeepProgram:
         self.dev = None
         self.lds = 0
         self.sync = None
+        self._produced: Dict[int, torch.Tensor] = {}     # storage pointer -> tensor, of everything a recorded phase writes
+
+    def _note_output(self, out: Optional["Act"]):
+        if out is not None:
+            self._produced.setdefault(out.t.untyped_storage().data_ptr(), out.t)
+
+    def is_live(self, t: Optional[torch.Tensor]) -> bool:
+        """was ``t`` (or the tensor it is a view of) written by an earlier phase of this program?  Such operands start every
+        launch poisoned and are polled by their consumers (include/jen1_deep.h)"""
+        return t is not None and t.untyped_storage().data_ptr() in self._produced
 
     def _new(self):
         return (C.c_char * self.psize)()
@@ -277,6 +287,7 @@ class DeepProgram:
         self.bufs.append(buf)
         self.labels.append(label)
         self.outs.append(out)
+        self._note_output(out)
 
     def add_conv(self, a: "L.ConvArgs", label: str, out, nb_max: int = 0):
         buf = self._new()
@@ -316,6 +327,18 @@ class DeepProgram:
         self.sync = sync
         # the error word lives outside the per-step zeroed area: the first time-out of any replay stays visible (error())
         self.err = torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
+        # every tensor a phase writes starts each launch as the sentinel (jen1_deep_poison): {pointer, bytes} per storage
+        ent = []
+        for ptr, t in self._produced.items():
+            nb = t.untyped_storage().nbytes()
+            assert ptr % 16 == 0 and nb % 16 == 0, (ptr, nb)
+            ent += [ptr, nb]
+        self.poison_tab = torch.tensor(ent, dtype=torch.int64).view(-1, 2).to(self.eng.device)
+        self.poison_bytes = int(sum(ent[1::2]))
+
+    def poison(self, stream: int):
+        """before every launch, after the last reader of the previous one: the step's first node (Plan) does this"""
+        L.check(self.lib.jen1_deep_poison(self.poison_tab.data_ptr(), self.poison_tab.shape[0], stream), "jen1_deep_poison")
 
     def launch(self, stream: int):
         n = len(self.bufs)
@@ -473,6 +496,8 @@ class OpBuilder:
             # computes the GroupNorm statistics itself, FiLM comes from the fused GroupNorm-FiLM table
             if pro == L.PRO_LN or y_f32 or row_scale is not None:
                 raise DeepIneligible(f"{label}: prologue / epilogue option outside the persistent kernel")
+            if out.ld != out.C:
+                raise DeepIneligible(f"{label}: {out.C} output channels are not a multiple of 32 (padding columns would stay poisoned)")
             a.out_gn_stats = a.out_rowstats = None
             w8 = None
             if eng.deep_dt == L.FP8:
@@ -487,6 +512,11 @@ class OpBuilder:
                     assert e.B == a.B and e.L == a.L_in and e.t.dtype == eng.tdtype and e.cp == e.C
                     a.seg[i].x, a.seg[i].ld, a.seg[i].shift, a.seg[i].kch = e.t.data_ptr(), e.ld, sh, e.cp // 32
                 a.nseg = len(extra_segs)
+            # operands produced by earlier phases of the launch are polled (they start poisoned); source order as in
+            # jen1_deep_phase_conv: x0, x1 (when present), then the extra segments
+            srcs_ = [src0] + ([src1] if src1 is not None else []) + [e for e, _ in (extra_segs or [])]
+            a.live_mask = sum(1 << i for i, s_ in enumerate(srcs_) if self.deep.is_live(s_.t)) | \
+                (256 if residual is not None and self.deep.is_live(residual.t) else 0)
             if m_split:
                 a.m_split, a.k_split = m_split, k_split
             self._keep.append((a, src0, src1, w, w8, bias, out, residual, gn, film, extra_segs))
@@ -764,6 +794,8 @@ class OpBuilder:
         rs_, u_, b_, lnC, eps, fq, fkv = fin if fin is not None else (None, None, None, 0, 0.0, 0, 0)
         if self._deep_on:
             kv_live = 1 if kv_row is None and kv_extra is None else 0      # self-attention: K / V come from the previous phase
+            assert not kv_live or self.deep.is_live(kv_t)
+            kv_live |= 2 if self.deep.is_live(q.t) else 0                  # bit 1: q's tensor was produced inside the launch
             dargs = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
                      _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off,
                      out.ld, 1 if causal else 0, float(d) ** -0.5, _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, kv_live, eng.deep_dt)
@@ -856,6 +888,10 @@ class Plan(OpBuilder):
         sync = self._stats(n).view(torch.int32)
         self.deep.finalize(sync)
         prog = self.deep
+        pz = lambda s, prog=prog: prog.poison(s)
+        pz.kind = "deep_poison"
+        pz.label = f"deep_poison[{prog.poison_tab.shape[0]} tensors, {prog.poison_bytes} B]"
+        self.ops.insert(1, pz)          # right behind the arena reset: long before the launch, after the previous step's last reader
         fn = lambda s, prog=prog: prog.launch(s)
         fn.kind = "deep"
         fn.label = f"deep[{len(prog)} phases, {prog.nwg} workgroups, {prog.lds} B LDS]"

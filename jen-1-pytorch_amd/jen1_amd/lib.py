@@ -59,6 +59,7 @@ class ConvArgs(C.Structure):
         ("zeros", c_void_p), ("tiles_t", c_int), ("inv_tiles_t", c_float), ("inv_tb", c_float),
         ("film_step", c_void_p), ("ln_u", c_void_p), ("ln_fold", c_int), ("nseg", c_int),
         ("seg", ConvSeg * MAX_SEG), ("m_split", c_int), ("k_split", c_int), ("w_scale", c_void_p),
+        ("live_mask", c_int), ("reserved_", c_int),
     ]
 
 
@@ -139,6 +140,7 @@ SYMBOLS = {
                                   [c_float, _P, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
     "jen1_deep_phase_stats": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_deep_link": (c_int, [_P, c_int, c_int, _P, _P]),
+    "jen1_deep_poison": (c_int, [_P, c_int, _P]),
     "jen1_deep_blob_bytes": (c_int, []),
     "jen1_deep_sync_bytes": (c_int64, [c_int]),
     "jen1_deep_num_workgroups": (c_int, []),

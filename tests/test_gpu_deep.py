@@ -164,7 +164,7 @@ def test_deep_launch_replays_bit_identically(full_f32, full_bf16):
         for rep in range(200):
             for a in watch:
                 a.t.fill_(float("nan"))                 # poison: a skipped store would show
-            prog.sync.zero_()
+            prog.poison(s)                            # every tensor of the launch back to the sentinel (a skipped store would hang a consumer -> error word)
             if rep % 2:
                 with torch.cuda.stream(hog_stream):
                     hog.add_(1.0)
@@ -295,7 +295,7 @@ def test_fp8_launch_replays_bit_identically(full_fp8):
     for rep in range(50):
         for a in watch:
             a.t.fill_(float("nan"))
-        prog.sync.zero_()
+        prog.poison(s)
         prog.launch(s)
         torch.cuda.synchronize()
         assert prog.error() == 0
