@@ -138,7 +138,7 @@ typedef struct jen1_deep_phase {
   const float* ln_u;
   const float* ln_b;
   int32_t ld_extra, kx_off, vx_off, H, d, Nq, Nk, ldq, q_off, ldkv, k_off, v_off, ldo, causal;
-  int32_t ln_C, fin_q, fin_kv, kv_live, nqc, log2_vpr;   /* kv_live: K/V were produced inside this launch (sc1 loads) */
+  int32_t ln_C, fin_q, fin_kv, kv_live, nqc, log2_vpr, vsep, pad1_;   /* kv_live: K/V were produced inside this launch (sc1 loads) */
   float scale, ln_eps, inv_H, inv_nqc;
   /* ---- stats ---- */
   const void* sx;             /* [B][L][ld] */

@@ -39,6 +39,9 @@ constexpr int SHW = JEN1_DEEP_SHARD_WORDS;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int RSRC_FLAGS = 0x00020000;
 constexpr int QCHUNK = 32;
+#ifndef JEN1_DEEP_ATTN_LIVE_VEC
+#define JEN1_DEEP_ATTN_LIVE_VEC 2     // K / V vectors per thread of a self-attention (produced inside the launch: held across the polled loads)
+#endif
 
 __device__ __forceinline__ gu64* g64(const void* p) { return (gu64*)(u64)p; }
 __device__ __forceinline__ gu32* g32(const void* p) { return (gu32*)(u64)p; }
@@ -1115,8 +1118,12 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   const int dq = DP + 8, vt = NKP + 8, sp = NKP + 4;
   T* q_s = reinterpret_cast<T*>(smem + WS_OFF);                      // [32][dq]  (later the output tile, in the activations' type)
   GT* o_s = reinterpret_cast<GT*>(smem + WS_OFF);
-  T* kv_s = reinterpret_cast<T*>(o_s + QCHUNK * dq);                // K [NKP][dq], later V^T [DC][vt]
-  const int kv_elems = (NKP * dq > DC * vt) ? NKP * dq : DC * vt;
+  T* kv_s = reinterpret_cast<T*>(o_s + QCHUNK * dq);                // K [NKP][dq]
+  // V^T [DC][vt]: a region of its own when the phase's LDS allows (vsep: staged together with K -- for cross-attention BEFORE the
+  // dependency wait, its K / V are cached text projections), else in K's place once the scores are done
+  const bool vsep = AI(vsep) != 0;
+  T* vt_s = vsep ? kv_s + ((NKP * dq + 15) & ~15) : kv_s;
+  const int kv_elems = vsep ? ((NKP * dq + 15) & ~15) + DC * vt : ((NKP * dq > DC * vt) ? NKP * dq : DC * vt);
   float* s_s = reinterpret_cast<float*>(kv_s + ((kv_elems + 15) & ~15));   // [32][sp]
   T* p_s = reinterpret_cast<T*>(s_s + ((QCHUNK * sp + 3) & ~3));      // [32][vt]
   float2* st_s = reinterpret_cast<float2*>(p_s + ((QCHUNK * vt + 7) & ~7));   // [max(Nk, 32)] LayerNorm (mean, rstd) per row
@@ -1140,40 +1147,108 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   const int kvbase = (AP(kv_row, const int32_t*) ? AP(kv_row, const int32_t*)[b] : b) * Nk;
   int xr = (AP(kv_extra, const void*) && AP(extra_row, const int32_t*)) ? AP(extra_row, const int32_t*)[b] : -1;
   if (xr >= 0 && AP(extra_step, const int32_t*)) xr = AP(extra_step, const int32_t*)[0];
-  Raw8<GT> kraw[MAXVA], vraw[MAXVA], qraw;
-  const GT* kadr[MAXVA];
-  const GT* vadr[MAXVA];
-  bool kvok[MAXVA];
-  {
-    const int ld_extra = AI(ld_extra), kx_off = AI(kx_off), vx_off = AI(vx_off), k_off = AI(k_off), v_off = AI(v_off);
-#pragma unroll
-    for (int i = 0; i < MAXVA; ++i) {
-      const int idx = tid + i * NT;
-      kvok[i] = idx < nkv;
-      const int r = idx >> log2_vpr, c = (idx & (vpr - 1)) * 8;
-      const bool ex = (xr >= 0 && r == Nk - 1);
-      kadr[i] = ex ? xp_ + ((size_t)((unsigned)xr * (unsigned)ld_extra) + (unsigned)(kx_off + hd + c))
-                   : kp_ + ((size_t)((unsigned)(kvbase + r) * (unsigned)ldkv) + (unsigned)(k_off + hd + c));
-      vadr[i] = ex ? xp_ + ((size_t)((unsigned)xr * (unsigned)ld_extra) + (unsigned)(vx_off + hd + c))
-                   : vp_ + ((size_t)((unsigned)(kvbase + r) * (unsigned)ldkv) + (unsigned)(v_off + hd + c));
-      if (!kv_live) {
-        if (kvok[i]) { ld_plain(kraw[i], kadr[i]); ld_plain(vraw[i], vadr[i]); }
-        else { zero_raw(kraw[i]); zero_raw(vraw[i]); }
-      }
-    }
-  }
+  const int ld_extra = AI(ld_extra), kx_off = AI(kx_off), vx_off = AI(vx_off), k_off = AI(k_off), v_off = AI(v_off);
+  // K (which = 0) or V (which = 1) vector `idx` of the unit's head: row idx >> log2_vpr, 8 channels from (idx & (vpr - 1)) * 8
+  auto kv_ptr = [&](int idx, int which) __attribute__((always_inline)) -> const GT* {
+    const int r = idx >> log2_vpr, c = (idx & (vpr - 1)) * 8;
+    const bool ex = (xr >= 0 && r == Nk - 1);
+    const GT* base = ex ? xp_ : (which ? vp_ : kp_);
+    const unsigned row = ex ? (unsigned)xr * (unsigned)ld_extra : (unsigned)(kvbase + r) * (unsigned)ldkv;
+    const unsigned col = (unsigned)((ex ? (which ? vx_off : kx_off) : (which ? v_off : k_off)) + hd + c);
+    return base + ((size_t)row + col);
+  };
   float uk[8], bk[8], uv[8], bv[8], uq[8], bq[8];
   const int kr0 = tid >> log2_vpr, kc0 = (tid & (vpr - 1)) * 8;            // vector 0 of this thread (the only one with a K/V finish)
   if (fin_kv && tid < nkv) {
-    load8(AP(ln_u, const float*) + AI(k_off) + hd + kc0, uk);
-    load8(AP(ln_b, const float*) + AI(k_off) + hd + kc0, bk);
-    load8(AP(ln_u, const float*) + AI(v_off) + hd + kc0, uv);
-    load8(AP(ln_b, const float*) + AI(v_off) + hd + kc0, bv);
+    load8(AP(ln_u, const float*) + k_off + hd + kc0, uk);
+    load8(AP(ln_b, const float*) + k_off + hd + kc0, bk);
+    load8(AP(ln_u, const float*) + v_off + hd + kc0, uv);
+    load8(AP(ln_b, const float*) + v_off + hd + kc0, bv);
   }
   if (fin_q && tid < nqv) {
     load8(AP(ln_u, const float*) + q_off + hd + kc0, uq);
     load8(AP(ln_b, const float*) + q_off + hd + kc0, bq);
   }
+  // ---- LDS the matrix cores read but nobody stores: Q rows >= nq, K rows >= Nk, V^T keys >= Nk (LDS is free: the previous unit
+  // ended on a barrier) ------------------------------------------------------------------------------------------------------------
+  {
+    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (d < 32) {
+      for (int i = tid; i < QCHUNK * (dq >> 3); i += NT) store8(q_s + i * 8, z8);
+      for (int i = tid; i < NKP * (dq >> 3); i += NT) store8(kv_s + i * 8, z8);
+      __syncthreads();
+    } else {
+      for (int i = tid; i < (QCHUNK - nq) * vpr; i += NT) store8(q_s + (nq + (i >> log2_vpr)) * dq + (i & (vpr - 1)) * 8, z8);
+      for (int i = tid; i < (NKP - Nk) * vpr; i += NT) store8(kv_s + (Nk + (i >> log2_vpr)) * dq + (i & (vpr - 1)) * 8, z8);
+    }
+  }
+  auto zero_vt_pad = [&]() __attribute__((always_inline)) {
+    if (d < 16) {
+      for (int i = tid; i < DC * vt; i += NT) vt_s[i] = to_elem<T>(0.f);
+      __syncthreads();                                  // (the whole region is cleared there; the real columns follow)
+    } else {
+      for (int i = tid; i < d * 32; i += NT) {
+        const int c = i >> 5, j = Nk + (i & 31);
+        if (j < NKP) vt_s[c * vt + (j ^ (((c >> 3) & 3) << 3))] = to_elem<T>(0.f);
+      }
+    }
+  };
+  auto finish = [&](float (&x)[8], const float2 st, const float (&uu)[8], const float (&bb)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (x[e] - st.x * uu[e]) * st.y + bb[e];
+  };
+  // one K vector into its LDS row / one V vector into V^T (fin0: vector 0 of a thread takes the deferred LayerNorm finish from st_s)
+  auto put_k = [&](const Raw8<GT>& raw, int idx, bool fin0) __attribute__((always_inline)) {
+    const int r = idx >> log2_vpr, c = (idx & (vpr - 1)) * 8;
+    float x[8];
+    raw_to_float(raw, x);
+    if (fin0) finish(x, st_s[r], uk, bk);
+    store8(kv_s + r * dq + c, x);
+  };
+  auto put_vt = [&](const Raw8<GT>& raw, int idx, bool fin0) __attribute__((always_inline)) {
+    const int r = idx >> log2_vpr, c = (idx & (vpr - 1)) * 8;
+    float x[8];
+    raw_to_float(raw, x);
+    if (fin0) finish(x, st_s[r], uv, bv);
+    // the 8-key blocks of a row are permuted by the row's channel block (XOR inside each 32-key group): the 16 channel blocks a
+    // wave transposes at once would otherwise land on two LDS banks
+    const int rs = r ^ (((c >> 3) & 3) << 3);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt_s[(c + e) * vt + rs] = to_elem<T>(x[e]);
+  };
+  // the cached K / V of a cross-attention (not produced in this launch): plain loads, staged right away
+  auto stage_cached = [&](int which) __attribute__((always_inline)) {
+    Raw8<GT> raw[MAXVA];
+#pragma unroll
+    for (int i = 0; i < MAXVA; ++i) {
+      if (tid + i * NT < nkv) ld_plain(raw[i], kv_ptr(tid + i * NT, which));
+    }
+#pragma unroll
+    for (int i = 0; i < MAXVA; ++i) {
+      if (tid + i * NT < nkv) {
+        if (which) put_vt(raw[i], tid + i * NT, false);
+        else put_k(raw[i], tid + i * NT, false);
+      }
+    }
+  };
+  if (vsep) zero_vt_pad();
+  if (!kv_live) {                                     // cross-attention: K (and V^T with a region of its own) are in LDS before the wait ends
+    stage_cached(0);
+    if (vsep) stage_cached(1);
+  }
+  // self-attention: K / V of at most MAXVL vectors per thread arrive with the polled loads
+  constexpr int MAXVL = JEN1_DEEP_ATTN_LIVE_VEC;
+  Raw8<GT> kl[MAXVL], vl[MAXVL], qraw;
+  // LayerNorm statistics of the rows the finish needs: 16 lanes per row over the ln_C leading columns of q's tensor; the first
+  // LNB vectors per lane ride in the same round of polled loads as q / k / v (bf16: a whole 1024-column row)
+  constexpr int LNB = sizeof(GT) == 2 ? 4 : 2;
+  const bool fin = fin_q || fin_kv;
+  const int rs0 = fin_kv ? 0 : q0, rsn = fin ? (fin_kv ? Nk : nq) : 0;
+  const int nvec = ln_C >> 3;
+  const int lrow = tid >> 4;
+  const bool lhas = lrow < rsn;
+  const GT* lrowp = qp + (size_t)((unsigned)(b * Nq + rs0 + (lhas ? lrow : 0)) * (unsigned)ldq);
+  Raw8<GT> lx[LNB];
 
   DK_STAMP(sy, 1);
 
@@ -1190,43 +1265,56 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
       bad = false;
       if (kv_live) {
 #pragma unroll
-        for (int i = 0; i < MAXVA; ++i) {
-          if (kvok[i]) { ld_live(kraw[i], kadr[i]); ld_live(vraw[i], vadr[i]); }
-          else { zero_raw(kraw[i]); zero_raw(vraw[i]); }
+        for (int i = 0; i < MAXVL; ++i) {
+          if (tid + i * NT < nkv) { ld_live(kl[i], kv_ptr(tid + i * NT, 0)); ld_live(vl[i], kv_ptr(tid + i * NT, 1)); }
+          else { zero_raw(kl[i]); zero_raw(vl[i]); }
         }
-#pragma unroll
-        for (int i = 0; i < MAXVA; ++i) bad |= raw_bad(kraw[i]) | raw_bad(vraw[i]);
       }
       if (tid < nqv) ld_live(qraw, qp + ((size_t)((unsigned)(b * Nq + q0 + kr0) * (unsigned)ldq) + (unsigned)(q_off + hd + kc0)));
       else zero_raw(qraw);
+      if (lhas) {
+#pragma unroll
+        for (int k = 0; k < LNB; ++k) {
+          if (li + 16 * k < nvec) ld_live(lx[k], lrowp + (li + 16 * k) * 8);
+          else zero_raw(lx[k]);
+        }
+      }
+      if (kv_live) {
+#pragma unroll
+        for (int i = 0; i < MAXVL; ++i) bad |= raw_bad(kl[i]) | raw_bad(vl[i]);
+      }
       bad |= q_live && raw_bad(qraw);
+      if (lhas) {
+#pragma unroll
+        for (int k = 0; k < LNB; ++k) bad |= q_live && raw_bad(lx[k]);
+      }
     } while (poll_again(sy, bad, spins));
   }
   DK_STAMP(sy, 2);
-  // LayerNorm statistics of the rows the finish needs: 16 lanes per row over the ln_C leading columns of q's tensor
-  if (fin_q || fin_kv) {
-    const int rs0 = fin_kv ? 0 : q0, rsn = fin_kv ? Nk : nq;
-    const int nvec = ln_C >> 3;
+  if (fin) {
     const float inv_c = 1.0f / (float)ln_C;
-    for (int r = tid >> 4; r < rsn; r += NT / 16) {
+    for (int r = lrow; r < rsn; r += NT / 16) {
       const GT* rowp = qp + (size_t)((unsigned)(b * Nq + rs0 + r) * (unsigned)ldq);
       float s = 0.f, q2 = 0.f;
-      // LNB vectors per lane requested together (bf16: a 1024-column row in one round trip; f32 keeps 2: registers)
-      constexpr int LNB = sizeof(GT) == 2 ? 8 : 2;
       for (int v0 = li; v0 < nvec; v0 += 16 * LNB) {
         Raw8<GT> x[LNB];
-        unsigned spins = 0;
-        bool bad;
-        do {
-          bad = false;
+        if (r == lrow && v0 == li) {
 #pragma unroll
-          for (int k = 0; k < LNB; ++k) {
-            if (v0 + 16 * k < nvec) ld_live(x[k], rowp + (v0 + 16 * k) * 8);
-            else zero_raw(x[k]);
-          }
+          for (int k = 0; k < LNB; ++k) x[k] = lx[k];                  // the chunk that came with the first round
+        } else {                                                       // (long rows in float32 / more than 32 rows: further rounds)
+          unsigned spins = 0;
+          bool bad;
+          do {
+            bad = false;
 #pragma unroll
-          for (int k = 0; k < LNB; ++k) bad |= q_live && raw_bad(x[k]);
-        } while (poll_again(sy, bad, spins));
+            for (int k = 0; k < LNB; ++k) {
+              if (v0 + 16 * k < nvec) ld_live(x[k], rowp + (v0 + 16 * k) * 8);
+              else zero_raw(x[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < LNB; ++k) bad |= q_live && raw_bad(x[k]);
+          } while (poll_again(sy, bad, spins));
+        }
 #pragma unroll
         for (int k = 0; k < LNB; ++k) {
           float f[8];
@@ -1245,32 +1333,16 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
         st_s[r] = make_float2(mean, rstd);
       }
     }
+    __syncthreads();                                                   // the finish below reads other threads' row statistics
   }
-  // zero the padding the matrix cores will read
-  {
-    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (d < 32) {
-      for (int i = tid; i < (QCHUNK + NKP) * (dq >> 3); i += NT) store8(q_s + i * 8, z8);
-    } else {
-      for (int i = tid; i < (QCHUNK - nq) * vpr; i += NT) store8(q_s + (nq + (i >> log2_vpr)) * dq + (i & (vpr - 1)) * 8, z8);
-      for (int i = tid; i < (NKP - Nk) * vpr; i += NT) store8(kv_s + (Nk + (i >> log2_vpr)) * dq + (i & (vpr - 1)) * 8, z8);
-    }
-  }
-  __syncthreads();
-  auto finish = [&](float (&x)[8], const float2 st, const float (&uu)[8], const float (&bb)[8]) {
+  // ---- K (and V^T) of a self-attention, Q -> LDS -----------------------------------------------------------------------------------
+  if (kv_live) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (x[e] - st.x * uu[e]) * st.y + bb[e];
-  };
-  // ---- K, Q -> LDS ---------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int i = 0; i < MAXVA; ++i) {
-    const int idx = tid + i * NT;
-    if (idx < nkv) {
-      const int r = idx >> log2_vpr, c = (idx & (vpr - 1)) * 8;
-      float x[8];
-      raw_to_float(kraw[i], x);
-      if (i == 0 && fin_kv) finish(x, st_s[r], uk, bk);
-      store8(kv_s + r * dq + c, x);
+    for (int i = 0; i < MAXVL; ++i) {
+      if (tid + i * NT < nkv) {
+        put_k(kl[i], tid + i * NT, i == 0 && fin_kv);
+        if (vsep) put_vt(vl[i], tid + i * NT, i == 0 && fin_kv);
+      }
     }
   }
   if (tid < nqv) {
@@ -1316,29 +1388,16 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
   }
   __syncthreads();
   DK_STAMP(sy, 10);
-  // ---- V replaces K in LDS, transposed: V^T [d][keys] is the B operand of P V ---------------------------------------------------
-  if (d < 16) {
-    for (int i = tid; i < DC * vt; i += NT) kv_s[i] = to_elem<T>(0.f);
-    __syncthreads();
-  } else {
-    for (int i = tid; i < d * 32; i += NT) {
-      const int c = i >> 5, j = Nk + (i & 31);
-      if (j < NKP) kv_s[c * vt + (j ^ (((c >> 3) & 3) << 3))] = to_elem<T>(0.f);
-    }
-  }
+  // ---- without a region of its own V replaces K in LDS now, transposed: V^T [d][keys] is the B operand of P V --------------------------
+  if (!vsep) {
+    zero_vt_pad();
+    if (kv_live) {
 #pragma unroll
-  for (int i = 0; i < MAXVA; ++i) {
-    const int idx = tid + i * NT;
-    if (idx < nkv) {
-      const int r = idx >> log2_vpr, c = (idx & (vpr - 1)) * 8;
-      float x[8];
-      raw_to_float(vraw[i], x);
-      if (i == 0 && fin_kv) finish(x, st_s[r], uv, bv);
-      // the 8-key blocks of a row are permuted by the row's channel block (XOR inside each 32-key group): the 16 channel blocks a
-      // wave transposes at once would otherwise land on two LDS banks
-      const int rs = r ^ (((c >> 3) & 3) << 3);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) kv_s[(c + e) * vt + rs] = to_elem<T>(x[e]);
+      for (int i = 0; i < MAXVL; ++i) {
+        if (tid + i * NT < nkv) put_vt(vl[i], tid + i * NT, i == 0 && fin_kv);
+      }
+    } else {
+      stage_cached(1);                                 // (read again: an L2 hit; the float32 mode's large contexts come here)
     }
   }
   DK_STAMP(sy, 11);
@@ -1396,7 +1455,7 @@ __device__ __forceinline__ void attn_unit(const unsigned char* D, int u, Sync& s
       for (int j = 0; j < NKP; j += 32) {
         Frag pa, vb;
         dlds(pa, p_s + (qt * 16 + li) * vt + j + lg * 8);
-        dlds(vb, kv_s + (ct * 16 + li) * vt + ((j + lg * 8) ^ ((((ct * 16 + li) >> 3) & 3) << 3)));
+        dlds(vb, vt_s + (ct * 16 + li) * vt + ((j + lg * 8) ^ ((((ct * 16 + li) >> 3) & 3) << 3)));
         dmma(acc, pa, vb);
       }
 #pragma unroll
@@ -1752,15 +1811,21 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
              (!kv_extra || (ld_extra % 8 == 0 && kx_off % 8 == 0 && vx_off % 8 == 0)), "deep attention: offsets / strides must be multiples of 8 elements");
   const bool fin = finish_q || finish_kv;
   JEN1_CHECK(!fin || (ln_u && ln_b && ln_C >= 8 && ln_C % 8 == 0), "deep attention: a LayerNorm finish needs u, bias and ln_C");
+  JEN1_CHECK(!(kv_live & 1) || Nk * (d / 8) <= JEN1_DEEP_ATTN_LIVE_VEC * JEN1_DEEP_THREADS, "deep attention: self-attention over Nk=%d d=%d is outside the unit's range", Nk, d);
   JEN1_CHECK(!finish_kv || (!kv_row && !kv_extra && Nk * (d / 8) <= JEN1_DEEP_THREADS && Nq == Nk && (kv_live & 1)),
              "deep attention: the K/V finish is for self-attention over at most %d vectors", JEN1_DEEP_THREADS);
   const int es = dtype == JEN1_F32 ? 4 : 2;      // (JEN1_FP8: sized like bf16 -- the output tile is bf16, the fp8 operands need less)
   const int DP = d < 32 ? 32 : d, DC = d < 16 ? 16 : d;
   const int NKP = (Nk + 31) & ~31, dq = DP + 8, vt = NKP + 8, sp = NKP + 4;
-  const int64_t kv_elems = (NKP * dq > DC * vt) ? NKP * dq : DC * vt;
   const int st_rows = Nk > QCHUNK ? Nk : QCHUNK;
-  const int64_t lds = (int64_t)es * QCHUNK * dq + es * ((kv_elems + 7) & ~(int64_t)7) + 4 * (((int64_t)QCHUNK * sp + 3) & ~(int64_t)3) +
-                      es * (((int64_t)QCHUNK * vt + 7) & ~(int64_t)7) + 8 * st_rows + 32;
+  auto lds_of = [&](bool vsep) {
+    const int64_t kv_elems = vsep ? (((int64_t)NKP * dq + 15) & ~(int64_t)15) + (int64_t)DC * vt : ((NKP * dq > DC * vt) ? NKP * dq : DC * vt);
+    return (int64_t)es * QCHUNK * dq + es * ((kv_elems + 15) & ~(int64_t)15) + 4 * (((int64_t)QCHUNK * sp + 3) & ~(int64_t)3) +
+           es * (((int64_t)QCHUNK * vt + 7) & ~(int64_t)7) + 8 * st_rows + 64;
+  };
+  // V^T gets LDS of its own when it fits half of the budget (the GEMM phases of the launch need theirs anyway)
+  const bool vsep = lds_of(true) <= LDS_BUDGET / 2;
+  const int64_t lds = lds_of(vsep);
   JEN1_CHECK(lds <= LDS_BUDGET, "deep attention: Nk=%d d=%d needs %lld B of LDS", Nk, d, (long long)lds);
   jen1_deep_phase& p = *out;
   memset(&p, 0, sizeof(p));
@@ -1773,6 +1838,7 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
   p.ld_extra = ld_extra; p.kx_off = kx_off; p.vx_off = vx_off; p.h.B = B; p.H = H; p.d = d; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.q_off = q_off;
   p.ldkv = ldkv; p.k_off = k_off; p.v_off = v_off; p.ldo = ldo; p.causal = causal;
   p.ln_C = ln_C; p.fin_q = finish_q; p.fin_kv = finish_kv; p.kv_live = kv_live;
+  p.vsep = vsep ? 1 : 0;
   p.nqc = ceil_div(Nq, QCHUNK);
   int l2 = 0;
   while ((8 << l2) < d) ++l2;

@@ -520,8 +520,17 @@ class OpBuilder:
             if m_split:
                 a.m_split, a.k_split = m_split, k_split
             self._keep.append((a, src0, src1, w, w8, bias, out, residual, gn, film, extra_segs))
+            # batch elements per unit: fewer per unit = smaller tiles to normalise and stage (the critical path of a phase) on more
+            # workgroups, but every batch group streams the layer's weights again -- so only where the weights are small
+            nb_cap = eng.deep_nb_max
+            if eng.deep_unit_target > 0:
+                wbytes_ = (taps * (a.c0 + a.c1) + sum(e.cp for e, _ in (extra_segs or []))) * a.M * (1 if w8 is not None else (4 if eng.dt == L.F32 else 2))
+                nb_ = 1
+                while nb_ < a.B and ((a.M // 16) * -(-a.B // nb_) > eng.deep_unit_target or -(-a.B // nb_) * wbytes_ > eng.deep_reread_cap):
+                    nb_ *= 2
+                nb_cap = nb_ if nb_cap == 0 else min(nb_cap, nb_)
             self.deep.add_conv(a, f"conv[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} M={a.M}", out,
-                               nb_max=eng.deep_nb_max)
+                               nb_max=nb_cap)
             es_ = 4 if eng.dt == L.F32 else 2
             c_real_ = src0.C + (src1.C if src1 is not None else 0)
             c_extra_ = sum(e.C for e, _ in extra_segs) if extra_segs else 0
@@ -1283,6 +1292,11 @@ class Engine:
         self.deterministic = os.environ.get("JEN1_DETERMINISTIC", "0") != "0"
         self.deep_max_len = int(os.environ.get("JEN1_DEEP_MAX_LEN", "64"))
         self.deep_nb_max = int(os.environ.get("JEN1_DEEP_NB_MAX", "0"))
+        # units per phase the batch split aims for (0: as many batch elements per unit as fit) and the weight bytes a phase may stream
+        # in total when every batch group reads the layer's weights again; measured at B = 8, T = 1500 (deep launch, us):
+        # 0 -> 922, 128 / 2 MB -> 927, 128 / 8 MB -> 893, 128 / 16 MB -> 889, 192 / 4 MB -> 918, 256 / 8 MB -> 909, 256 / 32 MB -> 1001
+        self.deep_unit_target = int(os.environ.get("JEN1_DEEP_UNIT_TARGET", "128"))
+        self.deep_reread_cap = int(float(os.environ.get("JEN1_DEEP_REREAD_MB", "16")) * (1 << 20))
         self.plans: Dict[tuple, Plan] = {}
         self.load_params(params)
 
