@@ -803,6 +803,8 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 
 #ifndef JEN1_DEEP_EXP_NOSTAGE
   // ---- every load (sc1: another workgroup wrote the data in this launch), no branches; the wave repeats them until complete ---
+  // (measured, not kept: two rounds of polled loads in flight half a round trip apart, to sample the producers' stores twice as
+  // often -- deep launch 889 -> 997 / 1005 / 1024 / 1067 us at gaps of 4 / 8 / 16 / 24 x 64 clocks)
   Raw8<GT> xn[MAXV], xw[MAXV];
   float rres[4] = {0.f, 0.f, 0.f, 0.f};
   {
