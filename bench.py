@@ -122,6 +122,8 @@ def concurrent_batches_bench(model, B, T, device, n, steps, warmup):
     run(warmup, steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for st in sts:
+        st.check()                 # the error word of every persistent launch (a dependency wait that timed out raises here)
     return {"batches_in_flight": n, "steps_per_s_aggregate": round(n * steps / dt, 1), "ms_per_step_per_batch": round(dt / steps * 1e3, 3)}
 
 

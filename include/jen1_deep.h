@@ -179,10 +179,11 @@ int jen1_deep_blob_bytes(void);
 
 /* Poison the tensors the launch produces: table_dev = n device entries {uint64 pointer, uint64 bytes (multiple of 16)}, one per
  * tensor written by a phase (the caller collects them while it records the phases).  Must run after the previous launch's last
- * reader and complete before the launch starts (same stream: the first node of the step).  Capturable. */
-int jen1_deep_poison(const void* table_dev, int n, void* stream);
+ * reader and complete before the launch starts (same stream: the first node of the step).  Also zeroes sync[0], the launch's ticket
+ * counter (units are handed to workgroups by ticket: the launch makes progress with any number of resident workgroups).  Capturable. */
+int jen1_deep_poison(const void* table_dev, int n, uint32_t* sync, void* stream);
 
-/* (round 2's arrival counters; the area is no longer used by the kernel -- kept so that callers of jen1_deep_run need not change) */
+/* bytes of the synchronisation area: word 0 is the ticket counter (zero when the launch starts: jen1_deep_poison), the rest is unused */
 int64_t jen1_deep_sync_bytes(int n_phases);
 
 /* workgroups the launch should use on the current device (one per CU, all resident) */
@@ -199,6 +200,14 @@ int jen1_deep_run(const void* blobs_dev, const void* headers_dev, int n_phases, 
 int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes,
                       int dtype, void* stream);
 int jen1_deep_error_word(int n_phases);
+/* the same with the scheduling form chosen by the caller.  tickets = 1 (what jen1_deep_run / jen1_deep_run_err use): units are handed
+ * to workgroups by ticket from sync[0]; the launch makes progress with ANY number of resident workgroups, so persistent launches that
+ * share the GPU (other streams, other processes) cannot deadlock each other.  tickets = 0: the static unit -> workgroup map, ~9 %
+ * faster (889 against 971 us per launch at B = 8, T = 1500), correct only while all nwg workgroups are resident together: for a caller
+ * that runs at most ONE such launch per device at a time.  Either way a dependency wait that exceeds its bound (~40 ms) raises the
+ * error word instead of hanging. */
+int jen1_deep_run_mode(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes,
+                       int dtype, int tickets, void* stream);
 
 #ifdef __cplusplus
 }

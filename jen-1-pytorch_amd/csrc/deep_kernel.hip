@@ -277,12 +277,13 @@ constexpr int CUR_OFF = SLOT_OFF + NW * SLOTS * 8;
 static_assert(CUR_OFF + NW * 32 <= BLOB, "run / slot / cursor tables must fit the blob");
 static_assert(JEN1_DEEP_PF_B <= SLOTS && JEN1_DEEP_PF_F <= SLOTS, "the slot table covers the ring");
 constexpr int HDR_BYTES = JEN1_DEEP_MAX_PHASES * 16;
-constexpr int WS_OFF = HDR_BYTES + 2 * BLOB;           // LDS: headers | two descriptor slots | unit workspace
+constexpr int TICKET_OFF = HDR_BYTES + 2 * BLOB;       // LDS: headers | two descriptor slots | the next ticket | unit workspace
+constexpr int WS_OFF = TICKET_OFF + 16;
 static_assert(sizeof(jen1_deep_phase) <= TAB_OFF, "descriptor must fit ahead of the chunk table");
 static_assert(BLOB == NT * 8, "one 8-byte word per thread moves a blob");
 static_assert(JEN1_DEEP_MAX_PHASES <= NT, "one header per thread at start-up");
 struct Hdr {
-  int n_units, rot, kind, pad;
+  int n_units, rot, kind, before;      // before: units of all earlier phases (the first ticket of this phase)
 };
 
 // ---- synchronisation: the data is its own flag ------------------------------------------------------------------------
@@ -371,6 +372,12 @@ __device__ __forceinline__ bool poll_again(Sync& sy, bool bad, unsigned& spins) 
   return true;
 }
 
+// ---- scheduling: static ------------------------------------------------------------------------------------------------------------
+// Unit u of phase p runs on workgroup (u + rot_p) mod nwg: every workgroup knows its units from the headers alone, requests the
+// next unit's descriptor during the current one and its weight ring right behind it, and a workgroup that just finished a unit is
+// rarely the one the next phase waits for.  Fastest (889 us per launch at B = 8, T = 1500 against 971 with tickets), but correct only
+// while all nwg workgroups are resident together: the host uses it for ONE plan per device at a time (engine.py) and the ticket
+// form below for every other persistent launch that may share the GPU with it.
 // next unit of this workgroup after (p, u): the same phase first (more units than workgroups), then later phases
 __device__ __forceinline__ bool find_next(const Hdr* hdr, int n_phases, int wg, int nwg, int& p, int& u) {
   if (p >= 0) {
@@ -383,6 +390,18 @@ __device__ __forceinline__ bool find_next(const Hdr* hdr, int n_phases, int wg, 
     if (u0 < hdr[q].n_units) { p = q; u = u0; return true; }
   }
   return false;
+}
+
+// ---- scheduling: tickets -----------------------------------------------------------------------------------------------------------
+// The units of the launch are numbered phase by phase; a workgroup takes the next number from one device counter (sync[0], zeroed
+// with the poisoning) whenever it needs work.  Whoever holds the smallest unfinished ticket depends only on smaller tickets, which are
+// finished or held by workgroups that are already running: the launch makes progress with ANY number of resident workgroups, so two
+// persistent launches sharing the GPU (another stream, another process) slow each other down but cannot deadlock.  A workgroup keeps
+// two tickets ahead of the unit it runs -- the next unit's descriptor and weight ring are requested a whole unit early -- and the
+// counter's round trip rides on the unit in between.
+__device__ __forceinline__ void ticket_decode(const Hdr* hdr, int n_phases, int t, int& p, int& u) {      // p: hint, tickets only grow
+  while (p + 1 < n_phases && t >= hdr[p + 1].before) ++p;
+  u = t - hdr[p].before;
 }
 
 // =====================================================================================================================
@@ -1557,7 +1576,7 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
   DK_STAMP(sy, 6);
 }
 
-template <typename T>
+template <typename T, bool TK>      // TK: units by ticket (any number of resident workgroups) instead of the static unit -> workgroup map
 __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restrict__ blobs, const int4* __restrict__ hdr_g, int n_phases,
                                                   unsigned* sync, unsigned* err) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1579,6 +1598,7 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
 #pragma unroll
   for (int i_ = 0; i_ < 16; ++i_) sy.tt[i_] = 0;
 #endif
+  if constexpr (!TK) {
   int p = -1, u = 0;
   if (!find_next(hdr, n_phases, wg, nwg, p, u)) return;
   p = rfl(p);
@@ -1614,6 +1634,48 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
     p = p2;
     u = u2;
     if (reload) slot ^= 1;
+  }
+    return;
+  }
+  const int total = hdr[n_phases - 1].before + hdr[n_phases - 1].n_units;
+  volatile int* tick_s = reinterpret_cast<volatile int*>(smem + TICKET_OFF);
+  gu32* const ticket = g32(sync);
+  if (tid == 0) tick_s[0] = (int)__hip_atomic_fetch_add(ticket, 1u, RLX_AGENT);
+  __syncthreads();
+  int ta = rfl(tick_s[0]);
+  int p = 0, u = 0, p_loaded = -1;
+  Frag ra[PF];
+  unsigned char* const D = smem + HDR_BYTES;
+  while (ta < total) {
+    ticket_decode(hdr, n_phases, ta, p, u);
+    p = rfl(p);
+    u = rfl(u);
+    if (p != p_loaded) {                               // the phase's descriptor + per-wave tables: global -> LDS
+      __syncthreads();                                 // (a ticket read of the previous round may still be under way)
+      reinterpret_cast<u64*>(D)[tid] = reinterpret_cast<const u64*>(blobs + (size_t)p * BLOB)[tid];
+      __syncthreads();
+      p_loaded = p;
+    }
+    const int kind = hdr[p].kind;
+    // the unit's weight ring: requested as soon as the unit is known, long before its dependency wait ends (a workgroup that is
+    // free takes the smallest open ticket, typically a phase or two ahead of the ones being computed)
+#ifndef JEN1_DEEP_EXP_NOPRE
+    if (kind == JEN1_DEEP_GEMM) gemm_prefill<T>(D, u, wk, lane, ra);
+#endif
+    // the next ticket: requested late in the unit (a workgroup must not sit on a ticket while it computes: the unit it would hold
+    // is on the critical path a phase later), picked up behind the unit
+    unsigned tc = 0;
+    auto publish_next = [&]() {
+      if (tid == 0 && tc == 0) tc = 1u + __hip_atomic_fetch_add(ticket, 1u, RLX_AGENT);
+    };
+    sy.p = p;
+    if (kind == JEN1_DEEP_GEMM) gemm_unit<T>(D, u, sy, ra, publish_next, tid);
+    else if (kind == JEN1_DEEP_ATTN) attn_unit<T>(D, u, sy, publish_next, tid);
+    else stats_unit<T>(D, u, sy, publish_next, tid);
+    DK_FLUSH(sy);
+    if (tid == 0) tick_s[0] = (int)(tc - 1u);
+    __syncthreads();
+    ta = rfl(tick_s[0]);
   }
 }
 
@@ -1873,7 +1935,7 @@ extern "C" int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, 
 extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, void* blobs, void* headers) {
   JEN1_CHECK(phases && blobs && headers && n_phases >= 1 && nwg >= 1, "deep link: bad arguments");
   JEN1_CHECK(n_phases <= JEN1_DEEP_MAX_PHASES, "deep link: %d phases (at most %d)", n_phases, JEN1_DEEP_MAX_PHASES);
-  int lds = 0, rot = 0;
+  int lds = 0, rot = 0, units_before = 0;
   unsigned char* bl = reinterpret_cast<unsigned char*>(blobs);
   int32_t* hd = reinterpret_cast<int32_t*>(headers);
   memset(bl, 0, (size_t)n_phases * BLOB);
@@ -1902,7 +1964,8 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
     lds = P.h.lds_bytes > lds ? P.h.lds_bytes : lds;
     unsigned char* b = bl + (size_t)p * BLOB;
     memcpy(b, &P, sizeof(P));
-    hd[4 * p + 0] = P.h.n_units; hd[4 * p + 1] = P.h.rot; hd[4 * p + 2] = P.h.kind; hd[4 * p + 3] = 0;
+    hd[4 * p + 0] = P.h.n_units; hd[4 * p + 1] = P.h.rot; hd[4 * p + 2] = P.h.kind; hd[4 * p + 3] = units_before;
+    units_before += P.h.n_units;
     if (P.h.kind != JEN1_DEEP_GEMM) continue;
     // K chunks that can touch a real input row (a segment whose every row is conv padding for every position is skipped
     // together with its weights: exact), dealt round-robin to the waves; per wave and segment that is one run
@@ -1966,7 +2029,8 @@ namespace {
 struct PoisonEntry {
   unsigned long long ptr, bytes;          // bytes: a multiple of 16
 };
-__global__ __launch_bounds__(256) void poison_kernel(const PoisonEntry* __restrict__ tab) {
+__global__ __launch_bounds__(256) void poison_kernel(const PoisonEntry* __restrict__ tab, unsigned* __restrict__ sync) {
+  if (sync && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync[0] = 0u;      // the ticket counter of the launch
   const PoisonEntry e = tab[blockIdx.y];
   uint4* p = reinterpret_cast<uint4*>(e.ptr);
   const size_t n = e.bytes >> 4;
@@ -1975,9 +2039,9 @@ __global__ __launch_bounds__(256) void poison_kernel(const PoisonEntry* __restri
 }
 }  // namespace
 
-extern "C" int jen1_deep_poison(const void* table_dev, int n, void* stream) {
+extern "C" int jen1_deep_poison(const void* table_dev, int n, uint32_t* sync, void* stream) {
   JEN1_CHECK(table_dev && n >= 1 && n <= 65535, "deep poison: bad table");
-  hipLaunchKernelGGL(poison_kernel, dim3(8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const PoisonEntry*>(table_dev));
+  hipLaunchKernelGGL(poison_kernel, dim3(8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const PoisonEntry*>(table_dev), sync);
   JEN1_HIP(hipGetLastError());
   return 0;
 }
@@ -1993,34 +2057,43 @@ extern "C" int jen1_deep_num_workgroups(void) {
   return cus;
 }
 
-extern "C" int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
-                                 int lds_bytes, int dtype, void* stream);
+extern "C" int jen1_deep_run_mode(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
+                                  int lds_bytes, int dtype, int tickets, void* stream);
 extern "C" int jen1_deep_run(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, int nwg, int lds_bytes, int dtype,
                              void* stream) {
   JEN1_CHECK(sync, "deep run: bad arguments");
-  return jen1_deep_run_err(blobs_dev, headers_dev, n_phases, sync, sync + jen1_deep_error_word(n_phases), nwg, lds_bytes, dtype, stream);
+  return jen1_deep_run_mode(blobs_dev, headers_dev, n_phases, sync, sync + jen1_deep_error_word(n_phases), nwg, lds_bytes, dtype, 1, stream);
 }
-
 extern "C" int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
                                  int lds_bytes, int dtype, void* stream) {
+  return jen1_deep_run_mode(blobs_dev, headers_dev, n_phases, sync, err, nwg, lds_bytes, dtype, 1, stream);
+}
+
+namespace {
+template <typename T, bool TK>
+int launch_deep(const unsigned char* bl, const int4* hd, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes, hipStream_t s) {
+  auto kern = deep_kernel<T, TK>;
+  JEN1_MAX_LDS_ONCE(kern, LDS_TOTAL);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int jen1_deep_run_mode(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
+                                  int lds_bytes, int dtype, int tickets, void* stream) {
   JEN1_CHECK(blobs_dev && headers_dev && sync && err && n_phases >= 1 && n_phases <= JEN1_DEEP_MAX_PHASES && nwg >= 1, "deep run: bad arguments");
   JEN1_CHECK(lds_bytes >= WS_OFF && lds_bytes <= LDS_TOTAL, "deep run: %d B of LDS", lds_bytes);
   JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "deep run: bad dtype");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int dev = 0;
-  JEN1_HIP(hipGetDevice(&dev));
-  static unsigned long long attr_set[3] = {0ull, 0ull, 0ull};       // per dtype, one bit per device ordinal
-  const void* fn = dtype == JEN1_F32 ? reinterpret_cast<const void*>(deep_kernel<float>)
-                 : dtype == JEN1_FP8 ? reinterpret_cast<const void*>(deep_kernel<fp8_t>) : reinterpret_cast<const void*>(deep_kernel<bf16_t>);
-  if (dev >= 64 || !(attr_set[dtype] >> dev & 1ull)) {
-    JEN1_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    if (dev < 64) attr_set[dtype] |= 1ull << dev;
-  }
   const unsigned char* bl = reinterpret_cast<const unsigned char*>(blobs_dev);
   const int4* hd = reinterpret_cast<const int4*>(headers_dev);
-  if (dtype == JEN1_F32) hipLaunchKernelGGL(deep_kernel<float>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
-  else if (dtype == JEN1_FP8) hipLaunchKernelGGL(deep_kernel<fp8_t>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
-  else hipLaunchKernelGGL(deep_kernel<bf16_t>, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
-  JEN1_HIP(hipGetLastError());
-  return 0;
+  if (tickets) {
+    if (dtype == JEN1_F32) return launch_deep<float, true>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+    if (dtype == JEN1_FP8) return launch_deep<fp8_t, true>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+    return launch_deep<bf16_t, true>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  }
+  if (dtype == JEN1_F32) return launch_deep<float, false>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  if (dtype == JEN1_FP8) return launch_deep<fp8_t, false>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  return launch_deep<bf16_t, false>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
 }

@@ -23,6 +23,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import weakref
 import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
@@ -255,6 +256,8 @@ class DeepProgram:
     levels with few positions, links them (dependency chain, unit -> workgroup rotation) and copies the array to the device.
     The descriptors are opaque bytes here; libjen1_hip.so fills and validates them."""
 
+    _static_owner: Dict[str, "weakref.ref"] = {}       # per device: the program that may use the static schedule
+
     def __init__(self, eng):
         self.eng = eng
         self.lib = eng.lib
@@ -267,6 +270,11 @@ class DeepProgram:
         self.lds = 0
         self.sync = None
         self._produced: Dict[int, torch.Tensor] = {}     # storage pointer -> tensor, of everything a recorded phase writes
+        # scheduling form of the launch (jen1_deep_run_mode): the static unit -> workgroup map is ~9 % faster but needs every
+        # workgroup resident, so only ONE program per device and process may use it at a time -- the first one alive claims it, every
+        # other persistent launch that could share the GPU with it (concurrent samplers, other shapes on other streams) goes by ticket
+        # and cannot deadlock.  JEN1_DEEP_SHARED=1 (the GPU is shared with other PROCESSES that run this library) forces tickets.
+        self.exclusive = False
 
     def _note_output(self, out: Optional["Act"]):
         if out is not None:
@@ -333,19 +341,24 @@ class DeepProgram:
             nb = t.untyped_storage().nbytes()
             assert ptr % 16 == 0 and nb % 16 == 0, (ptr, nb)
             ent += [ptr, nb]
+        key = str(self.eng.device)
+        owner = DeepProgram._static_owner.get(key)
+        if os.environ.get("JEN1_DEEP_SHARED", "0") != "1" and (owner is None or owner() is None):
+            DeepProgram._static_owner[key] = weakref.ref(self)
+            self.exclusive = True
         self.poison_tab = torch.tensor(ent, dtype=torch.int64).view(-1, 2).to(self.eng.device)
         self.poison_bytes = int(sum(ent[1::2]))
 
     def poison(self, stream: int):
         """before every launch, after the last reader of the previous one: the step's first node (Plan) does this"""
-        L.check(self.lib.jen1_deep_poison(self.poison_tab.data_ptr(), self.poison_tab.shape[0], stream), "jen1_deep_poison")
+        L.check(self.lib.jen1_deep_poison(self.poison_tab.data_ptr(), self.poison_tab.shape[0], self.sync.data_ptr(), stream), "jen1_deep_poison")
 
     def launch(self, stream: int):
         n = len(self.bufs)
         if os.environ.get("JEN1_DEEP_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_DEEP_RUN_PHASES"]))
-        L.check(self.lib.jen1_deep_run_err(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.err.data_ptr(), self.nwg,
-                                           self.lds, self.eng.deep_dt, stream), "jen1_deep_run_err")
+        L.check(self.lib.jen1_deep_run_mode(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.err.data_ptr(), self.nwg,
+                                            self.lds, self.eng.deep_dt, 0 if self.exclusive else 1, stream), "jen1_deep_run_mode")
 
     def error(self) -> int:
         """non-zero after a launch whose dependency wait timed out (1 + phase index); synchronises with the device"""
@@ -1286,9 +1299,9 @@ class Engine:
         self.tile_min_rows = int(os.environ.get("JEN1_TILE_MIN_ROWS", "512"))
         self.tile_target_wgs = int(os.environ.get("JEN1_TILE_TARGET_WGS", "256"))
         self.tile_one_round = os.environ.get("JEN1_TILE_ONE_ROUND", "0") != "0"
-        # persistent deep-level kernel (DeepProgram): levels of at most deep_max_len positions, plans of slot 0 only
-        # (two persistent launches in flight on different streams could each hold CUs the other waits for)
+        # persistent deep-level kernel (DeepProgram): levels of at most deep_max_len positions
         self.use_deep = os.environ.get("JEN1_DEEP", "1") != "0"
+        self.deep_all_slots = os.environ.get("JEN1_DEEP_ALL_SLOTS", "0") != "0"
         self.deterministic = os.environ.get("JEN1_DETERMINISTIC", "0") != "0"
         self.deep_max_len = int(os.environ.get("JEN1_DEEP_MAX_LEN", "64"))
         self.deep_nb_max = int(os.environ.get("JEN1_DEEP_NB_MAX", "0"))
@@ -1338,10 +1351,13 @@ class Engine:
              deep: Optional[bool] = None, deterministic: Optional[bool] = None) -> Plan:
         """``slot`` distinguishes plans of the same shape that must own separate buffers because
         they run concurrently on different streams (sub-batches of one sampler step); ``n_t`` selects
-        the sampler's table mode (see Plan).  ``deep``: use the persistent deep-level launch (default: slot 0 only).
+        the sampler's table mode (see Plan).  ``deep``: use the persistent deep-level launch (default: yes).
         ``deterministic``: fixed-order statistics (see Plan; default: ``self.deterministic``, env JEN1_DETERMINISTIC)."""
         if deep is None:
-            deep = slot == 0
+            # concurrent samplers (slot > 0) keep one launch per layer by default: persistent launches are safe to share the GPU
+            # (tickets) but each one wants every CU, while independent launch-per-layer chains overlap -- 4 batches in flight:
+            # 1 109 steps/s aggregate with four persistent launches against 1 412 with one (bench.py extra.concurrent_batches)
+            deep = slot == 0 or self.deep_all_slots
         deep = bool(deep) and self.use_deep
         det = self.deterministic if deterministic is None else bool(deterministic)
         key = (B, T, nrep, bool(causal), slot, n_t, deep, det)

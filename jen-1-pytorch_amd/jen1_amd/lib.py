@@ -140,13 +140,14 @@ SYMBOLS = {
                                   [c_float, _P, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
     "jen1_deep_phase_stats": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_deep_link": (c_int, [_P, c_int, c_int, _P, _P]),
-    "jen1_deep_poison": (c_int, [_P, c_int, _P]),
+    "jen1_deep_poison": (c_int, [_P, c_int, _P, _P]),
     "jen1_deep_blob_bytes": (c_int, []),
     "jen1_deep_sync_bytes": (c_int64, [c_int]),
     "jen1_deep_num_workgroups": (c_int, []),
     "jen1_deep_run": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "jen1_deep_run_err": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "jen1_deep_error_word": (c_int, [c_int]),
+    "jen1_deep_run_mode": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),
