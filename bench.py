@@ -70,13 +70,17 @@ def dev(a, device):
     return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def build_stepper(model, B, T, device, cfg_pair, use_graph, plan_slot=0):
-    from jen1_amd import synth
+def make_diffusion(device, cfg_pair):
     from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
     betas, _ = get_beta_schedule("linear", 1000)
-    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device=device,
-                           cfg_dropout_proba=0.0, embedding_scale=0.8 if cfg_pair else 1.0, batch_cfg=True,
-                           scale_cfg=True, sampling_timesteps=100)
+    return GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device=device,
+                             cfg_dropout_proba=0.0, embedding_scale=0.8 if cfg_pair else 1.0, batch_cfg=True,
+                             scale_cfg=True, sampling_timesteps=100)
+
+
+def build_stepper(model, B, T, device, cfg_pair, use_graph, plan_slot=0):
+    from jen1_amd import synth
+    gd = make_diffusion(device, cfg_pair)
     cond = {k: dev(v, device) for k, v in synth.conditioning(B, T).items()}
     st = gd.stepper(model, (B, 128, T), cond, causal=False, use_graph=use_graph, plan_slot=plan_slot)
     st.reset(dev(synth.latents(B, T), device))
@@ -96,6 +100,38 @@ def timed_steps(st, steps, warmup, barrier):
     barrier()
     t1 = time.perf_counter()
     return t1 - t0
+
+
+def end_to_end_bench(model, st, B, T, device):
+    """What the timed region leaves out, measured: (a) the per-run set-up of a sampling run -- text K/V projection
+    (``Plan.set_context``) and the schedule tables (``Plan.run_time``: time MLP, FiLM GEMM and time-token K/V GEMM for all 100
+    steps) -- and (b) the wall time of real ``GaussianDiffusion.sample()`` calls of 100 DDIM steps on the bench shape (start noise,
+    set-up, 100 replays, final copy, error check, one host sync), first call (builds the plan's graph) and repeated call."""
+    from jen1_amd import synth
+    plan = st.plan
+    cond = {k: dev(v, device) for k, v in synth.conditioning(B, T).items()}
+    s = torch.cuda.current_stream(device).cuda_stream
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    e[0].record()
+    plan.set_context(cond["cross_attn_cond"], cond["cross_attn_masks"], s)
+    e[1].record()
+    plan.run_time(s)
+    e[2].record()
+    torch.cuda.synchronize()
+    gd = make_diffusion(device, False)
+    walls = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x = gd.sample(model, (B, 128, T), cond)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    assert bool(torch.isfinite(x).all())
+    return {"set_context_ms": round(e[0].elapsed_time(e[1]), 3), "run_time_tables_ms": round(e[1].elapsed_time(e[2]), 3),
+            "setup_ms": round(e[0].elapsed_time(e[2]), 3),
+            "sample_100_steps_wall_ms": {"first_call": round(walls[0] * 1e3, 1), "repeated_call": round(min(walls[1:]) * 1e3, 1)},
+            "steps_per_s_end_to_end": round(100.0 / min(walls[1:]), 1)}
 
 
 def concurrent_batches_bench(model, B, T, device, n, steps, warmup):
@@ -127,14 +163,25 @@ def concurrent_batches_bench(model, B, T, device, n, steps, warmup):
     return {"batches_in_flight": n, "steps_per_s_aggregate": round(n * steps / dt, 1), "ms_per_step_per_batch": round(dt / steps * 1e3, 3)}
 
 
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round present"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not c:
+        raise FileNotFoundError(suffix)
+    return c[-1]
+
+
 def pmc_entry(name):
-    """HBM bytes / MFMA-busy of the committed rocprofv3 --pmc passes of this command (profiles/r02_pmc.json, produced by
-    tools/pmc_summary.py from the per-pass CSVs; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)"""
+    """HBM bytes / MFMA-busy of the committed rocprofv3 --pmc passes of this command (profiles/rNN_pmc.json of the latest
+    round, produced by tools/profile_round.sh -> tools/pmc_summary.py from the per-pass databases; FETCH_SIZE / WRITE_SIZE
+    corrected as MI355X_MICROARCH.md prescribes)"""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        path = latest_profile("pmc.json")
+        d = json.load(open(path))
         e = d["kernels"].get(name)
         if e is not None:
-            e = dict(e, collected_at=d.get("collected_at"))      # commit + bench.py hash + command of the PMC run
+            e = dict(e, collected_at=d.get("collected_at"), source="profiles/" + os.path.basename(path))
         return e
     except Exception:
         return None
@@ -275,7 +322,8 @@ def conv_roofline(st, reps=3):
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_busy_pct": mfma_busy,
         "mfma": {"bound": "mfma", "achieved": round(flops / (conv_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                  "frac": round(flops / (conv_ms * 1e-3) / 1e12 / 2500.0, 5)},
-        "kernel": "jen1_conv_gemm family: stream_gemm_kernel<*> + conv_gemm_kernel<*> (fused norm + conv/linear implicit GEMM)",
+        "kernel": "jen1_conv_gemm launches of the levels above the persistent launch: tile_gemm_kernel<*> (fused GroupNorm+FiLM+SiLU "
+                  "prologue + conv implicit GEMM) and the few stream_gemm / conv_gemm launches among them",
         "launches_per_step": n, "avg_launch_us": round(conv_ms * 1e3 / n, 2), "conv_ms_per_step": round(conv_ms, 4),
         "conv_ms_per_step_eager_with_event_pairs": round(eager_ms, 4),
         "alg_bytes_per_step": int(alg), "alg_weight_bytes": int(w_bytes), "alg_act_bytes": int(a_bytes),
@@ -347,14 +395,15 @@ def train_step_bench(cfg, B, T, dtype, device, reps=5, fwd_flops=None):
         # GEMM work of the pass: the forward of 2B rows (the CFG pair) + data and weight gradients = 3 x 2 x the B-row forward that the
         # sampling plan counts; against the dense bf16 MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s; f32 mode is not priced)
         tf = 6.0 * fwd_flops / (fb * 1e-3) / 1e12
-        busy = None
+        busy = tp = None
         try:
-            busy = json.load(open(os.path.join(ROOT, "profiles", "r02_train_pmc.json")))["kernels"]["train_gemm"]["mfma_busy_pct"]
+            tp = latest_profile("train_pmc.json")
+            busy = json.load(open(tp))["kernels"]["train_gemm"]["mfma_busy_pct"]
         except Exception:
             pass
         mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
                 "kernel": "train_gemm_kernel<bf16> (forward, data-gradient and weight-gradient GEMMs of the pass)",
-                "executed_gflop_per_pass": round(6.0 * fwd_flops / 1e9, 1), "mfma_busy_pct": busy, "pmc_source": "profiles/r02_train_pmc.json"}
+                "executed_gflop_per_pass": round(6.0 * fwd_flops / 1e9, 1), "mfma_busy_pct": busy, "pmc_source": None if busy is None else "profiles/" + os.path.basename(tp)}
     return {"what": f"configs[3] per-GPU shape: forward + backward of {B} clips x 128x{T} through the CFG pair (2B rows), hipGraph replay",
             "fwd_bwd_ms": round(fb, 2), "roofline_mfma": mfma, "clips_per_s": round(B / fb * 1e3, 1), "optimizer_ms": round(e[1].elapsed_time(e[2]), 2),
             "loss": round(float(loss), 4), "grad_allreduce_bytes": 4 * opt.numel,
@@ -627,6 +676,15 @@ def main():
             out["extra"]["deterministic statistics mode, launches_per_step"] = st_d.plan.n_launch + 1
             del st_d
             model.deterministic = False
+            out["extra"]["end_to_end"] = end_to_end_bench(model, st, B, T, device)
+            if args.dtype != "f32":
+                # the parity dtype (tests gate f32 at 1e-3 against the reference) timed on the same workload
+                m32 = UNetCFG1d(**cfg, init_seed=1234, compute_dtype="f32", device=device)
+                st32 = build_stepper(m32, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
+                n32 = max(10, args.steps // 2)
+                dt32 = timed_steps(st32, n32, max(3, args.warmup // 2), lambda: None)
+                out["extra"]["f32 mode (the dtype of the 1e-3 parity gate), steps/s"] = round(n32 / dt32, 2)
+                del st32, m32
             if not args.tiny:
                 out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
                 fwd_flops = sum(getattr(op, "flops", 0) for op in st.plan.ops)

@@ -13,6 +13,7 @@ not fit one pass).  Corrections applied here and recorded in the output:
 import collections
 import json
 import sqlite3
+import os
 import sys
 
 
@@ -89,7 +90,7 @@ def main():
             e["mfma_busy_cycles"] = int(busy)
             e["gui_active_cycles"] = int(act)
             e["mfma_busy_pct"] = round(100.0 * busy / (act * 256 * 4), 3) if act else None
-        e["source"] = "profiles/r02_pmc.txt"
+        e["source"] = "profiles/" + os.path.basename(out).replace(".json", ".txt")
         res["kernels"][f] = e
     json.dump(res, open(out, "w"), indent=1)
     for f, e in sorted(res["kernels"].items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0) * kv[1]["launches_per_step"]):
