@@ -732,6 +732,13 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     wap[i] = rbase + (size_t)((unsigned)rc * (unsigned)rld);
     wtile[i] = ok ? (rc + bl * lpx + Hb) * pitch + cr : dummy_tile;
   }
+  // vectors of this unit that exist for at least one lane (scalar): the branch-free slots beyond them are skipped altogether --
+  // at L_in <= 6 most units own one or two of the MAXV slots, and the normalisation (two transcendentals per element, two waves
+  // per SIMD) is what a unit spends its time on behind the wait: deep launch 891 -> 857 us together with V^T's own LDS region
+  int nvn = norm_C > 0 ? (L_in + ntstep - 1) >> (lS - lvpg) : 0;         // (ntstep = 2^(lS - lvpg), rpr = NT >> lvr)
+  nvn = nvn < MAXV ? nvn : MAXV;
+  int nvr = (rows_ok + rpr - 1) >> (__builtin_ctz(NT) - lvr);
+  nvr = nvr < MAXV ? nvr : MAXV;
   DK_STAMP(sy, 9);
   // ---- halo rows and the zero block: nobody else touches them, written before the wait ----------------------------------------
   {
@@ -823,7 +830,10 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 #ifndef JEN1_DEEP_EXP_NOSTAGE
   // ---- every load (sc1: another workgroup wrote the data in this launch), no branches; the wave repeats them until complete ---
   // (measured, not kept: two rounds of polled loads in flight half a round trip apart, to sample the producers' stores twice as
-  // often -- deep launch 889 -> 997 / 1005 / 1024 / 1067 us at gaps of 4 / 8 / 16 / 24 x 64 clocks)
+  // often -- deep launch 889 -> 997 / 1005 / 1024 / 1067 us at gaps of 4 / 8 / 16 / 24 x 64 clocks; a light pre-poll of ONE vector
+  // per lane ahead of the full round -- the polled volume is what an exchange costs, tools/microbench/flagchain.hip: 1.22 / 1.35 /
+  // 1.85 / 2.5 us per stage at 1 / 2 / 4 / 8 vectors per thread on 256 workgroups -- 857 -> 896 us: the serial extra round trip
+  // costs more than the lighter polls save)
   Raw8<GT> xn[MAXV], xw[MAXV];
   float rres[4] = {0.f, 0.f, 0.f, 0.f};
   {
@@ -832,15 +842,23 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     bool bad;
     do {
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) ld_live(xn[i], nap[i]);
+      for (int i = 0; i < MAXV; ++i) {
+        if (i < nvn) ld_live(xn[i], nap[i]);
+      }
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) ld_live(xw[i], wap[i]);
+      for (int i = 0; i < MAXV; ++i) {
+        if (i < nvr) ld_live(xw[i], wap[i]);
+      }
       if (use_res) ld_live4r(rr, resp);
       bad = false;
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) bad |= nlive && raw_bad(xn[i]);
+      for (int i = 0; i < MAXV; ++i) {
+        if (i < nvn) bad |= nlive && raw_bad(xn[i]);
+      }
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) bad |= rlive && raw_bad(xw[i]);
+      for (int i = 0; i < MAXV; ++i) {
+        if (i < nvr) bad |= rlive && raw_bad(xw[i]);
+      }
       if (use_res) bad |= reslive && raw_bad(rr);
     } while (poll_again(sy, bad, spins));
     if (use_res) raw4_to_float(rr, rres);
@@ -849,14 +867,16 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   // raw vectors: straight into the tile
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    if (rscale != 1.0f) {
-      float x[8];
-      raw_to_float(xw[i], x);
+    if (i < nvr) {
+      if (rscale != 1.0f) {
+        float x[8];
+        raw_to_float(xw[i], x);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] *= rscale;
-      float_to_raw(x, xw[i]);
+        for (int j = 0; j < 8; ++j) x[j] *= rscale;
+        float_to_raw(x, xw[i]);
+      }
+      stage_raw(tile + wtile[i], xw[i]);
     }
-    stage_raw(tile + wtile[i], xw[i]);
   }
   // further trips of a long raw input (e.g. the 94 rows a downsampling conv reads)
   for (int rbeg = MAXV * rpr; rbeg < rows_ok; rbeg += MAXV * rpr) {
@@ -897,6 +917,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
+      if (i >= nvn) continue;
       raw_to_float(xn[i], xf[i]);
       const float nm = ntile[i] != dummy_tile ? nscale : 0.f;           // scale of the source, 0 for vectors that do not exist
 #pragma unroll
@@ -948,6 +969,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     const bool silu = HI(pro_mode) == JEN1_PRO_GN_SILU;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
+      if (i >= nvn) continue;
 #pragma unroll
       for (int j = 0; j < 8; ++j) xf[i][j] = (xf[i][j] - mean) * rstd * p1[j] + p2[j];
       if (silu) {
@@ -1887,8 +1909,10 @@ extern "C" int jen1_deep_phase_attention(const void* q, const void* k, const voi
     return (int64_t)es * QCHUNK * dq + es * ((kv_elems + 15) & ~(int64_t)15) + 4 * (((int64_t)QCHUNK * sp + 3) & ~(int64_t)3) +
            es * (((int64_t)QCHUNK * vt + 7) & ~(int64_t)7) + 8 * st_rows + 64;
   };
-  // V^T gets LDS of its own when it fits half of the budget (the GEMM phases of the launch need theirs anyway)
-  const bool vsep = lds_of(true) <= LDS_BUDGET / 2;
+  // V^T gets LDS of its own whenever it fits: one 512-thread workgroup of 256-register waves owns the CU either way, so LDS is free,
+  // and a cross-attention then has K AND V^T staged before its dependency wait ends (restaging V^T in K's place behind the scores
+  // was 1.2 - 2.0 us of every cross-attention phase with d >= 64)
+  const bool vsep = lds_of(true) <= LDS_BUDGET;
   const int64_t lds = lds_of(vsep);
   JEN1_CHECK(lds <= LDS_BUDGET, "deep attention: Nk=%d d=%d needs %lld B of LDS", Nk, d, (long long)lds);
   jen1_deep_phase& p = *out;
