@@ -215,11 +215,11 @@ def deep_roofline(st, dtype):
     poisoning replayed alone.  Algorithmic bytes = every phase's weights once + its input and output activations once
     (DESIGN.md section 5); inputs are whatever the last step left in the plan's buffers (no data-dependent control flow)."""
     plan = st.plan
-    deep = [op for op in plan.ops if getattr(op, "kind", "") == "deep"]
+    prog = plan.deep
+    deep = [op for op in plan.ops if getattr(op, "kind", "") == "deep" and getattr(op, "prog", prog) is prog]
     if not deep:
         return None
     op = deep[0]
-    prog = plan.deep
 
     def zero(s):
         prog.poison(s)

@@ -20,6 +20,17 @@
  *                    recomputed by the consumer from the rows themselves;
  *   JEN1_DEEP_STATS  GroupNorm fine-group sums of the last tensor of the chain, for the
  *                    launch-per-layer kernels that consume it after the persistent launch.
+ *   JEN1_DEEP_TILE   the same convolution algebra for the LONG levels (T' = 1500 / 375 at
+ *                    T = 1500: ConvBlock1d blocks.py:137-145 over [x, skip], strided down
+ *                    convs, sub-pixel up convs, 1x1 shortcut as extra K segments): a unit is
+ *                    ALL output channels (or a block of 128 / 256 of them) x a tile of 16..64
+ *                    positions of one batch element, like jen1_conv_gemm's T* tiles.  A batch
+ *                    element is far too long to be re-read by every consumer, so GroupNorm
+ *                    statistics travel as per-tile partial sums: every producing unit writes
+ *                    (sum, sumsq) of its tile per statistics group, the consumer adds the
+ *                    partials of its batch element in a fixed order (bit-reproducible, no
+ *                    float atomics).  The partials start poisoned like every tensor of the
+ *                    launch, so reading them complete IS the wait for the whole batch element.
  *
  * A unit of a phase (16 output rows x the positions of a few batch elements; one
  * (batch element, head, 32-query chunk)) is done by one workgroup.  Results travel through
@@ -47,6 +58,7 @@ extern "C" {
 #define JEN1_DEEP_GEMM 0
 #define JEN1_DEEP_ATTN 1
 #define JEN1_DEEP_STATS 2
+#define JEN1_DEEP_TILE 3
 
 #define JEN1_DEEP_MAX_SRC 4
 #define JEN1_DEEP_MAX_SEG 12
@@ -123,6 +135,28 @@ typedef struct jen1_deep_hot {
   const float* wscale;        /* JEN1_FP8: [M] scale of the e4m3 weight rows (jen1_conv_args.w_scale), else NULL */
 } jen1_deep_hot;
 
+/* JEN1_DEEP_TILE: what a tile unit needs beyond the shared fields of jen1_deep_hot (w / bias / residual / y and its row mapping,
+ * p1 / p2 / p_ld / film_row / film_step, pro_mode, gn_*, B / L_in / L_out / stride, src[], Ctot, pitch, live_mask) */
+typedef struct jen1_deep_tile {
+  /* GroupNorm statistics of the two normalised sources: st_tiles = 0: totals [B][32][2] (sum, sumsq per fine group of
+   * ld / 32 channels: jen1_conv_args.gn_stats*, complete before the launch); st_tiles > 0: partials [B][st_tiles][st_nfg][2]
+   * written by a tile phase (bit k of st_live: by a phase of THIS launch, polled) */
+  const float* st[2];
+  float* out_part;            /* [B][tiles_t * mblocks][out_nfg][2] partial sums of this phase's output, or NULL */
+  int32_t st_tiles[2], st_nfg[2];
+  int32_t st_live;
+  int32_t cmain;              /* c0 + c1: the channels the taps run over (the extra segments follow at row shift 0) */
+  int32_t taps, pad_left;
+  int32_t tb, tiles_t;        /* positions per tile (multiple of 16 except the last tile's tail), tiles per batch element */
+  int32_t BM, mblocks, MF;    /* output rows per unit, units per tile, 16-row M tiles per wave (1 or 2) */
+  int32_t NF, KS, kch, rows_in;
+  int32_t out_nfg, out_cps;   /* statistics groups of the output and channels per group (multiple of 16) */
+  int32_t tab_off, red_off;   /* LDS byte offsets behind the staged tile: affine tables, reduction scratch */
+  float inv_tiles_t, inv_bt, inv_cpg, inv_out_cps;
+  float inv_cps[2];           /* 1 / channels per statistics group of source k */
+  int32_t pad_[2];
+} jen1_deep_tile;
+
 typedef struct jen1_deep_phase {
   jen1_deep_hot h;
   jen1_deep_seg seg[JEN1_DEEP_MAX_SEG];
@@ -144,6 +178,8 @@ typedef struct jen1_deep_phase {
   const void* sx;             /* [B][L][ld] */
   float* sstats;              /* [B][32][2] */
   int32_t sL, sld, scpf, sgran;
+  /* ---- tile ---- */
+  jen1_deep_tile tl;
 } jen1_deep_phase;
 
 /* sizeof(jen1_deep_phase), for host bindings that treat it as opaque bytes */
@@ -168,6 +204,18 @@ int jen1_deep_phase_attention(const void* q, const void* k, const void* v, void*
                               int finish_kv, int kv_live /* bit 0: k / v, bit 1: q produced inside this launch */, int dtype, jen1_deep_phase* out);
 
 int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, int ld, int dtype, jen1_deep_phase* out);
+
+/* One layer of a long level as a tile phase.  Reads from `a` what jen1_deep_phase_conv reads (sources, taps / stride / pad_left,
+ * seg[0..nseg) as raw extra K segments at row shift 0, packed weight, bias, residual, y and its row mapping incl. the sub-pixel
+ * form, pro_mode NONE / GN / GN_SILU with gn_* and the FUSED GroupNorm-FiLM table, live_mask, dtype JEN1_F32 / JEN1_BF16).
+ * tb: positions per tile (16, 32, 48 or 64); bm: output rows per unit (128 or 256; M is cut into M / bm blocks).
+ * st0 / st1 with their tile counts and group counts: the statistics of x0 / x1 as described at jen1_deep_tile (st_live: bit k = the
+ * partials of source k are written inside this launch).  out_part (or NULL) receives this phase's own partials with out_nfg groups
+ * per tile ([B][jen1_deep_tile_count][out_nfg][2] floats; out_C / out_nfg must be a multiple of 16). */
+int jen1_deep_phase_tile(const jen1_conv_args* a, int tb, int bm, const float* st0, int st0_tiles, int st0_nfg, const float* st1,
+                         int st1_tiles, int st1_nfg, int st_live, float* out_part, int out_nfg, jen1_deep_phase* out);
+/* tile entries per batch element of the partial array a phase built with (L_out, tb, M, bm) writes: ceil(L_out / tb) * (M / bm) */
+int jen1_deep_tile_count(int L_out, int tb, int M, int bm);
 
 /* chain the phases (dep = previous phase, rotation of the unit -> workgroup map) and build the device image:
  * blobs   n_phases * jen1_deep_blob_bytes() bytes (HOST memory): per phase the descriptor followed by the per-wave lists of the
@@ -208,6 +256,11 @@ int jen1_deep_error_word(int n_phases);
  * error word instead of hanging. */
 int jen1_deep_run_mode(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes,
                        int dtype, int tickets, void* stream);
+/* the same for a program of the given unit kinds (kind_mask: bit k = the program holds phases of kind JEN1_DEEP_<k>).  Two kernels
+ * exist: GEMM + attention + statistics phases (what jen1_deep_run_mode launches) and tile + statistics phases; a caller records the
+ * long levels and the deep levels as separate programs (one launch each, back to back on the stream). */
+int jen1_deep_run_kinds(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes,
+                        int dtype, int tickets, int kind_mask, void* stream);
 
 #ifdef __cplusplus
 }

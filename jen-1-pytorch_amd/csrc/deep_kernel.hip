@@ -20,6 +20,7 @@
 // atomic; consumers poll relaxed, then read with sc1 (L1-bypassing) loads.  Every spin is bounded: a time-out
 // raises the error word and releases every other waiter.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "jen1_deep.h"
 
@@ -1598,12 +1599,540 @@ __device__ __forceinline__ void stats_unit(const unsigned char* D, int u, Sync& 
   DK_STAMP(sy, 6);
 }
 
-template <typename T, bool TK>      // TK: units by ticket (any number of resident workgroups) instead of the static unit -> workgroup map
+// =====================================================================================================================
+// tile unit (JEN1_DEEP_TILE): a layer of a LONG level (include/jen1_deep.h).  All output channels of a block x a tile of tb positions
+// of one batch element.  Same algebra and LDS structure as tile_gemm.hip (the activation tile + conv halo is staged once, taps are
+// row-shifted views, weights come through a register ring with scalar offsets), but inside the persistent launch:
+//   * the 8 waves form a (BM / 32) x (8 / (BM / 32)) grid: a wave owns 32 output rows (two M tiles) and half (BM = 128) or all
+//     (BM = 256) of the tile's 16-position fragments -- an activation fragment read from LDS feeds two matrix instructions and is
+//     read by 4 waves, not 8 (the loop is LDS-bandwidth bound: with one M tile per wave it took 2.4 us per 48 positions);
+//   * the weight ring (24 fragments per wave: all of K at 128 channels x 3 taps) and gamma / beta / FiLM are requested before the
+//     dependency wait; deeper K streams through the same ring from L2;
+//   * GroupNorm statistics arrive as the producers' per-tile partial sums (8-byte (sum, sumsq) words, poisoned like every tensor of
+//     the launch): a thread adds the partials of ONE statistics group over the tiles in ascending order, the lanes / waves holding the
+//     same group are merged by a fixed shuffle tree and a fixed LDS pass -- bit-reproducible;
+//   * the unit's own output partials leave as one 8-byte word per statistics group, written last.
+// T: element type of activations, weights and the staged tile (bf16 or float; the JEN1_FP8 mode runs these units in bf16).
+// =====================================================================================================================
+#define TI(f) ph_i32<offsetof(jen1_deep_phase, f)>(pr)
+#define TF(f) ph_f32<offsetof(jen1_deep_phase, f)>(pr)
+#define TP(f, type) ph_ptr<offsetof(jen1_deep_phase, f), type>(pr)
+#ifndef JEN1_TILE_RING_B
+#define JEN1_TILE_RING_B 24
+#endif
+#ifndef JEN1_TILE_RING_F
+#define JEN1_TILE_RING_F 8
+#endif
+template <typename T> struct TileCfg {             // bf16: 24 weight fragments of 4 registers (12 k-steps x 2 M tiles), 4 staging vectors of 4 registers
+  static constexpr int RING = JEN1_TILE_RING_B, VB = 4;
+};
+template <> struct TileCfg<float> {                // float32: fragments and vectors are twice as wide
+  static constexpr int RING = JEN1_TILE_RING_F, VB = 2;
+};
+constexpr int TILE_SP = 4;             // statistics partials (8 bytes each) per thread, source and polled round
+constexpr int TILE_MF = 2;             // 16-row M tiles per wave
+
+template <typename T, typename FPub>
+__device__ __forceinline__ void tile_unit(const unsigned char* D, int u, Sync& sy, typename DFrag<T>::type (&ring)[TileCfg<T>::RING], FPub publish_next,
+                                          int tid) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef typename DFrag<T>::type Frag;
+  constexpr bool PRECISE = is_f32<T>::value;
+  constexpr unsigned ES = sizeof(T);
+  constexpr unsigned BLK = 512 * ES;
+  constexpr int MF = TILE_MF;
+  constexpr int TILE_VB = TileCfg<T>::VB;             // staging vectors per thread per polled batch
+  constexpr int PFT = TileCfg<T>::RING / MF;          // k-steps in the ring
+  const int lane = tid & 63;
+  const int wv = rfl(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  DK_STAMP(sy, 0);
+  const PhaseRegs pr = phase_regs(D, lane);
+  // ---- unit -> (M block, batch element, tile) ------------------------------------------------------------------------------------
+  const int B = TI(h.B), tiles_t = TI(tl.tiles_t), tb = TI(tl.tb);
+  const int bt = B * tiles_t;
+  const int mblk = (int)(((float)u + 0.5f) * TF(tl.inv_bt));
+  const int rem = u - mblk * bt;
+  const int b = (int)(((float)rem + 0.5f) * TF(tl.inv_tiles_t));
+  const int tt = rem - b * tiles_t;
+  const int L_in = TI(h.L_in), L_out = TI(h.L_out), stride = TI(h.stride), taps = TI(tl.taps), pad_left = TI(tl.pad_left);
+  const int t0 = tt * tb;
+  const int cmain = TI(tl.cmain), call = TI(h.Ctot), ldsld = TI(h.pitch), kch = TI(tl.kch), KS = TI(tl.KS), NF = TI(tl.NF);
+  const int rows_in = TI(tl.rows_in);
+  const int tin0 = t0 * stride - pad_left;
+  const int MT = TI(h.MT), mtb = TI(tl.BM) >> 4;
+  // wave grid: WM = BM / 32 waves along M, WN = 8 / WM along the positions
+  const int WM = mtb >> 1;
+  const int wm = wv & (WM - 1), wn = WM == NW ? 0 : (wv >> 2);
+  const int NFh = WM == NW ? NF : ((NF + 1) >> 1);    // fragments of the first wave column
+  const int nf0 = wn * NFh;                           // this wave's first fragment and how many it owns
+  const int nfw = (NF - nf0) < NFh ? (NF - nf0) : NFh;
+  const int mt0 = mblk * mtb + wm * MF;               // this wave's first 16-row tile of M
+  unsigned char* ws = smem + WS_OFF;
+  T* tile = reinterpret_cast<T*>(ws);
+  float* tabA = reinterpret_cast<float*>(ws + TI(tl.tab_off));
+  float* tabS = tabA + cmain;
+  float* red = reinterpret_cast<float*>(ws + TI(tl.red_off));     // [2 sources][NW][32][2] partial merge, later [NW * MF][4] output partials
+
+  // ---- (1) weight ring (filled behind the first polled round, below) ----------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(TP(h.w, const void*)), 0, TI(h.w_bytes), RSRC_FLAGS);
+  unsigned voffA[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) voffA[mf] = (nfw > 0 && mt0 + mf < MT) ? (unsigned)(mt0 + mf) * BLK + (unsigned)lane * (8u * ES) : OOB;
+  const unsigned stepA = (unsigned)MT * BLK;
+  unsigned soffA = 0;
+  int issuedA = 0;
+  auto issueA = [&](int slot) __attribute__((always_inline)) {
+    const bool in = issuedA < KS;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) wload(ring[slot * MF + mf], rw, in ? voffA[mf] : OOB, in ? soffA : 0u);
+    soffA += stepA;
+    ++issuedA;
+  };
+  const int pro_mode = TI(h.pro_mode);
+  const bool gn = pro_mode == JEN1_PRO_GN || pro_mode == JEN1_PRO_GN_SILU;
+  const bool do_silu = pro_mode == JEN1_PRO_GN_SILU;
+  // ---- (3) addresses of the staging vectors --------------------------------------------------------------------------------------------
+  typedef T GT;
+  const int vpr = call >> 3;
+  const float inv_vpr = TF(h.inv_vpr);
+  const int nvec = rows_in * vpr;
+  const int live = TI(h.live_mask);
+  const int nsrc = TI(h.nsrc);
+  const void* sx1 = TP(h.src[1].x, const void*); const int sld1 = TI(h.src[1].ld), sco1 = TI(h.src[1].coff);
+  const void* sx2 = TP(h.src[2].x, const void*); const int sld2 = TI(h.src[2].ld), sco2 = TI(h.src[2].coff);
+  const void* sx3 = TP(h.src[3].x, const void*); const int sld3 = TI(h.src[3].ld), sco3 = TI(h.src[3].coff);
+  const void* sx0 = TP(h.src[0].x, const void*); const int sld0 = TI(h.src[0].ld);
+  const float sc1 = TF(h.src[1].scale);
+  const bool two_main = nsrc > 1 && sco1 < cmain;      // the second source is normalised / tapped like the first (the skip)
+  // vector v of the tile: row v / vpr, 8 channels from (v % vpr) * 8: global address; LDS element offset, or -1 - offset for a row
+  // of the zero padding; whether the tensor is written inside this launch
+  auto vec_of = [&](int v, const GT*& gp, bool& lv, int& c) __attribute__((always_inline)) -> int {
+    const int vv = v < nvec ? v : 0;
+    const int row = (int)(((float)vv + 0.5f) * inv_vpr);
+    c = (vv - row * vpr) * 8;
+    const int tin = tin0 + row;
+    const bool ok = tin >= 0 && tin < L_in;
+    const void* xp = sx0;
+    int ld = sld0, coff = 0, k = 0;
+    if (nsrc > 1 && c >= sco1) { xp = sx1; ld = sld1; coff = sco1; k = 1; }
+    if (nsrc > 2 && c >= sco2) { xp = sx2; ld = sld2; coff = sco2; k = 2; }
+    if (nsrc > 3 && c >= sco3) { xp = sx3; ld = sld3; coff = sco3; k = 3; }
+    lv = ok && v < nvec && ((live >> k) & 1);
+    gp = reinterpret_cast<const GT*>(xp) + ((unsigned)(b * L_in + (ok ? tin : 0)) * (unsigned)ld + (unsigned)(c - coff));
+    const int to = row * ldsld + c;
+    return ok ? to : -1 - to;
+  };
+  struct Batch {
+    Raw8<GT> x[TILE_VB];
+    const GT* gp[TILE_VB];
+    int to[TILE_VB], c[TILE_VB];
+    bool lv[TILE_VB];
+  };
+  auto prep_batch = [&](Batch& bt_, int v0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < TILE_VB; ++k) {
+      if (v0 + k * NT < nvec) bt_.to[k] = vec_of(v0 + k * NT + tid, bt_.gp[k], bt_.lv[k], bt_.c[k]);
+    }
+  };
+  auto load_batch = [&](Batch& bt_, int v0) __attribute__((always_inline)) -> bool {      // one round of loads; true = a sentinel was seen
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < TILE_VB; ++k) {
+      if (v0 + k * NT < nvec) {
+        ld_live(bt_.x[k], bt_.gp[k]);
+        bad |= bt_.lv[k] && raw_bad(bt_.x[k]);
+      }
+    }
+    return bad;
+  };
+  Batch cur;
+  prep_batch(cur, 0);
+
+  // ---- (4) statistics partials of the batch element + the first staging batch: one polled round ------------------------------------------
+  const int st_live = TI(tl.st_live);
+  const int nt0 = TI(tl.st_tiles[0]), nt1 = TI(tl.st_tiles[1]);
+  const int nfg0 = TI(tl.st_nfg[0]), nfg1 = TI(tl.st_nfg[1]);
+  const int np0 = gn ? (nt0 ? nt0 : 1) * nfg0 : 0;                            // 8-byte pairs of source 0 / 1 for this batch element
+  const int np1 = (gn && two_main) ? (nt1 ? nt1 : 1) * nfg1 : 0;
+  const gu64* q0 = g64(TP(tl.st[0], const float*)) + (size_t)b * (nt0 ? np0 : 32);
+  const gu64* q1 = np1 ? g64(TP(tl.st[1], const float*)) + (size_t)b * (nt1 ? np1 : 32) : q0;
+  float s0 = 0.f, qq0 = 0.f, s1 = 0.f, qq1 = 0.f;                             // this thread's share of its statistics group
+  DK_STAMP(sy, 1);
+  float g1 = 0.f, g2 = 0.f;                            // p1 / p2 of channel tid (cmain <= NT is checked on the host)
+  f32x4 bias4[MF];
+  {
+    u64 w0[TILE_SP], w1[TILE_SP];
+    // the first polled round is issued BEFORE everything that no other workgroup writes (weight ring, gamma / beta / FiLM, bias): those
+    // requests ride behind it instead of delaying it, and their latency hides behind the wait
+    auto issue_poll = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < TILE_SP; ++k) {
+        const int i = tid + k * NT;
+        if (k * NT < np0) w0[k] = i < np0 ? __hip_atomic_load(q0 + i, RLX_AGENT) : 0ull;
+        if (k * NT < np1) w1[k] = i < np1 ? __hip_atomic_load(q1 + i, RLX_AGENT) : 0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < TILE_VB; ++k) {
+        if (k * NT < nvec) ld_live(cur.x[k], cur.gp[k]);
+      }
+    };
+    auto check_poll = [&]() __attribute__((always_inline)) -> bool {
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < TILE_SP; ++k) {
+        if (k * NT < np0) bad |= (st_live & 1) && w0[k] == POISON;
+        if (k * NT < np1) bad |= (st_live & 2) && w1[k] == POISON;
+      }
+#pragma unroll
+      for (int k = 0; k < TILE_VB; ++k) {
+        if (k * NT < nvec) bad |= cur.lv[k] && raw_bad(cur.x[k]);
+      }
+      return bad;
+    };
+    issue_poll();
+    // ---- weight ring: the first PFT k-steps of this wave's M tiles; gamma / beta or the fused GroupNorm-FiLM row; bias ----------------------
+#pragma unroll
+    for (int s_ = 0; s_ < PFT; ++s_) issueA(s_);
+    if (gn && tid < cmain) {
+      const int p_ld = TI(h.p_ld);
+      const int* fstep = TP(h.film_step, const int*);
+      const int* frow = TP(h.film_row, const int*);
+      const int fr = p_ld ? (fstep ? fstep[0] : (frow ? frow[b] : b)) : 0;
+      const size_t po = (size_t)((unsigned)fr * (unsigned)p_ld) + (unsigned)tid;
+      g1 = TP(h.p1, const float*)[po];
+      g2 = TP(h.p2, const float*)[po];
+    }
+    {
+      const float* biasp = TP(h.bias, const float*);
+      const int out_C0 = TI(h.out_C), ps_f0 = TI(h.ps_f);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int m = (mt0 + mf) * 16 + lg * 4;
+        int ph = 0;
+        for (int k = 1; k < ps_f0; ++k) ph += (m >= k * out_C0) ? 1 : 0;
+        bias4[mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (biasp && nfw > 0 && mt0 + mf < MT) bias4[mf] = *reinterpret_cast<const f32x4*>(biasp + (m - ph * out_C0));
+      }
+    }
+    DK_STAMP(sy, 7);
+    unsigned spins = 0;
+    bool bad = check_poll();
+    while (poll_again(sy, bad, spins)) {
+      issue_poll();
+      bad = check_poll();
+    }
+#pragma unroll
+    for (int k = 0; k < TILE_SP; ++k) {
+      if (k * NT < np0) { s0 += __uint_as_float((unsigned)w0[k]); qq0 += __uint_as_float((unsigned)(w0[k] >> 32)); }
+      if (k * NT < np1) { s1 += __uint_as_float((unsigned)w1[k]); qq1 += __uint_as_float((unsigned)(w1[k] >> 32)); }
+    }
+    // batch elements with more than TILE_SP * NT partials per source (very long inputs): further rounds
+    for (int i0 = TILE_SP * NT; i0 < np0 || i0 < np1; i0 += NT) {
+      u64 a0 = 0, a1 = 0;
+      unsigned sp2 = 0;
+      do {
+        bad = false;
+        const int i = i0 + tid;
+        if (i0 < np0) { a0 = i < np0 ? __hip_atomic_load(q0 + i, RLX_AGENT) : 0ull; bad |= (st_live & 1) && a0 == POISON; }
+        if (i0 < np1) { a1 = i < np1 ? __hip_atomic_load(q1 + i, RLX_AGENT) : 0ull; bad |= (st_live & 2) && a1 == POISON; }
+      } while (poll_again(sy, bad, sp2));
+      s0 += __uint_as_float((unsigned)a0); qq0 += __uint_as_float((unsigned)(a0 >> 32));
+      s1 += __uint_as_float((unsigned)a1); qq1 += __uint_as_float((unsigned)(a1 >> 32));
+    }
+  }
+  DK_STAMP(sy, 2);
+  // ---- (5) group sums -> affine tables  y = silu?(A[c] x + S[c])  (blocks.py:137-145) ---------------------------------------------------
+  if (gn) {
+    // threads t, t + nfg, ... hold the same statistics group (NT is a multiple of nfg): merge inside the wave (fixed tree), the
+    // waves' sums meet in LDS and every channel adds them in wave order
+    auto wave_merge = [&](float v, int nfg) __attribute__((always_inline)) -> float {
+      v += __shfl_xor(v, 32);                       // (nfg is 8, 16 or 32: lanes l, l + nfg, ... of a wave hold group l mod nfg)
+      if (nfg <= 16) v += __shfl_xor(v, 16);
+      if (nfg <= 8) v += __shfl_xor(v, 8);
+      return v;
+    };
+    s0 = wave_merge(s0, nfg0); qq0 = wave_merge(qq0, nfg0);
+    if (lane < nfg0) *reinterpret_cast<float2*>(red + (wv * 32 + lane) * 2) = make_float2(s0, qq0);
+    if (np1) {
+      s1 = wave_merge(s1, nfg1); qq1 = wave_merge(qq1, nfg1);
+      if (lane < nfg1) *reinterpret_cast<float2*>(red + NW * 64 + (wv * 32 + lane) * 2) = make_float2(s1, qq1);
+    }
+    __syncthreads();
+    if (tid < cmain) {
+      const int c = tid;
+      const int cpg = TI(h.gn_cpg), groups = TI(h.gn_groups);
+      const int gch = (int)(((float)c + 0.5f) * TF(tl.inv_cpg));
+      const int g = gch < groups ? gch : groups - 1;
+      const int lo0 = g * cpg;
+      const bool k1 = np1 > 0 && lo0 >= sco1;                                  // the group lies in the second source
+      const int lo = lo0 - (k1 ? sco1 : 0);
+      const float icps = k1 ? TF(tl.inv_cps[1]) : TF(tl.inv_cps[0]);
+      const int nfg = k1 ? nfg1 : nfg0;
+      const int f0 = (int)(((float)lo + 0.5f) * icps);
+      int cnt = (int)(((float)cpg + 0.5f) * icps);
+      cnt = cnt < 1 ? 1 : cnt;
+      const float* rk = red + (k1 ? NW * 64 : 0);
+      float s = 0.f, q = 0.f;
+      for (int f = f0; f < f0 + cnt && f < nfg; ++f) {
+        float fs = 0.f, fq = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) {
+          const float2 e2 = *reinterpret_cast<const float2*>(rk + (w2 * 32 + f) * 2);
+          fs += e2.x; fq += e2.y;
+        }
+        s += fs; q += fq;
+      }
+      const float sc = k1 ? sc1 : 1.0f;
+      s *= sc;
+      q *= sc * sc;
+      const float inv_count = TF(h.inv_count);
+      const float mean = s * inv_count;
+      float var = q * inv_count - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      const float rstd = PRECISE ? 1.0f / sqrtf(var + TF(h.gn_eps)) : rsqrtf(var + TF(h.gn_eps));
+      const float A = rstd * g1;
+      tabA[c] = A * sc;
+      tabS[c] = g2 - mean * A;
+    }
+    __syncthreads();
+  }
+  DK_STAMP(sy, 8);
+  // ---- (6) stage the tile: prologue applied once, zero padding applied after it (most layers are ONE batch of vectors: it came with
+  // the statistics; longer tiles poll their further batches one after the other) ------------------------------------------------------
+  for (int v0 = 0; v0 < nvec; v0 += NT * TILE_VB) {
+    if (v0 > 0) {
+      prep_batch(cur, v0);
+      unsigned spins = 0;
+      bool bad;
+      do {
+        bad = load_batch(cur, v0);
+      } while (poll_again(sy, bad, spins));
+    }
+#pragma unroll
+    for (int k = 0; k < TILE_VB; ++k) {
+      const int v = v0 + k * NT + tid;
+      if (v0 + k * NT >= nvec) continue;
+      if (v >= nvec) continue;
+      const int c = cur.c[k];
+      float x[8];
+      raw_to_float(cur.x[k], x);
+      int to = cur.to[k];
+      if (to >= 0) {
+        if (c < cmain) {
+          if (gn) {
+            const float4 a0 = *reinterpret_cast<const float4*>(tabA + c), a1 = *reinterpret_cast<const float4*>(tabA + c + 4);
+            const float4 e0 = *reinterpret_cast<const float4*>(tabS + c), e1 = *reinterpret_cast<const float4*>(tabS + c + 4);
+            x[0] = x[0] * a0.x + e0.x; x[1] = x[1] * a0.y + e0.y; x[2] = x[2] * a0.z + e0.z; x[3] = x[3] * a0.w + e0.w;
+            x[4] = x[4] * a1.x + e1.x; x[5] = x[5] * a1.y + e1.y; x[6] = x[6] * a1.z + e1.z; x[7] = x[7] * a1.w + e1.w;
+            if (do_silu) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
+            }
+          } else if (two_main && c >= sco1 && sc1 != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] *= sc1;
+          }
+        }
+      } else {
+        to = -1 - to;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = 0.f;
+      }
+      store8(tile + to, x);
+    }
+  }
+  DK_STAMP(sy, 11);
+  // ---- (7) .. (9): MFMA loop and epilogue, specialised by the number of fragments this wave owns ---------------------------------------------
+  const int out_C = TI(h.out_C), ps_f = TI(h.ps_f), ps_off = TI(h.ps_off), L_y = TI(h.L_y), y_brows = TI(h.y_brows), y_row0 = TI(h.y_row0);
+  const GT* resb = TP(h.residual, const GT*);
+  const bool reslive = resb && ((live >> 8) & 1);
+  const int ld_res = TI(h.ld_res);
+  float* const out_part = TP(tl.out_part, float*);
+  auto body = [&](auto nfc) __attribute__((always_inline)) {
+    constexpr int NFW = decltype(nfc)::value;
+    int ldsrow[NFW];
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) {
+      const int n = (nf0 + nf) * 16 + li;
+      ldsrow[nf] = ((n < tb ? n : 0) * stride) * ldsld + lg * 8;
+    }
+    __syncthreads();
+    DK_STAMP(sy, 3);
+    // MFMA loop: weights from the ring, activations from row-shifted views of the LDS tile; k-steps in (tap, chunk) order, behind the
+    // last tap the extra chunks follow at the centre row, columns cmain + 32 j
+    f32x4 acc[MF][NFW];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) acc[mf][nf] = bias4[mf];                 // the accumulators start from the bias
+    {
+      int c_tap = 0, c_kc = 0;
+      bool in_extra = false;
+      const bool xs = call > cmain;
+      auto kstep = [&](int slot) __attribute__((always_inline)) {
+        const T* bp = tile + c_tap * ldsld + c_kc * 32;
+        Frag bfr[NFW];
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) dlds(bfr[nf], bp + ldsrow[nf]);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NFW; ++nf) dmma(acc[mf][nf], ring[slot * MF + mf], bfr[nf]);
+        if (++c_kc == kch && !in_extra) {
+          c_kc = 0;
+          if (++c_tap == taps && xs) { in_extra = true; c_tap = pad_left; c_kc = kch; }
+        }
+#ifndef JEN1_TILE_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler hoists the LDS reads of the whole round: ~190 registers beside the ring)
+#endif
+      };
+      int ks = 0;
+      for (; ks + PFT <= KS; ks += PFT) {               // whole rounds of the ring, straight-line
+        const bool refill = ks + PFT < KS;
+#pragma unroll
+        for (int s_ = 0; s_ < PFT; ++s_) {
+          kstep(s_);
+          if (refill) issueA(s_);
+        }
+      }
+      if (ks < KS) {                                      // the tail round
+#pragma unroll
+        for (int s_ = 0; s_ < PFT; ++s_) {
+          if (ks + s_ < KS) kstep(s_);
+        }
+      }
+    }
+    DK_STAMP(sy, 4);
+    // epilogue: bias, residual, sub-pixel row mapping, write-through stores, partial sums of the next GroupNorm
+    // output rows of this lane (-1: none), the residual (nothing of the epilogue lives across the loop: registers); offsets stay 32-bit (the host checks
+    // the tensor sizes) so that an address is a scalar base + one register
+    int co_[MF];
+    int yrow_[MF][NFW];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int m = (mt0 + mf) * 16 + lg * 4;
+      int ph = 0;
+      for (int k = 1; k < ps_f; ++k) ph += (m >= k * out_C) ? 1 : 0;
+      co_[mf] = m - ph * out_C;
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) {
+        const int n = (nf0 + nf) * 16 + li;
+        const int q = t0 + n;
+        const int ty = q * ps_f + ph - ps_off;
+        const bool ok = mt0 + mf < MT && n < tb && q < L_out && ty >= 0 && ty < L_y;
+        yrow_[mf][nf] = ok ? b * y_brows + y_row0 + ty : -1;
+      }
+    }
+    Raw4<GT> rr[MF][NFW];
+    auto load_res = [&]() __attribute__((always_inline)) -> bool {
+      bool bad = false;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) {
+          if (yrow_[mf][nf] >= 0) {
+            const unsigned off = (unsigned)yrow_[mf][nf] * (unsigned)ld_res + (unsigned)co_[mf];
+            ld_live4r(rr[mf][nf], resb + off);
+            bad |= reslive && raw_bad(rr[mf][nf]);
+          }
+        }
+      return bad;
+    };
+    bool rbad = false;
+    if (resb) rbad = load_res();
+    if (resb) {
+      unsigned spins = 0;
+      while (poll_again(sy, rbad, spins)) rbad = load_res();
+    }
+    DK_STAMP(sy, 9);
+    const int ld_y = TI(h.ld_y), y_f32 = TI(h.y_f32);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      float gs = 0.f, gq = 0.f;
+      {
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) {
+          if (yrow_[mf][nf] >= 0) {
+            float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
+            if (resb) {
+              float r4[4];
+              raw4_to_float(rr[mf][nf], r4);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += r4[r];
+            }
+            const unsigned off = (unsigned)yrow_[mf][nf] * (unsigned)ld_y + (unsigned)co_[mf];
+            if (y_f32) st_live4(TP(h.y, float*) + off, v);
+            else st_live4(TP(h.y, GT*) + off, v);
+            gs += (v[0] + v[1]) + (v[2] + v[3]);
+            gq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          }
+        }
+      }
+      if (mf == MF - 1) DK_STAMP(sy, 10);
+      if (out_part) {
+        // the 16 rows of an M tile lie in ONE statistics group (out_cps is a multiple of 16): all 64 lanes, fixed tree
+        gs = row16_sum_d(gs); gq = row16_sum_d(gq);
+        auto rl = [](float v, int l) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+        const float ts = (rl(gs, 0) + rl(gs, 16)) + (rl(gs, 32) + rl(gs, 48));       // the four rows of the wave, fixed order, no LDS round trips
+        const float tq = (rl(gq, 0) + rl(gq, 16)) + (rl(gq, 32) + rl(gq, 48));
+        const float fgo = mt0 + mf < MT ? (float)(int)(((float)__builtin_amdgcn_readlane(co_[mf], 0) + 0.5f) * TF(tl.inv_out_cps)) : -1.0f;
+        if (lane == 0) *reinterpret_cast<float4*>(red + (wv * MF + mf) * 4) = make_float4(ts, tq, fgo, 0.f);
+      }
+    }
+  };
+  if (nfw <= 0) {                                         // (a wave column without fragments: the tile's tail)
+    __syncthreads();
+    if (out_part && lane == 0) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) red[(wv * MF + mf) * 4 + 2] = -1.0f;
+    }
+  } else if (nfw == 1) body(std::integral_constant<int, 1>());
+#ifdef JEN1_TILE_NFW4
+  else if (nfw == 2) body(std::integral_constant<int, 2>());
+  else if (nfw == 3) body(std::integral_constant<int, 3>());
+  else body(std::integral_constant<int, 4>());
+#else
+  else body(std::integral_constant<int, 2>());       // (the host keeps a wave at two fragments: tb <= 64 at BM = 128, tb <= 32 at BM = 256)
+#endif
+  DK_STAMP(sy, 12);
+  publish_next();
+  __syncthreads();
+  DK_STAMP(sy, 13);
+  if (out_part) {
+    const int onfg = TI(tl.out_nfg), mblocks = TI(tl.mblocks);
+    if (tid < onfg) {
+      float s = 0.f, q = 0.f;
+      float4 e4[NW * MF];
+#pragma unroll
+      for (int e = 0; e < NW * MF; ++e) e4[e] = *reinterpret_cast<const float4*>(red + e * 4);      // (all reads first: no dependent LDS chain)
+#pragma unroll
+      for (int e = 0; e < NW * MF; ++e) {
+        const bool mine = e4[e].z == (float)tid;
+        s += mine ? e4[e].x : 0.f;
+        q += mine ? e4[e].y : 0.f;
+      }
+      const size_t idx = ((size_t)b * (size_t)(tiles_t * mblocks) + (size_t)(tt * mblocks + mblk)) * (size_t)onfg + (size_t)tid;
+      __hip_atomic_store(g64(out_part) + idx, ((u64)__float_as_uint(q) << 32) | __float_as_uint(s), RLX_AGENT);
+    }
+  }
+  DK_STAMP(sy, 14);
+  DK_STAMP(sy, 15);
+  __syncthreads();            // (LDS: the next unit stages over this one's tile and scratch)
+  DK_STAMP(sy, 5);
+  DK_STAMP(sy, 6);
+}
+
+// KM: the unit kinds compiled into this instance (bit k: kind k).  A program of tile phases and a program of GEMM / attention phases
+// are different kernels: each keeps its own register allocation (one kernel with every unit kind spills in the GEMM unit).
+constexpr int KM_DEEP = (1 << JEN1_DEEP_GEMM) | (1 << JEN1_DEEP_ATTN) | (1 << JEN1_DEEP_STATS);
+constexpr int KM_TILE = (1 << JEN1_DEEP_TILE) | (1 << JEN1_DEEP_STATS);
+template <typename T, bool TK, int KM>      // TK: units by ticket (any number of resident workgroups) instead of the static unit -> workgroup map
 __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restrict__ blobs, const int4* __restrict__ hdr_g, int n_phases,
                                                   unsigned* sync, unsigned* err) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef typename DFrag<T>::type Frag;
-  constexpr int PF = DeepCfg<T>::PF;
+  constexpr int PF = KM == KM_TILE ? TileCfg<T>::RING : DeepCfg<T>::PF;      // the weight ring of the kernel's units
   const int tid = threadIdx.x;
   const int lane = tid & 63, wk = rfl(tid >> 6);
   const int wg = blockIdx.x, nwg = gridDim.x;
@@ -1629,7 +2158,9 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
   reinterpret_cast<u64*>(smem + HDR_BYTES)[tid] = reinterpret_cast<const u64*>(blobs + (size_t)p * BLOB)[tid];
   __syncthreads();
   Frag ra[PF];
-  if (hdr[p].kind == JEN1_DEEP_GEMM) gemm_prefill<T>(smem + HDR_BYTES, u, wk, lane, ra);
+  if constexpr ((KM >> JEN1_DEEP_GEMM) & 1) {
+    if (hdr[p].kind == JEN1_DEEP_GEMM) gemm_prefill<T>(smem + HDR_BYTES, u, wk, lane, ra);
+  }
   for (;;) {
     int p2 = p, u2 = u;
     const bool more = find_next(hdr, n_phases, wg, nwg, p2, u2);
@@ -1644,14 +2175,22 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
     auto publish_next = [&]() { if (reload) reinterpret_cast<u64*>(Dn)[tid] = nx; };
     sy.p = p;
     const int kind = hdr[p].kind;
-    if (kind == JEN1_DEEP_GEMM) gemm_unit<T>(D, u, sy, ra, publish_next, tid);
-    else if (kind == JEN1_DEEP_ATTN) attn_unit<T>(D, u, sy, publish_next, tid);
-    else stats_unit<T>(D, u, sy, publish_next, tid);
+    if (((KM >> JEN1_DEEP_GEMM) & 1) && kind == JEN1_DEEP_GEMM) {
+      if constexpr ((KM >> JEN1_DEEP_GEMM) & 1) gemm_unit<T>(D, u, sy, ra, publish_next, tid);
+    } else if (((KM >> JEN1_DEEP_ATTN) & 1) && kind == JEN1_DEEP_ATTN) {
+      if constexpr ((KM >> JEN1_DEEP_ATTN) & 1) attn_unit<T>(D, u, sy, publish_next, tid);
+    } else if (((KM >> JEN1_DEEP_TILE) & 1) && kind == JEN1_DEEP_TILE) {
+      if constexpr (KM == KM_TILE) tile_unit<T>(D, u, sy, ra, publish_next, tid);
+    } else {
+      stats_unit<T>(D, u, sy, publish_next, tid);
+    }
     DK_FLUSH(sy);
     if (!more) break;
     // the next unit's weight ring: requested right behind this unit's arrival, long before its dependency wait ends
 #ifndef JEN1_DEEP_EXP_NOPRE
-    if (hdr[p2].kind == JEN1_DEEP_GEMM) gemm_prefill<T>(Dn, u2, wk, lane, ra);
+    if constexpr ((KM >> JEN1_DEEP_GEMM) & 1) {
+      if (hdr[p2].kind == JEN1_DEEP_GEMM) gemm_prefill<T>(Dn, u2, wk, lane, ra);
+    }
 #endif
     p = p2;
     u = u2;
@@ -1682,7 +2221,9 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
     // the unit's weight ring: requested as soon as the unit is known, long before its dependency wait ends (a workgroup that is
     // free takes the smallest open ticket, typically a phase or two ahead of the ones being computed)
 #ifndef JEN1_DEEP_EXP_NOPRE
-    if (kind == JEN1_DEEP_GEMM) gemm_prefill<T>(D, u, wk, lane, ra);
+    if constexpr ((KM >> JEN1_DEEP_GEMM) & 1) {
+      if (kind == JEN1_DEEP_GEMM) gemm_prefill<T>(D, u, wk, lane, ra);
+    }
 #endif
     // the next ticket: requested late in the unit (a workgroup must not sit on a ticket while it computes: the unit it would hold
     // is on the critical path a phase later), picked up behind the unit
@@ -1691,9 +2232,15 @@ __global__ __launch_bounds__(NT) void deep_kernel(const unsigned char* __restric
       if (tid == 0 && tc == 0) tc = 1u + __hip_atomic_fetch_add(ticket, 1u, RLX_AGENT);
     };
     sy.p = p;
-    if (kind == JEN1_DEEP_GEMM) gemm_unit<T>(D, u, sy, ra, publish_next, tid);
-    else if (kind == JEN1_DEEP_ATTN) attn_unit<T>(D, u, sy, publish_next, tid);
-    else stats_unit<T>(D, u, sy, publish_next, tid);
+    if (((KM >> JEN1_DEEP_GEMM) & 1) && kind == JEN1_DEEP_GEMM) {
+      if constexpr ((KM >> JEN1_DEEP_GEMM) & 1) gemm_unit<T>(D, u, sy, ra, publish_next, tid);
+    } else if (((KM >> JEN1_DEEP_ATTN) & 1) && kind == JEN1_DEEP_ATTN) {
+      if constexpr ((KM >> JEN1_DEEP_ATTN) & 1) attn_unit<T>(D, u, sy, publish_next, tid);
+    } else if (((KM >> JEN1_DEEP_TILE) & 1) && kind == JEN1_DEEP_TILE) {
+      if constexpr (KM == KM_TILE) tile_unit<T>(D, u, sy, ra, publish_next, tid);
+    } else {
+      stats_unit<T>(D, u, sy, publish_next, tid);
+    }
     DK_FLUSH(sy);
     if (tid == 0) tick_s[0] = (int)(tc - 1u);
     __syncthreads();
@@ -1956,6 +2503,131 @@ extern "C" int jen1_deep_phase_stats(const void* x, float* stats, int B, int L, 
   return 0;
 }
 
+extern "C" int jen1_deep_tile_count(int L_out, int tb, int M, int bm) {
+  if (tb < 1 || bm < 1) return 0;
+  return ceil_div(L_out, tb) * ceil_div(M, bm);
+}
+
+extern "C" int jen1_deep_phase_tile(const jen1_conv_args* a, int tb, int bm, const float* st0, int st0_tiles, int st0_nfg, const float* st1,
+                                    int st1_tiles, int st1_nfg, int st_live, float* out_part, int out_nfg, jen1_deep_phase* out) {
+  JEN1_CHECK(a && out, "deep tile: null pointer");
+  JEN1_CHECK(a->dtype == JEN1_F32 || a->dtype == JEN1_BF16, "deep tile: dtype must be float32 or bf16 (the JEN1_FP8 mode runs the long levels in bf16)");
+  JEN1_CHECK(a->x0 && a->w && a->y, "deep tile: null tensor");
+  JEN1_CHECK(a->pro_mode == JEN1_PRO_NONE || a->pro_mode == JEN1_PRO_GN || a->pro_mode == JEN1_PRO_GN_SILU, "deep tile: prologue %d is not supported", a->pro_mode);
+  JEN1_CHECK(!a->ln_fold && !a->row_scale && !a->out_rowstats && a->act == JEN1_ACT_NONE && a->m_split == 0, "deep tile: LayerNorm / row scale / activation / dual range are not tile options");
+  JEN1_CHECK(a->c0 > 0 && a->c0 % 32 == 0 && a->c1 % 32 == 0 && a->M % 16 == 0, "deep tile: channels must be multiples of 32, M of 16");
+  JEN1_CHECK(a->taps >= 1 && a->stride >= 1 && a->B >= 1 && a->L_in >= 1 && a->L_out >= 1, "deep tile: bad geometry");
+  JEN1_CHECK(a->nseg >= 0 && a->nseg <= 2, "deep tile: at most two raw extra K segments");
+  JEN1_CHECK(tb == 16 || tb == 32 || tb == 48 || tb == 64, "deep tile: %d positions per tile (16, 32, 48 or 64)", tb);
+  JEN1_CHECK((bm == 128 || bm == 256) && a->M % bm == 0, "deep tile: %d output rows per unit (128 or 256, dividing M = %d)", bm, a->M);
+  JEN1_CHECK(bm == 128 || tb <= 32, "deep tile: at 256 output rows per unit a tile has at most 32 positions (two fragments per wave)");
+  const int es = a->dtype == JEN1_F32 ? 4 : 2;
+  const bool gn = a->pro_mode != JEN1_PRO_NONE;
+  jen1_deep_phase& p = *out;
+  memset(&p, 0, sizeof(p));
+  p.h.kind = JEN1_DEEP_TILE;
+  p.h.dtype = a->dtype;
+  p.h.dep = -1;
+  p.h.mrep = 1;
+  p.h.live_mask = a->live_mask;
+  int ns = 0, coff = 0;
+  p.h.src[ns++] = jen1_deep_src{a->x0, a->ld0, a->c0, 0, 1.0f};
+  coff = a->c0;
+  if (a->c1) {
+    JEN1_CHECK(a->x1, "deep tile: c1 without x1");
+    p.h.src[ns++] = jen1_deep_src{a->x1, a->ld1, a->c1, coff, a->src1_scale};
+    coff += a->c1;
+  }
+  const int cmain = coff;
+  JEN1_CHECK(cmain <= JEN1_DEEP_THREADS, "deep tile: %d main channels (at most %d: one affine pair per thread)", cmain, JEN1_DEEP_THREADS);
+  int kx = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    const jen1_conv_seg& e = a->seg[s];
+    JEN1_CHECK(e.x && e.kch > 0 && e.shift == 0 && e.ld >= 32 * e.kch, "deep tile: bad extra segment %d", s);
+    p.h.src[ns++] = jen1_deep_src{e.x, e.ld, 32 * e.kch, coff, 1.0f};
+    coff += 32 * e.kch;
+    kx += e.kch;
+  }
+  for (int k = ns; k < JEN1_DEEP_MAX_SRC; ++k) p.h.src[k] = jen1_deep_src{a->x0, a->ld0, 0, 1 << 30, 1.0f};
+  p.h.nsrc = ns; p.h.Ctot = coff; p.h.pitch = coff + 8;
+  p.h.MT = a->M / 16;
+  p.tl.cmain = cmain; p.tl.taps = a->taps; p.tl.pad_left = a->pad_left;
+  p.tl.kch = cmain / 32;
+  p.tl.KS = a->taps * p.tl.kch + kx;
+  p.h.G = p.tl.KS;
+  const int64_t wb = (int64_t)p.tl.KS * p.h.MT * 512 * es;
+  JEN1_CHECK(wb < ((int64_t)1 << 31), "deep tile: packed weight too large for 31-bit offsets");
+  p.h.w = a->w; p.h.w_bytes = (uint32_t)wb;
+  p.h.B = a->B; p.h.L_in = a->L_in; p.h.L_out = a->L_out; p.h.stride = a->stride;
+  p.h.pro_mode = a->pro_mode;
+  if (gn) {
+    JEN1_CHECK(a->gn_gamma && a->gn_beta && a->gn_groups >= 1 && a->gn_cpg >= 1 && a->gn_count >= 1 && st0, "deep tile: incomplete GroupNorm");
+    p.h.norm_C = cmain;
+    p.h.gn_groups = a->gn_groups;
+    p.h.gn_cpg = a->gn_groups == 1 ? cmain : a->gn_cpg;
+    JEN1_CHECK(a->gn_groups > 1 || a->c1 == 0, "deep tile: a single GroupNorm group over two sources is not supported");
+    p.h.inv_count = 1.0f / (float)a->gn_count;
+    p.h.gn_eps = a->gn_eps;
+    if (a->film) {
+      JEN1_CHECK(a->film_C == cmain && a->film_ld >= a->film_off + 2 * a->film_C, "deep tile: bad FiLM table geometry");
+      p.h.p1 = a->film + a->film_off;
+      p.h.p2 = a->film + a->film_off + a->film_C;
+      p.h.p_ld = a->film_ld;
+      p.h.film_row = a->film_row; p.h.film_step = a->film_step;
+    } else {
+      p.h.p1 = a->gn_gamma; p.h.p2 = a->gn_beta; p.h.p_ld = 0;
+    }
+    p.tl.st[0] = st0; p.tl.st_tiles[0] = st0_tiles; p.tl.st_nfg[0] = st0_tiles ? st0_nfg : 32;
+    p.tl.st[1] = a->c1 ? st1 : st0; p.tl.st_tiles[1] = a->c1 ? st1_tiles : 0; p.tl.st_nfg[1] = (a->c1 && st1_tiles) ? st1_nfg : 32;
+    JEN1_CHECK(!a->c1 || st1, "deep tile: the second normalised source needs statistics");
+    p.tl.st_live = st_live & (a->c1 ? 3 : 1);
+    for (int k = 0; k < (a->c1 ? 2 : 1); ++k) {
+      const int nfg = p.tl.st_nfg[k], ck = k ? a->c1 : a->c0;
+      JEN1_CHECK(nfg == 8 || nfg == 16 || nfg == 32, "deep tile: %d statistics groups per tile (8, 16 or 32)", nfg);
+      JEN1_CHECK(ck % nfg == 0, "deep tile: %d channels do not split into %d statistics groups", ck, nfg);
+      const int cps = ck / nfg;
+      JEN1_CHECK(p.h.gn_cpg % cps == 0 || a->gn_groups == 1, "deep tile: GroupNorm groups of %d channels are not made of whole statistics groups of %d", p.h.gn_cpg, cps);
+      p.tl.inv_cps[k] = 1.0f / (float)cps;
+    }
+    if (!a->c1) p.tl.inv_cps[1] = p.tl.inv_cps[0];
+    p.tl.inv_cpg = 1.0f / (float)p.h.gn_cpg;
+  }
+  p.h.bias = a->bias; p.h.residual = a->residual; p.h.y = a->y;
+  p.h.out_C = a->out_C; p.h.ps_f = a->ps_f < 1 ? 1 : a->ps_f; p.h.ps_off = a->ps_off; p.h.L_y = a->L_y; p.h.y_brows = a->y_brows;
+  p.h.y_row0 = a->y_row0; p.h.ld_y = a->ld_y; p.h.ld_res = a->ld_res; p.h.act = a->act; p.h.y_f32 = a->y_f32;
+  JEN1_CHECK(a->out_C % 16 == 0 && a->ld_y % 4 == 0 && (!a->residual || a->ld_res % 4 == 0) && a->out_C * p.h.ps_f == a->M,
+             "deep tile: output channels must be a multiple of 16 (an M tile never straddles a sub-pixel phase), pitches of 4");
+  JEN1_CHECK((int64_t)a->B * a->L_in * (a->ld0 > a->ld1 ? a->ld0 : a->ld1) < ((int64_t)1 << 31) && (int64_t)a->B * a->y_brows * a->ld_y < ((int64_t)1 << 31),
+             "deep tile: tensor too large");
+  p.tl.tb = tb;
+  p.tl.tiles_t = ceil_div(a->L_out, tb);
+  p.tl.BM = bm; p.tl.mblocks = a->M / bm; p.tl.MF = 2;
+  p.tl.NF = tb / 16;
+  p.tl.rows_in = (tb - 1) * a->stride + a->taps;
+  p.tl.out_part = out_part;
+  if (out_part) {
+    JEN1_CHECK((out_nfg == 8 || out_nfg == 16 || out_nfg == 32) && a->out_C % out_nfg == 0 && (a->out_C / out_nfg) % 16 == 0 && !a->y_f32,
+               "deep tile: %d output channels in %d statistics groups (groups of a multiple of 16 channels)", a->out_C, out_nfg);
+    p.tl.out_nfg = out_nfg;
+    p.tl.out_cps = a->out_C / out_nfg;
+    p.tl.inv_out_cps = 1.0f / (float)p.tl.out_cps;
+  }
+  const int tile_b = align16i(p.tl.rows_in * p.h.pitch * es);
+  p.tl.tab_off = tile_b;
+  p.tl.red_off = tile_b + align16i(8 * cmain);
+  const int tot = p.tl.red_off + (2 * (JEN1_DEEP_THREADS / 64) * 64 + 128) * 4;
+  JEN1_CHECK(tot <= LDS_BUDGET, "deep tile: %d B of LDS", tot);
+  p.h.lds_bytes = tot;
+  p.h.n_units = p.tl.mblocks * a->B * p.tl.tiles_t;
+  JEN1_CHECK(p.h.n_units < (1 << 20), "deep tile: too many units");
+  p.tl.inv_tiles_t = 1.0f / (float)p.tl.tiles_t;
+  p.tl.inv_bt = 1.0f / (float)(a->B * p.tl.tiles_t);
+  p.h.inv_vpr = 1.0f / (float)(coff / 8);
+  p.h.inv_Lin = 1.0f / (float)a->L_in;
+  p.h.inv_Lout = 1.0f / (float)a->L_out;
+  return 0;
+}
+
 extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, void* blobs, void* headers) {
   JEN1_CHECK(phases && blobs && headers && n_phases >= 1 && nwg >= 1, "deep link: bad arguments");
   JEN1_CHECK(n_phases <= JEN1_DEEP_MAX_PHASES, "deep link: %d phases (at most %d)", n_phases, JEN1_DEEP_MAX_PHASES);
@@ -2081,8 +2753,12 @@ extern "C" int jen1_deep_num_workgroups(void) {
   return cus;
 }
 
+extern "C" int jen1_deep_run_kinds(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
+                                   int lds_bytes, int dtype, int tickets, int kind_mask, void* stream);
 extern "C" int jen1_deep_run_mode(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
-                                  int lds_bytes, int dtype, int tickets, void* stream);
+                                  int lds_bytes, int dtype, int tickets, void* stream) {
+  return jen1_deep_run_kinds(blobs_dev, headers_dev, n_phases, sync, err, nwg, lds_bytes, dtype, tickets, KM_DEEP, stream);
+}
 extern "C" int jen1_deep_run(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, int nwg, int lds_bytes, int dtype,
                              void* stream) {
   JEN1_CHECK(sync, "deep run: bad arguments");
@@ -2094,9 +2770,9 @@ extern "C" int jen1_deep_run_err(const void* blobs_dev, const void* headers_dev,
 }
 
 namespace {
-template <typename T, bool TK>
+template <typename T, bool TK, int KM>
 int launch_deep(const unsigned char* bl, const int4* hd, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes, hipStream_t s) {
-  auto kern = deep_kernel<T, TK>;
+  auto kern = deep_kernel<T, TK, KM>;
   JEN1_MAX_LDS_ONCE(kern, LDS_TOTAL);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), (size_t)lds_bytes, s, bl, hd, n_phases, sync, err);
   JEN1_HIP(hipGetLastError());
@@ -2104,20 +2780,29 @@ int launch_deep(const unsigned char* bl, const int4* hd, int n_phases, uint32_t*
 }
 }  // namespace
 
-extern "C" int jen1_deep_run_mode(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
-                                  int lds_bytes, int dtype, int tickets, void* stream) {
+extern "C" int jen1_deep_run_kinds(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg,
+                                   int lds_bytes, int dtype, int tickets, int kind_mask, void* stream) {
   JEN1_CHECK(blobs_dev && headers_dev && sync && err && n_phases >= 1 && n_phases <= JEN1_DEEP_MAX_PHASES && nwg >= 1, "deep run: bad arguments");
   JEN1_CHECK(lds_bytes >= WS_OFF && lds_bytes <= LDS_TOTAL, "deep run: %d B of LDS", lds_bytes);
   JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "deep run: bad dtype");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned char* bl = reinterpret_cast<const unsigned char*>(blobs_dev);
   const int4* hd = reinterpret_cast<const int4*>(headers_dev);
-  if (tickets) {
-    if (dtype == JEN1_F32) return launch_deep<float, true>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
-    if (dtype == JEN1_FP8) return launch_deep<fp8_t, true>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
-    return launch_deep<bf16_t, true>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  if ((kind_mask & ~KM_TILE) == 0) {
+    // tile phases (+ statistics) only; the JEN1_FP8 mode runs them in bf16
+    const bool f32 = dtype == JEN1_F32;
+    if (tickets) return f32 ? launch_deep<float, true, KM_TILE>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s)
+                            : launch_deep<bf16_t, true, KM_TILE>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+    return f32 ? launch_deep<float, false, KM_TILE>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s)
+               : launch_deep<bf16_t, false, KM_TILE>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
   }
-  if (dtype == JEN1_F32) return launch_deep<float, false>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
-  if (dtype == JEN1_FP8) return launch_deep<fp8_t, false>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
-  return launch_deep<bf16_t, false>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  JEN1_CHECK((kind_mask & ~KM_DEEP) == 0, "deep run: a program mixes tile phases with GEMM / attention phases (kinds 0x%x): record them as separate programs", kind_mask);
+  if (tickets) {
+    if (dtype == JEN1_F32) return launch_deep<float, true, KM_DEEP>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+    if (dtype == JEN1_FP8) return launch_deep<fp8_t, true, KM_DEEP>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+    return launch_deep<bf16_t, true, KM_DEEP>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  }
+  if (dtype == JEN1_F32) return launch_deep<float, false, KM_DEEP>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  if (dtype == JEN1_FP8) return launch_deep<fp8_t, false, KM_DEEP>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
+  return launch_deep<bf16_t, false, KM_DEEP>(bl, hd, n_phases, sync, err, nwg, lds_bytes, s);
 }

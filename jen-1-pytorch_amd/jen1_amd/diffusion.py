@@ -434,8 +434,8 @@ class DDIMStepper:
         """once per sampling run (one host sync): a dependency wait of the persistent deep-level launch that timed out leaves an
         error word behind instead of hanging the GPU; results are garbage then and must not be returned silently"""
         for _, plan, _, _ in self.parts:
-            if getattr(plan, "deep_level", None) is not None:
-                e = plan.deep.take_error()
+            if getattr(plan, "progs", None):
+                e = plan.take_error()
                 if e:
                     raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {e - 1} timed out "
                                          "(another persistent launch on the same GPU?); the error word was cleared")

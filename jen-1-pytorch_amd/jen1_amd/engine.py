@@ -49,11 +49,15 @@ class Act:
     """a channel-last activation [B][L][ld] plus the statistics its consumers need.
     ``ld`` is the row pitch; ``cp`` the channels a GEMM reads (C padded to 32): they differ only for a column
     window of a wider tensor (``cols``)."""
-    __slots__ = ("t", "B", "L", "C", "ld", "gn", "rs", "cp")
+    __slots__ = ("t", "B", "L", "C", "ld", "gn", "rs", "cp", "part", "gn_valid")
 
     def __init__(self, t, B, L, C, ld, gn=None, rs=None, cp=None):
         self.t, self.B, self.L, self.C, self.ld, self.gn, self.rs = t, B, L, C, ld, gn, rs
         self.cp = cp if cp is not None else ld
+        # GroupNorm statistics as a tile phase of the persistent launch leaves them: (tensor [B][tiles][groups][2], tiles, groups)
+        self.part = None
+        # ``gn`` (the fine-group totals) is written by whoever produces the tensor -- except phases of the persistent launch
+        self.gn_valid = True
 
     def cols(self, c0: int, n: int, rs=None) -> "Act":
         """channels [c0, c0 + n) of this tensor as an activation of its own (same row pitch)"""
@@ -258,8 +262,14 @@ class DeepProgram:
 
     _static_owner: Dict[str, "weakref.ref"] = {}       # per device: the program that may use the static schedule
 
-    def __init__(self, eng):
+    def __init__(self, eng, leader: Optional["DeepProgram"] = None, err: Optional[torch.Tensor] = None):
+        """leader: the first program of the same plan (a plan may run several persistent launches per step, one behind the other on one
+        stream: they share the scheduling form and the error word)"""
         self.eng = eng
+        self.leader = leader if leader is not None else self
+        self._err_shared = err
+        self.w_bytes = self.act_bytes = self.flops = 0      # algorithmic traffic / work of the recorded phases
+        self.kinds: List[str] = []
         self.lib = eng.lib
         self.psize = self.lib.jen1_deep_phase_size()
         self.bufs: List[C.Array] = []
@@ -274,7 +284,15 @@ class DeepProgram:
         # workgroup resident, so only ONE program per device and process may use it at a time -- the first one alive claims it, every
         # other persistent launch that could share the GPU with it (concurrent samplers, other shapes on other streams) goes by ticket
         # and cannot deadlock.  JEN1_DEEP_SHARED=1 (the GPU is shared with other PROCESSES that run this library) forces tickets.
-        self.exclusive = False
+        self._exclusive = False
+
+    @property
+    def exclusive(self) -> bool:
+        return self.leader._exclusive
+
+    @exclusive.setter
+    def exclusive(self, v: bool):
+        self.leader._exclusive = bool(v)
 
     def _note_output(self, out: Optional["Act"]):
         if out is not None:
@@ -288,27 +306,40 @@ class DeepProgram:
     def _new(self):
         return (C.c_char * self.psize)()
 
-    def _add(self, buf, rc, label, out):
+    def _add(self, buf, rc, label, out, kind="gemm"):
         if rc != 0:
             msg = self.lib.jen1_last_error()
             raise DeepIneligible(f"{label}: {msg.decode() if msg else 'does not fit'}")
         self.bufs.append(buf)
         self.labels.append(label)
         self.outs.append(out)
+        self.kinds.append(kind)
         self._note_output(out)
 
     def add_conv(self, a: "L.ConvArgs", label: str, out, nb_max: int = 0):
         buf = self._new()
         self._add(buf, self.lib.jen1_deep_phase_conv(C.byref(a), nb_max, C.cast(buf, C.c_void_p)), label, out)
 
+    def add_tile(self, a: "L.ConvArgs", tb: int, bm: int, st, out_part, out_nfg: int, label: str, out):
+        """a layer of a long level (jen1_deep_phase_tile).  st: per normalised source (pointer, tiles, groups, live) or None"""
+        buf = self._new()
+        st = list(st) + [None] * (2 - len(st))
+        p = [(0, 0, 0) if e is None else (e[0], e[1], e[2]) for e in st]
+        live = sum(1 << k for k, e in enumerate(st) if e is not None and e[3])
+        rc = self.lib.jen1_deep_phase_tile(C.byref(a), tb, bm, p[0][0] or None, p[0][1], p[0][2], p[1][0] or None, p[1][1], p[1][2], live,
+                                           None if out_part is None else out_part.data_ptr(), out_nfg, C.cast(buf, C.c_void_p))
+        self._add(buf, rc, label, out, kind="tile")
+        if out_part is not None:
+            self._produced.setdefault(out_part.untyped_storage().data_ptr(), out_part)
+
     def add_attention(self, args, label: str, out):
         buf = self._new()
-        self._add(buf, self.lib.jen1_deep_phase_attention(*args, C.cast(buf, C.c_void_p)), label, out)
+        self._add(buf, self.lib.jen1_deep_phase_attention(*args, C.cast(buf, C.c_void_p)), label, out, kind="attn")
 
     def add_stats(self, x: "Act", stats: torch.Tensor, label: str):
         buf = self._new()
         self._add(buf, self.lib.jen1_deep_phase_stats(x.t.data_ptr(), stats.data_ptr(), x.B, x.L, x.ld, self.eng.deep_dt,
-                                                      C.cast(buf, C.c_void_p)), label, None)
+                                                      C.cast(buf, C.c_void_p)), label, None, kind="stats")
 
     def __len__(self):
         return len(self.bufs)
@@ -334,7 +365,7 @@ class DeepProgram:
         self.hdr = torch.frombuffer(bytearray(bytes(hdrs)), dtype=torch.uint8).to(self.eng.device)
         self.sync = sync
         # the error word lives outside the per-step zeroed area: the first time-out of any replay stays visible (error())
-        self.err = torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
+        self.err = self._err_shared if self._err_shared is not None else torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
         # every tensor a phase writes starts each launch as the sentinel (jen1_deep_poison): {pointer, bytes} per storage
         ent = []
         for ptr, t in self._produced.items():
@@ -343,7 +374,7 @@ class DeepProgram:
             ent += [ptr, nb]
         key = str(self.eng.device)
         owner = DeepProgram._static_owner.get(key)
-        if os.environ.get("JEN1_DEEP_SHARED", "0") != "1" and (owner is None or owner() is None):
+        if self.leader is self and os.environ.get("JEN1_DEEP_SHARED", "0") != "1" and (owner is None or owner() is None):
             DeepProgram._static_owner[key] = weakref.ref(self)
             self.exclusive = True
         self.poison_tab = torch.tensor(ent, dtype=torch.int64).view(-1, 2).to(self.eng.device)
@@ -357,8 +388,9 @@ class DeepProgram:
         n = len(self.bufs)
         if os.environ.get("JEN1_DEEP_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_DEEP_RUN_PHASES"]))
-        L.check(self.lib.jen1_deep_run_mode(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.err.data_ptr(), self.nwg,
-                                            self.lds, self.eng.deep_dt, 0 if self.exclusive else 1, stream), "jen1_deep_run_mode")
+        km = sum(1 << k for k, name in enumerate(("gemm", "attn", "stats", "tile")) if name in self.kinds)
+        L.check(self.lib.jen1_deep_run_kinds(self.dev.data_ptr(), self.hdr.data_ptr(), n, self.sync.data_ptr(), self.err.data_ptr(), self.nwg,
+                                             self.lds, self.eng.deep_dt, 0 if self.exclusive else 1, km, stream), "jen1_deep_run_kinds")
 
     def error(self) -> int:
         """non-zero after a launch whose dependency wait timed out (1 + phase index); synchronises with the device"""
@@ -412,8 +444,11 @@ class OpBuilder:
         self.slab = None
         self.counters = None
         self.det = getattr(self, "det", False)      # fixed-order statistics launches instead of epilogue atomics (Plan)
-        self.deep: Optional[DeepProgram] = None     # the persistent deep-level program being recorded (Plan._deep_begin)
-        self._deep_on = False
+        self.deep: Optional[DeepProgram] = None     # the persistent program being recorded (Plan._prog_open); after the build: the one with the deep levels
+        self._deep_on = False                       # layers are GEMM / attention phases (the levels with few positions)
+        self._prog: Optional[DeepProgram] = None    # the open program, if any
+        self.tile_lens = getattr(self, "tile_lens", frozenset())      # input lengths whose layers are tile phases (Plan)
+        self.tile_errors: List[str] = []
 
     def _empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.eng.tdtype, device=self.eng.device)
@@ -547,10 +582,25 @@ class OpBuilder:
             es_ = 4 if eng.dt == L.F32 else 2
             c_real_ = src0.C + (src1.C if src1 is not None else 0)
             c_extra_ = sum(e.C for e, _ in extra_segs) if extra_segs else 0
-            self.deep_w_bytes += (taps * c_real_ + c_extra_) * a.M * (1 if w8 is not None else es_) + (4 * a.M if w8 is not None else 0)
-            self.deep_act_bytes += a.B * a.L_in * (c_real_ + c_extra_) * es_ + a.B * a.L_y * out_C * es_
-            self.deep_flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
+            self.deep.w_bytes += (taps * c_real_ + c_extra_) * a.M * (1 if w8 is not None else es_) + (4 * a.M if w8 is not None else 0)
+            self.deep.act_bytes += a.B * a.L_in * (c_real_ + c_extra_) * es_ + a.B * a.L_y * out_C * es_
+            self.deep.flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
+            out.gn_valid = False
             return out
+        if src0.L in self.tile_lens and not self.det:
+            # a long level inside the persistent launch: a tile phase (jen1_deep_phase_tile); a layer that does not fit runs as a launch
+            try:
+                return self._conv_tile(L.ConvArgs.from_buffer_copy(a), src0=src0, src1=src1, w=w, bias=bias, out=out, pro=pro, gn=gn, film=film, ln=ln, act=act,
+                                       residual=residual, row_scale=row_scale, y_f32=y_f32, extra_segs=extra_segs, m_split=m_split,
+                                       flat_w=flat_w, label=label, taps=taps, out_C=out_C)
+            except DeepIneligible as e:
+                self.tile_errors.append(str(e))
+        if self._prog is not None:
+            # a launch behind phases of the open program: the program ends here; what this launch normalises gets its totals first
+            need = [s_ for s_ in (src0, src1) if s_ is not None and pro in (L.PRO_GN, L.PRO_GN_SILU) and not s_.gn_valid]
+            self._prog_close(need)
+        if pro in (L.PRO_GN, L.PRO_GN_SILU):
+            assert src0.gn_valid and (src1 is None or src1.gn_valid), f"{label}: GroupNorm totals of a tensor produced inside a persistent launch were never written"
         # the tile kernel takes up to two raw extra K segments at row shift 0 (a 1x1 shortcut riding on the block's second conv)
         extras_tile = not extra_segs or (len(extra_segs) <= 2 and all(sh == 0 and e.cp == e.C and e.cp % 32 == 0 for e, sh in extra_segs))
         det_gn = det_rs = False
@@ -658,6 +708,95 @@ class OpBuilder:
         if det_rs:
             self.rowstats_launch(ops, out, m_split if m_split else out_C)
         return out
+
+    # ---------------------------------------------------------------- tile phases of the persistent launch (long levels)
+    def _conv_tile(self, a: "L.ConvArgs", *, src0, src1, w, bias, out, pro, gn, film, ln, act, residual, row_scale, y_f32, extra_segs,
+                   m_split, flat_w, label, taps, out_C):
+        eng = self.eng
+        if pro not in (L.PRO_NONE, L.PRO_GN, L.PRO_GN_SILU) or act != L.ACT_NONE or row_scale is not None or m_split or out.rs is not None:
+            raise DeepIneligible(f"{label}: option outside the tile phases")
+        if out.ld != out.C and not y_f32:
+            raise DeepIneligible(f"{label}: {out.C} output channels are not a multiple of 32 (padding columns would stay poisoned)")
+        if extra_segs and not (len(extra_segs) <= 2 and all(sh == 0 and e.cp == e.C and e.cp % 32 == 0 for e, sh in extra_segs)):
+            raise DeepIneligible(f"{label}: extra K segments outside the tile phases")
+        if a.M % 128 != 0:
+            raise DeepIneligible(f"{label}: {a.M} output rows are not a multiple of 128")
+        if self._prog is not None and any(k in self._prog.kinds for k in ("gemm", "attn")):
+            # tile phases and GEMM / attention phases are different kernels: the deep program ends here, with the totals of what this
+            # layer normalises
+            self._prog_close([s_ for s_ in (src0, src1) if s_ is not None and pro in (L.PRO_GN, L.PRO_GN_SILU) and not s_.gn_valid and s_.part is None])
+        prog_was_open = self._prog is not None
+        self._prog_open()
+        prog = self._prog
+        a.out_gn_stats = a.out_rowstats = None
+        a.dtype = eng.dt                                     # (JEN1_FP8: the long levels stay bf16)
+        if pro in (L.PRO_GN, L.PRO_GN_SILU) and film is not None:
+            a.film = self.film2.data_ptr()
+        a.nseg = 0
+        if extra_segs:
+            for i, (e, sh) in enumerate(extra_segs):
+                assert e.B == a.B and e.L == a.L_in and e.t.dtype == eng.tdtype
+                a.seg[i].x, a.seg[i].ld, a.seg[i].shift, a.seg[i].kch = e.t.data_ptr(), e.ld, 0, e.cp // 32
+            a.nseg = len(extra_segs)
+        srcs_ = [src0] + ([src1] if src1 is not None else []) + [e for e, _ in (extra_segs or [])]
+        a.live_mask = sum(1 << i for i, s_ in enumerate(srcs_) if prog.is_live(s_.t)) | \
+            (256 if residual is not None and prog.is_live(residual.t) else 0)
+        # statistics of the normalised sources: per-tile partials of a tile phase, or the totals somebody wrote before the launch
+        st = []
+        if pro in (L.PRO_GN, L.PRO_GN_SILU):
+            for s_ in [src0] + ([src1] if src1 is not None else []):
+                if s_.part is not None:
+                    pt, tiles, nfg = s_.part
+                    st.append((pt.data_ptr(), tiles, nfg, prog.is_live(pt)))
+                elif s_.gn is not None and s_.gn_valid:
+                    st.append((s_.gn.data_ptr(), 0, 32, False))
+                else:
+                    if not prog_was_open:
+                        self._prog = None
+                    raise DeepIneligible(f"{label}: no GroupNorm statistics for a normalised source")
+        # geometry: all output rows in one unit up to 256; the smallest tile that needs the fewest rounds of the resident workgroups
+        bm = 256 if a.M % 256 == 0 else 128
+        mblocks = a.M // bm
+        best = None
+        for tb in ((16, 32, 48, 64) if bm == 128 else (16, 32)):
+            units = mblocks * a.B * -(-a.L_out // tb)
+            rounds = -(-units // max(prog.nwg, 1))
+            if best is None or rounds < best[0]:
+                best = (rounds, tb)
+        tb = best[1]
+        part, nfg_out = None, 0
+        if out.gn is not None and not y_f32:
+            nfg_out = 8 if (out_C % 8 == 0 and (out_C // 8) % 16 == 0) else 0
+            if not nfg_out:
+                if not prog_was_open:
+                    self._prog = None
+                raise DeepIneligible(f"{label}: {out_C} output channels do not split into 8 statistics groups of whole M tiles")
+            tiles = int(eng.lib.jen1_deep_tile_count(a.L_out, tb, a.M, bm))
+            part = torch.empty((a.B, tiles, nfg_out, 2), dtype=torch.float32, device=eng.device)
+        try:
+            prog.add_tile(a, tb, bm, st, part, nfg_out,
+                          f"tile[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} s={a.stride} M={a.M} tb={tb} bm={bm}", out)
+        except DeepIneligible:
+            if not prog_was_open:
+                self._prog = None
+            raise
+        self._keep.append((a, src0, src1, w, bias, out, residual, gn, film, extra_segs, part))
+        if part is not None:
+            out.part = (part, tiles, nfg_out)
+        out.gn_valid = False
+        es_ = 4 if eng.dt == L.F32 else 2
+        c_real_ = src0.C + (src1.C if src1 is not None else 0)
+        c_extra_ = sum(e.C for e, _ in extra_segs) if extra_segs else 0
+        prog.w_bytes += (taps * c_real_ + c_extra_) * a.M * es_
+        prog.act_bytes += a.B * a.L_in * (c_real_ + c_extra_) * es_ + a.B * a.L_y * out_C * (4 if y_f32 else es_)
+        prog.flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
+        return out
+
+    def _prog_open(self):
+        raise DeepIneligible("no persistent program outside a Plan")
+
+    def _prog_close(self, need_totals=()):
+        raise AssertionError("no persistent program outside a Plan")
 
     # ---------------------------------------------------------------- deterministic statistics (Plan(deterministic=True))
     def stats_launch(self, ops, x: Act):
@@ -824,6 +963,8 @@ class OpBuilder:
             self._keep.append((q, kv_t, out, kv_row, kv_extra, extra_row, extra_step, fin))
             self.deep.add_attention(dargs, f"attention B={q.B} H={H} d={d} Nq={q.L} Nk={Nk} causal={causal}", out)
             return
+        if self._prog is not None:
+            self._prog_close()
         args = (q.t.data_ptr(), kv_t.data_ptr(), kv_t.data_ptr(), out.t.data_ptr(), _ptr(kv_row), _ptr(kv_extra),
                 _ptr(extra_row), _ptr(extra_step), ld_extra, kx_off, vx_off, q.B, H, d, q.L, Nk, q.ld, q_off, ldkv, k_off, v_off, out.ld,
                 1 if causal else 0, float(d) ** -0.5, _ptr(rs_), _ptr(u_), _ptr(b_), lnC, float(eps), fq, fkv, eng.deep_dt)
@@ -863,21 +1004,30 @@ class Plan(OpBuilder):
             # candidates: levels whose length is within the persistent kernel's reach, shallowest first
             first = next((i for i in range(n_lv) if lens[i + 1] <= eng.deep_max_len), n_lv)
         self.deep_errors: List[str] = []
+        # long levels as tile phases of the persistent launch(es): layers whose input has at least eng.tile_phase_min_len positions
+        self.tile_lens = frozenset(l for l in lens if l >= eng.tile_phase_min_len) if (deep and eng.use_deep and eng.use_tile_phases
+                                                                                       and not self.det) else frozenset()
         while True:
             super().__init__(eng)
+            self.progs: List[DeepProgram] = []
+            self._deep_prog: Optional[DeepProgram] = None
+            self._deep_err = None
             self.time_ops: List[Callable[[int], None]] = []
             self.ctx_ops: List[Callable[[int], None]] = []
             self.taps: Dict[str, Act] = {}
             self.acts: List[Act] = []
             self.n_launch = 0
             self.deep_level = first if first < n_lv else None
-            self.deep_w_bytes = self.deep_act_bytes = self.deep_flops = 0
             try:
                 self._build()
                 break
             except DeepIneligible as e:
                 self.deep_errors.append(f"level {first}: {e}")
-                first += 1
+                if first >= n_lv:
+                    assert self.tile_lens, f"persistent launch: {e}"
+                    self.tile_lens = frozenset()           # not even the tile phases alone link: one launch per layer everywhere
+                else:
+                    first += 1
 
     # ---------------------------------------------------------------- allocation helpers
     def _stats(self, nfloats: int) -> torch.Tensor:
@@ -897,28 +1047,55 @@ class Plan(OpBuilder):
         return a
 
     # ---------------------------------------------------------------- persistent deep-level launch
+    def _prog_open(self):
+        """phases are recorded into ONE program as long as consecutive layers are phases (tile phases of the long levels, GEMM /
+        attention phases of the deep levels); a layer that runs as a launch closes it (_prog_close) and the next phase opens another"""
+        if self._prog is None:
+            if self._deep_err is None:
+                self._deep_err = torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
+            self._prog = DeepProgram(self.eng, leader=self.progs[0] if self.progs else None, err=self._deep_err)
+            self.deep = self._prog
+
     def _deep_begin(self):
-        self.deep = DeepProgram(self.eng)
+        if self._prog is not None and "tile" in self._prog.kinds:
+            self._prog_close()        # tile phases and GEMM / attention phases are different kernels (jen1_deep_run_kinds)
+        self._prog_open()
+        self._deep_prog = self._prog
         self._deep_on = True
 
     def _deep_end(self, last: Act):
-        """close the recorded program: fine-group statistics of its last tensor for the launch-per-layer consumer, the
-        synchronisation area inside the per-step arena (zeroed by the step's first node), ONE launch op"""
-        self.deep.add_stats(last, last.gn, f"stats B={last.B} L={last.L} ld={last.ld}")
+        """the deep levels end here; the program stays open: the next layer either continues it (a tile phase of a long level) or
+        closes it (a launch; conv() then asks for the GroupNorm totals of what it normalises)"""
         self._deep_on = False
-        n = self.deep.sync_words()
+
+    def _prog_close(self, need_totals=()):
+        """close the recorded program: fine-group totals of the tensors a launch-per-layer consumer normalises next, the
+        synchronisation area inside the per-step arena, ONE launch op (+ the poisoning of its tensors at the head of the step)"""
+        prog = self._prog
+        assert prog is not None and len(prog) > 0
+        for x in need_totals:
+            prog.add_stats(x, x.gn, f"stats B={x.B} L={x.L} ld={x.ld}")
+            x.gn_valid = True
+        self._prog = None
+        self._deep_on = False
+        n = prog.sync_words()
         sync = self._stats(n).view(torch.int32)
-        self.deep.finalize(sync)
-        prog = self.deep
+        prog.finalize(sync)
+        self.progs.append(prog)
         pz = lambda s, prog=prog: prog.poison(s)
         pz.kind = "deep_poison"
         pz.label = f"deep_poison[{prog.poison_tab.shape[0]} tensors, {prog.poison_bytes} B]"
         self.ops.insert(1, pz)          # right behind the arena reset: long before the launch, after the previous step's last reader
         fn = lambda s, prog=prog: prog.launch(s)
         fn.kind = "deep"
-        fn.label = f"deep[{len(prog)} phases, {prog.nwg} workgroups, {prog.lds} B LDS]"
-        fn.w_bytes, fn.act_bytes, fn.flops = self.deep_w_bytes, self.deep_act_bytes, self.deep_flops
+        fn.prog = prog
+        fn.label = f"deep[{len(prog)} phases ({prog.kinds.count('tile')} tile), {prog.nwg} workgroups, {prog.lds} B LDS]"
+        fn.w_bytes, fn.act_bytes, fn.flops = prog.w_bytes, prog.act_bytes, prog.flops
         self.ops.append(fn)
+
+    def take_error(self) -> int:
+        """the error word of the plan's persistent launches (shared; see DeepProgram.take_error)"""
+        return self.progs[0].take_error() if self.progs else 0
 
     # ---------------------------------------------------------------- network blocks
     def resblock(self, r: ResSpec, src0: Act, src1: Optional[Act], causal: bool, gn=True) -> Act:
@@ -1024,7 +1201,7 @@ class Plan(OpBuilder):
         n_tr = len(spec.transformers())
         lens = spec.level_lengths(T)
         Ltr = max([lens[i + 1] for i, d in enumerate(spec.downs) if d.transformer] + [lens[-1]])
-        deep_sync = (int(eng.lib.jen1_deep_sync_bytes(256)) // 4) if self.deep_level is not None else 0    # arrival counters of <= 256 phases
+        deep_sync = 4 * (int(eng.lib.jen1_deep_sync_bytes(256)) // 4) if (self.deep_level is not None or self.tile_lens) else 0    # <= 4 programs of <= 256 phases
         self.arena = torch.zeros(600 * Be * 64 + (4 * n_tr + 8) * Be * Ltr * 2 + 4096 + deep_sync + 64, dtype=f32, device=dev)
         self._arena_used = 0
         ops = self.ops
@@ -1083,7 +1260,7 @@ class Plan(OpBuilder):
         # fused GroupNorm-FiLM table of the persistent kernel: y = xhat * gamma (scale + 1) + beta (scale + 1) + shift
         # (blocks.py:141-143); timestep-only work like the FiLM GEMM itself
         self.film2 = torch.empty_like(self.film)
-        if self.deep_level is not None:
+        if self.deep_level is not None or self.tile_lens:
             film, film2, fa, fb, fp = self.film, self.film2, W.film2_a, W.film2_b, W.film2_partner
             tmp_a, tmp_b = torch.empty_like(film), torch.empty_like(film)
 
@@ -1180,6 +1357,9 @@ class Plan(OpBuilder):
         out = self.resblock(spec.to_out, x, None, causal=False, gn=False)
         self.net_out = out
         self.taps["out"] = out
+        if self._prog is not None:
+            self._prog_close()            # (the network's output is read by a launch that normalises nothing)
+        self.deep = self._deep_prog if self._deep_prog is not None else (self.progs[-1] if self.progs else None)
 
         # ---- 5. context ops: text K/V (hoisted out of the step loop) -------------------------------
         if n_tr:
@@ -1304,6 +1484,12 @@ class Engine:
         self.deep_all_slots = os.environ.get("JEN1_DEEP_ALL_SLOTS", "0") != "0"
         self.deterministic = os.environ.get("JEN1_DETERMINISTIC", "0") != "0"
         self.deep_max_len = int(os.environ.get("JEN1_DEEP_MAX_LEN", "64"))
+        # long levels as tile phases of persistent launches (jen1_deep_phase_tile): layers over at least this many positions.  Off by
+        # default: measured at B = 8, T = 1500 the 26 tile phases of levels 0 - 1 take 10 - 11 us each against 9.8 us for the launches
+        # they replace (726 against 776 steps/s; DESIGN.md section 4b says where the time goes) -- kept as the bit-reproducible form of
+        # the long levels (fixed-order statistics without the extra launches of Plan(deterministic=True)) and as the base of further work
+        self.use_tile_phases = os.environ.get("JEN1_TILE_PHASES", "0") != "0"
+        self.tile_phase_min_len = int(os.environ.get("JEN1_TILE_PHASE_MIN_LEN", "200"))
         self.deep_nb_max = int(os.environ.get("JEN1_DEEP_NB_MAX", "0"))
         # units per phase the batch split aims for (0: as many batch elements per unit as fit) and the weight bytes a phase may stream
         # in total when every batch group reads the layer's weights again; measured at B = 8, T = 1500 (deep launch, us):

@@ -139,6 +139,8 @@ SYMBOLS = {
     "jen1_deep_phase_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 +
                                   [c_float, _P, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
     "jen1_deep_phase_stats": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "jen1_deep_phase_tile": (c_int, [C.POINTER(ConvArgs), c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "jen1_deep_tile_count": (c_int, [c_int, c_int, c_int, c_int]),
     "jen1_deep_link": (c_int, [_P, c_int, c_int, _P, _P]),
     "jen1_deep_poison": (c_int, [_P, c_int, _P, _P]),
     "jen1_deep_blob_bytes": (c_int, []),
@@ -148,6 +150,7 @@ SYMBOLS = {
     "jen1_deep_run_err": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "jen1_deep_error_word": (c_int, [c_int]),
     "jen1_deep_run_mode": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "jen1_deep_run_kinds": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),

@@ -178,8 +178,8 @@ class UNetCFG1d(nn.Module):
         were not all resident, e.g. another persistent launch held CUs); the results are garbage then and ``forward`` must not
         return them.  One host sync per call -- ``forward`` returns a tensor the caller reads next anyway; the fused sampler
         checks once per sampling run instead (DDIMStepper.check)."""
-        if getattr(plan, "deep_level", None) is not None:
-            e = plan.deep.take_error()
+        if getattr(plan, "progs", None):
+            e = plan.take_error()
             if e:
                 raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {e - 1} timed out (another persistent "
                                      "launch on the same GPU?); the error word was cleared, the call can be repeated")

@@ -361,3 +361,72 @@ def test_concurrent_persistent_launches_match_solo_runs(full_f32, n):
     finally:
         m.deterministic = False
         m.engine().deep_all_slots = False
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tile phases: the long levels inside persistent launches (JEN1_TILE_PHASES=1; include/jen1_deep.h JEN1_DEEP_TILE)
+# ---------------------------------------------------------------------------------------------------------------------
+def tile_plan(model, B, T, nrep, causal):
+    """a plan whose layers over >= 200 positions are tile phases (built directly: the engine's plan cache is keyed without the knob)"""
+    from jen1_amd.engine import Plan
+    eng = model.engine()
+    old = eng.use_tile_phases
+    eng.use_tile_phases = True
+    try:
+        return Plan(eng, B, T, nrep, causal, None, deep=True)
+    finally:
+        eng.use_tile_phases = old
+
+
+@pytest.mark.parametrize("B,T,nrep,causal", [(8, 1500, 1, False), (2, 1500, 2, True), (3, 1499, 1, False)])
+def test_tile_phases_equal_launch_path_f32(full_f32, B, T, nrep, causal):
+    """every activation of the plan with tile phases (levels of 1500 / 375 positions: two more persistent launches around the
+    deep one) against the launch-per-layer plan; the statistics partials are summed in a fixed order, so two runs are bit-identical"""
+    model = full_f32
+    pt = tile_plan(model, B, T, nrep, causal)
+    pl = model.engine().plan(B, T, nrep, causal, deep=False)
+    assert len(pt.progs) == 3 and pt.progs[0].kinds.count("tile") >= 12 and pt.progs[2].kinds.count("tile") >= 10, [p.kinds for p in pt.progs]
+    assert not pt.tile_errors, pt.tile_errors
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "music_cont" if causal else "text_guided")
+    t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+    run_plan(model, pl, x, t, cond)
+    run_plan(model, pt, x, t, cond)
+    assert pt.take_error() == 0
+    assert len(pt.acts) == len(pl.acts)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(pt.acts, pl.acts)):
+        ra, rb = a.t[:, :, : a.C].float(), b.t[:, :, : b.C].float()
+        if not torch.isfinite(rb).all() or float(rb.abs().max()) == 0.0:
+            continue
+        assert torch.isfinite(ra).all(), f"activation {i}: a sentinel / non-finite value survived"
+        e = float((ra - rb).abs().max()) / float(rb.abs().max())
+        worst = max(worst, e)
+        assert e < 2e-5, f"activation {i} of {len(pt.acts)} (shape {tuple(a.t.shape)}): {e:.3e}"
+    first = pt.net_out.t.clone()
+    run_plan(model, pt, x, t, cond)
+    assert torch.equal(first, pt.net_out.t), "two runs of the tile-phase plan differ bitwise"
+    print(f"tile phases B={B} T={T} nrep={nrep}: {pt.n_launch} launches (launch path {pl.n_launch}), worst activation difference {worst:.2e}")
+
+
+def test_tile_phases_bf16_and_fp8_mode(full_bf16, full_fp8):
+    """bf16: close to the launch path; JEN1_FP8 mode: the tile phases stay bf16 (same long-level activations as the bf16 model)"""
+    B, T = 8, 1500
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "text_guided")
+    t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+    pt = tile_plan(full_bf16, B, T, 1, False)
+    pl = full_bf16.engine().plan(B, T, 1, False, deep=False)
+    run_plan(full_bf16, pl, x, t, cond)
+    run_plan(full_bf16, pt, x, t, cond)
+    assert pt.take_error() == 0 and len(pt.progs) == 3
+    for a, b in zip(pt.acts, pl.acts):
+        ra, rb = a.t[:, :, : a.C].float(), b.t[:, :, : b.C].float()
+        if not torch.isfinite(rb).all() or float(rb.abs().max()) == 0.0:
+            continue
+        assert float((ra - rb).abs().max()) / float(rb.abs().max()) < 6e-2
+    p8 = tile_plan(full_fp8, B, T, 1, False)
+    run_plan(full_fp8, p8, x, t, cond)
+    assert p8.take_error() == 0 and len(p8.progs) == 3
+    # program 0 (to_in, level 0 / 1 down) does not depend on the deep levels: identical in both modes
+    assert torch.equal(p8.taps["to_in"].t, pt.taps["to_in"].t) and torch.equal(p8.taps["down0"].t, pt.taps["down0"].t)
+    ra, rb = p8.net_out.t.float(), pt.net_out.t.float()
+    assert float((ra - rb).abs().max()) / float(rb.abs().max()) < 0.25

@@ -25,6 +25,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--general", action="store_true", help="one timestep per batch element (model.forward) instead of the sampler's table mode")
 ap.add_argument("--defs", default="", help="extra -D flags for the tuning build, space separated")
+ap.add_argument("--prog", type=int, default=-1, help="which persistent program of the plan (default: the one with the deep levels)")
 args = ap.parse_args()
 
 out_lib = os.path.join(ROOT, "gpurun_out", "libjen1_hip_prof.so")
@@ -57,7 +58,8 @@ t = np.array([(131 * i + 7) % 1000 for i in range(plan.n_t)], dtype=np.int64)
 if plan.table_mode:
     plan.t_in.copy_(tt(t))
 model._prepare(plan, tt(x), tt(t), tt(cond["cross_attn_cond"]), tt(cond["cross_attn_masks"]), [tt(cond["input_concat_cond"])], None)
-prog = plan.deep
+prog = plan.deep if args.prog < 0 else plan.progs[args.prog]
+print(f"# programs of the plan: {[(len(p_), p_.kinds.count('tile')) for p_ in plan.progs]}; profiling {'the deep one' if args.prog < 0 else args.prog}")
 n, nwg = len(prog), prog.nwg
 dbg = torch.zeros((n, nwg, 16), dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
@@ -66,9 +68,17 @@ if plan.table_mode:
 for rep in range(args.reps):
     plan.run(s)
 torch.cuda.synchronize()
+# the stamps are indexed by (phase, workgroup) of ONE program: run the step, then the chosen program alone on what the step left
+# in its input buffers
+for rep in range(3):
+    prog.poison(s)
+    prog.launch(s)
+torch.cuda.synchronize()
 assert lib.jen1_deep_debug_buffer(dbg.data_ptr()) == 0
 dbg.zero_()
-plan.run(s)
+prog.poison(s)
+torch.cuda.synchronize()
+prog.launch(s)
 torch.cuda.synchronize()
 assert prog.error() == 0
 d = dbg.cpu().numpy().astype(np.float64) * 0.01       # microseconds
@@ -134,3 +144,18 @@ for p in range(n):
     st = d[p, m]
     vals = [np.mean(st[:, b] - st[:, a]) for a, b in zip(order[:-1], order[1:])]
     print(f"{p:3d} " + " ".join(f"{v:5.2f}" for v in vals) + "  " + prog.labels[p][:70])
+
+# tile units: 0 start, 1 addresses ready (first polled round goes out), 7 weight ring / parameters requested, 2 statistics partials + first batch complete, 8 affine
+# tables, 11 tile staged, 3 barrier, 4 MFMA loop, 15 epilogue stores + output partials, 5 end
+order = [0, 1, 7, 2, 8, 11, 3, 4, 9, 10, 12, 13, 15, 5]
+print("# (4>9 epilogue addresses + residual, 9>10 bias / stores, 10>12 output partials -> LDS, 12>13 barrier, 13>15 partial store)")
+print("# tile: " + " ".join(f"{a}>{b}" for a, b in zip(order[:-1], order[1:])) + " | unit total, units")
+for p in range(n):
+    if not prog.labels[p].startswith("tile"):
+        continue
+    m = (d[p, :, 0] > 0) & (d[p, :, 5] > 0)
+    if not m.any():
+        continue
+    st = d[p, m]
+    vals = [np.mean(st[:, b] - st[:, a]) for a, b in zip(order[:-1], order[1:])]
+    print(f"{p:3d} " + " ".join(f"{v:5.2f}" for v in vals) + f" | {np.mean(st[:, 5] - st[:, 0]):5.2f} {int(m.sum()):4d}  " + prog.labels[p][:90])
