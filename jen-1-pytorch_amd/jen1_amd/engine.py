@@ -1486,8 +1486,8 @@ class Engine:
         self.deep_max_len = int(os.environ.get("JEN1_DEEP_MAX_LEN", "64"))
         # long levels as tile phases of persistent launches (jen1_deep_phase_tile): layers over at least this many positions.  Off by
         # default: measured at B = 8, T = 1500 the 26 tile phases of levels 0 - 1 take 10 - 11 us each against 9.8 us for the launches
-        # they replace (726 against 776 steps/s; DESIGN.md section 4b says where the time goes) -- kept as the bit-reproducible form of
-        # the long levels (fixed-order statistics without the extra launches of Plan(deterministic=True)) and as the base of further work
+        # they replace (726 against 776 steps/s; DESIGN.md section 4b says where the time goes) -- kept because the tile programs are
+        # bit-reproducible without the extra statistics launches of Plan(deterministic=True), and as the base of further work
         self.use_tile_phases = os.environ.get("JEN1_TILE_PHASES", "0") != "0"
         self.tile_phase_min_len = int(os.environ.get("JEN1_TILE_PHASE_MIN_LEN", "200"))
         self.deep_nb_max = int(os.environ.get("JEN1_DEEP_NB_MAX", "0"))

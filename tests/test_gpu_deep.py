@@ -402,9 +402,18 @@ def test_tile_phases_equal_launch_path_f32(full_f32, B, T, nrep, causal):
         e = float((ra - rb).abs().max()) / float(rb.abs().max())
         worst = max(worst, e)
         assert e < 2e-5, f"activation {i} of {len(pt.acts)} (shape {tuple(a.t.shape)}): {e:.3e}"
-    first = pt.net_out.t.clone()
-    run_plan(model, pt, x, t, cond)
-    assert torch.equal(first, pt.net_out.t), "two runs of the tile-phase plan differ bitwise"
+    # the tile programs themselves are bit-reproducible (fixed-order partial sums; the rest of this plan -- the pack kernel's
+    # statistics, the launches of the 94-position level -- still uses float atomics): each one alone, twice, on unchanged inputs
+    s = torch.cuda.current_stream().cuda_stream
+    for prog, out in ((pt.progs[0], pt.taps["down1"].t), (pt.progs[2], pt.net_out.t)):
+        res = []
+        for _ in range(2):
+            prog.poison(s)
+            prog.launch(s)
+            torch.cuda.synchronize()
+            res.append(out.clone())
+        assert pt.take_error() == 0
+        assert torch.isfinite(res[0].float()).all() and torch.equal(res[0], res[1]), "two runs of a tile program differ bitwise"
     print(f"tile phases B={B} T={T} nrep={nrep}: {pt.n_launch} launches (launch path {pl.n_launch}), worst activation difference {worst:.2e}")
 
 
@@ -426,7 +435,10 @@ def test_tile_phases_bf16_and_fp8_mode(full_bf16, full_fp8):
     p8 = tile_plan(full_fp8, B, T, 1, False)
     run_plan(full_fp8, p8, x, t, cond)
     assert p8.take_error() == 0 and len(p8.progs) == 3
-    # program 0 (to_in, level 0 / 1 down) does not depend on the deep levels: identical in both modes
-    assert torch.equal(p8.taps["to_in"].t, pt.taps["to_in"].t) and torch.equal(p8.taps["down0"].t, pt.taps["down0"].t)
+    # program 0 (to_in, level 0 / 1 down) does not depend on the deep levels: the same bf16 computation in both modes (up to the
+    # float atomics of the pack kernel's statistics)
+    for k in ("to_in", "down0"):
+        ra, rb = p8.taps[k].t.float(), pt.taps[k].t.float()
+        assert float((ra - rb).abs().max()) / float(rb.abs().max()) < 2e-2, k
     ra, rb = p8.net_out.t.float(), pt.net_out.t.float()
     assert float((ra - rb).abs().max()) / float(rb.abs().max()) < 0.25
