@@ -94,6 +94,7 @@ class UNetCFG1d(nn.Module):
         self._deterministic: Optional[bool] = None     # None: the engine's default (env JEN1_DETERMINISTIC)
         self._train_graph = None
         self._ctx_key = None
+        self._handle: Optional[int] = None             # torch.ops.jen1.unet_cfg_forward's handle of this module (jen1_amd/ops.py)
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     # ------------------------------------------------------------------ plumbing
@@ -193,8 +194,27 @@ class UNetCFG1d(nn.Module):
                 causal: Optional[bool] = False, dropout_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same contract as the reference forward (model.py:299-376); returns a fresh
         float32 [B, out_channels, T] tensor.  ``dropout_rows`` (bool[B]) optionally injects
-        the CFG-dropout draw that the reference takes from ``rand_bool`` (model.py:325)."""
+        the CFG-dropout draw that the reference takes from ``rand_bool`` (model.py:325).
+        The call goes through the dispatcher as ``torch.ops.jen1.unet_cfg_forward`` (jen1_amd/ops.py)."""
         assert features is None, "context_features is unused on the JEN-1 path"
+        from . import ops as _ops  # noqa: F401  (registers torch.ops.jen1.*)
+        if self._handle is None:
+            self._handle = _ops.register_model(self)
+        ctx = None
+        if self.spec.ctx_ch0:
+            assert channels_list is not None and channels_list[0] is not None, "Missing context"   # model.py:189
+            ctx = channels_list[0]
+        return torch.ops.jen1.unet_cfg_forward(self._handle, x, time, embedding, embedding_mask, ctx, float(embedding_scale),
+                                               float(embedding_mask_proba), bool(batch_cfg), bool(scale_cfg), float(scale_phi), bool(causal),
+                                               dropout_rows)
+
+    @torch.no_grad()
+    def _forward_impl(self, x: torch.Tensor, time: torch.Tensor, *, embedding: torch.Tensor,
+                      embedding_mask: Optional[torch.Tensor] = None, embedding_scale: float = 1.0,
+                      embedding_mask_proba: float = 0.0, batch_cfg: bool = False, scale_cfg: bool = False,
+                      scale_phi: float = 0.7, channels_list: Optional[Sequence[torch.Tensor]] = None,
+                      causal: Optional[bool] = False, dropout_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """what ``torch.ops.jen1.unet_cfg_forward`` runs: plans + launches on the engine"""
         eng = self.engine()
         lib = eng.lib
         B, _, T = x.shape

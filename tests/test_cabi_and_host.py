@@ -348,3 +348,43 @@ def test_deep_phase_planner_host_side(lib):
     slot1 = (C.c_int32 * 24).from_buffer(blobs, 1024 + 64 + 8 * 12 * 16 + 1 * 96)
     assert list(slot1)[:12] == [65 + 8 * j for j in range(8)] + [121] * 4
     assert list(slot1)[12:] == [32 + 256 * j for j in range(8)] + [32 + 256 * 7] * 4
+
+
+def test_torch_library_ops_are_registered_with_schemas_and_fake_impls():
+    """BASELINE north_star: "through PyTorch-ROCm custom ops".  Every op of jen1_amd/ops.py has a dispatcher schema and a fake
+    implementation (FakeTensor tracing needs no GPU and no extension call); UNetCFG1d.forward is the unet_cfg_forward op."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from jen1_amd import ops
+    from jen1_amd.config import tiny_model_config
+    from jen1_amd.model import UNetCFG1d
+    for name in ops.OPS:
+        op = getattr(torch.ops.jen1, name)
+        assert str(op.default._schema).startswith(f"jen1::{name}("), op.default._schema
+    sch = str(torch.ops.jen1.unet_cfg_forward.default._schema)
+    assert "Tensor x, Tensor time, Tensor embedding, Tensor? embedding_mask, Tensor? context" in sch and sch.endswith("-> Tensor")
+    cfg = tiny_model_config()
+    model = UNetCFG1d(**cfg, init_seed=None, device="cpu")
+    B, T = 2, 96
+    with FakeTensorMode():
+        x = torch.empty((B, model.spec.in_channels, T))
+        t = torch.empty((B,), dtype=torch.int64)
+        emb = torch.empty((B, model.spec.ctx_max_length, model.spec.ctx_features))
+        msk = torch.empty((B, model.spec.ctx_max_length))
+        ctx = torch.empty((B, model.spec.ctx_ch0, T))
+        y = model(x, t, embedding=emb, embedding_mask=msk, embedding_scale=0.8, batch_cfg=True, scale_cfg=True, channels_list=[ctx])
+        assert tuple(y.shape) == (B, model.spec.out_channels, T) and y.dtype == torch.float32
+        h = torch.empty((B, T, 64), dtype=torch.bfloat16)
+        g = torch.empty((64,))
+        yy, sums = torch.ops.jen1.group_norm(h, g, g, None, 64, 8, 1e-5, True)
+        assert yy.shape == h.shape and tuple(sums.shape) == (B, 8, 2)
+        yl, st = torch.ops.jen1.layer_norm(h, g, g, 1e-5)
+        assert yl.shape == h.shape and tuple(st.shape) == (B * T, 2)
+        assert torch.ops.jen1.activation(h, 0).shape == h.shape
+        assert tuple(torch.ops.jen1.cfg_combine(torch.empty((2 * B, T, 128)), 128, 0.8, True, 0.7).shape) == (B, 128, T)
+    # the real call without a GPU fails loudly (no CPU path)
+    import pytest
+    from jen1_amd.lib import Jen1HipError
+    with pytest.raises((Jen1HipError, RuntimeError)):
+        model(torch.zeros((B, model.spec.in_channels, T)), torch.zeros((B,), dtype=torch.int64),
+              embedding=torch.zeros((B, model.spec.ctx_max_length, model.spec.ctx_features)), channels_list=[torch.zeros((B, model.spec.ctx_ch0, T))])

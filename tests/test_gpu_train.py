@@ -809,3 +809,50 @@ def test_merged_task_passes_equal_one_pass_per_task(use_graph, monkeypatch):
     for k in p0:
         assert abs(p0[k] - p1[k]) <= 1e-5 * abs(p0[k]), k
     assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
+
+
+@pytest.mark.gpu
+def test_torch_library_training_ops_match_torch_autograd():
+    """torch.ops.jen1.group_norm / layer_norm / activation (jen1_amd/ops.py: dispatcher ops with registered autograd) against the
+    same operators in plain PyTorch float32 autograd: forward, data gradient and parameter gradients (float32 mode <= 1e-3)"""
+    import torch.nn.functional as F
+    from jen1_amd import ops  # noqa: F401
+    torch.manual_seed(0)
+    dev = "cuda"
+    B, Lx, C, G = 3, 37, 64, 8
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+    x = torch.randn((B, Lx, C), device=dev, requires_grad=True)
+    gamma = (torch.randn(C, device=dev) * 0.3 + 1).requires_grad_()
+    beta = (torch.randn(C, device=dev) * 0.3).requires_grad_()
+    film = torch.randn((B, 2 * C), device=dev, requires_grad=True)
+    w = torch.randn((B, Lx, C), device=dev)
+    y, _ = torch.ops.jen1.group_norm(x, gamma, beta, film, C, G, 1e-5, True)
+    (y * w).sum().backward()
+    got = [y.detach(), x.grad.clone(), gamma.grad.clone(), beta.grad.clone(), film.grad.clone()]
+    for t in (x, gamma, beta, film):
+        t.grad = None
+    xr = F.group_norm(x.transpose(1, 2), G, gamma, beta, 1e-5).transpose(1, 2)
+    yr = F.silu(xr * (film[:, None, :C] + 1) + film[:, None, C:])
+    (yr * w).sum().backward()
+    ref = [yr.detach(), x.grad, gamma.grad, beta.grad, film.grad]
+    for a, b, name in zip(got, ref, ("y", "dx", "dgamma", "dbeta", "dfilm")):
+        assert rel(a, b) < 1e-3, (name, rel(a, b))
+    for t in (x, gamma, beta, film):
+        t.grad = None
+    y, _ = torch.ops.jen1.layer_norm(x, gamma, beta, 1e-5)
+    y = torch.ops.jen1.activation(y, 0)
+    (y * w).sum().backward()
+    got = [y.detach(), x.grad.clone(), gamma.grad.clone(), beta.grad.clone()]
+    for t in (x, gamma, beta):
+        t.grad = None
+    yr = F.gelu(F.layer_norm(x, (C,), gamma, beta, 1e-5))
+    (yr * w).sum().backward()
+    for a, b, name in zip(got, [yr.detach(), x.grad, gamma.grad, beta.grad], ("y", "dx", "dgamma", "dbeta")):
+        assert rel(a, b) < 1e-3, (name, rel(a, b))
+    # the stacked CFG pair through the dispatcher op against the formula of model.py:362-369
+    net = torch.randn((2 * B, Lx, 128), device=dev)
+    out = torch.ops.jen1.cfg_combine(net, 128, 0.8, True, 0.7)
+    c, u = net[:B].transpose(1, 2), net[B:].transpose(1, 2)
+    cfg = u + (c - u) * 0.8
+    want = 0.7 * (cfg * (c.std(dim=1, keepdim=True) / cfg.std(dim=1, keepdim=True))) + 0.3 * cfg
+    assert rel(out, want) < 1e-4
