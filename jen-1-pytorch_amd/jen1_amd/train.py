@@ -71,6 +71,8 @@ class TrainRuntime:
         # keep a second, transposed compute copy of every weight so that the data gradient is K-contiguous on both operands
         self.dgrad_copies = os.environ.get("JEN1_TRAIN_DGRAD_COPIES", "1") == "1"
         self.wgrad_plain_rmw = os.environ.get("JEN1_TRAIN_WGRAD_RMW", "1") == "1"
+        # plain many-row linears (the text-context K/V projections) as library GEMMs (PlainLinearFn)
+        self.blas_linears = os.environ.get("JEN1_TRAIN_BLAS_LINEARS", "1") == "1"
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
 
@@ -343,11 +345,37 @@ def conv_transpose1d(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: in
     return ConvFn.apply(x, weight, bias, rt, ConvGeom("convT", k, stride, padding, Lin, Lout, ci, co))
 
 
+class PlainLinearFn(Function):
+    """A PLAIN bias-free linear with many rows and a big weight (the to_kv projections of the text context, blocks.py:428: 2B x 129
+    rows, 1024 -> 1024 / 2048): three library GEMMs (hipBLASLt behind torch.matmul) instead of jen1_train_gemm, whose 64 x 64 tiles
+    reach 37 - 80 TFLOP/s on these shapes (115 us for one weight gradient).  bf16 compute only: the weight gradient is rounded to
+    bf16 once (after a float32 accumulation over the rows) before it is added to the float32 ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, rt: TrainRuntime):
+        wp = rt.packed(weight, "linear", x2d.dtype)[0]              # [co][pad8(ci)] in the compute dtype
+        ctx.rt, ctx.weight, ctx.wp = rt, weight, wp
+        ctx.save_for_backward(x2d)
+        return torch.matmul(x2d, wp.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2d,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        gw = ctx.rt.grad_of(ctx.weight)
+        gw.add_(torch.matmul(dy.t(), x2d)[:, : gw.shape[1]])
+        dx = torch.matmul(dy, ctx.wp) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
 def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None) -> torch.Tensor:
     """nn.Linear on the last axis; x [..., pad8(in)] -> [..., pad8(out)]"""
     co, ci = weight.shape
     lead = x.shape[:-1]
     rows = x.numel() // x.shape[-1]
+    if (rt.blas_linears and bias is None and x.dtype == torch.bfloat16 and rows >= 1024 and ci >= 512 and co >= 512 and co % 8 == 0
+            and x.shape[-1] == pad8(ci)):
+        return PlainLinearFn.apply(x.reshape(rows, x.shape[-1]), weight, rt).view(*lead, co)
     y = ConvFn.apply(x.reshape(1, rows, x.shape[-1]), weight, bias, rt, ConvGeom("linear", 1, 1, 0, rows, rows, ci, co))
     return y.view(*lead, y.shape[-1])
 
