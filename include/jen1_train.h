@@ -73,6 +73,11 @@ int jen1_train_gemm(const jen1_gemm_args* args, void* stream);
 int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int ld, int groups, int dtype, void* stream);
 int jen1_gn_apply(const void* x, const float* sums, const float* gamma, const float* beta, const void* film, int film_ld,
                   void* y, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
+/* jen1_gn_sums + jen1_gn_apply as ONE launch where the shape allows (rows without padding, groups of 8 x 2^k channels, at least 32
+ * (batch element, group) pairs of at most 2^17 elements: a workgroup per pair computes the statistics and normalises, no scratch
+ * reset, no atomics); other shapes run the two calls.  sums[B][G][2] is written as by jen1_gn_sums (the backward pass reads it). */
+int jen1_gn_forward(const void* x, float* sums, const float* gamma, const float* beta, const void* film, int film_ld, void* y, int B,
+                    int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
 /* backward: P[B][C][4] and Gm[B][G][2] are float32 scratch (P is zeroed by the call); dgamma/dbeta are ACCUMULATED
  * (float32, the parameter's .grad); dfilm [B][2C] float32 is written (NULL when film is NULL). */
 int jen1_gn_backward(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,

@@ -1,6 +1,7 @@
 // Normalisation / pointwise / softmax kernels of the training path, forward and backward (include/jen1_train.h).
 // Channel-last rows x[row][c]; consecutive threads take consecutive channels, so every access is coalesced.
 // All of these are HBM-bound streaming kernels: one read of each input, one write of each output, float32 math.
+#include <cstdlib>
 #include "common.h"
 #include "jen1_train.h"
 
@@ -314,6 +315,155 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_vec_kernel(const GnDev g, void* 
   }
 }
 
+// ---------------------------------------------------------------- one launch per GroupNorm: a workgroup owns one (batch element, group).
+// The training pass is a chain of ~2 800 short launches; GroupNorm was 3 of them forward (scratch reset, sums, apply) and 4 backward
+// (scratch reset, per-channel sums, finish, dx) 125 times per pass.  A group is L x cpg elements (at most 48 000 on the bench shape):
+// one workgroup reads it twice (the second read is an L2 hit) and needs no scratch, no atomics on the statistics and no second launch.
+// Thread layout: vector column v = tid % VPG (8 channels), rows tid / VPG, tid / VPG + NT / VPG, ...  (VPG = cpg / 8, a power of two).
+__device__ __forceinline__ float block_sum(float v, float* red) {       // all threads get the sum; fixed order
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_fwd_fused_kernel(const GnDev g, float* __restrict__ sums_out, int lvpg) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / g.groups, grp = blockIdx.x - b * g.groups;
+  const int VPG = 1 << lvpg;
+  const int v = threadIdx.x & (VPG - 1), r0 = threadIdx.x >> lvpg, RT = NT >> lvpg;
+  const int c0 = grp * g.cpg + v * 8;
+  const T* x = reinterpret_cast<const T*>(g.x) + (long long)b * g.L * g.C + c0;
+  T* y = reinterpret_cast<T*>(g.y) + (long long)b * g.L * g.C + c0;
+  float s = 0.f, ss = 0.f;
+  for (int t = r0; t < g.L; t += RT) {
+    float w[8];
+    load8(x + (long long)t * g.C, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s += w[j]; ss += w[j] * w[j]; }
+  }
+  s = block_sum(s, red);
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) { sums_out[2 * (long long)blockIdx.x] = s; sums_out[2 * (long long)blockIdx.x + 1] = ss; }
+  const float mean = s * g.inv_count;
+  const float rstd = 1.0f / sqrtf(fmaxf(ss * g.inv_count - mean * mean, 0.f) + g.eps);
+  float ga[8], be[8], sc[8], sh[8];
+  load8(g.gamma + c0, ga);
+  load8(g.beta + c0, be);
+  const T* film = reinterpret_cast<const T*>(g.film);
+  if (film != nullptr) {
+    load8(film + (long long)b * g.film_ld + c0, sc);
+    load8(film + (long long)b * g.film_ld + g.C + c0, sh);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                       // y = x A + S
+    float A = rstd * ga[j], S = be[j] - mean * A;
+    if (film != nullptr) { A *= sc[j] + 1.0f; S = S * (sc[j] + 1.0f) + sh[j]; }
+    ga[j] = A; be[j] = S;
+  }
+  for (int t = r0; t < g.L; t += RT) {
+    float w[8];
+    load8(x + (long long)t * g.C, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float n = w[j] * ga[j] + be[j];
+      w[j] = (g.flags & 1) ? silu_precise(n) : n;
+    }
+    store8(y + (long long)t * g.C, w);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const GnDev g, void* dx_, int lvpg) {
+  extern __shared__ float lds[];                       // [NT][32] per-thread partials | [cpg][4] | [4]
+  const int b = blockIdx.x / g.groups, grp = blockIdx.x - b * g.groups;
+  const int VPG = 1 << lvpg;
+  const int v = threadIdx.x & (VPG - 1), r0 = threadIdx.x >> lvpg, RT = NT >> lvpg;
+  const int c0 = grp * g.cpg + v * 8;
+  const long long base = (long long)b * g.L * g.C + c0;
+  const T* x = reinterpret_cast<const T*>(g.x) + base;
+  const T* dy = reinterpret_cast<const T*>(g.dy) + base;
+  T* dx = reinterpret_cast<T*>(dx_) + base;
+  const float* sm = g.sums + 2 * (long long)blockIdx.x;
+  const float mean = sm[0] * g.inv_count;
+  const float rstd = 1.0f / sqrtf(fmaxf(sm[1] * g.inv_count - mean * mean, 0.f) + g.eps);
+  float ga[8], be[8], s1[8], s0[8];
+  load8(g.gamma + c0, ga);
+  load8(g.beta + c0, be);
+  const T* film = reinterpret_cast<const T*>(g.film);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 1.0f; s0[j] = 0.f; }
+  if (film != nullptr) {
+    load8(film + (long long)b * g.film_ld + c0, s1);
+    load8(film + (long long)b * g.film_ld + g.C + c0, s0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] += 1.0f;
+  }
+  // P[c] = (sum dn, sum dn xhat, sum df n, sum df) over the rows
+  float p[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { p[j][0] = p[j][1] = p[j][2] = p[j][3] = 0.f; }
+  for (int t = r0; t < g.L; t += RT) {
+    float w[8], d[8];
+    load8(x + (long long)t * g.C, w);
+    load8(dy + (long long)t * g.C, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (w[j] - mean) * rstd;
+      const float n = xh * ga[j] + be[j];
+      float df = d[j];
+      if (g.flags & 1) df *= silu_grad(n * s1[j] + s0[j]);
+      const float dn = df * s1[j];
+      p[j][0] += dn; p[j][1] += dn * xh; p[j][2] += df * n; p[j][3] += df;
+    }
+  }
+  float* part = lds + (size_t)threadIdx.x * 32;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(part + 4 * j) = make_float4(p[j][0], p[j][1], p[j][2], p[j][3]);
+  __syncthreads();
+  float* Pl = lds + (size_t)NT * 32;                   // [cpg][4]
+  float* red = Pl + (size_t)g.cpg * 4;
+  const int rows_active = g.L < RT ? g.L : RT;
+  for (int o = threadIdx.x; o < g.cpg * 4; o += NT) {
+    const int c = o >> 2, k = o & 3, vv = c >> 3, j = c & 7;
+    float a = 0.f;
+    for (int r = 0; r < rows_active; ++r) a += lds[(size_t)((r << lvpg) + vv) * 32 + 4 * j + k];      // fixed order
+    Pl[o] = a;
+  }
+  __syncthreads();
+  float m1 = 0.f, m2 = 0.f;
+  if ((int)threadIdx.x < g.cpg) {
+    const int c = grp * g.cpg + threadIdx.x;
+    const float4 P = *reinterpret_cast<const float4*>(Pl + 4 * threadIdx.x);
+    const float gam = g.gamma[c];
+    m1 = gam * P.x;
+    m2 = gam * P.y;
+    if (g.dfilm != nullptr) {
+      g.dfilm[(long long)b * 2 * g.C + c] = P.z;
+      g.dfilm[(long long)b * 2 * g.C + g.C + c] = P.w;
+    }
+    atomicAdd(g.dgamma + c, P.y);                      // (the other batch elements add to the same entry)
+    atomicAdd(g.dbeta + c, P.x);
+  }
+  m1 = block_sum(m1, red) * g.inv_count;
+  m2 = block_sum(m2, red) * g.inv_count;
+  for (int t = r0; t < g.L; t += RT) {
+    float w[8], d[8];
+    load8(x + (long long)t * g.C, w);
+    load8(dy + (long long)t * g.C, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (w[j] - mean) * rstd;
+      float df = d[j];
+      if (g.flags & 1) df *= silu_grad((xh * ga[j] + be[j]) * s1[j] + s0[j]);
+      w[j] = rstd * (df * s1[j] * ga[j] - m1 - xh * m2);
+    }
+    store8(dx + (long long)t * g.C, w);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void act_fwd_vec_kernel(const void* x_, void* y_, long long n8, int mode) {
   const T* x = reinterpret_cast<const T*>(x_);
@@ -560,6 +710,40 @@ extern "C" int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int
   return 0;
 }
 
+namespace {
+// the one-launch form: vector-aligned rows, a power-of-two number of 8-channel vectors per group, enough (batch element, group) pairs
+// to fill the chip reasonably and a group small enough for one workgroup
+bool gn_fused_ok(const void* x, const void* y, const void* dy, const float* gamma, const float* beta, const void* film, int film_ld, int B, int L,
+                 int C, int ld, int groups, int& lvpg) {
+  const int cpg = C / groups;
+  if (!vec_ok(x, y, dy, C, ld, cpg) || ((((uintptr_t)gamma | (uintptr_t)beta) & 15) != 0)) return false;
+  if (film != nullptr && ((film_ld & 7) != 0 || ((uintptr_t)film & 15) != 0)) return false;
+  const int vpg = cpg / 8;
+  if ((vpg & (vpg - 1)) != 0 || vpg > NT) return false;
+  lvpg = 0;
+  while ((1 << lvpg) < vpg) ++lvpg;
+  if (getenv("JEN1_GN_FUSED") && atoi(getenv("JEN1_GN_FUSED")) == 0) return false;
+  return B * groups >= 32 && (long long)L * cpg <= (1 << 17);
+}
+}  // namespace
+
+extern "C" int jen1_gn_forward(const void* x, float* sums, const float* gamma, const float* beta, const void* film, int film_ld, void* y, int B,
+                               int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_gn_forward")) return 1;
+  GnDev g;
+  if (gn_fill(g, "jen1_gn_forward", x, sums, gamma, beta, film, film_ld, B, L, C, ld, groups, eps, flags)) return 1;
+  JEN1_CHECK(y != nullptr, "jen1_gn_forward: y is NULL");
+  int lvpg = 0;
+  if (!gn_fused_ok(x, y, nullptr, gamma, beta, film, film_ld, B, L, C, ld, groups, lvpg)) {
+    if (jen1_gn_sums(x, sums, B, L, C, ld, groups, dtype, stream)) return 1;
+    return jen1_gn_apply(x, sums, gamma, beta, film, film_ld, y, B, L, C, ld, groups, eps, flags, dtype, stream);
+  }
+  g.y = y;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, gn_fwd_fused_kernel, dim3(B * groups), g, sums, lvpg);
+  return 0;
+}
+
 extern "C" int jen1_gn_apply(const void* x, const float* sums, const float* gamma, const float* beta, const void* film, int film_ld,
                              void* y, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_gn_apply")) return 1;
@@ -587,6 +771,14 @@ extern "C" int jen1_gn_backward(const void* dy, const void* x, const float* sums
   JEN1_CHECK((film == nullptr) == (dfilm == nullptr), "jen1_gn_backward: dfilm must be given exactly when film is");
   g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = dfilm;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int lvpg = 0;
+  if (gn_fused_ok(x, dx, dy, gamma, beta, film, film_ld, B, L, C, ld, groups, lvpg)) {
+    const size_t lds = ((size_t)NT * 32 + (size_t)(C / groups) * 4 + 4) * sizeof(float);
+    if (dtype == JEN1_F32) hipLaunchKernelGGL(gn_bwd_fused_kernel<float>, dim3(B * groups), dim3(NT), lds, s, g, dx, lvpg);
+    else hipLaunchKernelGGL(gn_bwd_fused_kernel<bf16_t>, dim3(B * groups), dim3(NT), lds, s, g, dx, lvpg);
+    JEN1_HIP(hipGetLastError());
+    return 0;
+  }
   if (zero2(P, 4 * B * C, nullptr, 0, s)) return 1;
   int CT, rpb, gx, gy;
   red_geom(C, L, CT, rpb, gx, gy);

@@ -395,10 +395,9 @@ class GroupNormFn(Function):
         if film is not None:
             film = film.contiguous()
             assert film.dtype == x.dtype and film.shape[-1] >= 2 * C
-        L.check(rt.lib.jen1_gn_sums(x.data_ptr(), sums.data_ptr(), B, Lx, C, ld, groups, dt, s), "jen1_gn_sums")
-        L.check(rt.lib.jen1_gn_apply(x.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                     None if film is None else film.data_ptr(), 0 if film is None else film.shape[-1],
-                                     y.data_ptr(), B, Lx, C, ld, groups, float(eps), 1 if silu else 0, dt, s), "jen1_gn_apply")
+        L.check(rt.lib.jen1_gn_forward(x.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                       None if film is None else film.data_ptr(), 0 if film is None else film.shape[-1],
+                                       y.data_ptr(), B, Lx, C, ld, groups, float(eps), 1 if silu else 0, dt, s), "jen1_gn_forward")
         ctx.rt, ctx.C, ctx.groups, ctx.eps, ctx.silu, ctx.gamma, ctx.beta = rt, C, groups, eps, silu, gamma, beta
         ctx.has_film = film is not None
         ctx.save_for_backward(x, sums, film if film is not None else x.new_empty(0))
