@@ -122,6 +122,12 @@ int jen1_lstm_layer(const float* gin, const void* whh_t, const void* skip, void*
 int jen1_lstm_layer_multi(const float* gin, const void* whh, const void* skip, void* y, float* hbuf, uint32_t* counters, int B, int T,
                           int H, int ld_y, int dtype, void* stream);
 
+/* --- the skip concat of the up path (blocks.py:732-734: torch.cat([x, skip * 2^-1/2], dim=channels)) on channel-last rows ---
+ * jen1_concat2: out[row] = [a[row][0..Ca) | scale_b * b[row][0..Cb)];  jen1_split2 (its backward): da[row] = d[row][0..Ca),
+ * db[row] = scale_b * d[row][Ca..Ca+Cb).  Rows are dense (pitch = channel count), channel counts multiples of 8. */
+int jen1_concat2(const void* a, const void* b, void* out, int64_t rows, int Ca, int Cb, float scale_b, int dtype, void* stream);
+int jen1_split2(const void* d, void* da, void* db, int64_t rows, int Ca, int Cb, float scale_b, int dtype, void* stream);
+
 /* out[c] += sum_rows x[row][c]  (bias gradients), float32 accumulate */
 int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream);
 

@@ -575,8 +575,25 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const void* dy_, const void*
     n = 0;
     for (int c = lane; c < C; c += 64, ++n) xo[c] = (T)(rstd * (dh[n] - s1 - xh[n] * s2));
   }
+  // the four waves of the block meet in LDS, then ONE atomic per column and block (512 waves adding 2 C columns each was the
+  // kernel's time: 26 us at 2 064 rows x 1 024 columns)
+  __shared__ float colg[(NT / 64 - 1) * 64 * LN_MAXPL], colb[(NT / 64 - 1) * 64 * LN_MAXPL];
+  const int w = threadIdx.x >> 6;
   int n = 0;
-  for (int c = lane; c < C; c += 64, ++n) { atomicAdd(dgamma + c, ag[n]); atomicAdd(dbeta + c, ab[n]); }
+  if (w > 0) {
+    for (int c = lane; c < C; c += 64, ++n) { colg[(w - 1) * 64 * LN_MAXPL + c] = ag[n]; colb[(w - 1) * 64 * LN_MAXPL + c] = ab[n]; }
+  }
+  __syncthreads();
+  if (w == 0) {
+    n = 0;
+    for (int c = lane; c < C; c += 64, ++n) {
+      float a = ag[n], b2 = ab[n];
+#pragma unroll
+      for (int k = 0; k < NT / 64 - 1; ++k) { a += colg[k * 64 * LN_MAXPL + c]; b2 += colb[k * 64 * LN_MAXPL + c]; }
+      atomicAdd(dgamma + c, a);
+      atomicAdd(dbeta + c, b2);
+    }
+  }
 }
 
 // ---------------------------------------------------------------- pointwise
@@ -811,7 +828,7 @@ extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stat
   JEN1_CHECK(rows >= 1 && C >= 1 && ld >= C && C <= 64 * LN_MAXPL, "jen1_ln_backward: bad shape rows=%d C=%d ld=%d", rows, C, ld);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int blocks = (rows + 3) / 4;
-  if (blocks > 128) blocks = 128;           // each wave keeps column sums over many rows: few atomics
+  if (blocks > 64) blocks = 64;             // each wave keeps column sums over many rows: few atomics
   DISPATCH(dtype, ln_bwd_kernel, dim3(blocks), dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
   return 0;
 }
@@ -865,6 +882,71 @@ extern "C" int jen1_colsum(const void* x, float* out, int rows, int C, int ld, i
   int CT, rpb, gx, gy;
   red_geom(C, rows, CT, rpb, gx, gy);
   DISPATCH(dtype, colsum_kernel, dim3(gx, gy), x, out, rows, C, ld, CT, rpb);
+  return 0;
+}
+
+namespace {
+// out[row] = [a[row] | scale * b[row]]  (the skip concat of the up path, blocks.py:732-734) and its transpose: one launch each
+// instead of a scale launch + a concat launch forward and two strided copies + a scale launch backward
+template <typename T>
+__global__ __launch_bounds__(NT) void concat2_kernel(const void* a_, const void* b_, void* out_, long long rows, int Ca, int Cb, float scale) {
+  const T* a = reinterpret_cast<const T*>(a_);
+  const T* b = reinterpret_cast<const T*>(b_);
+  T* out = reinterpret_cast<T*>(out_);
+  const int va = Ca >> 3, vb = Cb >> 3, vt = va + vb;
+  const long long total = rows * vt;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const long long row = i / vt;
+    const int v = (int)(i - row * vt);
+    float w[8];
+    if (v < va) {
+      load8(a + row * Ca + v * 8, w);
+    } else {
+      load8(b + row * Cb + (v - va) * 8, w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] *= scale;
+    }
+    store8(out + row * (Ca + Cb) + v * 8, w);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void split2_kernel(const void* d_, void* da_, void* db_, long long rows, int Ca, int Cb, float scale) {
+  const T* d = reinterpret_cast<const T*>(d_);
+  T* da = reinterpret_cast<T*>(da_);
+  T* db = reinterpret_cast<T*>(db_);
+  const int va = Ca >> 3, vb = Cb >> 3, vt = va + vb;
+  const long long total = rows * vt;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const long long row = i / vt;
+    const int v = (int)(i - row * vt);
+    float w[8];
+    load8(d + row * (Ca + Cb) + v * 8, w);
+    if (v < va) {
+      store8(da + row * Ca + v * 8, w);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] *= scale;
+      store8(db + row * Cb + (v - va) * 8, w);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int jen1_concat2(const void* a, const void* b, void* out, int64_t rows, int Ca, int Cb, float scale_b, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_concat2")) return 1;
+  JEN1_CHECK(a && b && out && rows >= 1 && Ca >= 8 && Cb >= 8 && (Ca & 7) == 0 && (Cb & 7) == 0, "jen1_concat2: channel counts must be positive multiples of 8");
+  JEN1_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "jen1_concat2: pointers must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, concat2_kernel, dim3(ew_grid(rows * ((Ca + Cb) / 8))), a, b, out, (long long)rows, Ca, Cb, scale_b);
+  return 0;
+}
+
+extern "C" int jen1_split2(const void* d, void* da, void* db, int64_t rows, int Ca, int Cb, float scale_b, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_split2")) return 1;
+  JEN1_CHECK(d && da && db && rows >= 1 && Ca >= 8 && Cb >= 8 && (Ca & 7) == 0 && (Cb & 7) == 0, "jen1_split2: channel counts must be positive multiples of 8");
+  JEN1_CHECK((((uintptr_t)d | (uintptr_t)da | (uintptr_t)db) & 15) == 0, "jen1_split2: pointers must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, split2_kernel, dim3(ew_grid(rows * ((Ca + Cb) / 8))), d, da, db, (long long)rows, Ca, Cb, scale_b);
   return 0;
 }
 

@@ -491,6 +491,36 @@ class ActFn(Function):
         return dx, None, None
 
 
+class ConcatScaleFn(Function):
+    """torch.cat([a, b * scale], dim=-1) on dense channel-last rows (the skip concat of the up path, blocks.py:732-734)"""
+
+    @staticmethod
+    def forward(ctx, a, b, rt: TrainRuntime, scale: float):
+        a, b = a.contiguous(), b.contiguous()
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        out = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=a.dtype, device=a.device)
+        L.check(rt.lib.jen1_concat2(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel() // Ca, Ca, Cb, float(scale), rt.dt_of(a), rt.stream()),
+                "jen1_concat2")
+        ctx.rt, ctx.scale, ctx.Ca, ctx.Cb = rt, scale, Ca, Cb
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        rt, Ca, Cb = ctx.rt, ctx.Ca, ctx.Cb
+        da = torch.empty(d.shape[:-1] + (Ca,), dtype=d.dtype, device=d.device)
+        db = torch.empty(d.shape[:-1] + (Cb,), dtype=d.dtype, device=d.device)
+        L.check(rt.lib.jen1_split2(d.data_ptr(), da.data_ptr(), db.data_ptr(), d.numel() // (Ca + Cb), Ca, Cb, float(ctx.scale), rt.dt_of(d),
+                                   rt.stream()), "jen1_split2")
+        return da, db, None, None
+
+
+def concat_scale(rt, a, b, scale: float):
+    if a.shape[-1] % 8 or b.shape[-1] % 8 or a.dtype != b.dtype:
+        return torch.cat([a, b * scale], dim=-1)
+    return ConcatScaleFn.apply(a, b, rt, scale)
+
+
 def gelu(rt, x):
     return ActFn.apply(x, rt, 0)
 
@@ -510,7 +540,11 @@ def _rows_view(t: torch.Tensor) -> Tuple[int, int]:
 
 class AttentionCoreFn(Function):
     @staticmethod
-    def forward(ctx, q, k, v, rt: TrainRuntime, heads: int, causal: bool):
+    def forward(ctx, q, kv, rt: TrainRuntime, heads: int, causal: bool):
+        """kv: [B, Nk, 2 C] = to_kv's output (K | V): the gradient comes back as ONE tensor (two column windows written by the data-gradient
+        GEMMs) instead of two slice gradients that autograd pads with zeros and adds"""
+        mid = kv.shape[-1] // 2
+        k, v = kv[..., :mid], kv[..., mid:]
         B, Nq, C = q.shape
         Nk = k.shape[1]
         d = C // heads
@@ -531,12 +565,14 @@ class AttentionCoreFn(Function):
         rt.gemm(_operand(P.data_ptr(), ldS, 1, zs0=Nq * ldS), _operand(vp, 1, ldv, zs0=Nk * ldv, zs1=d, zdiv=heads),
                 O.data_ptr(), Nq, d, Nk, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nq * C, c_zs1=d, c_zdiv=heads)
         ctx.rt, ctx.heads, ctx.scale = rt, heads, scale
-        ctx.save_for_backward(q, k, v, P)
+        ctx.save_for_backward(q, kv, P)
         return O
 
     @staticmethod
     def backward(ctx, dO):
-        q, k, v, P = ctx.saved_tensors
+        q, kv, P = ctx.saved_tensors
+        mid = kv.shape[-1] // 2
+        k, v = kv[..., :mid], kv[..., mid:]
         rt, heads, scale = ctx.rt, ctx.heads, ctx.scale
         dO = dO.contiguous()
         B, Nq, C = q.shape
@@ -551,8 +587,8 @@ class AttentionCoreFn(Function):
         dP = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
         dS = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
         dQ = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
-        dK = torch.empty((B, Nk, C), dtype=q.dtype, device=q.device)
-        dV = torch.empty((B, Nk, C), dtype=q.dtype, device=q.device)
+        dKV = torch.empty((B, Nk, 2 * C), dtype=q.dtype, device=q.device)
+        esz = dKV.element_size()
         o_do = lambda ld_r, ld_k: _operand(dO.data_ptr(), ld_r, ld_k, zs0=Nq * C, zs1=d, zdiv=heads)
         # dP = dO V^T
         rt.gemm(o_do(C, 1), _operand(vp, ldv, 1, zs0=Nk * ldv, zs1=d, zdiv=heads), dP.data_ptr(), Nq, Nk, d, dtype=dt, batches=Z,
@@ -563,14 +599,14 @@ class AttentionCoreFn(Function):
         rt.gemm(_operand(dS.data_ptr(), ldS, 1, zs0=Nq * ldS), _operand(kp, 1, ldk, zs0=Nk * ldk, zs1=d, zdiv=heads),
                 dQ.data_ptr(), Nq, d, Nk, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nq * C, c_zs1=d, c_zdiv=heads, alpha=scale)
         rt.gemm(_operand(dS.data_ptr(), 1, ldS, zs0=Nq * ldS), _operand(qp, 1, ldq, zs0=Nq * ldq, zs1=d, zdiv=heads),
-                dK.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nk * C, c_zs1=d, c_zdiv=heads, alpha=scale)
+                dKV.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads, alpha=scale)
         rt.gemm(_operand(P.data_ptr(), 1, ldS, zs0=Nq * ldS), o_do(1, C),
-                dV.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=C, c_zs0=Nk * C, c_zs1=d, c_zdiv=heads)
-        return dQ, dK, dV, None, None, None
+                dKV.data_ptr() + C * esz, Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads)
+        return dQ, dKV, None, None, None
 
 
-def attention_core(rt, q, k, v, heads: int, causal: bool):
-    return AttentionCoreFn.apply(q, k, v, rt, heads, causal)
+def attention_core(rt, q, kv, heads: int, causal: bool):
+    return AttentionCoreFn.apply(q, kv.contiguous(), rt, heads, causal)
 
 
 # =====================================================================================================================
@@ -663,11 +699,9 @@ class TrainGraph:
         q = linear(rt, xn, p[f"{n}.to_q.weight"])
         kv = linear(rt, cn, p[f"{n}.to_kv.weight"])
         mid = kv.shape[-1] // 2
-        k, v = kv[..., :mid], kv[..., mid:]
         if context_mask is not None:
-            m = context_mask.to(kv.dtype)[:, :, None]
-            k, v = k * m, v * m
-        o = attention_core(rt, q, k, v, heads, causal)
+            kv = kv * context_mask.to(kv.dtype)[:, :, None]          # the padding mask multiplies K and V (one launch for both halves)
+        o = attention_core(rt, q, kv, heads, causal)
         return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"])
 
     def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool) -> torch.Tensor:
@@ -728,7 +762,7 @@ class TrainGraph:
             skips = skips_list.pop()
             for r in u.blocks:
                 a, sk = self._crop_pair(h, skips.pop())                 # blocks.py:732-734
-                h = torch.cat([a, sk * self.skip_scale], dim=-1)
+                h = concat_scale(rt, a, sk, self.skip_scale)
                 h = self.res_block(r, h, smap, causal)
             if u.transformer:
                 h = self.transformer(u.transformer, h, embedding, embedding_mask, causal)

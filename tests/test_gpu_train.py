@@ -252,11 +252,8 @@ def test_attention_core_forward_backward(rts, mode, B, Nq, Nk, C, heads, causal,
     o_ref.backward(do)
     qd = q.detach().to("cuda", rt.tdtype).requires_grad_()
     kvd = kv.detach().to("cuda", rt.tdtype).requires_grad_()
-    if strided:
-        kd, vd = kvd[..., :C], kvd[..., C:]
-    else:
-        kd, vd = kvd[..., :C] * 1.0, kvd[..., C:] * 1.0
-    o = TR.attention_core(rt, qd, kd, vd, heads, causal)
+    # K | V travel as ONE tensor (to_kv's output); ``strided``: as it is / as the product of an elementwise op (the padding mask)
+    o = TR.attention_core(rt, qd, kvd if strided else kvd * 1.0, heads, causal)
     o.backward(do.to("cuda", rt.tdtype))
     torch.cuda.synchronize()
     tol = _tol(mode)
@@ -856,3 +853,24 @@ def test_torch_library_training_ops_match_torch_autograd():
     cfg = u + (c - u) * 0.8
     want = 0.7 * (cfg * (c.std(dim=1, keepdim=True) / cfg.std(dim=1, keepdim=True))) + 0.3 * cfg
     assert rel(out, want) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_concat_scale_forward_backward(rts, mode):
+    """jen1_concat2 / jen1_split2: torch.cat([a, b * 2^-1/2], -1) of the up path (blocks.py:732-734) and its gradient"""
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    torch.manual_seed(3)
+    a = torch.randn((3, 37, 64), device="cuda").to(rt.tdtype).requires_grad_()
+    b = torch.randn((3, 37, 128), device="cuda").to(rt.tdtype).requires_grad_()
+    w = torch.randn((3, 37, 192), device="cuda").to(rt.tdtype)
+    out = TR.concat_scale(rt, a, b, 2 ** -0.5)
+    (out.float() * w.float()).sum().backward()
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    ref = torch.cat([a, b * 2 ** -0.5], dim=-1)
+    (ref.float() * w.float()).sum().backward()
+    tol = 1e-6 if mode == "f32" else 1e-2
+    assert float((out.float() - ref.float()).abs().max()) <= tol
+    assert float((ga.float() - a.grad.float()).abs().max()) <= tol and float((gb.float() - b.grad.float()).abs().max()) <= tol
