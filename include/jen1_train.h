@@ -63,6 +63,8 @@ typedef struct jen1_gemm_args {
   int32_t reserved;
   float* rowsum;           /* taps_in_z only: rowsum[m] += alpha * sum_k A(m, tap 0, k)  (the bias gradient, blocks.py:52
                               nn.Conv1d bias, riding on the weight gradient); float32 [M] or NULL */
+  const void* residual;    /* NULL, or a tensor of C's dtype and indexing that is added in the epilogue (the residual of a
+                              ResnetBlock1d / transformer sub-block, blocks.py:231, :486-488); not with the atomic epilogue */
 } jen1_gemm_args;
 
 int jen1_train_gemm(const jen1_gemm_args* args, void* stream);
@@ -104,6 +106,8 @@ int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, in
 /* dst[i] = (dtype) src[i]; src[i] = 0  for i < n (n a multiple of 4): hands the float32 accumulator of a split-K GEMM
  * over in the compute dtype and leaves it zeroed for the next launch of the stream. */
 int jen1_convert_clear(float* src, void* dst, int64_t n, int dtype, void* stream);
+/* the same with a residual: dst[i] = (dtype)(src[i] + res[i]) (res in `dtype`) */
+int jen1_convert_clear_add(float* src, void* dst, const void* res, int64_t n, int dtype, void* stream);
 
 /* --- Encodec pieces either side of the sampler (generation.py:113, :130, :145-150) ---
  * jen1_rvq_decode: ResidualVectorQuantizer.decode -- out[b][d][t] = sum_q tables[q][codes[q][b][t]][d]

@@ -28,6 +28,7 @@ struct GemmDev {
   void* c;
   const float* bias;
   float* rowsum;     // += sum_k A(m, tap 0, k) for every m (bias gradient riding on the weight gradient), or NULL
+  const void* res;   // residual added in the epilogue (C's dtype and indexing), or NULL
   long long ldc_m, ldc_n, c_tap_stride;
   long long a_zs0, a_zs1, b_zs0, b_zs1, c_zs0, c_zs1;
   int a_zdiv, b_zdiv, c_zdiv;
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
         } else {
           T* cp = reinterpret_cast<T*>(cb) + off;
           if (g.accumulate) v += (float)*cp;
+          if (g.res) v += (float)reinterpret_cast<const T*>(g.res)[off];
           *cp = (T)v;
         }
       }
@@ -447,6 +449,8 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   g.b = to_dev(a.b, a.N);
   g.c = a.c; g.bias = reinterpret_cast<const float*>(a.bias);
   g.rowsum = reinterpret_cast<float*>(a.rowsum);
+  g.res = a.residual;
+  JEN1_CHECK(a.residual == nullptr || (!a.atomic && !a.c_f32), "train_gemm: a residual needs the plain epilogue in C's dtype");
   JEN1_CHECK(a.rowsum == nullptr || a.taps_in_z, "train_gemm: rowsum rides on the per-tap (weight gradient) form only");
   g.ldc_m = a.ldc_m; g.ldc_n = a.ldc_n; g.c_tap_stride = a.c_tap_stride;
   g.a_zs0 = a.a.zs0; g.a_zs1 = a.a.zs1; g.b_zs0 = a.b.zs0; g.b_zs1 = a.b.zs1; g.c_zs0 = a.c_zs0; g.c_zs1 = a.c_zs1;

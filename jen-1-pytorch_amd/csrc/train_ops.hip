@@ -682,6 +682,20 @@ __global__ __launch_bounds__(NT) void convert_clear_kernel(float* __restrict__ s
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(NT) void convert_clear_add_kernel(float* __restrict__ src, void* dst_, const void* res_, long long n4) {
+  T* dst = reinterpret_cast<T*>(dst_);
+  const T* res = reinterpret_cast<const T*>(res_);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<float4*>(src)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float r[4];
+    load4(res + 4 * i, r);
+    const float o[4] = {v.x + r[0], v.y + r[1], v.z + r[2], v.w + r[3]};
+    store4(dst + 4 * i, o);
+  }
+}
+
 #define DISPATCH(dtype, KERNEL, grid, ...)                                                        \
   do {                                                                                            \
     if ((dtype) == JEN1_F32) hipLaunchKernelGGL(KERNEL<float>, grid, dim3(NT), 0, s, __VA_ARGS__); \
@@ -882,6 +896,14 @@ extern "C" int jen1_colsum(const void* x, float* out, int rows, int C, int ld, i
   int CT, rpb, gx, gy;
   red_geom(C, rows, CT, rpb, gx, gy);
   DISPATCH(dtype, colsum_kernel, dim3(gx, gy), x, out, rows, C, ld, CT, rpb);
+  return 0;
+}
+
+extern "C" int jen1_convert_clear_add(float* src, void* dst, const void* res, int64_t n, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_convert_clear_add")) return 1;
+  JEN1_CHECK(src && dst && res && n >= 4 && (n & 3) == 0, "jen1_convert_clear_add: n must be a positive multiple of 4");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, convert_clear_add_kernel, dim3(ew_grid(n / 4)), src, dst, res, (long long)(n / 4));
   return 0;
 }
 

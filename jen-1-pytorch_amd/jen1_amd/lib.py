@@ -89,7 +89,7 @@ class GemmArgs(C.Structure):
                 ("c_zs0", c_int64), ("c_zs1", c_int64), ("ldc_m", c_int64), ("ldc_n", c_int64), ("c_tap_stride", c_int64),
                 ("c_zdiv", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("taps", c_int), ("batches", c_int),
                 ("taps_in_z", c_int), ("splitk", c_int), ("atomic", c_int), ("accumulate", c_int), ("c_f32", c_int),
-                ("dtype", c_int), ("alpha", c_float), ("reserved", c_int), ("rowsum", c_void_p)]
+                ("dtype", c_int), ("alpha", c_float), ("reserved", c_int), ("rowsum", c_void_p), ("residual", c_void_p)]
 
 
 # every symbol include/jen1_hip.h and include/jen1_train.h declare: (name, restype, argtypes)
@@ -133,6 +133,7 @@ SYMBOLS = {
     "jen1_softmax_backward": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_colsum": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_convert_clear": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "jen1_convert_clear_add": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "jen1_rvq_decode": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_lstm_layer": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "jen1_lstm_layer_multi": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),

@@ -157,7 +157,8 @@ class TrainRuntime:
     def gemm(self, a: L.GemmOperand, b: L.GemmOperand, c_ptr: int, M: int, N: int, K: int, *, dtype: int, taps: int = 1,
              batches: int = 1, taps_in_z: bool = False, ldc_m: int, ldc_n: int = 1, c_tap_stride: int = 0, c_zs0: int = 0,
              c_zs1: int = 0, c_zdiv: int = 1, bias: Optional[torch.Tensor] = None, splitk: int = 1, atomic: bool = False,
-             accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0, rowsum: Optional[torch.Tensor] = None) -> None:
+             accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0, rowsum: Optional[torch.Tensor] = None,
+             residual: Optional[torch.Tensor] = None) -> None:
         g = L.GemmArgs()
         g.a, g.b, g.c, g.bias = a, b, c_ptr, (None if bias is None else bias.data_ptr())
         g.c_zs0, g.c_zs1, g.ldc_m, g.ldc_n, g.c_tap_stride, g.c_zdiv = c_zs0, c_zs1, ldc_m, ldc_n, c_tap_stride, c_zdiv
@@ -165,6 +166,7 @@ class TrainRuntime:
         g.taps_in_z, g.splitk, g.atomic, g.accumulate, g.c_f32, g.dtype = int(taps_in_z), splitk, int(atomic), int(accumulate), int(c_f32), dtype
         g.alpha = alpha
         g.rowsum = None if rowsum is None else rowsum.data_ptr()
+        g.residual = None if residual is None else residual.data_ptr()
         L.check(self.lib.jen1_train_gemm(g, self.stream()), "jen1_train_gemm")
 
     def split_accumulator(self, n: int) -> torch.Tensor:
@@ -175,8 +177,12 @@ class TrainRuntime:
             self._acc32 = torch.zeros(max(n, 1 << 23), dtype=torch.float32, device=self.device)
         return self._acc32
 
-    def hand_over(self, acc: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    def hand_over(self, acc: torch.Tensor, out: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         n = out.numel()
+        if residual is not None:
+            L.check(self.lib.jen1_convert_clear_add(acc.data_ptr(), out.data_ptr(), residual.data_ptr(), n, self.dt_of(out), self.stream()),
+                    "jen1_convert_clear_add")
+            return out
         L.check(self.lib.jen1_convert_clear(acc.data_ptr(), out.data_ptr(), n, self.dt_of(out), self.stream()), "jen1_convert_clear")
         return out
 
@@ -215,8 +221,10 @@ class ConvGeom:
         return Map(axis, self.L_in, self.L_out, mul=self.stride, tapmul=1, shift=-self.pad)
 
 
-def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom) -> torch.Tensor:
-    """x: [..rows.., ldx] channel-last with ldx == wp.shape[2]; returns [B, L_out, pad8(co)]"""
+def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom,
+                  residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: [..rows.., ldx] channel-last with ldx == wp.shape[2]; returns [B, L_out, pad8(co)] (+ ``residual`` of that shape, added in
+    the epilogue of the GEMM or of the split-K hand-over)"""
     dt = rt.dt_of(x)
     ldx = x.shape[-1]
     k, co, cip = wp.shape
@@ -230,12 +238,18 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     ksteps = k * ((cip + 31) // 32)
     sk = rt.pick_splitk(M, co, ksteps)
     alloc = torch.zeros if (ldy != co or sk > 1) else torch.empty
+    if residual is not None:
+        assert residual.is_contiguous() and residual.numel() == B * g.L_out * ldy and residual.dtype == x.dtype, (residual.shape, B, g.L_out, ldy)
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_out * ldy)
         rt.gemm(a, b, acc.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, splitk=sk, atomic=True, c_f32=True)
-        return rt.hand_over(acc, torch.empty((B, g.L_out, ldy), dtype=x.dtype, device=x.device))
+        return rt.hand_over(acc, torch.empty((B, g.L_out, ldy), dtype=x.dtype, device=x.device), residual)
+    if residual is not None and ldy != co:
+        y = residual.clone()                   # (padding columns: keep the residual's)
+        rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, accumulate=True)
+        return y
     y = alloc((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
-    rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias)
+    rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, residual=residual)
     return y
 
 
@@ -301,12 +315,13 @@ class ConvFn(Function):
     """y = conv(x, weight) + bias; backward writes the parameter gradients into ``.grad`` itself"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, rt: TrainRuntime, g: ConvGeom):
+    def forward(ctx, x, weight, bias, rt: TrainRuntime, g: ConvGeom, residual=None):
         wp = rt.packed(weight, g.kind, x.dtype)
         ctx.rt, ctx.g, ctx.weight, ctx.bias, ctx.wp = rt, g, weight, bias, wp
         ctx.wd = rt.packed(weight, g.kind + "D", x.dtype) if (ctx.needs_input_grad[0] and rt.dgrad_copies) else None
+        ctx.has_res = residual is not None
         ctx.save_for_backward(x)
-        return _conv_forward(rt, x, wp, None if bias is None else bias.detach(), g)
+        return _conv_forward(rt, x, wp, None if bias is None else bias.detach(), g, None if residual is None else residual.detach().contiguous())
 
     @staticmethod
     def backward(ctx, dy):
@@ -319,15 +334,16 @@ class ConvFn(Function):
             L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
                     "jen1_colsum")
         dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd).view(x.shape) if ctx.needs_input_grad[0] else None
-        return dx, None, None, None, None
+        return dx, None, None, None, None, (dy if ctx.has_res else None)       # (the residual's gradient IS dy: no launch)
 
 
-def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal: bool) -> torch.Tensor:
-    """_Conv1d (blocks.py:34-53): total padding k - 1, all on the left when causal else split evenly."""
+def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal: bool, residual=None) -> torch.Tensor:
+    """_Conv1d (blocks.py:34-53): total padding k - 1, all on the left when causal else split evenly.  ``residual`` (the output's
+    shape) is added in the GEMM's epilogue."""
     co, ci, k = weight.shape
     B, Lin, _ = x.shape
     pad = (k - 1) if causal else (k - 1) // 2
-    return ConvFn.apply(x, weight, bias, rt, ConvGeom("conv", k, stride, pad, Lin, (Lin - 1) // stride + 1, ci, co))
+    return ConvFn.apply(x, weight, bias, rt, ConvGeom("conv", k, stride, pad, Lin, (Lin - 1) // stride + 1, ci, co), residual)
 
 
 def conv1d_zero_pad(rt: TrainRuntime, x: torch.Tensor, weight, bias, padding: int) -> torch.Tensor:
@@ -368,15 +384,16 @@ class PlainLinearFn(Function):
         return dx, None, None
 
 
-def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None) -> torch.Tensor:
-    """nn.Linear on the last axis; x [..., pad8(in)] -> [..., pad8(out)]"""
+def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None, residual=None) -> torch.Tensor:
+    """nn.Linear on the last axis; x [..., pad8(in)] -> [..., pad8(out)] (+ ``residual`` of the output's shape, in the epilogue)"""
     co, ci = weight.shape
     lead = x.shape[:-1]
     rows = x.numel() // x.shape[-1]
-    if (rt.blas_linears and bias is None and x.dtype == torch.bfloat16 and rows >= 1024 and ci >= 512 and co >= 512 and co % 8 == 0
+    if (rt.blas_linears and residual is None and bias is None and x.dtype == torch.bfloat16 and rows >= 1024 and ci >= 512 and co >= 512 and co % 8 == 0
             and x.shape[-1] == pad8(ci)):
         return PlainLinearFn.apply(x.reshape(rows, x.shape[-1]), weight, rt).view(*lead, co)
-    y = ConvFn.apply(x.reshape(1, rows, x.shape[-1]), weight, bias, rt, ConvGeom("linear", 1, 1, 0, rows, rows, ci, co))
+    y = ConvFn.apply(x.reshape(1, rows, x.shape[-1]), weight, bias, rt, ConvGeom("linear", 1, 1, 0, rows, rows, ci, co),
+                     None if residual is None else residual.reshape(1, rows, residual.shape[-1]))
     return y.view(*lead, y.shape[-1])
 
 
@@ -684,14 +701,14 @@ class TrainGraph:
         h = conv1d_same(rt, h, p[f"{n}.block1.project.conv.weight"], p[f"{n}.block1.project.conv.bias"], 1, causal)
         film = linear(rt, smap, p[f"{n}.to_scale_shift.to_scale_shift.1.weight"], p[f"{n}.to_scale_shift.to_scale_shift.1.bias"])
         h = group_norm(rt, h, p[f"{n}.block2.groupnorm.weight"], p[f"{n}.block2.groupnorm.bias"], r.c_out, r.groups, 1e-5, film, True)
-        h = conv1d_same(rt, h, p[f"{n}.block2.project.conv.weight"], p[f"{n}.block2.project.conv.bias"], 1, causal)
         if r.has_shortcut:
             x = conv1d_same(rt, x, p[f"{n}.to_out.conv.weight"], p[f"{n}.to_out.conv.bias"], 1, causal)
-        return h + x
+        # h + x (blocks.py:231) in the epilogue of the second conv
+        return conv1d_same(rt, h, p[f"{n}.block2.project.conv.weight"], p[f"{n}.block2.project.conv.bias"], 1, causal, residual=x)
 
     def attention(self, n: str, x: torch.Tensor, context: Optional[torch.Tensor], context_mask: Optional[torch.Tensor],
-                  heads: int, causal: bool) -> torch.Tensor:
-        """Attention.forward (blocks.py:415-437): the padding mask multiplies K and V (:431-434)"""
+                  heads: int, causal: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Attention.forward (blocks.py:415-437): the padding mask multiplies K and V (:431-434); ``residual`` is added by to_out's GEMM"""
         rt, p = self.rt, self.p
         ctx = x if context is None else context
         xn = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"])
@@ -702,7 +719,7 @@ class TrainGraph:
         if context_mask is not None:
             kv = kv * context_mask.to(kv.dtype)[:, :, None]          # the padding mask multiplies K and V (one launch for both halves)
         o = attention_core(rt, q, kv, heads, causal)
-        return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"])
+        return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"], residual=residual)
 
     def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool) -> torch.Tensor:
         """Transformer1d.forward (blocks.py:528-537): the SAME 1x1 conv before and after the blocks"""
@@ -712,10 +729,10 @@ class TrainGraph:
         h = conv1d_same(rt, h, w, b, 1, causal)
         for l in range(t.num_layers):
             bn = f"{n}.blocks.{l}"
-            h = self.attention(f"{bn}.attention", h, None, None, t.heads, causal) + h
-            h = self.attention(f"{bn}.cross_attention", h, embedding, embedding_mask, t.heads, False) + h
+            h = self.attention(f"{bn}.attention", h, None, None, t.heads, causal, residual=h)            # (+ h: blocks.py:486-488)
+            h = self.attention(f"{bn}.cross_attention", h, embedding, embedding_mask, t.heads, False, residual=h)
             f = gelu(rt, linear(rt, h, p[f"{bn}.feed_forward.0.weight"], p[f"{bn}.feed_forward.0.bias"]))
-            h = linear(rt, f, p[f"{bn}.feed_forward.2.weight"], p[f"{bn}.feed_forward.2.bias"]) + h
+            h = linear(rt, f, p[f"{bn}.feed_forward.2.weight"], p[f"{bn}.feed_forward.2.bias"], residual=h)
         return conv1d_same(rt, h, w, b, 1, causal)
 
     @staticmethod
