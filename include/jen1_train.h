@@ -60,7 +60,9 @@ typedef struct jen1_gemm_args {
   int32_t M, N, K, taps, batches;
   int32_t taps_in_z, splitk, atomic, accumulate, c_f32, dtype;
   float alpha;
-  int32_t reserved;
+  int32_t reserved;        /* 0, or 1 = prefer the SKINNY form when both operands are K-contiguous and aligned: 32 x 16 output tiles whose
+                              four waves split K (few rows against a big weight: N / 16 x M / 32 workgroups instead of a split-K launch
+                              with float atomics + a conversion launch); ignored when the operands do not allow it */
   float* rowsum;           /* taps_in_z only: rowsum[m] += alpha * sum_k A(m, tap 0, k)  (the bias gradient, blocks.py:52
                               nn.Conv1d bias, riding on the weight gradient); float32 [M] or NULL */
   const void* residual;    /* NULL, or a tensor of C's dtype and indexing that is added in the epilogue (the residual of a

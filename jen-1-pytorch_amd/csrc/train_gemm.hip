@@ -408,6 +408,117 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
     }
 }
 
+// ---- skinny form of the register-direct path: few rows, a big weight -- the deep levels of the pass (M = B x T' = 16 .. 384 rows
+// against 512 .. 1024 x 1024 x 3 weights).  In 64 x 64 tiles such a GEMM is a handful of workgroups, so it ran split over K with float
+// atomics into a float32 scratch plus a convert launch (14 + 4.6 us).  Here a workgroup owns 32 rows x 16 columns and ITS FOUR WAVES
+// split K (step s goes to wave s mod 4, 8 steps of loads in flight per wave), meet in LDS in a fixed order and write C in its own
+// dtype: N / 16 x M / 32 workgroups, no atomics, no scratch, no second launch.
+template <typename T> struct SkinnyPF;
+template <> struct SkinnyPF<bf16_t> { static constexpr int PF = 8; };
+template <> struct SkinnyPF<float> { static constexpr int PF = 3; };
+
+template <typename T>
+__global__ __launch_bounds__(NT) void train_gemm_skinny_kernel(const GemmDev g) {
+  typedef typename DFrag<T>::type Frag;
+  constexpr int PF = SkinnyPF<T>::PF;
+  constexpr unsigned ES = sizeof(T);
+  __shared__ float red[3][2][64][4];
+  jen1_prefetch_kernarg<sizeof(GemmDev)>();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 16;
+  int z = blockIdx.z;
+  const int split = z % g.splitk;
+  z /= g.splitk;
+  const T* abase = reinterpret_cast<const T*>(g.a.p) + (long long)(z / g.a_zdiv) * g.a_zs0 + (long long)(z % g.a_zdiv) * g.a_zs1;
+  const T* bbase = reinterpret_cast<const T*>(g.b.p) + (long long)(z / g.b_zdiv) * g.b_zs0 + (long long)(z % g.b_zdiv) * g.b_zs1;
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int total = ksteps * g.taps;
+  const int per = (total + g.splitk - 1) / g.splitk;
+  const int s_begin = split * per, s_end = min(total, s_begin + per);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(abase), 0, 0x7fffffff, D_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(bbase), 0, 0x7fffffff, D_RSRC_FLAGS);
+  const int li = lane & 15, kq = (lane >> 4) * 8;
+  int a_b[2], a_t[2], a_row[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = m0 + i * 16 + li;
+    a_ok[i] = r < g.M;
+    a_row[i] = r;
+    a_b[i] = (g.a.map_axis == 1) ? r / g.a.map_L : 0;
+    a_t[i] = (g.a.map_axis == 1) ? r - a_b[i] * g.a.map_L : 0;
+  }
+  const int nb = n0 + li;
+  const unsigned b_off = nb < g.N ? (unsigned)((long long)nb * g.b.ld_r) * ES : D_OOB;
+  float bias_v = 0.f;
+  if (g.bias != nullptr && wave == 0 && split == 0) bias_v = nb < g.N ? g.bias[nb] : 0.f;
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  Frag fa[PF][2], fb[PF];
+  int s_next = s_begin + wave;
+  auto issue = [&](Frag (&xa)[2], Frag& xb) {
+    const int s = s_next;
+    s_next += NT / 64;
+    const int tap = s / ksteps, k = (s - tap * ksteps) * BK + kq;
+    const bool live = s < s_end && k < g.K;
+    const unsigned tb = (unsigned)((long long)tap * g.b.tap_stride + k) * ES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      long long row = a_row[i];
+      if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap);
+      const bool ok = live && a_ok[i] && row >= 0;
+      dload(xa[i], ra, ok ? (unsigned)((long long)tap * g.a.tap_stride + row * g.a.ld_r + k) * ES : D_OOB);
+    }
+    dload(xb, rb, (live && b_off != D_OOB) ? b_off + tb : D_OOB);
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u) issue(fa[u], fb[u]);
+  for (int c = s_begin + wave; c < s_end; c += PF * (NT / 64)) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (c + u * (NT / 64) < s_end) {
+        dmma(acc[0], fa[u][0], fb[u]);
+        dmma(acc[1], fa[u][1], fb[u]);
+      }
+      issue(fa[u], fb[u]);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) *reinterpret_cast<float4*>(&red[wave - 1][mi][lane][0]) = make_float4(acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]);
+  }
+  __syncthreads();
+  if (wave != 0 || nb >= g.N) return;
+  char* cb = reinterpret_cast<char*>(g.c);
+  const long long coff = (long long)(z / g.c_zdiv) * g.c_zs0 + (long long)(z % g.c_zdiv) * g.c_zs1;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    float4 t = make_float4(acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]);
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float4 o = *reinterpret_cast<const float4*>(&red[w][mi][lane][0]);
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + mi * 16 + (lane >> 4) * 4 + r;
+      if (m >= g.M) continue;
+      float v = g.alpha * tv[r] + bias_v;
+      const long long off = coff + (long long)m * g.ldc_m + (long long)nb * g.ldc_n;
+      if (g.c_f32) {
+        float* cp = reinterpret_cast<float*>(cb) + off;
+        if (g.atomic) atomicAdd(cp, v);
+        else { if (g.accumulate) v += *cp; *cp = v; }
+      } else {
+        T* cp = reinterpret_cast<T*>(cb) + off;
+        if (g.accumulate) v += (float)*cp;
+        if (g.res) v += (float)reinterpret_cast<const T*>(g.res)[off];
+        *cp = (T)v;
+      }
+    }
+  }
+}
+
 int check_operand(const jen1_gemm_operand& o, const char* name) {
   JEN1_CHECK(o.p != nullptr, "train_gemm: operand %s is NULL", name);
   JEN1_CHECK(o.zdiv >= 1, "train_gemm: operand %s: zdiv must be >= 1", name);
@@ -477,6 +588,17 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   // narrow outputs (N <= 32, e.g. the last stages of the SEANet decoder): in the 2 x 2 wave layout half of the waves
   // would only multiply padding; on the direct path the four waves stack along M instead
   g.tall = (g.direct && a.N <= 32) ? 1 : 0;
+  if (a.reserved == 1 && g.direct && !g.tall) {
+    // the caller asked for the skinny form (few rows, a big weight: see train_gemm_skinny_kernel) and the operands allow it
+    const long long wgs = (long long)((a.M + 31) / 32) * ((a.N + 15) / 16);
+    JEN1_CHECK(wgs * gz <= (1ll << 24) && (a.N + 15) / 16 <= 65535, "train_gemm: skinny grid too large");
+    dim3 sgrid((a.M + 31) / 32, (a.N + 15) / 16, (unsigned)gz);
+    hipStream_t ss = reinterpret_cast<hipStream_t>(stream);
+    if (a.dtype == JEN1_F32) hipLaunchKernelGGL(train_gemm_skinny_kernel<float>, sgrid, dim3(NT), 0, ss, g);
+    else hipLaunchKernelGGL(train_gemm_skinny_kernel<bf16_t>, sgrid, dim3(NT), 0, ss, g);
+    JEN1_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 grid(g.tall ? (a.M + 2 * BM - 1) / (2 * BM) : (a.M + BM - 1) / BM, g.tall ? 1 : gy, (unsigned)gz);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a.dtype == JEN1_F32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);

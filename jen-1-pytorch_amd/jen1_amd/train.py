@@ -73,6 +73,8 @@ class TrainRuntime:
         self.wgrad_plain_rmw = os.environ.get("JEN1_TRAIN_WGRAD_RMW", "1") == "1"
         # plain many-row linears (the text-context K/V projections) as library GEMMs (PlainLinearFn)
         self.blas_linears = os.environ.get("JEN1_TRAIN_BLAS_LINEARS", "1") == "1"
+        self.skinny_gemm = os.environ.get("JEN1_TRAIN_SKINNY", "1") == "1"
+        self.skinny_max_steps = int(os.environ.get("JEN1_TRAIN_SKINNY_STEPS", "64"))      # K steps per wave
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
 
@@ -158,7 +160,7 @@ class TrainRuntime:
              batches: int = 1, taps_in_z: bool = False, ldc_m: int, ldc_n: int = 1, c_tap_stride: int = 0, c_zs0: int = 0,
              c_zs1: int = 0, c_zdiv: int = 1, bias: Optional[torch.Tensor] = None, splitk: int = 1, atomic: bool = False,
              accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0, rowsum: Optional[torch.Tensor] = None,
-             residual: Optional[torch.Tensor] = None) -> None:
+             residual: Optional[torch.Tensor] = None, skinny: bool = False) -> None:
         g = L.GemmArgs()
         g.a, g.b, g.c, g.bias = a, b, c_ptr, (None if bias is None else bias.data_ptr())
         g.c_zs0, g.c_zs1, g.ldc_m, g.ldc_n, g.c_tap_stride, g.c_zdiv = c_zs0, c_zs1, ldc_m, ldc_n, c_tap_stride, c_zdiv
@@ -167,6 +169,7 @@ class TrainRuntime:
         g.alpha = alpha
         g.rowsum = None if rowsum is None else rowsum.data_ptr()
         g.residual = None if residual is None else residual.data_ptr()
+        g.reserved = 1 if skinny else 0
         L.check(self.lib.jen1_train_gemm(g, self.stream()), "jen1_train_gemm")
 
     def split_accumulator(self, n: int) -> torch.Tensor:
@@ -185,6 +188,15 @@ class TrainRuntime:
             return out
         L.check(self.lib.jen1_convert_clear(acc.data_ptr(), out.data_ptr(), n, self.dt_of(out), self.stream()), "jen1_convert_clear")
         return out
+
+    def want_skinny(self, M: int, N: int, ksteps: int) -> bool:
+        """few rows against a big weight: 32 x 16 tiles with the K split inside the workgroup (train_gemm_skinny_kernel) instead of a
+        split-K launch + conversion; as long as that gives the chip enough workgroups of a reasonable length"""
+        if not self.skinny_gemm:
+            return False
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        wgs = ((M + 31) // 32) * ((N + 15) // 16)
+        return tiles < self.target_wgs // 2 and wgs <= 4096 and ksteps <= 4 * self.skinny_max_steps
 
     def pick_splitk(self, M: int, N: int, ksteps: int, z: int = 1) -> int:
         tiles = ((M + 63) // 64) * ((N + 63) // 64) * z
@@ -236,7 +248,8 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     a = _operand(x.data_ptr(), ldx, 1, m=g.fwd_map(1))
     b = _operand(wp.data_ptr(), cip, 1, tap_stride=co * cip)
     ksteps = k * ((cip + 31) // 32)
-    sk = rt.pick_splitk(M, co, ksteps)
+    skinny = rt.want_skinny(M, co, ksteps)
+    sk = 1 if skinny else rt.pick_splitk(M, co, ksteps)
     alloc = torch.zeros if (ldy != co or sk > 1) else torch.empty
     if residual is not None:
         assert residual.is_contiguous() and residual.numel() == B * g.L_out * ldy and residual.dtype == x.dtype, (residual.shape, B, g.L_out, ldy)
@@ -246,10 +259,10 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
         return rt.hand_over(acc, torch.empty((B, g.L_out, ldy), dtype=x.dtype, device=x.device), residual)
     if residual is not None and ldy != co:
         y = residual.clone()                   # (padding columns: keep the residual's)
-        rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, accumulate=True)
+        rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, accumulate=True, skinny=skinny)
         return y
     y = alloc((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
-    rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, residual=residual)
+    rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, residual=residual, skinny=skinny)
     return y
 
 
@@ -273,13 +286,14 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
         b = _operand(wp.data_ptr(), 1, cip, tap_stride=co * cip)
         cip_n = cip
     ksteps = k * ((co + 31) // 32)
-    sk = rt.pick_splitk(M, cip, ksteps)
+    skinny = wd is not None and rt.want_skinny(M, cip_n, ksteps)
+    sk = 1 if skinny else rt.pick_splitk(M, cip, ksteps)
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_in * cip)
         rt.gemm(a, b, acc.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True)
         return rt.hand_over(acc, torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device))
     dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
-    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip)
+    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny)
     return dx
 
 
