@@ -573,7 +573,9 @@ def train_mode(args, world, rank, device, dist, barrier):
         "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[3] full JEN-1 1D-UNet (296.5M params)")
                    + f", {B} clips per GPU (3/3/2 over text_guided / music_inpaint / music_cont; sub-batches with the same causal flag share "
                    + f"one pass), latents 128x{T}, CFG pair, "
-                   + ("eager backward with the exchange overlapped" if args.eager_train else "hipGraph-replayed forward+backward, exchange after the replays")
+                   + ("eager backward with the exchange overlapped" if args.eager_train else
+                      "hipGraph-replayed forward+backward; with N > 1 the replayed pass that completes the gradients carries the RCCL all-reduces "
+                      "of the finished regions on a forked communication stream")
                    + ", clip 0.7 + AdamW + LinearLR", "global_batch": B * world, "seq_len": T, "parallelism": f"ddp x{world}"},
         "loss": round(float(loss), 4),
     }
@@ -676,6 +678,11 @@ def main():
             out["extra"]["deterministic statistics mode, launches_per_step"] = st_d.plan.n_launch + 1
             del st_d
             model.deterministic = False
+            if not args.tiny and not args.no_graph:
+                # first of the extras: HIP maps streams onto four hardware queues in creation order, and every stepper built below
+                # creates streams -- measured later, two of the four chains can land on one queue (1 409 -> 819 steps/s)
+                out["extra"]["concurrent_batches"] = [concurrent_batches_bench(model, B, T, device, n, max(20, args.steps // 2), 5)
+                                                      for n in (2, 4)]
             out["extra"]["end_to_end"] = end_to_end_bench(model, st, B, T, device)
             if args.dtype != "f32":
                 # the parity dtype (tests gate f32 at 1e-3 against the reference) timed on the same workload
@@ -685,6 +692,18 @@ def main():
                 dt32 = timed_steps(st32, n32, max(3, args.warmup // 2), lambda: None)
                 out["extra"]["f32 mode (the dtype of the 1e-3 parity gate), steps/s"] = round(n32 / dt32, 2)
                 del st32, m32
+            if not args.tiny and not args.no_graph:
+                # the long levels as tile phases of two more persistent launches (JEN1_TILE_PHASES=1; off by default: DESIGN.md 4b)
+                mt = UNetCFG1d(**cfg, init_seed=1234, compute_dtype=args.dtype, device=device)
+                mt.engine().use_tile_phases = True
+                stt = build_stepper(mt, B, T, device, cfg_pair=False, use_graph=True)
+                ntl = max(10, args.steps // 2)
+                dtt = timed_steps(stt, ntl, max(3, args.warmup // 2), lambda: None)
+                stt.check()
+                out["extra"]["long levels as tile phases (JEN1_TILE_PHASES=1)"] = {
+                    "steps_per_s": round(ntl / dtt, 2), "launches_per_step": stt.plan.n_launch + 1,
+                    "programs": [{"phases": len(p_), "tile_phases": p_.kinds.count("tile")} for p_ in stt.plan.progs]}
+                del stt, mt
             if not args.tiny:
                 out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
                 fwd_flops = sum(getattr(op, "flops", 0) for op in st.plan.ops)
@@ -727,8 +746,6 @@ def main():
                             e8["configs[1] shape deep_kernel<fp8>"] = {k: d8[k] for k in ("avg_launch_us", "us_per_phase", "alg_bytes_per_launch", "achieved", "frac")}
                         out["extra"]["configs[4] fp8"] = e8
                         del st8, m8
-                    out["extra"]["concurrent_batches"] = [concurrent_batches_bench(model, B, T, device, n, max(20, args.steps // 2), 5)
-                                                          for n in (2, 4)]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.tiny)
         print(json.dumps(out))
