@@ -834,7 +834,9 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   // often -- deep launch 889 -> 997 / 1005 / 1024 / 1067 us at gaps of 4 / 8 / 16 / 24 x 64 clocks; a light pre-poll of ONE vector
   // per lane ahead of the full round -- the polled volume is what an exchange costs, tools/microbench/flagchain.hip: 1.22 / 1.35 /
   // 1.85 / 2.5 us per stage at 1 / 2 / 4 / 8 vectors per thread on 256 workgroups -- 857 -> 896 us: the serial extra round trip
-  // costs more than the lighter polls save)
+  // costs more than the lighter polls save; re-requesting only the vectors that came back incomplete (wave-uniform flags per
+  // vector: the raw part and the residual of a block's second conv are phases old) 860 -> 867 us: the ballots and branches per
+  // vector cost more than the re-read of complete vectors)
   Raw8<GT> xn[MAXV], xw[MAXV];
   float rres[4] = {0.f, 0.f, 0.f, 0.f};
   {
