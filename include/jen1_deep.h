@@ -133,6 +133,12 @@ typedef struct jen1_deep_hot {
   int32_t mrep;
   int32_t live_mask;          /* bit k: source k was produced inside this launch, bit 8: the residual (jen1_conv_args.live_mask) */
   const float* wscale;        /* JEN1_FP8: [M] scale of the e4m3 weight rows (jen1_conv_args.w_scale), else NULL */
+  /* column chunks: a batch element with more than 64 output positions (the 94-position level at T = 1500) is cut into n_chunks
+   * chunks of Lc positions; a unit computes ONE chunk but stages -- and normalises over -- the whole batch element (nb = 1).
+   * Without chunking n_chunks = 1 and Lc = L_out.  n_units = (MT / mrep) * groups_n * n_chunks; inv_Lout is 1 / Lc. */
+  int32_t n_chunks, Lc;
+  float inv_nchunks;
+  int32_t pad_hot_;
 } jen1_deep_hot;
 
 /* JEN1_DEEP_TILE: what a tile unit needs beyond the shared fields of jen1_deep_hot (w / bias / residual / y and its row mapping,
@@ -184,6 +190,10 @@ typedef struct jen1_deep_phase {
 
 /* sizeof(jen1_deep_phase), for host bindings that treat it as opaque bytes */
 int jen1_deep_phase_size(void);
+/* 1 when the library was built with -DJEN1_DEEP_CHUNKS (column chunks of jen1_deep_hot.n_chunks: levels of more than 64 positions as
+ * GEMM phases).  Off in the default build: measured at T = 1500 the 94-position level inside the launch gives 765 against 777 steps/s,
+ * and the chunk decode alone costs every GEMM unit of every plan ~50 ns (8 us per launch). */
+int jen1_deep_has_chunks(void);
 
 /* HOST helpers: fill *out (host memory) for one layer.  Return non-zero (message in jen1_last_error) when the layer does
  * not fit the persistent kernel (LDS, register-resident staging vectors, unsupported option); the caller then keeps the

@@ -494,7 +494,7 @@ struct KRun {                // one run of a wave's K chunks: chunk j is flat ch
 
 template <typename T>
 struct GemmWave {            // what prefill and the K loop share (all scalar)
-  int mt, total, nruns, MT, grp;
+  int mt, total, nruns, MT, grp, chunk;
   bool low_m;
   const KRun* runs;          // this wave's run list in the LDS blob
   __amdgpu_buffer_rsrc_t rw;
@@ -506,8 +506,15 @@ __device__ __forceinline__ GemmWave<T> gemm_wave(const unsigned char* D, const H
   g.MT = HI(MT);
   const int mrep = HI(mrep);
   const int MTg = g.MT >> (mrep > 4 ? 3 : (mrep > 2 ? 2 : (mrep > 1 ? 1 : 0)));      // units per batch group (mrep: 1, 2, 4, 8)
-  const int grp = (int)(((float)u + 0.5f) * (1.0f / (float)MTg));      // u < 2^20: exact
-  g.mt = (u - grp * MTg) * mrep;                                        // the unit's first M tile
+  const int grpc = (int)(((float)u + 0.5f) * (1.0f / (float)MTg));     // u < 2^20: exact; (batch group, column chunk)
+  g.mt = (u - grpc * MTg) * mrep;                                       // the unit's first M tile
+#ifndef JEN1_DEEP_CHUNKS      // (column chunks are a build option: their decode costs every GEMM unit ~50 ns = 8 us per launch)
+  const int grp = grpc;
+  g.chunk = 0;
+#else
+  const int grp = (int)(((float)grpc + 0.5f) * HF(inv_nchunks));        // (n_chunks = 1: grp = grpc, chunk = 0)
+  g.chunk = grpc - grp * HI(n_chunks);
+#endif
   g.grp = grp;
   g.low_m = g.mt < HI(mt_split);
   const short* cnt = reinterpret_cast<const short*>(D + TAB_OFF);
@@ -641,6 +648,11 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
   const int zrow = HI(zrow), Rtot = HI(Rtot);
   const int mrep = HI(mrep);                       // the unit finishes mrep M tiles from one staged tile
   const int b0 = gw.grp * nb;
+#ifndef JEN1_DEEP_CHUNKS
+  const int Lc = L_out, q0 = 0;
+#else
+  const int Lc = HI(Lc), q0 = gw.chunk * Lc;          // the unit's column chunk (Lc = L_out, q0 = 0 without chunking)
+#endif
   const bool low_m = gw.low_m;
   unsigned char* ws = smem + WS_OFF;
   T* tile = reinterpret_cast<T*>(ws);
@@ -785,9 +797,9 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       if (sizeof(T) == 1) wsc4 = *reinterpret_cast<const f32x4*>(HP(wscale, const float*) + m);
       const int n = nfe * 16 + li;
       const int ebl = (int)(((float)n + 0.5f) * inv_Lout);
-      const int t = n - ebl * L_out;
+      const int t = n - ebl * Lc + q0;
       const int ty = t * ps_f + ph - HI(ps_off);
-      okk = n < nb * L_out && b0 + ebl < B && ty >= 0 && ty < HI(L_y);
+      okk = n < nb * Lc && t < L_out && b0 + ebl < B && ty >= 0 && ty < HI(L_y);
       yrow = okk ? (b0 + ebl) * HI(y_brows) + HI(y_row0) + ty : 0;
     }
     const GT* resb = HP(residual, const GT*);
@@ -805,8 +817,9 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     for (int nf = 0; nf < 4; ++nf) {
       const int n = nf * 16 + li;
       const int bl = (int)(((float)n + 0.5f) * inv_Lout);
-      const bool ok = nf < NF && n < nb * L_out && b0 + bl < B;
-      cbase[nf] = (ok ? bl * Lp + Hb + (n - bl * L_out) * stride : zrow) * pitch + lg * 8;
+      const int t = n - bl * Lc + q0;
+      const bool ok = nf < NF && n < nb * Lc && t < L_out && b0 + bl < B;
+      cbase[nf] = (ok ? bl * Lp + Hb + t * stride : zrow) * pitch + lg * 8;
     }
   }
   int soff[PF];
@@ -2259,6 +2272,13 @@ constexpr int LDS_BUDGET = LDS_TOTAL - WS_OFF;      // what a unit may use behin
 }  // namespace
 
 extern "C" int jen1_deep_phase_size(void) { return (int)sizeof(jen1_deep_phase); }
+extern "C" int jen1_deep_has_chunks(void) {
+#ifdef JEN1_DEEP_CHUNKS
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" int jen1_deep_blob_bytes(void) { return BLOB; }
 
 #ifdef JEN1_DEEP_PROFILE
@@ -2394,7 +2414,17 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   for (;; nb /= 2) {
     if (nb < 1 && max_trips == 1) { max_trips = MAX_TRIPS; nb = nb0; }
     JEN1_CHECK(nb >= 1, "deep conv: one batch element (%d rows x %d channels) does not fit a unit", a->L_in, coff);
-    const int cols = nb * a->L_out;
+    int n_chunks = 1, Lc = a->L_out;
+#ifdef JEN1_DEEP_CHUNKS
+    const bool chunks_built = true;
+#else
+    const bool chunks_built = false;
+#endif
+    if (chunks_built && nb == 1 && a->L_out > 64) {                 // one batch element is wider than a unit: column chunks (balanced)
+      n_chunks = ceil_div(a->L_out, 64);
+      Lc = ceil_div(a->L_out, n_chunks);
+    }
+    const int cols = nb * Lc;
     const int NF = ceil_div(cols, 16);
     if (NF > 4) continue;
     int lS = 6, ntrips = 1;
@@ -2416,6 +2446,7 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
     const int tot = tile_b + red_b;
     if (tot > LDS_BUDGET) continue;
     p.h.ntrips = ntrips;
+    p.h.n_chunks = n_chunks; p.h.Lc = Lc; p.h.inv_nchunks = 1.0f / (float)n_chunks;
     p.h.nb = nb; p.h.NF = NF; p.h.R = nb * a->L_in; p.h.Rtot = Rtot; p.h.zrow = nb * p.h.Lp + p.h.Hb; p.h.lS = lS;
     p.h.red_off = tile_b;
     p.h.red_bytes = red_b;
@@ -2424,11 +2455,11 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   }
   p.h.groups_n = ceil_div(a->B, p.h.nb);
   p.h.mrep = 1;
-  p.h.n_units = p.h.MT * p.h.groups_n;
+  p.h.n_units = p.h.MT * p.h.groups_n * p.h.n_chunks;
   JEN1_CHECK(p.h.n_units < (1 << 20), "deep conv: too many units");
   p.h.inv_vpr = 1.0f / (float)(coff / 8);
   p.h.inv_Lin = 1.0f / (float)a->L_in;
-  p.h.inv_Lout = 1.0f / (float)a->L_out;
+  p.h.inv_Lout = 1.0f / (float)p.h.Lc;
   return 0;
 }
 
@@ -2645,10 +2676,11 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
       int mrep = 1;
       const char* cap_s = getenv("JEN1_DEEP_UNIT_CAP");          // tuning: at most this many units per phase (default: one per workgroup)
       const int cap = cap_s ? atoi(cap_s) : nwg;
-      while (mrep < 8 && (P.h.MT / mrep) * P.h.groups_n > cap && P.h.MT % (2 * mrep) == 0 && P.h.mt_split % (2 * mrep) == 0) mrep *= 2;
+      const int nch = P.h.n_chunks < 1 ? 1 : P.h.n_chunks;
+      while (mrep < 8 && (P.h.MT / mrep) * P.h.groups_n * nch > cap && P.h.MT % (2 * mrep) == 0 && P.h.mt_split % (2 * mrep) == 0) mrep *= 2;
       if (mrep > 1 && P.h.lds_bytes + P.h.red_bytes <= LDS_BUDGET) {
         P.h.mrep = mrep;
-        P.h.n_units = (P.h.MT / mrep) * P.h.groups_n;
+        P.h.n_units = (P.h.MT / mrep) * P.h.groups_n * nch;
         P.h.lds_bytes += P.h.red_bytes;
       }
     }

@@ -1116,9 +1116,15 @@ class Plan(OpBuilder):
                 and all(s_.cp == s_.C for s_ in srcs_raw) and 3 + len(srcs_raw) <= L.MAX_SEG:
             # the 1x1 shortcut is one or two more K segments of the second conv (streaming levels, the persistent kernel and the
             # tiled long levels; a wide-tile launch declines and the separate shortcut launch below is used)
-            if self.conv(ops, src0=h, w=W.w[f"{n}.conv2s"], bias=W.v[f"{n}.conv2s.bias"], out=y, taps=3, pad_left=pad,
-                         pro=L.PRO_GN_SILU, gn=gn2, film=film, extra_segs=[(s_, 0) for s_ in srcs_raw]) is not None:
-                return y
+            try:
+                if self.conv(ops, src0=h, w=W.w[f"{n}.conv2s"], bias=W.v[f"{n}.conv2s.bias"], out=y, taps=3, pad_left=pad,
+                             pro=L.PRO_GN_SILU, gn=gn2, film=film, extra_segs=[(s_, 0) for s_ in srcs_raw]) is not None:
+                    return y
+            except DeepIneligible:
+                if not self._deep_on:
+                    raise
+                # (the persistent kernel stages the whole batch element: with the block's input riding along a 94-position, 768-channel
+                # tile does not fit LDS -- the shortcut becomes a phase of its own below)
         if r.has_shortcut:
             res = self.new_act(src0.B, src0.L, r.c_out)
             self.conv(ops, src0=src0, src1=src1, src1_scale=1.0, w=W.w[f"{n}.short"], bias=W.v[f"{n}.short.bias"], out=res)
@@ -1483,6 +1489,10 @@ class Engine:
         self.use_deep = os.environ.get("JEN1_DEEP", "1") != "0"
         self.deep_all_slots = os.environ.get("JEN1_DEEP_ALL_SLOTS", "0") != "0"
         self.deterministic = os.environ.get("JEN1_DETERMINISTIC", "0") != "0"
+        # (a library built with -DJEN1_DEEP_CHUNKS runs a level of more than 64 positions in column chunks -- a unit computes <= 64
+        # positions but stages, and normalises over, the whole batch element: JEN1_DEEP_MAX_LEN=96 then takes the 94-position level of
+        # T = 1500 in, 188 phases and 30 launches per step; measured 765 against 777 steps/s -- the 17 new phases cost 9.4 us each,
+        # what the launches they replace cost -- so the default build leaves the chunk decode out)
         self.deep_max_len = int(os.environ.get("JEN1_DEEP_MAX_LEN", "64"))
         # long levels as tile phases of persistent launches (jen1_deep_phase_tile): layers over at least this many positions.  Off by
         # default: measured at B = 8, T = 1500 the 26 tile phases of levels 0 - 1 take 10 - 11 us each against 9.8 us for the launches

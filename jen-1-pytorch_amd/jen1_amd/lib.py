@@ -139,6 +139,7 @@ SYMBOLS = {
     "jen1_lstm_layer_multi": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     # include/jen1_deep.h: the persistent deep-level kernel (phase descriptors are opaque bytes on this side)
     "jen1_deep_phase_size": (c_int, []),
+    "jen1_deep_has_chunks": (c_int, []),
     "jen1_deep_phase_conv": (c_int, [C.POINTER(ConvArgs), c_int, _P]),
     "jen1_deep_phase_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 +
                                   [c_float, _P, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),

@@ -442,3 +442,32 @@ def test_tile_phases_bf16_and_fp8_mode(full_bf16, full_fp8):
         assert float((ra - rb).abs().max()) / float(rb.abs().max()) < 2e-2, k
     ra, rb = p8.net_out.t.float(), pt.net_out.t.float()
     assert float((ra - rb).abs().max()) / float(rb.abs().max()) < 0.25
+
+
+def test_column_chunked_level_equals_launch_path(full_f32, full_bf16):
+    """JEN1_DEEP_MAX_LEN=96: the 94-position level of T = 1500 inside the persistent launch (units of <= 64 positions that stage the
+    whole batch element; the block input of a second conv does not fit LDS there, so its 1x1 shortcut becomes a phase of its own).
+    bf16: the level joins (188 phases); float32: its first conv does not fit and the plan starts one level deeper, as by default."""
+    from jen1_amd.engine import Plan
+    if not full_bf16.engine().lib.jen1_deep_has_chunks():
+        pytest.skip("column chunks are a build option (-DJEN1_DEEP_CHUNKS; JEN1_LIB points at such a build): off in the default library")
+    B, T = 8, 1500
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "text_guided")
+    t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+    for model, tol, n_ph in ((full_bf16, 6e-2, 188), (full_f32, 2e-5, 171)):
+        eng = model.engine()
+        old = eng.deep_max_len
+        eng.deep_max_len = 96
+        try:
+            pd = Plan(eng, B, T, 1, False, None, deep=True)
+        finally:
+            eng.deep_max_len = old
+        pl = eng.plan(B, T, 1, False, deep=False)
+        assert pd.deep_level is not None and len(pd.deep) == n_ph, (pd.deep_level, len(pd.deep), pd.deep_errors)
+        run_plan(model, pl, x, t, cond)
+        run_plan(model, pd, x, t, cond)
+        assert pd.take_error() == 0
+        for k in pd.taps:
+            ra, rb = pd.taps[k].t[:, :, : pd.taps[k].C].float(), pl.taps[k].t[:, :, : pl.taps[k].C].float()
+            assert torch.isfinite(ra).all()
+            assert float((ra - rb).abs().max()) / float(rb.abs().max()) < tol, k

@@ -1,8 +1,9 @@
 # MFMA-busy of the training step's kernels: rocprofv3 PMC pass over tools/train_step.py (counters in their own run)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+TAG=${1:-r03}
 O=gpurun_out/trainpmc; mkdir -p $O
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc -o p --output-format rocpd -- python tools/train_step.py --iters 3 > $O/pmc.log 2>&1
-python - $(find $O/pmc -name "*.db" | head -1) > $O/r02_train_pmc.txt <<'PY'
+python - $(find $O/pmc -name "*.db" | head -1) > $O/${TAG}_train_pmc.txt <<'PY'
 import sqlite3, sys, collections, json
 c = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -30,5 +31,5 @@ for k in res["GRBM_GUI_ACTIVE"]:
 print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python tools/train_step.py --iters 3 (tools/train_pmc.sh); "
                             "MFMA busy = 100 * busy / (GUI_ACTIVE per XCD * 256 CUs * 4)", "kernels": out}, indent=1))
 PY
-cat $O/r02_train_pmc.txt; tail -2 $O/pmc.log
+cat $O/${TAG}_train_pmc.txt; tail -2 $O/pmc.log
 rm -rf $O/pmc
