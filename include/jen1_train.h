@@ -134,6 +134,20 @@ int jen1_lstm_layer_multi(const float* gin, const void* whh, const void* skip, v
 int jen1_concat2(const void* a, const void* b, void* out, int64_t rows, int Ca, int Cb, float scale_b, int dtype, void* stream);
 int jen1_split2(const void* d, void* da, void* db, int64_t rows, int Ca, int Cb, float scale_b, int dtype, void* stream);
 
+/* --- compute copies of the parameters, all in one launch (refreshed after every optimiser step) ---
+ * entry: dst[i0][i1][i2] (dims d0 x d1 x d2, row pitch ld >= d2, element type `dtype`; padding columns are not touched)
+ *        = (dtype) src[i0 s0 + i1 s1 + i2 s2]   (float32 parameter in the reference layout: _Conv1d [Co][Ci][k] blocks.py:41-52,
+ *        ConvTranspose1d [Ci][Co][k] :80-88, Linear [Co][Ci]); tile0 = first 32 x 32 tile of the entry in the launch
+ *        (prefix sum of d0 ceil(d1 / 32) ceil(d2 / 32)), entries sorted by tile0.  entries_dev: device copy of n entries. */
+typedef struct jen1_repack_entry {
+  const float* src;
+  void* dst;
+  int32_t d0, d1, d2, ld;
+  int64_t s0, s1, s2;
+  int32_t tile0, reserved;
+} jen1_repack_entry;
+int jen1_repack(const jen1_repack_entry* entries_dev, int n, int total_tiles, int dtype, void* stream);
+
 /* out[c] += sum_rows x[row][c]  (bias gradients), float32 accumulate */
 int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream);
 

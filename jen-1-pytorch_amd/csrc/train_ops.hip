@@ -899,6 +899,57 @@ extern "C" int jen1_colsum(const void* x, float* out, int rows, int C, int ld, i
   return 0;
 }
 
+namespace {
+// every compute copy of the parameters in ONE launch (they are refreshed after each optimiser step: [k][C_out][C_in] and its
+// transposes from the reference layouts -- 387 strided torch copies of 10 us each, 4 ms per step, before this).  A block moves one
+// 32 x 32 tile of one (entry, i0) slice; lanes run along whichever of the two inner axes is closer to contiguous in the source and
+// the tile turns in LDS when that is not the destination's inner axis.
+template <typename T>
+__global__ __launch_bounds__(256) void repack_kernel(const jen1_repack_entry* __restrict__ ent, int n, int total_tiles) {
+  __shared__ float tile[32][33];
+  const int tileno = blockIdx.x;
+  if (tileno >= total_tiles) return;
+  int lo = 0, hi = n - 1;                              // last entry with tile0 <= tileno
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (ent[mid].tile0 <= tileno) lo = mid; else hi = mid - 1;
+  }
+  const jen1_repack_entry e = ent[lo];
+  const int t1n = (e.d1 + 31) >> 5, t2n = (e.d2 + 31) >> 5;
+  int r = tileno - e.tile0;
+  const int i0 = r / (t1n * t2n);
+  r -= i0 * t1n * t2n;
+  const int r1 = (r / t2n) * 32, c2 = (r - (r / t2n) * t2n) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  T* dst = reinterpret_cast<T*>(e.dst);
+  const float* src = e.src + (long long)i0 * e.s0;
+  if (e.s2 <= e.s1) {
+    for (int k = ty; k < 32; k += 8) {
+      const int i1 = r1 + k, i2 = c2 + tx;
+      if (i1 < e.d1 && i2 < e.d2) dst[((long long)i0 * e.d1 + i1) * e.ld + i2] = (T)src[(long long)i1 * e.s1 + (long long)i2 * e.s2];
+    }
+    return;
+  }
+  for (int k = ty; k < 32; k += 8) {                   // lanes along i1 (the source's near-contiguous axis)
+    const int i1 = r1 + tx, i2 = c2 + k;
+    tile[k][tx] = (i1 < e.d1 && i2 < e.d2) ? src[(long long)i1 * e.s1 + (long long)i2 * e.s2] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int i1 = r1 + k, i2 = c2 + tx;
+    if (i1 < e.d1 && i2 < e.d2) dst[((long long)i0 * e.d1 + i1) * e.ld + i2] = (T)tile[tx][k];
+  }
+}
+}  // namespace
+
+extern "C" int jen1_repack(const jen1_repack_entry* entries_dev, int n, int total_tiles, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_repack")) return 1;
+  JEN1_CHECK(entries_dev && n >= 1 && total_tiles >= 1, "jen1_repack: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, repack_kernel, dim3(total_tiles), entries_dev, n, total_tiles);
+  return 0;
+}
+
 extern "C" int jen1_convert_clear_add(float* src, void* dst, const void* res, int64_t n, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_convert_clear_add")) return 1;
   JEN1_CHECK(src && dst && res && n >= 4 && (n & 3) == 0, "jen1_convert_clear_add: n must be a positive multiple of 4");

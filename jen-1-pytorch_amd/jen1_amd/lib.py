@@ -92,6 +92,12 @@ class GemmArgs(C.Structure):
                 ("dtype", c_int), ("alpha", c_float), ("reserved", c_int), ("rowsum", c_void_p), ("residual", c_void_p)]
 
 
+class RepackEntry(C.Structure):
+    """mirror of ``jen1_repack_entry`` (include/jen1_train.h)."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("d0", c_int), ("d1", c_int), ("d2", c_int), ("ld", c_int),
+                ("s0", c_int64), ("s1", c_int64), ("s2", c_int64), ("tile0", c_int), ("reserved", c_int)]
+
+
 # every symbol include/jen1_hip.h and include/jen1_train.h declare: (name, restype, argtypes)
 _P = c_void_p
 SYMBOLS = {
@@ -122,6 +128,7 @@ SYMBOLS = {
     "jen1_gn_sums": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "jen1_gn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_gn_backward": (c_int, [_P] * 6 + [c_int] + [_P] * 6 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
+    "jen1_repack": (c_int, [_P, c_int, c_int, c_int, _P]),
     "jen1_concat2": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_int, _P]),
     "jen1_split2": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_int, _P]),
     "jen1_gn_forward": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),

@@ -74,6 +74,8 @@ class TrainRuntime:
         # plain many-row linears (the text-context K/V projections) as library GEMMs (PlainLinearFn)
         self.blas_linears = os.environ.get("JEN1_TRAIN_BLAS_LINEARS", "1") == "1"
         self.skinny_gemm = os.environ.get("JEN1_TRAIN_SKINNY", "1") == "1"
+        self.fused_repack = os.environ.get("JEN1_TRAIN_FUSED_REPACK", "1") == "1"      # every compute copy in one launch (jen1_repack)
+        self._repack_tab, self._repack_meta, self._repack_n = None, (0, 0), -1
         self.skinny_max_steps = int(os.environ.get("JEN1_TRAIN_SKINNY_STEPS", "64"))      # K steps per wave
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
@@ -141,10 +143,38 @@ class TrainRuntime:
         """bring every packed copy up to date now (outside any graph capture)"""
         if self._fresh_epoch == self.epoch:
             return
-        for hit in self._packed.values():
-            w = hit[0]()
-            if w is not None and hit[2] != self.epoch and hit[2] != -1:
-                self._refresh(hit, w)
+        live = [(hit, hit[0]()) for hit in self._packed.values() if hit[2] != -1]
+        live = [(hit, w) for hit, w in live if w is not None]
+        if self.fused_repack and live:
+            # ONE launch for every copy (jen1_repack): the table of (source view, destination) is rebuilt when a copy was added
+            if self._repack_tab is None or self._repack_n != len(self._packed):
+                self._repack_tab = []              # one table per destination dtype (the time MLPs keep float32 copies in bf16 mode)
+                for dt_t, dt_c in ((torch.float32, L.F32), (torch.bfloat16, L.BF16)):
+                    ents, t0 = [], 0
+                    for hit, w in live:
+                        if hit[1].dtype != dt_t:
+                            continue
+                        d = self._layout(w, hit[3])
+                        assert w.dtype == torch.float32
+                        e = L.RepackEntry()
+                        e.src, e.dst = d.data_ptr(), hit[1].data_ptr()
+                        e.d0, e.d1, e.d2, e.ld = d.shape[0], d.shape[1], d.shape[2], hit[1].shape[2]
+                        e.s0, e.s1, e.s2 = d.stride(0), d.stride(1), d.stride(2)
+                        e.tile0 = t0
+                        t0 += d.shape[0] * ((d.shape[1] + 31) // 32) * ((d.shape[2] + 31) // 32)
+                        ents.append(e)
+                    if ents:
+                        arr = (L.RepackEntry * len(ents))(*ents)
+                        self._repack_tab.append((torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(ents), t0, dt_c))
+                self._repack_n = len(self._packed)
+            for tab, n, tiles, dt_c in self._repack_tab:
+                L.check(self.lib.jen1_repack(tab.data_ptr(), n, tiles, dt_c, self.stream()), "jen1_repack")
+            for hit, _ in live:
+                hit[2] = self.epoch
+        else:
+            for hit, w in live:
+                if hit[2] != self.epoch:
+                    self._refresh(hit, w)
         self._fresh_epoch = self.epoch
 
     @staticmethod

@@ -874,3 +874,33 @@ def test_concat_scale_forward_backward(rts, mode):
     tol = 1e-6 if mode == "f32" else 1e-2
     assert float((out.float() - ref.float()).abs().max()) <= tol
     assert float((ga.float() - a.grad.float()).abs().max()) <= tol and float((gb.float() - b.grad.float()).abs().max()) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_fused_repack_equals_per_tensor_copies(mode):
+    """jen1_repack: every compute copy of the parameters ([k][C_out][pad8(C_in)] and its data-gradient transposes, from Conv1d /
+    ConvTranspose1d / Linear layouts) in one launch == the per-tensor permuted copies; padding columns stay zero"""
+    from jen1_amd import train as TR
+    rt = TR.TrainRuntime(mode, "cuda")
+    torch.manual_seed(5)
+    ws = [(torch.randn((48, 36, 3), device="cuda"), "conv"), (torch.randn((40, 70, 5), device="cuda"), "convT"),
+          (torch.randn((100, 52), device="cuda"), "linear"), (torch.randn((33, 129, 9), device="cuda"), "conv")]
+    keys = []
+    for w, kind in ws:
+        for k in (kind, kind + "D"):
+            rt.packed(w, k, rt.tdtype)
+            keys.append((w, k))
+    for w, _ in ws:
+        w.mul_(1.7).add_(0.25)                     # "an optimiser step"
+    rt.invalidate()
+    assert rt.fused_repack
+    rt.refresh_all()
+    torch.cuda.synchronize()
+    for w, k in keys:
+        got = rt._packed[(id(w), k, rt.tdtype)][1]
+        d = rt._layout(w, k)
+        if got.data_ptr() == w.data_ptr():
+            continue                               # (float32 linear: the parameter itself is the compute copy)
+        assert torch.equal(got[:, :, : d.shape[2]], d.to(rt.tdtype)), k
+        assert float(got[:, :, d.shape[2]:].abs().sum()) == 0.0
