@@ -540,10 +540,11 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const void* x_, const float*
 }
 
 // each wave walks rows row0, row0 + stride, ... and keeps the column sums of its lanes in registers
-template <typename T>
-__global__ __launch_bounds__(NT) void ln_bwd_kernel(const void* dy_, const void* x_, const float* __restrict__ stats,
-                                                     const float* __restrict__ gamma, void* dx_, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int C, int ld) {
+template <typename T, int NTB>
+__global__ __launch_bounds__(NTB) void ln_bwd_kernel(const void* dy_, const void* x_, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, void* dx_, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, int rows, int C, int ld) {
+  constexpr int NT = NTB;                    // (shadows the file's 256: a block of NTB / 64 waves)
   const T* dy = reinterpret_cast<const T*>(dy_);
   const T* x = reinterpret_cast<const T*>(x_);
   T* dx = reinterpret_cast<T*>(dx_);
@@ -577,21 +578,111 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const void* dy_, const void*
   }
   // the four waves of the block meet in LDS, then ONE atomic per column and block (512 waves adding 2 C columns each was the
   // kernel's time: 26 us at 2 064 rows x 1 024 columns)
-  __shared__ float colg[(NT / 64 - 1) * 64 * LN_MAXPL], colb[(NT / 64 - 1) * 64 * LN_MAXPL];
+  extern __shared__ float ln_col[];            // [NT / 64 - 1][2][C]
   const int w = threadIdx.x >> 6;
   int n = 0;
   if (w > 0) {
-    for (int c = lane; c < C; c += 64, ++n) { colg[(w - 1) * 64 * LN_MAXPL + c] = ag[n]; colb[(w - 1) * 64 * LN_MAXPL + c] = ab[n]; }
+    for (int c = lane; c < C; c += 64, ++n) { ln_col[((w - 1) * 2) * C + c] = ag[n]; ln_col[((w - 1) * 2 + 1) * C + c] = ab[n]; }
   }
   __syncthreads();
   if (w == 0) {
     n = 0;
     for (int c = lane; c < C; c += 64, ++n) {
       float a = ag[n], b2 = ab[n];
-#pragma unroll
-      for (int k = 0; k < NT / 64 - 1; ++k) { a += colg[k * 64 * LN_MAXPL + c]; b2 += colb[k * 64 * LN_MAXPL + c]; }
+      for (int k = 0; k < NT / 64 - 1; ++k) { a += ln_col[(k * 2) * C + c]; b2 += ln_col[(k * 2 + 1) * C + c]; }
       atomicAdd(dgamma + c, a);
       atomicAdd(dbeta + c, b2);
+    }
+  }
+}
+
+// 8 channels per lane and access (rows of a multiple of 8 channels): the scalar form above moves two bytes per lane and load -- 43 us for
+// the 2 064 x 1 024 rows of the text context, ten times its traffic at HBM speed
+constexpr int LN_MAXV = 4;        // 8-channel vectors per lane: C <= 2048
+template <typename T, int NTB>
+__global__ __launch_bounds__(NTB) void ln_bwd_vec_kernel(const void* dy_, const void* x_, const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma, void* dx_, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int rows, int C, int ld) {
+  extern __shared__ float ln_col[];            // [NTB / 64 - 1][2][C]
+  const T* dy = reinterpret_cast<const T*>(dy_);
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* dx = reinterpret_cast<T*>(dx_);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wid = blockIdx.x * (NTB / 64) + w, nw = gridDim.x * (NTB / 64);
+  const int nvec = C >> 3;
+  float ag[LN_MAXV][8], ab[LN_MAXV][8], gv[LN_MAXV][8];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int v = lane + 64 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gv[j][e] = 0.f; }
+    if (v < nvec) load8(gamma + v * 8, gv[j]);
+  }
+  const float inv_C = 1.0f / (float)C;
+  for (int row = wid; row < rows; row += nw) {
+    const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
+    const T* xr = x + (long long)row * ld;
+    const T* dr = dy + (long long)row * ld;
+    float xh[LN_MAXV][8], dh[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        float d[8];
+        load8(xr + v * 8, xh[j]);
+        load8(dr + v * 8, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[j][e] = (xh[j][e] - mean) * rstd;
+          dh[j][e] = d[e] * gv[j][e];
+          s1 += dh[j][e];
+          s2 += dh[j][e] * xh[j][e];
+          ag[j][e] += d[e] * xh[j][e];
+          ab[j][e] += d[e];
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 *= inv_C; s2 *= inv_C;
+    T* xo = dx + (long long)row * ld;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = rstd * (dh[j][e] - s1 - xh[j][e] * s2);
+        store8(xo + v * 8, o8);
+      }
+    }
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        store8(ln_col + ((w - 1) * 2) * C + v * 8, ag[j]);
+        store8(ln_col + ((w - 1) * 2 + 1) * C + v * 8, ab[j]);
+      }
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        for (int k = 0; k < NTB / 64 - 1; ++k) {
+          float a8[8], b8[8];
+          load8(ln_col + (k * 2) * C + v * 8, a8);
+          load8(ln_col + (k * 2 + 1) * C + v * 8, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ag[j][e] += a8[e]; ab[j][e] += b8[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(dgamma + v * 8 + e, ag[j][e]); atomicAdd(dbeta + v * 8 + e, ab[j][e]); }
+      }
     }
   }
 }
@@ -841,9 +932,43 @@ extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stat
   JEN1_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta, "jen1_ln_backward: NULL argument");
   JEN1_CHECK(rows >= 1 && C >= 1 && ld >= C && C <= 64 * LN_MAXPL, "jen1_ln_backward: bad shape rows=%d C=%d ld=%d", rows, C, ld);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // many rows (the text context: 2B x 129): 8 waves per block meet in LDS, so 32 blocks x 2 C atomics finish the column sums
+  // (the atomics of hundreds of waves on 2 C addresses were the kernel's time: 26 us at 2 064 x 1 024); 16 waves per block would
+  // leave 128 registers per lane and push the per-lane column sums into scratch
+  if ((C & 7) == 0 && (ld & 7) == 0 && C <= 512 * LN_MAXV && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0 &&
+      (size_t)7 * 2 * C * sizeof(float) <= 64 * 1024) {
+    // 8 waves per block when there are rows for them, else 4; at most 32 blocks: each wave keeps its column sums over many rows
+    const bool big8 = rows >= 256;
+    const int wpb = big8 ? 8 : 4;
+    int blocks = (rows + wpb - 1) / wpb;
+    if (blocks > 32) blocks = 32;
+    const size_t lds = (size_t)(wpb - 1) * 2 * C * sizeof(float);
+    if (big8) {
+      if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_vec_kernel<float, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+      else hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+    } else {
+      if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_vec_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+      else hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+    }
+    JEN1_HIP(hipGetLastError());
+    return 0;
+  }
+  const bool big = rows >= 512 && (size_t)7 * 2 * C * sizeof(float) <= 64 * 1024;
+  if (big) {
+    int blocks = (rows + 31) / 32;
+    if (blocks > 32) blocks = 32;
+    const size_t lds = (size_t)7 * 2 * C * sizeof(float);
+    if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+    else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+    JEN1_HIP(hipGetLastError());
+    return 0;
+  }
   int blocks = (rows + 3) / 4;
   if (blocks > 64) blocks = 64;             // each wave keeps column sums over many rows: few atomics
-  DISPATCH(dtype, ln_bwd_kernel, dim3(blocks), dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+  const size_t lds = (size_t)3 * 2 * C * sizeof(float);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+  else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+  JEN1_HIP(hipGetLastError());
   return 0;
 }
 
