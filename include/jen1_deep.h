@@ -240,6 +240,9 @@ int jen1_deep_blob_bytes(void);
  * reader and complete before the launch starts (same stream: the first node of the step).  Also zeroes sync[0], the launch's ticket
  * counter (units are handed to workgroups by ticket: the launch makes progress with any number of resident workgroups).  Capturable. */
 int jen1_deep_poison(const void* table_dev, int n, uint32_t* sync, void* stream);
+/* the same launch also zeroes the caller's per-step scratch (zero_bytes at zero_ptr, multiples of 16): the statistics arena reset and
+ * the poisoning are one node at the head of the step instead of two */
+int jen1_deep_poison_zero(const void* table_dev, int n, uint32_t* sync, void* zero_ptr, int64_t zero_bytes, void* stream);
 
 /* bytes of the synchronisation area: word 0 is the ticket counter (zero when the launch starts: jen1_deep_poison), the rest is unused */
 int64_t jen1_deep_sync_bytes(int n_phases);

@@ -286,6 +286,11 @@ int jen1_cfg_ddim_step(const void* net, const float* x, const float* noise, cons
  * jen1_step_advance increments the scalar; it is the last node of a captured sampler step, so replaying the
  * graph S times walks the schedule with no host-side update in between. */
 int jen1_step_advance(int32_t* step_idx, void* stream);
+/* jen1_cfg_ddim_step with the advance inside: the block that takes the last of the grid's tickets increments step_idx[0] (every thread
+ * has read it by then) and leaves *ticket at zero -- one launch fewer per sampler step.  ticket: one uint32, zero on first use. */
+int jen1_cfg_ddim_step_adv(const void* net, const float* x, const float* noise, const float* coef, float* x_out, float* eps_out,
+                           float* x0_out, int32_t* step_idx, uint32_t* ticket, int B, int C, int T, int ld, int nrep,
+                           float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype, void* stream);
 
 /* CFG combine + rescale only: writes the guided denoiser output [B][C][T] float32 (model.py:362-369). */
 int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale, int scale_cfg,

@@ -2759,19 +2759,42 @@ namespace {
 struct PoisonEntry {
   unsigned long long ptr, bytes;          // bytes: a multiple of 16
 };
-__global__ __launch_bounds__(256) void poison_kernel(const PoisonEntry* __restrict__ tab, unsigned* __restrict__ sync) {
-  if (sync && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync[0] = 0u;      // the ticket counter of the launch
+__global__ __launch_bounds__(256) void poison_kernel(const PoisonEntry* __restrict__ tab, unsigned* __restrict__ sync, int n_tab, void* zero_ptr,
+                                                      unsigned long long zero_bytes) {
+  if ((int)blockIdx.y >= n_tab) {
+    // rows behind the table: the caller's per-step scratch (statistics arena) is zeroed by the same launch, the rows share it
+    uint4* z = reinterpret_cast<uint4*>(zero_ptr);
+    const size_t n = zero_bytes >> 4;
+    const size_t nblk = (size_t)gridDim.x * (gridDim.y - n_tab), blk = (size_t)(blockIdx.y - n_tab) * gridDim.x + blockIdx.x;
+    for (size_t i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   const PoisonEntry e = tab[blockIdx.y];
   uint4* p = reinterpret_cast<uint4*>(e.ptr);
   const size_t n = e.bytes >> 4;
   const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = ones;
+  // the ticket counter of the launch (it may lie inside the zeroed scratch: zero either way)
+  if (sync && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync[0] = 0u;
 }
 }  // namespace
 
 extern "C" int jen1_deep_poison(const void* table_dev, int n, uint32_t* sync, void* stream) {
   JEN1_CHECK(table_dev && n >= 1 && n <= 65535, "deep poison: bad table");
-  hipLaunchKernelGGL(poison_kernel, dim3(8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const PoisonEntry*>(table_dev), sync);
+  hipLaunchKernelGGL(poison_kernel, dim3(8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const PoisonEntry*>(table_dev), sync,
+                     n, (void*)nullptr, 0ull);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_deep_poison_zero(const void* table_dev, int n, uint32_t* sync, void* zero_ptr, int64_t zero_bytes, void* stream) {
+  JEN1_CHECK(table_dev && n >= 1 && n <= 60000, "deep poison: bad table");
+  JEN1_CHECK(zero_ptr && zero_bytes > 0 && (zero_bytes & 15) == 0 && ((uintptr_t)zero_ptr & 15) == 0, "deep poison: the zeroed area must be 16-byte aligned and sized");
+  // enough rows for the zeroing to keep up with the poisoning of the biggest tensors (8 blocks per row)
+  int zrows = (int)((zero_bytes + (1 << 18) - 1) >> 18);
+  zrows = zrows < 1 ? 1 : (zrows > 64 ? 64 : zrows);
+  hipLaunchKernelGGL(poison_kernel, dim3(8, n + zrows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const PoisonEntry*>(table_dev), sync,
+                     n, zero_ptr, (unsigned long long)zero_bytes);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

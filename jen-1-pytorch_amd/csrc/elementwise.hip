@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
                                                         float* __restrict__ x_out, float* __restrict__ eps_out,
                                                         float* __restrict__ x0_out, const int32_t* __restrict__ step_idx,
                                                         int B, int C, int Tn, int ld, int nrep,
-                                                        float scale, int scale_cfg, float phi, int objective, int clip_x0) {
+                                                        float scale, int scale_cfg, float phi, int objective, int clip_x0,
+                                                        int32_t* __restrict__ adv_step, unsigned* __restrict__ adv_ticket) {
   extern __shared__ float tile[];   // [C][33]
   if (DDIM && step_idx) {            // per-step rows of the coefficient / noise tables
     const int st = step_idx[0];
@@ -315,6 +316,15 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
       if (lane + 64 * k < C) tile[(lane + 64 * k) * 33 + r] = og[k];
   }
   __syncthreads();
+  // the step counter advances here instead of in a launch of its own (jen1_cfg_ddim_step_adv): every thread of the grid has read it
+  // once its block is past the barrier above, so the block that takes the last ticket may write it (and leaves the ticket at zero)
+  if (adv_ticket != nullptr && threadIdx.x == 0) {
+    const unsigned nblk = gridDim.x * gridDim.y;
+    if (atomicAdd(adv_ticket, 1u) == nblk - 1u) {
+      adv_step[0] += 1;
+      adv_ticket[0] = 0u;
+    }
+  }
   // phase 2: [C][T]-major elementwise, 8 channels per pass with their loads issued together
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t = t0 + tx;
@@ -456,7 +466,7 @@ extern "C" int jen1_linear_f32(const float* x, const float* w, const float* bias
 template <bool DDIM>
 static int launch_cfg(const void* net, const float* x, const float* noise, const float* coef, float* x_out, float* eps_out,
                       float* x0_out, const int32_t* step_idx, int B, int C, int T, int ld, int nrep, float scale, int scale_cfg, float phi,
-                      int objective, int clip_x0, int dtype, void* stream) {
+                      int objective, int clip_x0, int dtype, void* stream, int32_t* adv_step = nullptr, unsigned* adv_ticket = nullptr) {
   JEN1_CHECK(net && x_out, "cfg step: null pointer");
   JEN1_CHECK(nrep == 1 || nrep == 2, "cfg step: nrep must be 1 or 2");
   JEN1_CHECK(C >= 2 && C <= 256 && ld >= C, "cfg step: C must be in [2, 256]");
@@ -466,11 +476,11 @@ static int launch_cfg(const void* net, const float* x, const float* noise, const
   if (dtype == JEN1_F32) {
     auto kern = cfg_step_kernel<float, DDIM>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket);
   } else if (dtype == JEN1_BF16) {
     auto kern = cfg_step_kernel<bf16_t, DDIM>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket);
   } else {
     return jen1_set_error("cfg step: bad dtype");
   }
@@ -495,6 +505,16 @@ extern "C" int jen1_cfg_ddim_step(const void* net, const float* x, const float* 
   JEN1_CHECK(objective >= 0 && objective <= 2, "cfg_ddim_step: bad objective");
   return launch_cfg<true>(net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, embedding_scale, scale_cfg,
                           scale_phi, objective, clip_x0, dtype, stream);
+}
+
+extern "C" int jen1_cfg_ddim_step_adv(const void* net, const float* x, const float* noise, const float* coef, float* x_out,
+                                      float* eps_out, float* x0_out, int32_t* step_idx, uint32_t* ticket, int B, int C, int T, int ld,
+                                      int nrep, float embedding_scale, int scale_cfg, float scale_phi, int objective,
+                                      int clip_x0, int dtype, void* stream) {
+  JEN1_CHECK(x && coef && step_idx && ticket, "cfg_ddim_step_adv: null x / coef / step_idx / ticket");
+  JEN1_CHECK(objective >= 0 && objective <= 2, "cfg_ddim_step_adv: bad objective");
+  return launch_cfg<true>(net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, embedding_scale, scale_cfg,
+                          scale_phi, objective, clip_x0, dtype, stream, step_idx, ticket);
 }
 
 extern "C" int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale,

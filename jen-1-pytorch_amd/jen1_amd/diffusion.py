@@ -373,11 +373,13 @@ class DDIMStepper:
                     float(gd.embedding_scale), 1 if (cfg and gd.scale_cfg) else 0, 0.7, _OBJ[getattr(gd, "objective", "v")],
                     0 if mode == "vdm" else 1, eng.dt)
             sp = plan.step_idx.data_ptr()
+            # the step counter advances inside the CFG / DDIM kernel (its last block; jen1_cfg_ddim_step_adv): one launch fewer per step
+            ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
+            adv_args = args[:7] + (sp, ticket.data_ptr()) + args[8:]
 
-            def run(s, plan=plan, args=args, sp=sp):
+            def run(s, plan=plan, adv_args=adv_args, ticket=ticket):
                 plan.run(s)
-                L.check(lib.jen1_cfg_ddim_step(*args, s), "jen1_cfg_ddim_step")
-                L.check(lib.jen1_step_advance(sp, s), "jen1_step_advance")
+                L.check(lib.jen1_cfg_ddim_step_adv(*adv_args, s), "jen1_cfg_ddim_step_adv")
 
             self.parts.append((sl, plan, run, ntab))
             b0 += nb

@@ -380,8 +380,13 @@ class DeepProgram:
         self.poison_tab = torch.tensor(ent, dtype=torch.int64).view(-1, 2).to(self.eng.device)
         self.poison_bytes = int(sum(ent[1::2]))
 
-    def poison(self, stream: int):
-        """before every launch, after the last reader of the previous one: the step's first node (Plan) does this"""
+    def poison(self, stream: int, zero: Optional[Tuple[int, int]] = None):
+        """before every launch, after the last reader of the previous one: the step's first node (Plan) does this; ``zero`` =
+        (pointer, bytes) of the plan's per-step statistics arena, reset by the same launch"""
+        if zero is not None:
+            L.check(self.lib.jen1_deep_poison_zero(self.poison_tab.data_ptr(), self.poison_tab.shape[0], self.sync.data_ptr(), zero[0], zero[1],
+                                                   stream), "jen1_deep_poison_zero")
+            return
         L.check(self.lib.jen1_deep_poison(self.poison_tab.data_ptr(), self.poison_tab.shape[0], self.sync.data_ptr(), stream), "jen1_deep_poison")
 
     def launch(self, stream: int):
@@ -1084,6 +1089,7 @@ class Plan(OpBuilder):
         self.progs.append(prog)
         pz = lambda s, prog=prog: prog.poison(s)
         pz.kind = "deep_poison"
+        pz.prog = prog
         pz.label = f"deep_poison[{prog.poison_tab.shape[0]} tensors, {prog.poison_bytes} B]"
         self.ops.insert(1, pz)          # right behind the arena reset: long before the launch, after the previous step's last reader
         fn = lambda s, prog=prog: prog.launch(s)
@@ -1366,6 +1372,12 @@ class Plan(OpBuilder):
         if self._prog is not None:
             self._prog_close()            # (the network's output is read by a launch that normalises nothing)
         self.deep = self._deep_prog if self._deep_prog is not None else (self.progs[-1] if self.progs else None)
+        if self.progs and getattr(self.ops[1], "kind", "") == "deep_poison" and arena_bytes % 16 == 0 and arena_ptr % 16 == 0:
+            # the arena reset rides on the first poisoning launch: one node at the head of the step instead of two
+            pz0 = self.ops[1]
+            fused = lambda s, prog=pz0.prog, z=(arena_ptr, arena_bytes): prog.poison(s, zero=z)
+            fused.kind, fused.label, fused.prog = "deep_poison", pz0.label + " + arena reset", pz0.prog
+            self.ops[0:2] = [fused]
 
         # ---- 5. context ops: text K/V (hoisted out of the step loop) -------------------------------
         if n_tr:

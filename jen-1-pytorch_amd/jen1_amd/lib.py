@@ -117,6 +117,7 @@ SYMBOLS = {
     "jen1_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_cfg_ddim_step": (c_int, [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
     "jen1_step_advance": (c_int, [_P, _P]),
+    "jen1_cfg_ddim_step_adv": (c_int, [_P] * 9 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
     "jen1_cfg_combine": (c_int, [_P, _P] + [c_int] * 4 + [c_float, c_int, c_float, c_int, _P]),
     "jen1_grad_sqnorm": (c_int, [_P, c_int64, _P, _P]),
     "jen1_grad_sqnorm_scratch_bytes": (c_int64, []),
@@ -155,6 +156,7 @@ SYMBOLS = {
     "jen1_deep_tile_count": (c_int, [c_int, c_int, c_int, c_int]),
     "jen1_deep_link": (c_int, [_P, c_int, c_int, _P, _P]),
     "jen1_deep_poison": (c_int, [_P, c_int, _P, _P]),
+    "jen1_deep_poison_zero": (c_int, [_P, c_int, _P, _P, c_int64, _P]),
     "jen1_deep_blob_bytes": (c_int, []),
     "jen1_deep_sync_bytes": (c_int64, [c_int]),
     "jen1_deep_num_workgroups": (c_int, []),
