@@ -234,7 +234,8 @@ class GradExchange:
         """a forward pass registered one more hook for ``region`` (several sub-batches share one backward pass)"""
         self._expect[region] = self._expect.get(region, 0) + 1
 
-    def region_ready(self, region: str) -> None:
+    def region_ready(self, region: str, also: Optional["torch.cuda.Stream"] = None) -> None:
+        """``also``: a second stream gradients of the region were enqueued on (train.TrainRuntime.weight_grad_stream)"""
         if not self.active or region not in self.regions or region in self._sent:
             return
         left = self._expect.get(region, 1) - 1
@@ -244,9 +245,11 @@ class GradExchange:
         self.sent_during_pass += 1
         if self.debug_check:
             lo, hi = self.regions[region]
+            if also is not None:
+                torch.cuda.current_stream(self.opt.flat_grad.device).wait_stream(also)
             self._snap[region] = self.opt.flat_grad[lo:hi].clone()
             return
-        self._send(region)
+        self._send(region, also)
 
     def _reduce(self, chunk: torch.Tensor, sync: bool) -> None:
         import torch.distributed as dist
@@ -260,7 +263,7 @@ class GradExchange:
         else:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _send(self, region: str) -> None:
+    def _send(self, region: str, also=None) -> None:
         self._sent.add(region)
         lo, hi = self.regions[region]
         g = self.opt.flat_grad
@@ -268,6 +271,8 @@ class GradExchange:
             cur = torch.cuda.current_stream(g.device)
             capturing = torch.cuda.is_current_stream_capturing()
             self._comm.wait_stream(cur)      # the gradients of the region are enqueued before this point
+            if also is not None:
+                self._comm.wait_stream(also)
             with torch.cuda.stream(self._comm):
                 for o in range(lo, hi, self.bucket):
                     # while a graph is being recorded the collective is a node of it: issued in stream order on the communication

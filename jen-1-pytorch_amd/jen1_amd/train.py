@@ -18,13 +18,14 @@ There is no fallback: without libjen1_hip.so / a ROCm device every entry point r
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
-from torch.autograd import Function
+from torch.autograd import Function, Variable
 
 from . import lib as L
 from .config import ResSpec, TransformerSpec, UNetSpec
@@ -79,6 +80,13 @@ class TrainRuntime:
         self.skinny_max_steps = int(os.environ.get("JEN1_TRAIN_SKINNY_STEPS", "64"))      # K steps per wave
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
+        # weight gradients on their own stream (weight_grad below)
+        self.wgrad_group = int(os.environ.get("JEN1_TRAIN_WGRAD_GROUP", "64"))         # layers per fork; 0: on the pass's own stream
+        self._wstream: Optional[torch.cuda.Stream] = None
+        self._wqueue: list = []
+        self._wheld: list = []
+        self._wforked = False
+        self._wjoin: list = []                   # streams the weight-gradient stream was forked from in the running backward pass
 
     # ------------------------------------------------------------------ plumbing
     def stream(self) -> int:
@@ -87,6 +95,54 @@ class TrainRuntime:
     def invalidate(self) -> None:
         """the parameters changed (optimiser step / load): every packed compute copy is stale"""
         self.epoch += 1
+
+    def weight_grad(self, launch, *keep: torch.Tensor) -> None:
+        """Nothing in the backward pass reads a weight gradient, but every launch costs the chain ~4.5 us + its run time, and one third
+        of the pass's GEMM launches are weight gradients.  Inside a backward node: ``launch()`` (the weight / bias gradient launches of
+        one layer) is put off; every ``wgrad_group`` layers the queue is issued on a second stream forked from the current one -- a
+        parallel branch of the captured graph, in eager mode a second hardware queue -- and the stream the pass runs on joins that
+        stream when the autograd engine finishes (a final callback), so whatever reads ``.grad`` after ``backward()`` is ordered behind
+        it as before.  The queue keeps its order (two uses of one weight accumulate into the same buffer).  One fork per GROUP, not per
+        layer: a cross-stream edge of a replayed graph costs more than the launch it hides (a fork per layer: 22.0 -> 25.0 ms).
+        ``keep``: the operands, held until the join so that the allocator cannot hand their memory to a later launch of the main stream
+        while the second stream still reads them."""
+        if self.wgrad_group <= 0:
+            launch()
+            return
+        if not self._wjoin:
+            Variable._execution_engine.queue_callback(self.join_weight_grads)
+        cur = torch.cuda.current_stream(self.device)
+        if cur not in self._wjoin:
+            self._wjoin.append(cur)
+        self._wqueue.append(launch)
+        self._wheld.extend(keep)
+        if len(self._wqueue) >= self.wgrad_group:
+            self.flush_weight_grads()
+
+    def flush_weight_grads(self, frm: Optional[torch.cuda.Stream] = None) -> Optional[torch.cuda.Stream]:
+        """issue the queued weight-gradient launches; returns their stream if the running backward pass has used it (a collective over
+        gradients waits on it too)"""
+        if self._wqueue:
+            if self._wstream is None:
+                self._wstream = torch.cuda.Stream(self.device)
+            self._wstream.wait_stream(torch.cuda.current_stream(self.device) if frm is None else frm)
+            with torch.cuda.stream(self._wstream):
+                for launch in self._wqueue:
+                    launch()
+            self._wqueue.clear()
+            self._wforked = True
+        return self._wstream if self._wforked else None
+
+    def join_weight_grads(self) -> None:
+        if not self._wjoin:
+            return
+        self.flush_weight_grads(self._wjoin[-1])         # (the stream the backward nodes ran on: the callback runs on the caller's thread)
+        cur = torch.cuda.current_stream(self.device)
+        for s in [cur] + [s for s in self._wjoin if s != cur]:
+            s.wait_stream(self._wstream)
+        self._wjoin.clear()
+        self._wheld.clear()
+        self._wforked = False
 
     def dt_of(self, t: torch.Tensor) -> int:
         if t.dtype == torch.float32:
@@ -373,10 +429,15 @@ class ConvFn(Function):
         rt, g = ctx.rt, ctx.g
         dy = dy.contiguous()
         gb = None if ctx.bias is None else rt.grad_of(ctx.bias)
-        if not _conv_wgrad(rt, x, dy, rt.grad_of(ctx.weight), g, gb) and ctx.bias is not None:
-            ldy = dy.shape[-1]
-            L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
-                    "jen1_colsum")
+        gw = rt.grad_of(ctx.weight)
+        has_bias = ctx.bias is not None
+
+        def wgrad():
+            if not _conv_wgrad(rt, x, dy, gw, g, gb) and has_bias:
+                ldy = dy.shape[-1]
+                L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
+                        "jen1_colsum")
+        rt.weight_grad(wgrad, x, dy)
         dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd).view(x.shape) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None, (dy if ctx.has_res else None)       # (the residual's gradient IS dy: no launch)
 
@@ -423,7 +484,7 @@ class PlainLinearFn(Function):
         (x2d,) = ctx.saved_tensors
         dy = dy.contiguous()
         gw = ctx.rt.grad_of(ctx.weight)
-        gw.add_(torch.matmul(dy.t(), x2d)[:, : gw.shape[1]])
+        ctx.rt.weight_grad(lambda: gw.add_(torch.matmul(dy.t(), x2d)[:, : gw.shape[1]]), x2d, dy)
         dx = torch.matmul(dy, ctx.wp) if ctx.needs_input_grad[0] else None
         return dx, None, None
 
@@ -698,7 +759,7 @@ class TrainGraph:
         ex = self.exchange
         if ex is not None and ex.active and h.requires_grad:
             ex.expect(region)
-            h.register_hook(lambda g, ex=ex, region=region: ex.region_ready(region))
+            h.register_hook(lambda g, ex=ex, region=region: ex.region_ready(region, also=self.rt.flush_weight_grads()))
         return h
 
     def invalidate(self) -> None:

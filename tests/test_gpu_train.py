@@ -904,3 +904,43 @@ def test_fused_repack_equals_per_tensor_copies(mode):
             continue                               # (float32 linear: the parameter itself is the compute copy)
         assert torch.equal(got[:, :, : d.shape[2]], d.to(rt.tdtype)), k
         assert float(got[:, :, d.shape[2]:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_weight_gradients_on_the_second_stream_equal_in_order_launches(use_graph):
+    """TrainRuntime.weight_grad: the weight / bias gradient launches of a pass queued and issued in groups on a forked stream (joined
+    when the autograd engine finishes) leave the same gradients as the same launches issued in place, eager and replayed"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    from jen1_amd.train import GraphedLossStep
+    betas, _ = get_beta_schedule("linear", 1000)
+    B, T = 2, 300
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, "text_guided").items()}
+    t = torch.tensor([17, 801], dtype=torch.long, device="cuda")
+    grads = {}
+    for group in (0, 3, 1000):
+        model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        graph = model.train_graph("f32")
+        graph.rt.wgrad_group = group
+        gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                               cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+        step = GraphedLossStep(graph, gd) if use_graph else None
+        if step is not None:
+            step(x0, t, cond, False)            # capture
+        opt.zero_grad()
+        for rnd in range(2):                    # two passes accumulate
+            torch.manual_seed(11 + rnd)
+            if step is not None:
+                step(x0, t, cond, False)
+            else:
+                gd.training_loosses(graph, x0, t, cond, causal=False).backward()
+        assert not graph.rt._wqueue and not graph.rt._wjoin and not graph.rt._wheld
+        torch.cuda.synchronize()
+        grads[group] = opt.flat_grad.clone()
+        assert float(grads[group].abs().max()) > 0
+    for group in (3, 1000):
+        assert float((grads[group] - grads[0]).abs().max()) <= 2e-5 * float(grads[0].abs().max()), group
