@@ -83,9 +83,11 @@ int jen1_gn_apply(const void* x, const float* sums, const float* gamma, const fl
 int jen1_gn_forward(const void* x, float* sums, const float* gamma, const float* beta, const void* film, int film_ld, void* y, int B,
                     int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
 /* backward: P[B][C][4] and Gm[B][G][2] are float32 scratch (P is zeroed by the call); dgamma/dbeta are ACCUMULATED
- * (float32, the parameter's .grad); dfilm [B][2C] float32 is written (NULL when film is NULL). */
+ * (float32, the parameter's .grad); dfilm [B][2C] float32 is written (NULL when film is NULL).  flags bit1: dfilm MIRRORS film
+ * instead -- x's dtype, rows film_ld apart (scale gradient at [c], shift gradient at [C + c]): the slice of a buffer that holds the
+ * FiLM gradients of every block side by side, the operand of ONE data-gradient GEMM for all their projections. */
 int jen1_gn_backward(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,
-                     int film_ld, void* dx, float* dgamma, float* dbeta, float* dfilm, float* P, float* Gm, int B, int L, int C,
+                     int film_ld, void* dx, float* dgamma, float* dbeta, void* dfilm, float* P, float* Gm, int B, int L, int C,
                      int ld, int groups, float eps, int flags, int dtype, void* stream);
 
 /* --- LayerNorm over the last axis (blocks.py:400-401): stats[rows][2] = (mean, rstd) --- */

@@ -69,9 +69,24 @@ __global__ __launch_bounds__(NT) void gn_sums_kernel(const void* x_, float* __re
 struct GnDev {
   const void* x; const void* dy; const float* sums; const float* gamma; const float* beta; const void* film;
   void* y; float* P; float* Gm; float* dgamma; float* dbeta; float* dfilm;
-  int B, L, C, ld, groups, cpg, film_ld, flags;
+  int B, L, C, ld, groups, cpg, film_ld, flags, film_bf16;
   float eps, inv_count;
 };
+
+// FiLM gradients of one channel: [B][2C] float32, or with flags bit1 a mirror of ``film`` (its dtype, its row stride: the slice of a
+// buffer that holds the gradients of every block's FiLM projection side by side)
+__device__ inline void store_dfilm(const GnDev& g, int b, int c, float d_scale, float d_shift) {
+  if (g.flags & 2) {
+    const long long o = (long long)b * g.film_ld + c;
+    if (g.film_bf16) {
+      bf16_t* d = reinterpret_cast<bf16_t*>(g.dfilm);
+      d[o] = (bf16_t)d_scale; d[o + g.C] = (bf16_t)d_shift;
+    } else { g.dfilm[o] = d_scale; g.dfilm[o + g.C] = d_shift; }
+  } else {
+    g.dfilm[(long long)b * 2 * g.C + c] = d_scale;
+    g.dfilm[(long long)b * 2 * g.C + g.C + c] = d_shift;
+  }
+}
 
 // (mean, rstd) of the group of channel c in batch element b
 __device__ __forceinline__ void gn_moments(const GnDev& g, int b, int c, float& mean, float& rstd) {
@@ -143,10 +158,7 @@ __global__ __launch_bounds__(64) void gn_bwd_finish_kernel(const GnDev g) {
       const float ga = g.gamma[c];
       m1 += ga * P[0];
       m2 += ga * P[1];
-      if (g.dfilm != nullptr) {
-        g.dfilm[(long long)b * 2 * g.C + c] = P[2];
-        g.dfilm[(long long)b * 2 * g.C + g.C + c] = P[3];
-      }
+      if (g.dfilm != nullptr) store_dfilm(g, b, c, P[2], P[3]);
     }
     for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
     if (threadIdx.x == 0) {
@@ -440,10 +452,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const GnDev g, void* d
     const float gam = g.gamma[c];
     m1 = gam * P.x;
     m2 = gam * P.y;
-    if (g.dfilm != nullptr) {
-      g.dfilm[(long long)b * 2 * g.C + c] = P.z;
-      g.dfilm[(long long)b * 2 * g.C + g.C + c] = P.w;
-    }
+    if (g.dfilm != nullptr) store_dfilm(g, b, c, P.z, P.w);
     atomicAdd(g.dgamma + c, P.y);                      // (the other batch elements add to the same entry)
     atomicAdd(g.dbeta + c, P.x);
   }
@@ -934,14 +943,15 @@ extern "C" int jen1_gn_apply(const void* x, const float* sums, const float* gamm
 }
 
 extern "C" int jen1_gn_backward(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta,
-                                const void* film, int film_ld, void* dx, float* dgamma, float* dbeta, float* dfilm, float* P,
+                                const void* film, int film_ld, void* dx, float* dgamma, float* dbeta, void* dfilm, float* P,
                                 float* Gm, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_gn_backward")) return 1;
   GnDev g;
   if (gn_fill(g, "jen1_gn_backward", x, sums, gamma, beta, film, film_ld, B, L, C, ld, groups, eps, flags)) return 1;
   JEN1_CHECK(dy && dx && dgamma && dbeta && P && Gm, "jen1_gn_backward: NULL argument");
   JEN1_CHECK((film == nullptr) == (dfilm == nullptr), "jen1_gn_backward: dfilm must be given exactly when film is");
-  g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = dfilm;
+  g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = reinterpret_cast<float*>(dfilm);
+  g.film_bf16 = dtype == JEN1_BF16 ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int lvpg = 0;
   if (gn_fused_ok(x, dx, dy, gamma, beta, film, film_ld, B, L, C, ld, groups, lvpg)) {

@@ -87,6 +87,9 @@ class TrainRuntime:
         self._wheld: list = []
         self._wforked = False
         self._wjoin: list = []                   # streams the weight-gradient stream was forked from in the running backward pass
+        # every block's FiLM projection as one GEMM (FilmBankFn)
+        self.film_bank = os.environ.get("JEN1_TRAIN_FILM_BANK", "1") == "1"
+        self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
 
     # ------------------------------------------------------------------ plumbing
     def stream(self) -> int:
@@ -189,6 +192,42 @@ class TrainRuntime:
             self._refresh(hit, w)
         return hit[1]
 
+    def packed_bank(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Compute copies of several Linear weights of one input width as ONE matrix [1][sum C_out][pad8(C_in)] (+ their biases as one
+        float32 vector): each weight's copy is a row slice of it, registered like any other packed copy (refreshed by the same
+        jen1_repack launch).  The C_out must be multiples of 8 (slices start on 16-byte boundaries in either dtype)."""
+        key = (tuple(id(w) for w in weights), dtype)
+        hit = self._banks.get(key)
+        if hit is not None and any(r() is not w for r, w in zip(hit[0], weights)):
+            hit = None
+        if hit is None:
+            ci = weights[0].shape[1]
+            assert all(w.shape[1] == ci and w.shape[0] % 8 == 0 and w.dtype == torch.float32 for w in weights)
+            assert all(b.shape[0] == w.shape[0] for w, b in zip(weights, biases))
+            total = sum(w.shape[0] for w in weights)
+            dev = weights[0].device
+            mat = torch.zeros((1, total, pad8(ci)), dtype=dtype, device=dev)
+            off = 0
+            for w in weights:
+                self._packed[(id(w), "linear", dtype)] = [weakref.ref(w), mat[:, off:off + w.shape[0], :], -2, "linear"]
+                off += w.shape[0]
+            self._repack_tab = None                # (entries may have been replaced: rebuild the table of jen1_repack)
+            hit = [[weakref.ref(w) for w in weights], mat, [weakref.ref(b) for b in biases],
+                   torch.zeros(total, dtype=torch.float32, device=dev), -2]
+            self._banks[key] = hit
+        for w in weights:
+            self.packed(w, "linear", dtype)        # (refreshes a stale slice; after refresh_all none is)
+        self._refresh_bank_bias(hit)
+        return hit[1], hit[3]
+
+    def _refresh_bank_bias(self, hit) -> None:
+        if hit[4] != self.epoch:
+            bs = [r() for r in hit[2]]
+            if all(b is not None for b in bs):
+                with torch.no_grad():
+                    torch.cat([b.detach() for b in bs], out=hit[3])
+            hit[4] = self.epoch
+
     def _refresh(self, hit, w) -> None:
         with torch.no_grad():
             d = self._layout(w, hit[3])
@@ -199,6 +238,8 @@ class TrainRuntime:
         """bring every packed copy up to date now (outside any graph capture)"""
         if self._fresh_epoch == self.epoch:
             return
+        for bank in self._banks.values():
+            self._refresh_bank_bias(bank)
         live = [(hit, hit[0]()) for hit in self._packed.values() if hit[2] != -1]
         live = [(hit, w) for hit, w in live if w is not None]
         if self.fused_repack and live:
@@ -388,6 +429,10 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
     when dy is the row operand (Conv1d / Linear); returns whether it was."""
     dt = rt.dt_of(x)
     ldx, ldy = x.shape[-1], dy.shape[-1]
+    rows_dy = dy.numel() // ldy
+    if not dy.is_contiguous():                 # a column slice of a wider matrix (FilmBankFn): rows dy.stride(0) apart
+        assert dy.dim() == 2 and dy.stride(1) == 1 and g.kind == "linear"
+        ldy = dy.stride(0)
     k = g.taps
     if g.kind == "convT":
         # W[ci][co][k]: rows m = ci from x (K = (b, t_in)), rows n = co from dy at the mapped row
@@ -397,7 +442,7 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
         M, N = g.ci, g.co
     else:
         # W[co][ci][k]: rows m = co from dy (K = (b, t_out)), rows n = ci from x at the mapped row
-        K = dy.numel() // ldy
+        K = rows_dy
         a = _operand(dy.data_ptr(), 1, ldy)
         b = _operand(x.data_ptr(), 1, ldx, m=g.fwd_map(2))
         M, N = g.co, g.ci
@@ -507,21 +552,30 @@ def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None, residual=None) 
 # =====================================================================================================================
 class GroupNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, film, rt: TrainRuntime, C: int, groups: int, eps: float, silu: bool):
+    def forward(ctx, x, gamma, beta, film, rt: TrainRuntime, C: int, groups: int, eps: float, silu: bool, dfilm_slot=None):
+        """``film`` [B, >= 2C]: contiguous, or a column slice of a wider matrix (rows ``film.stride(0)`` apart: FilmBankFn); with
+        ``dfilm_slot`` (FilmSlot: the same slice of the matrix of FiLM gradients) the backward kernel writes the gradient there itself"""
         B, Lx, ld = x.shape
         assert x.is_contiguous() and ld >= C
         dt = rt.dt_of(x)
         sums = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
         y = (torch.zeros_like if ld != C else torch.empty_like)(x)
         s = rt.stream()
+        film_ld = 0
         if film is not None:
-            film = film.contiguous()
-            assert film.dtype == x.dtype and film.shape[-1] >= 2 * C
+            if not (film.dim() == 2 and film.stride(1) == 1 and film.stride(0) >= film.shape[1]):
+                film = film.contiguous().view(B, -1)
+            film_ld = film.stride(0)
+            assert film.dtype == x.dtype and film.shape[-1] >= 2 * C and film.shape[0] == B
+            if dfilm_slot is not None:
+                sv = dfilm_slot.view
+                assert sv.shape == film.shape and sv.stride() == film.stride() and sv.dtype == film.dtype
         L.check(rt.lib.jen1_gn_forward(x.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                       None if film is None else film.data_ptr(), 0 if film is None else film.shape[-1],
+                                       None if film is None else film.data_ptr(), film_ld,
                                        y.data_ptr(), B, Lx, C, ld, groups, float(eps), 1 if silu else 0, dt, s), "jen1_gn_forward")
         ctx.rt, ctx.C, ctx.groups, ctx.eps, ctx.silu, ctx.gamma, ctx.beta = rt, C, groups, eps, silu, gamma, beta
         ctx.has_film = film is not None
+        ctx.film_ld, ctx.dfilm_slot = film_ld, (dfilm_slot if film is not None else None)
         ctx.save_for_backward(x, sums, film if film is not None else x.new_empty(0))
         return y
 
@@ -535,13 +589,20 @@ class GroupNormFn(Function):
         dx = (torch.zeros_like if ld != C else torch.empty_like)(x)
         P = torch.empty((B, C, 4), dtype=torch.float32, device=x.device)
         Gm = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
-        dfilm = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device) if ctx.has_film else None
+        slot = ctx.dfilm_slot
+        dfilm = None
+        if ctx.has_film:
+            dfilm = slot.view if slot is not None else torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
+        flags = (1 if ctx.silu else 0) | (2 if slot is not None else 0)
         L.check(rt.lib.jen1_gn_backward(dy.data_ptr(), x.data_ptr(), sums.data_ptr(), ctx.gamma.data_ptr(), ctx.beta.data_ptr(),
-                                        film.data_ptr() if ctx.has_film else None, film.shape[-1] if ctx.has_film else 0,
+                                        film.data_ptr() if ctx.has_film else None, ctx.film_ld,
                                         dx.data_ptr(), rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(),
                                         None if dfilm is None else dfilm.data_ptr(), P.data_ptr(), Gm.data_ptr(), B, Lx, C, ld,
-                                        groups, float(ctx.eps), 1 if ctx.silu else 0, dt, rt.stream()), "jen1_gn_backward")
-        if dfilm is not None:
+                                        groups, float(ctx.eps), flags, dt, rt.stream()), "jen1_gn_backward")
+        if slot is not None:
+            df = slot.view                     # (written in place: FilmBankFn.backward recognises its own slice)
+            slot.written()
+        elif dfilm is not None:
             df = torch.zeros((B, film.shape[-1]), dtype=film.dtype, device=x.device) if film.shape[-1] != 2 * C else None
             if df is None:
                 df = dfilm.to(film.dtype)
@@ -549,11 +610,79 @@ class GroupNormFn(Function):
                 df[:, :2 * C] = dfilm
         else:
             df = None
-        return dx, None, None, df, None, None, None, None, None
+        return dx, None, None, df, None, None, None, None, None, None
 
 
-def group_norm(rt, x, gamma, beta, C, groups, eps, film=None, silu=False):
-    return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu)
+def group_norm(rt, x, gamma, beta, C, groups, eps, film=None, silu=False, dfilm_slot=None):
+    return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu, dfilm_slot)
+
+
+# =====================================================================================================================
+# the FiLM projections of every block: MappingToScaleShift (blocks.py:177-196) = Linear(SiLU(mapping)) -> (scale, shift), one per
+# ResnetBlock1d, all reading the same [B, features] vector
+# =====================================================================================================================
+class FilmSlot:
+    """where block i's FiLM gradient goes (a column slice of the gradient matrix) + what to do once it is there: queue the block's
+    weight / bias gradient.  That happens inside the block's own GroupNorm backward node, so "the gradient of a block's input exists =>
+    all its parameter gradients are enqueued" (TrainGraph._mark, the overlapped exchange) still holds."""
+
+    def __init__(self, view: torch.Tensor, written):
+        self.view, self.written = view, written
+
+
+class FilmBankFn(Function):
+    """The ~40 projections as ONE GEMM against the row-stacked weights (TrainRuntime.packed_bank): y [B, sum 2 C_i], block i reads its
+    column slice in place (GroupNormFn takes the row pitch).  Backward: every block's GroupNorm kernel writes its FiLM gradient into
+    the same slice of ONE gradient matrix, which is the operand of one data-gradient GEMM (instead of ~40 GEMMs + ~40 conversions +
+    ~40 accumulations of the mapping's gradient); the weight / bias gradients stay per block (their .grad buffers are separate) and
+    go to the weight-gradient queue as soon as the block's slice is written (FilmSlot)."""
+
+    @staticmethod
+    def forward(ctx, smap, rt: TrainRuntime, weights, biases, slots):
+        B, F = smap.shape
+        wall, ball = rt.packed_bank(weights, biases, smap.dtype)
+        total = wall.shape[1]
+        g = ConvGeom("linear", 1, 1, 0, B, B, weights[0].shape[1], total)
+        y = _conv_forward(rt, smap.view(1, B, F), wall, ball, g).view(B, total)
+        ctx.rt, ctx.g, ctx.wall, ctx.slots = rt, g, wall, slots
+        outs, off = [], 0
+        for w in weights:
+            outs.append(y[:, off:off + w.shape[0]])
+            off += w.shape[0]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        rt = ctx.rt
+        dY = ctx.slots[0].view._base
+        for slot, gr in zip(ctx.slots, grads):
+            if gr is not None and (gr.data_ptr() != slot.view.data_ptr() or gr.stride() != slot.view.stride()):
+                slot.view.copy_(gr)            # (a gradient that did not come from GroupNormFn's in-place write)
+                slot.written()
+        B = dY.shape[0]
+        dx = _conv_dgrad(rt, dY.view(1, B, dY.shape[1]), ctx.wall, ctx.g).view(B, -1) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None
+
+
+def film_bank(rt: TrainRuntime, smap: torch.Tensor, weights, biases):
+    """-> [(film_i, FilmSlot_i)]: block i's (scale | shift) [B, 2 C_i] and the ``dfilm_slot`` of its group_norm"""
+    B, F = smap.shape
+    total = sum(w.shape[0] for w in weights)
+    dY = torch.zeros((B, total), dtype=smap.dtype, device=smap.device)
+    xs = smap.detach().view(1, B, F)
+    slots, off = [], 0
+    for w, b in zip(weights, biases):
+        co = w.shape[0]
+        view = dY[:, off:off + co]
+        lg = ConvGeom("linear", 1, 1, 0, B, B, w.shape[1], co)
+
+        def written(w=w, b=b, view=view, lg=lg):
+            gw, gb = rt.grad_of(w), rt.grad_of(b)
+            rt.weight_grad(lambda: _conv_wgrad(rt, xs, view, gw, lg, gb), xs, dY)
+        slots.append(FilmSlot(view, written))
+        off += co
+    outs = FilmBankFn.apply(smap, rt, tuple(weights), tuple(biases), tuple(slots))
+    return list(zip(outs, slots))
 
 
 # =====================================================================================================================
@@ -799,13 +928,29 @@ class TrainGraph:
         m = gelu(rt, linear(rt, m, p["to_mapping.0.weight"], p["to_mapping.0.bias"]))
         return gelu(rt, linear(rt, m, p["to_mapping.2.weight"], p["to_mapping.2.bias"]))
 
-    def res_block(self, r: ResSpec, x: torch.Tensor, smap: torch.Tensor, causal: bool) -> torch.Tensor:
+    def films(self, smap: torch.Tensor) -> Optional[dict]:
+        """every ResnetBlock1d's (scale | shift) from one GEMM (FilmBankFn), by block name; None: each block projects for itself"""
+        rt, p, sp = self.rt, self.p, self.spec
+        if not rt.film_bank or smap.dim() != 2:
+            return None
+        blocks = ([sp.to_in] + [r for d in sp.downs for r in d.blocks] + [sp.bott_pre, sp.bott_post]
+                  + [r for u in sp.ups for r in u.blocks] + [sp.to_out])
+        ws = [p[f"{r.name}.to_scale_shift.to_scale_shift.1.weight"] for r in blocks]
+        bs = [p[f"{r.name}.to_scale_shift.to_scale_shift.1.bias"] for r in blocks]
+        if any(w.shape[0] % 8 or w.shape[1] != ws[0].shape[1] for w in ws) or smap.shape[1] != pad8(ws[0].shape[1]):
+            return None
+        return {r.name: fs for r, fs in zip(blocks, film_bank(rt, smap, ws, bs))}
+
+    def res_block(self, r: ResSpec, x: torch.Tensor, smap: torch.Tensor, causal: bool, films: Optional[dict] = None) -> torch.Tensor:
         """ResnetBlock1d.forward (blocks.py:219-231); ``smap`` = SiLU(mapping) in the compute dtype"""
         rt, p, n = self.rt, self.p, r.name
         h = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True)
         h = conv1d_same(rt, h, p[f"{n}.block1.project.conv.weight"], p[f"{n}.block1.project.conv.bias"], 1, causal)
-        film = linear(rt, smap, p[f"{n}.to_scale_shift.to_scale_shift.1.weight"], p[f"{n}.to_scale_shift.to_scale_shift.1.bias"])
-        h = group_norm(rt, h, p[f"{n}.block2.groupnorm.weight"], p[f"{n}.block2.groupnorm.bias"], r.c_out, r.groups, 1e-5, film, True)
+        if films is not None:
+            film, slot = films[n]
+        else:
+            film, slot = linear(rt, smap, p[f"{n}.to_scale_shift.to_scale_shift.1.weight"], p[f"{n}.to_scale_shift.to_scale_shift.1.bias"]), None
+        h = group_norm(rt, h, p[f"{n}.block2.groupnorm.weight"], p[f"{n}.block2.groupnorm.bias"], r.c_out, r.groups, 1e-5, film, True, slot)
         if r.has_shortcut:
             x = conv1d_same(rt, x, p[f"{n}.to_out.conv.weight"], p[f"{n}.to_out.conv.bias"], 1, causal)
         # h + x (blocks.py:231) in the epilogue of the second conv
@@ -861,31 +1006,32 @@ class TrainGraph:
         h = self._to_rows(x)
         mp = self.mapping(t)
         smap = silu(rt, mp).to(rt.tdtype)
-        h = self.res_block(sp.to_in, h, smap, False)          # Patcher / Unpatcher are never causal (blocks.py:256-259)
+        films = self.films(smap)
+        h = self.res_block(sp.to_in, h, smap, False, films)          # Patcher / Unpatcher are never causal (blocks.py:256-259)
         skips_list: List = [h]
         for d in sp.downs:
             h = self._mark(h, d.name)
             h = conv1d_same(rt, h, p[f"{d.name}.downsample.conv.weight"], p[f"{d.name}.downsample.conv.bias"], d.factor, causal)
             skips = []
             for r in d.blocks:
-                h = self.res_block(r, h, smap, causal)
+                h = self.res_block(r, h, smap, causal, films)
                 skips.append(h)
             if d.transformer:
                 h = self.transformer(d.transformer, h, embedding, embedding_mask, causal)
                 skips.append(h)
             skips_list.append(skips)
         h = self._mark(h, "bottleneck")
-        h = self.res_block(sp.bott_pre, h, smap, causal)
+        h = self.res_block(sp.bott_pre, h, smap, causal, films)
         if sp.bott_tr:
             h = self.transformer(sp.bott_tr, h, embedding, embedding_mask, causal)
-        h = self.res_block(sp.bott_post, h, smap, causal)
+        h = self.res_block(sp.bott_post, h, smap, causal, films)
         for u in sp.ups:
             h = self._mark(h, u.name)
             skips = skips_list.pop()
             for r in u.blocks:
                 a, sk = self._crop_pair(h, skips.pop())                 # blocks.py:732-734
                 h = concat_scale(rt, a, sk, self.skip_scale)
-                h = self.res_block(r, h, smap, causal)
+                h = self.res_block(r, h, smap, causal, films)
             if u.transformer:
                 h = self.transformer(u.transformer, h, embedding, embedding_mask, causal)
             w, b = p[f"{u.name}.upsample.weight"], p[f"{u.name}.upsample.bias"]
@@ -896,7 +1042,7 @@ class TrainGraph:
                 h = conv_transpose1d(rt, h, w, b, f, f // 2 + f % 2, f % 2)
         h = h + skips_list.pop()                                         # model.py:261
         h = self._mark(h, "to_out")
-        h = self.res_block(sp.to_out, h, smap, False)
+        h = self.res_block(sp.to_out, h, smap, False, films)
         return h[:, :, :sp.out_channels].to(torch.float32).transpose(1, 2)
 
     # ------------------------------------------------------------------ UNetCFG1d.forward
