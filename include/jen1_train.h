@@ -70,6 +70,12 @@ typedef struct jen1_gemm_args {
 } jen1_gemm_args;
 
 int jen1_train_gemm(const jen1_gemm_args* args, void* stream);
+/* Two INDEPENDENT products of one dtype in one launch: one grid holds the workgroups jen1_train_gemm(first) and
+ * jen1_train_gemm(second) would launch (the second's are dispatched first); results are those of the two calls.  For the weight gradient (first) and the data gradient
+ * (second) of one layer -- loss.backward() of trainer.py:141 issues them back to back, both read dY, neither reads the other -- the
+ * launch lasts as long as the longer of the two instead of their sum.  first must be of the 64 x 64 form (reserved == 0 or operands
+ * that do not allow the skinny form); second may be either.  Nothing may order the two (no common output). */
+int jen1_train_gemm_pair(const jen1_gemm_args* first, const jen1_gemm_args* second, void* stream);
 
 /* --- GroupNorm (+FiLM) (+SiLU): ConvBlock1d's prologue, blocks.py:137-143; Transformer1d's GroupNorm, :509 ---
  * sums[B][G][2] float32 = (sum x, sum x^2) over the group (zeroed by the call).  film: [B][film_ld] float32 or bf16

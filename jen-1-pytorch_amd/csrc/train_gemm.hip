@@ -299,16 +299,14 @@ __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, co
   }
 }
 
+// one workgroup of the 64 x 64 form: (bx, by, bz) = its position in the grid jen1_train_gemm would launch
 template <typename T>
-__global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
+__device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int bz, T* As, T* Bs) {
   constexpr int PITCH = BK + 16 / (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
-  __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
-  jen1_prefetch_kernarg<sizeof(GemmDev)>();      // one batch of scalar loads instead of one round trip per argument line
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = g.tall ? wave : wave >> 1, wn = g.tall ? 0 : wave & 1;
-  const int m0 = blockIdx.x * (g.tall ? 2 * BM : BM), n0 = blockIdx.y * (g.tall ? BN / 2 : BN);
-  int z = blockIdx.z;
+  const int m0 = bx * (g.tall ? 2 * BM : BM), n0 = by * (g.tall ? BN / 2 : BN);
+  int z = bz;
   const int split = z % g.splitk;
   z /= g.splitk;
   int tap_z = 0;
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
   }
 
   // bias gradient: the workgroups of the first N tile and tap 0 also sum their A rows over K
-  const bool do_rowsum = g.rowsum != nullptr && blockIdx.y == 0 && tap_z == 0;
+  const bool do_rowsum = g.rowsum != nullptr && by == 0 && tap_z == 0;
   float rsum = 0.f;
 
   if (g.direct) {
@@ -417,16 +415,17 @@ template <typename T> struct SkinnyPF;
 template <> struct SkinnyPF<bf16_t> { static constexpr int PF = 8; };
 template <> struct SkinnyPF<float> { static constexpr int PF = 3; };
 
+typedef float SkinnyRed[2][64][4];
+constexpr int SKINNY_RED_BYTES = 3 * (int)sizeof(SkinnyRed);
+
 template <typename T>
-__global__ __launch_bounds__(NT) void train_gemm_skinny_kernel(const GemmDev g) {
+__device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, int bz, SkinnyRed* red) {
   typedef typename DFrag<T>::type Frag;
   constexpr int PF = SkinnyPF<T>::PF;
   constexpr unsigned ES = sizeof(T);
-  __shared__ float red[3][2][64][4];
-  jen1_prefetch_kernarg<sizeof(GemmDev)>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 16;
-  int z = blockIdx.z;
+  const int m0 = bx * 32, n0 = by * 16;
+  int z = bz;
   const int split = z % g.splitk;
   z /= g.splitk;
   const T* abase = reinterpret_cast<const T*>(g.a.p) + (long long)(z / g.a_zdiv) * g.a_zs0 + (long long)(z % g.a_zdiv) * g.a_zs1;
@@ -519,28 +518,57 @@ __global__ __launch_bounds__(NT) void train_gemm_skinny_kernel(const GemmDev g) 
   }
 }
 
-int check_operand(const jen1_gemm_operand& o, const char* name) {
-  JEN1_CHECK(o.p != nullptr, "train_gemm: operand %s is NULL", name);
-  JEN1_CHECK(o.zdiv >= 1, "train_gemm: operand %s: zdiv must be >= 1", name);
-  JEN1_CHECK(o.map_axis >= 0 && o.map_axis <= 2, "train_gemm: operand %s: map_axis must be 0, 1 or 2", name);
-  if (o.map_axis) {
-    JEN1_CHECK(o.map_L >= 1 && o.map_Lsrc >= 1 && o.map_div >= 1 && o.map_mul >= 1,
-               "train_gemm: operand %s: map_L, map_Lsrc, map_mul and map_div must be >= 1", name);
+template <typename T>
+__global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
+  constexpr int PITCH = BK + 16 / (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
+  __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
+  jen1_prefetch_kernarg<sizeof(GemmDev)>();      // one batch of scalar loads instead of one round trip per argument line
+  gemm_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void train_gemm_skinny_kernel(const GemmDev g) {
+  __shared__ __attribute__((aligned(16))) SkinnyRed red[3];
+  jen1_prefetch_kernarg<sizeof(GemmDev)>();
+  skinny_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z, red);
+}
+
+// ---- two independent products in ONE launch (jen1_train_gemm_pair): the weight gradient and the data gradient of a layer read the
+// same dY and nothing orders them, but as two launches they cost the chain two launch latencies and each leaves most of the chip
+// idle (16 .. 384 rows at the deep levels).  One grid holds the workgroups of the first product (64 x 64 form) and of the second
+// (64 x 64 or skinny form); the launch lasts as long as the longer of the two.
+struct PairDev {
+  GemmDev g0, g1;
+  int nb1, gx0, gy0, gx1, gy1;
+};
+
+template <typename T, bool SKINNY1>
+__global__ __launch_bounds__(NT) void train_gemm_pair_kernel(const PairDev p) {
+  constexpr int PITCH = BK + 16 / (int)sizeof(T);
+  constexpr int AB = 2 * BM * PITCH * (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) char lds[AB > SKINNY_RED_BYTES ? AB : SKINNY_RED_BYTES];
+  jen1_prefetch_kernarg<sizeof(PairDev)>();
+  T* As = reinterpret_cast<T*>(lds);
+  T* Bs = As + BM * PITCH;
+  // the SECOND product's workgroups come first in the dispatch order: it is the short chain-critical one (few workgroups, each a
+  // long K walk), and starts at once while the first product's many short workgroups fill the rest of the chip behind it
+  int id = blockIdx.x;
+  if (id >= p.nb1) {
+    id -= p.nb1;
+    const int bx = id % p.gx0;
+    id /= p.gx0;
+    gemm_body<T>(p.g0, bx, id % p.gy0, id / p.gy0, As, Bs);
+  } else {
+    const int bx = id % p.gx1;
+    id /= p.gx1;
+    if constexpr (SKINNY1) skinny_body<T>(p.g1, bx, id % p.gy1, id / p.gy1, reinterpret_cast<SkinnyRed*>(lds));
+    else gemm_body<T>(p.g1, bx, id % p.gy1, id / p.gy1, As, Bs);
   }
-  return 0;
 }
 
-Operand to_dev(const jen1_gemm_operand& o, int rows) {
-  Operand d;
-  d.p = o.p; d.ld_r = o.ld_r; d.ld_k = o.ld_k; d.tap_stride = o.tap_stride;
-  d.map_axis = o.map_axis; d.map_L = o.map_L; d.map_Lsrc = o.map_Lsrc; d.map_mul = o.map_mul;
-  d.map_tapmul = o.map_tapmul; d.map_shift = o.map_shift; d.map_div = o.map_div; d.map_reflect = o.map_reflect ? 1 : 0; d.rows = rows;
-  return d;
-}
-
-}  // namespace
-
-extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
+// validates one call and lays out its launch: the device descriptor, the grid, and whether it is the skinny form
+int prepare(const jen1_gemm_args* args, GemmDev& g, dim3& grid, bool& skinny) {
   JEN1_CHECK(args != nullptr, "train_gemm: args is NULL");
   const jen1_gemm_args& a = *args;
   JEN1_CHECK(a.dtype == JEN1_F32 || a.dtype == JEN1_BF16, "train_gemm: dtype must be JEN1_F32 or JEN1_BF16");
@@ -555,7 +583,6 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   JEN1_CHECK(gz <= 65535, "train_gemm: batches * taps * splitk = %lld exceeds the grid limit", gz);
   const int gy = (a.N + BN - 1) / BN;
   JEN1_CHECK(gy <= 65535, "train_gemm: N = %d is too large", a.N);
-  GemmDev g;
   g.a = to_dev(a.a, a.M);
   g.b = to_dev(a.b, a.N);
   g.c = a.c; g.bias = reinterpret_cast<const float*>(a.bias);
@@ -588,21 +615,58 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   // narrow outputs (N <= 32, e.g. the last stages of the SEANet decoder): in the 2 x 2 wave layout half of the waves
   // would only multiply padding; on the direct path the four waves stack along M instead
   g.tall = (g.direct && a.N <= 32) ? 1 : 0;
-  if (a.reserved == 1 && g.direct && !g.tall) {
+  skinny = a.reserved == 1 && g.direct && !g.tall;
+  if (skinny) {
     // the caller asked for the skinny form (few rows, a big weight: see train_gemm_skinny_kernel) and the operands allow it
     const long long wgs = (long long)((a.M + 31) / 32) * ((a.N + 15) / 16);
     JEN1_CHECK(wgs * gz <= (1ll << 24) && (a.N + 15) / 16 <= 65535, "train_gemm: skinny grid too large");
-    dim3 sgrid((a.M + 31) / 32, (a.N + 15) / 16, (unsigned)gz);
-    hipStream_t ss = reinterpret_cast<hipStream_t>(stream);
-    if (a.dtype == JEN1_F32) hipLaunchKernelGGL(train_gemm_skinny_kernel<float>, sgrid, dim3(NT), 0, ss, g);
-    else hipLaunchKernelGGL(train_gemm_skinny_kernel<bf16_t>, sgrid, dim3(NT), 0, ss, g);
-    JEN1_HIP(hipGetLastError());
+    grid = dim3((a.M + 31) / 32, (a.N + 15) / 16, (unsigned)gz);
     return 0;
   }
-  dim3 grid(g.tall ? (a.M + 2 * BM - 1) / (2 * BM) : (a.M + BM - 1) / BM, g.tall ? 1 : gy, (unsigned)gz);
+  grid = dim3(g.tall ? (a.M + 2 * BM - 1) / (2 * BM) : (a.M + BM - 1) / BM, g.tall ? 1 : gy, (unsigned)gz);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
+  GemmDev g;
+  dim3 grid;
+  bool skinny = false;
+  if (prepare(args, g, grid, skinny)) return 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (a.dtype == JEN1_F32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);
-  else hipLaunchKernelGGL(train_gemm_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
+  const bool f32 = args->dtype == JEN1_F32;
+  if (skinny) {
+    if (f32) hipLaunchKernelGGL(train_gemm_skinny_kernel<float>, grid, dim3(NT), 0, s, g);
+    else hipLaunchKernelGGL(train_gemm_skinny_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
+  } else {
+    if (f32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);
+    else hipLaunchKernelGGL(train_gemm_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
+  }
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_train_gemm_pair(const jen1_gemm_args* first, const jen1_gemm_args* second, void* stream) {
+  PairDev p;
+  dim3 g0, g1;
+  bool sk0 = false, sk1 = false;
+  if (prepare(first, p.g0, g0, sk0) || prepare(second, p.g1, g1, sk1)) return 1;
+  JEN1_CHECK(first->dtype == second->dtype, "train_gemm_pair: both products must have one dtype");
+  JEN1_CHECK(!sk0, "train_gemm_pair: the first product must be of the 64 x 64 form (the skinny form is for the second)");
+  const long long nb0 = (long long)g0.x * g0.y * g0.z, nb1 = (long long)g1.x * g1.y * g1.z;
+  JEN1_CHECK(nb0 + nb1 < (1ll << 31), "train_gemm_pair: grid too large");
+  p.nb1 = (int)nb1; p.gx0 = (int)g0.x; p.gy0 = (int)g0.y; p.gx1 = (int)g1.x; p.gy1 = (int)g1.y;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(nb0 + nb1));
+  const bool f32 = first->dtype == JEN1_F32;
+  if (sk1) {
+    if (f32) hipLaunchKernelGGL((train_gemm_pair_kernel<float, true>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((train_gemm_pair_kernel<bf16_t, true>), grid, dim3(NT), 0, s, p);
+  } else {
+    if (f32) hipLaunchKernelGGL((train_gemm_pair_kernel<float, false>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((train_gemm_pair_kernel<bf16_t, false>), grid, dim3(NT), 0, s, p);
+  }
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -78,7 +78,7 @@ class TrainRuntime:
         self.fused_repack = os.environ.get("JEN1_TRAIN_FUSED_REPACK", "1") == "1"      # every compute copy in one launch (jen1_repack)
         self._repack_tab, self._repack_meta, self._repack_n = None, (0, 0), -1
         self.skinny_max_steps = int(os.environ.get("JEN1_TRAIN_SKINNY_STEPS", "64"))      # K steps per wave
-        self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "512"))
+        self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "256"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
         # weight gradients on their own stream (weight_grad below)
         self.wgrad_group = int(os.environ.get("JEN1_TRAIN_WGRAD_GROUP", "64"))         # layers per fork; 0: on the pass's own stream
@@ -89,6 +89,8 @@ class TrainRuntime:
         self._wjoin: list = []                   # streams the weight-gradient stream was forked from in the running backward pass
         # every block's FiLM projection as one GEMM (FilmBankFn)
         self.film_bank = os.environ.get("JEN1_TRAIN_FILM_BANK", "1") == "1"
+        # a layer's weight gradient and data gradient in one launch (jen1_train_gemm_pair)
+        self.pair_grads = os.environ.get("JEN1_TRAIN_PAIR_GRADS", "1") == "1"
         self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
 
     # ------------------------------------------------------------------ plumbing
@@ -287,7 +289,9 @@ class TrainRuntime:
              batches: int = 1, taps_in_z: bool = False, ldc_m: int, ldc_n: int = 1, c_tap_stride: int = 0, c_zs0: int = 0,
              c_zs1: int = 0, c_zdiv: int = 1, bias: Optional[torch.Tensor] = None, splitk: int = 1, atomic: bool = False,
              accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0, rowsum: Optional[torch.Tensor] = None,
-             residual: Optional[torch.Tensor] = None, skinny: bool = False) -> None:
+             residual: Optional[torch.Tensor] = None, skinny: bool = False, defer: bool = False, pair_with=None):
+        """``defer``: no launch, the filled argument block comes back; ``pair_with`` (such a block): both products in ONE launch
+        (jen1_train_gemm_pair: the deferred one first)"""
         g = L.GemmArgs()
         g.a, g.b, g.c, g.bias = a, b, c_ptr, (None if bias is None else bias.data_ptr())
         g.c_zs0, g.c_zs1, g.ldc_m, g.ldc_n, g.c_tap_stride, g.c_zdiv = c_zs0, c_zs1, ldc_m, ldc_n, c_tap_stride, c_zdiv
@@ -297,7 +301,13 @@ class TrainRuntime:
         g.rowsum = None if rowsum is None else rowsum.data_ptr()
         g.residual = None if residual is None else residual.data_ptr()
         g.reserved = 1 if skinny else 0
-        L.check(self.lib.jen1_train_gemm(g, self.stream()), "jen1_train_gemm")
+        if defer:
+            return g
+        if pair_with is not None:
+            L.check(self.lib.jen1_train_gemm_pair(pair_with, g, self.stream()), "jen1_train_gemm_pair")
+        else:
+            L.check(self.lib.jen1_train_gemm(g, self.stream()), "jen1_train_gemm")
+        return None
 
     def split_accumulator(self, n: int) -> torch.Tensor:
         """the persistent zeroed float32 scratch every split-K forward / data-gradient GEMM of the stream accumulates
@@ -393,9 +403,10 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     return y
 
 
-def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeom, wd: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeom, wd: Optional[torch.Tensor] = None, pair_with=None) -> torch.Tensor:
     """``wd``: the data-gradient copy [k][Ci][pad8(Co)] of the weight (both GEMM operands K-contiguous: the register-direct
-    path of jen1_train_gemm); without it the forward copy ``wp`` is read transposed through LDS"""
+    path of jen1_train_gemm); without it the forward copy ``wp`` is read transposed through LDS.  ``pair_with``: the deferred
+    weight-gradient product of the same layer, launched together with this one"""
     dt = rt.dt_of(dy)
     ldy = dy.shape[-1]
     k, co, cip = wp.shape
@@ -417,16 +428,18 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     sk = 1 if skinny else rt.pick_splitk(M, cip, ksteps)
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_in * cip)
-        rt.gemm(a, b, acc.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True)
+        rt.gemm(a, b, acc.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True, pair_with=pair_with)
         return rt.hand_over(acc, torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device))
     dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
-    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny)
+    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with)
     return dx
 
 
-def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.Tensor, g: ConvGeom, gb: Optional[torch.Tensor] = None) -> bool:
+def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.Tensor, g: ConvGeom, gb: Optional[torch.Tensor] = None,
+                defer: bool = False):
     """gw (float32, reference layout) += the weight gradient.  ``gb`` (bias gradient) is accumulated by the same launch
-    when dy is the row operand (Conv1d / Linear); returns whether it was."""
+    when dy is the row operand (Conv1d / Linear); returns whether it was -- with ``defer`` (whether, the argument block of the
+    launch that has NOT been issued)."""
     dt = rt.dt_of(x)
     ldx, ldy = x.shape[-1], dy.shape[-1]
     rows_dy = dy.numel() // ldy
@@ -451,9 +464,9 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
     # one K slice: every (tap, tile) of the gradient belongs to exactly one workgroup of this launch and launches are
     # stream-ordered, so a plain read-modify-write accumulates; float atomics only when the K range is split
     na = sk == 1 and rt.wgrad_plain_rmw
-    rt.gemm(a, b, gw.data_ptr(), M, N, K, dtype=dt, taps=k, taps_in_z=True, ldc_m=N * k, ldc_n=k, c_tap_stride=1,
-            splitk=sk, atomic=not na, accumulate=na, c_f32=True, rowsum=gb if fused_bias else None)
-    return fused_bias
+    blk = rt.gemm(a, b, gw.data_ptr(), M, N, K, dtype=dt, taps=k, taps_in_z=True, ldc_m=N * k, ldc_n=k, c_tap_stride=1,
+                  splitk=sk, atomic=not na, accumulate=na, c_f32=True, rowsum=gb if fused_bias else None, defer=defer)
+    return (fused_bias, blk) if defer else fused_bias
 
 
 class ConvFn(Function):
@@ -477,11 +490,21 @@ class ConvFn(Function):
         gw = rt.grad_of(ctx.weight)
         has_bias = ctx.bias is not None
 
+        def colsum():
+            ldy = dy.shape[-1]
+            L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()), "jen1_colsum")
+
+        if ctx.needs_input_grad[0] and rt.pair_grads:
+            # both gradients of the layer in one launch: they share dY and nothing orders them
+            fused, blk = _conv_wgrad(rt, x, dy, gw, g, gb, defer=True)
+            dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd, pair_with=blk).view(x.shape)
+            if not fused and has_bias:
+                rt.weight_grad(colsum, dy)
+            return dx, None, None, None, None, (dy if ctx.has_res else None)
+
         def wgrad():
             if not _conv_wgrad(rt, x, dy, gw, g, gb) and has_bias:
-                ldy = dy.shape[-1]
-                L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()),
-                        "jen1_colsum")
+                colsum()
         rt.weight_grad(wgrad, x, dy)
         dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd).view(x.shape) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None, (dy if ctx.has_res else None)       # (the residual's gradient IS dy: no launch)

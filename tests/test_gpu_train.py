@@ -944,3 +944,47 @@ def test_weight_gradients_on_the_second_stream_equal_in_order_launches(use_graph
         assert float(grads[group].abs().max()) > 0
     for group in (3, 1000):
         assert float((grads[group] - grads[0]).abs().max()) <= 2e-5 * float(grads[0].abs().max()), group
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("skinny_second", [False, True])
+def test_gemm_pair_equals_two_launches(rts, mode, skinny_second):
+    """jen1_train_gemm_pair: two independent products in one launch give, bit for bit, what the two jen1_train_gemm launches give
+    (64 x 64 form first; 64 x 64 or skinny form second; ragged M / N / K)"""
+    from jen1_amd.train import _operand
+    rt = rts[mode]
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    M0, N0, K0 = 200, 136, 72            # first: K not contiguous on either operand (the weight-gradient layout), float32 accumulate
+    M1, N1, K1 = (24, 520, 256) if skinny_second else (150, 100, 96)
+    a0 = torch.randn(K0, M0, device="cuda", generator=gen).to(dt)
+    b0 = torch.randn(K0, N0, device="cuda", generator=gen).to(dt)
+    a1 = torch.randn(M1, K1, device="cuda", generator=gen).to(dt)
+    b1 = torch.randn(N1, K1, device="cuda", generator=gen).to(dt)
+    init0 = torch.randn(M0, N0, device="cuda", generator=gen)
+
+    def run(paired):
+        c0 = init0.clone()
+        c1 = torch.zeros(M1, N1, device="cuda", dtype=dt)
+        kw0 = dict(dtype=rt.dt, ldc_m=N0, accumulate=True, c_f32=True)
+        kw1 = dict(dtype=rt.dt, ldc_m=N1, skinny=skinny_second)
+        o0 = (_operand(a0.data_ptr(), 1, M0), _operand(b0.data_ptr(), 1, N0))
+        o1 = (_operand(a1.data_ptr(), K1, 1), _operand(b1.data_ptr(), K1, 1))
+        if paired:
+            blk = rt.gemm(o0[0], o0[1], c0.data_ptr(), M0, N0, K0, defer=True, **kw0)
+            rt.gemm(o1[0], o1[1], c1.data_ptr(), M1, N1, K1, pair_with=blk, **kw1)
+        else:
+            rt.gemm(o0[0], o0[1], c0.data_ptr(), M0, N0, K0, **kw0)
+            rt.gemm(o1[0], o1[1], c1.data_ptr(), M1, N1, K1, **kw1)
+        torch.cuda.synchronize()
+        return c0, c1
+
+    p0, p1 = run(True)
+    s0, s1 = run(False)
+    assert torch.equal(p0, s0) and torch.equal(p1, s1)
+    ref0 = init0 + a0.float().t() @ b0.float()
+    ref1 = a1.float() @ b1.float().t()
+    tol = 1e-4 if mode == "f32" else 2e-2
+    assert float((p0 - ref0).abs().max()) <= tol * float(ref0.abs().max())
+    assert float((p1.float() - ref1).abs().max()) <= tol * float(ref1.abs().max())
