@@ -340,45 +340,75 @@ __device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int 
   const bool do_rowsum = g.rowsum != nullptr && by == 0 && tap_z == 0;
   float rsum = 0.f;
 
+  // plain read-modify-write of a float32 C (the weight gradient accumulating into .grad): the tile's old values are requested HERE,
+  // all sixteen at once and ahead of the K loop.  Read in the epilogue, each load would sit behind the previous element's store
+  // (the compiler cannot reorder them: same array) -- sixteen memory round trips in a row, ~15 us, the floor of every weight-
+  // gradient launch before this.
+  char* cb = reinterpret_cast<char*>(g.c);
+  const long long coff = (long long)(z / g.c_zdiv) * g.c_zs0 + (long long)(z % g.c_zdiv) * g.c_zs1 + (long long)tap_z * g.c_tap_stride;
+  const bool rmw32 = g.c_f32 && !g.atomic && g.accumulate;
+  float cold[2][2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 32 + ni * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + mi * 16 + (lane >> 4) * 4 + r;
+        cold[mi][ni][r] = 0.f;
+        if (rmw32 && n < g.N && m < g.M) cold[mi][ni][r] = reinterpret_cast<const float*>(cb)[coff + (long long)m * g.ldc_m + (long long)n * g.ldc_n];
+      }
+    }
+
   if (g.direct) {
     direct_loop<T>(g, abase, bbase, m0, n0, wm, wn, lane, s_begin, s_end, ksteps, acc);
   } else {
-  Staged<T> sa, sb;
+  // ST steps of global loads in flight per thread (a step is one 16-byte vector per operand in bf16, two in float32).  Measured on
+  // the weight gradients (tools/wgrad_shapes.py): ST = 2 changes nothing, ST = 4 is SLOWER (512 x 512 x 192: 13.4 -> 17.9 us) -- a step's
+  // ~1.3 us is address arithmetic and the transposing LDS writes, not the memory round trip.
+  constexpr int ST = 1;
+  Staged<T> sa[ST], sb[ST];
   Pre<T> pa, pb;
   // with one matrix per tap (weight gradient) the steps of this K slice are consecutive in k: s -> k0 = s * BK
   pre_init<T>(pa, g.a, m0, s_begin * BK, g.taps_in_z != 0, tid);
   pre_init<T>(pb, g.b, n0, s_begin * BK, g.taps_in_z != 0, tid);
-  auto fetch_step = [&](int s) {
+  auto fetch_step = [&](int s, Staged<T>& xa, Staged<T>& xb) {      // (called in step order: the hoisted indices advance per call)
     const int tap = g.taps_in_z ? tap_z : s / ksteps;
     const int k0 = (g.taps_in_z ? s : s % ksteps) * BK;
-    fetch<T>(sa, pa, g.a, abase, m0, tap, k0, g.K, tid);
-    fetch<T>(sb, pb, g.b, bbase, n0, tap, k0, g.K, tid);
+    fetch<T>(xa, pa, g.a, abase, m0, tap, k0, g.K, tid);
+    fetch<T>(xb, pb, g.b, bbase, n0, tap, k0, g.K, tid);
   };
-  if (s_begin < s_end) fetch_step(s_begin);
-  for (int s = s_begin; s < s_end; ++s) {
-    stash<T, PITCH>(sa, g.a, As, tid);
-    stash<T, PITCH>(sb, g.b, Bs, tid);
-    __syncthreads();
-    if (s + 1 < s_end) fetch_step(s + 1);
-    if (do_rowsum && tid < BM) {
 #pragma unroll
-      for (int k = 0; k < BK; ++k) rsum += (float)As[tid * PITCH + k];
+  for (int u = 0; u < ST; ++u)
+    if (s_begin + u < s_end) fetch_step(s_begin + u, sa[u], sb[u]);
+  for (int s0 = s_begin; s0 < s_end; s0 += ST) {
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int s = s0 + u;
+      if (s >= s_end) break;
+      stash<T, PITCH>(sa[u], g.a, As, tid);
+      stash<T, PITCH>(sb[u], g.b, Bs, tid);
+      __syncthreads();
+      if (s + ST < s_end) fetch_step(s + ST, sa[u], sb[u]);
+      if (do_rowsum && tid < BM) {
+#pragma unroll
+        for (int k = 0; k < BK; ++k) rsum += (float)As[tid * PITCH + k];
+      }
+      const int kq = (lane >> 4) * 8, rr = lane & 15;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          mma8(acc[mi][ni], As + (wm * 32 + mi * 16 + rr) * PITCH + kq, Bs + (wn * 32 + ni * 16 + rr) * PITCH + kq);
+      __syncthreads();
     }
-    const int kq = (lane >> 4) * 8, rr = lane & 15;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-        mma8(acc[mi][ni], As + (wm * 32 + mi * 16 + rr) * PITCH + kq, Bs + (wn * 32 + ni * 16 + rr) * PITCH + kq);
-    __syncthreads();
   }
   }
 
   if (do_rowsum && tid < BM && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, g.alpha * rsum);
 
   // epilogue: acc[r] <-> (m = 4 * (lane / 16) + r, n = lane % 16) of the 16 x 16 tile
-  char* cb = reinterpret_cast<char*>(g.c);
-  const long long coff = (long long)(z / g.c_zdiv) * g.c_zs0 + (long long)(z % g.c_zdiv) * g.c_zs1 + (long long)tap_z * g.c_tap_stride;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -395,7 +425,7 @@ __device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int 
         if (g.c_f32) {
           float* cp = reinterpret_cast<float*>(cb) + off;
           if (g.atomic) atomicAdd(cp, v);
-          else { if (g.accumulate) v += *cp; *cp = v; }
+          else *cp = v + cold[mi][ni][r];
         } else {
           T* cp = reinterpret_cast<T*>(cb) + off;
           if (g.accumulate) v += (float)*cp;
@@ -565,6 +595,25 @@ __global__ __launch_bounds__(NT) void train_gemm_pair_kernel(const PairDev p) {
     if constexpr (SKINNY1) skinny_body<T>(p.g1, bx, id % p.gy1, id / p.gy1, reinterpret_cast<SkinnyRed*>(lds));
     else gemm_body<T>(p.g1, bx, id % p.gy1, id / p.gy1, As, Bs);
   }
+}
+
+int check_operand(const jen1_gemm_operand& o, const char* name) {
+  JEN1_CHECK(o.p != nullptr, "train_gemm: operand %s is NULL", name);
+  JEN1_CHECK(o.zdiv >= 1, "train_gemm: operand %s: zdiv must be >= 1", name);
+  JEN1_CHECK(o.map_axis >= 0 && o.map_axis <= 2, "train_gemm: operand %s: map_axis must be 0, 1 or 2", name);
+  if (o.map_axis) {
+    JEN1_CHECK(o.map_L >= 1 && o.map_Lsrc >= 1 && o.map_div >= 1 && o.map_mul >= 1,
+               "train_gemm: operand %s: map_L, map_Lsrc, map_mul and map_div must be >= 1", name);
+  }
+  return 0;
+}
+
+Operand to_dev(const jen1_gemm_operand& o, int rows) {
+  Operand d;
+  d.p = o.p; d.ld_r = o.ld_r; d.ld_k = o.ld_k; d.tap_stride = o.tap_stride;
+  d.map_axis = o.map_axis; d.map_L = o.map_L; d.map_Lsrc = o.map_Lsrc; d.map_mul = o.map_mul;
+  d.map_tapmul = o.map_tapmul; d.map_shift = o.map_shift; d.map_div = o.map_div; d.map_reflect = o.map_reflect ? 1 : 0; d.rows = rows;
+  return d;
 }
 
 // validates one call and lays out its launch: the device descriptor, the grid, and whether it is the skinny form
