@@ -35,6 +35,7 @@ struct GemmDev {
   int M, N, K, taps, taps_in_z, splitk, atomic, accumulate, c_f32;
   int direct;        // both operands K-contiguous, fragments straight from global memory (no LDS staging)
   int tall;          // direct path only: the 4 waves stack along M (tile 128 x 32) because N <= 32
+  int fastw;         // weight-gradient layout (both operands [k][row], rows contiguous, bf16): wgrad_loop instead of the generic staging
   float alpha;
 };
 
@@ -299,6 +300,79 @@ __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, co
   }
 }
 
+// ---- K loop of the weight gradient (bf16): C[m][n] += sum_k A[k][m] * B[map(k, tap)][n], both operands stored [k][row] with the rows
+// contiguous (dY and the layer's input as they lie in memory).  The generic staging above transposes on the way INTO LDS: eight 2-byte
+// scattered writes per 16-byte vector, most of them on two banks, behind address arithmetic written for every layout -- ~1.3 us of CU
+// time per 32-k step, which is what every weight-gradient launch of the pass was made of.  Here a step's tiles go into LDS as they
+// are (one 16-byte global load + two 8-byte LDS stores per thread and operand, rows 136 bytes apart), and the transposition happens
+// on the way OUT: a lane's MFMA fragment (row i, 8 consecutive k) is eight 2-byte LDS reads down one column; with the 136-byte pitch
+// the four k groups of a wave land on four different bank groups, the sixteen rows on consecutive half-words.
+constexpr int WP = 68;                           // LDS row pitch in elements (64 + 4)
+
+__device__ __forceinline__ void wgrad_loop(const GemmDev& g, const bf16_t* abase, const bf16_t* bbase, int m0, int n0, int wm, int wn,
+                                           int tap, int s_begin, int s_end, bool do_rowsum, float& rsum, bf16_t* lds,
+                                           f32x4 (&acc)[2][2]) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  bf16_t* At = lds;
+  bf16_t* Bt = lds + BK * WP;
+  const int kk = tid >> 3, cv = (tid & 7) * 8;           // this thread's slot in a step: row kk, columns cv .. cv + 7 of both tiles
+  const bool a_col = m0 + cv + 8 <= (int)g.a.ld_k, b_col = n0 + cv + 8 <= (int)g.b.ld_k;     // (a tile may hang over the matrix)
+  const bf16_t* ap = abase + m0 + cv;
+  const bf16_t* bp = bbase + n0 + cv;
+  int k = s_begin * BK + kk;
+  int kb = 0, kt = k;                                   // (batch element, position) of k under B's index map
+  if (g.b.map_axis == 2) { kb = k / g.b.map_L; kt = k - kb * g.b.map_L; }
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 ra = zero, rb = zero;
+  auto fetch_ab = [&]() {
+    ra = zero;
+    rb = zero;
+    if (k < g.K) {
+      if (a_col) ra = *reinterpret_cast<const bf16x8*>(ap + (long long)k * g.a.ld_k);
+      long long row = k;
+      if (g.b.map_axis == 2) row = map_from_bt(g.b, kb, kt, tap);
+      if (b_col && row >= 0) rb = *reinterpret_cast<const bf16x8*>(bp + row * g.b.ld_k);
+    }
+    k += BK;
+    if (g.b.map_axis == 2) {
+      kt += BK;
+      while (kt >= g.b.map_L) { kt -= g.b.map_L; ++kb; }
+    }
+  };
+  if (s_begin < s_end) fetch_ab();
+  const int li = lane & 15, kq = (lane >> 4) * 8;
+  typedef unsigned long long u64;
+  for (int s = s_begin; s < s_end; ++s) {
+    {
+      const u64* pa = reinterpret_cast<const u64*>(&ra);
+      const u64* pb = reinterpret_cast<const u64*>(&rb);
+      u64* da = reinterpret_cast<u64*>(At + kk * WP + cv);
+      u64* db = reinterpret_cast<u64*>(Bt + kk * WP + cv);
+      da[0] = pa[0]; da[1] = pa[1];
+      db[0] = pb[0]; db[1] = pb[1];
+    }
+    __syncthreads();
+    if (s + 1 < s_end) fetch_ab();
+    if (do_rowsum && tid < BM) {
+#pragma unroll
+      for (int j = 0; j < BK; ++j) rsum += (float)At[j * WP + tid];
+    }
+    bf16x8 fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        fa[i][j] = At[(kq + j) * WP + wm * 32 + i * 16 + li];
+        fb[i][j] = Bt[(kq + j) * WP + wn * 32 + i * 16 + li];
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    __syncthreads();
+  }
+}
+
 // one workgroup of the 64 x 64 form: (bx, by, bz) = its position in the grid jen1_train_gemm would launch
 template <typename T>
 __device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int bz, T* As, T* Bs) {
@@ -361,8 +435,12 @@ __device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int 
       }
     }
 
+  bool fastw = false;
+  if constexpr (sizeof(T) == 2) fastw = g.fastw != 0;
   if (g.direct) {
     direct_loop<T>(g, abase, bbase, m0, n0, wm, wn, lane, s_begin, s_end, ksteps, acc);
+  } else if (fastw) {
+    if constexpr (sizeof(T) == 2) wgrad_loop(g, abase, bbase, m0, n0, wm, wn, tap_z, s_begin, s_end, do_rowsum, rsum, As, acc);
   } else {
   // ST steps of global loads in flight per thread (a step is one 16-byte vector per operand in bf16, two in float32).  Measured on
   // the weight gradients (tools/wgrad_shapes.py): ST = 2 changes nothing, ST = 4 is SLOWER (512 x 512 x 192: 13.4 -> 17.9 us) -- a step's
@@ -551,10 +629,10 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
 template <typename T>
 __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
   constexpr int PITCH = BK + 16 / (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
-  __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
+  __shared__ __attribute__((aligned(16))) T tiles[(BM + BN) * PITCH];      // A tile, then B tile (wgrad_loop lays its own two tiles over both)
+  static_assert(sizeof(T) != 2 || 2 * BK * WP <= (BM + BN) * PITCH, "wgrad_loop's tiles must fit");
   jen1_prefetch_kernarg<sizeof(GemmDev)>();      // one batch of scalar loads instead of one round trip per argument line
-  gemm_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+  gemm_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z, tiles, tiles + BM * PITCH);
 }
 
 template <typename T>
@@ -664,6 +742,16 @@ int prepare(const jen1_gemm_args* args, GemmDev& g, dim3& grid, bool& skinny) {
   // narrow outputs (N <= 32, e.g. the last stages of the SEANet decoder): in the 2 x 2 wave layout half of the waves
   // would only multiply padding; on the direct path the four waves stack along M instead
   g.tall = (g.direct && a.N <= 32) ? 1 : 0;
+  {
+    // the weight-gradient layout in bf16: both operands [k][row] with contiguous rows on 16-byte boundaries, one matrix per tap, A
+    // unmapped, B unmapped or mapped along k
+    static const bool no_fastw = getenv("JEN1_TRAIN_GEMM_NO_FASTW") != nullptr;       // tuning / A-B switch, read once
+    auto rows_ok = [&](const jen1_gemm_operand& o) {
+      return o.ld_r == 1 && o.ld_k >= 8 && o.ld_k % 8 == 0 && o.zs0 % 8 == 0 && o.zs1 % 8 == 0 && ((uintptr_t)o.p & 15) == 0 && !o.map_reflect;
+    };
+    g.fastw = (a.dtype == JEN1_BF16 && a.taps_in_z && !g.direct && rows_ok(a.a) && rows_ok(a.b) && a.a.map_axis == 0 &&
+               (a.b.map_axis == 0 || a.b.map_axis == 2) && a.a.tap_stride == 0 && a.b.tap_stride == 0 && !no_fastw) ? 1 : 0;
+  }
   skinny = a.reserved == 1 && g.direct && !g.tall;
   if (skinny) {
     // the caller asked for the skinny form (few rows, a big weight: see train_gemm_skinny_kernel) and the operands allow it
