@@ -305,9 +305,19 @@ __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, co
 // scattered writes per 16-byte vector, most of them on two banks, behind address arithmetic written for every layout -- ~1.3 us of CU
 // time per 32-k step, which is what every weight-gradient launch of the pass was made of.  Here a step's tiles go into LDS as they
 // are (one 16-byte global load + two 8-byte LDS stores per thread and operand, rows 136 bytes apart), and the transposition happens
-// on the way OUT: a lane's MFMA fragment (row i, 8 consecutive k) is eight 2-byte LDS reads down one column; with the 136-byte pitch
-// the four k groups of a wave land on four different bank groups, the sixteen rows on consecutive half-words.
+// on the way OUT: a lane's MFMA fragment (row i, 8 consecutive k) is two hardware transpose reads (ds_read_b64_tr_b16) down one
+// column.
 constexpr int WP = 68;                           // LDS row pitch in elements (64 + 4)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_pair(const bf16_t* lo, const bf16_t* hi) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(hi));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
 
 __device__ __forceinline__ void wgrad_loop(const GemmDev& g, const bf16_t* abase, const bf16_t* bbase, int m0, int n0, int wm, int wn,
                                            int tap, int s_begin, int s_end, bool do_rowsum, float& rsum, bf16_t* lds,
@@ -323,15 +333,16 @@ __device__ __forceinline__ void wgrad_loop(const GemmDev& g, const bf16_t* abase
   int kb = 0, kt = k;                                   // (batch element, position) of k under B's index map
   if (g.b.map_axis == 2) { kb = k / g.b.map_L; kt = k - kb * g.b.map_L; }
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  bf16x8 ra = zero, rb = zero;
-  auto fetch_ab = [&]() {
-    ra = zero;
-    rb = zero;
+  constexpr int WST = 4;                                 // steps of global loads in flight (one 16-byte vector per operand each)
+  bf16x8 ra[WST], rb[WST];
+  auto fetch_ab = [&](bf16x8& xa, bf16x8& xb) {          // (called in step order)
+    xa = zero;
+    xb = zero;
     if (k < g.K) {
-      if (a_col) ra = *reinterpret_cast<const bf16x8*>(ap + (long long)k * g.a.ld_k);
+      if (a_col) xa = *reinterpret_cast<const bf16x8*>(ap + (long long)k * g.a.ld_k);
       long long row = k;
       if (g.b.map_axis == 2) row = map_from_bt(g.b, kb, kt, tap);
-      if (b_col && row >= 0) rb = *reinterpret_cast<const bf16x8*>(bp + row * g.b.ld_k);
+      if (b_col && row >= 0) xb = *reinterpret_cast<const bf16x8*>(bp + row * g.b.ld_k);
     }
     k += BK;
     if (g.b.map_axis == 2) {
@@ -339,37 +350,59 @@ __device__ __forceinline__ void wgrad_loop(const GemmDev& g, const bf16_t* abase
       while (kt >= g.b.map_L) { kt -= g.b.map_L; ++kb; }
     }
   };
-  if (s_begin < s_end) fetch_ab();
+#pragma unroll
+  for (int u = 0; u < WST; ++u)
+    if (s_begin + u < s_end) fetch_ab(ra[u], rb[u]);
   const int li = lane & 15, kq = (lane >> 4) * 8;
   typedef unsigned long long u64;
-  for (int s = s_begin; s < s_end; ++s) {
-    {
-      const u64* pa = reinterpret_cast<const u64*>(&ra);
-      const u64* pb = reinterpret_cast<const u64*>(&rb);
-      u64* da = reinterpret_cast<u64*>(At + kk * WP + cv);
-      u64* db = reinterpret_cast<u64*>(Bt + kk * WP + cv);
-      da[0] = pa[0]; da[1] = pa[1];
-      db[0] = pb[0]; db[1] = pb[1];
-    }
-    __syncthreads();
-    if (s + 1 < s_end) fetch_ab();
-    if (do_rowsum && tid < BM) {
+  float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s0 = s_begin; s0 < s_end; s0 += WST) {
 #pragma unroll
-      for (int j = 0; j < BK; ++j) rsum += (float)At[j * WP + tid];
-    }
-    bf16x8 fa[2], fb[2];
+    for (int u = 0; u < WST; ++u) {
+      const int s = s0 + u;
+      if (s >= s_end) break;
+      if (do_rowsum) {                                   // bias gradient: column sums of A, from the registers that hold its rows
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 8; ++j) rs[j] += (float)ra[u][j];
+      }
+      {
+        const u64* pa = reinterpret_cast<const u64*>(&ra[u]);
+        const u64* pb = reinterpret_cast<const u64*>(&rb[u]);
+        u64* da = reinterpret_cast<u64*>(At + kk * WP + cv);
+        u64* db = reinterpret_cast<u64*>(Bt + kk * WP + cv);
+        da[0] = pa[0]; da[1] = pa[1];
+        db[0] = pb[0]; db[1] = pb[1];
+      }
+      __syncthreads();
+      if (s + WST < s_end) fetch_ab(ra[u], rb[u]);
+      // ds_read_b64_tr_b16: the sixteen lanes of a k group each name 4 consecutive columns of one of 4 consecutive rows (lane p: row
+      // p / 4, columns 4 (p % 4) ..) and receive column p of that 4 x 16 block, i.e. 4 consecutive k of their own row of the fragment
+      bf16x8 fa[2], fb[2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        fa[i][j] = At[(kq + j) * WP + wm * 32 + i * 16 + li];
-        fb[i][j] = Bt[(kq + j) * WP + wn * 32 + i * 16 + li];
+      for (int i = 0; i < 2; ++i) {
+        const int ao = (kq + (li >> 2)) * WP + wm * 32 + i * 16 + (li & 3) * 4;
+        const int bo = (kq + (li >> 2)) * WP + wn * 32 + i * 16 + (li & 3) * 4;
+        fa[i] = tr_pair(At + ao, At + ao + 4 * WP);
+        fb[i] = tr_pair(Bt + bo, Bt + bo + 4 * WP);
       }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+      __syncthreads();
+    }
+  }
+  if (do_rowsum) {                                       // the 32 threads of a column group meet in LDS once, in a fixed order
+    float* red = reinterpret_cast<float*>(lds);          // [32][64] float32 = 8 KB over the two tiles (the loop is done with them)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[kk * BM + cv + j] = rs[j];
     __syncthreads();
+    if (tid < BM) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < BK; ++r) t += red[r * BM + tid];
+      rsum = t;
+    }
   }
 }
 
