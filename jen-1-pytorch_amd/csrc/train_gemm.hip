@@ -559,10 +559,11 @@ template <> struct SkinnyPF<float> { static constexpr int PF = 3; };
 typedef float SkinnyRed[2][64][4];
 constexpr int SKINNY_RED_BYTES = 3 * (int)sizeof(SkinnyRed);
 
-template <typename T>
+// NW waves split the K steps of the workgroup's 32 x 16 tile (step s goes to wave s mod NW)
+template <typename T, int NW = 4>
 __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, int bz, SkinnyRed* red) {
   typedef typename DFrag<T>::type Frag;
-  constexpr int PF = SkinnyPF<T>::PF;
+  constexpr int PF = (NW == 16 && sizeof(T) == 2) ? 6 : SkinnyPF<T>::PF;      // (16 waves leave 128 registers per lane)
   constexpr unsigned ES = sizeof(T);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = bx * 32, n0 = by * 16;
@@ -597,7 +598,7 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
   int s_next = s_begin + wave;
   auto issue = [&](Frag (&xa)[2], Frag& xb) {
     const int s = s_next;
-    s_next += NT / 64;
+    s_next += NW;
     const int tap = s / ksteps, k = (s - tap * ksteps) * BK + kq;
     const bool live = s < s_end && k < g.K;
     const unsigned tb = (unsigned)((long long)tap * g.b.tap_stride + k) * ES;
@@ -612,10 +613,10 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) issue(fa[u], fb[u]);
-  for (int c = s_begin + wave; c < s_end; c += PF * (NT / 64)) {
+  for (int c = s_begin + wave; c < s_end; c += PF * NW) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      if (c + u * (NT / 64) < s_end) {
+      if (c + u * NW < s_end) {
         dmma(acc[0], fa[u][0], fb[u]);
         dmma(acc[1], fa[u][1], fb[u]);
       }
@@ -634,7 +635,7 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
   for (int mi = 0; mi < 2; ++mi) {
     float4 t = make_float4(acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]);
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < NW - 1; ++w) {
       const float4 o = *reinterpret_cast<const float4*>(&red[w][mi][lane][0]);
       t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
     }
@@ -668,11 +669,11 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
   gemm_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z, tiles, tiles + BM * PITCH);
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void train_gemm_skinny_kernel(const GemmDev g) {
-  __shared__ __attribute__((aligned(16))) SkinnyRed red[3];
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void train_gemm_skinny_kernel(const GemmDev g) {
+  __shared__ __attribute__((aligned(16))) SkinnyRed red[NW - 1];
   jen1_prefetch_kernarg<sizeof(GemmDev)>();
-  skinny_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z, red);
+  skinny_body<T, NW>(g, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
 // ---- two independent products in ONE launch (jen1_train_gemm_pair): the weight gradient and the data gradient of a layer read the
@@ -807,8 +808,14 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool f32 = args->dtype == JEN1_F32;
   if (skinny) {
-    if (f32) hipLaunchKernelGGL(train_gemm_skinny_kernel<float>, grid, dim3(NT), 0, s, g);
-    else hipLaunchKernelGGL(train_gemm_skinny_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
+    // waves per workgroup by the length of the K walk: a wave keeps 8 (bf16) / 3 (float32) steps of loads in flight, and a tile with
+    // 96 steps (3 taps x 1024 channels) on 4 waves is three memory round trips in a row where 16 waves make it one
+    const int steps = ((args->K + BK - 1) / BK) * args->taps / args->splitk;
+    const int nw = steps >= 64 ? 16 : steps >= 48 ? 8 : 4;      // (32 steps on 8 waves measured slower than on 4: 7.1 vs 5.6 us)
+#define JEN1_SKINNY(TT, NWV) hipLaunchKernelGGL((train_gemm_skinny_kernel<TT, NWV>), grid, dim3(NWV * 64), 0, s, g)
+    if (f32) { if (nw == 16) JEN1_SKINNY(float, 16); else if (nw == 8) JEN1_SKINNY(float, 8); else JEN1_SKINNY(float, 4); }
+    else { if (nw == 16) JEN1_SKINNY(bf16_t, 16); else if (nw == 8) JEN1_SKINNY(bf16_t, 8); else JEN1_SKINNY(bf16_t, 4); }
+#undef JEN1_SKINNY
   } else {
     if (f32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);
     else hipLaunchKernelGGL(train_gemm_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
