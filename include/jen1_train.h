@@ -113,6 +113,20 @@ int jen1_act_backward(const void* dy, const void* x, void* dx, int64_t n, int mo
 int jen1_softmax_forward(const float* s, void* p, int rows, int Nq, int Nk, int ld_s, int ld_p, int causal, int dtype, void* stream);
 int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, int Nk, int ld_s, int ld_p, int dtype, void* stream);
 
+/* --- the whole attention core (AttentionBase.forward, math path, blocks.py:355-380) of SHORT sequences in one launch each way: one
+ * workgroup per (batch element, head) keeps Q, K, V (and dO) in LDS -- the transformer blocks of JEN-1 sit where a 1500-frame clip
+ * is 1 .. 24 positions and the text context 130 tokens.  q [B][Nq][ldq], k / v [B][Nk][ldk / ldv], o / d_o [B][Nq][ldo] hold head h
+ * in columns [h d, (h + 1) d); p [B H][Nq][ldp] (dtype) is the softmax output rounded to the dtype (P V uses the rounded values;
+ * columns Nk .. ldp - 1 are written as 0), saved for the backward pass; causal keeps j <= i + (Nk - Nq) (blocks.py:315-319).
+ * backward writes dq [B][Nq][lddq], dk [B][Nk][lddk], dv [B][Nk][lddv] (head h in the same columns).
+ * jen1_attn_small_fits: whether (Nq, Nk, d) fit one workgroup's LDS (callers fall back to jen1_train_gemm + softmax otherwise). */
+int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype);
+int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                            void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal, int dtype, void* stream);
+int jen1_attn_small_backward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* p,
+                             int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                             int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, int dtype, void* stream);
+
 /* dst[i] = (dtype) src[i]; src[i] = 0  for i < n (n a multiple of 4): hands the float32 accumulator of a split-K GEMM
  * over in the compute dtype and leaves it zeroed for the next launch of the stream. */
 int jen1_convert_clear(float* src, void* dst, int64_t n, int dtype, void* stream);

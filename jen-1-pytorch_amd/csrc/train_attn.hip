@@ -1,0 +1,245 @@
+// jen1_attn_small_forward / jen1_attn_small_backward: the attention core of the training path (AttentionBase.forward, math path:
+// reference blocks.py:355-380) for SHORT sequences -- the transformer blocks of JEN-1 sit at the deep levels of the UNet, where a
+// 1500-frame clip is 1 .. 24 positions and the text context 130 tokens.  As three + five launches of jen1_train_gemm / softmax per
+// attention (208 launches per pass) these products are pure launch latency: a (batch element, head) is 24 x 130 x 64 multiply-adds.
+// Here one workgroup owns one (batch element, head): Q, K, V (and dO) go into LDS once, the scores, the softmax, P V -- and in the
+// backward pass dP, dS, dQ, dK, dV -- are computed from there in float32 on the vector units.  Results follow the GEMM path's
+// roundings where they are visible to the rest of the pass: P is rounded to the activations' dtype before P V and is what the
+// backward pass reads; dS stays float32 (the GEMM path rounds it once more).
+#include "common.h"
+#include "jen1_train.h"
+
+namespace {
+
+constexpr int ANT = 256;
+
+struct AttnDev {
+  const void* q; const void* k; const void* v; const void* d_o;
+  void* o; void* p; void* dq; void* dk; void* dv;
+  long long ldq, ldk, ldv, ldo, ldp, lddq, lddk, lddv;      // row pitches (elements)
+  int B, H, Nq, Nk, d, causal;
+  float scale;
+};
+
+// rows [n][d] of one head from a [B][n][ld] tensor -> LDS rows of pitch dp (elements of T); 16-byte vectors when the head's rows
+// start on 16-byte boundaries
+template <typename T>
+__device__ __forceinline__ void stage_rows(T* dst, int dp, const T* src, long long ld, int n, int d, bool vec_ok) {
+  constexpr int V = 16 / (int)sizeof(T);
+  if (vec_ok) {
+    const int vpr = d / V;
+    for (int e = threadIdx.x; e < n * vpr; e += ANT) {
+      const int r = e / vpr, c = (e - r * vpr) * V;
+      const uint4 w = *reinterpret_cast<const uint4*>(src + (long long)r * ld + c);
+      T tmp[V];
+      *reinterpret_cast<uint4*>(tmp) = w;
+#pragma unroll
+      for (int j = 0; j < V; ++j) dst[r * dp + c + j] = tmp[j];
+    }
+  } else {
+    for (int e = threadIdx.x; e < n * d; e += ANT) {
+      const int r = e / d, c = e - r * d;
+      dst[r * dp + c] = src[(long long)r * ld + c];
+    }
+  }
+}
+
+__device__ __forceinline__ bool rows_aligned(const void* p, long long ld, int d, int esz) {
+  const int V = 16 / esz;
+  return (d % V) == 0 && (ld % V) == 0 && ((unsigned long long)p & 15) == 0;
+}
+
+// LDS layout (both kernels): Q [Nq][dp] | K [Nk][dp] | V [Nk][dp] | (dO [Nq][dp]) in T, then S [Nq][sp] (and dS [Nq][sp]) in float
+__host__ __device__ inline int pitch_d(int d, int esz) { return esz == 2 ? (d | 1) + 1 : d | 1; }   // odd number of 4-byte words per row
+__host__ __device__ inline int pitch_s(int Nk) { return Nk | 1; }
+
+template <typename T>
+__global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const int z = blockIdx.x, b = z / a.H, h = z - b * a.H;
+  const int Nq = a.Nq, Nk = a.Nk, d = a.d;
+  const int dp = pitch_d(d, sizeof(T)), sp = pitch_s(Nk);
+  T* Qs = reinterpret_cast<T*>(lds_raw);
+  T* Ks = Qs + Nq * dp;
+  T* Vs = Ks + Nk * dp;
+  float* S = reinterpret_cast<float*>(lds_raw + (((size_t)(Nq + 2 * Nk) * dp * sizeof(T) + 15) & ~(size_t)15));
+  const T* q = reinterpret_cast<const T*>(a.q) + (long long)b * Nq * a.ldq + h * d;
+  const T* k = reinterpret_cast<const T*>(a.k) + (long long)b * Nk * a.ldk + h * d;
+  const T* v = reinterpret_cast<const T*>(a.v) + (long long)b * Nk * a.ldv + h * d;
+  stage_rows<T>(Qs, dp, q, a.ldq, Nq, d, rows_aligned(q, a.ldq, d, sizeof(T)));
+  stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)));
+  stage_rows<T>(Vs, dp, v, a.ldv, Nk, d, rows_aligned(v, a.ldv, d, sizeof(T)));
+  __syncthreads();
+  // scores: consecutive threads take consecutive keys of one query (K rows an odd number of words apart: no bank conflicts)
+  for (int e = threadIdx.x; e < Nq * Nk; e += ANT) {
+    const int i = e / Nk, j = e - i * Nk;
+    float acc = 0.f;
+    for (int c = 0; c < d; ++c) acc += (float)Qs[i * dp + c] * (float)Ks[j * dp + c];
+    S[i * sp + j] = acc * a.scale;
+  }
+  __syncthreads();
+  // softmax over the kept keys, one wave per row; P is rounded to T (what P V multiplies and what the backward pass reads)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* P = reinterpret_cast<T*>(a.p) + (long long)z * Nq * a.ldp;
+  for (int i = wave; i < Nq; i += ANT / 64) {
+    const int lim = a.causal ? min(Nk, i + (Nk - Nq) + 1) : Nk;       // keys j < lim are kept (blocks.py:315-319)
+    float m = -3.0e38f;
+    for (int j = lane; j < lim; j += 64) m = fmaxf(m, S[i * sp + j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float zs = 0.f;
+    for (int j = lane; j < lim; j += 64) zs += expf(S[i * sp + j] - m);
+    for (int o = 32; o > 0; o >>= 1) zs += __shfl_xor(zs, o);
+    const float inv = 1.0f / zs;
+    for (int j = lane; j < (int)a.ldp; j += 64) {
+      const T pv = (T)(j < lim ? expf(S[i * sp + j] - m) * inv : 0.f);
+      P[(long long)i * a.ldp + j] = pv;
+      if (j < Nk) S[i * sp + j] = (float)pv;
+    }
+  }
+  __syncthreads();
+  // O = P V: consecutive threads take consecutive channels of one query
+  T* O = reinterpret_cast<T*>(a.o) + (long long)b * Nq * a.ldo + h * d;
+  for (int e = threadIdx.x; e < Nq * d; e += ANT) {
+    const int i = e / d, c = e - i * d;
+    float acc = 0.f;
+    for (int j = 0; j < Nk; ++j) acc += S[i * sp + j] * (float)Vs[j * dp + c];
+    O[(long long)i * a.ldo + c] = (T)acc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const int z = blockIdx.x, b = z / a.H, h = z - b * a.H;
+  const int Nq = a.Nq, Nk = a.Nk, d = a.d;
+  const int dp = pitch_d(d, sizeof(T)), sp = pitch_s(Nk);
+  T* Qs = reinterpret_cast<T*>(lds_raw);
+  T* Ks = Qs + Nq * dp;
+  T* Vs = Ks + Nk * dp;
+  T* Gs = Vs + Nk * dp;                                   // dO
+  float* Pf = reinterpret_cast<float*>(lds_raw + (((size_t)(2 * Nq + 2 * Nk) * dp * sizeof(T) + 15) & ~(size_t)15));
+  float* dS = Pf + Nq * sp;
+  const T* q = reinterpret_cast<const T*>(a.q) + (long long)b * Nq * a.ldq + h * d;
+  const T* k = reinterpret_cast<const T*>(a.k) + (long long)b * Nk * a.ldk + h * d;
+  const T* v = reinterpret_cast<const T*>(a.v) + (long long)b * Nk * a.ldv + h * d;
+  const T* g = reinterpret_cast<const T*>(a.d_o) + (long long)b * Nq * a.ldo + h * d;
+  const T* P = reinterpret_cast<const T*>(a.p) + (long long)z * Nq * a.ldp;
+  stage_rows<T>(Qs, dp, q, a.ldq, Nq, d, rows_aligned(q, a.ldq, d, sizeof(T)));
+  stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)));
+  stage_rows<T>(Vs, dp, v, a.ldv, Nk, d, rows_aligned(v, a.ldv, d, sizeof(T)));
+  stage_rows<T>(Gs, dp, g, a.ldo, Nq, d, rows_aligned(g, a.ldo, d, sizeof(T)));
+  for (int e = threadIdx.x; e < Nq * Nk; e += ANT) {
+    const int i = e / Nk, j = e - i * Nk;
+    Pf[i * sp + j] = (float)P[(long long)i * a.ldp + j];
+  }
+  __syncthreads();
+  // dP = dO V^T
+  for (int e = threadIdx.x; e < Nq * Nk; e += ANT) {
+    const int i = e / Nk, j = e - i * Nk;
+    float acc = 0.f;
+    for (int c = 0; c < d; ++c) acc += (float)Gs[i * dp + c] * (float)Vs[j * dp + c];
+    dS[i * sp + j] = acc;
+  }
+  __syncthreads();
+  // dS = P (dP - sum_j dP P), one wave per row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = wave; i < Nq; i += ANT / 64) {
+    float t = 0.f;
+    for (int j = lane; j < Nk; j += 64) t += Pf[i * sp + j] * dS[i * sp + j];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    for (int j = lane; j < Nk; j += 64) dS[i * sp + j] = Pf[i * sp + j] * (dS[i * sp + j] - t);
+  }
+  __syncthreads();
+  // dQ = scale dS K
+  T* dQ = reinterpret_cast<T*>(a.dq) + (long long)b * Nq * a.lddq + h * d;
+  for (int e = threadIdx.x; e < Nq * d; e += ANT) {
+    const int i = e / d, c = e - i * d;
+    float acc = 0.f;
+    for (int j = 0; j < Nk; ++j) acc += dS[i * sp + j] * (float)Ks[j * dp + c];
+    dQ[(long long)i * a.lddq + c] = (T)(acc * a.scale);
+  }
+  // dK = scale dS^T Q, dV = P^T dO
+  T* dK = reinterpret_cast<T*>(a.dk) + (long long)b * Nk * a.lddk + h * d;
+  T* dV = reinterpret_cast<T*>(a.dv) + (long long)b * Nk * a.lddv + h * d;
+  for (int e = threadIdx.x; e < Nk * d; e += ANT) {
+    const int j = e / d, c = e - j * d;
+    float ak = 0.f, av = 0.f;
+    for (int i = 0; i < Nq; ++i) {
+      ak += dS[i * sp + j] * (float)Qs[i * dp + c];
+      av += Pf[i * sp + j] * (float)Gs[i * dp + c];
+    }
+    dK[(long long)j * a.lddk + c] = (T)(ak * a.scale);
+    dV[(long long)j * a.lddv + c] = (T)av;
+  }
+}
+
+size_t fwd_lds(int Nq, int Nk, int d, int esz) {
+  return (((size_t)(Nq + 2 * Nk) * pitch_d(d, esz) * esz + 15) & ~(size_t)15) + (size_t)Nq * pitch_s(Nk) * 4;
+}
+size_t bwd_lds(int Nq, int Nk, int d, int esz) {
+  return (((size_t)(2 * Nq + 2 * Nk) * pitch_d(d, esz) * esz + 15) & ~(size_t)15) + (size_t)2 * Nq * pitch_s(Nk) * 4;
+}
+constexpr size_t LDS_MAX = 160 * 1024;
+
+int check_common(const char* who, int B, int H, int Nq, int Nk, int d, int dtype) {
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "%s: dtype must be JEN1_F32 or JEN1_BF16", who);
+  JEN1_CHECK(B >= 1 && H >= 1 && Nq >= 1 && Nk >= 1 && d >= 1, "%s: B, H, Nq, Nk, d must be >= 1", who);
+  JEN1_CHECK((long long)B * H <= 0x7fffffff, "%s: too many (batch element, head) pairs", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype) {
+  const int esz = dtype == JEN1_F32 ? 4 : 2;
+  return (Nq <= 64 && Nk <= 512 && d <= 128 && bwd_lds(Nq, Nk, d, esz) <= LDS_MAX) ? 1 : 0;
+}
+
+extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                                       int64_t ldo, void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal,
+                                       int dtype, void* stream) {
+  if (check_common("jen1_attn_small_forward", B, H, Nq, Nk, d, dtype)) return 1;
+  JEN1_CHECK(q && k && v && o && p, "jen1_attn_small_forward: NULL argument");
+  JEN1_CHECK(ldp >= Nk, "jen1_attn_small_forward: ldp must be >= Nk");
+  JEN1_CHECK(jen1_attn_small_fits(Nq, Nk, d, dtype), "jen1_attn_small_forward: Nq = %d, Nk = %d, d = %d do not fit one workgroup", Nq, Nk, d);
+  AttnDev a = {};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.p = p;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.causal = causal ? 1 : 0; a.scale = scale;
+  const size_t lds = fwd_lds(Nq, Nk, d, dtype == JEN1_F32 ? 4 : 2);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == JEN1_F32) {
+    JEN1_MAX_LDS_ONCE(attn_small_fwd_kernel<float>, (int)LDS_MAX);
+    hipLaunchKernelGGL(attn_small_fwd_kernel<float>, dim3(B * H), dim3(ANT), lds, s, a);
+  } else {
+    JEN1_MAX_LDS_ONCE(attn_small_fwd_kernel<bf16_t>, (int)LDS_MAX);
+    hipLaunchKernelGGL(attn_small_fwd_kernel<bf16_t>, dim3(B * H), dim3(ANT), lds, s, a);
+  }
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_attn_small_backward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* p,
+                                        int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                                        void* dv, int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, int dtype,
+                                        void* stream) {
+  if (check_common("jen1_attn_small_backward", B, H, Nq, Nk, d, dtype)) return 1;
+  JEN1_CHECK(q && k && v && p && d_o && dq && dk && dv, "jen1_attn_small_backward: NULL argument");
+  JEN1_CHECK(ldp >= Nk, "jen1_attn_small_backward: ldp must be >= Nk");
+  JEN1_CHECK(jen1_attn_small_fits(Nq, Nk, d, dtype), "jen1_attn_small_backward: Nq = %d, Nk = %d, d = %d do not fit one workgroup", Nq, Nk, d);
+  AttnDev a = {};
+  a.q = q; a.k = k; a.v = v; a.p = const_cast<void*>(p); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
+  const size_t lds = bwd_lds(Nq, Nk, d, dtype == JEN1_F32 ? 4 : 2);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == JEN1_F32) {
+    JEN1_MAX_LDS_ONCE(attn_small_bwd_kernel<float>, (int)LDS_MAX);
+    hipLaunchKernelGGL(attn_small_bwd_kernel<float>, dim3(B * H), dim3(ANT), lds, s, a);
+  } else {
+    JEN1_MAX_LDS_ONCE(attn_small_bwd_kernel<bf16_t>, (int)LDS_MAX);
+    hipLaunchKernelGGL(attn_small_bwd_kernel<bf16_t>, dim3(B * H), dim3(ANT), lds, s, a);
+  }
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}

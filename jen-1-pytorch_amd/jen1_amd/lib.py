@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # 
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "deep_kernel.hip", "elementwise.hip",
-           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "encodec.hip"]
+           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip"]
 
 F32, BF16, FP8 = 0, 1, 2
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -127,6 +127,9 @@ SYMBOLS = {
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
     "jen1_train_gemm": (c_int, [C.POINTER(GemmArgs), _P]),
     "jen1_train_gemm_pair": (c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _P]),
+    "jen1_attn_small_fits": (c_int, [c_int, c_int, c_int, c_int]),
+    "jen1_attn_small_forward": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64] + [c_int] * 5 + [c_float, c_int, c_int, _P]),
+    "jen1_attn_small_backward": (c_int, [_P, c_int64] * 8 + [c_int] * 5 + [c_float, c_int, _P]),
     "jen1_gn_sums": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "jen1_gn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_gn_backward": (c_int, [_P] * 6 + [c_int] + [_P] * 6 + [c_int] * 5 + [c_float, c_int, c_int, _P]),

@@ -91,6 +91,8 @@ class TrainRuntime:
         self.film_bank = os.environ.get("JEN1_TRAIN_FILM_BANK", "1") == "1"
         # a layer's weight gradient and data gradient in one launch (jen1_train_gemm_pair)
         self.pair_grads = os.environ.get("JEN1_TRAIN_PAIR_GRADS", "1") == "1"
+        # short sequences: the whole attention core in one launch each way (jen1_attn_small_forward / _backward)
+        self.small_attn = os.environ.get("JEN1_TRAIN_SMALL_ATTN", "1") == "1"
         self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
 
     # ------------------------------------------------------------------ plumbing
@@ -829,9 +831,16 @@ class AttentionCoreFn(Function):
         kp, ldk = _rows_view(k)
         vp, ldv = _rows_view(v)
         scale = d ** -0.5
-        S = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
         P = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
         O = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+        ctx.rt, ctx.heads, ctx.scale = rt, heads, scale
+        ctx.small = bool(rt.small_attn and rt.lib.jen1_attn_small_fits(Nq, Nk, d, dt))
+        if ctx.small:
+            L.check(rt.lib.jen1_attn_small_forward(qp, ldq, kp, ldk, vp, ldv, O.data_ptr(), C, P.data_ptr(), ldS, B, heads, Nq, Nk, d,
+                                                   float(scale), 1 if causal else 0, dt, rt.stream()), "jen1_attn_small_forward")
+            ctx.save_for_backward(q, kv, P)
+            return O
+        S = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
         rt.gemm(_operand(qp, ldq, 1, zs0=Nq * ldq, zs1=d, zdiv=heads), _operand(kp, ldk, 1, zs0=Nk * ldk, zs1=d, zdiv=heads),
                 S.data_ptr(), Nq, Nk, d, dtype=dt, batches=Z, ldc_m=ldS, c_zs0=Nq * ldS, c_f32=True, alpha=scale)
         L.check(rt.lib.jen1_softmax_forward(S.data_ptr(), P.data_ptr(), Z * Nq, Nq, Nk, ldS, ldS, 1 if causal else 0, dt, rt.stream()),
@@ -858,11 +867,16 @@ class AttentionCoreFn(Function):
         qp, ldq = _rows_view(q)
         kp, ldk = _rows_view(k)
         vp, ldv = _rows_view(v)
-        dP = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
-        dS = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
         dQ = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
         dKV = torch.empty((B, Nk, 2 * C), dtype=q.dtype, device=q.device)
         esz = dKV.element_size()
+        if ctx.small:
+            L.check(rt.lib.jen1_attn_small_backward(qp, ldq, kp, ldk, vp, ldv, P.data_ptr(), ldS, dO.data_ptr(), C, dQ.data_ptr(), C,
+                                                    dKV.data_ptr(), 2 * C, dKV.data_ptr() + C * esz, 2 * C, B, heads, Nq, Nk, d,
+                                                    float(scale), dt, rt.stream()), "jen1_attn_small_backward")
+            return dQ, dKV, None, None, None
+        dP = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
+        dS = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
         o_do = lambda ld_r, ld_k: _operand(dO.data_ptr(), ld_r, ld_k, zs0=Nq * C, zs1=d, zdiv=heads)
         # dP = dO V^T
         rt.gemm(o_do(C, 1), _operand(vp, ldv, 1, zs0=Nk * ldv, zs1=d, zdiv=heads), dP.data_ptr(), Nq, Nk, d, dtype=dt, batches=Z,

@@ -229,11 +229,15 @@ def test_activation_forward_backward(rts, mode, fn):
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("B,Nq,Nk,C,heads,causal,strided", [
     (2, 24, 24, 64, 8, False, True), (2, 24, 24, 64, 8, True, True), (3, 6, 129, 128, 8, False, False),
-    (2, 1, 129, 512, 8, False, True), (2, 150, 150, 64, 8, True, True), (2, 75, 129, 128, 8, False, False)])
-def test_attention_core_forward_backward(rts, mode, B, Nq, Nk, C, heads, causal, strided):
-    """AttentionBase.forward math path (blocks.py:355-380) incl. the causal mask of blocks.py:315-319"""
+    (2, 1, 129, 512, 8, False, True), (2, 150, 150, 64, 8, True, True), (2, 75, 129, 128, 8, False, False),
+    (2, 12, 130, 1024, 16, False, True), (1, 64, 64, 40, 8, True, False)])
+@pytest.mark.parametrize("small_attn", [True, False], ids=["one-launch", "gemm-path"])
+def test_attention_core_forward_backward(rts, mode, B, Nq, Nk, C, heads, causal, strided, small_attn, monkeypatch):
+    """AttentionBase.forward math path (blocks.py:355-380) incl. the causal mask of blocks.py:315-319; short sequences both through
+    the one-launch kernels (jen1_attn_small_forward / _backward) and through the GEMM + softmax launches"""
     from jen1_amd import train as TR
     rt = rts[mode]
+    monkeypatch.setattr(rt, "small_attn", small_attn)
     gen = torch.Generator().manual_seed(Nq * Nk)
     q = torch.randn((B, Nq, C), generator=gen).requires_grad_()
     kv = torch.randn((B, Nk, 2 * C), generator=gen).requires_grad_()
