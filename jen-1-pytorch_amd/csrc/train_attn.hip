@@ -2,7 +2,7 @@
 // reference blocks.py:355-380) for SHORT sequences -- the transformer blocks of JEN-1 sit at the deep levels of the UNet, where a
 // 1500-frame clip is 1 .. 24 positions and the text context 130 tokens.  As three + five launches of jen1_train_gemm / softmax per
 // attention (208 launches per pass) these products are pure launch latency: a (batch element, head) is 24 x 130 x 64 multiply-adds.
-// Here one workgroup owns one (batch element, head): Q, K, V (and dO) go into LDS once, the scores, the softmax, P V -- and in the
+// Here one workgroup owns one (batch element, head): Q, K, V (and dO) go into LDS once (as float32), the scores, the softmax, P V -- and in the
 // backward pass dP, dS, dQ, dK, dV -- are computed from there in float32 on the vector units.  Results follow the GEMM path's
 // roundings where they are visible to the rest of the pass: P is rounded to the activations' dtype before P V and is what the
 // backward pass reads; dS stays float32 (the GEMM path rounds it once more).
@@ -21,10 +21,10 @@ struct AttnDev {
   float scale;
 };
 
-// rows [n][d] of one head from a [B][n][ld] tensor -> LDS rows of pitch dp (elements of T); 16-byte vectors when the head's rows
+// rows [n][d] of one head from a [B][n][ld] tensor -> float32 LDS rows of pitch dp; 16-byte global vectors when the head's rows
 // start on 16-byte boundaries
 template <typename T>
-__device__ __forceinline__ void stage_rows(T* dst, int dp, const T* src, long long ld, int n, int d, bool vec_ok) {
+__device__ __forceinline__ void stage_rows(float* dst, int dp, const T* src, long long ld, int n, int d, bool vec_ok) {
   constexpr int V = 16 / (int)sizeof(T);
   if (vec_ok) {
     const int vpr = d / V;
@@ -34,12 +34,13 @@ __device__ __forceinline__ void stage_rows(T* dst, int dp, const T* src, long lo
       T tmp[V];
       *reinterpret_cast<uint4*>(tmp) = w;
 #pragma unroll
-      for (int j = 0; j < V; ++j) dst[r * dp + c + j] = tmp[j];
+      for (int j = 0; j < V; j += 4)
+        *reinterpret_cast<float4*>(dst + r * dp + c + j) = make_float4((float)tmp[j], (float)tmp[j + 1], (float)tmp[j + 2], (float)tmp[j + 3]);
     }
   } else {
     for (int e = threadIdx.x; e < n * d; e += ANT) {
       const int r = e / d, c = e - r * d;
-      dst[r * dp + c] = src[(long long)r * ld + c];
+      dst[r * dp + c] = (float)src[(long long)r * ld + c];
     }
   }
 }
@@ -49,20 +50,30 @@ __device__ __forceinline__ bool rows_aligned(const void* p, long long ld, int d,
   return (d % V) == 0 && (ld % V) == 0 && ((unsigned long long)p & 15) == 0;
 }
 
-// LDS layout (both kernels): Q [Nq][dp] | K [Nk][dp] | V [Nk][dp] | (dO [Nq][dp]) in T, then S [Nq][sp] (and dS [Nq][sp]) in float
-__host__ __device__ inline int pitch_d(int d, int esz) { return esz == 2 ? (d | 1) + 1 : d | 1; }   // odd number of 4-byte words per row
+__device__ __forceinline__ float dot4(const float4& x, const float4& y) { return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& y) {
+  acc.x += s * y.x; acc.y += s * y.y; acc.z += s * y.z; acc.w += s * y.w;
+}
+template <typename T>
+__device__ __forceinline__ void store4t(T* p, const float4& v, float s) {
+  p[0] = (T)(v.x * s); p[1] = (T)(v.y * s); p[2] = (T)(v.z * s); p[3] = (T)(v.w * s);
+}
+
+// LDS layout (both kernels, float32): Q [Nq][dp] | K [Nk][dp] | V [Nk][dp] | (dO [Nq][dp]) | S [Nq][sp] | (dS [Nq][sp]).  d is a multiple
+// of 4: every inner loop reads 16-byte vectors along d (rows dp = d + 4 floats apart: 16-byte aligned, 4 banks further per row)
+__host__ __device__ inline int pitch_d(int d) { return d + 4; }
 __host__ __device__ inline int pitch_s(int Nk) { return Nk | 1; }
 
 template <typename T>
 __global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const int z = blockIdx.x, b = z / a.H, h = z - b * a.H;
-  const int Nq = a.Nq, Nk = a.Nk, d = a.d;
-  const int dp = pitch_d(d, sizeof(T)), sp = pitch_s(Nk);
-  T* Qs = reinterpret_cast<T*>(lds_raw);
-  T* Ks = Qs + Nq * dp;
-  T* Vs = Ks + Nk * dp;
-  float* S = reinterpret_cast<float*>(lds_raw + (((size_t)(Nq + 2 * Nk) * dp * sizeof(T) + 15) & ~(size_t)15));
+  const int Nq = a.Nq, Nk = a.Nk, d = a.d, d4 = d >> 2;
+  const int dp = pitch_d(d), sp = pitch_s(Nk);
+  float* Qs = reinterpret_cast<float*>(lds_raw);
+  float* Ks = Qs + Nq * dp;
+  float* Vs = Ks + Nk * dp;
+  float* S = Vs + Nk * dp;
   const T* q = reinterpret_cast<const T*>(a.q) + (long long)b * Nq * a.ldq + h * d;
   const T* k = reinterpret_cast<const T*>(a.k) + (long long)b * Nk * a.ldk + h * d;
   const T* v = reinterpret_cast<const T*>(a.v) + (long long)b * Nk * a.ldv + h * d;
@@ -70,11 +81,13 @@ __global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
   stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)));
   stage_rows<T>(Vs, dp, v, a.ldv, Nk, d, rows_aligned(v, a.ldv, d, sizeof(T)));
   __syncthreads();
-  // scores: consecutive threads take consecutive keys of one query (K rows an odd number of words apart: no bank conflicts)
+  // scores: consecutive threads take consecutive keys of one query
   for (int e = threadIdx.x; e < Nq * Nk; e += ANT) {
     const int i = e / Nk, j = e - i * Nk;
+    const float4* qr = reinterpret_cast<const float4*>(Qs + i * dp);
+    const float4* kr = reinterpret_cast<const float4*>(Ks + j * dp);
     float acc = 0.f;
-    for (int c = 0; c < d; ++c) acc += (float)Qs[i * dp + c] * (float)Ks[j * dp + c];
+    for (int c = 0; c < d4; ++c) acc += dot4(qr[c], kr[c]);
     S[i * sp + j] = acc * a.scale;
   }
   __syncthreads();
@@ -97,13 +110,13 @@ __global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
     }
   }
   __syncthreads();
-  // O = P V: consecutive threads take consecutive channels of one query
+  // O = P V: consecutive threads take consecutive groups of 4 channels of one query
   T* O = reinterpret_cast<T*>(a.o) + (long long)b * Nq * a.ldo + h * d;
-  for (int e = threadIdx.x; e < Nq * d; e += ANT) {
-    const int i = e / d, c = e - i * d;
-    float acc = 0.f;
-    for (int j = 0; j < Nk; ++j) acc += S[i * sp + j] * (float)Vs[j * dp + c];
-    O[(long long)i * a.ldo + c] = (T)acc;
+  for (int e = threadIdx.x; e < Nq * d4; e += ANT) {
+    const int i = e / d4, c = (e - i * d4) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Nk; ++j) fma4(acc, S[i * sp + j], *reinterpret_cast<const float4*>(Vs + j * dp + c));
+    store4t<T>(O + (long long)i * a.ldo + c, acc, 1.0f);
   }
 }
 
@@ -111,13 +124,13 @@ template <typename T>
 __global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const int z = blockIdx.x, b = z / a.H, h = z - b * a.H;
-  const int Nq = a.Nq, Nk = a.Nk, d = a.d;
-  const int dp = pitch_d(d, sizeof(T)), sp = pitch_s(Nk);
-  T* Qs = reinterpret_cast<T*>(lds_raw);
-  T* Ks = Qs + Nq * dp;
-  T* Vs = Ks + Nk * dp;
-  T* Gs = Vs + Nk * dp;                                   // dO
-  float* Pf = reinterpret_cast<float*>(lds_raw + (((size_t)(2 * Nq + 2 * Nk) * dp * sizeof(T) + 15) & ~(size_t)15));
+  const int Nq = a.Nq, Nk = a.Nk, d = a.d, d4 = d >> 2;
+  const int dp = pitch_d(d), sp = pitch_s(Nk);
+  float* Qs = reinterpret_cast<float*>(lds_raw);
+  float* Ks = Qs + Nq * dp;
+  float* Vs = Ks + Nk * dp;
+  float* Gs = Vs + Nk * dp;                               // dO
+  float* Pf = Gs + Nq * dp;
   float* dS = Pf + Nq * sp;
   const T* q = reinterpret_cast<const T*>(a.q) + (long long)b * Nq * a.ldq + h * d;
   const T* k = reinterpret_cast<const T*>(a.k) + (long long)b * Nk * a.ldk + h * d;
@@ -136,8 +149,10 @@ __global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
   // dP = dO V^T
   for (int e = threadIdx.x; e < Nq * Nk; e += ANT) {
     const int i = e / Nk, j = e - i * Nk;
+    const float4* gr = reinterpret_cast<const float4*>(Gs + i * dp);
+    const float4* vr = reinterpret_cast<const float4*>(Vs + j * dp);
     float acc = 0.f;
-    for (int c = 0; c < d; ++c) acc += (float)Gs[i * dp + c] * (float)Vs[j * dp + c];
+    for (int c = 0; c < d4; ++c) acc += dot4(gr[c], vr[c]);
     dS[i * sp + j] = acc;
   }
   __syncthreads();
@@ -150,35 +165,30 @@ __global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
     for (int j = lane; j < Nk; j += 64) dS[i * sp + j] = Pf[i * sp + j] * (dS[i * sp + j] - t);
   }
   __syncthreads();
-  // dQ = scale dS K
-  T* dQ = reinterpret_cast<T*>(a.dq) + (long long)b * Nq * a.lddq + h * d;
-  for (int e = threadIdx.x; e < Nq * d; e += ANT) {
-    const int i = e / d, c = e - i * d;
-    float acc = 0.f;
-    for (int j = 0; j < Nk; ++j) acc += dS[i * sp + j] * (float)Ks[j * dp + c];
-    dQ[(long long)i * a.lddq + c] = (T)(acc * a.scale);
-  }
-  // dK = scale dS^T Q, dV = P^T dO
+  // dK = scale dS^T Q, dV = P^T dO (the long loop first: Nk d / 4 items), then dQ = scale dS K
   T* dK = reinterpret_cast<T*>(a.dk) + (long long)b * Nk * a.lddk + h * d;
   T* dV = reinterpret_cast<T*>(a.dv) + (long long)b * Nk * a.lddv + h * d;
-  for (int e = threadIdx.x; e < Nk * d; e += ANT) {
-    const int j = e / d, c = e - j * d;
-    float ak = 0.f, av = 0.f;
+  for (int e = threadIdx.x; e < Nk * d4; e += ANT) {
+    const int j = e / d4, c = (e - j * d4) * 4;
+    float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), av = ak;
     for (int i = 0; i < Nq; ++i) {
-      ak += dS[i * sp + j] * (float)Qs[i * dp + c];
-      av += Pf[i * sp + j] * (float)Gs[i * dp + c];
+      fma4(ak, dS[i * sp + j], *reinterpret_cast<const float4*>(Qs + i * dp + c));
+      fma4(av, Pf[i * sp + j], *reinterpret_cast<const float4*>(Gs + i * dp + c));
     }
-    dK[(long long)j * a.lddk + c] = (T)(ak * a.scale);
-    dV[(long long)j * a.lddv + c] = (T)av;
+    store4t<T>(dK + (long long)j * a.lddk + c, ak, a.scale);
+    store4t<T>(dV + (long long)j * a.lddv + c, av, 1.0f);
+  }
+  T* dQ = reinterpret_cast<T*>(a.dq) + (long long)b * Nq * a.lddq + h * d;
+  for (int e = threadIdx.x; e < Nq * d4; e += ANT) {
+    const int i = e / d4, c = (e - i * d4) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Nk; ++j) fma4(acc, dS[i * sp + j], *reinterpret_cast<const float4*>(Ks + j * dp + c));
+    store4t<T>(dQ + (long long)i * a.lddq + c, acc, a.scale);
   }
 }
 
-size_t fwd_lds(int Nq, int Nk, int d, int esz) {
-  return (((size_t)(Nq + 2 * Nk) * pitch_d(d, esz) * esz + 15) & ~(size_t)15) + (size_t)Nq * pitch_s(Nk) * 4;
-}
-size_t bwd_lds(int Nq, int Nk, int d, int esz) {
-  return (((size_t)(2 * Nq + 2 * Nk) * pitch_d(d, esz) * esz + 15) & ~(size_t)15) + (size_t)2 * Nq * pitch_s(Nk) * 4;
-}
+size_t fwd_lds(int Nq, int Nk, int d) { return ((size_t)(Nq + 2 * Nk) * pitch_d(d) + (size_t)Nq * pitch_s(Nk)) * 4; }
+size_t bwd_lds(int Nq, int Nk, int d) { return ((size_t)(2 * Nq + 2 * Nk) * pitch_d(d) + (size_t)2 * Nq * pitch_s(Nk)) * 4; }
 constexpr size_t LDS_MAX = 160 * 1024;
 
 int check_common(const char* who, int B, int H, int Nq, int Nk, int d, int dtype) {
@@ -191,8 +201,8 @@ int check_common(const char* who, int B, int H, int Nq, int Nk, int d, int dtype
 }  // namespace
 
 extern "C" int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype) {
-  const int esz = dtype == JEN1_F32 ? 4 : 2;
-  return (Nq <= 64 && Nk <= 512 && d <= 128 && bwd_lds(Nq, Nk, d, esz) <= LDS_MAX) ? 1 : 0;
+  (void)dtype;
+  return (Nq <= 64 && Nk <= 512 && d <= 128 && d % 4 == 0 && bwd_lds(Nq, Nk, d) <= LDS_MAX) ? 1 : 0;
 }
 
 extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
@@ -206,7 +216,7 @@ extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k
   a.q = q; a.k = k; a.v = v; a.o = o; a.p = p;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.causal = causal ? 1 : 0; a.scale = scale;
-  const size_t lds = fwd_lds(Nq, Nk, d, dtype == JEN1_F32 ? 4 : 2);
+  const size_t lds = fwd_lds(Nq, Nk, d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == JEN1_F32) {
     JEN1_MAX_LDS_ONCE(attn_small_fwd_kernel<float>, (int)LDS_MAX);
@@ -231,7 +241,7 @@ extern "C" int jen1_attn_small_backward(const void* q, int64_t ldq, const void* 
   a.q = q; a.k = k; a.v = v; a.p = const_cast<void*>(p); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
-  const size_t lds = bwd_lds(Nq, Nk, d, dtype == JEN1_F32 ? 4 : 2);
+  const size_t lds = bwd_lds(Nq, Nk, d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == JEN1_F32) {
     JEN1_MAX_LDS_ONCE(attn_small_bwd_kernel<float>, (int)LDS_MAX);
