@@ -96,11 +96,22 @@ int jen1_gn_backward(const void* dy, const void* x, const float* sums, const flo
                      int film_ld, void* dx, float* dgamma, float* dbeta, void* dfilm, float* P, float* Gm, int B, int L, int C,
                      int ld, int groups, float eps, int flags, int dtype, void* stream);
 
+/* the same with dx_add (x's dtype and layout, may be NULL): dx = the GroupNorm gradient + dx_add.  A tensor that feeds a norm AND a
+ * residual branch (ResnetBlock1d's input, blocks.py:219-231) gets two gradients; adding the second one here replaces autograd's
+ * accumulation launch. */
+int jen1_gn_backward_add(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,
+                         int film_ld, void* dx, const void* dx_add, float* dgamma, float* dbeta, void* dfilm, float* P, float* Gm, int B,
+                         int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
+
 /* --- LayerNorm over the last axis (blocks.py:400-401): stats[rows][2] = (mean, rstd) --- */
 int jen1_ln_forward(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, int ld,
                     float eps, int dtype, void* stream);
 int jen1_ln_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* dgamma,
                      float* dbeta, int rows, int C, int ld, int dtype, void* stream);
+/* the same with dx_add (x's dtype, rows ld apart, may be NULL): dx = the LayerNorm gradient + dx_add (the residual branch of a
+ * transformer sub-block, blocks.py:486-488) */
+int jen1_ln_backward_add(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, const void* dx_add,
+                         float* dgamma, float* dbeta, int rows, int C, int ld, int dtype, void* stream);
 
 /* --- pointwise activations: mode 0 GELU(erf) (blocks.py:443, model.py:77-89), 1 SiLU (blocks.py:158),
  *     2 ELU(alpha = 1) (the SEANet decoder behind generation.py:130) --- */

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(NT) void gn_sums_kernel(const void* x_, float* __re
 struct GnDev {
   const void* x; const void* dy; const float* sums; const float* gamma; const float* beta; const void* film;
   void* y; float* P; float* Gm; float* dgamma; float* dbeta; float* dfilm;
+  const void* dx_add;      // backward: added to dx (the gradient that reached the same tensor along another branch), or NULL
   int B, L, C, ld, groups, cpg, film_ld, flags, film_bf16;
   float eps, inv_count;
 };
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_kernel(const GnDev g, void* dx_)
     if (g.flags & 1) df *= silu_grad((xh * ga + g.beta[c]) * sc1 + sh);
     const float dxh = df * sc1 * ga;
     const float* gm = g.Gm + ((long long)b * g.groups + c / g.cpg) * 2;
-    dx[row * g.ld + c] = (T)(rstd * (dxh - gm[0] - xh * gm[1]));
+    float o = rstd * (dxh - gm[0] - xh * gm[1]);
+    if (g.dx_add != nullptr) o += (float)reinterpret_cast<const T*>(g.dx_add)[row * g.ld + c];
+    dx[row * g.ld + c] = (T)o;
   }
 }
 
@@ -322,6 +325,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_vec_kernel(const GnDev g, void* 
       float df = d[j];
       if (g.flags & 1) df *= silu_grad((xh * ga[j] + be[j]) * s1 + s0);
       v[j] = rstd * (df * s1 * ga[j] - m1 - xh * m2);
+    }
+    if (g.dx_add != nullptr) {
+      float ad[8];
+      load8(reinterpret_cast<const T*>(g.dx_add) + row * g.C + c0, ad);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += ad[j];
     }
     store8(dx + row * g.C + c0, v);
   }
@@ -469,6 +478,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const GnDev g, void* d
       if (g.flags & 1) df *= silu_grad((xh * ga[j] + be[j]) * s1[j] + s0[j]);
       w[j] = rstd * (df * s1[j] * ga[j] - m1 - xh * m2);
     }
+    if (g.dx_add != nullptr) {
+      float ad[8];
+      load8(reinterpret_cast<const T*>(g.dx_add) + base + (long long)t * g.C, ad);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] += ad[j];
+    }
     store8(dx + (long long)t * g.C, w);
   }
 }
@@ -601,8 +616,8 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const void* x_, const fl
 // each wave walks rows row0, row0 + stride, ... and keeps the column sums of its lanes in registers
 template <typename T, int NTB>
 __global__ __launch_bounds__(NTB) void ln_bwd_kernel(const void* dy_, const void* x_, const float* __restrict__ stats,
-                                                      const float* __restrict__ gamma, void* dx_, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta, int rows, int C, int ld) {
+                                                      const float* __restrict__ gamma, void* dx_, const void* add_,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int ld) {
   constexpr int NT = NTB;                    // (shadows the file's 256: a block of NTB / 64 waves)
   const T* dy = reinterpret_cast<const T*>(dy_);
   const T* x = reinterpret_cast<const T*>(x_);
@@ -633,7 +648,11 @@ __global__ __launch_bounds__(NTB) void ln_bwd_kernel(const void* dy_, const void
     s1 /= C; s2 /= C;
     T* xo = dx + (long long)row * ld;
     n = 0;
-    for (int c = lane; c < C; c += 64, ++n) xo[c] = (T)(rstd * (dh[n] - s1 - xh[n] * s2));
+    for (int c = lane; c < C; c += 64, ++n) {
+      float o = rstd * (dh[n] - s1 - xh[n] * s2);
+      if (add_ != nullptr) o += (float)reinterpret_cast<const T*>(add_)[(long long)row * ld + c];
+      xo[c] = (T)o;
+    }
   }
   // the four waves of the block meet in LDS, then ONE atomic per column and block (512 waves adding 2 C columns each was the
   // kernel's time: 26 us at 2 064 rows x 1 024 columns)
@@ -660,8 +679,8 @@ __global__ __launch_bounds__(NTB) void ln_bwd_kernel(const void* dy_, const void
 constexpr int LN_MAXV = 4;        // 8-channel vectors per lane: C <= 2048
 template <typename T, int NTB>
 __global__ __launch_bounds__(NTB) void ln_bwd_vec_kernel(const void* dy_, const void* x_, const float* __restrict__ stats,
-                                                          const float* __restrict__ gamma, void* dx_, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int rows, int C, int ld) {
+                                                          const float* __restrict__ gamma, void* dx_, const void* add_,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int ld) {
   extern __shared__ float ln_col[];            // [NTB / 64 - 1][2][C]
   const T* dy = reinterpret_cast<const T*>(dy_);
   const T* x = reinterpret_cast<const T*>(x_);
@@ -712,6 +731,12 @@ __global__ __launch_bounds__(NTB) void ln_bwd_vec_kernel(const void* dy_, const 
         float o8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o8[e] = rstd * (dh[j][e] - s1 - xh[j][e] * s2);
+        if (add_ != nullptr) {
+          float ad[8];
+          load8(reinterpret_cast<const T*>(add_) + (long long)row * ld + v * 8, ad);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] += ad[e];
+        }
         store8(xo + v * 8, o8);
       }
     }
@@ -945,12 +970,22 @@ extern "C" int jen1_gn_apply(const void* x, const float* sums, const float* gamm
 extern "C" int jen1_gn_backward(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta,
                                 const void* film, int film_ld, void* dx, float* dgamma, float* dbeta, void* dfilm, float* P,
                                 float* Gm, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream) {
+  return jen1_gn_backward_add(dy, x, sums, gamma, beta, film, film_ld, dx, nullptr, dgamma, dbeta, dfilm, P, Gm, B, L, C, ld, groups, eps,
+                              flags, dtype, stream);
+}
+
+extern "C" int jen1_gn_backward_add(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta,
+                                    const void* film, int film_ld, void* dx, const void* dx_add, float* dgamma, float* dbeta,
+                                    void* dfilm, float* P, float* Gm, int B, int L, int C, int ld, int groups, float eps, int flags,
+                                    int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_gn_backward")) return 1;
+  JEN1_CHECK(((uintptr_t)dx_add & 15) == 0, "jen1_gn_backward_add: dx_add must start on a 16-byte boundary");
   GnDev g;
   if (gn_fill(g, "jen1_gn_backward", x, sums, gamma, beta, film, film_ld, B, L, C, ld, groups, eps, flags)) return 1;
   JEN1_CHECK(dy && dx && dgamma && dbeta && P && Gm, "jen1_gn_backward: NULL argument");
   JEN1_CHECK((film == nullptr) == (dfilm == nullptr), "jen1_gn_backward: dfilm must be given exactly when film is");
   g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = reinterpret_cast<float*>(dfilm);
+  g.dx_add = dx_add;
   g.film_bf16 = dtype == JEN1_BF16 ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int lvpg = 0;
@@ -992,6 +1027,11 @@ extern "C" int jen1_ln_forward(const void* x, const float* gamma, const float* b
 
 extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* dgamma,
                                 float* dbeta, int rows, int C, int ld, int dtype, void* stream) {
+  return jen1_ln_backward_add(dy, x, stats, gamma, dx, nullptr, dgamma, dbeta, rows, C, ld, dtype, stream);
+}
+
+extern "C" int jen1_ln_backward_add(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, const void* dx_add,
+                                    float* dgamma, float* dbeta, int rows, int C, int ld, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_ln_backward")) return 1;
   JEN1_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta, "jen1_ln_backward: NULL argument");
   JEN1_CHECK(rows >= 1 && C >= 1 && ld >= C && C <= 64 * LN_MAXPL, "jen1_ln_backward: bad shape rows=%d C=%d ld=%d", rows, C, ld);
@@ -999,7 +1039,7 @@ extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stat
   // many rows (the text context: 2B x 129): 8 waves per block meet in LDS, so 32 blocks x 2 C atomics finish the column sums
   // (the atomics of hundreds of waves on 2 C addresses were the kernel's time: 26 us at 2 064 x 1 024); 16 waves per block would
   // leave 128 registers per lane and push the per-lane column sums into scratch
-  if ((C & 7) == 0 && (ld & 7) == 0 && C <= 512 * LN_MAXV && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0 &&
+  if ((C & 7) == 0 && (ld & 7) == 0 && C <= 512 * LN_MAXV && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)gamma) & 15) == 0 &&
       (size_t)7 * 2 * C * sizeof(float) <= 64 * 1024) {
     // 8 waves per block when there are rows for them, else 4; at most 32 blocks: each wave keeps its column sums over many rows
     const bool big8 = rows >= 256;
@@ -1008,11 +1048,11 @@ extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stat
     if (blocks > 32) blocks = 32;
     const size_t lds = (size_t)(wpb - 1) * 2 * C * sizeof(float);
     if (big8) {
-      if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_vec_kernel<float, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
-      else hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+      if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_vec_kernel<float, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
+      else hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
     } else {
-      if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_vec_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
-      else hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+      if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_vec_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
+      else hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
     }
     JEN1_HIP(hipGetLastError());
     return 0;
@@ -1022,16 +1062,16 @@ extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stat
     int blocks = (rows + 31) / 32;
     if (blocks > 32) blocks = 32;
     const size_t lds = (size_t)7 * 2 * C * sizeof(float);
-    if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
-    else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+    if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
+    else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 512>), dim3(blocks), dim3(512), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
     JEN1_HIP(hipGetLastError());
     return 0;
   }
   int blocks = (rows + 3) / 4;
   if (blocks > 64) blocks = 64;             // each wave keeps column sums over many rows: few atomics
   const size_t lds = (size_t)3 * 2 * C * sizeof(float);
-  if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
-  else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dgamma, dbeta, rows, C, ld);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
+  else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -93,6 +93,8 @@ class TrainRuntime:
         self.pair_grads = os.environ.get("JEN1_TRAIN_PAIR_GRADS", "1") == "1"
         # short sequences: the whole attention core in one launch each way (jen1_attn_small_forward / _backward)
         self.small_attn = os.environ.get("JEN1_TRAIN_SMALL_ATTN", "1") == "1"
+        # a tensor that feeds a norm / linear AND a branch around it: forked, its gradients merge inside the layer's backward kernel
+        self.fork_norms = os.environ.get("JEN1_TRAIN_FORK", "1") == "1"
         self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
 
     # ------------------------------------------------------------------ plumbing
@@ -405,10 +407,12 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     return y
 
 
-def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeom, wd: Optional[torch.Tensor] = None, pair_with=None) -> torch.Tensor:
+def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeom, wd: Optional[torch.Tensor] = None, pair_with=None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``wd``: the data-gradient copy [k][Ci][pad8(Co)] of the weight (both GEMM operands K-contiguous: the register-direct
     path of jen1_train_gemm); without it the forward copy ``wp`` is read transposed through LDS.  ``pair_with``: the deferred
-    weight-gradient product of the same layer, launched together with this one"""
+    weight-gradient product of the same layer, launched together with this one.  ``residual`` (dx's shape): added in the epilogue
+    (the gradient that reached the layer's input along a branch around it: ConvFn's ``fork``)"""
     dt = rt.dt_of(dy)
     ldy = dy.shape[-1]
     k, co, cip = wp.shape
@@ -431,9 +435,13 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_in * cip)
         rt.gemm(a, b, acc.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True, pair_with=pair_with)
-        return rt.hand_over(acc, torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device))
+        return rt.hand_over(acc, torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device), residual)
+    if residual is not None and cip_n != cip:
+        dx = residual.clone()                  # (padding columns: keep the residual's)
+        rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with, accumulate=True)
+        return dx
     dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
-    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with)
+    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with, residual=residual)
     return dx
 
 
@@ -475,19 +483,24 @@ class ConvFn(Function):
     """y = conv(x, weight) + bias; backward writes the parameter gradients into ``.grad`` itself"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, rt: TrainRuntime, g: ConvGeom, residual=None):
+    def forward(ctx, x, weight, bias, rt: TrainRuntime, g: ConvGeom, residual=None, fork: bool = False):
+        """``fork``: also return ``x`` (an alias) for a branch around the layer (the feed-forward's residual, blocks.py:488); its
+        gradient comes back as ``backward``'s second argument and is added in the epilogue of the data-gradient GEMM"""
         wp = rt.packed(weight, g.kind, x.dtype)
         ctx.rt, ctx.g, ctx.weight, ctx.bias, ctx.wp = rt, g, weight, bias, wp
         ctx.wd = rt.packed(weight, g.kind + "D", x.dtype) if (ctx.needs_input_grad[0] and rt.dgrad_copies) else None
         ctx.has_res = residual is not None
         ctx.save_for_backward(x)
-        return _conv_forward(rt, x, wp, None if bias is None else bias.detach(), g, None if residual is None else residual.detach().contiguous())
+        y = _conv_forward(rt, x, wp, None if bias is None else bias.detach(), g, None if residual is None else residual.detach().contiguous())
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         (x,) = ctx.saved_tensors
         rt, g = ctx.rt, ctx.g
         dy = dy.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous().view(-1, g.L_in, x.shape[-1])
         gb = None if ctx.bias is None else rt.grad_of(ctx.bias)
         gw = rt.grad_of(ctx.weight)
         has_bias = ctx.bias is not None
@@ -499,17 +512,17 @@ class ConvFn(Function):
         if ctx.needs_input_grad[0] and rt.pair_grads:
             # both gradients of the layer in one launch: they share dY and nothing orders them
             fused, blk = _conv_wgrad(rt, x, dy, gw, g, gb, defer=True)
-            dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd, pair_with=blk).view(x.shape)
+            dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd, pair_with=blk, residual=dskip).view(x.shape)
             if not fused and has_bias:
                 rt.weight_grad(colsum, dy)
-            return dx, None, None, None, None, (dy if ctx.has_res else None)
+            return dx, None, None, None, None, (dy if ctx.has_res else None), None
 
         def wgrad():
             if not _conv_wgrad(rt, x, dy, gw, g, gb) and has_bias:
                 colsum()
         rt.weight_grad(wgrad, x, dy)
-        dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd).view(x.shape) if ctx.needs_input_grad[0] else None
-        return dx, None, None, None, None, (dy if ctx.has_res else None)       # (the residual's gradient IS dy: no launch)
+        dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd, residual=dskip).view(x.shape) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, (dy if ctx.has_res else None), None       # (the residual's gradient IS dy: no launch)
 
 
 def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal: bool, residual=None) -> torch.Tensor:
@@ -559,11 +572,18 @@ class PlainLinearFn(Function):
         return dx, None, None
 
 
-def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None, residual=None) -> torch.Tensor:
-    """nn.Linear on the last axis; x [..., pad8(in)] -> [..., pad8(out)] (+ ``residual`` of the output's shape, in the epilogue)"""
+def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None, residual=None, fork: bool = False):
+    """nn.Linear on the last axis; x [..., pad8(in)] -> [..., pad8(out)] (+ ``residual`` of the output's shape, in the epilogue).
+    ``fork``: -> (y, x) with x's two gradients merged in the data-gradient GEMM (ConvFn.forward)"""
     co, ci = weight.shape
     lead = x.shape[:-1]
     rows = x.numel() // x.shape[-1]
+    if fork:
+        if not (x.is_contiguous() and x.requires_grad):
+            return linear(rt, x, weight, bias, residual), x
+        y, xa = ConvFn.apply(x.view(1, rows, x.shape[-1]), weight, bias, rt, ConvGeom("linear", 1, 1, 0, rows, rows, ci, co),
+                             None if residual is None else residual.reshape(1, rows, residual.shape[-1]), True)
+        return y.view(*lead, y.shape[-1]), xa.view(x.shape)
     if (rt.blas_linears and residual is None and bias is None and x.dtype == torch.bfloat16 and rows >= 1024 and ci >= 512 and co >= 512 and co % 8 == 0
             and x.shape[-1] == pad8(ci)):
         return PlainLinearFn.apply(x.reshape(rows, x.shape[-1]), weight, rt).view(*lead, co)
@@ -577,8 +597,11 @@ def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None, residual=None) 
 # =====================================================================================================================
 class GroupNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, film, rt: TrainRuntime, C: int, groups: int, eps: float, silu: bool, dfilm_slot=None):
-        """``film`` [B, >= 2C]: contiguous, or a column slice of a wider matrix (rows ``film.stride(0)`` apart: FilmBankFn); with
+    def forward(ctx, x, gamma, beta, film, rt: TrainRuntime, C: int, groups: int, eps: float, silu: bool, dfilm_slot=None, fork: bool = False):
+        """``fork``: also return ``x`` itself (an alias) for the branch that goes AROUND the norm (ResnetBlock1d's residual / shortcut,
+        blocks.py:229-231): the gradient of that branch then arrives here as a second argument of ``backward`` and is added inside the
+        GroupNorm backward kernel (jen1_gn_backward_add) instead of by an accumulation launch of autograd.
+        ``film`` [B, >= 2C]: contiguous, or a column slice of a wider matrix (rows ``film.stride(0)`` apart: FilmBankFn); with
         ``dfilm_slot`` (FilmSlot: the same slice of the matrix of FiLM gradients) the backward kernel writes the gradient there itself"""
         B, Lx, ld = x.shape
         assert x.is_contiguous() and ld >= C
@@ -601,15 +624,21 @@ class GroupNormFn(Function):
         ctx.rt, ctx.C, ctx.groups, ctx.eps, ctx.silu, ctx.gamma, ctx.beta = rt, C, groups, eps, silu, gamma, beta
         ctx.has_film = film is not None
         ctx.film_ld, ctx.dfilm_slot = film_ld, (dfilm_slot if film is not None else None)
+        if fork:
+            ctx.save_for_backward(x, sums, film if film is not None else x.new_empty(0))
+            return y, x.view_as(x)
         ctx.save_for_backward(x, sums, film if film is not None else x.new_empty(0))
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, sums, film = ctx.saved_tensors
         rt, C, groups = ctx.rt, ctx.C, ctx.groups
         B, Lx, ld = x.shape
         dy = dy.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            assert dskip.shape == x.shape and dskip.dtype == x.dtype
         dt = rt.dt_of(x)
         dx = (torch.zeros_like if ld != C else torch.empty_like)(x)
         P = torch.empty((B, C, 4), dtype=torch.float32, device=x.device)
@@ -619,11 +648,12 @@ class GroupNormFn(Function):
         if ctx.has_film:
             dfilm = slot.view if slot is not None else torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
         flags = (1 if ctx.silu else 0) | (2 if slot is not None else 0)
-        L.check(rt.lib.jen1_gn_backward(dy.data_ptr(), x.data_ptr(), sums.data_ptr(), ctx.gamma.data_ptr(), ctx.beta.data_ptr(),
-                                        film.data_ptr() if ctx.has_film else None, ctx.film_ld,
-                                        dx.data_ptr(), rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(),
-                                        None if dfilm is None else dfilm.data_ptr(), P.data_ptr(), Gm.data_ptr(), B, Lx, C, ld,
-                                        groups, float(ctx.eps), flags, dt, rt.stream()), "jen1_gn_backward")
+        L.check(rt.lib.jen1_gn_backward_add(dy.data_ptr(), x.data_ptr(), sums.data_ptr(), ctx.gamma.data_ptr(), ctx.beta.data_ptr(),
+                                            film.data_ptr() if ctx.has_film else None, ctx.film_ld,
+                                            dx.data_ptr(), None if dskip is None else dskip.data_ptr(),
+                                            rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(),
+                                            None if dfilm is None else dfilm.data_ptr(), P.data_ptr(), Gm.data_ptr(), B, Lx, C, ld,
+                                            groups, float(ctx.eps), flags, dt, rt.stream()), "jen1_gn_backward_add")
         if slot is not None:
             df = slot.view                     # (written in place: FilmBankFn.backward recognises its own slice)
             slot.written()
@@ -635,11 +665,14 @@ class GroupNormFn(Function):
                 df[:, :2 * C] = dfilm
         else:
             df = None
-        return dx, None, None, df, None, None, None, None, None, None
+        return dx, None, None, df, None, None, None, None, None, None, None
 
 
-def group_norm(rt, x, gamma, beta, C, groups, eps, film=None, silu=False, dfilm_slot=None):
-    return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu, dfilm_slot)
+def group_norm(rt, x, gamma, beta, C, groups, eps, film=None, silu=False, dfilm_slot=None, fork=False):
+    """``fork``: -> (norm(x), x) with the two gradients of x merged inside the backward kernel (GroupNormFn.forward)"""
+    if fork and x.shape[-1] != C:
+        return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu, dfilm_slot, False), x     # (padded rows: plain accumulation)
+    return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu, dfilm_slot, fork)
 
 
 # =====================================================================================================================
@@ -715,7 +748,10 @@ def film_bank(rt: TrainRuntime, smap: torch.Tensor, weights, biases):
 # =====================================================================================================================
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rt: TrainRuntime, C: int, eps: float):
+    def forward(ctx, x, gamma, beta, rt: TrainRuntime, C: int, eps: float, fork: bool = False):
+        """``fork``: also return ``x`` (an alias) for the residual branch around the sub-block (blocks.py:486-488); its gradient comes
+        back as the second argument of ``backward`` and is added inside the kernel (jen1_ln_backward_add)"""
+        assert not fork or x.is_contiguous()
         x = x.contiguous()
         ld = x.shape[-1]
         rows = x.numel() // ld
@@ -725,24 +761,33 @@ class LayerNormFn(Function):
                                        float(eps), rt.dt_of(x), rt.stream()), "jen1_ln_forward")
         ctx.rt, ctx.C, ctx.gamma, ctx.beta = rt, C, gamma, beta
         ctx.save_for_backward(x, stats)
+        if fork:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, stats = ctx.saved_tensors
         rt, C = ctx.rt, ctx.C
         dy = dy.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            assert dskip.shape == x.shape and dskip.dtype == x.dtype
         ld = x.shape[-1]
         rows = x.numel() // ld
         dx = (torch.zeros_like if ld != C else torch.empty_like)(x)
-        L.check(rt.lib.jen1_ln_backward(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), ctx.gamma.data_ptr(), dx.data_ptr(),
-                                        rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(), rows, C, ld, rt.dt_of(x),
-                                        rt.stream()), "jen1_ln_backward")
-        return dx, None, None, None, None, None
+        L.check(rt.lib.jen1_ln_backward_add(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), ctx.gamma.data_ptr(), dx.data_ptr(),
+                                            None if dskip is None else dskip.data_ptr(),
+                                            rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(), rows, C, ld, rt.dt_of(x),
+                                            rt.stream()), "jen1_ln_backward_add")
+        return dx, None, None, None, None, None, None
 
 
-def layer_norm(rt, x, gamma, beta, eps: float = 1e-5):
-    return LayerNormFn.apply(x, gamma, beta, rt, gamma.shape[0], eps)
+def layer_norm(rt, x, gamma, beta, eps: float = 1e-5, fork: bool = False):
+    """``fork``: -> (norm(x), x) with the two gradients of x merged inside the backward kernel (LayerNormFn.forward)"""
+    if fork and (not x.is_contiguous() or x.shape[-1] != gamma.shape[0]):
+        return LayerNormFn.apply(x, gamma, beta, rt, gamma.shape[0], eps, False), x
+    return LayerNormFn.apply(x, gamma, beta, rt, gamma.shape[0], eps, fork)
 
 
 class ActFn(Function):
@@ -981,7 +1026,11 @@ class TrainGraph:
     def res_block(self, r: ResSpec, x: torch.Tensor, smap: torch.Tensor, causal: bool, films: Optional[dict] = None) -> torch.Tensor:
         """ResnetBlock1d.forward (blocks.py:219-231); ``smap`` = SiLU(mapping) in the compute dtype"""
         rt, p, n = self.rt, self.p, r.name
-        h = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True)
+        # x feeds the first norm AND the residual / shortcut: forked, its two gradients meet inside the GroupNorm backward kernel
+        if rt.fork_norms and x.requires_grad:
+            h, x = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True, fork=True)
+        else:
+            h = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True)
         h = conv1d_same(rt, h, p[f"{n}.block1.project.conv.weight"], p[f"{n}.block1.project.conv.bias"], 1, causal)
         if films is not None:
             film, slot = films[n]
@@ -997,9 +1046,20 @@ class TrainGraph:
                   heads: int, causal: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Attention.forward (blocks.py:415-437): the padding mask multiplies K and V (:431-434); ``residual`` is added by to_out's GEMM"""
         rt, p = self.rt, self.p
-        ctx = x if context is None else context
-        xn = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"])
-        cn = layer_norm(rt, ctx, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"])
+        # x feeds the norm(s) AND (as ``residual``) the sum after to_out: forked through the LayerNorms, so its gradients meet
+        # inside their backward kernels instead of in accumulation launches
+        fork = rt.fork_norms and residual is x and x.requires_grad
+        if fork:
+            xn, x = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"], fork=True)
+            if context is None:
+                cn, x = layer_norm(rt, x, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"], fork=True)
+            else:
+                cn = layer_norm(rt, context, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"])
+            residual = x
+        else:
+            ctx = x if context is None else context
+            xn = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"])
+            cn = layer_norm(rt, ctx, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"])
         q = linear(rt, xn, p[f"{n}.to_q.weight"])
         kv = linear(rt, cn, p[f"{n}.to_kv.weight"])
         mid = kv.shape[-1] // 2
@@ -1018,8 +1078,11 @@ class TrainGraph:
             bn = f"{n}.blocks.{l}"
             h = self.attention(f"{bn}.attention", h, None, None, t.heads, causal, residual=h)            # (+ h: blocks.py:486-488)
             h = self.attention(f"{bn}.cross_attention", h, embedding, embedding_mask, t.heads, False, residual=h)
-            f = gelu(rt, linear(rt, h, p[f"{bn}.feed_forward.0.weight"], p[f"{bn}.feed_forward.0.bias"]))
-            h = linear(rt, f, p[f"{bn}.feed_forward.2.weight"], p[f"{bn}.feed_forward.2.bias"], residual=h)
+            if rt.fork_norms:
+                f, h = linear(rt, h, p[f"{bn}.feed_forward.0.weight"], p[f"{bn}.feed_forward.0.bias"], fork=True)
+            else:
+                f = linear(rt, h, p[f"{bn}.feed_forward.0.weight"], p[f"{bn}.feed_forward.0.bias"])
+            h = linear(rt, gelu(rt, f), p[f"{bn}.feed_forward.2.weight"], p[f"{bn}.feed_forward.2.bias"], residual=h)
         return conv1d_same(rt, h, w, b, 1, causal)
 
     @staticmethod

@@ -992,3 +992,45 @@ def test_gemm_pair_equals_two_launches(rts, mode, skinny_second):
     tol = 1e-4 if mode == "f32" else 2e-2
     assert float((p0 - ref0).abs().max()) <= tol * float(ref0.abs().max())
     assert float((p1.float() - ref1).abs().max()) <= tol * float(ref1.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("op", ["group_norm", "layer_norm", "linear"])
+def test_forked_layers_merge_the_gradient_of_the_branch_around_them(rts, mode, op):
+    """fork=True: (layer(x), x) -- the gradient that reaches x along the second output is added INSIDE the layer's backward kernel
+    (jen1_gn_backward_add / jen1_ln_backward_add / the residual of the data-gradient GEMM); same gradients as the plain layer plus
+    autograd's accumulation"""
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    B, Lx, C = 4, 40, 64
+    x0 = torch.randn(B, Lx, C, device="cuda", generator=gen).to(rt.tdtype)
+    w1 = torch.randn(B, Lx, C, device="cuda", generator=gen).to(rt.tdtype)
+    w2 = torch.randn(B, Lx, C, device="cuda", generator=gen).to(rt.tdtype)
+    gamma = torch.nn.Parameter(torch.rand(C, device="cuda", generator=gen) + 0.5)
+    beta = torch.nn.Parameter(torch.randn(C, device="cuda", generator=gen))
+    weight = torch.nn.Parameter(torch.randn(C, C, device="cuda", generator=gen) * 0.1)
+    bias = torch.nn.Parameter(torch.randn(C, device="cuda", generator=gen))
+
+    def run(fork):
+        for p_ in (gamma, beta, weight, bias):
+            p_.grad = None
+        rt.invalidate()
+        x = x0.clone().requires_grad_()
+        if op == "group_norm":
+            out = TR.group_norm(rt, x, gamma, beta, C, 8, 1e-5, None, True, fork=fork)
+        elif op == "layer_norm":
+            out = TR.layer_norm(rt, x, gamma, beta, fork=fork)
+        else:
+            out = TR.linear(rt, x, weight, bias, fork=fork)
+        y, xa = out if fork else (out, x)
+        ((y * w1).float().sum() + (xa * w2).float().sum()).backward()
+        torch.cuda.synchronize()
+        return y.detach().float(), x.grad.float()
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert torch.equal(y1, y0)
+    tol = 1e-6 if mode == "f32" else 2e-2
+    assert float((g1 - g0).abs().max()) <= tol * float(g0.abs().max())
