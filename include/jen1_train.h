@@ -39,7 +39,7 @@ typedef struct jen1_gemm_operand {
   int32_t map_L, map_Lsrc, map_mul, map_tapmul, map_shift, map_div;
   int32_t map_reflect;     /* 1: out-of-range s is mirrored (s < 0 -> -s, s >= Lsrc -> 2 (Lsrc - 1) - s) instead of reading 0:
                               F.pad(mode="reflect") of the SEANet convolutions (encodec 0.1.1 modules/conv.py pad1d) */
-  int32_t reserved;
+  int32_t reserved;        /* 0, or 1: the shift of batch element b of the mapped axis is jen1_gemm_args.map_shift_b[b] instead of map_shift */
 } jen1_gemm_operand;
 
 /*
@@ -67,6 +67,11 @@ typedef struct jen1_gemm_args {
                               nn.Conv1d bias, riding on the weight gradient); float32 [M] or NULL */
   const void* residual;    /* NULL, or a tensor of C's dtype and indexing that is added in the epilogue (the residual of a
                               ResnetBlock1d / transformer sub-block, blocks.py:231, :486-488); not with the atomic epilogue */
+  const int32_t* map_shift_b;  /* NULL, or one map_shift per batch element of the mapped axis (for the operands with reserved == 1): a
+                              pass that holds causal and non-causal clips side by side -- _Conv1d pads k - 1 on the left for the
+                              former and (k - 1) / 2 on both sides for the latter (blocks.py:45-50), which is the only place the
+                              flag enters a convolution.  One entry more than there are batch elements (the K walk of a weight
+                              gradient steps one element past the end before its loads are masked). */
 } jen1_gemm_args;
 
 int jen1_train_gemm(const jen1_gemm_args* args, void* stream);
@@ -128,12 +133,14 @@ int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, in
  * workgroup per (batch element, head) keeps Q, K, V (and dO) in LDS -- the transformer blocks of JEN-1 sit where a 1500-frame clip
  * is 1 .. 24 positions and the text context 130 tokens.  q [B][Nq][ldq], k / v [B][Nk][ldk / ldv], o / d_o [B][Nq][ldo] hold head h
  * in columns [h d, (h + 1) d); p [B H][Nq][ldp] (dtype) is the softmax output rounded to the dtype (P V uses the rounded values;
- * columns Nk .. ldp - 1 are written as 0), saved for the backward pass; causal keeps j <= i + (Nk - Nq) (blocks.py:315-319).
+ * columns Nk .. ldp - 1 are written as 0), saved for the backward pass; causal keeps j <= i + (Nk - Nq) (blocks.py:315-319);
+ * causal_b (int32 [B], may be NULL) gives the flag per batch element instead (a pass that mixes causal and non-causal clips).
  * backward writes dq [B][Nq][lddq], dk [B][Nk][lddk], dv [B][Nk][lddv] (head h in the same columns).
  * jen1_attn_small_fits: whether (Nq, Nk, d) fit one workgroup's LDS (callers fall back to jen1_train_gemm + softmax otherwise). */
 int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype);
 int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
-                            void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal, int dtype, void* stream);
+                            void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal, const int32_t* causal_b,
+                            int dtype, void* stream);
 int jen1_attn_small_backward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* p,
                              int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
                              int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, int dtype, void* stream);

@@ -19,6 +19,7 @@ struct AttnDev {
   long long ldq, ldk, ldv, ldo, ldp, lddq, lddk, lddv;      // row pitches (elements)
   int B, H, Nq, Nk, d, causal;
   float scale;
+  const int* causal_b;      // per batch element: causal or not (a pass that mixes both), or NULL: `causal` for all
 };
 
 // rows [n][d] of one head from a [B][n][ld] tensor -> float32 LDS rows of pitch dp; 16-byte global vectors when the head's rows
@@ -92,10 +93,11 @@ __global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
   }
   __syncthreads();
   // softmax over the kept keys, one wave per row; P is rounded to T (what P V multiplies and what the backward pass reads)
+  const bool causal = a.causal_b != nullptr ? a.causal_b[b] != 0 : a.causal != 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* P = reinterpret_cast<T*>(a.p) + (long long)z * Nq * a.ldp;
   for (int i = wave; i < Nq; i += ANT / 64) {
-    const int lim = a.causal ? min(Nk, i + (Nk - Nq) + 1) : Nk;       // keys j < lim are kept (blocks.py:315-319)
+    const int lim = causal ? min(Nk, i + (Nk - Nq) + 1) : Nk;       // keys j < lim are kept (blocks.py:315-319)
     float m = -3.0e38f;
     for (int j = lane; j < lim; j += 64) m = fmaxf(m, S[i * sp + j]);
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -207,7 +209,7 @@ extern "C" int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype) {
 
 extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                                        int64_t ldo, void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal,
-                                       int dtype, void* stream) {
+                                       const int32_t* causal_b, int dtype, void* stream) {
   if (check_common("jen1_attn_small_forward", B, H, Nq, Nk, d, dtype)) return 1;
   JEN1_CHECK(q && k && v && o && p, "jen1_attn_small_forward: NULL argument");
   JEN1_CHECK(ldp >= Nk, "jen1_attn_small_forward: ldp must be >= Nk");
@@ -216,6 +218,7 @@ extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k
   a.q = q; a.k = k; a.v = v; a.o = o; a.p = p;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.causal = causal ? 1 : 0; a.scale = scale;
+  a.causal_b = reinterpret_cast<const int*>(causal_b);
   const size_t lds = fwd_lds(Nq, Nk, d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == JEN1_F32) {

@@ -21,6 +21,7 @@ struct Operand {
   long long ld_r, ld_k, tap_stride;
   int map_axis, map_L, map_Lsrc, map_mul, map_tapmul, map_shift, map_div, map_reflect;
   int rows;   // number of valid rows (M or N)
+  const int* shift_b;   // per batch element b of the mapped axis: its map_shift (a pass that mixes causal and non-causal clips), or NULL
 };
 
 struct GemmDev {
@@ -44,9 +45,11 @@ template <> struct Vec<bf16_t> { static constexpr int N = 8; typedef bf16x8 type
 template <> struct Vec<float> { static constexpr int N = 4; typedef f32x4 type; };
 
 // index map of jen1_gemm_operand: returns the mapped index or -1
+__device__ __forceinline__ int shift_of(const Operand& o, int b) { return o.shift_b != nullptr ? o.shift_b[b] : o.map_shift; }
+
 __device__ __forceinline__ long long map_index(const Operand& o, int i, int tap) {
   const int b = i / o.map_L, t = i - b * o.map_L;
-  int s = t * o.map_mul + tap * o.map_tapmul + o.map_shift;
+  int s = t * o.map_mul + tap * o.map_tapmul + shift_of(o, b);
   if (o.map_reflect) {                       // F.pad(mode="reflect"): ... 2 1 | 0 1 2 ... L-1 | L-2 L-3 ...
     if (s < 0) s = -s;
     if (s >= o.map_Lsrc) s = 2 * (o.map_Lsrc - 1) - s;
@@ -78,8 +81,8 @@ struct Staged {
 // The index map without its division: (b, t) of the mapped index are kept per thread (rows of a k-contiguous
 // operand never change during the K loop; the k index of a row-contiguous one advances by BK per step), so the
 // loop body only does the multiply-add of the map.  Integer divisions per vector per step used to dominate the loop.
-__device__ __forceinline__ long long map_from_bt(const Operand& o, int b, int t, int tap) {
-  int s = t * o.map_mul + tap * o.map_tapmul + o.map_shift;
+__device__ __forceinline__ long long map_from_bt(const Operand& o, int b, int t, int tap, int shift) {      // shift = shift_of(o, b), hoisted
+  int s = t * o.map_mul + tap * o.map_tapmul + shift;
   if (o.map_reflect) {
     if (s < 0) s = -s;
     if (s >= o.map_Lsrc) s = 2 * (o.map_Lsrc - 1) - s;
@@ -97,7 +100,7 @@ __device__ __forceinline__ long long map_from_bt(const Operand& o, int b, int t,
 template <typename T>
 struct Pre {            // per-thread (b, t) of the mapped index of every vector this thread fetches
   static constexpr int NV = BM * BK / Vec<T>::N / NT;
-  int b[NV], t[NV];
+  int b[NV], t[NV], s[NV];   // s = shift_of(o, b)
   bool hoisted;         // false: fall back to map_index (division) every step
 };
 
@@ -112,6 +115,7 @@ __device__ __forceinline__ void pre_init(Pre<T>& p, const Operand& o, int row0, 
     const int idx = !rc ? row0 + v / (BK / V) : k_first + v / (BM / V);
     p.b[i] = p.hoisted ? idx / o.map_L : 0;
     p.t[i] = p.hoisted ? idx - p.b[i] * o.map_L : 0;
+    p.s[i] = p.hoisted ? shift_of(o, p.b[i]) : 0;
   }
 }
 
@@ -136,7 +140,7 @@ __device__ __forceinline__ void fetch(Staged<T>& st, Pre<T>& pre, const Operand&
         long long off;
         if (r >= o.rows) off = -1;
         else if (o.map_axis == 1 && pre.hoisted) {
-          const long long rr = map_from_bt(o, pre.b[i], pre.t[i], tap);
+          const long long rr = map_from_bt(o, pre.b[i], pre.t[i], tap, pre.s[i]);
           off = rr < 0 ? -1 : (long long)tap * o.tap_stride + rr * o.ld_r + k;
         } else {
           off = elem_offset(o, r, tap, k, K);
@@ -159,7 +163,7 @@ __device__ __forceinline__ void fetch(Staged<T>& st, Pre<T>& pre, const Operand&
         long long off;
         if (k >= K) off = -1;
         else if (o.map_axis == 2 && pre.hoisted) {
-          const long long kk = map_from_bt(o, pre.b[i], pre.t[i], tap);
+          const long long kk = map_from_bt(o, pre.b[i], pre.t[i], tap, pre.s[i]);
           off = kk < 0 ? -1 : (long long)tap * o.tap_stride + r + kk * o.ld_k;
         } else {
           off = elem_offset(o, r, tap, k, K);
@@ -176,7 +180,10 @@ __device__ __forceinline__ void fetch(Staged<T>& st, Pre<T>& pre, const Operand&
       }
       if (o.map_axis == 2 && pre.hoisted) {        // next step of this K slice: k += BK
         pre.t[i] += BK;
-        while (pre.t[i] >= o.map_L) { pre.t[i] -= o.map_L; ++pre.b[i]; }
+        if (pre.t[i] >= o.map_L) {
+          while (pre.t[i] >= o.map_L) { pre.t[i] -= o.map_L; ++pre.b[i]; }
+          pre.s[i] = shift_of(o, pre.b[i]);
+        }
       }
     }
     st.v[i] = val;
@@ -255,7 +262,7 @@ __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, co
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(abase), 0, 0x7fffffff, D_RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(bbase), 0, 0x7fffffff, D_RSRC_FLAGS);
   const int li = lane & 15, kq = (lane >> 4) * 8;
-  int a_b[2], a_t[2], a_row[2];
+  int a_b[2], a_t[2], a_s[2], a_row[2];
   bool a_ok[2];
   unsigned b_off[2];
 #pragma unroll
@@ -265,6 +272,7 @@ __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, co
     a_row[i] = r;
     a_b[i] = (g.a.map_axis == 1) ? r / g.a.map_L : 0;
     a_t[i] = (g.a.map_axis == 1) ? r - a_b[i] * g.a.map_L : 0;
+    a_s[i] = (g.a.map_axis == 1 && a_ok[i]) ? shift_of(g.a, a_b[i]) : 0;
     const int n = n0 + wn * 32 + i * 16 + li;
     b_off[i] = n < g.N ? (unsigned)((long long)n * g.b.ld_r) * ES : D_OOB;
   }
@@ -278,7 +286,7 @@ __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, co
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       long long row = a_row[i];
-      if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap);
+      if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap, a_s[i]);
       const bool ok = live && a_ok[i] && row >= 0;
       dload(xa[i], ra, ok ? (unsigned)((long long)tap * g.a.tap_stride + row * g.a.ld_r + k) * ES : D_OOB);
       dload(xb[i], rb, (live && b_off[i] != D_OOB) ? b_off[i] + tb : D_OOB);
@@ -331,7 +339,8 @@ __device__ __forceinline__ void wgrad_loop(const GemmDev& g, const bf16_t* abase
   const bf16_t* bp = bbase + n0 + cv;
   int k = s_begin * BK + kk;
   int kb = 0, kt = k;                                   // (batch element, position) of k under B's index map
-  if (g.b.map_axis == 2) { kb = k / g.b.map_L; kt = k - kb * g.b.map_L; }
+  int ks = 0;
+  if (g.b.map_axis == 2) { kb = k / g.b.map_L; kt = k - kb * g.b.map_L; ks = k < g.K ? shift_of(g.b, kb) : 0; }
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   constexpr int WST = 4;                                 // steps of global loads in flight (one 16-byte vector per operand each)
   bf16x8 ra[WST], rb[WST];
@@ -341,13 +350,16 @@ __device__ __forceinline__ void wgrad_loop(const GemmDev& g, const bf16_t* abase
     if (k < g.K) {
       if (a_col) xa = *reinterpret_cast<const bf16x8*>(ap + (long long)k * g.a.ld_k);
       long long row = k;
-      if (g.b.map_axis == 2) row = map_from_bt(g.b, kb, kt, tap);
+      if (g.b.map_axis == 2) row = map_from_bt(g.b, kb, kt, tap, ks);
       if (b_col && row >= 0) xb = *reinterpret_cast<const bf16x8*>(bp + row * g.b.ld_k);
     }
     k += BK;
     if (g.b.map_axis == 2) {
       kt += BK;
-      while (kt >= g.b.map_L) { kt -= g.b.map_L; ++kb; }
+      if (kt >= g.b.map_L) {
+        while (kt >= g.b.map_L) { kt -= g.b.map_L; ++kb; }
+        ks = k < g.K ? shift_of(g.b, kb) : 0;
+      }
     }
   };
 #pragma unroll
@@ -579,7 +591,7 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(abase), 0, 0x7fffffff, D_RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(bbase), 0, 0x7fffffff, D_RSRC_FLAGS);
   const int li = lane & 15, kq = (lane >> 4) * 8;
-  int a_b[2], a_t[2], a_row[2];
+  int a_b[2], a_t[2], a_s[2], a_row[2];
   bool a_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -588,6 +600,7 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
     a_row[i] = r;
     a_b[i] = (g.a.map_axis == 1) ? r / g.a.map_L : 0;
     a_t[i] = (g.a.map_axis == 1) ? r - a_b[i] * g.a.map_L : 0;
+    a_s[i] = (g.a.map_axis == 1 && a_ok[i]) ? shift_of(g.a, a_b[i]) : 0;
   }
   const int nb = n0 + li;
   const unsigned b_off = nb < g.N ? (unsigned)((long long)nb * g.b.ld_r) * ES : D_OOB;
@@ -605,7 +618,7 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       long long row = a_row[i];
-      if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap);
+      if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap, a_s[i]);
       const bool ok = live && a_ok[i] && row >= 0;
       dload(xa[i], ra, ok ? (unsigned)((long long)tap * g.a.tap_stride + row * g.a.ld_r + k) * ES : D_OOB);
     }
@@ -720,11 +733,12 @@ int check_operand(const jen1_gemm_operand& o, const char* name) {
   return 0;
 }
 
-Operand to_dev(const jen1_gemm_operand& o, int rows) {
+Operand to_dev(const jen1_gemm_operand& o, int rows, const int32_t* shift_b) {
   Operand d;
   d.p = o.p; d.ld_r = o.ld_r; d.ld_k = o.ld_k; d.tap_stride = o.tap_stride;
   d.map_axis = o.map_axis; d.map_L = o.map_L; d.map_Lsrc = o.map_Lsrc; d.map_mul = o.map_mul;
   d.map_tapmul = o.map_tapmul; d.map_shift = o.map_shift; d.map_div = o.map_div; d.map_reflect = o.map_reflect ? 1 : 0; d.rows = rows;
+  d.shift_b = (o.reserved == 1 && o.map_axis != 0) ? reinterpret_cast<const int*>(shift_b) : nullptr;
   return d;
 }
 
@@ -744,8 +758,9 @@ int prepare(const jen1_gemm_args* args, GemmDev& g, dim3& grid, bool& skinny) {
   JEN1_CHECK(gz <= 65535, "train_gemm: batches * taps * splitk = %lld exceeds the grid limit", gz);
   const int gy = (a.N + BN - 1) / BN;
   JEN1_CHECK(gy <= 65535, "train_gemm: N = %d is too large", a.N);
-  g.a = to_dev(a.a, a.M);
-  g.b = to_dev(a.b, a.N);
+  g.a = to_dev(a.a, a.M, a.map_shift_b);
+  g.b = to_dev(a.b, a.N, a.map_shift_b);
+  JEN1_CHECK((a.a.reserved != 1 && a.b.reserved != 1) || a.map_shift_b != nullptr, "train_gemm: an operand asks for per-batch-element shifts but map_shift_b is NULL");
   g.c = a.c; g.bias = reinterpret_cast<const float*>(a.bias);
   g.rowsum = reinterpret_cast<float*>(a.rowsum);
   g.res = a.residual;

@@ -89,7 +89,8 @@ class GemmArgs(C.Structure):
                 ("c_zs0", c_int64), ("c_zs1", c_int64), ("ldc_m", c_int64), ("ldc_n", c_int64), ("c_tap_stride", c_int64),
                 ("c_zdiv", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("taps", c_int), ("batches", c_int),
                 ("taps_in_z", c_int), ("splitk", c_int), ("atomic", c_int), ("accumulate", c_int), ("c_f32", c_int),
-                ("dtype", c_int), ("alpha", c_float), ("reserved", c_int), ("rowsum", c_void_p), ("residual", c_void_p)]
+                ("dtype", c_int), ("alpha", c_float), ("reserved", c_int), ("rowsum", c_void_p), ("residual", c_void_p),
+                ("map_shift_b", c_void_p)]
 
 
 class RepackEntry(C.Structure):
@@ -128,7 +129,7 @@ SYMBOLS = {
     "jen1_train_gemm": (c_int, [C.POINTER(GemmArgs), _P]),
     "jen1_train_gemm_pair": (c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _P]),
     "jen1_attn_small_fits": (c_int, [c_int, c_int, c_int, c_int]),
-    "jen1_attn_small_forward": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64] + [c_int] * 5 + [c_float, c_int, c_int, _P]),
+    "jen1_attn_small_forward": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64] + [c_int] * 5 + [c_float, c_int, _P, c_int, _P]),
     "jen1_attn_small_backward": (c_int, [_P, c_int64] * 8 + [c_int] * 5 + [c_float, c_int, _P]),
     "jen1_gn_sums": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "jen1_gn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),

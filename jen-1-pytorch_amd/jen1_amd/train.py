@@ -38,8 +38,10 @@ def pad8(c: int) -> int:
 class Map:
     """index map of ``jen1_gemm_operand`` (include/jen1_train.h)"""
 
-    def __init__(self, axis: int, L_idx: int, L_src: int, mul: int = 1, tapmul: int = 0, shift: int = 0, div: int = 1, reflect: bool = False):
+    def __init__(self, axis: int, L_idx: int, L_src: int, mul: int = 1, tapmul: int = 0, shift: int = 0, div: int = 1, reflect: bool = False,
+                 per_batch: bool = False):
         self.axis, self.L, self.Lsrc, self.mul, self.tapmul, self.shift, self.div, self.reflect = axis, L_idx, L_src, mul, tapmul, shift, div, reflect
+        self.per_batch = per_batch        # the shift of batch element b comes from jen1_gemm_args.map_shift_b[b] (CausalRows)
 
 
 def _operand(ptr: int, ld_r: int, ld_k: int, tap_stride: int = 0, zs0: int = 0, zs1: int = 0, zdiv: int = 1,
@@ -51,6 +53,7 @@ def _operand(ptr: int, ld_r: int, ld_k: int, tap_stride: int = 0, zs0: int = 0, 
     else:
         o.map_axis, o.map_L, o.map_Lsrc, o.map_mul, o.map_tapmul, o.map_shift, o.map_div = m.axis, m.L, m.Lsrc, m.mul, m.tapmul, m.shift, m.div
         o.map_reflect = int(m.reflect)
+        o.reserved = 1 if m.per_batch else 0
     return o
 
 
@@ -293,7 +296,8 @@ class TrainRuntime:
              batches: int = 1, taps_in_z: bool = False, ldc_m: int, ldc_n: int = 1, c_tap_stride: int = 0, c_zs0: int = 0,
              c_zs1: int = 0, c_zdiv: int = 1, bias: Optional[torch.Tensor] = None, splitk: int = 1, atomic: bool = False,
              accumulate: bool = False, c_f32: bool = False, alpha: float = 1.0, rowsum: Optional[torch.Tensor] = None,
-             residual: Optional[torch.Tensor] = None, skinny: bool = False, defer: bool = False, pair_with=None):
+             residual: Optional[torch.Tensor] = None, skinny: bool = False, defer: bool = False, pair_with=None,
+             shift_b: Optional[torch.Tensor] = None):
         """``defer``: no launch, the filled argument block comes back; ``pair_with`` (such a block): both products in ONE launch
         (jen1_train_gemm_pair: the deferred one first)"""
         g = L.GemmArgs()
@@ -305,6 +309,7 @@ class TrainRuntime:
         g.rowsum = None if rowsum is None else rowsum.data_ptr()
         g.residual = None if residual is None else residual.data_ptr()
         g.reserved = 1 if skinny else 0
+        g.map_shift_b = None if shift_b is None else shift_b.data_ptr()
         if defer:
             return g
         if pair_with is not None:
@@ -353,16 +358,21 @@ class TrainRuntime:
 class ConvGeom:
     """static description of one convolution call"""
 
-    def __init__(self, kind: str, taps: int, stride: int, pad: int, L_in: int, L_out: int, ci: int, co: int, reflect: bool = False):
+    def __init__(self, kind: str, taps: int, stride: int, pad: int, L_in: int, L_out: int, ci: int, co: int, reflect: bool = False,
+                 pad_b: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         self.kind, self.taps, self.stride, self.pad, self.L_in, self.L_out, self.ci, self.co = kind, taps, stride, pad, L_in, L_out, ci, co
         self.reflect = reflect        # forward only: F.pad(mode="reflect") instead of zeros (SEANet convolutions)
+        # (-pad, +pad) per batch element as int32 tensors: a pass that mixes causal and non-causal clips ("conv" kind only)
+        self.pad_b = pad_b
+        assert pad_b is None or kind == "conv"
 
     def fwd_map(self, axis: int) -> Optional[Map]:
         """activation index (b, t_out) [+ tap] -> input row"""
         if self.kind == "linear":
             return None
         if self.kind == "conv":
-            return Map(axis, self.L_out, self.L_in, mul=self.stride, tapmul=1, shift=-self.pad, reflect=self.reflect)
+            return Map(axis, self.L_out, self.L_in, mul=self.stride, tapmul=1, shift=-self.pad, reflect=self.reflect,
+                       per_batch=self.pad_b is not None)
         return Map(axis, self.L_out, self.L_in, mul=1, tapmul=-1, shift=self.pad, div=self.stride)
 
     def bwd_map(self, axis: int) -> Optional[Map]:
@@ -370,8 +380,16 @@ class ConvGeom:
         if self.kind == "linear":
             return None
         if self.kind == "conv":
-            return Map(axis, self.L_in, self.L_out, mul=1, tapmul=-1, shift=self.pad, div=self.stride)
+            return Map(axis, self.L_in, self.L_out, mul=1, tapmul=-1, shift=self.pad, div=self.stride, per_batch=self.pad_b is not None)
         return Map(axis, self.L_in, self.L_out, mul=self.stride, tapmul=1, shift=-self.pad)
+
+    @property
+    def fwd_shift_b(self) -> Optional[torch.Tensor]:
+        return None if self.pad_b is None else self.pad_b[0]
+
+    @property
+    def bwd_shift_b(self) -> Optional[torch.Tensor]:
+        return None if self.pad_b is None else self.pad_b[1]
 
 
 def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom,
@@ -396,14 +414,14 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
         assert residual.is_contiguous() and residual.numel() == B * g.L_out * ldy and residual.dtype == x.dtype, (residual.shape, B, g.L_out, ldy)
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_out * ldy)
-        rt.gemm(a, b, acc.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, splitk=sk, atomic=True, c_f32=True)
+        rt.gemm(a, b, acc.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, splitk=sk, atomic=True, c_f32=True, shift_b=g.fwd_shift_b)
         return rt.hand_over(acc, torch.empty((B, g.L_out, ldy), dtype=x.dtype, device=x.device), residual)
     if residual is not None and ldy != co:
         y = residual.clone()                   # (padding columns: keep the residual's)
-        rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, accumulate=True, skinny=skinny)
+        rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, accumulate=True, skinny=skinny, shift_b=g.fwd_shift_b)
         return y
     y = alloc((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
-    rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, residual=residual, skinny=skinny)
+    rt.gemm(a, b, y.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, residual=residual, skinny=skinny, shift_b=g.fwd_shift_b)
     return y
 
 
@@ -434,14 +452,14 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     sk = 1 if skinny else rt.pick_splitk(M, cip, ksteps)
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_in * cip)
-        rt.gemm(a, b, acc.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True, pair_with=pair_with)
+        rt.gemm(a, b, acc.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, splitk=sk, atomic=True, c_f32=True, pair_with=pair_with, shift_b=g.bwd_shift_b)
         return rt.hand_over(acc, torch.empty((B, g.L_in, cip), dtype=dy.dtype, device=dy.device), residual)
     if residual is not None and cip_n != cip:
         dx = residual.clone()                  # (padding columns: keep the residual's)
-        rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with, accumulate=True)
+        rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with, accumulate=True, shift_b=g.bwd_shift_b)
         return dx
     dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
-    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with, residual=residual)
+    rt.gemm(a, b, dx.data_ptr(), M, cip_n, co, dtype=dt, taps=k, ldc_m=cip, skinny=skinny, pair_with=pair_with, residual=residual, shift_b=g.bwd_shift_b)
     return dx
 
 
@@ -475,7 +493,8 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
     # stream-ordered, so a plain read-modify-write accumulates; float atomics only when the K range is split
     na = sk == 1 and rt.wgrad_plain_rmw
     blk = rt.gemm(a, b, gw.data_ptr(), M, N, K, dtype=dt, taps=k, taps_in_z=True, ldc_m=N * k, ldc_n=k, c_tap_stride=1,
-                  splitk=sk, atomic=not na, accumulate=na, c_f32=True, rowsum=gb if fused_bias else None, defer=defer)
+                  splitk=sk, atomic=not na, accumulate=na, c_f32=True, rowsum=gb if fused_bias else None, defer=defer,
+                  shift_b=g.fwd_shift_b if g.kind == "conv" else None)
     return (fused_bias, blk) if defer else fused_bias
 
 
@@ -525,12 +544,42 @@ class ConvFn(Function):
         return dx, None, None, None, None, (dy if ctx.has_res else None), None       # (the residual's gradient IS dy: no launch)
 
 
-def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal: bool, residual=None) -> torch.Tensor:
+class CausalRows:
+    """``causal`` per batch element (int32 [B] on the device, 1 = causal) for a pass that holds causal and non-causal clips side by
+    side (the reference runs one pass per task, trainer.py:189-211; the samples of a pass do not interact, so one pass over all of
+    them computes the same thing).  The flag enters the network in two places: _Conv1d's padding (blocks.py:45-50) -> a map shift
+    per batch element (jen1_gemm_args.map_shift_b), and the causal mask of self-attention (blocks.py:315-319) -> a flag per batch
+    element (jen1_attn_small_forward's causal_b)."""
+
+    def __init__(self, flags: torch.Tensor):
+        self.flags = flags.to(torch.int32).contiguous()
+        self._pads: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def pads(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(-pad_left, +pad_left) per batch element for a kernel of k taps, each one entry longer than the batch"""
+        hit = self._pads.get(k)
+        if hit is None:
+            f = torch.cat([self.flags, self.flags[-1:]])
+            pos = torch.where(f != 0, k - 1, (k - 1) // 2).to(torch.int32)
+            hit = ((-pos).contiguous(), pos.contiguous())
+            self._pads[k] = hit
+        return hit
+
+    def twice(self) -> "CausalRows":
+        """for the CFG pair: the batch stacked on itself (model.py:349-353)"""
+        return CausalRows(torch.cat([self.flags, self.flags]))
+
+
+def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal, residual=None) -> torch.Tensor:
     """_Conv1d (blocks.py:34-53): total padding k - 1, all on the left when causal else split evenly.  ``residual`` (the output's
-    shape) is added in the GEMM's epilogue."""
+    shape) is added in the GEMM's epilogue.  ``causal``: bool, or CausalRows (the flag per batch element)."""
     co, ci, k = weight.shape
     B, Lin, _ = x.shape
-    pad = (k - 1) if causal else (k - 1) // 2
+    if isinstance(causal, CausalRows) and k > 1:
+        assert causal.flags.shape[0] == B
+        g = ConvGeom("conv", k, stride, (k - 1) // 2, Lin, (Lin - 1) // stride + 1, ci, co, pad_b=causal.pads(k))
+        return ConvFn.apply(x, weight, bias, rt, g, residual)
+    pad = (k - 1) if (causal is True) else (k - 1) // 2
     return ConvFn.apply(x, weight, bias, rt, ConvGeom("conv", k, stride, pad, Lin, (Lin - 1) // stride + 1, ci, co), residual)
 
 
@@ -880,9 +929,16 @@ class AttentionCoreFn(Function):
         O = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
         ctx.rt, ctx.heads, ctx.scale = rt, heads, scale
         ctx.small = bool(rt.small_attn and rt.lib.jen1_attn_small_fits(Nq, Nk, d, dt))
+        rows = causal if isinstance(causal, CausalRows) else None
+        if rows is not None and not ctx.small:
+            raise L.Jen1HipError(f"a pass that mixes causal and non-causal clips needs the one-launch attention core "
+                                 f"(Nq = {Nq}, Nk = {Nk}, d = {d} do not fit one workgroup)")
         if ctx.small:
+            assert rows is None or rows.flags.shape[0] == B
             L.check(rt.lib.jen1_attn_small_forward(qp, ldq, kp, ldk, vp, ldv, O.data_ptr(), C, P.data_ptr(), ldS, B, heads, Nq, Nk, d,
-                                                   float(scale), 1 if causal else 0, dt, rt.stream()), "jen1_attn_small_forward")
+                                                   float(scale), 1 if (rows is None and causal) else 0,
+                                                   None if rows is None else rows.flags.data_ptr(), dt, rt.stream()),
+                    "jen1_attn_small_forward")
             ctx.save_for_backward(q, kv, P)
             return O
         S = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
@@ -975,6 +1031,25 @@ class TrainGraph:
 
     def invalidate(self) -> None:
         self.rt.invalidate()
+
+    def per_clip_causal_ok(self, T: int, n_context: int) -> bool:
+        """whether a pass over clips of T frames with ``n_context`` conditioning tokens may carry the causal flag per clip
+        (CausalRows): every attention of the network must fit the one-launch kernels, which take the flag per batch element"""
+        sp, rt = self.spec, self.rt
+        if not rt.small_attn:
+            return False
+        nk = n_context + (1 if sp.use_xattn_time else 0)
+        Lx = T
+        lens = []
+        for d in sp.downs:
+            Lx = (Lx - 1) // d.factor + 1
+            lens.append(Lx)
+        trs = [(d.transformer, n) for d, n in zip(sp.downs, lens) if d.transformer]
+        if sp.bott_tr:
+            trs.append((sp.bott_tr, lens[-1]))
+        trs += [(u.transformer, n) for u, n in zip(sp.ups, reversed(lens)) if u.transformer]
+        return all(rt.lib.jen1_attn_small_fits(n, n, t.head_features, rt.dt) and rt.lib.jen1_attn_small_fits(n, nk, t.head_features, rt.dt)
+                   for t, n in trs)
 
     def attach_optimizer(self, opt) -> None:
         """after every ``FusedAdamW.step``: re-pack the compute weights of the training path AND drop the inference engine's
@@ -1153,7 +1228,10 @@ class TrainGraph:
         """Same contract as the reference forward (model.py:299-376), differentiable."""
         assert features is None, "context_features is unused on the JEN-1 path"
         rt, p, sp = self.rt, self.p, self.spec
-        causal = bool(causal)
+        # a bool, or one flag per clip (tensor [B]): a pass that holds causal and non-causal clips side by side (CausalRows)
+        rows = CausalRows(causal) if torch.is_tensor(causal) else None
+        causal = rows if rows is not None else bool(causal)
+        causal2 = rows.twice() if rows is not None else causal          # for the CFG pair stacked on the batch axis
         B = embedding.shape[0]
         dev = x.device
         emb = embedding.to(rt.tdtype)
@@ -1180,7 +1258,7 @@ class TrainGraph:
             if batch_cfg:
                 out_all = self.unet(torch.cat([x, x], 0), torch.cat([time, time], 0), torch.cat([emb, fixed], 0).contiguous(),
                                     None if mask is None else torch.cat([mask, mask], 0),
-                                    None if ctx is None else torch.cat([ctx, ctx], 0), causal)
+                                    None if ctx is None else torch.cat([ctx, ctx], 0), causal2)
                 out, out_masked = out_all[:B], out_all[B:]
             else:
                 out = self.unet(x, time, emb.contiguous(), mask, ctx, causal)
@@ -1239,6 +1317,8 @@ class GraphedLossStep:
     def _body(self, static, causal):
         cond = {"cross_attn_cond": static["emb"], "cross_attn_masks": static["mask"], "global_cond": None,
                 "input_concat_cond": static["concat"]}
+        if static["causal"] is not None:
+            causal = static["causal"]          # one flag per clip, read by the replayed kernels: refreshed before every replay
         if static["w"] is None:
             loss = self.diffusion.training_loosses(self.graph, static["x0"], static["t"], cond, causal=causal)
             (loss * self.scale).backward()
@@ -1252,6 +1332,7 @@ class GraphedLossStep:
     def _capture(self, key, x0, t, conditioning, causal, weights=None, exchange=None):
         params = list(self.graph.p.values())
         static = {"x0": x0.clone(), "t": t.clone(), "emb": conditioning["cross_attn_cond"].clone(),
+                  "causal": causal.to(torch.int32).clone() if torch.is_tensor(causal) else None,
                   "mask": None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"].clone(),
                   "concat": None if conditioning["input_concat_cond"] is None else conditioning["input_concat_cond"].clone(),
                   "w": None if weights is None else weights.to(torch.float32).clone()}
@@ -1289,12 +1370,13 @@ class GraphedLossStep:
         per-sample losses [B] of the pass whose objective is their weighted sum"""
         assert conditioning.get("global_cond") is None
         ex = self.exchange if (self.exchange is not None and self.exchange.active and self.exchange.capturable) else None
-        key = (tuple(x0.shape), bool(causal), conditioning["cross_attn_masks"] is None, conditioning["input_concat_cond"] is None,
+        per_clip = torch.is_tensor(causal)
+        key = (tuple(x0.shape), "per clip" if per_clip else bool(causal), conditioning["cross_attn_masks"] is None, conditioning["input_concat_cond"] is None,
                sample_weights is None, ex is not None)
         hit = self._captured.get(key)
         first = hit is None
         if first:
-            hit = self._capture(key, x0, t, conditioning, bool(causal), sample_weights, ex)
+            hit = self._capture(key, x0, t, conditioning, causal if per_clip else bool(causal), sample_weights, ex)
             if ex is not None:
                 ex.begin()                 # (recording the exchange consumed the armed state; the replay below is the real pass)
         g, static, loss = hit
@@ -1302,6 +1384,8 @@ class GraphedLossStep:
             static["w"].copy_(sample_weights)
         static["x0"].copy_(x0)
         static["t"].copy_(t)
+        if per_clip:
+            static["causal"].copy_(causal)
         static["emb"].copy_(conditioning["cross_attn_cond"])
         if static["mask"] is not None:
             static["mask"].copy_(conditioning["cross_attn_masks"])

@@ -54,7 +54,7 @@ class UnifiedMultiTaskTrainer:
       grad_clip     the clip norm of the fused optimiser step (nn.utils.clip_grad_norm_, trainer.py:145)
       grad_accum_every   micro-batches per optimiser step (trainer.py:139-149)
     Keyword-only extras (not in the reference): ``process_group``, ``rng``, ``compute_dtype``, ``use_graph``,
-    ``allow_uneven_tasks``, ``bucket_bytes``, ``merge_tasks``.  ``UnifiedMultiTaskTrainer.build(model, diffusion, conditioner,
+    ``allow_uneven_tasks``, ``bucket_bytes``, ``merge_tasks``, ``merge_causal``.  ``UnifiedMultiTaskTrainer.build(model, diffusion, conditioner,
     optimizer, ...)`` is the short form for code that has no config object."""
 
     def __init__(self, config, rank: int, epoch_str: int, global_step: int, model, diffusion, conditioner: Callable, dls, optimizer,
@@ -62,7 +62,7 @@ class UnifiedMultiTaskTrainer:
                  cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
                  input_concat_ids: Sequence[str] = ("masked_input", "mask"), *, process_group=None, rng=_random,
                  compute_dtype: Optional[str] = None, use_graph: bool = True, allow_uneven_tasks: bool = False,
-                 bucket_bytes: int = 128 << 20, merge_tasks: bool = True):
+                 bucket_bytes: int = 128 << 20, merge_tasks: bool = True, merge_causal: bool = True):
         self.config = config
         self.tasks = tuple(getattr(config, "tasks", TASKS))
         self.device = getattr(config, "device", "cuda")
@@ -101,6 +101,8 @@ class UnifiedMultiTaskTrainer:
         # task sub-batches that drew the same ``causal`` flag run as ONE pass through the network (same loss: the sum of the
         # per-task means, each sample weighted 1 / its sub-batch size); False = the reference's literal one pass per task
         self.merge_tasks = merge_tasks and self.is_gdm
+        # ... and sub-batches with DIFFERENT flags too: the flag travels per clip (train.CausalRows), one pass per micro-batch
+        self.merge_causal = merge_causal and self.merge_tasks
         # DDP's gradient exchange (train.py:88-89): buckets in reverse execution order; in eager mode each bucket leaves as soon
         # as the backward pass has finished it, behind a replayed graph the regions leave between the segments of the replay
         names = [n for n, _ in model.named_parameters()]
@@ -185,18 +187,22 @@ class UnifiedMultiTaskTrainer:
                 all_loss = all_loss + loss
             return all_loss, loss_dict
         flags = [f for f in (False, True) if any(p[4] == f for p in parts)]
+        if len(flags) == 2 and self.merge_causal and self.graph.per_clip_causal_ok(parts[0][1].shape[-1], parts[0][3]["cross_attn_cond"].shape[1]):
+            flags = ["per clip"]               # ONE pass for all sub-batches: the causal flag travels per clip (train.CausalRows)
         for flag in flags:
-            group = [p for p in parts if p[4] == flag]
+            group = parts if flag == "per clip" else [p for p in parts if p[4] == flag]
             cat = lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)        # noqa: E731
             x = cat([p[1] for p in group])
             t = cat([p[2] for p in group])
             keys = group[0][3].keys()
             conditioning = {k: (None if group[0][3][k] is None else cat([p[3][k] for p in group])) for k in keys}
             w = torch.cat([torch.full((p[1].shape[0],), 1.0 / p[1].shape[0], device=self.device) for p in group])
+            if flag == "per clip":
+                flag = torch.cat([torch.full((p[1].shape[0],), int(p[4]), dtype=torch.int32, device=self.device) for p in group])
             if self.graphed is not None:
                 if self.grad_accum == 0 and first:
                     self.optimizer.zero_grad()
-                self.graphed.exchange = self.exchange if (armed and flag == flags[-1]) else None
+                self.graphed.exchange = self.exchange if (armed and (torch.is_tensor(flag) or flag == flags[-1])) else None
                 per_sample = self.graphed(x, t, conditioning, flag, sample_weights=w)
                 group_loss = (per_sample * w).sum()
             else:

@@ -773,10 +773,13 @@ def test_inference_engine_follows_optimizer_steps():
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_merged_task_passes_equal_one_pass_per_task(use_graph, monkeypatch):
+@pytest.mark.parametrize("T", [300, 48], ids=["one-pass-per-flag", "causal-flag-per-clip"])
+def test_merged_task_passes_equal_one_pass_per_task(use_graph, T, monkeypatch):
     """UnifiedMultiTaskTrainer(merge_tasks=True): sub-batches that drew the same causal flag share one pass through the network
     with per-sample weights 1 / sub-batch size -- the same objective as the reference's one pass per task (trainer.py:189-211: the
-    sum of the three per-task means), so the same per-task losses and the same gradients; 8 clips split 3 / 3 / 2"""
+    sum of the three per-task means), so the same per-task losses and the same gradients; 8 clips split 3 / 3 / 2.  At T = 48 every
+    attention fits the one-launch kernels and ALL sub-batches share one pass, the causal flag travelling per clip (train.CausalRows:
+    per-clip padding shifts in every convolution, per-clip causal mask in the self-attention)"""
     import random
     from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
     from jen1_amd.model import UNetCFG1d
@@ -784,7 +787,7 @@ def test_merged_task_passes_equal_one_pass_per_task(use_graph, monkeypatch):
     from jen1_amd.trainer import UnifiedMultiTaskTrainer
     # the diffusion noise as a function of the clip itself, so that a sample gets the same noise however it is batched
     monkeypatch.setattr(torch, "rand_like", lambda x, **kw: torch.sin(x * 997.0) * 0.5 + 0.5)
-    B, T = 8, 300
+    B = 8
     emb = dev(synth.conditioning(B, T, "text_guided")["cross_attn_cond"])
     msk = dev(synth.conditioning(B, T, "text_guided")["cross_attn_masks"])
     audio = dev(synth.latents(B, T, key="clip"))
@@ -803,6 +806,10 @@ def test_merged_task_passes_equal_one_pass_per_task(use_graph, monkeypatch):
         torch.cuda.synchronize()
         assert not stepped
         res[merge] = (float(loss), {k: float(v) for k, v in per_task.items()}, opt.flat_grad.clone())
+        if merge:
+            assert tr.graph.per_clip_causal_ok(T, emb.shape[1]) == (T == 48)
+            if use_graph:
+                assert len(tr.graphed._captured) == (1 if T == 48 else 2)       # passes per micro-batch
     l0, p0, g0 = res[False]
     l1, p1, g1 = res[True]
     assert set(p0) == set(p1) == {"text_guided", "music_inpaint", "music_cont"}
