@@ -571,8 +571,8 @@ def train_mode(args, world, rank, device, dist, barrier):
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[3] full JEN-1 1D-UNet (296.5M params)")
-                   + f", {B} clips per GPU (3/3/2 over text_guided / music_inpaint / music_cont; sub-batches with the same causal flag share "
-                   + f"one pass), latents 128x{T}, CFG pair, "
+                   + f", {B} clips per GPU (3/3/2 over text_guided / music_inpaint / music_cont; all sub-batches share ONE pass per "
+                   + f"micro-batch: the causal flag travels per clip), latents 128x{T}, CFG pair, "
                    + ("eager backward with the exchange overlapped" if args.eager_train else
                       "hipGraph-replayed forward+backward; with N > 1 the replayed pass that completes the gradients carries the RCCL all-reduces "
                       "of the finished regions on a forked communication stream")
