@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int ANT = 256;
+constexpr int ANT = 512;
 
 struct AttnDev {
   const void* q; const void* k; const void* v; const void* d_o;
