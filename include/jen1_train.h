@@ -135,15 +135,18 @@ int jen1_softmax_backward(const void* p, const float* dp, void* ds, int rows, in
  * in columns [h d, (h + 1) d); p [B H][Nq][ldp] (dtype) is the softmax output rounded to the dtype (P V uses the rounded values;
  * columns Nk .. ldp - 1 are written as 0), saved for the backward pass; causal keeps j <= i + (Nk - Nq) (blocks.py:315-319);
  * causal_b (int32 [B], may be NULL) gives the flag per batch element instead (a pass that mixes causal and non-causal clips).
+ * kv_mask (float32 [B][Nk], may be NULL) multiplies the rows of K and V on the way in -- the padding mask of the text context, which
+ * the reference multiplies into k and v (blocks.py:431-434) -- and the rows of dk / dv on the way out.
  * backward writes dq [B][Nq][lddq], dk [B][Nk][lddk], dv [B][Nk][lddv] (head h in the same columns).
  * jen1_attn_small_fits: whether (Nq, Nk, d) fit one workgroup's LDS (callers fall back to jen1_train_gemm + softmax otherwise). */
 int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype);
 int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
                             void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal, const int32_t* causal_b,
-                            int dtype, void* stream);
+                            const float* kv_mask, int dtype, void* stream);
 int jen1_attn_small_backward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* p,
                              int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
-                             int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, int dtype, void* stream);
+                             int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, const float* kv_mask, int dtype,
+                             void* stream);
 
 /* dst[i] = (dtype) src[i]; src[i] = 0  for i < n (n a multiple of 4): hands the float32 accumulator of a split-K GEMM
  * over in the compute dtype and leaves it zeroed for the next launch of the stream. */

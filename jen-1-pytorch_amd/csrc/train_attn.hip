@@ -20,28 +20,33 @@ struct AttnDev {
   int B, H, Nq, Nk, d, causal;
   float scale;
   const int* causal_b;      // per batch element: causal or not (a pass that mixes both), or NULL: `causal` for all
+  const float* kmask;       // [B][Nk] float32 multiplied into the rows of K and V (the padding mask of the context, blocks.py:431-434), or NULL
 };
 
 // rows [n][d] of one head from a [B][n][ld] tensor -> float32 LDS rows of pitch dp; 16-byte global vectors when the head's rows
 // start on 16-byte boundaries
 template <typename T>
-__device__ __forceinline__ void stage_rows(float* dst, int dp, const T* src, long long ld, int n, int d, bool vec_ok) {
+__device__ __forceinline__ void stage_rows(float* dst, int dp, const T* src, long long ld, int n, int d, bool vec_ok,
+                                           const float* row_scale = nullptr) {
   constexpr int V = 16 / (int)sizeof(T);
   if (vec_ok) {
     const int vpr = d / V;
     for (int e = threadIdx.x; e < n * vpr; e += ANT) {
       const int r = e / vpr, c = (e - r * vpr) * V;
       const uint4 w = *reinterpret_cast<const uint4*>(src + (long long)r * ld + c);
+      const float sc = row_scale != nullptr ? row_scale[r] : 1.0f;
       T tmp[V];
       *reinterpret_cast<uint4*>(tmp) = w;
 #pragma unroll
       for (int j = 0; j < V; j += 4)
-        *reinterpret_cast<float4*>(dst + r * dp + c + j) = make_float4((float)tmp[j], (float)tmp[j + 1], (float)tmp[j + 2], (float)tmp[j + 3]);
+        *reinterpret_cast<float4*>(dst + r * dp + c + j) =
+            make_float4((float)(T)((float)tmp[j] * sc), (float)(T)((float)tmp[j + 1] * sc), (float)(T)((float)tmp[j + 2] * sc), (float)(T)((float)tmp[j + 3] * sc));
     }
   } else {
     for (int e = threadIdx.x; e < n * d; e += ANT) {
       const int r = e / d, c = e - r * d;
-      dst[r * dp + c] = (float)src[(long long)r * ld + c];
+      const float sc = row_scale != nullptr ? row_scale[r] : 1.0f;
+      dst[r * dp + c] = (float)(T)((float)src[(long long)r * ld + c] * sc);      // (rounded to T like the tensor product it replaces)
     }
   }
 }
@@ -79,8 +84,9 @@ __global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
   const T* k = reinterpret_cast<const T*>(a.k) + (long long)b * Nk * a.ldk + h * d;
   const T* v = reinterpret_cast<const T*>(a.v) + (long long)b * Nk * a.ldv + h * d;
   stage_rows<T>(Qs, dp, q, a.ldq, Nq, d, rows_aligned(q, a.ldq, d, sizeof(T)));
-  stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)));
-  stage_rows<T>(Vs, dp, v, a.ldv, Nk, d, rows_aligned(v, a.ldv, d, sizeof(T)));
+  const float* km = a.kmask != nullptr ? a.kmask + (long long)b * Nk : nullptr;
+  stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)), km);
+  stage_rows<T>(Vs, dp, v, a.ldv, Nk, d, rows_aligned(v, a.ldv, d, sizeof(T)), km);
   __syncthreads();
   // scores: consecutive threads take consecutive keys of one query
   for (int e = threadIdx.x; e < Nq * Nk; e += ANT) {
@@ -140,8 +146,9 @@ __global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
   const T* g = reinterpret_cast<const T*>(a.d_o) + (long long)b * Nq * a.ldo + h * d;
   const T* P = reinterpret_cast<const T*>(a.p) + (long long)z * Nq * a.ldp;
   stage_rows<T>(Qs, dp, q, a.ldq, Nq, d, rows_aligned(q, a.ldq, d, sizeof(T)));
-  stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)));
-  stage_rows<T>(Vs, dp, v, a.ldv, Nk, d, rows_aligned(v, a.ldv, d, sizeof(T)));
+  const float* km = a.kmask != nullptr ? a.kmask + (long long)b * Nk : nullptr;
+  stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)), km);
+  stage_rows<T>(Vs, dp, v, a.ldv, Nk, d, rows_aligned(v, a.ldv, d, sizeof(T)), km);
   stage_rows<T>(Gs, dp, g, a.ldo, Nq, d, rows_aligned(g, a.ldo, d, sizeof(T)));
   for (int e = threadIdx.x; e < Nq * Nk; e += ANT) {
     const int i = e / Nk, j = e - i * Nk;
@@ -177,8 +184,9 @@ __global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
       fma4(ak, dS[i * sp + j], *reinterpret_cast<const float4*>(Qs + i * dp + c));
       fma4(av, Pf[i * sp + j], *reinterpret_cast<const float4*>(Gs + i * dp + c));
     }
-    store4t<T>(dK + (long long)j * a.lddk + c, ak, a.scale);
-    store4t<T>(dV + (long long)j * a.lddv + c, av, 1.0f);
+    const float mj = km != nullptr ? km[j] : 1.0f;         // d(k mask) / dk = mask
+    store4t<T>(dK + (long long)j * a.lddk + c, ak, a.scale * mj);
+    store4t<T>(dV + (long long)j * a.lddv + c, av, mj);
   }
   T* dQ = reinterpret_cast<T*>(a.dq) + (long long)b * Nq * a.lddq + h * d;
   for (int e = threadIdx.x; e < Nq * d4; e += ANT) {
@@ -209,7 +217,7 @@ extern "C" int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype) {
 
 extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                                        int64_t ldo, void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal,
-                                       const int32_t* causal_b, int dtype, void* stream) {
+                                       const int32_t* causal_b, const float* kv_mask, int dtype, void* stream) {
   if (check_common("jen1_attn_small_forward", B, H, Nq, Nk, d, dtype)) return 1;
   JEN1_CHECK(q && k && v && o && p, "jen1_attn_small_forward: NULL argument");
   JEN1_CHECK(ldp >= Nk, "jen1_attn_small_forward: ldp must be >= Nk");
@@ -219,6 +227,7 @@ extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.causal = causal ? 1 : 0; a.scale = scale;
   a.causal_b = reinterpret_cast<const int*>(causal_b);
+  a.kmask = kv_mask;
   const size_t lds = fwd_lds(Nq, Nk, d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == JEN1_F32) {
@@ -234,8 +243,8 @@ extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k
 
 extern "C" int jen1_attn_small_backward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* p,
                                         int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk,
-                                        void* dv, int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, int dtype,
-                                        void* stream) {
+                                        void* dv, int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, const float* kv_mask,
+                                        int dtype, void* stream) {
   if (check_common("jen1_attn_small_backward", B, H, Nq, Nk, d, dtype)) return 1;
   JEN1_CHECK(q && k && v && p && d_o && dq && dk && dv, "jen1_attn_small_backward: NULL argument");
   JEN1_CHECK(ldp >= Nk, "jen1_attn_small_backward: ldp must be >= Nk");
@@ -244,6 +253,7 @@ extern "C" int jen1_attn_small_backward(const void* q, int64_t ldq, const void* 
   a.q = q; a.k = k; a.v = v; a.p = const_cast<void*>(p); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
+  a.kmask = kv_mask;
   const size_t lds = bwd_lds(Nq, Nk, d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == JEN1_F32) {

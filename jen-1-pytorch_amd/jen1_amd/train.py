@@ -910,7 +910,7 @@ def _rows_view(t: torch.Tensor) -> Tuple[int, int]:
 
 class AttentionCoreFn(Function):
     @staticmethod
-    def forward(ctx, q, kv, rt: TrainRuntime, heads: int, causal: bool):
+    def forward(ctx, q, kv, rt: TrainRuntime, heads: int, causal: bool, kv_mask=None):
         """kv: [B, Nk, 2 C] = to_kv's output (K | V): the gradient comes back as ONE tensor (two column windows written by the data-gradient
         GEMMs) instead of two slice gradients that autograd pads with zeros and adds"""
         mid = kv.shape[-1] // 2
@@ -933,11 +933,15 @@ class AttentionCoreFn(Function):
         if rows is not None and not ctx.small:
             raise L.Jen1HipError(f"a pass that mixes causal and non-causal clips needs the one-launch attention core "
                                  f"(Nq = {Nq}, Nk = {Nk}, d = {d} do not fit one workgroup)")
+        assert kv_mask is None or ctx.small, "kv_mask rides on the one-launch attention core only (attention() multiplies otherwise)"
+        ctx.kv_mask = None if kv_mask is None else kv_mask.to(torch.float32).contiguous()
         if ctx.small:
             assert rows is None or rows.flags.shape[0] == B
+            assert ctx.kv_mask is None or ctx.kv_mask.shape == (B, Nk)
             L.check(rt.lib.jen1_attn_small_forward(qp, ldq, kp, ldk, vp, ldv, O.data_ptr(), C, P.data_ptr(), ldS, B, heads, Nq, Nk, d,
                                                    float(scale), 1 if (rows is None and causal) else 0,
-                                                   None if rows is None else rows.flags.data_ptr(), dt, rt.stream()),
+                                                   None if rows is None else rows.flags.data_ptr(),
+                                                   None if ctx.kv_mask is None else ctx.kv_mask.data_ptr(), dt, rt.stream()),
                     "jen1_attn_small_forward")
             ctx.save_for_backward(q, kv, P)
             return O
@@ -974,8 +978,9 @@ class AttentionCoreFn(Function):
         if ctx.small:
             L.check(rt.lib.jen1_attn_small_backward(qp, ldq, kp, ldk, vp, ldv, P.data_ptr(), ldS, dO.data_ptr(), C, dQ.data_ptr(), C,
                                                     dKV.data_ptr(), 2 * C, dKV.data_ptr() + C * esz, 2 * C, B, heads, Nq, Nk, d,
-                                                    float(scale), dt, rt.stream()), "jen1_attn_small_backward")
-            return dQ, dKV, None, None, None
+                                                    float(scale), None if ctx.kv_mask is None else ctx.kv_mask.data_ptr(), dt, rt.stream()),
+                    "jen1_attn_small_backward")
+            return dQ, dKV, None, None, None, None
         dP = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
         dS = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
         o_do = lambda ld_r, ld_k: _operand(dO.data_ptr(), ld_r, ld_k, zs0=Nq * C, zs1=d, zdiv=heads)
@@ -991,11 +996,18 @@ class AttentionCoreFn(Function):
                 dKV.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads, alpha=scale)
         rt.gemm(_operand(P.data_ptr(), 1, ldS, zs0=Nq * ldS), o_do(1, C),
                 dKV.data_ptr() + C * esz, Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads)
-        return dQ, dKV, None, None, None
+        return dQ, dKV, None, None, None, None
 
 
-def attention_core(rt, q, kv, heads: int, causal: bool):
-    return AttentionCoreFn.apply(q, kv.contiguous(), rt, heads, causal)
+def attention_core(rt, q, kv, heads: int, causal, kv_mask=None):
+    """``kv_mask`` [B, Nk]: multiplied into the rows of K and V (blocks.py:431-434) -- inside the one-launch kernels when the shape
+    fits them, else as a tensor product before the GEMM path"""
+    if kv_mask is not None:
+        B, Nq, C = q.shape
+        if not (rt.small_attn and rt.lib.jen1_attn_small_fits(Nq, kv.shape[1], C // heads, rt.dt_of(q))):
+            kv = kv * kv_mask.to(kv.dtype)[:, :, None]
+            kv_mask = None
+    return AttentionCoreFn.apply(q, kv.contiguous(), rt, heads, causal, kv_mask)
 
 
 # =====================================================================================================================
@@ -1138,9 +1150,8 @@ class TrainGraph:
         q = linear(rt, xn, p[f"{n}.to_q.weight"])
         kv = linear(rt, cn, p[f"{n}.to_kv.weight"])
         mid = kv.shape[-1] // 2
-        if context_mask is not None:
-            kv = kv * context_mask.to(kv.dtype)[:, :, None]          # the padding mask multiplies K and V (one launch for both halves)
-        o = attention_core(rt, q, kv, heads, causal)
+        # the padding mask multiplies K and V (blocks.py:431-434): inside the attention kernels when the shape fits them
+        o = attention_core(rt, q, kv, heads, causal, context_mask)
         return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"], residual=residual)
 
     def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool) -> torch.Tensor:

@@ -247,6 +247,10 @@ def test_attention_core_forward_backward(rts, mode, B, Nq, Nk, C, heads, causal,
         return t.reshape(B, n, heads, d).transpose(1, 2)
 
     k, v = kv[..., :C], kv[..., C:]
+    # the padding mask of the context multiplies K and V (blocks.py:431-434); given for the non-causal (cross-attention) cases
+    kv_mask = None if causal else (torch.rand((B, Nk), generator=gen) > 0.3).float()
+    if kv_mask is not None:
+        k, v = k * kv_mask[:, :, None], v * kv_mask[:, :, None]
     sim = torch.einsum("bhnd,bhmd->bhnm", split(q, Nq), split(k, Nk)) * d ** -0.5
     if causal:
         keep = ~torch.ones((Nq, Nk), dtype=torch.bool).triu(Nk - Nq + 1)
@@ -257,7 +261,7 @@ def test_attention_core_forward_backward(rts, mode, B, Nq, Nk, C, heads, causal,
     qd = q.detach().to("cuda", rt.tdtype).requires_grad_()
     kvd = kv.detach().to("cuda", rt.tdtype).requires_grad_()
     # K | V travel as ONE tensor (to_kv's output); ``strided``: as it is / as the product of an elementwise op (the padding mask)
-    o = TR.attention_core(rt, qd, kvd if strided else kvd * 1.0, heads, causal)
+    o = TR.attention_core(rt, qd, kvd if strided else kvd * 1.0, heads, causal, None if kv_mask is None else kv_mask.cuda())
     o.backward(do.to("cuda", rt.tdtype))
     torch.cuda.synchronize()
     tol = _tol(mode)
