@@ -187,7 +187,9 @@ typedef struct jen1_repack_entry {
   void* dst;
   int32_t d0, d1, d2, ld;
   int64_t s0, s1, s2;
-  int32_t tile0, reserved;
+  int32_t tile0, ld2;
+  void* dst2;              /* NULL, or a second copy written from the same read: dst2[i0][i2][i1] with rows ld2 apart (the
+                              data-gradient transpose [k][C_in][C_out] of the same weight) */
 } jen1_repack_entry;
 int jen1_repack(const jen1_repack_entry* entries_dev, int n, int total_tiles, int dtype, void* stream);
 

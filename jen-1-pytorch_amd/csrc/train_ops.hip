@@ -1152,6 +1152,25 @@ __global__ __launch_bounds__(256) void repack_kernel(const jen1_repack_entry* __
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   T* dst = reinterpret_cast<T*>(e.dst);
   const float* src = e.src + (long long)i0 * e.s0;
+  if (e.dst2 != nullptr) {
+    // both compute copies of a weight from ONE read of the parameter: dst [i0][i1][i2] and dst2 [i0][i2][i1] (the data-gradient
+    // transpose).  The tile is read along whichever inner axis is closer to contiguous in the source and written once each way.
+    T* dst2 = reinterpret_cast<T*>(e.dst2);
+    const bool along2 = e.s2 <= e.s1;
+    for (int k = ty; k < 32; k += 8) {
+      const int i1 = along2 ? r1 + k : r1 + tx, i2 = along2 ? c2 + tx : c2 + k;
+      const float v = (i1 < e.d1 && i2 < e.d2) ? src[(long long)i1 * e.s1 + (long long)i2 * e.s2] : 0.f;
+      if (along2) tile[k][tx] = v; else tile[tx][k] = v;           // tile[i1 - r1][i2 - c2]
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      int i1 = r1 + k, i2 = c2 + tx;                                // dst: lanes along i2
+      if (i1 < e.d1 && i2 < e.d2) dst[((long long)i0 * e.d1 + i1) * e.ld + i2] = (T)tile[k][tx];
+      i1 = r1 + tx; i2 = c2 + k;                                    // dst2: lanes along i1
+      if (i1 < e.d1 && i2 < e.d2) dst2[((long long)i0 * e.d2 + i2) * e.ld2 + i1] = (T)tile[tx][k];
+    }
+    return;
+  }
   if (e.s2 <= e.s1) {
     for (int k = ty; k < 32; k += 8) {
       const int i1 = r1 + k, i2 = c2 + tx;

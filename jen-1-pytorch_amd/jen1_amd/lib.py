@@ -96,7 +96,7 @@ class GemmArgs(C.Structure):
 class RepackEntry(C.Structure):
     """mirror of ``jen1_repack_entry`` (include/jen1_train.h)."""
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("d0", c_int), ("d1", c_int), ("d2", c_int), ("ld", c_int),
-                ("s0", c_int64), ("s1", c_int64), ("s2", c_int64), ("tile0", c_int), ("reserved", c_int)]
+                ("s0", c_int64), ("s1", c_int64), ("s2", c_int64), ("tile0", c_int), ("ld2", c_int), ("dst2", c_void_p)]
 
 
 # every symbol include/jen1_hip.h and include/jen1_train.h declare: (name, restype, argtypes)

@@ -79,6 +79,7 @@ class TrainRuntime:
         self.blas_linears = os.environ.get("JEN1_TRAIN_BLAS_LINEARS", "1") == "1"
         self.skinny_gemm = os.environ.get("JEN1_TRAIN_SKINNY", "1") == "1"
         self.fused_repack = os.environ.get("JEN1_TRAIN_FUSED_REPACK", "1") == "1"      # every compute copy in one launch (jen1_repack)
+        self.repack_twins = os.environ.get("JEN1_TRAIN_REPACK_TWINS", "1") == "1"      # ... a weight's two copies from one read of it
         self._repack_tab, self._repack_meta, self._repack_n = None, (0, 0), -1
         self.skinny_max_steps = int(os.environ.get("JEN1_TRAIN_SKINNY_STEPS", "64"))      # K steps per wave
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "256"))
@@ -257,15 +258,22 @@ class TrainRuntime:
                 self._repack_tab = []              # one table per destination dtype (the time MLPs keep float32 copies in bf16 mode)
                 for dt_t, dt_c in ((torch.float32, L.F32), (torch.bfloat16, L.BF16)):
                     ents, t0 = [], 0
+                    # a weight's forward copy [k][Co][Ci] and its data-gradient transpose [k][Ci][Co] come from ONE read (dst2)
+                    twins = {(id(w), hit[3][:-1]): hit for hit, w in live if hit[1].dtype == dt_t and hit[3].endswith("D")} if self.repack_twins else {}
+                    fwd = {(id(w), hit[3]) for hit, w in live if hit[1].dtype == dt_t and not hit[3].endswith("D")}
                     for hit, w in live:
-                        if hit[1].dtype != dt_t:
-                            continue
+                        if hit[1].dtype != dt_t or (hit[3].endswith("D") and twins and (id(w), hit[3][:-1]) in fwd):
+                            continue                   # (a transpose whose forward copy is in this table rides on that entry)
                         d = self._layout(w, hit[3])
                         assert w.dtype == torch.float32
                         e = L.RepackEntry()
                         e.src, e.dst = d.data_ptr(), hit[1].data_ptr()
                         e.d0, e.d1, e.d2, e.ld = d.shape[0], d.shape[1], d.shape[2], hit[1].shape[2]
                         e.s0, e.s1, e.s2 = d.stride(0), d.stride(1), d.stride(2)
+                        twin = twins.get((id(w), hit[3]))
+                        if twin is not None and twin[0]() is w:
+                            assert twin[1].shape[0] == d.shape[0] and twin[1].shape[1] == d.shape[2] and twin[1].shape[2] >= d.shape[1]
+                            e.dst2, e.ld2 = twin[1].data_ptr(), twin[1].shape[2]
                         e.tile0 = t0
                         t0 += d.shape[0] * ((d.shape[1] + 31) // 32) * ((d.shape[2] + 31) // 32)
                         ents.append(e)
