@@ -341,6 +341,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_vec_kernel(const GnDev g, void* 
 // (scratch reset, per-channel sums, finish, dx) 125 times per pass.  A group is L x cpg elements (at most 48 000 on the bench shape):
 // one workgroup reads it twice (the second read is an L2 hit) and needs no scratch, no atomics on the statistics and no second launch.
 // Thread layout: vector column v = tid % VPG (8 channels), rows tid / VPG, tid / VPG + NT / VPG, ...  (VPG = cpg / 8, a power of two).
+constexpr int GU = 4;        // rows per thread whose loads are in flight together
 __device__ __forceinline__ float block_sum(float v, float* red) {       // all threads get the sum; fixed order
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __syncthreads();
@@ -358,12 +359,20 @@ __global__ __launch_bounds__(NT) void gn_fwd_fused_kernel(const GnDev g, float* 
   const int c0 = grp * g.cpg + v * 8;
   const T* x = reinterpret_cast<const T*>(g.x) + (long long)b * g.L * g.C + c0;
   T* y = reinterpret_cast<T*>(g.y) + (long long)b * g.L * g.C + c0;
+  // (rows in batches of GU: all of a batch's loads are issued before the first is used -- a long group is 12 .. 24 dependent memory
+  // round trips otherwise, 32 / 63 us forward / backward for the 1500-position levels)
   float s = 0.f, ss = 0.f;
-  for (int t = r0; t < g.L; t += RT) {
-    float w[8];
-    load8(x + (long long)t * g.C, w);
+  for (int t = r0; t < g.L; t += GU * RT) {
+    float w[GU][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s += w[j]; ss += w[j] * w[j]; }
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) load8(x + (long long)(t + u * RT) * g.C, w[u]);
+#pragma unroll
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s += w[u][j]; ss += w[u][j] * w[u][j]; }
+      }
   }
   s = block_sum(s, red);
   ss = block_sum(ss, red);
@@ -384,15 +393,21 @@ __global__ __launch_bounds__(NT) void gn_fwd_fused_kernel(const GnDev g, float* 
     if (film != nullptr) { A *= sc[j] + 1.0f; S = S * (sc[j] + 1.0f) + sh[j]; }
     ga[j] = A; be[j] = S;
   }
-  for (int t = r0; t < g.L; t += RT) {
-    float w[8];
-    load8(x + (long long)t * g.C, w);
+  for (int t = r0; t < g.L; t += GU * RT) {
+    float w[GU][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float n = w[j] * ga[j] + be[j];
-      w[j] = (g.flags & 1) ? silu_precise(n) : n;
-    }
-    store8(y + (long long)t * g.C, w);
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) load8(x + (long long)(t + u * RT) * g.C, w[u]);
+#pragma unroll
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float n = w[u][j] * ga[j] + be[j];
+          w[u][j] = (g.flags & 1) ? silu_precise(n) : n;
+        }
+        store8(y + (long long)(t + u * RT) * g.C, w[u]);
+      }
   }
 }
 
@@ -426,19 +441,27 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const GnDev g, void* d
   float p[8][4];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { p[j][0] = p[j][1] = p[j][2] = p[j][3] = 0.f; }
-  for (int t = r0; t < g.L; t += RT) {
-    float w[8], d[8];
-    load8(x + (long long)t * g.C, w);
-    load8(dy + (long long)t * g.C, d);
+  for (int t = r0; t < g.L; t += GU * RT) {
+    float w[GU][8], d[GU][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xh = (w[j] - mean) * rstd;
-      const float n = xh * ga[j] + be[j];
-      float df = d[j];
-      if (g.flags & 1) df *= silu_grad(n * s1[j] + s0[j]);
-      const float dn = df * s1[j];
-      p[j][0] += dn; p[j][1] += dn * xh; p[j][2] += df * n; p[j][3] += df;
-    }
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) {
+        load8(x + (long long)(t + u * RT) * g.C, w[u]);
+        load8(dy + (long long)(t + u * RT) * g.C, d[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (w[u][j] - mean) * rstd;
+          const float n = xh * ga[j] + be[j];
+          float df = d[u][j];
+          if (g.flags & 1) df *= silu_grad(n * s1[j] + s0[j]);
+          const float dn = df * s1[j];
+          p[j][0] += dn; p[j][1] += dn * xh; p[j][2] += df * n; p[j][3] += df;
+        }
+      }
   }
   float* part = lds + (size_t)threadIdx.x * 32;
 #pragma unroll
@@ -467,24 +490,28 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const GnDev g, void* d
   }
   m1 = block_sum(m1, red) * g.inv_count;
   m2 = block_sum(m2, red) * g.inv_count;
-  for (int t = r0; t < g.L; t += RT) {
-    float w[8], d[8];
-    load8(x + (long long)t * g.C, w);
-    load8(dy + (long long)t * g.C, d);
+  for (int t = r0; t < g.L; t += GU * RT) {
+    float w[GU][8], d[GU][8], ad[GU][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xh = (w[j] - mean) * rstd;
-      float df = d[j];
-      if (g.flags & 1) df *= silu_grad((xh * ga[j] + be[j]) * s1[j] + s0[j]);
-      w[j] = rstd * (df * s1[j] * ga[j] - m1 - xh * m2);
-    }
-    if (g.dx_add != nullptr) {
-      float ad[8];
-      load8(reinterpret_cast<const T*>(g.dx_add) + base + (long long)t * g.C, ad);
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) {
+        load8(x + (long long)(t + u * RT) * g.C, w[u]);
+        load8(dy + (long long)(t + u * RT) * g.C, d[u]);
+        if (g.dx_add != nullptr) load8(reinterpret_cast<const T*>(g.dx_add) + base + (long long)(t + u * RT) * g.C, ad[u]);
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] += ad[j];
-    }
-    store8(dx + (long long)t * g.C, w);
+    for (int u = 0; u < GU; ++u)
+      if (t + u * RT < g.L) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (w[u][j] - mean) * rstd;
+          float df = d[u][j];
+          if (g.flags & 1) df *= silu_grad((xh * ga[j] + be[j]) * s1[j] + s0[j]);
+          w[u][j] = rstd * (df * s1[j] * ga[j] - m1 - xh * m2);
+          if (g.dx_add != nullptr) w[u][j] += ad[u][j];
+        }
+        store8(dx + (long long)(t + u * RT) * g.C, w[u]);
+      }
   }
 }
 
