@@ -342,17 +342,26 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_vec_kernel(const GnDev g, void* 
 // one workgroup reads it twice (the second read is an L2 hit) and needs no scratch, no atomics on the statistics and no second launch.
 // Thread layout: vector column v = tid % VPG (8 channels), rows tid / VPG, tid / VPG + NT / VPG, ...  (VPG = cpg / 8, a power of two).
 constexpr int GU = 4;        // rows per thread whose loads are in flight together
-__device__ __forceinline__ float block_sum(float v, float* red) {       // all threads get the sum; fixed order
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {       // all threads of the NW waves get the sum; fixed order
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w += 4) t += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+  return t;
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_fwd_fused_kernel(const GnDev g, float* __restrict__ sums_out, int lvpg) {
-  __shared__ float red[4];
+// NTB threads per workgroup: 256, or 1024 for the long groups (the 1500- and 375-position levels: 12 000 .. 48 000 elements).  There
+// are only B x groups = 128 workgroups; with 4 waves each half of the chip's SIMDs had no wave at all and the others one, and the
+// per-element arithmetic (SiLU and its derivative: exp, reciprocal) of 94 .. 188 elements per thread ran at one wave's issue rate:
+// 30 / 58 us forward / backward for 6 - 12 MB.
+template <typename T, int NTB>
+__global__ __launch_bounds__(NTB) void gn_fwd_fused_kernel(const GnDev g, float* __restrict__ sums_out, int lvpg) {
+  constexpr int NT = NTB;                    // (shadows the file's 256)
+  __shared__ float red[NTB / 64];
   const int b = blockIdx.x / g.groups, grp = blockIdx.x - b * g.groups;
   const int VPG = 1 << lvpg;
   const int v = threadIdx.x & (VPG - 1), r0 = threadIdx.x >> lvpg, RT = NT >> lvpg;
@@ -374,8 +383,8 @@ __global__ __launch_bounds__(NT) void gn_fwd_fused_kernel(const GnDev g, float* 
         for (int j = 0; j < 8; ++j) { s += w[u][j]; ss += w[u][j] * w[u][j]; }
       }
   }
-  s = block_sum(s, red);
-  ss = block_sum(ss, red);
+  s = block_sum<NTB / 64>(s, red);
+  ss = block_sum<NTB / 64>(ss, red);
   if (threadIdx.x == 0) { sums_out[2 * (long long)blockIdx.x] = s; sums_out[2 * (long long)blockIdx.x + 1] = ss; }
   const float mean = s * g.inv_count;
   const float rstd = 1.0f / sqrtf(fmaxf(ss * g.inv_count - mean * mean, 0.f) + g.eps);
@@ -411,9 +420,11 @@ __global__ __launch_bounds__(NT) void gn_fwd_fused_kernel(const GnDev g, float* 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const GnDev g, void* dx_, int lvpg) {
-  extern __shared__ float lds[];                       // [NT][32] per-thread partials | [cpg][4] | [4]
+template <typename T, int NTB>
+__global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* dx_, int lvpg) {
+  constexpr int NT = NTB;                    // (shadows the file's 256)
+  constexpr int GU = NTB > 256 ? 1 : 4;      // (1024 threads leave 128 registers per lane; their occupancy hides the round trips)
+  extern __shared__ float lds[];                       // [NT][32] per-thread partials | [cpg][4] | [NT / 64]
   const int b = blockIdx.x / g.groups, grp = blockIdx.x - b * g.groups;
   const int VPG = 1 << lvpg;
   const int v = threadIdx.x & (VPG - 1), r0 = threadIdx.x >> lvpg, RT = NT >> lvpg;
@@ -488,8 +499,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const GnDev g, void* d
     atomicAdd(g.dgamma + c, P.y);                      // (the other batch elements add to the same entry)
     atomicAdd(g.dbeta + c, P.x);
   }
-  m1 = block_sum(m1, red) * g.inv_count;
-  m2 = block_sum(m2, red) * g.inv_count;
+  m1 = block_sum<NTB / 64>(m1, red) * g.inv_count;
+  m2 = block_sum<NTB / 64>(m2, red) * g.inv_count;
   for (int t = r0; t < g.L; t += GU * RT) {
     float w[GU][8], d[GU][8], ad[GU][8];
 #pragma unroll
@@ -946,6 +957,9 @@ extern "C" int jen1_gn_sums(const void* x, float* sums, int B, int L, int C, int
 namespace {
 // the one-launch form: vector-aligned rows, a power-of-two number of 8-channel vectors per group, enough (batch element, group) pairs
 // to fill the chip reasonably and a group small enough for one workgroup
+constexpr long long GN_LONG_GROUP = 12000;       // elements per (batch element, group) from which the 1024-thread form runs
+constexpr size_t lds_cap = 160 * 1024;
+
 bool gn_fused_ok(const void* x, const void* y, const void* dy, const float* gamma, const float* beta, const void* film, int film_ld, int B, int L,
                  int C, int ld, int groups, int& lvpg) {
   const int cpg = C / groups;
@@ -973,7 +987,14 @@ extern "C" int jen1_gn_forward(const void* x, float* sums, const float* gamma, c
   }
   g.y = y;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  DISPATCH(dtype, gn_fwd_fused_kernel, dim3(B * groups), g, sums, lvpg);
+  if ((long long)L * (C / groups) >= GN_LONG_GROUP) {
+    if (dtype == JEN1_F32) hipLaunchKernelGGL((gn_fwd_fused_kernel<float, 1024>), dim3(B * groups), dim3(1024), 0, s, g, sums, lvpg);
+    else hipLaunchKernelGGL((gn_fwd_fused_kernel<bf16_t, 1024>), dim3(B * groups), dim3(1024), 0, s, g, sums, lvpg);
+  } else {
+    if (dtype == JEN1_F32) hipLaunchKernelGGL((gn_fwd_fused_kernel<float, 256>), dim3(B * groups), dim3(256), 0, s, g, sums, lvpg);
+    else hipLaunchKernelGGL((gn_fwd_fused_kernel<bf16_t, 256>), dim3(B * groups), dim3(256), 0, s, g, sums, lvpg);
+  }
+  JEN1_HIP(hipGetLastError());
   return 0;
 }
 
@@ -1017,9 +1038,20 @@ extern "C" int jen1_gn_backward_add(const void* dy, const void* x, const float* 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int lvpg = 0;
   if (gn_fused_ok(x, dx, dy, gamma, beta, film, film_ld, B, L, C, ld, groups, lvpg)) {
-    const size_t lds = ((size_t)NT * 32 + (size_t)(C / groups) * 4 + 4) * sizeof(float);
-    if (dtype == JEN1_F32) hipLaunchKernelGGL(gn_bwd_fused_kernel<float>, dim3(B * groups), dim3(NT), lds, s, g, dx, lvpg);
-    else hipLaunchKernelGGL(gn_bwd_fused_kernel<bf16_t>, dim3(B * groups), dim3(NT), lds, s, g, dx, lvpg);
+    if ((long long)L * (C / groups) >= GN_LONG_GROUP) {
+      const size_t lds = ((size_t)1024 * 32 + (size_t)(C / groups) * 4 + 16) * sizeof(float);
+      if (dtype == JEN1_F32) {
+        JEN1_MAX_LDS_ONCE((gn_bwd_fused_kernel<float, 1024>), (int)lds_cap);
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<float, 1024>), dim3(B * groups), dim3(1024), lds, s, g, dx, lvpg);
+      } else {
+        JEN1_MAX_LDS_ONCE((gn_bwd_fused_kernel<bf16_t, 1024>), (int)lds_cap);
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<bf16_t, 1024>), dim3(B * groups), dim3(1024), lds, s, g, dx, lvpg);
+      }
+    } else {
+      const size_t lds = ((size_t)256 * 32 + (size_t)(C / groups) * 4 + 4) * sizeof(float);
+      if (dtype == JEN1_F32) hipLaunchKernelGGL((gn_bwd_fused_kernel<float, 256>), dim3(B * groups), dim3(256), lds, s, g, dx, lvpg);
+      else hipLaunchKernelGGL((gn_bwd_fused_kernel<bf16_t, 256>), dim3(B * groups), dim3(256), lds, s, g, dx, lvpg);
+    }
     JEN1_HIP(hipGetLastError());
     return 0;
   }
