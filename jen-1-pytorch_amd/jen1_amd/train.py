@@ -146,6 +146,17 @@ class TrainRuntime:
             self._wforked = True
         return self._wstream if self._wforked else None
 
+    def abandon_weight_grads(self) -> None:
+        """called when a new forward pass starts: anything still queued belongs to a backward pass that raised before its final
+        callback ran (the callback is registered once per pass, so stale state would keep the next pass from registering its own)"""
+        if self._wjoin or self._wqueue or self._wheld:
+            if self._wforked and self._wstream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._wstream)
+            self._wqueue.clear()
+            self._wjoin.clear()
+            self._wheld.clear()
+            self._wforked = False
+
     def join_weight_grads(self) -> None:
         if not self._wjoin:
             return
@@ -1247,6 +1258,7 @@ class TrainGraph:
         """Same contract as the reference forward (model.py:299-376), differentiable."""
         assert features is None, "context_features is unused on the JEN-1 path"
         rt, p, sp = self.rt, self.p, self.spec
+        self.rt.abandon_weight_grads()
         # a bool, or one flag per clip (tensor [B]): a pass that holds causal and non-causal clips side by side (CausalRows)
         rows = CausalRows(causal) if torch.is_tensor(causal) else None
         causal = rows if rows is not None else bool(causal)
