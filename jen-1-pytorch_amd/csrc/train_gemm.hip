@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 32, NT = 256;
+#ifndef JEN1_LEAN_PF
+#define JEN1_LEAN_PF 4          // K steps of loads in flight per wave in the lean register-direct kernel (bf16); measured at 24 000 rows: 4 -> 22.4 us (4 waves per SIMD), 6 -> 23.5 (3), 8 -> 27.9 (2)
+#endif
 
 struct Operand {
   const void* p;
@@ -253,11 +256,11 @@ __device__ __forceinline__ void dmma(f32x4& acc, const f32x8& a, const f32x8& b)
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
 
-template <typename T>
+template <typename T, int PFX = 0>
 __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, const T* bbase, int m0, int n0, int wm, int wn, int lane,
                                             int s_begin, int s_end, int ksteps, f32x4 (&acc)[2][2]) {
   typedef typename DFrag<T>::type Frag;
-  constexpr int PF = DFrag<T>::PF;
+  constexpr int PF = PFX > 0 ? PFX : DFrag<T>::PF;
   constexpr unsigned ES = sizeof(T);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(abase), 0, 0x7fffffff, D_RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(bbase), 0, 0x7fffffff, D_RSRC_FLAGS);
@@ -419,7 +422,10 @@ __device__ __forceinline__ void wgrad_loop(const GemmDev& g, const bf16_t* abase
 }
 
 // one workgroup of the 64 x 64 form: (bx, by, bz) = its position in the grid jen1_train_gemm would launch
-template <typename T>
+// LEAN: only the register-direct K loop is compiled in (the caller guarantees g.direct and no float32 read-modify-write epilogue):
+// the full body holds the staging registers of every path at once (224 VGPRs: 2 waves per SIMD), the lean one fits 4 waves per SIMD,
+// which is what the many-row forward / data-gradient products of the long levels need to hide their K walk's round trips.
+template <typename T, bool LEAN = false>
 __device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int bz, T* As, T* Bs) {
   constexpr int PITCH = BK + 16 / (int)sizeof(T);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -465,7 +471,7 @@ __device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int 
   // gradient launch before this.
   char* cb = reinterpret_cast<char*>(g.c);
   const long long coff = (long long)(z / g.c_zdiv) * g.c_zs0 + (long long)(z % g.c_zdiv) * g.c_zs1 + (long long)tap_z * g.c_tap_stride;
-  const bool rmw32 = g.c_f32 && !g.atomic && g.accumulate;
+  const bool rmw32 = !LEAN && g.c_f32 && !g.atomic && g.accumulate;
   float cold[2][2][4];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -482,8 +488,9 @@ __device__ __forceinline__ void gemm_body(const GemmDev& g, int bx, int by, int 
 
   bool fastw = false;
   if constexpr (sizeof(T) == 2) fastw = g.fastw != 0;
-  if (g.direct) {
-    direct_loop<T>(g, abase, bbase, m0, n0, wm, wn, lane, s_begin, s_end, ksteps, acc);
+  if (LEAN || g.direct) {
+    direct_loop<T, (LEAN && sizeof(T) == 2) ? JEN1_LEAN_PF : 0>(g, abase, bbase, m0, n0, wm, wn, lane, s_begin, s_end, ksteps, acc);
+  } else if constexpr (LEAN) {
   } else if (fastw) {
     if constexpr (sizeof(T) == 2) wgrad_loop(g, abase, bbase, m0, n0, wm, wn, tap_z, s_begin, s_end, do_rowsum, rsum, As, acc);
   } else {
@@ -682,6 +689,12 @@ __global__ __launch_bounds__(NT) void train_gemm_kernel(const GemmDev g) {
   gemm_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z, tiles, tiles + BM * PITCH);
 }
 
+template <typename T>
+__global__ __launch_bounds__(NT) void train_gemm_direct_kernel(const GemmDev g) {
+  jen1_prefetch_kernarg<sizeof(GemmDev)>();
+  gemm_body<T, true>(g, blockIdx.x, blockIdx.y, blockIdx.z, nullptr, nullptr);
+}
+
 template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void train_gemm_skinny_kernel(const GemmDev g) {
   __shared__ __attribute__((aligned(16))) SkinnyRed red[NW - 1];
@@ -831,6 +844,9 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
     if (f32) { if (nw == 16) JEN1_SKINNY(float, 16); else if (nw == 8) JEN1_SKINNY(float, 8); else JEN1_SKINNY(float, 4); }
     else { if (nw == 16) JEN1_SKINNY(bf16_t, 16); else if (nw == 8) JEN1_SKINNY(bf16_t, 8); else JEN1_SKINNY(bf16_t, 4); }
 #undef JEN1_SKINNY
+  } else if (g.direct && !(g.c_f32 && g.accumulate && !g.atomic) && g.rowsum == nullptr) {
+    if (f32) hipLaunchKernelGGL(train_gemm_direct_kernel<float>, grid, dim3(NT), 0, s, g);
+    else hipLaunchKernelGGL(train_gemm_direct_kernel<bf16_t>, grid, dim3(NT), 0, s, g);
   } else {
     if (f32) hipLaunchKernelGGL(train_gemm_kernel<float>, grid, dim3(NT), 0, s, g);
     else hipLaunchKernelGGL(train_gemm_kernel<bf16_t>, grid, dim3(NT), 0, s, g);

@@ -547,7 +547,11 @@ class ConvFn(Function):
             ldy = dy.shape[-1]
             L.check(rt.lib.jen1_colsum(dy.data_ptr(), gb.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()), "jen1_colsum")
 
-        if ctx.needs_input_grad[0] and rt.pair_grads:
+        # (many-row layers: both products fill the chip, a pair would last their sum; the data gradient runs as the lean register-direct
+        # kernel instead and the weight gradient goes to the queue)
+        rows = (x.numel() // x.shape[-1])
+        many_rows = ((rows + 63) // 64) * ((g.ci + 63) // 64) >= rt.target_wgs
+        if ctx.needs_input_grad[0] and rt.pair_grads and not many_rows:
             # both gradients of the layer in one launch: they share dY and nothing orders them
             fused, blk = _conv_wgrad(rt, x, dy, gw, g, gb, defer=True)
             dx = _conv_dgrad(rt, dy, ctx.wp, g, ctx.wd, pair_with=blk, residual=dskip).view(x.shape)
