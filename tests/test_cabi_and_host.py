@@ -388,3 +388,18 @@ def test_torch_library_ops_are_registered_with_schemas_and_fake_impls():
     with pytest.raises((Jen1HipError, RuntimeError)):
         model(torch.zeros((B, model.spec.in_channels, T)), torch.zeros((B,), dtype=torch.int64),
               embedding=torch.zeros((B, model.spec.ctx_max_length, model.spec.ctx_features)), channels_list=[torch.zeros((B, model.spec.ctx_ch0, T))])
+
+
+def test_causal_rows_pads_follow_conv1d_padding():
+    """train.CausalRows: the per-clip index-map shifts of a pass that mixes causal and non-causal clips restate _Conv1d's padding
+    (blocks.py:45-50: k - 1 on the left when causal, else (k - 1) // 2), one entry longer than the batch; ``twice`` stacks the
+    batch on itself for the CFG pair (model.py:349-353)"""
+    import torch
+    from jen1_amd.train import CausalRows
+    rows = CausalRows(torch.tensor([0, 1, 1, 0], dtype=torch.bool))
+    for k, nc, c in ((3, 1, 2), (5, 2, 4), (9, 4, 8)):
+        neg, pos = rows.pads(k)
+        assert pos.dtype == torch.int32 and neg.dtype == torch.int32
+        assert pos.tolist() == [nc, c, c, nc, nc] and neg.tolist() == [-nc, -c, -c, -nc, -nc]
+        assert rows.pads(k)[0] is neg          # cached per kernel size
+    assert rows.twice().flags.tolist() == [0, 1, 1, 0, 0, 1, 1, 0]

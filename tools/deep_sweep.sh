@@ -2,7 +2,7 @@
 # usage: bash tools/deep_sweep.sh "<-D flags A>" "<-D flags B>" ...   (an entry starting with ENV: sets environment variables instead)
 cd $GRAFT_REPO_ROOT
 CS=jen-1-pytorch_amd/csrc
-SRC="$CS/conv_gemm.hip $CS/stream_gemm.hip $CS/tile_gemm.hip $CS/norm_apply.hip $CS/attention.hip $CS/deep_kernel.hip $CS/elementwise.hip $CS/optimizer.hip $CS/train_gemm.hip $CS/train_ops.hip $CS/encodec.hip"
+SRC="$CS/conv_gemm.hip $CS/stream_gemm.hip $CS/tile_gemm.hip $CS/norm_apply.hip $CS/attention.hip $CS/deep_kernel.hip $CS/elementwise.hip $CS/optimizer.hip $CS/train_gemm.hip $CS/train_ops.hip $CS/train_attn.hip $CS/encodec.hip"
 i=0
 for v in "$@"; do
   i=$((i+1))
