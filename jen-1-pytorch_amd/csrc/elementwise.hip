@@ -20,8 +20,8 @@ int jen1_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* jen1_last_error(void) { return g_jen1_err; }
-extern "C" const char* jen1_build_info(void) { return "libjen1_hip gfx950 (CDNA4) hipcc; abi 1"; }
-extern "C" int jen1_abi_version(void) { return 1; }
+extern "C" const char* jen1_build_info(void) { return "libjen1_hip gfx950 (CDNA4) hipcc; abi 2"; }
+extern "C" int jen1_abi_version(void) { return 2; }    // 2: jen1_gemm_args.map_shift_b, jen1_repack_entry.dst2 (round 3)
 
 // A kernel, not hipMemsetAsync: memset nodes interleaved with kernel nodes in a captured graph were observed to
 // run out of order on ROCm 7.2 (training step), a kernel node never is.

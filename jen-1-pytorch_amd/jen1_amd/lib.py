@@ -13,6 +13,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
+ABI_VERSION = 2          # layout of the structs mirrored below (GemmArgs, RepackEntry, ...): bumped together with jen1_abi_version()
 LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # JEN1_LIB: tuning builds only
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
@@ -222,7 +223,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # raises AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.jen1_abi_version() != 1:
+    if lib.jen1_abi_version() != ABI_VERSION:
         raise Jen1HipError("libjen1_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_build_info_and_tile_table(lib):
-    assert lib.jen1_abi_version() == 1
+    assert lib.jen1_abi_version() == 2
     assert b"gfx950" in lib.jen1_build_info()
     assert [(lib.jen1_cfg_bm(c), lib.jen1_cfg_bn(c)) for c in range(5)] == [(64, 64), (128, 64), (16, 64), (16, 32), (16, 16)]
     assert lib.jen1_cfg_bm(99) == -1
