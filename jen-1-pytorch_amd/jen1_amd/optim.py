@@ -235,7 +235,7 @@ class GradExchange:
         self._expect[region] = self._expect.get(region, 0) + 1
 
     def region_ready(self, region: str, also: Optional["torch.cuda.Stream"] = None) -> None:
-        """``also``: a second stream gradients of the region were enqueued on (train.TrainRuntime.weight_grad_stream)"""
+        """``also``: a second stream gradients of the region were enqueued on (train.TrainRuntime.weight_grad: the queue of weight-gradient launches)"""
         if not self.active or region not in self.regions or region in self._sent:
             return
         left = self._expect.get(region, 1) - 1
