@@ -15,6 +15,12 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 32, NT = 256;
+#ifndef JEN1_SKINNY_PF8
+#define JEN1_SKINNY_PF8 8
+#endif
+#ifndef JEN1_SKINNY_NW96
+#define JEN1_SKINNY_NW96 16     // waves per workgroup for K walks of 64 steps or more
+#endif
 #ifndef JEN1_LEAN_PF
 #define JEN1_LEAN_PF 4          // K steps of loads in flight per wave in the lean register-direct kernel (bf16); measured at 24 000 rows: 4 -> 22.4 us (4 waves per SIMD), 6 -> 23.5 (3), 8 -> 27.9 (2)
 #endif
@@ -280,20 +286,34 @@ __device__ __forceinline__ void direct_loop(const GemmDev& g, const T* abase, co
     b_off[i] = n < g.N ? (unsigned)((long long)n * g.b.ld_r) * ES : D_OOB;
   }
   Frag fa[PF][2], fb[PF][2];
+  // The byte offsets of this lane's rows are functions of the TAP only: they are computed when the walk enters a tap (one division
+  // per kernel, the 64-bit products and the index map once per tap) and a step adds its k.  Recomputed per step they were the
+  // kernel: ~100 vector instructions with quarter-rate 64-bit multiplies per step and lane, on 4 waves per SIMD.
   int s_next = s_begin;
-  auto issue = [&](Frag (&xa)[2], Frag (&xb)[2]) {
-    const int s = s_next++;
-    const int tap = s / ksteps, k = (s - tap * ksteps) * BK + kq;
-    const bool live = s < s_end && k < g.K;
-    const unsigned tb = (unsigned)((long long)tap * g.b.tap_stride + k) * ES;
+  int cur_tap = s_begin / ksteps;
+  int kidx = s_begin - cur_tap * ksteps;
+  unsigned a_base[2], b_base[2];
+  auto enter_tap = [&](int tap) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       long long row = a_row[i];
       if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap, a_s[i]);
-      const bool ok = live && a_ok[i] && row >= 0;
-      dload(xa[i], ra, ok ? (unsigned)((long long)tap * g.a.tap_stride + row * g.a.ld_r + k) * ES : D_OOB);
-      dload(xb[i], rb, (live && b_off[i] != D_OOB) ? b_off[i] + tb : D_OOB);
+      a_base[i] = (a_ok[i] && row >= 0) ? (unsigned)(((long long)tap * g.a.tap_stride + row * g.a.ld_r) * ES) : D_OOB;
+      b_base[i] = b_off[i] != D_OOB ? b_off[i] + (unsigned)((long long)tap * g.b.tap_stride * ES) : D_OOB;
     }
+  };
+  enter_tap(cur_tap);
+  auto issue = [&](Frag (&xa)[2], Frag (&xb)[2]) {
+    const int k = kidx * BK + kq;
+    const bool live = s_next < s_end && k < g.K;
+    const unsigned kb = (unsigned)k * ES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dload(xa[i], ra, (live && a_base[i] != D_OOB) ? a_base[i] + kb : D_OOB);
+      dload(xb[i], rb, (live && b_base[i] != D_OOB) ? b_base[i] + kb : D_OOB);
+    }
+    ++s_next;
+    if (++kidx >= ksteps) { kidx = 0; enter_tap(++cur_tap); }
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) issue(fa[u], fb[u]);
@@ -582,7 +602,7 @@ constexpr int SKINNY_RED_BYTES = 3 * (int)sizeof(SkinnyRed);
 template <typename T, int NW = 4>
 __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, int bz, SkinnyRed* red) {
   typedef typename DFrag<T>::type Frag;
-  constexpr int PF = (NW == 16 && sizeof(T) == 2) ? 6 : SkinnyPF<T>::PF;      // (16 waves leave 128 registers per lane)
+  constexpr int PF = (NW == 16 && sizeof(T) == 2) ? 6 : (NW == 8 && sizeof(T) == 2) ? JEN1_SKINNY_PF8 : SkinnyPF<T>::PF;      // (16 waves leave 128 registers per lane)
   constexpr unsigned ES = sizeof(T);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = bx * 32, n0 = by * 16;
@@ -615,21 +635,34 @@ __device__ __forceinline__ void skinny_body(const GemmDev& g, int bx, int by, in
   if (g.bias != nullptr && wave == 0 && split == 0) bias_v = nb < g.N ? g.bias[nb] : 0.f;
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   Frag fa[PF][2], fb[PF];
+  // (row offsets per tap, k added per step: see direct_loop)
   int s_next = s_begin + wave;
-  auto issue = [&](Frag (&xa)[2], Frag& xb) {
-    const int s = s_next;
-    s_next += NW;
-    const int tap = s / ksteps, k = (s - tap * ksteps) * BK + kq;
-    const bool live = s < s_end && k < g.K;
-    const unsigned tb = (unsigned)((long long)tap * g.b.tap_stride + k) * ES;
+  int cur_tap = s_next / ksteps;
+  int kidx = s_next - cur_tap * ksteps;
+  unsigned a_base[2], b_base;
+  auto enter_tap = [&](int tap) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       long long row = a_row[i];
       if (g.a.map_axis == 1) row = map_from_bt(g.a, a_b[i], a_t[i], tap, a_s[i]);
-      const bool ok = live && a_ok[i] && row >= 0;
-      dload(xa[i], ra, ok ? (unsigned)((long long)tap * g.a.tap_stride + row * g.a.ld_r + k) * ES : D_OOB);
+      a_base[i] = (a_ok[i] && row >= 0) ? (unsigned)(((long long)tap * g.a.tap_stride + row * g.a.ld_r) * ES) : D_OOB;
     }
-    dload(xb, rb, (live && b_off != D_OOB) ? b_off + tb : D_OOB);
+    b_base = b_off != D_OOB ? b_off + (unsigned)((long long)tap * g.b.tap_stride * ES) : D_OOB;
+  };
+  enter_tap(cur_tap);
+  auto issue = [&](Frag (&xa)[2], Frag& xb) {
+    const int k = kidx * BK + kq;
+    const bool live = s_next < s_end && k < g.K;
+    const unsigned kb = (unsigned)k * ES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dload(xa[i], ra, (live && a_base[i] != D_OOB) ? a_base[i] + kb : D_OOB);
+    dload(xb, rb, (live && b_base != D_OOB) ? b_base + kb : D_OOB);
+    s_next += NW;
+    kidx += NW;
+    if (kidx >= ksteps) {
+      do { kidx -= ksteps; ++cur_tap; } while (kidx >= ksteps);
+      enter_tap(cur_tap);
+    }
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) issue(fa[u], fb[u]);
@@ -839,7 +872,7 @@ extern "C" int jen1_train_gemm(const jen1_gemm_args* args, void* stream) {
     // waves per workgroup by the length of the K walk: a wave keeps 8 (bf16) / 3 (float32) steps of loads in flight, and a tile with
     // 96 steps (3 taps x 1024 channels) on 4 waves is three memory round trips in a row where 16 waves make it one
     const int steps = ((args->K + BK - 1) / BK) * args->taps / args->splitk;
-    const int nw = steps >= 64 ? 16 : steps >= 48 ? 8 : 4;      // (32 steps on 8 waves measured slower than on 4: 7.1 vs 5.6 us)
+    const int nw = steps >= 64 ? JEN1_SKINNY_NW96 : steps >= 48 ? 8 : 4;      // (32 steps on 8 waves measured slower than on 4: 7.1 vs 5.6 us)
 #define JEN1_SKINNY(TT, NWV) hipLaunchKernelGGL((train_gemm_skinny_kernel<TT, NWV>), grid, dim3(NWV * 64), 0, s, g)
     if (f32) { if (nw == 16) JEN1_SKINNY(float, 16); else if (nw == 8) JEN1_SKINNY(float, 8); else JEN1_SKINNY(float, 4); }
     else { if (nw == 16) JEN1_SKINNY(bf16_t, 16); else if (nw == 8) JEN1_SKINNY(bf16_t, 8); else JEN1_SKINNY(bf16_t, 4); }
