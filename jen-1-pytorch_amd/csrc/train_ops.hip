@@ -16,6 +16,24 @@ __device__ __forceinline__ float silu_grad(float f) {
   const float s = 1.0f / (1.0f + expf(-f));
   return s * (1.0f + f * (1.0f - s));
 }
+// bf16 mode of the one-launch GroupNorm kernels: v_exp_f32 / v_rcp_f32 (1 ulp each, against 8 mantissa bits of the tensors) instead of
+// expf and an IEEE division -- on the long levels these kernels are bound by their vector arithmetic (128 workgroups = half of the
+// chip's CUs, ~80 instructions per element and pass before), not by memory.  float32 mode keeps the exact forms (parity runs).
+template <typename T>
+__device__ __forceinline__ float sigmoid_t(float x) {
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+  else return 1.0f / (1.0f + expf(-x));
+}
+template <typename T>
+__device__ __forceinline__ float silu_t(float x) {
+  if constexpr (sizeof(T) == 2) return x * sigmoid_t<T>(x);
+  else return silu_precise(x);
+}
+template <typename T>
+__device__ __forceinline__ float silu_grad_t(float f) {
+  const float s = sigmoid_t<T>(f);
+  return s * (1.0f + f * (1.0f - s));
+}
 __device__ __forceinline__ float gelu_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
@@ -354,6 +372,22 @@ __device__ __forceinline__ float block_sum(float v, float* red) {       // all t
   return t;
 }
 
+// (batch element, group) of a workgroup of the one-launch GroupNorm kernels.  A group is cpg channels = 32 .. 64 bytes of every row; the
+// groups of one batch element share the rows' cache lines.  Workgroups go to the 8 XCDs round-robin by blockIdx, so with the plain
+// order b = bid / groups the 8 groups that share a line sat on 8 different XCDs and every L2 fetched every line for itself (the long
+// levels' 6 MB tensors cost ~120 MB of traffic, 30 us).  With B % 8 == 0 the groups of a batch element go to ONE XCD.
+__device__ __forceinline__ void gn_block(const GnDev& g, int& b, int& grp) {
+  const int bid = blockIdx.x;
+  if ((g.B & 7) == 0) {
+    const int slot = bid >> 3;
+    grp = slot % g.groups;
+    b = (slot / g.groups) * 8 + (bid & 7);
+  } else {
+    b = bid / g.groups;
+    grp = bid - b * g.groups;
+  }
+}
+
 // NTB threads per workgroup: 256, or 1024 for the long groups (the 1500- and 375-position levels: 12 000 .. 48 000 elements).  There
 // are only B x groups = 128 workgroups; with 4 waves each half of the chip's SIMDs had no wave at all and the others one, and the
 // per-element arithmetic (SiLU and its derivative: exp, reciprocal) of 94 .. 188 elements per thread ran at one wave's issue rate:
@@ -362,7 +396,9 @@ template <typename T, int NTB>
 __global__ __launch_bounds__(NTB) void gn_fwd_fused_kernel(const GnDev g, float* __restrict__ sums_out, int lvpg) {
   constexpr int NT = NTB;                    // (shadows the file's 256)
   __shared__ float red[NTB / 64];
-  const int b = blockIdx.x / g.groups, grp = blockIdx.x - b * g.groups;
+  int b, grp;
+  gn_block(g, b, grp);
+  const long long bg = (long long)b * g.groups + grp;
   const int VPG = 1 << lvpg;
   const int v = threadIdx.x & (VPG - 1), r0 = threadIdx.x >> lvpg, RT = NT >> lvpg;
   const int c0 = grp * g.cpg + v * 8;
@@ -385,7 +421,7 @@ __global__ __launch_bounds__(NTB) void gn_fwd_fused_kernel(const GnDev g, float*
   }
   s = block_sum<NTB / 64>(s, red);
   ss = block_sum<NTB / 64>(ss, red);
-  if (threadIdx.x == 0) { sums_out[2 * (long long)blockIdx.x] = s; sums_out[2 * (long long)blockIdx.x + 1] = ss; }
+  if (threadIdx.x == 0) { sums_out[2 * bg] = s; sums_out[2 * bg + 1] = ss; }
   const float mean = s * g.inv_count;
   const float rstd = 1.0f / sqrtf(fmaxf(ss * g.inv_count - mean * mean, 0.f) + g.eps);
   float ga[8], be[8], sc[8], sh[8];
@@ -413,7 +449,7 @@ __global__ __launch_bounds__(NTB) void gn_fwd_fused_kernel(const GnDev g, float*
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float n = w[u][j] * ga[j] + be[j];
-          w[u][j] = (g.flags & 1) ? silu_precise(n) : n;
+          w[u][j] = (g.flags & 1) ? silu_t<T>(n) : n;
         }
         store8(y + (long long)(t + u * RT) * g.C, w[u]);
       }
@@ -424,8 +460,10 @@ template <typename T, int NTB>
 __global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* dx_, int lvpg) {
   constexpr int NT = NTB;                    // (shadows the file's 256)
   constexpr int GU = NTB > 256 ? 1 : 4;      // (1024 threads leave 128 registers per lane; their occupancy hides the round trips)
-  extern __shared__ float lds[];                       // [NT][32] per-thread partials | [cpg][4] | [NT / 64]
-  const int b = blockIdx.x / g.groups, grp = blockIdx.x - b * g.groups;
+  extern __shared__ float lds[];                       // [NT][32] per-thread partials | [cpg][4] | [NT / 64] | [NT] chunk sums
+  int b, grp;
+  gn_block(g, b, grp);
+  const long long bg = (long long)b * g.groups + grp;
   const int VPG = 1 << lvpg;
   const int v = threadIdx.x & (VPG - 1), r0 = threadIdx.x >> lvpg, RT = NT >> lvpg;
   const int c0 = grp * g.cpg + v * 8;
@@ -433,7 +471,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* 
   const T* x = reinterpret_cast<const T*>(g.x) + base;
   const T* dy = reinterpret_cast<const T*>(g.dy) + base;
   T* dx = reinterpret_cast<T*>(dx_) + base;
-  const float* sm = g.sums + 2 * (long long)blockIdx.x;
+  const float* sm = g.sums + 2 * bg;
   const float mean = sm[0] * g.inv_count;
   const float rstd = 1.0f / sqrtf(fmaxf(sm[1] * g.inv_count - mean * mean, 0.f) + g.eps);
   float ga[8], be[8], s1[8], s0[8];
@@ -468,7 +506,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* 
           const float xh = (w[u][j] - mean) * rstd;
           const float n = xh * ga[j] + be[j];
           float df = d[u][j];
-          if (g.flags & 1) df *= silu_grad(n * s1[j] + s0[j]);
+          if (g.flags & 1) df *= silu_grad_t<T>(n * s1[j] + s0[j]);
           const float dn = df * s1[j];
           p[j][0] += dn; p[j][1] += dn * xh; p[j][2] += df * n; p[j][3] += df;
         }
@@ -480,12 +518,34 @@ __global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* 
   __syncthreads();
   float* Pl = lds + (size_t)NT * 32;                   // [cpg][4]
   float* red = Pl + (size_t)g.cpg * 4;
+  float* scr = red + NT / 64;                          // [NT / O][O] partial sums of row chunks
   const int rows_active = g.L < RT ? g.L : RT;
-  for (int o = threadIdx.x; o < g.cpg * 4; o += NT) {
-    const int c = o >> 2, k = o & 3, vv = c >> 3, j = c & 7;
-    float a = 0.f;
-    for (int r = 0; r < rows_active; ++r) a += lds[(size_t)((r << lvpg) + vv) * 32 + 4 * j + k];      // fixed order
-    Pl[o] = a;
+  const int O = g.cpg * 4;
+  if (2 * O <= NT) {
+    // every thread sums a chunk of the rows for one output, then O threads add the chunks: with one thread per output walking all
+    // rows (128 .. 512 dependent LDS reads) this reduction WAS the kernel for the long groups (fixed order either way)
+    const int chunks = NT / O, per = (rows_active + chunks - 1) / chunks;
+    const int o = threadIdx.x % O, ch = threadIdx.x / O;
+    if (ch < chunks) {
+      const int c = o >> 2, k = o & 3, vv = c >> 3, j = c & 7;
+      const int r1 = min(rows_active, (ch + 1) * per);
+      float a = 0.f;
+      for (int r = ch * per; r < r1; ++r) a += lds[(size_t)((r << lvpg) + vv) * 32 + 4 * j + k];
+      scr[ch * O + o] = a;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < O) {
+      float a = 0.f;
+      for (int c2 = 0; c2 < chunks; ++c2) a += scr[c2 * O + threadIdx.x];
+      Pl[threadIdx.x] = a;
+    }
+  } else {
+    for (int o = threadIdx.x; o < O; o += NT) {
+      const int c = o >> 2, k = o & 3, vv = c >> 3, j = c & 7;
+      float a = 0.f;
+      for (int r = 0; r < rows_active; ++r) a += lds[(size_t)((r << lvpg) + vv) * 32 + 4 * j + k];      // fixed order
+      Pl[o] = a;
+    }
   }
   __syncthreads();
   float m1 = 0.f, m2 = 0.f;
@@ -517,7 +577,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* 
         for (int j = 0; j < 8; ++j) {
           const float xh = (w[u][j] - mean) * rstd;
           float df = d[u][j];
-          if (g.flags & 1) df *= silu_grad((xh * ga[j] + be[j]) * s1[j] + s0[j]);
+          if (g.flags & 1) df *= silu_grad_t<T>((xh * ga[j] + be[j]) * s1[j] + s0[j]);
           w[u][j] = rstd * (df * s1[j] * ga[j] - m1 - xh * m2);
           if (g.dx_add != nullptr) w[u][j] += ad[u][j];
         }
@@ -1039,7 +1099,7 @@ extern "C" int jen1_gn_backward_add(const void* dy, const void* x, const float* 
   int lvpg = 0;
   if (gn_fused_ok(x, dx, dy, gamma, beta, film, film_ld, B, L, C, ld, groups, lvpg)) {
     if ((long long)L * (C / groups) >= GN_LONG_GROUP) {
-      const size_t lds = ((size_t)1024 * 32 + (size_t)(C / groups) * 4 + 16) * sizeof(float);
+      const size_t lds = ((size_t)1024 * 32 + (size_t)(C / groups) * 4 + 16 + 1024) * sizeof(float);
       if (dtype == JEN1_F32) {
         JEN1_MAX_LDS_ONCE((gn_bwd_fused_kernel<float, 1024>), (int)lds_cap);
         hipLaunchKernelGGL((gn_bwd_fused_kernel<float, 1024>), dim3(B * groups), dim3(1024), lds, s, g, dx, lvpg);
@@ -1048,7 +1108,7 @@ extern "C" int jen1_gn_backward_add(const void* dy, const void* x, const float* 
         hipLaunchKernelGGL((gn_bwd_fused_kernel<bf16_t, 1024>), dim3(B * groups), dim3(1024), lds, s, g, dx, lvpg);
       }
     } else {
-      const size_t lds = ((size_t)256 * 32 + (size_t)(C / groups) * 4 + 4) * sizeof(float);
+      const size_t lds = ((size_t)256 * 32 + (size_t)(C / groups) * 4 + 4 + 256) * sizeof(float);
       if (dtype == JEN1_F32) hipLaunchKernelGGL((gn_bwd_fused_kernel<float, 256>), dim3(B * groups), dim3(256), lds, s, g, dx, lvpg);
       else hipLaunchKernelGGL((gn_bwd_fused_kernel<bf16_t, 256>), dim3(B * groups), dim3(256), lds, s, g, dx, lvpg);
     }
