@@ -653,6 +653,22 @@ def test_training_overfits_one_batch():
 
 
 def _ddp_worker(rank, world, port, q):
+    try:
+        _ddp_worker_body(rank, world, port, q)
+    except BaseException:                      # (the parent would otherwise wait out its queue timeout without a message)
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ddp_worker_body(rank, world, port, q):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -728,11 +744,13 @@ def test_data_parallel_step_two_ranks_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + (os.getpid() % 200)
+    port = _free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for r in res.values():
+        assert "error" not in r, r["error"]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
