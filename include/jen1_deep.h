@@ -265,7 +265,7 @@ int jen1_deep_error_word(int n_phases);
  * to workgroups by ticket from sync[0]; the launch makes progress with ANY number of resident workgroups, so persistent launches that
  * share the GPU (other streams, other processes) cannot deadlock each other.  tickets = 0: the static unit -> workgroup map, ~9 %
  * faster (889 against 971 us per launch at B = 8, T = 1500), correct only while all nwg workgroups are resident together: for a caller
- * that runs at most ONE such launch per device at a time.  Either way a dependency wait that exceeds its bound (~40 ms) raises the
+ * that runs at most ONE such launch per device at a time.  Either way a dependency wait that exceeds its bound (~170 ms) raises the
  * error word instead of hanging. */
 int jen1_deep_run_mode(const void* blobs_dev, const void* headers_dev, int n_phases, uint32_t* sync, uint32_t* err, int nwg, int lds_bytes,
                        int dtype, int tickets, void* stream);

