@@ -403,3 +403,19 @@ def test_causal_rows_pads_follow_conv1d_padding():
         assert pos.tolist() == [nc, c, c, nc, nc] and neg.tolist() == [-nc, -c, -c, -nc, -nc]
         assert rows.pads(k)[0] is neg          # cached per kernel size
     assert rows.twice().flags.tolist() == [0, 1, 1, 0, 0, 1, 1, 0]
+
+
+def test_ctypes_mirrors_have_the_size_of_the_c_structs(tmp_path):
+    """lib.GemmArgs / GemmOperand / RepackEntry against sizeof() of the structs in include/jen1_train.h as gcc lays them out (the
+    mirrors are filled field by field on the host and read by the kernels' launchers)"""
+    import ctypes
+    import subprocess
+    from jen1_amd import lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stdint.h>\n#include "jen1_hip.h"\n#include "jen1_train.h"\n'
+                   'int main(void) { printf("%zu %zu %zu\\n", sizeof(jen1_gemm_operand), sizeof(jen1_gemm_args), sizeof(jen1_repack_entry)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", f"-I{os.path.join(root, 'include')}", str(src), "-o", str(exe)], check=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(L.GemmOperand), ctypes.sizeof(L.GemmArgs), ctypes.sizeof(L.RepackEntry)]
