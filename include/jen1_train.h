@@ -114,7 +114,8 @@ int jen1_ln_forward(const void* x, const float* gamma, const float* beta, void* 
 int jen1_ln_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* dgamma,
                      float* dbeta, int rows, int C, int ld, int dtype, void* stream);
 /* the same with dx_add (x's dtype, rows ld apart, may be NULL): dx = the LayerNorm gradient + dx_add (the residual branch of a
- * transformer sub-block, blocks.py:486-488) */
+ * transformer sub-block, blocks.py:486-488).  dx may be NULL when the input needs no gradient (norm_context over the text
+ * embedding, blocks.py:426): only dgamma / dbeta are accumulated. */
 int jen1_ln_backward_add(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, const void* dx_add,
                          float* dgamma, float* dbeta, int rows, int C, int ld, int dtype, void* stream);
 

@@ -742,6 +742,7 @@ __global__ __launch_bounds__(NTB) void ln_bwd_kernel(const void* dy_, const void
       ag[n] += d * xh[n];
       ab[n] += d;
     }
+    if (dx_ == nullptr) continue;
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     s1 /= C; s2 /= C;
     T* xo = dx + (long long)row * ld;
@@ -819,6 +820,7 @@ __global__ __launch_bounds__(NTB) void ln_bwd_vec_kernel(const void* dy_, const 
         }
       }
     }
+    if (dx_ == nullptr) continue;            // (the input needs no gradient -- the text context: only the column sums are wanted)
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     s1 *= inv_C; s2 *= inv_C;
     T* xo = dx + (long long)row * ld;
@@ -1152,7 +1154,8 @@ extern "C" int jen1_ln_backward(const void* dy, const void* x, const float* stat
 extern "C" int jen1_ln_backward_add(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, const void* dx_add,
                                     float* dgamma, float* dbeta, int rows, int C, int ld, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_ln_backward")) return 1;
-  JEN1_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta, "jen1_ln_backward: NULL argument");
+  JEN1_CHECK(dy && x && stats && gamma && dgamma && dbeta, "jen1_ln_backward: NULL argument");
+  JEN1_CHECK(dx != nullptr || dx_add == nullptr, "jen1_ln_backward_add: dx_add without dx");
   JEN1_CHECK(rows >= 1 && C >= 1 && ld >= C && C <= 64 * LN_MAXPL, "jen1_ln_backward: bad shape rows=%d C=%d ld=%d", rows, C, ld);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // many rows (the text context: 2B x 129): 8 waves per block meet in LDS, so 32 blocks x 2 C atomics finish the column sums

@@ -847,8 +847,10 @@ class LayerNormFn(Function):
             assert dskip.shape == x.shape and dskip.dtype == x.dtype
         ld = x.shape[-1]
         rows = x.numel() // ld
-        dx = (torch.zeros_like if ld != C else torch.empty_like)(x)
-        L.check(rt.lib.jen1_ln_backward_add(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), ctx.gamma.data_ptr(), dx.data_ptr(),
+        # (norm_context over the text embedding: the input needs no gradient, the kernel then only sums the columns)
+        dx = (torch.zeros_like if ld != C else torch.empty_like)(x) if (ctx.needs_input_grad[0] or dskip is not None) else None
+        L.check(rt.lib.jen1_ln_backward_add(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), ctx.gamma.data_ptr(),
+                                            None if dx is None else dx.data_ptr(),
                                             None if dskip is None else dskip.data_ptr(),
                                             rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(), rows, C, ld, rt.dt_of(x),
                                             rt.stream()), "jen1_ln_backward_add")

@@ -1063,3 +1063,28 @@ def test_forked_layers_merge_the_gradient_of_the_branch_around_them(rts, mode, o
     assert torch.equal(y1, y0)
     tol = 1e-6 if mode == "f32" else 2e-2
     assert float((g1 - g0).abs().max()) <= tol * float(g0.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("rows,C", [(2080, 1024), (48, 512), (7, 64)])
+def test_layer_norm_backward_without_input_gradient(rts, mode, rows, C):
+    """norm_context over the text embedding (blocks.py:426): the input needs no gradient, jen1_ln_backward_add runs with dx = NULL and
+    only accumulates dgamma / dbeta -- the same values as when dx is computed too"""
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator(device="cuda").manual_seed(rows + C)
+    x0 = torch.randn(rows, C, device="cuda", generator=gen).to(rt.tdtype)
+    w = torch.randn(rows, C, device="cuda", generator=gen).to(rt.tdtype)
+    gamma = torch.nn.Parameter(torch.rand(C, device="cuda", generator=gen) + 0.5)
+    beta = torch.nn.Parameter(torch.randn(C, device="cuda", generator=gen))
+    got = {}
+    for needs in (True, False):
+        gamma.grad, beta.grad = None, None
+        x = x0.clone().requires_grad_(needs)
+        (TR.layer_norm(rt, x, gamma, beta) * w).float().sum().backward()
+        torch.cuda.synchronize()
+        got[needs] = (gamma.grad.clone(), beta.grad.clone())
+        assert (x.grad is not None) == needs
+    for a, b in zip(got[True], got[False]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
