@@ -565,7 +565,8 @@ def test_full_model_training_gradients_vs_reference_autograd_f32():
     print(f"full model: worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
 
 
-def test_configs3_micro_batch_merged_passes_vs_reference_autograd_f32():
+@pytest.mark.parametrize("mode,tol_loss,tol_norm,tol_samp", [("f32", 1e-3, 1e-3, 5e-3), ("bf16", 2e-2, 3e-2, 1.0)])
+def test_configs3_micro_batch_merged_passes_vs_reference_autograd(mode, tol_loss, tol_norm, tol_samp):
     """BASELINE configs[3] at its per-GPU shape: the full model, 8 clips as the 3 / 3 / 2 task sub-batches (text_guided,
     music_inpaint, music_cont with their masks) of one micro-batch.  The reference runs one pass per task and sums the three
     mean losses (trainer.py:183-213); the trainer here merges the sub-batches that share the causal flag into one pass with
@@ -578,14 +579,14 @@ def test_configs3_micro_batch_merged_passes_vs_reference_autograd_f32():
     from jen1_amd.trainer import UnifiedMultiTaskTrainer
     g = golden("full_train8")
     names = json.loads(str(g["grad_names_all"]))
-    model = UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
+    model = UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype=mode, device="cuda")
     model.train()
     betas, _ = get_beta_schedule("linear", 1000)
     gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
                            cfg_dropout_proba=0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
     opt = FusedAdamW(model.parameters(), lr=0.0, max_norm=None)
     tr = UnifiedMultiTaskTrainer.build(model, gd, None, opt, None, grad_accum_every=1, use_graph=False, allow_uneven_tasks=True,
-                                       merge_tasks=True, compute_dtype="f32")
+                                       merge_tasks=True, compute_dtype=mode)
     parts, noises = [], {}
     for task, x0, t, cond, noise, causal in synth.train8_inputs():
         parts.append((task, dev(x0), torch.from_numpy(t).cuda(), {k: (None if v is None else dev(v)) for k, v in cond.items()}, causal))
@@ -596,8 +597,8 @@ def test_configs3_micro_batch_merged_passes_vs_reference_autograd_f32():
     torch.cuda.synchronize()
     for task in per_task:
         ref = float(g[f"loss.{task}"])
-        assert abs(float(per_task[task]) - ref) <= 1e-3 * abs(ref), (task, float(per_task[task]), ref)
-    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+        assert abs(float(per_task[task]) - ref) <= tol_loss * abs(ref), (task, float(per_task[task]), ref)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= tol_loss * abs(float(g["loss"]))
     grads = {n: p.grad for n, p in model.named_parameters()}
     assert sorted(names) == sorted(grads.keys()) and len(names) == 979
     ref_norm, ref_samp = g["gradnorm_all"], g["gradsample_all"]
@@ -613,10 +614,10 @@ def test_configs3_micro_batch_merged_passes_vs_reference_autograd_f32():
         scale = max(float(np.abs(ref).max()), ref_norm[i] / np.sqrt(gr.numel()))
         es = float(np.abs(samp - ref).max() / max(scale, 1e-12))
         worst_n, worst_s = max(worst_n, en), max(worst_s, es)
-        assert en <= 1e-3, (n, nrm, ref_norm[i])
-        assert es <= 5e-3, (n, es)
+        assert en <= tol_norm, (n, nrm, ref_norm[i])
+        assert es <= tol_samp, (n, es)
     assert off == ref_samp.size
-    print(f"configs[3] micro-batch (3/3/2 merged): worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
+    print(f"configs[3] micro-batch (3/3/2, one pass, {mode}): worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
 
 
 def test_training_overfits_one_batch():
