@@ -85,7 +85,10 @@ class TrainRuntime:
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "256"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
         # weight gradients on their own stream (weight_grad below)
-        self.wgrad_group = int(os.environ.get("JEN1_TRAIN_WGRAD_GROUP", "64"))         # layers per fork; 0: on the pass's own stream
+        # layers per fork; 0 (default): on the pass's own stream.  The fork was worth 1 ms while every weight gradient went through it; since
+        # a layer's two gradients share a launch only the FiLM / many-row / library-GEMM ones are left, and the branch costs the replayed
+        # graph more than it hides (14.63 ms with groups of 64, 14.23 ms inline)
+        self.wgrad_group = int(os.environ.get("JEN1_TRAIN_WGRAD_GROUP", "0"))
         self._wstream: Optional[torch.cuda.Stream] = None
         self._wqueue: list = []
         self._wheld: list = []
