@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- denoiser steps/sec of the JEN-1 hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,8 +11,11 @@ BASELINE.json configs[1]: full JEN-1 1D-UNet (296.5 M parameters, random init), 
 Encodec latents 128x1500, 100-step DDIM schedule, bf16 storage / fp32 accumulate.  With N>1 every
 rank runs its own B=8 batch (independent samples, no data-path collective): weak scaling.
 
-Inside the timed region: the time-embedding / FiLM tables were computed once for the whole schedule
-and the DDIM noise is eta=0 (none); CFG dropout is off (sampling).  Nothing else is hoisted.
+Inside the timed region: every launch of the step.  Computed once per sampling run, outside it: the text
+K/V projection and the time-embedding / FiLM / time-token K/V tables of the whole schedule; the DDIM
+noise (eta = 1, the reference's default) is a table drawn before the region and read inside it; CFG
+dropout is off (sampling).  ``extra.end_to_end`` times whole ``sample()`` calls including all of that.
+The timed region of --steps steps is repeated (>= 3 regions) and the median region is the headline.
 
 The JSON line also carries
   roofline      -- the dominant kernel of the step, ``deep_kernel`` (the persistent launch that
@@ -52,8 +55,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each (0: as many as make >= 600 steps, at least 3)")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--length", type=int, default=1500)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
@@ -87,19 +91,25 @@ def build_stepper(model, B, T, device, cfg_pair, use_graph, plan_slot=0):
     return st
 
 
-def timed_steps(st, steps, warmup, barrier):
+def timed_steps(st, steps, warmup, barrier, repeats=1):
+    """``warmup`` untimed steps, then ``repeats`` timed regions of EXACTLY ``steps`` steps, each bracketed by barrier +
+    synchronize on both sides.  Returns the list of region durations (seconds)."""
     for i in range(warmup):
         st.step(i % st.num_steps)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        st.step((warmup + i) % st.num_steps)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    return t1 - t0
+    out = []
+    k = warmup
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            st.step((k + i) % st.num_steps)
+        torch.cuda.synchronize()
+        barrier()
+        out.append(time.perf_counter() - t0)
+        k += steps
+    return out if repeats > 1 else out[0]
 
 
 def end_to_end_bench(model, st, B, T, device):
@@ -639,17 +649,30 @@ def main():
     B, T = args.batch, args.length
     model = UNetCFG1d(**cfg, init_seed=1234, compute_dtype=args.dtype, device=device)
     st = build_stepper(model, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
-    dt = timed_steps(st, args.steps, args.warmup, barrier)
-    dt, value = aggregate(dist, dt, args.steps, world, device)
+    # the timed region is EXACTLY --steps steps; it is repeated (>= 3 regions, >= 600 steps in total) and the MEDIAN region is the
+    # headline, so one clock hiccup of a 26 ms region cannot move it; every region's ms/step is in the line ("regions")
+    reps = args.repeats if args.repeats > 0 else max(3, -(-600 // max(1, args.steps)))
+    dts = timed_steps(st, args.steps, args.warmup, barrier, repeats=reps)
+    per_region = []
+    for d in dts:
+        d_, _ = aggregate(dist, d, args.steps, world, device)
+        per_region.append(d_)
+    dt = float(np.median(per_region))
+    value = world * args.steps / dt
 
     out = {
         "metric": "denoiser steps/sec (B=8, 128x1500 latents)", "value": round(value, 2), "unit": "denoiser steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[1] full JEN-1 1D-UNet (296.5M params)")
-                   + f", B={B} per GPU, latents 128x{T}, 100-step DDIM schedule (eta=0), no CFG (CFG dropout off: sampling), "
-                     "hipGraph-replayed step; the time-embedding / FiLM tables of the schedule are computed once outside the timed region",
+                   + f", B={B} per GPU, latents 128x{T}, 100-step DDIM schedule, eta=1 (the reference's default, gdm.py:28: every step adds "
+                     "sigma * noise; the per-step noise is a table drawn before the timed region and READ inside it), no CFG (CFG dropout off: "
+                     "sampling), hipGraph-replayed step; per sampling run and outside the timed region: the text K/V projection and the "
+                     "time-embedding / FiLM / time-token K/V tables of the schedule (extra.end_to_end times a whole sample() call with them)",
                    "global_batch": B * world, "seq_len": T, "parallelism": f"replicas x{world} (independent samples)"},
+        "regions": {"count": len(per_region), "steps_each": args.steps, "ms_per_step": [round(d / args.steps * 1e3, 4) for d in per_region],
+                    "min": round(min(per_region) / args.steps * 1e3, 4), "median": round(dt / args.steps * 1e3, 4),
+                    "max": round(max(per_region) / args.steps * 1e3, 4), "headline": "median"},
     }
     if rank == 0:
         long_levels = conv_roofline(st)
@@ -659,6 +682,13 @@ def main():
             out["roofline"]["long_levels"] = long_levels  # the fused conv-GEMM launches of the levels above the deep launch
         else:
             out["roofline"] = long_levels
+        # the whole step against the HBM roofline: SURVEY.md 8(d)'s algorithmic bytes of one denoiser step (every layer's weights once +
+        # its input and output activations once, summed over the plan's launches and phases) / the headline time per step
+        step_alg = sum(getattr(op, "w_bytes", 0) + getattr(op, "act_bytes", 0) for op in st.plan.ops)
+        step_gbs = step_alg / (dt / args.steps) / 1e9
+        out["roofline"]["whole_step"] = {"bound": "hbm", "alg_bytes_per_step": int(step_alg), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                                         "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                                         "executed_gflop_per_step": round(sum(getattr(op, "flops", 0) for op in st.plan.ops) / 1e9, 2)}
         out["launches_per_step"] = st.plan.n_launch + 1
         if not args.no_extra:
             st2 = build_stepper(model, B, T, device, cfg_pair=True, use_graph=not args.no_graph)

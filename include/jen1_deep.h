@@ -42,6 +42,20 @@
  * protocol of round 2: tools/microbench/flagchain.hip).  Weight slices are requested BEFORE
  * the dependency wait, so their HBM latency hides behind the exchange.
  *
+ * Reserved word (contract of the protocol).  The all-ones 8-byte word -- four bf16 or two
+ * float32 NaNs with the sign bit and every mantissa bit set -- means "not stored yet" and is
+ * never delivered as data.  No finite value encodes as it, and every store of the launch
+ * breaks exactly that pattern (it clears the lowest payload bit of the word's first element:
+ * still a NaN, no longer the sentinel), so NaN / Inf activations (NaN weights, overflow) flow
+ * through the program as NaNs like they do through the reference: they cannot make a
+ * consumer wait.  A consumer that still does
+ * not see its operands complete within JEN1_DEEP_POLL_LIMIT polls (~170 ms: a lost producer,
+ * a launch that is not fully resident next to a static schedule) gives up, writes 1 + phase
+ * to the error word (jen1_deep_run_err) and releases every other waiter; the results of
+ * that launch are garbage, the host raises Jen1HipError and clears the word, and the next
+ * launch is clean (tests/test_gpu_deep.py::test_nan_activations_flow_through_the_launch,
+ * ::test_time_out_is_reported_and_cleared).
+ *
  * Plain pointers and sizes only; all pointers are device pointers unless noted.
  */
 #ifndef JEN1_DEEP_H

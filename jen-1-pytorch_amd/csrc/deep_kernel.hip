@@ -30,6 +30,7 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr int NT = JEN1_DEEP_THREADS;
@@ -126,16 +127,27 @@ __device__ __forceinline__ void stage_raw(fp8_t* dst, const Raw8<bf16_t>& r) {
   raw_to_float(r, x);
   store8(dst, x);
 }
+// The all-ones 8-byte word is RESERVED (it means "not stored yet", see Sync below).  A finite result never encodes as it; four bf16
+// (two float32) NaNs with sign and every mantissa bit set would -- e.g. NaN weights whose payload propagates.  Every live store
+// therefore breaks exactly that pattern (the lowest payload bit of the word's first element is cleared: still a NaN, no longer
+// the sentinel): the consumer sees NaNs, as the reference's consumer would, and no data a producer can compute makes a consumer
+// wait (include/jen1_deep.h "Reserved word").  Three vector instructions per store.
+template <typename G>
+__device__ __forceinline__ void st_word(G* p, int i, unsigned lo, unsigned hi) {
+  lo -= ((lo & hi) == 0xffffffffu) ? 1u : 0u;
+  __hip_atomic_store(g64(p) + i, ((u64)hi << 32) | lo, RLX_AGENT);
+}
 // 4 consecutive output channels of one position, write-through
 __device__ __forceinline__ void st_live4(bf16_t* p, const float (&v)[4]) {
   bf16x4 a;
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
-  __hip_atomic_store(g64(p), __builtin_bit_cast(u64, a), RLX_AGENT);
+  const u32x2 w = __builtin_bit_cast(u32x2, a);
+  st_word(p, 0, w[0], w[1]);
 }
 __device__ __forceinline__ void st_live4(float* p, const float (&v)[4]) {
-  __hip_atomic_store(g64(p), ((u64)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), RLX_AGENT);
-  __hip_atomic_store(g64(p) + 1, ((u64)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), RLX_AGENT);
+  st_word(p, 0, __float_as_uint(v[0]), __float_as_uint(v[1]));
+  st_word(p, 1, __float_as_uint(v[2]), __float_as_uint(v[3]));
 }
 __device__ __forceinline__ void ld_live4(float (&o)[4], const bf16_t* p) {
   const u64 x = __hip_atomic_load(g64(p), RLX_AGENT);
@@ -150,16 +162,16 @@ __device__ __forceinline__ void ld_live4(float (&o)[4], const float* p) {
 }
 __device__ __forceinline__ void st_live8(bf16_t* p, const bf16_t* s) {   // 8 elements from LDS, write-through
   const u32x4 v = *reinterpret_cast<const u32x4*>(s);
-  __hip_atomic_store(g64(p), ((u64)v[1] << 32) | v[0], RLX_AGENT);
-  __hip_atomic_store(g64(p) + 1, ((u64)v[3] << 32) | v[2], RLX_AGENT);
+  st_word(p, 0, v[0], v[1]);
+  st_word(p, 1, v[2], v[3]);
 }
 __device__ __forceinline__ void st_live8(float* p, const float* s) {
   const u32x4 a = *reinterpret_cast<const u32x4*>(s);
   const u32x4 b = *reinterpret_cast<const u32x4*>(s + 4);
-  __hip_atomic_store(g64(p), ((u64)a[1] << 32) | a[0], RLX_AGENT);
-  __hip_atomic_store(g64(p) + 1, ((u64)a[3] << 32) | a[2], RLX_AGENT);
-  __hip_atomic_store(g64(p) + 2, ((u64)b[1] << 32) | b[0], RLX_AGENT);
-  __hip_atomic_store(g64(p) + 3, ((u64)b[3] << 32) | b[2], RLX_AGENT);
+  st_word(p, 0, a[0], a[1]);
+  st_word(p, 1, a[2], a[3]);
+  st_word(p, 2, b[0], b[1]);
+  st_word(p, 3, b[2], b[3]);
 }
 
 // ---- MFMA fragments ------------------------------------------------------------------------------------------------
@@ -199,7 +211,6 @@ __device__ __forceinline__ void wload(f32x8& f, __amdgpu_buffer_rsrc_t r, unsign
   }
 }
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void wload(long& f, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   f = __builtin_bit_cast(long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2));
 }
@@ -2129,7 +2140,7 @@ __device__ __forceinline__ void tile_unit(const unsigned char* D, int u, Sync& s
         q += mine ? e4[e].y : 0.f;
       }
       const size_t idx = ((size_t)b * (size_t)(tiles_t * mblocks) + (size_t)(tt * mblocks + mblk)) * (size_t)onfg + (size_t)tid;
-      __hip_atomic_store(g64(out_part) + idx, ((u64)__float_as_uint(q) << 32) | __float_as_uint(s), RLX_AGENT);
+      st_word(reinterpret_cast<float*>(out_part) + 2 * idx, 0, __float_as_uint(s), __float_as_uint(q));      // (sum, sumsq) partial: same reserved word
     }
   }
   DK_STAMP(sy, 14);

@@ -243,15 +243,23 @@ template <typename T, bool DDIM>
 __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net, const float* __restrict__ x,
                                                         const float* __restrict__ noise, const float* __restrict__ coef,
                                                         float* __restrict__ x_out, float* __restrict__ eps_out,
-                                                        float* __restrict__ x0_out, const int32_t* __restrict__ step_idx,
+                                                        float* __restrict__ x0_out, const int32_t* step_idx,
                                                         int B, int C, int Tn, int ld, int nrep,
                                                         float scale, int scale_cfg, float phi, int objective, int clip_x0,
-                                                        int32_t* __restrict__ adv_step, unsigned* __restrict__ adv_ticket) {
+                                                        int32_t* adv_step, unsigned* __restrict__ adv_ticket) {
   extern __shared__ float tile[];   // [C][33]
-  if (DDIM && step_idx) {            // per-step rows of the coefficient / noise tables
-    const int st = step_idx[0];
-    coef += (size_t)st * 8;
-    if (noise) noise += (size_t)st * B * C * Tn;
+  // step_idx and adv_step may be the SAME word (jen1_cfg_ddim_step_adv: the last block advances the counter every block reads),
+  // so neither is __restrict__, the counter is read with an atomic load that cannot be sunk behind the ticket below, and the
+  // row of coefficients is in registers before the barrier
+  float cf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (DDIM) {
+    if (step_idx) {                  // per-step rows of the coefficient / noise tables
+      const int st = __hip_atomic_load(step_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      coef += (size_t)st * 8;
+      if (noise) noise += (size_t)st * B * C * Tn;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cf[i] = coef[i];
   }
   const int t0 = blockIdx.x * 32, b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
   if (adv_ticket != nullptr && threadIdx.x == 0) {
     const unsigned nblk = gridDim.x * gridDim.y;
     if (atomicAdd(adv_ticket, 1u) == nblk - 1u) {
-      adv_step[0] += 1;
+      __hip_atomic_fetch_add(adv_step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       adv_ticket[0] = 0u;
     }
   }
@@ -329,10 +337,7 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t = t0 + tx;
   if (t >= Tn) return;
-  float sr = 0.f, srm1 = 0.f, sa_n = 0.f, cc = 0.f, sg = 0.f, last = 0.f, sa_t = 0.f, s1m_t = 0.f;
-  if (DDIM) {
-    sr = coef[0]; srm1 = coef[1]; sa_n = coef[2]; cc = coef[3]; sg = coef[4]; last = coef[5]; sa_t = coef[6]; s1m_t = coef[7];
-  }
+  const float sr = cf[0], srm1 = cf[1], sa_n = cf[2], cc = cf[3], sg = cf[4], last = cf[5], sa_t = cf[6], s1m_t = cf[7];
   for (int cb = 0; cb < C; cb += 64) {
     float xv[8], nv[8];
 #pragma unroll

@@ -210,7 +210,22 @@ class GaussianDiffusion(torch.nn.Module):
 
     def stepper(self, model, shape, conditioning, causal=False, use_graph=True, n_streams=None, plan_slot: int = 0,
                 mode: str = "ddim") -> "DDIMStepper":
-        return DDIMStepper(self, model, shape, conditioning, causal, use_graph, n_streams, plan_slot, mode)
+        """the fused stepper of (model, shape, causal, schedule), built once and kept: a later sampling run of the same shape
+        rebinds its conditioning (text K/V projection, concat context) and replays the graph captured the first time instead of
+        planning and capturing again (the reference rebuilds everything per ``generate`` call, generation.py:36-74: A-20)"""
+        cache = self.__dict__.setdefault("_steppers", {})
+        key = (id(model), id(model.engine()), tuple(shape), bool(causal), bool(use_graph), n_streams, plan_slot, mode,
+               float(self.embedding_scale), bool(self.batch_cfg), bool(self.scale_cfg), getattr(self, "sampling_timesteps", None),
+               float(getattr(self, "ddim_sampling_eta", 0.0)), bool(model.deterministic), bool(model.engine().use_tile_phases))
+        st = cache.get(key)
+        if st is not None and st.model is model and st.eng is model.engine():
+            st.rebind(conditioning)
+            return st
+        st = DDIMStepper(self, model, shape, conditioning, causal, use_graph, n_streams, plan_slot, mode)
+        if len(cache) >= 8:                        # a handful of shapes per process; drop the oldest
+            cache.pop(next(iter(cache)))
+        cache[key] = st
+        return st
 
     def _ddim_generic(self, model, shape, conditioning, return_all_timesteps, causal, init_data, init_noise, step_noises,
                       dropout_rows):
@@ -389,27 +404,66 @@ class DDIMStepper:
         self._set_step(0)                             # the cached plan may carry a previous run's counter
         self.graph = None
         self.graphs = None
+        self.use_graph = bool(use_graph)
+        self._cap_modes = None
         if use_graph:
             saved = self.x.clone()
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):             # warm-up outside capture (lazy attribute init)
-                self._run_all()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            if self.streams and os.environ.get("JEN1_GRAPH_PER_STREAM", "1") == "1":
-                self.graphs = []
-                for _, _, run, _ in self.parts:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        run(torch.cuda.current_stream(dev).cuda_stream)
-                    self.graphs.append(g)
-            else:
+            self._capture()
+            self.reset(saved)                         # the warm-up advanced x and the step counter: restore
+
+    def _modes(self):
+        """scheduling form of every persistent launch of the step (static / tickets): recorded into a captured graph"""
+        return tuple(bool(plan.progs[0].exclusive) for _, plan, _, _ in self.parts if getattr(plan, "progs", None))
+
+    def _capture(self):
+        """warm-up + capture of one step (called again when the scheduling form of a persistent launch changed hands)"""
+        dev = self.gd.device
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):             # warm-up outside capture (lazy attribute init)
+            self._run_all()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph, self.graphs = None, None
+        if self.streams and os.environ.get("JEN1_GRAPH_PER_STREAM", "1") == "1":
+            self.graphs = []
+            for _, _, run, _ in self.parts:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._run_all()
-                self.graph = g
-            self.reset(saved)                         # the warm-up advanced x and the step counter: restore
+                    run(torch.cuda.current_stream(dev).cuda_stream)
+                self.graphs.append(g)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_all()
+            self.graph = g
+        self._cap_modes = self._modes()
+
+    def _sync_modes(self, claim: bool):
+        """the static schedule of the persistent launch belongs to the program used most recently (engine.DeepProgram.claim_static):
+        ask for it at the start of a trajectory, and re-capture when the form recorded in the graph is no longer the program's"""
+        if claim:
+            for _, plan, _, _ in self.parts:
+                if getattr(plan, "progs", None):
+                    plan.progs[0].claim_static()
+        if self.use_graph and self._cap_modes is not None and self._cap_modes != self._modes():
+            saved, nxt = self.x.clone(), self._next
+            self._set_step(0)                      # (the warm-up pass reads the tables of the current step: keep it inside them)
+            self._capture()
+            for sl, plan, _, _ in self.parts:
+                plan.x_in.copy_(saved[sl])
+            self._set_step(nxt)
+
+    def rebind(self, conditioning) -> None:
+        """new conditioning for the next trajectory of the same shape: text K/V cache (when the tensors changed), concat context;
+        the schedule tables and the captured graph stay (they depend on the weights and the shape only)"""
+        self._cond = conditioning
+        for sl, plan, _, _ in self.parts:
+            emb = conditioning["cross_attn_cond"][sl]
+            msk = None if conditioning["cross_attn_masks"] is None else conditioning["cross_attn_masks"][sl]
+            cc = conditioning["input_concat_cond"]
+            self.model._prepare(plan, plan.x_in, None, emb, msk, [None if cc is None else cc[sl]], None)
+            plan._cond_refs = (emb, msk)
 
     def _run_all(self):
         """enqueue every sub-batch; with several parts they fork onto side streams and join back."""
@@ -451,6 +505,8 @@ class DDIMStepper:
         """start a trajectory at x0; unless noises are injected per step, draw the whole per-step noise
         table now (gdm.py:218 draws randn_like inside the loop: same distribution, one launch)."""
         x0 = x0.to(torch.float32)
+        if self._cap_modes is not None or not self.use_graph:
+            self._sync_modes(claim=True)
         for sl, plan, _, _ in self.parts:
             plan.x_in.copy_(x0[sl])
         if fresh_noise and self.mode != "vdm":
@@ -473,6 +529,11 @@ class DDIMStepper:
     def step(self, i: int, noise: Optional[torch.Tensor] = None, drop_rows=None, set_rows=False):
         if i != self._next:
             self._set_step(i)
+        if self._cap_modes is not None and self._cap_modes != self._modes():
+            self._sync_modes(claim=False)
+        for _, plan, _, _ in self.parts:           # (a replayed graph does not pass through DeepProgram.launch: mark the use here)
+            if getattr(plan, "progs", None):
+                plan.progs[0].touch()
         if set_rows:
             for sl, plan, _, _ in self.parts:
                 plan.set_rows(None if drop_rows is None else torch.as_tensor(drop_rows)[sl])

@@ -186,21 +186,42 @@ class Jen1HipError(RuntimeError):
 
 
 def build(verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into jen1_amd/libjen1_hip.so (hipcc cross-compiles
-    without a GPU).  Skips the compile when the library is newer than every source."""
+    """Compile the HIP sources for gfx950 into jen1_amd/libjen1_hip.so (hipcc cross-compiles without a GPU): one object per source
+    under <package>/build/ (compiled in parallel, only when the source or a header is newer than its object), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h"), os.path.join(INCLUDE, "jen1_train.h"),
-                   os.path.join(INCLUDE, "jen1_deep.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h"), os.path.join(INCLUDE, "jen1_train.h"),
+            os.path.join(INCLUDE, "jen1_deep.h")]
+    hdrs += [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h") and h != "common.h"]
+    deps = srcs + hdrs
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
-           *srcs, "-o", LIB_PATH]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + os.environ.get("JEN1_HIPCC_FLAGS", "").split()
+    objdir = os.path.join(PKG_ROOT, "build", "obj" + ("" if not os.environ.get("JEN1_HIPCC_FLAGS") else "_" + str(abs(hash(os.environ["JEN1_HIPCC_FLAGS"])) % 10 ** 8)))
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
+            return obj
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise Jen1HipError(f"hipcc failed on {os.path.basename(src)}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("JEN1_BUILD_JOBS", "6"))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise Jen1HipError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        raise Jen1HipError(f"hipcc link failed:\n{r.stdout}\n{r.stderr}")
     global _lib
     _lib = None
     return LIB_PATH

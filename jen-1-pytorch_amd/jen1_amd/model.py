@@ -95,12 +95,15 @@ class UNetCFG1d(nn.Module):
         self._train_graph = None
         self._ctx_key = None
         self._handle: Optional[int] = None             # torch.ops.jen1.unet_cfg_forward's handle of this module (jen1_amd/ops.py)
+        self._pending_err = None                       # [plan, pinned word, event, armed]: the asynchronous error check of forward
+        self.strict_errors = False                     # True: every forward synchronises and raises for its own launch
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     # ------------------------------------------------------------------ plumbing
     def _invalidate_engine(self):
         """the parameters changed in place (an optimiser step): the inference engine's packed weights, its plans and their
         captured graphs are stale; the next ``engine()`` call packs again"""
+        self._pending_err = None
         self._engine = None
         self._ctx_key = None
 
@@ -176,14 +179,45 @@ class UNetCFG1d(nn.Module):
 
     def _check_deep(self, plan: Plan) -> None:
         """the persistent deep-level launch replaces a hang by an error word (a dependency wait that timed out: its workgroups
-        were not all resident, e.g. another persistent launch held CUs); the results are garbage then and ``forward`` must not
-        return them.  One host sync per call -- ``forward`` returns a tensor the caller reads next anyway; the fused sampler
-        checks once per sampling run instead (DDIMStepper.check)."""
-        if getattr(plan, "progs", None):
-            e = plan.take_error()
+        were not all resident, e.g. another persistent launch held CUs); the results are garbage then and must not be used.
+        ``forward`` does NOT synchronise for it: the word is copied to pinned host memory behind the call's launches and looked at
+        by the next ``forward`` / ``check_errors()`` once that copy has completed (a literal sampler loop or ``eval`` over many
+        calls stays asynchronous); ``check_errors()`` is the explicit, synchronising form and what ``strict_errors`` runs per call.
+        The fused sampler checks once per sampling run (DDIMStepper.check)."""
+        if not getattr(plan, "progs", None) or torch.cuda.is_current_stream_capturing():
+            return
+        if self.strict_errors:
+            self._raise_deep(plan, plan.take_error())
+            return
+        pend = self._pending_err
+        if pend is None or pend[0] is not plan:
+            self.check_errors()
+            pend = self._pending_err = [plan, torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event(), False]
+        pend[1].copy_(plan.progs[0].err[:1], non_blocking=True)
+        pend[2].record(torch.cuda.current_stream(self._device))
+        pend[3] = True
+
+    def _raise_deep(self, plan: Plan, e: int) -> None:
+        if e:
+            raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {e - 1} timed out (another persistent "
+                                 "launch on the same GPU?); the error word was cleared, the call can be repeated")
+
+    def _poll_errors(self) -> None:
+        """non-blocking: raise for an earlier call whose error word has arrived on the host"""
+        pend = self._pending_err
+        if pend is not None and pend[3] and pend[2].query():
+            pend[3] = False
+            e = int(pend[1][0])
             if e:
-                raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {e - 1} timed out (another persistent "
-                                     "launch on the same GPU?); the error word was cleared, the call can be repeated")
+                pend[0].take_error()           # clears the device word: the next launch is clean
+                self._raise_deep(pend[0], e)
+
+    def check_errors(self) -> None:
+        """synchronising form: raises ``Jen1HipError`` if any earlier ``forward`` of this module timed out inside its persistent launch"""
+        pend = self._pending_err
+        if pend is not None and pend[3]:
+            pend[2].synchronize()
+            self._poll_errors()
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -217,6 +251,7 @@ class UNetCFG1d(nn.Module):
         """what ``torch.ops.jen1.unet_cfg_forward`` runs: plans + launches on the engine"""
         eng = self.engine()
         lib = eng.lib
+        self._poll_errors()
         B, _, T = x.shape
         causal = bool(causal)
         drop = None

@@ -165,6 +165,35 @@ class FusedAdamW:
         self.step_count = steps.pop() if steps else 0
 
 
+def adopt_optimizer(params, optimizer, lr_scheduler, grad_clip=None, skip_nonfinite: bool = False):
+    """What the reference's call site hands the trainer (train.py:56-60, :84, :110-125) -> ``(FusedAdamW, LinearLR | None)``.
+
+    ``optimizer`` may be a ``torch.optim.AdamW`` over ONE parameter group, ``lr_scheduler`` torch's ``LinearLR`` built on it.
+    torch's scheduler constructor has already multiplied ``param_groups[0]["lr"]`` by ``start_factor`` by the time the trainer
+    sees the optimiser, so the configured rate is the group's ``initial_lr`` / the scheduler's ``base_lrs[0]``; moments and step
+    count of a resumed optimiser (train.py:63-81) are carried over into the flat buffers."""
+    if isinstance(optimizer, torch.optim.Optimizer):
+        g = optimizer.param_groups
+        assert len(g) == 1, "the trainer optimises one parameter group (train.py:56-60)"
+        base_lr = float(g[0].get("initial_lr", g[0]["lr"]))
+        if lr_scheduler is not None and getattr(lr_scheduler, "base_lrs", None):
+            base_lr = float(lr_scheduler.base_lrs[0])
+        torch_state = optimizer.state_dict()
+        optimizer = FusedAdamW(list(params), lr=base_lr, betas=tuple(g[0]["betas"]), eps=g[0]["eps"],
+                               weight_decay=g[0]["weight_decay"], max_norm=grad_clip, skip_nonfinite=skip_nonfinite)
+        if torch_state.get("state"):
+            optimizer.load_state_dict(torch_state)
+            optimizer.lr = base_lr             # load_state_dict read the (already scheduled) group rate: keep the base rate
+    else:
+        optimizer.max_norm = grad_clip if grad_clip is not None else optimizer.max_norm
+        optimizer.skip_nonfinite = optimizer.skip_nonfinite or skip_nonfinite
+    if lr_scheduler is not None and not isinstance(lr_scheduler, LinearLR):
+        ls = lr_scheduler                      # torch.optim.lr_scheduler.LinearLR (train.py:84)
+        lr_scheduler = LinearLR(optimizer.lr, getattr(ls, "start_factor", 1.0 / 3), getattr(ls, "end_factor", 1.0),
+                                getattr(ls, "total_iters", 5), last_epoch=getattr(ls, "last_epoch", 0) - 1)
+    return optimizer, lr_scheduler
+
+
 class GradExchange:
     """DDP's bucketed gradient exchange overlapped with the backward pass (train.py:88-89: ``DDP(model)`` all-reduces a
     bucket as soon as autograd has finished the gradients in it).
@@ -179,11 +208,14 @@ class GradExchange:
     all-reduce of the whole buffer chunked the same way (same chunks, same reduction)."""
 
     def __init__(self, opt: "FusedAdamW", names: List[str], group=None, bucket_bytes: int = 128 << 20, params: Optional[dict] = None,
-                 grad_dtype: str = "f32"):
+                 grad_dtype: str = "f32", single_rank: Optional[bool] = None):
         """``params``: ``dict(model.named_parameters())`` -- checked against the optimiser's parameter list by identity (an
         optimiser built over a re-ordered or filtered list would mis-assign regions).  ``grad_dtype="bf16"``: every chunk is
         rounded to bfloat16 for the wire and widened again (half the xGMI bytes, two extra passes over the chunk in HBM; the mean
-        is then only bf16-accurate) -- off by default, like torch DDP's bf16 compression hook."""
+        is then only bf16-accurate) -- off by default, like torch DDP's bf16 compression hook.  ``single_rank`` (default: env
+        JEN1_EXCHANGE_SINGLE_RANK=1): run the exchange -- hooks, communication stream, RCCL collectives, recording into the replayed
+        graph -- in a process group of ONE rank too, where it is the identity: the whole overlapped / recorded path can then be
+        exercised on a single GPU (tests/test_gpu_train.py::test_recorded_rccl_exchange_single_rank)."""
         import torch.distributed as dist
         assert grad_dtype in ("f32", "bf16")
         self.opt, self.group, self.bucket = opt, group, max(1, bucket_bytes // 4)
@@ -204,6 +236,11 @@ class GradExchange:
             "parameter regions must tile the flat gradient buffer"
         self.bf16 = grad_dtype == "bf16"
         self._wire: Optional[torch.Tensor] = None
+        import os
+        self.single_rank = (os.environ.get("JEN1_EXCHANGE_SINGLE_RANK", "0") == "1") if single_rank is None else bool(single_rank)
+        # cumulative counters (never reset): all-reduce calls issued (eager or recorded), those issued while a graph was being
+        # recorded, regions that left during a backward pass (before finish())
+        self.collectives = self.recorded_collectives = self.regions_in_pass = 0
         self.active = False
         # debugging aid for one step: instead of sending a region when its hook fires, keep a copy of it; ``finish`` checks that
         # no gradient landed in the region afterwards (the ordering assumption the overlap rests on), then sends everything
@@ -216,11 +253,16 @@ class GradExchange:
     @property
     def capturable(self) -> bool:
         """RCCL collectives on device buffers can be recorded into the replayed backward pass; gloo / CPU cannot"""
-        return self.world > 1 and self.backend == "nccl" and self.opt.flat_grad.is_cuda
+        return self.enabled and self.backend == "nccl" and self.opt.flat_grad.is_cuda
+
+    @property
+    def enabled(self) -> bool:
+        """more than one rank -- or one rank of an initialised process group when ``single_rank`` asks for the path anyway"""
+        return self.world > 1 or (self.single_rank and self.backend is not None)
 
     def begin(self) -> None:
         """arm the exchange for the backward pass(es) that follow (the last micro-batch of an accumulation window)"""
-        self.active = self.world > 1
+        self.active = self.enabled
         self._works, self._expect, self._sent = [], {}, set()
         self.sent_during_pass = 0
         g = self.opt.flat_grad
@@ -243,6 +285,7 @@ class GradExchange:
         if left > 0:
             return
         self.sent_during_pass += 1
+        self.regions_in_pass += 1
         if self.debug_check:
             lo, hi = self.regions[region]
             if also is not None:
@@ -253,6 +296,9 @@ class GradExchange:
 
     def _reduce(self, chunk: torch.Tensor, sync: bool) -> None:
         import torch.distributed as dist
+        self.collectives += 1
+        if chunk.is_cuda and torch.cuda.is_current_stream_capturing():
+            self.recorded_collectives += 1
         if self.bf16:
             w = self._wire[:chunk.numel()]
             w.copy_(chunk)

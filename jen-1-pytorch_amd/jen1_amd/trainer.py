@@ -19,7 +19,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from .optim import FusedAdamW, GradExchange, LinearLR
+from .optim import FusedAdamW, GradExchange, LinearLR, adopt_optimizer
 from .tasks import get_conditioning, random_mask
 from .train import GraphedLossStep
 
@@ -78,18 +78,7 @@ class UnifiedMultiTaskTrainer:
         self.group, self.rng = process_group, rng
         self.is_gdm = getattr(config, "diffusion_type", "gdm") == "gdm"
         scaling = bool(scaler is not None and getattr(scaler, "is_enabled", lambda: False)())
-        if isinstance(optimizer, torch.optim.Optimizer):
-            g = optimizer.param_groups
-            assert len(g) == 1, "the trainer optimises one parameter group (train.py:56-60)"
-            optimizer = FusedAdamW(list(model.parameters()), lr=g[0]["lr"], betas=tuple(g[0]["betas"]), eps=g[0]["eps"],
-                                   weight_decay=g[0]["weight_decay"], max_norm=grad_clip, skip_nonfinite=scaling)
-        else:
-            optimizer.max_norm = grad_clip if grad_clip is not None else optimizer.max_norm
-            optimizer.skip_nonfinite = optimizer.skip_nonfinite or scaling
-        if lr_scheduler is not None and not isinstance(lr_scheduler, LinearLR):
-            ls = lr_scheduler                # torch.optim.lr_scheduler.LinearLR (train.py:84)
-            lr_scheduler = LinearLR(optimizer.lr, getattr(ls, "start_factor", 1.0 / 3), getattr(ls, "end_factor", 1.0),
-                                    getattr(ls, "total_iters", 5), last_epoch=getattr(ls, "last_epoch", 0) - 1)
+        optimizer, lr_scheduler = adopt_optimizer(list(model.parameters()), optimizer, lr_scheduler, grad_clip, scaling)
         self.optimizer, self.lr_scheduler = optimizer, lr_scheduler
         self.graph = model.train_graph(compute_dtype)
         self.graph.attach_optimizer(optimizer)

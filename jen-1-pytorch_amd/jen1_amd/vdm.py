@@ -94,7 +94,18 @@ class VDM(torch.nn.Module):
         audios = [audio]
         if fused:
             self._steps = step
-            st = DDIMStepper(self, model, shape, conditioning, causal, use_graph, None, 0, "vdm")
+            # one stepper (plan + schedule tables + captured graph) per (model, shape, causal, steps): later calls rebind the conditioning
+            cache = self.__dict__.setdefault("_steppers", {})
+            key = (id(model), id(model.engine()), tuple(shape), bool(causal), bool(use_graph), int(step), float(self.embedding_scale),
+                   bool(self.batch_cfg), bool(self.scale_cfg), bool(model.deterministic))
+            st = cache.get(key)
+            if st is not None and st.model is model and st.eng is model.engine():
+                st.rebind(conditioning)
+            else:
+                st = DDIMStepper(self, model, shape, conditioning, causal, use_graph, None, 0, "vdm")
+                if len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                cache[key] = st
             st.reset(audio)
         B = shape[0]
         for i in range(step):

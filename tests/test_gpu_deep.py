@@ -473,3 +473,88 @@ def test_column_chunked_level_equals_launch_path(full_f32, full_bf16):
             ra, rb = pd.taps[k].t[:, :, : pd.taps[k].C].float(), pl.taps[k].t[:, :, : pl.taps[k].C].float()
             assert torch.isfinite(ra).all()
             assert float((ra - rb).abs().max()) / float(rb.abs().max()) < tol, k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reserved word of the exchange protocol (include/jen1_deep.h "Reserved word") and the time-out path
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_nan_activations_flow_through_the_launch(full_f32, full_bf16, mode):
+    """A producer whose results ARE the reserved pattern: the bias of a level-3 convolution is set to float32 NaNs with the sign
+    and every mantissa bit set (0xFFFFFFFF), so its epilogue computes acc + bias = that NaN for every channel -- stored as it is,
+    every 8-byte word of the layer's output would be the 'not stored yet' sentinel and its consumers would spin to the time-out.
+    The stores canonicalise the pattern: the launch completes at its usual speed with NO error word, NaNs come out (as the
+    reference produces them for NaN weights), and the next launch with the bias restored is clean and equal to the one before."""
+    import time
+    model = full_f32 if mode == "f32" else full_bf16
+    eng = model.engine()
+    B, T = 2, 1500
+    plan = eng.plan(B, T, 1, False, deep=True)
+    assert plan.deep_level is not None
+    x, cond = synth.latents(B, T), synth.conditioning(B, T)
+    t = np.array([999, 3], dtype=np.int64)
+    run_plan(model, plan, x, t, cond)
+    assert plan.take_error() == 0
+    want = plan.net_out.t.clone()
+    assert torch.isfinite(want.float()).all()
+    key = "downsamples.3.blocks.0.conv1.bias"
+    keys = [k for k in eng.W.v if k.endswith("blocks.0.conv1.bias") and k.startswith("downsamples.3")]
+    assert keys, [k for k in eng.W.v if "downsamples.3" in k][:8]
+    key = keys[0]
+    bias = eng.W.v[key]
+    saved = bias.clone()
+    try:
+        bias.view(torch.int32).fill_(-1)                    # 0xFFFFFFFF: -NaN, all mantissa bits
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_plan(model, plan, x, t, cond)
+        dt = time.perf_counter() - t0
+        assert plan.take_error() == 0, "a NaN activation was taken for the sentinel: a consumer waited for data that had arrived"
+        assert dt < 0.1, f"the launch took {dt * 1e3:.0f} ms: a consumer spun on a NaN word"
+        assert torch.isnan(plan.net_out.t.float()).any()
+    finally:
+        bias.copy_(saved)
+    run_plan(model, plan, x, t, cond)
+    assert plan.take_error() == 0
+    # (the launch-per-layer levels around the persistent launch sum their statistics with float atomics: equal to rounding)
+    assert rel_err(plan.net_out.t.float().cpu().numpy(), want.float().cpu().numpy()) < (1e-4 if mode == "f32" else 3e-2)
+
+
+def test_time_out_is_reported_and_cleared(full_bf16):
+    """Fault injection: the persistent program is re-linked WITHOUT its first phase, so the first remaining phase polls a tensor
+    nobody produces (it starts the launch poisoned).  The bounded spin gives up after JEN1_DEEP_POLL_LIMIT polls, the error word
+    says which phase, every other waiter is released (the launch ends in a fraction of a second instead of hanging the GPU),
+    ``take_error`` reports and clears the word, and the intact program runs clean right after."""
+    import copy
+    import time
+    model = full_bf16
+    eng = model.engine()
+    B, T = 2, 1500
+    plan = eng.plan(B, T, 1, False, deep=True)
+    prog = plan.deep
+    x, cond = synth.latents(B, T), synth.conditioning(B, T)
+    t = np.array([999, 3], dtype=np.int64)
+    run_plan(model, plan, x, t, cond)
+    assert plan.take_error() == 0
+    want = plan.net_out.t.clone()
+    broken = copy.copy(prog)
+    broken.leader = broken
+    broken._exclusive = False
+    broken._err_shared = prog.err
+    for name in ("bufs", "labels", "outs", "kinds"):
+        setattr(broken, name, list(getattr(prog, name))[1:])
+    broken.finalize(prog.sync)
+    s = torch.cuda.current_stream().cuda_stream
+    prog.poison(s)                                          # (the full program's table: phase 0's output starts as the sentinel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    broken.launch(s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    e = prog.take_error()
+    assert e >= 1, "the wait for a tensor nobody produced did not time out"
+    assert dt < 5.0, f"{dt:.1f} s: the other waiters were not released"
+    assert prog.error() == 0                                # cleared when reported
+    run_plan(model, plan, x, t, cond)                       # the intact program, right after
+    assert plan.take_error() == 0
+    assert rel_err(plan.net_out.t.float().cpu().numpy(), want.float().cpu().numpy()) < 3e-2

@@ -761,6 +761,103 @@ def test_data_parallel_step_two_ranks_gloo():
     assert res[0]["err"] < 1e-5, res[0]
 
 
+def _rccl_single_worker(port, q):
+    try:
+        import os
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+        from jen1_amd.model import UNetCFG1d
+        from jen1_amd.optim import FusedAdamW, GradExchange
+        from jen1_amd.train import GraphedLossStep
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        try:
+            betas, _ = get_beta_schedule("linear", 1000)
+            gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                                   embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+            B, T = 2, 300
+            cond = {k: dev(v) for k, v in synth.conditioning(B, T, "music_inpaint").items()}
+            x0 = dev(synth.latents(B, T, key="clip"))
+            t = torch.tensor([100, 900], dtype=torch.long, device="cuda")
+            model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
+            model.train()
+            opt = FusedAdamW(model.parameters(), lr=1e-3)
+            graph = model.train_graph("f32")
+            ex = GradExchange(opt, [n for n, _ in model.named_parameters()], bucket_bytes=64 << 10, single_rank=True)
+            assert ex.world == 1 and ex.backend == "nccl" and ex.enabled and ex.capturable
+            graph.exchange = ex
+            step = GraphedLossStep(graph, gd, scale=1.0)
+            # reference: the pass replayed WITHOUT the exchange, then the blocking exchange (RCCL all-reduce over one rank, / 1)
+            torch.manual_seed(7)
+            opt.zero_grad()
+            step.exchange = None
+            step(x0, t, cond, False)
+            torch.manual_seed(7)
+            opt.zero_grad()
+            step(x0, t, cond, False)                # same seed -> same noise draw inside the replay
+            torch.cuda.synchronize()
+            before_exchange = opt.flat_grad.clone()
+            c0 = ex.collectives
+            ex.blocking()
+            torch.cuda.synchronize()
+            want = opt.flat_grad.clone()
+            blocking_collectives = ex.collectives - c0
+            identity = bool(torch.equal(want, before_exchange))      # one rank: the RCCL all-reduce and the 1 / world scale change nothing
+            # the exchange recorded into the replayed pass: armed, captured as the second variant of the pass (first call), then
+            # replayed three times from the same generator state as the reference pass
+            outs, rec, sent = [], [], []
+            for rep in range(4):
+                torch.manual_seed(7)
+                opt.zero_grad()
+                r0, s0 = ex.recorded_collectives, ex.regions_in_pass
+                ex.begin()
+                step.exchange = ex
+                step(x0, t, cond, False)
+                assert not ex.active            # done_in_graph: nothing is left for finish()
+                ex.finish()
+                torch.cuda.synchronize()
+                if rep > 0:                     # (the capturing call's warm-up pass advanced the generator: other noise)
+                    outs.append(opt.flat_grad.clone())
+                rec.append(ex.recorded_collectives - r0)
+                sent.append(ex.regions_in_pass - s0)
+            gmax = float(want.abs().max())
+            q.put({"err": [float((o - want).abs().max()) / gmax for o in outs], "recorded": rec, "sent_during_pass": sent,
+                   "blocking_collectives": blocking_collectives, "variants": len(step._captured), "identity": identity,
+                   "gmax": gmax})
+        finally:
+            dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put({"error": traceback.format_exc()})
+        raise
+
+
+def test_recorded_rccl_exchange_single_rank():
+    """SURVEY.md section 8e / train.py:88-89 on the one GPU of the test box: a process group of ONE rank on the "nccl" (= RCCL)
+    backend, ``GradExchange(single_rank=True)``.  The backward pass is captured with the exchange armed -- every region's RCCL
+    all-reduce becomes a node of the replayed graph on the forked communication stream, ``finish()`` is recorded behind them --
+    and replayed three times: the gradients equal the pass without the exchange followed by the blocking exchange (which, over one
+    rank, is checked to be the bit-exact identity), at least four regions left during the recorded pass, at least four
+    collectives were recorded, and later calls replay without recording."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert "error" not in res, res["error"]
+    assert p.exitcode == 0
+    assert res["gmax"] > 0 and res["identity"], res
+    # same pass, same noise: the weight gradients are float atomics (split-K), so replays agree to rounding, not bit for bit
+    assert max(res["err"]) < 2e-5, res
+    assert res["recorded"][0] >= 4 and res["sent_during_pass"][0] >= 4, res        # captured on the first armed call ...
+    assert res["recorded"][1:] == [0, 0, 0], res                                   # ... later calls only replay
+    assert res["variants"] == 2, res                                               # the pass without and with the exchange
+    assert res["blocking_collectives"] >= 4, res
+
+
 def test_inference_engine_follows_optimizer_steps():
     """model(x, ...) between optimiser steps (the reference evaluates under no_grad every eval_interval, trainer.py:152-160)
     runs on the CURRENT weights: forward, train step, forward differs and equals a model freshly built from the new state_dict"""

@@ -324,3 +324,49 @@ def test_optimizer_state_is_torch_adamw_schema_both_ways():
     flat = {"step": 7, "exp_avg": torch.arange(opt.numel, dtype=torch.float32), "exp_avg_sq": torch.ones(opt.numel)}
     opt.load_state_dict(flat)
     assert opt.step_count == 7 and float(opt.exp_avg[5]) == 5.0
+
+
+def test_adopt_torch_optimizer_and_scheduler_keep_the_configured_rate_and_state():
+    """The reference's call site (train.py:56-60, :84, :110-125) hands the trainer a torch AdamW whose LinearLR has ALREADY scaled
+    param_groups[0]['lr'] by start_factor.  The takeover must schedule from the configured rate (lr sequence == torch's) and carry
+    the moments / step count of a resumed optimiser into the flat buffers."""
+    from jen1_amd.optim import adopt_optimizer
+    params0, grads = _data(3, scale=0.3)
+    ps = [torch.nn.Parameter(torch.from_numpy(p.copy())) for p in params0]
+    opt = torch.optim.AdamW(ps, lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1)
+    sched = torch.optim.lr_scheduler.LinearLR(opt)                     # train.py:84: built before the trainer
+    assert abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12               # ... which is why the group lr is not the base rate
+    want = []
+    ref_opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3e-5)
+    ref_sched = torch.optim.lr_scheduler.LinearLR(ref_opt)
+    for _ in range(8):
+        want.append(ref_sched.get_last_lr()[0])
+        ref_opt.step()
+        ref_sched.step()
+    fused, lin = adopt_optimizer(ps, opt, sched, grad_clip=0.7)
+    assert isinstance(fused, FusedAdamW) and isinstance(lin, LinearLR)
+    assert abs(fused.lr - 3e-5) < 1e-12 and fused.max_norm == 0.7 and fused.step_count == 0
+    got = []
+    for _ in range(8):
+        got.append(lin.get_last_lr())
+        lin.step()
+    assert np.allclose(got, want, rtol=1e-12, atol=0), (got, want)
+    # resumed run: two torch steps first, then the takeover (moments, step count and the scheduler's position are kept)
+    ps = [torch.nn.Parameter(torch.from_numpy(p.copy())) for p in params0]
+    opt = torch.optim.AdamW(ps, lr=3e-5, betas=(0.9, 0.95), weight_decay=0.1)
+    sched = torch.optim.lr_scheduler.LinearLR(opt)
+    for k in range(2):
+        for p, g in zip(ps, grads[k]):
+            p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        sched.step()
+    m_ref = [opt.state[p]["exp_avg"].clone() for p in ps]
+    v_ref = [opt.state[p]["exp_avg_sq"].clone() for p in ps]
+    fused, lin = adopt_optimizer(ps, opt, sched, grad_clip=0.7)
+    assert fused.step_count == 2 and abs(fused.lr - 3e-5) < 1e-12
+    assert abs(lin.get_last_lr() - want[2]) < 1e-15
+    for p, o, m, v in zip(fused.params, fused.offsets, m_ref, v_ref):
+        assert torch.equal(fused.exp_avg[o:o + p.numel()].view_as(p), m) and torch.equal(fused.exp_avg_sq[o:o + p.numel()].view_as(p), v)
+    # a FusedAdamW / LinearLR pair passes through (only clip norm and skip flag are applied)
+    f2, l2 = adopt_optimizer(ps, fused, lin, grad_clip=0.5, skip_nonfinite=True)
+    assert f2 is fused and l2 is lin and fused.max_norm == 0.5 and fused.skip_nonfinite
