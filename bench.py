@@ -342,6 +342,27 @@ def conv_roofline(st, reps=3):
     }
 
 
+def kv_gemm_roofline(st):
+    """The one large-M matrix-core GEMM of the path (MFMA roofline only where M is large): the text-token K/V
+    projection of all cross-attention layers, one grouped launch per conditioning (csrc/big_gemm.hip; blocks.py:402-407, :427-434).
+    Executed FLOPs / launch duration (replayed as a HIP graph between two events) against the dense bf16 MFMA peak."""
+    ops = [op for op in st.plan.ctx_ops if getattr(op, "kind", "") == "big_gemm"]
+    if not ops:
+        return None
+
+    def run(s):
+        for op in ops:
+            op(s)
+    ms = graph_time_ms(run)
+    fl = sum(op.flops for op in ops)
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "kernel": "big_gemm_nt_kernel<bf16> (LDS-DMA staged 128x128x64 tiles, v_mfma_f32_32x32x16_bf16): " + "; ".join(op.label for op in ops),
+            "launches": len(ops), "us": round(ms * 1e3, 1), "executed_gflop": round(fl / 1e9, 2),
+            "alg_bytes": int(sum(getattr(op, "bytes", 0) for op in ops)),
+            "when": "once per conditioning (Plan.set_context), outside the timed region; extra.end_to_end includes it"}
+
+
 def optimizer_step_bench(n_params, device, reps=5):
     """SURVEY.md section 8 row a16 measured on its own: clip_grad_norm_ + AdamW over the full model's parameter count
     (jen1_grad_sqnorm + jen1_adamw_step on flat float32 buffers).  Algorithmic bytes: the norm reads g (4 B), the update
@@ -690,6 +711,10 @@ def main():
                                          "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                                          "executed_gflop_per_step": round(sum(getattr(op, "flops", 0) for op in st.plan.ops) / 1e9, 2)}
         out["launches_per_step"] = st.plan.n_launch + 1
+        if args.dtype == "bf16":
+            kvr = kv_gemm_roofline(st)
+            if kvr is not None:
+                out["roofline"]["to_kv_gemm"] = kvr
         if not args.no_extra:
             st2 = build_stepper(model, B, T, device, cfg_pair=True, use_graph=not args.no_graph)
             dt2 = timed_steps(st2, max(10, args.steps // 2), max(3, args.warmup // 2), lambda: None)

@@ -323,6 +323,48 @@ int jen1_adamw_step_counted(float* p, const float* g, float* m, float* v, int64_
                             float weight_decay, int32_t* step_counter, const float* gnorm_sq, float max_norm, int skip_nonfinite,
                             void* stream);
 
+/*
+ * Large-M matrix-core GEMM (csrc/big_gemm.hip): the cross-attention ``to_kv`` projection over the text context, reference
+ * jen1/model/blocks.py:402-407 (``to_kv`` = Linear(1024 -> 2C), bias-free) as Attention.forward applies it at :427-434 --
+ * 45.9 % of the as-written FLOPs of a denoiser step.
+ *
+ *   C_g[orow(m)][n - n0_g] (+)= (alpha * sum_k A[m][k] B[n][k] + bias_g[n - n0_g]) * row_scale[orow(m)]      n0_g <= n < n0_g + N_g
+ *
+ * A [M][lda] and B [Ntot][ldb] are K-contiguous in the compute dtype (bf16: v_mfma_f32_32x32x16_bf16; f32: exact
+ * v_mfma_f32_16x16x4_f32); the rows of B are stacked column GROUPS, each with its own output tensor, bias and pitch (the 13
+ * cross-attention layers of a sampling plan: ONE launch projects the text tokens for all of them; LayerNorm's gamma / beta are
+ * folded into B and bias at pack time, the standardisation is shared: jen1_standardize_rows).  ``row_scale`` is the padding
+ * mask the reference multiplies into k and v (blocks.py:431-434).  orow(m) = (m / rows_in) * rows_out + m % rows_in maps the
+ * [B * 128] text rows into the [B][129] rows of a K/V cache (rows_in = 0: orow = m).  K must be a multiple of 64 (bf16) / 32
+ * (f32), every n0_g and N_g a multiple of 128 when there is more than one group.  ``groups`` is a DEVICE table.
+ */
+typedef struct jen1_bgemm_group {
+  void* c;                 /* output of the group: compute dtype, or float32 when c_f32 */
+  const float* bias;       /* [N] or NULL */
+  int32_t n0, N, ldc, reserved;
+} jen1_bgemm_group;
+
+typedef struct jen1_bgemm_args {
+  const void* a;
+  const void* b;
+  const jen1_bgemm_group* groups;   /* device pointer, n_groups entries, n0 ascending */
+  const float* row_scale;           /* indexed by the OUTPUT row orow(m), or NULL */
+  int32_t M, Ntot, K, lda, ldb, n_groups;
+  int32_t rows_in, rows_out;
+  int32_t c_f32, accumulate, dtype, reserved;
+  float alpha, reserved_f;
+} jen1_bgemm_args;
+int jen1_big_gemm(const jen1_bgemm_args* args, void* stream);
+
+/* y[r][0..C) = (x[r] - mean_r) / sqrt(var_r + eps): LayerNorm's standardisation (blocks.py:400-401 ``norm_context`` without its
+ * affine, which the packed weights carry) of float32 rows, written in the compute dtype; statistics over the ROUNDED values */
+int jen1_standardize_rows(const float* x, void* y, int rows, int C, int ldx, int ldy, float eps, int dtype, void* stream);
+
+/* the unconditional K/V slots of all cross-attention layers in one launch: out_l[b][n][:] = fixed_l[n][:] * mask[b][n]
+ * (model.py:337: the learned fixed embedding is masked with the TEXT mask).  table: device array of n_layers entries
+ * {const void* fixed; void* out; int32 C2; int32 0; int64 0}. */
+int jen1_kv_fixed_fill(const void* table_dev, int n_layers, const float* mask, int B, int rows, int dtype, void* stream);
+
 const char* jen1_last_error(void);
 /* "gfx950" build tag + ABI version, for the loader's sanity check */
 const char* jen1_build_info(void);

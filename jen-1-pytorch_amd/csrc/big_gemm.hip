@@ -1,0 +1,393 @@
+// Large-M matrix-core GEMM of the JEN-1 hot path on gfx950 (MI355X).  C ABI: include/jen1_hip.h (jen1_big_gemm,
+// jen1_standardize_rows, jen1_kv_fixed_fill).
+//
+// The one shape class of the denoiser where "fraction of the MFMA peak" means something: the bias-free
+// cross-attention projection ``to_kv`` = Linear(1024 -> 2C) over the text context (reference jen1/model/blocks.py:402-407,
+// :427-434; 45.9 % of the as-written FLOPs).  Sampling projects the 128 text tokens of every batch element ONCE per
+// conditioning for all 13 cross-attention layers (engine.Plan.set_context): one grouped GEMM  [B*128, 1024] x [17408, 1024]^T
+// whose column groups are the layers (LayerNorm gamma / beta folded into the weights at pack time, the standardisation shared:
+// jen1_standardize_rows), masked rows (blocks.py:431-434 multiplies K and V by the padding mask) and a row map into the
+// [2B][129][2C] K/V caches in the epilogue.  Training runs the same kernel for the forward and data-gradient products of the
+// 2B*129-row context (jen1_amd/train.py), and the TN form below for the weight gradient.
+//
+// Structure (cdna_hip_programming.md section 5):
+//   * 128 x 128 output tile per 256-thread workgroup, K step 128 bytes (64 bf16 / 32 float32), 2 x 2 waves of 64 x 64;
+//     v_mfma_f32_32x32x16_bf16 (float32 mode: v_mfma_f32_16x16x4_f32, exact fp32), accumulators in registers;
+//   * both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, rows past the matrix
+//     read as zeros through the buffer descriptor), two LDS buffers per operand (64 KiB: two workgroups per CU), the loads of
+//     tile t+1 in flight across the barrier while tile t is multiplied (counted vmcnt, raw s_barrier);
+//   * the LDS image is lane-linear per DMA instruction, so the bank swizzle sits on the SOURCE address: 16-byte chunk c of row r
+//     is stored at chunk c ^ ((r >> 1) & 7) of the 128-byte row; a fragment read (ds_read_b128, 16 rows x one k group per lane
+//     group) then touches every bank once;
+//   * workgroup ids are remapped so that the workgroups of one XCD walk M under the same weight tile: every weight byte is read
+//     from HBM once, the activations (2 - 4 MB) stay in the L2s.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int BM = 128, BN = 128, ROWB = 128;          // tile rows; bytes of one tile row (the K step)
+constexpr int TILE_B = BM * ROWB;                      // 16 KiB per operand tile
+constexpr int RSRC_FLAGS = 0x00020000;
+
+struct BGroup {                 // one column group of the stacked B operand = one output tensor (a layer)
+  void* c;                      // output rows: c + row * ldc (+ column n - n0), in the compute dtype or float32
+  const float* bias;            // [N] or null
+  int32_t n0, N, ldc, pad;
+};
+static_assert(sizeof(BGroup) == 32, "group table entry");
+
+struct BArgs {
+  const void* a;                // activations [M][lda], K contiguous
+  const void* b;                // weights [Ntot][ldb], K contiguous (all groups stacked)
+  const BGroup* groups;         // device table, n0 ascending, every n0 and N a multiple of 128 unless n_groups == 1
+  const float* row_scale;       // indexed by OUTPUT row, or null: the result row is multiplied by it (the padding mask)
+  int32_t M, Ntot, K, lda, ldb, n_groups;
+  int32_t rows_in, rows_out;    // output row of GEMM row m: (m / rows_in) * rows_out + m % rows_in  (rows_in = 0: m itself)
+  int32_t c_f32, tiles_m, tiles_n, accumulate;
+  float inv_rows_in, alpha;
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> { static constexpr int ES = 2, BK = 64; };
+template <> struct Elem<float> { static constexpr int ES = 4, BK = 32; };
+
+// XCD-aware, bijective: the launch's workgroup ids are dealt round-robin to the 8 XCDs; give every XCD a contiguous run of
+// tile ids (cdna_hip_programming.md T1)
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ void store_out(bf16_t* p, const float (&v)[4]) { store4(p, v); }
+__device__ __forceinline__ void store_out(float* p, const float (&v)[4]) { store4(p, v); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NT form: C[m][n] = alpha * sum_k A[m][k] B[n][k]  (+ bias[n]) (* row_scale[m])
+// WM waves along M (2: 128 x 128 tile, 256 threads; 4: 256 x 128 tile, 512 threads), 2 along N, 64 x 64 per wave.
+// NSTAGE = 3: ONE barrier per K step -- behind the barrier of step t every wave has finished step t - 1, so the stage it read is
+// refilled with tile t + 2 right there; two tiles in flight while one is multiplied.  NSTAGE = 2: the classic double buffer, two
+// barriers per step, half the LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int WM, int NSTAGE>
+__global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
+  constexpr int ES = Elem<T>::ES, BK = Elem<T>::BK;
+  constexpr bool F32 = is_f32<T>::value;
+  constexpr int NWV = WM * 2;                          // waves
+  constexpr int TM = WM * 64;                          // tile rows of the activation operand
+  constexpr int A_B = TM * ROWB, B_B = BN * ROWB;      // bytes of the two operand tiles of a stage
+  constexpr int STAGE = A_B + B_B;
+  constexpr int PA = TM / 8 / NWV, PB = BN / 8 / NWV;  // LDS-DMA instructions per wave, tile and operand (8 rows each)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tn = tile / g.tiles_m, tm = tile - tn * g.tiles_m;         // consecutive ids: same weight tile, next M tile
+  const int m0 = tm * TM, n0 = tn * BN;
+
+  // ---- LDS-DMA addressing: instruction i of wave w fills rows (i * NWV + w) * 8 .. + 8 of a tile; lane l lands at row + (l >> 3),
+  // physical chunk l & 7, and fetches the global chunk (l & 7) ^ ((row >> 1) & 7) of that row --------------------------------
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.a) + (size_t)m0 * (size_t)g.lda * ES), 0,
+      (int)((size_t)((g.M - m0) < TM ? (g.M - m0) : TM) * (size_t)g.lda * ES), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.b) + (size_t)n0 * (size_t)g.ldb * ES), 0,
+      (int)((size_t)((g.Ntot - n0) < BN ? (g.Ntot - n0) : BN) * (size_t)g.ldb * ES), RSRC_FLAGS);
+  unsigned voa[4], vob[4];          // (fixed bounds: a call of the LDS-DMA builtin with type-dependent operands does not instantiate in the host pass)
+  static_assert(PA <= 4 && PB <= 4, "DMA pieces per wave");
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (i * NWV + w) * 8 + (lane >> 3);
+    voa[i] = (unsigned)row * (unsigned)(g.lda * ES) + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (i * NWV + w) * 8 + (lane >> 3);
+    vob[i] = (unsigned)row * (unsigned)(g.ldb * ES) + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const lds0 = (lds_u8*)smem;
+#define BG_ISSUE(stage_, kt_)                                                                                                        \
+  do {                                                                                                                               \
+    const unsigned so_ = (unsigned)(kt_) * (unsigned)ROWB;                                                                           \
+    lds_u8* const sb_ = lds0 + (stage_) * STAGE + w * 1024;                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < PA; ++i_)                                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_ + i_ * NWV * 1024), 16, voa[i_], so_, 0, 0);                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < PB; ++i_)                                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B + i_ * NWV * 1024), 16, vob[i_], so_, 0, 0);              \
+  } while (0)
+
+  // ---- fragment addressing.  The weight tile is the MFMA's A operand (rows n), the activation tile its B operand (rows m): a
+  // lane then holds 4 consecutive n of one output row m -- 8-byte (bf16) stores -----------------------------------------------
+  const int wm = w % WM, wn = w / WM;
+  constexpr int SUB = F32 ? 16 : 32;                   // rows of one MFMA tile
+  constexpr int NSUB = 64 / SUB;                       // tiles per wave and operand
+  constexpr int KG = F32 ? 4 : 2;                      // k groups (16-byte chunks) one MFMA k block spans
+  constexpr int KB = 8 / KG;                           // k blocks per tile row
+  const int fi = lane & (SUB - 1), fg = lane / SUB;
+  const int swz = (fi >> 1) & 7;                       // (row >> 1) & 7: the wave's row bases are multiples of 16
+  const unsigned fa = (unsigned)(wn * 64 + fi) * ROWB + A_B;         // weight tile rows of this lane
+  const unsigned fb = (unsigned)(wm * 64 + fi) * ROWB;               // activation tile rows
+  unsigned xo[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xo[kb] = (unsigned)((kb * KG + fg) ^ swz) * 16u;
+
+  typedef typename std::conditional<F32, f32x4, f32x16>::type Acc;
+  Acc acc[NSUB][NSUB];
+#pragma unroll
+  for (int i = 0; i < NSUB; ++i)
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+      for (int r = 0; r < (F32 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+
+  const int KT = g.K / BK;
+  BG_ISSUE(0, 0);
+  if (NSTAGE == 3 && KT > 1) BG_ISSUE(1, 1);
+  int stage = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    if constexpr (NSTAGE == 2) {
+      // two stages (64 KiB at WM = 2: two workgroups per CU cover each other's waits): tile kt + 1 is requested into the other
+      // stage, which every wave left behind the closing barrier of step kt - 1
+      if (kt + 1 < KT) BG_ISSUE(stage ^ 1, kt + 1);
+    }
+    // this wave's pieces of tile kt have landed (tile kt + 1 may still be in flight) ...
+    if (kt + 1 < KT) {
+      if constexpr (PA + PB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                // ... and everybody else's; every wave is done with step kt - 1
+    if constexpr (NSTAGE == 3) {
+      if (kt + 2 < KT) BG_ISSUE(stage == 0 ? 2 : stage - 1, kt + 2);  // refill the stage step kt - 1 read
+    }
+    const unsigned char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      u32x4 wa[NSUB], xb[NSUB];
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        wa[s] = *reinterpret_cast<const u32x4*>(base + fa + s * SUB * ROWB + xo[kb]);
+        xb[s] = *reinterpret_cast<const u32x4*>(base + fb + s * SUB * ROWB + xo[kb]);
+      }
+#pragma unroll
+      for (int i = 0; i < NSUB; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+          if constexpr (F32) {
+            // lane group fg holds k = 4 fg .. 4 fg + 3 of the 16-float block in BOTH operands: step s multiplies element s
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa[i][s]), __uint_as_float(xb[j][s]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb[j]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    if constexpr (NSTAGE == 2) __builtin_amdgcn_s_barrier();     // the stage is free for the loads of tile kt + 2
+    stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+  }
+
+#undef BG_ISSUE
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------
+  // group of this column tile (groups never straddle a tile unless there is only one)
+  int gi = 0;
+  for (int k = 1; k < g.n_groups; ++k) gi += (n0 >= g.groups[k].n0) ? 1 : 0;
+  const BGroup grp = g.groups[gi];
+  T* cT = reinterpret_cast<T*>(grp.c);
+  float* cF = reinterpret_cast<float*>(grp.c);
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j) {
+    // C/D layout: 32x32: column (operand B index, here m) = lane & 31, rows (here n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
+    //             16x16: column m = lane & 15, rows n = 4 (lane >> 4) + r
+    const int m = m0 + wm * 64 + j * SUB + fi;
+    if (m >= g.M) continue;
+    int orow = m;
+    if (g.rows_in > 0) {
+      const int q = (int)(((float)m + 0.5f) * g.inv_rows_in);
+      orow = q * g.rows_out + (m - q * g.rows_in);
+    }
+    const float rs = g.row_scale ? g.row_scale[orow] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) {
+#pragma unroll
+      for (int q4 = 0; q4 < (F32 ? 1 : 4); ++q4) {
+        const int nl = F32 ? (wn * 64 + i * 16 + fg * 4) : (wn * 64 + i * 32 + q4 * 8 + fg * 4);
+        const int n = n0 + nl - grp.n0;                              // column inside the group
+        if (n >= grp.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q4 * 4 + r] * g.alpha;
+        if (grp.bias) {
+          const float4 bb = *reinterpret_cast<const float4*>(grp.bias + n);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rs;
+        const size_t off = (size_t)orow * (size_t)grp.ldc + (size_t)n;
+        if (g.c_f32) {
+          if (g.accumulate) {
+            float o[4];
+            load4(cF + off, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += o[r];
+          }
+          store_out(cF + off, v);
+        } else {
+          if (g.accumulate) {
+            float o[4];
+            load4(cT + off, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += o[r];
+          }
+          store_out(cT + off, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TN form (weight gradients, bf16): C[n][k] += alpha * sum_m A[m][n] B[m][k], float32 atomics (split over m), both operands with
+// the reduction index as their ROW index ([m][cols], cols contiguous).  Tiles go into LDS as they lie in memory (LDS-DMA, 64
+// reduction rows x 128 columns per operand) and are transposed on the reads: a lane's MFMA fragment -- 8 consecutive m of one
+// column -- is two ds_read_b64_tr_b16 (each: 4 consecutive m x 16 columns per 16-lane group).
+// LDS image of a tile: [64 m][16 chunks of 8 columns]; chunk c of row m is stored at chunk c ^ (((m >> 2) & 1) * 8 + ... ) -- see
+// tr_slot below: within a 16-lane group the 16 lanes read 4 rows x ... the conflict classes of the transposing read are
+// hardware-specific (MI355X_MICROARCH.md), so the layout was chosen by measuring SQ_LDS_BANK_CONFLICT, not derived.
+// ---------------------------------------------------------------------------------------------------------------------
+// (the TN form is jen1_train_gemm's wgrad_loop for now: see jen1_amd/train.py BigLinearFn.backward)
+
+// standardise rows: y = (x - mean) / sqrt(var + eps) per row of C channels, x float32, y in the compute dtype; the statistics are
+// taken over the values ROUNDED to the compute dtype (what the matrix cores see), var biased like nn.LayerNorm (blocks.py:400-401)
+template <typename T>
+__global__ __launch_bounds__(256) void standardize_rows_kernel(const float* __restrict__ x, T* __restrict__ y, int rows, int C, int ldx, int ldy, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  float s = 0.f, q = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    float v[4];
+    load4(xr + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (float)(T)v[j];
+      s += v[j];
+      q += v[j] * v[j];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  const float mean = s / (float)C;
+  float var = q / (float)C - mean * mean;
+  var = var < 0.f ? 0.f : var;
+  const float rstd = is_f32<T>::value ? 1.0f / sqrtf(var + eps) : rsqrtf(var + eps);
+  T* yr = y + (size_t)row * ldy;
+  for (int c = lane * 4; c < C; c += 256) {
+    float v[4];
+    load4(xr + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ((float)(T)v[j] - mean) * rstd;
+    store4(yr + c, v);
+  }
+}
+
+struct FixedEntry {             // one layer: out[b][n][0..C2) = fixed[n][0..C2) * mask[b][n]
+  const void* fixed;            // [rows][C2] in the compute dtype
+  void* out;                    // first unconditional slot of the layer's K/V cache: [B][rows][C2]
+  int32_t C2, pad;
+  int64_t pad2;
+};
+static_assert(sizeof(FixedEntry) == 32, "fixed-slot table entry");
+
+template <typename T>
+__global__ __launch_bounds__(256) void kv_fixed_fill_kernel(const FixedEntry* __restrict__ tab, const float* __restrict__ mask, int B, int rows) {
+  const FixedEntry e = tab[blockIdx.y];
+  const int vpr = e.C2 >> 3;                          // 8-element vectors per row
+  const int total = B * rows * vpr;
+  const T* fx = reinterpret_cast<const T*>(e.fixed);
+  T* out = reinterpret_cast<T*>(e.out);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int br = i / vpr, c = (i - br * vpr) * 8;
+    const int b = br / rows, n = br - b * rows;
+    float v[8];
+    load8(fx + (size_t)n * e.C2 + c, v);
+    const float mk = mask[br];
+    // (x * mask in the compute dtype, as the torch expression this replaces rounded it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= mk;
+    store8(out + (size_t)br * e.C2 + c, v);
+  }
+}
+
+}  // namespace
+
+extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
+  JEN1_CHECK(a && a->a && a->b && a->groups && a->n_groups >= 1, "big_gemm: null argument");
+  const int es = a->dtype == JEN1_F32 ? 4 : 2;
+  const int bk = 128 / es;
+  JEN1_CHECK(a->dtype == JEN1_F32 || a->dtype == JEN1_BF16, "big_gemm: dtype must be f32 or bf16");
+  JEN1_CHECK(a->M >= 1 && a->Ntot >= 1 && a->K >= bk && a->K % bk == 0, "big_gemm: K=%d must be a positive multiple of %d", a->K, bk);
+  JEN1_CHECK(a->lda >= a->K && a->ldb >= a->K && (a->lda * es) % 16 == 0 && (a->ldb * es) % 16 == 0, "big_gemm: row pitches must be 16-byte multiples >= K");
+  JEN1_CHECK((int64_t)a->M * a->lda * es < ((int64_t)1 << 31) && (int64_t)a->Ntot * a->ldb * es < ((int64_t)1 << 31), "big_gemm: operand too large for 31-bit offsets");
+  JEN1_CHECK(a->n_groups == 1 || a->Ntot % BN == 0, "big_gemm: stacked groups need 128-column multiples");
+  BArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = a->a; g.b = a->b; g.groups = reinterpret_cast<const BGroup*>(a->groups); g.row_scale = a->row_scale;
+  g.M = a->M; g.Ntot = a->Ntot; g.K = a->K; g.lda = a->lda; g.ldb = a->ldb; g.n_groups = a->n_groups;
+  g.rows_in = a->rows_in; g.rows_out = a->rows_out; g.c_f32 = a->c_f32; g.accumulate = a->accumulate;
+  g.inv_rows_in = a->rows_in > 0 ? 1.0f / (float)a->rows_in : 0.f;
+  g.alpha = a->alpha;
+  // Two forms.  128 x 128 tiles, two LDS stages (64 KiB: two workgroups per CU cover each other's barriers and waits) -- the shapes of
+  // this path (1024 .. 2064 rows): 742 TFLOP/s on the stacked projection of a sampling plan, 590 with the other form.  256 x 128
+  // tiles, 8 waves, three stages (one barrier per K step, two tiles in flight) once there are several rounds of them: 935 against
+  // 760 TFLOP/s at 4096^3.  JEN1_BGEMM_WM = 2 / 4 forces a form (tuning runs).
+  static const int force_wm = getenv("JEN1_BGEMM_WM") ? atoi(getenv("JEN1_BGEMM_WM")) : 0;
+  const int t256 = ((a->M + 255) / 256) * ((a->Ntot + BN - 1) / BN);
+  const int wm = force_wm ? force_wm : ((t256 >= 512 && a->K >= 2048) ? 4 : 2);
+  g.tiles_m = (a->M + wm * 64 - 1) / (wm * 64);
+  g.tiles_n = (a->Ntot + BN - 1) / BN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(g.tiles_m * g.tiles_n);
+  if (wm == 4) {
+    if (a->dtype == JEN1_F32) hipLaunchKernelGGL((big_gemm_nt_kernel<float, 4, 3>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((big_gemm_nt_kernel<bf16_t, 4, 3>), grid, dim3(512), 0, s, g);
+  } else {
+    if (a->dtype == JEN1_F32) hipLaunchKernelGGL((big_gemm_nt_kernel<float, 2, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((big_gemm_nt_kernel<bf16_t, 2, 2>), grid, dim3(256), 0, s, g);
+  }
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_standardize_rows(const float* x, void* y, int rows, int C, int ldx, int ldy, float eps, int dtype, void* stream) {
+  JEN1_CHECK(x && y && rows >= 1 && C >= 4 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0, "standardize_rows: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((rows + 3) / 4);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(standardize_rows_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, rows, C, ldx, ldy, eps);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(standardize_rows_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, rows, C, ldx, ldy, eps);
+  else return jen1_set_error("standardize_rows: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_kv_fixed_fill(const void* table_dev, int n_layers, const float* mask, int B, int rows, int dtype, void* stream) {
+  JEN1_CHECK(table_dev && mask && n_layers >= 1 && B >= 1 && rows >= 1, "kv_fixed_fill: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(64, n_layers);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(kv_fixed_fill_kernel<float>, grid, dim3(256), 0, s, reinterpret_cast<const FixedEntry*>(table_dev), mask, B, rows);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(kv_fixed_fill_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const FixedEntry*>(table_dev), mask, B, rows);
+  else return jen1_set_error("kv_fixed_fill: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}

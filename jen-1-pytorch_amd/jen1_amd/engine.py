@@ -176,9 +176,7 @@ class Weights:
             self.v[f"{n}.q2.bias"] = bq2.contiguous()
             self.v[f"{n}.q2.u"] = rowsum(wq2)
             wkv2, bkv2 = fold_layernorm(p[f"{x}.to_kv.weight"], p[f"{x}.norm_context.weight"], p[f"{x}.norm_context.bias"])
-            self.w[f"{n}.kv2"] = pk(wkv2[None])
             self.v[f"{n}.kv2.bias"] = bkv2.contiguous()
-            self.v[f"{n}.kv2.u"] = rowsum(wkv2)
             kvx_w.append(wkv2)
             kvx_b.append(bkv2)
             self.kvx_off[n] = off
@@ -226,6 +224,9 @@ class Weights:
         self.kvx_ld = off
         if kvx_w:
             # time-token K/V rows of every cross-attention layer as ONE GEMM per step
+            # ... and, row-major [sum 2C][F], the B operand of jen1_big_gemm: the text tokens' K/V of ALL layers in one launch per
+            # conditioning (Plan.set_context) and the fixed embedding's K/V once per weight load; ``kvx_off`` is each layer's n0
+            self.w["kv2_all"] = torch.cat(kvx_w, 0).to(dtype).contiguous()
             self.w["kvx"] = pk(torch.cat(kvx_w, 0)[None])
             self.v["kvx.bias"] = torch.cat(kvx_b, 0).contiguous()
             self.v["kvx.u"] = rowsum(torch.cat(kvx_w, 0))
@@ -250,6 +251,14 @@ class Weights:
         scale = scale.reshape(-1).contiguous()
         self._fp8[id(w)] = (w, q, scale)
         return q, scale
+
+
+def _bgemm_parts(groups):
+    """column groups (c, bias, n0, N, ldc) of a stacked jen1_big_gemm operand -> launches: all groups in one launch when every
+    n0 and N is a multiple of the kernel's 128-column tile, else one launch per group (a single group may have any width)"""
+    if all(n0 % 128 == 0 and N % 128 == 0 for _, _, n0, N, _ in groups):
+        return [groups]
+    return [[gr] for gr in groups]
 
 
 class DeepIneligible(Exception):
@@ -1412,19 +1421,38 @@ class Plan(OpBuilder):
         # ---- 5. context ops: text K/V (hoisted out of the step loop) -------------------------------
         if n_tr:
             cops = self.ctx_ops
+            # (blocks.py:427-434: k, v = to_kv(norm_context(context)) * mask.)  One standardisation of the B * 128 text rows, ONE
+            # grouped matrix-core GEMM for the 13 layers (LayerNorm's gamma / beta live in the stacked weights / the group biases),
+            # mask and row map into the [2B][129][2C] caches in its epilogue, one launch for the unconditional slots.
             self.emb_t = Act(self._empty((B, NL, F)), B, NL, F, F)
-            self.emb_rs = torch.zeros((B * NL * 2,), dtype=f32, device=dev)
-            self.emb_t.rs = self.emb_rs
-            self._add_cast(cops, self.emb_in, self.emb_t.t)
-            a = (self.emb_t.t.data_ptr(), self.emb_rs.data_ptr(), B * NL, F, F, eng.dt)
-            cops.append(lambda s, a=a: L.check(lib.jen1_row_stats(*a, s), "jen1_row_stats"))
-            self.mask_flat = self.mask_in.view(-1)
+            a = (self.emb_t.t.data_ptr(), B * NL, F, F, F, 1e-5, eng.dt)
+            # (the source pointer is the caller's float32 embedding when it can be read in place, else the plan's copy: _ctx_src)
+            cops.append(lambda s, a=a: L.check(lib.jen1_standardize_rows(self._ctx_src, *a, s), "jen1_standardize_rows"))
+            groups, fixed_rows = [], []
             for t in spec.transformers():
                 kv = self.kv_ctx[t.name]
                 mid2 = kv.shape[-1]
-                slot = Act(kv[:B], B, spec.ctx_len, mid2, mid2)
-                self.conv(cops, src0=self.emb_t, w=W.w[f"{t.name}.kv2"], bias=W.v[f"{t.name}.kv2.bias"], out=slot,
-                          L_y=NL, pro=L.PRO_LN, ln=(F, None, None), row_scale=self.mask_flat)
+                groups.append((kv.data_ptr(), W.v[f"{t.name}.kv2.bias"].data_ptr(), W.kvx_off[t.name], mid2, mid2))
+                fixed_rows.append((eng.kv_fixed[t.name].data_ptr(), kv[B:].data_ptr(), mid2, 0))
+            self._kv_gemms = []
+            for part in _bgemm_parts(groups):
+                # (one launch for all layers whenever every layer's width is a multiple of the 128-column tile; else one per layer)
+                tab = L.bgemm_group_table([(c, b_, n0 - part[0][2], N, ldc) for c, b_, n0, N, ldc in part], dev)
+                g = L.BGemmArgs()
+                n_lo, n_hi = part[0][2], part[-1][2] + part[-1][3]
+                g.a, g.groups, g.row_scale = self.emb_t.t.data_ptr(), tab.data_ptr(), self.mask_in.data_ptr()
+                g.b = W.w["kv2_all"].data_ptr() + n_lo * F * W.w["kv2_all"].element_size()
+                g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups = B * NL, n_hi - n_lo, F, F, F, len(part)
+                g.rows_in, g.rows_out, g.dtype, g.alpha = NL, spec.ctx_len, eng.dt, 1.0
+                self._kv_gemms.append((g, tab))
+                fn = lambda s, g=g: L.check(lib.jen1_big_gemm(C.byref(g), s), "jen1_big_gemm")
+                fn.kind, fn.label = "big_gemm", f"to_kv of {len(part)} layers: [{B * NL} x {F}] x [{n_hi - n_lo} x {F}]^T"
+                fn.flops = 2.0 * B * NL * (n_hi - n_lo) * F
+                fn.bytes = (B * NL * F + (n_hi - n_lo) * F + B * NL * (n_hi - n_lo)) * W.w["kv2_all"].element_size()
+                cops.append(fn)
+            self._kv_fixed_tab = torch.tensor(fixed_rows, dtype=torch.int64).to(dev)
+            a = (self._kv_fixed_tab.data_ptr(), len(fixed_rows), self.mask_in.data_ptr(), B, spec.ctx_len, eng.dt)
+            cops.append(lambda s, a=a: L.check(lib.jen1_kv_fixed_fill(*a, s), "jen1_kv_fixed_fill"))
 
         # ---- split-K workspace shared by all launches of the plan (stream-ordered reuse) -----------
         self.finalize_workspace()
@@ -1470,15 +1498,19 @@ class Plan(OpBuilder):
         eng, B = self.eng, self.B
         if not self.kv_ctx:
             return
-        self.emb_in.copy_(embedding.to(torch.float32))
-        self.mask_in.fill_(1.0)
+        if embedding.dtype == torch.float32 and embedding.is_contiguous() and embedding.device == self.emb_in.device:
+            self._ctx_src, self._ctx_keep = embedding.data_ptr(), embedding       # read in place by the standardisation launch
+        else:
+            self.emb_in.copy_(embedding)
+            self._ctx_src, self._ctx_keep = self.emb_in.data_ptr(), None
         if mask is not None:
-            self.mask_in[:, : eng.spec.ctx_max_length].copy_(mask.to(torch.float32))
+            self.mask_in[:, : eng.spec.ctx_max_length].copy_(mask)                # (bool -> float in the copy; column 128, the time token, stays 1)
+        else:
+            self.mask_in.fill_(1.0)
+        # three launches: standardise, the grouped to_kv GEMM, the unconditional slots (learned fixed embedding masked with the SAME
+        # text mask, model.py:337)
         for op in self.ctx_ops:
             op(stream)
-        # unconditional slots: learned fixed embedding, masked with the SAME text mask (model.py:337)
-        for name, kv in self.kv_ctx.items():
-            kv[B:].copy_(eng.kv_fixed[name][None] * self.mask_in[:, :, None].to(kv.dtype))
 
     def set_rows(self, drop_rows: Optional[torch.Tensor], uncond_only: bool = False):
         """Select, per effective batch row, which cached K/V slot cross-attention reads.
@@ -1568,21 +1600,24 @@ class Engine:
             return
         lib, dev = self.lib, self.device
         n, F = spec.ctx_len, spec.ctx_features
-        fx = W.fixed[:n].to(self.tdtype).contiguous()
-        rs = torch.zeros((n * 2,), dtype=torch.float32, device=dev)
         s = self._stream()
-        L.check(lib.jen1_row_stats(fx.data_ptr(), rs.data_ptr(), n, F, F, self.dt, s), "jen1_row_stats")
-        tmp = OpBuilder(self)
-        src = Act(fx.view(1, n, F), 1, n, F, F, rs=rs)
+        fx = torch.empty((n, F), dtype=self.tdtype, device=dev)
+        src = W.fixed[:n].contiguous()
+        L.check(lib.jen1_standardize_rows(src.data_ptr(), fx.data_ptr(), n, F, F, F, 1e-5, self.dt, s), "jen1_standardize_rows")
+        groups = []
         for t in spec.transformers():
             mid2 = 2 * t.heads * t.head_features
             out = torch.empty((n, mid2), dtype=self.tdtype, device=dev)
-            tmp.conv(tmp.ops, src0=src, w=W.w[f"{t.name}.kv2"], bias=W.v[f"{t.name}.kv2.bias"],
-                     out=Act(out.view(1, n, mid2), 1, n, mid2, mid2), pro=L.PRO_LN, ln=(F, None, None),
-                     force={"splitk": 1})
             self.kv_fixed[t.name] = out
-        tmp.finalize_workspace()
-        tmp.run(s)
+            groups.append((out.data_ptr(), W.v[f"{t.name}.kv2.bias"].data_ptr(), W.kvx_off[t.name], mid2, mid2))
+        for part in _bgemm_parts(groups):
+            tab = L.bgemm_group_table([(c, b_, n0 - part[0][2], N, ldc) for c, b_, n0, N, ldc in part], dev)
+            g = L.BGemmArgs()
+            n_lo, n_hi = part[0][2], part[-1][2] + part[-1][3]
+            g.a, g.groups = fx.data_ptr(), tab.data_ptr()
+            g.b = W.w["kv2_all"].data_ptr() + n_lo * F * W.w["kv2_all"].element_size()
+            g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups, g.dtype, g.alpha = n, n_hi - n_lo, F, F, F, len(part), self.dt, 1.0
+            L.check(lib.jen1_big_gemm(C.byref(g), s), "jen1_big_gemm")
         torch.cuda.synchronize(dev)
 
     def plan(self, B: int, T: int, nrep: int, causal: bool, slot: int = 0, n_t: Optional[int] = None,

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # 
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "deep_kernel.hip", "elementwise.hip",
-           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip"]
+           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip", "big_gemm.hip"]
 
 F32, BF16, FP8 = 0, 1, 2
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -94,6 +94,19 @@ class GemmArgs(C.Structure):
                 ("map_shift_b", c_void_p)]
 
 
+class BGemmGroup(C.Structure):
+    """mirror of ``jen1_bgemm_group`` (include/jen1_hip.h): one column group = one output tensor of the grouped GEMM"""
+    _fields_ = [("c", c_void_p), ("bias", c_void_p), ("n0", c_int), ("N", c_int), ("ldc", c_int), ("reserved", c_int)]
+
+
+class BGemmArgs(C.Structure):
+    """mirror of ``jen1_bgemm_args`` (include/jen1_hip.h)"""
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("groups", c_void_p), ("row_scale", c_void_p),
+                ("M", c_int), ("Ntot", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("n_groups", c_int),
+                ("rows_in", c_int), ("rows_out", c_int), ("c_f32", c_int), ("accumulate", c_int), ("dtype", c_int), ("reserved", c_int),
+                ("alpha", c_float), ("reserved_f", c_float)]
+
+
 class RepackEntry(C.Structure):
     """mirror of ``jen1_repack_entry`` (include/jen1_train.h)."""
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("d0", c_int), ("d1", c_int), ("d2", c_int), ("ld", c_int),
@@ -127,6 +140,9 @@ SYMBOLS = {
     "jen1_adamw_step": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [c_int, _P, c_float, c_int, _P]),
     "jen1_adamw_step_counted": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [_P, _P, c_float, c_int, _P]),
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
+    "jen1_big_gemm": (c_int, [C.POINTER(BGemmArgs), _P]),
+    "jen1_standardize_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "jen1_kv_fixed_fill": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "jen1_train_gemm": (c_int, [C.POINTER(GemmArgs), _P]),
     "jen1_train_gemm_pair": (c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _P]),
     "jen1_attn_small_fits": (c_int, [c_int, c_int, c_int, c_int]),
@@ -254,3 +270,13 @@ def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().jen1_last_error()
         raise Jen1HipError(f"{what}: {msg.decode() if msg else 'unknown error'}")
+
+
+def bgemm_group_table(groups, device):
+    """device copy of a ``jen1_bgemm_group`` table: ``groups`` = [(c_ptr, bias_ptr or None, n0, N, ldc)]"""
+    import numpy as np
+    import torch
+    arr = (BGemmGroup * len(groups))()
+    for i, (c, bias, n0, N, ldc) in enumerate(groups):
+        arr[i].c, arr[i].bias, arr[i].n0, arr[i].N, arr[i].ldc = c, bias, n0, N, ldc
+    return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)

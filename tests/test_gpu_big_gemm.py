@@ -1,0 +1,119 @@
+"""-m gpu: the large-M matrix-core GEMM (csrc/big_gemm.hip, include/jen1_hip.h jen1_big_gemm) through the C ABI against plain
+PyTorch float32 of the same product -- the cross-attention ``to_kv`` projection over the text context (reference
+jen1/model/blocks.py:402-407, :427-434): the grouped form of the sampling plan (13 layers, row map into [B][129] caches, padding
+mask, folded LayerNorm bias) and the plain form of the training pass (2B * 129 rows), ragged M, both compute dtypes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err  # noqa: F401
+from jen1_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(a, b, groups, *, row_scale=None, rows_in=0, rows_out=0, c_f32=False, accumulate=False, alpha=1.0, dtype="bf16"):
+    lib = L.load()
+    tab = L.bgemm_group_table([(c.data_ptr(), None if bias is None else bias.data_ptr(), n0, N, c.stride(-2)) for c, bias, n0, N in groups], a.device)
+    g = L.BGemmArgs()
+    g.a, g.b, g.groups = a.data_ptr(), b.data_ptr(), tab.data_ptr()
+    g.row_scale = None if row_scale is None else row_scale.data_ptr()
+    g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups = a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), len(groups)
+    g.rows_in, g.rows_out, g.c_f32, g.accumulate = rows_in, rows_out, int(c_f32), int(accumulate)
+    g.dtype = L.F32 if dtype == "f32" else L.BF16
+    g.alpha = alpha
+    L.check(lib.jen1_big_gemm(C.byref(g), torch.cuda.current_stream().cuda_stream), "jen1_big_gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(2064, 2048, 1024), (2064, 1024, 2048), (1024, 512, 1024), (129, 256, 64), (130, 384, 192), (1, 128, 64)])
+def test_plain_nt_matches_torch(dtype, M, N, K):
+    """C = A B^T (one group, no epilogue extras), asymmetric random operands, ragged M (rows past M read as zeros and are never stored)"""
+    if dtype == "f32" and K % 32 or dtype == "bf16" and K % 64:
+        pytest.skip("K granularity")
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    a = (torch.randn((M, K), device="cuda", generator=gen) * 0.5).to(td)
+    b = (torch.randn((N, K), device="cuda", generator=gen) * 0.5).to(td)
+    guard = torch.full((M + 3, N), 7.0, device="cuda", dtype=td)                  # rows past M must stay untouched
+    c = guard[:M]
+    _run(a, b, [(c, None, 0, N)], dtype=dtype)
+    ref = a.float() @ b.float().t()
+    tol = 1e-5 if dtype == "f32" else 1e-2
+    err = float((c.float() - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
+    assert bool((guard[M:] == 7.0).all())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_grouped_projection_with_row_map_mask_and_bias(dtype):
+    """the sampling plan's form: 3 column groups of different width (layers) over the same standardised rows; bias per group, the padding
+    mask as a row scale, rows of batch element b land at rows b * 129 + n of a [B][129] cache whose 129th row is not touched"""
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    B, NL, K = 3, 128, 1024
+    widths = [512, 1024, 256]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B * NL, K), device="cuda", generator=gen)
+    xs = torch.empty((B * NL, K), device="cuda", dtype=td)
+    lib = L.load()
+    L.check(lib.jen1_standardize_rows(x.data_ptr(), xs.data_ptr(), B * NL, K, K, K, 1e-5, L.F32 if dtype == "f32" else L.BF16,
+                                      torch.cuda.current_stream().cuda_stream), "jen1_standardize_rows")
+    xr = x.to(td).float()
+    want_xs = (xr - xr.mean(dim=1, keepdim=True)) / torch.sqrt(xr.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
+    assert float((xs.float() - want_xs).abs().max()) < (1e-5 if dtype == "f32" else 2e-2)
+    w = (torch.randn((sum(widths), K), device="cuda", generator=gen) * 0.05).to(td)
+    mask_b = (torch.rand((B, NL + 1), device="cuda", generator=gen) > 0.3).float()       # indexed by the OUTPUT row: [B][129]
+    mask = mask_b[:, :NL].reshape(-1)
+    outs, groups, n0 = [], [], 0
+    for wd in widths:
+        cache = torch.full((B, NL + 1, wd), -3.0, device="cuda", dtype=td)
+        bias = torch.randn((wd,), device="cuda", generator=gen)
+        outs.append((cache, bias, n0, wd))
+        groups.append((cache.view(B * (NL + 1), wd), bias, n0, wd))
+        n0 += wd
+    _run(xs, w, groups, row_scale=mask_b, rows_in=NL, rows_out=NL + 1, dtype=dtype)
+    for cache, bias, n0, wd in outs:
+        ref = (xs.float() @ w[n0:n0 + wd].float().t() + bias[None]) * mask[:, None]
+        got = cache[:, :NL].reshape(B * NL, wd).float()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < (1e-5 if dtype == "f32" else 1e-2), err
+        assert bool((cache[:, NL] == -3.0).all())                                 # the time-token row belongs to another kernel
+
+
+def test_accumulate_alpha_and_float32_output():
+    M, N, K = 300, 256, 128
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    a = torch.randn((M, K), device="cuda", generator=gen).to(torch.bfloat16)
+    b = torch.randn((N, K), device="cuda", generator=gen).to(torch.bfloat16)
+    c = torch.randn((M, N), device="cuda", generator=gen)
+    c0 = c.clone()
+    _run(a, b, [(c, None, 0, N)], c_f32=True, accumulate=True, alpha=0.25)
+    ref = c0 + 0.25 * (a.float() @ b.float().t())
+    assert float((c - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+def test_kv_fixed_fill_matches_torch_expression():
+    """kv[B:] = fixed[None] * mask[:, :, None] for every layer in one launch (model.py:337)"""
+    lib = L.load()
+    B, R = 3, 129
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    mask = (torch.rand((B, R), device="cuda", generator=gen) > 0.4).float()
+    ents, keep = [], []
+    import numpy as np
+    rows = []
+    for C2 in (512, 2048, 1024):
+        fixed = torch.randn((R, C2), device="cuda", generator=gen).to(torch.bfloat16)
+        out = torch.zeros((B, R, C2), device="cuda", dtype=torch.bfloat16)
+        keep.append((fixed, out))
+        rows.append((fixed.data_ptr(), out.data_ptr(), C2))
+    tab = np.zeros((len(rows), 4), dtype=np.int64)
+    for i, (f, o, c2) in enumerate(rows):
+        tab[i, 0], tab[i, 1], tab[i, 2] = f, o, c2
+    tab_d = torch.from_numpy(tab).cuda()
+    L.check(lib.jen1_kv_fixed_fill(tab_d.data_ptr(), len(rows), mask.data_ptr(), B, R, L.BF16, torch.cuda.current_stream().cuda_stream), "jen1_kv_fixed_fill")
+    torch.cuda.synchronize()
+    for fixed, out in keep:
+        assert torch.equal(out, fixed[None] * mask[:, :, None].to(torch.bfloat16))
