@@ -336,7 +336,8 @@ int jen1_adamw_step_counted(float* p, const float* g, float* m, float* v, int64_
  * folded into B and bias at pack time, the standardisation is shared: jen1_standardize_rows).  ``row_scale`` is the padding
  * mask the reference multiplies into k and v (blocks.py:431-434).  orow(m) = (m / rows_in) * rows_out + m % rows_in maps the
  * [B * 128] text rows into the [B][129] rows of a K/V cache (rows_in = 0: orow = m).  K must be a multiple of 64 (bf16) / 32
- * (f32), every n0_g and N_g a multiple of 128 when there is more than one group.  ``groups`` is a DEVICE table.
+ * (f32), every n0_g and N_g a multiple of 128 when there is more than one group.  ``groups`` is a DEVICE table; NULL = one
+ * group described by the inline fields c / bias / ldc (nothing to copy to the device: usable while a graph is being recorded).
  */
 typedef struct jen1_bgemm_group {
   void* c;                 /* output of the group: compute dtype, or float32 when c_f32 */
@@ -351,10 +352,16 @@ typedef struct jen1_bgemm_args {
   const float* row_scale;           /* indexed by the OUTPUT row orow(m), or NULL */
   int32_t M, Ntot, K, lda, ldb, n_groups;
   int32_t rows_in, rows_out;
-  int32_t c_f32, accumulate, dtype, reserved;
+  int32_t c_f32, accumulate, dtype, ldc;
   float alpha, reserved_f;
+  void* c;                          /* groups == NULL: ONE group over all Ntot columns, given inline (c, bias, ldc) */
+  const float* bias;
 } jen1_bgemm_args;
 int jen1_big_gemm(const jen1_bgemm_args* args, void* stream);
+/* the weight gradient of the same projection (autograd of blocks.py:428 ``to_kv``): C[n][k] += alpha * sum_m A[m][n] B[m][k] with
+ * A = dY [M][lda >= N], B = the layer's input [M][ldb >= K] (bf16, as they lie in memory: the reduction index is the row), C float32
+ * [N][ldc] accumulated with float atomics (the reduction is split over workgroups): ``param.grad`` of the reference layout. */
+int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream);
 
 /* y[r][0..C) = (x[r] - mean_r) / sqrt(var_r + eps): LayerNorm's standardisation (blocks.py:400-401 ``norm_context`` without its
  * affine, which the packed weights carry) of float32 rows, written in the compute dtype; statistics over the ROUNDED values */

@@ -51,6 +51,7 @@ struct BArgs {
   int32_t rows_in, rows_out;    // output row of GEMM row m: (m / rows_in) * rows_out + m % rows_in  (rows_in = 0: m itself)
   int32_t c_f32, tiles_m, tiles_n, accumulate;
   float inv_rows_in, alpha;
+  BGroup inl;                   // the one group of a launch whose ``groups`` is null (no device table: capturable without a copy)
 };
 
 template <typename T> struct Elem;
@@ -199,8 +200,9 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
   // ---- epilogue ---------------------------------------------------------------------------------------------------------
   // group of this column tile (groups never straddle a tile unless there is only one)
   int gi = 0;
-  for (int k = 1; k < g.n_groups; ++k) gi += (n0 >= g.groups[k].n0) ? 1 : 0;
-  const BGroup grp = g.groups[gi];
+  if (g.groups)
+    for (int k = 1; k < g.n_groups; ++k) gi += (n0 >= g.groups[k].n0) ? 1 : 0;
+  const BGroup grp = g.groups ? g.groups[gi] : g.inl;
   T* cT = reinterpret_cast<T*>(grp.c);
   float* cF = reinterpret_cast<float*>(grp.c);
 #pragma unroll
@@ -255,15 +257,142 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// TN form (weight gradients, bf16): C[n][k] += alpha * sum_m A[m][n] B[m][k], float32 atomics (split over m), both operands with
-// the reduction index as their ROW index ([m][cols], cols contiguous).  Tiles go into LDS as they lie in memory (LDS-DMA, 64
-// reduction rows x 128 columns per operand) and are transposed on the reads: a lane's MFMA fragment -- 8 consecutive m of one
-// column -- is two ds_read_b64_tr_b16 (each: 4 consecutive m x 16 columns per 16-lane group).
-// LDS image of a tile: [64 m][16 chunks of 8 columns]; chunk c of row m is stored at chunk c ^ (((m >> 2) & 1) * 8 + ... ) -- see
-// tr_slot below: within a 16-lane group the 16 lanes read 4 rows x ... the conflict classes of the transposing read are
-// hardware-specific (MI355X_MICROARCH.md), so the layout was chosen by measuring SQ_LDS_BANK_CONFLICT, not derived.
+// TN form (weight gradients, bf16): C[n][k] += alpha * sum_m A[m][n] B[m][k], float32 atomics (the reduction over m is split
+// across workgroups), both operands with the reduction index as their ROW index ([m][cols], cols contiguous: dY and the layer's
+// input as they lie in memory).  Tiles go into LDS as they are (LDS-DMA: 64 reduction rows x 128 columns per operand and stage,
+// two stages) and are transposed on the reads: a lane's MFMA fragment -- 8 consecutive m of one column -- is two
+// ds_read_b64_tr_b16 (each: a 16-lane group names 4 rows x 16 columns and receives them column-major).  LDS image of a tile:
+// [64 m][8 blocks of 16 columns]; block c of row m is stored at block c ^ (2 (m & 3)): the 32 lanes of one read pass (two adjacent
+// column blocks x 4 rows) then cover the 8 block positions = all 64 banks once.
 // ---------------------------------------------------------------------------------------------------------------------
-// (the TN form is jen1_train_gemm's wgrad_loop for now: see jen1_amd/train.py BigLinearFn.backward)
+struct TArgs {
+  const void* a;                // [M][lda]: columns n
+  const void* b;                // [M][ldb]: columns k
+  float* c;                     // [N][ldc] float32, accumulated with atomics
+  int32_t M, N, K, lda, ldb, ldc, tiles_n, tiles_k, splits, mt_per_split;
+  float alpha;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_pair8(const unsigned char* lo) {       // rows r .. r + 3 and r + 4 .. r + 7 (1 KiB apart)
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo));
+  const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo + 4 * 256));
+  const s16x8 v = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
+  constexpr int TROW = 256;                           // bytes of a tile row: 128 bf16 columns
+  constexpr int TB = 64 * TROW;                       // 16 KiB per operand tile (64 reduction rows)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TB];     // [stage][A | B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int id = xcd_remap(blockIdx.x, g.tiles_n * g.tiles_k * g.splits);
+  const int split = id % g.splits;
+  id /= g.splits;
+  const int tk = id % g.tiles_k, tn = id / g.tiles_k;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int mt0 = split * g.mt_per_split;
+  const int MT_all = (g.M + 63) / 64;
+  int mt1 = mt0 + g.mt_per_split;
+  mt1 = mt1 < MT_all ? mt1 : MT_all;
+  if (mt0 >= mt1) return;
+
+  // descriptors start at the tile's first column; rows past M are beyond num_records and read as zeros
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.a) + (size_t)n0 * 2), 0,
+      (int)(((size_t)g.M * (size_t)g.lda - (size_t)n0) * 2), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.b) + (size_t)k0 * 2), 0,
+      (int)(((size_t)g.M * (size_t)g.ldb - (size_t)k0) * 2), RSRC_FLAGS);
+  // instruction i of wave w fills rows (i * 4 + w) * 4 .. + 4 of a tile; lane l lands at row + (l >> 4), 16-byte chunk l & 15 =
+  // (block l >> 1 & 7, half l & 1) and fetches block ((l >> 1) & 7) ^ (2 (row & 3)) of that row
+  unsigned voa[4], vob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + w) * 4 + (lane >> 4);
+    const int blk = ((lane >> 1) & 7) ^ (2 * (row & 3));
+    const unsigned col = (unsigned)(blk * 32 + (lane & 1) * 16);
+    voa[i] = (unsigned)row * (unsigned)(g.lda * 2) + col;
+    vob[i] = (unsigned)row * (unsigned)(g.ldb * 2) + col;
+  }
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const lds0 = (lds_u8*)smem;
+#define TN_ISSUE(stage_, mt_)                                                                                                  \
+  do {                                                                                                                         \
+    const unsigned soa_ = (unsigned)(mt_) * 64u * (unsigned)(g.lda * 2), sob_ = (unsigned)(mt_) * 64u * (unsigned)(g.ldb * 2);   \
+    lds_u8* const sb_ = lds0 + (stage_) * 2 * TB + w * 1024;                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_ + i_ * 4096), 16, voa[i_], soa_, 0, 0);                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + TB + i_ * 4096), 16, vob[i_], sob_, 0, 0);              \
+  } while (0)
+
+  // fragment addressing: wave (wn, wk) owns 64 n x 64 k; lane = (g2 = lane >> 5: rows 8 g2 .. + 8 of a 16-row block, h = bit 4:
+  // which 16-column half of the 32-column MFMA tile, p = lane & 15: row p >> 2 (+ 4 in the second read), columns 4 (p & 3) ..)
+  const int wn = w >> 1, wk = w & 1;
+  const int g2 = lane >> 5, h = (lane >> 4) & 1, p = lane & 15;
+  const int x = 2 * (p >> 2);                                            // the row swizzle of this lane's rows ((row & 3) = p >> 2)
+  const unsigned rowb = (unsigned)(8 * g2 + (p >> 2)) * TROW + (unsigned)(p & 3) * 8u;
+  unsigned fa[2], fb[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    fa[s] = rowb + (unsigned)(((wn * 4 + s * 2 + h) ^ x) * 32);
+    fb[s] = rowb + (unsigned)(((wk * 4 + s * 2 + h) ^ x) * 32) + TB;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TN_ISSUE(0, mt0);
+  int stage = 0;
+  for (int mt = mt0; mt < mt1; ++mt) {
+    if (mt + 1 < mt1) {
+      TN_ISSUE(stage ^ 1, mt + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* base = smem + stage * 2 * TB;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {                                     // 16 reduction rows per MFMA
+      bf16x8 va[2], vb[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        va[s] = tr_pair8(base + fa[s] + kb * 16 * TROW);
+        vb[s] = tr_pair8(base + fb[s] + kb * 16 * TROW);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i], vb[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+    stage ^= 1;
+  }
+#undef TN_ISSUE
+  // D[n][k]: column (B operand index) k = lane & 31, rows n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+    if (k >= g.K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
+        if (n < g.N) unsafeAtomicAdd(g.c + (size_t)n * (size_t)g.ldc + (size_t)k, acc[i][j][r] * g.alpha);
+      }
+    }
+  }
+}
 
 // standardise rows: y = (x - mean) / sqrt(var + eps) per row of C channels, x float32, y in the compute dtype; the statistics are
 // taken over the values ROUNDED to the compute dtype (what the matrix cores see), var biased like nn.LayerNorm (blocks.py:400-401)
@@ -333,7 +462,7 @@ __global__ __launch_bounds__(256) void kv_fixed_fill_kernel(const FixedEntry* __
 }  // namespace
 
 extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
-  JEN1_CHECK(a && a->a && a->b && a->groups && a->n_groups >= 1, "big_gemm: null argument");
+  JEN1_CHECK(a && a->a && a->b && ((a->groups && a->n_groups >= 1) || (a->c && a->n_groups <= 1)), "big_gemm: null argument");
   const int es = a->dtype == JEN1_F32 ? 4 : 2;
   const int bk = 128 / es;
   JEN1_CHECK(a->dtype == JEN1_F32 || a->dtype == JEN1_BF16, "big_gemm: dtype must be f32 or bf16");
@@ -344,7 +473,8 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
   BArgs g;
   memset(&g, 0, sizeof(g));
   g.a = a->a; g.b = a->b; g.groups = reinterpret_cast<const BGroup*>(a->groups); g.row_scale = a->row_scale;
-  g.M = a->M; g.Ntot = a->Ntot; g.K = a->K; g.lda = a->lda; g.ldb = a->ldb; g.n_groups = a->n_groups;
+  g.M = a->M; g.Ntot = a->Ntot; g.K = a->K; g.lda = a->lda; g.ldb = a->ldb; g.n_groups = a->groups ? a->n_groups : 1;
+  if (!a->groups) { g.inl.c = a->c; g.inl.bias = a->bias; g.inl.n0 = 0; g.inl.N = a->Ntot; g.inl.ldc = a->ldc; }
   g.rows_in = a->rows_in; g.rows_out = a->rows_out; g.c_f32 = a->c_f32; g.accumulate = a->accumulate;
   g.inv_rows_in = a->rows_in > 0 ? 1.0f / (float)a->rows_in : 0.f;
   g.alpha = a->alpha;
@@ -366,6 +496,27 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
     if (a->dtype == JEN1_F32) hipLaunchKernelGGL((big_gemm_nt_kernel<float, 2, 2>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((big_gemm_nt_kernel<bf16_t, 2, 2>), grid, dim3(256), 0, s, g);
   }
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream) {
+  JEN1_CHECK(a && b && c && M >= 1 && N >= 1 && K >= 1, "big_gemm_tn: bad arguments");
+  JEN1_CHECK(lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0 && K % 8 == 0, "big_gemm_tn: widths and pitches must be multiples of 8 elements");
+  JEN1_CHECK((N % 128 == 0 || lda >= ((N + 127) / 128) * 128) && (K % 128 == 0 || ldb >= ((K + 127) / 128) * 128),
+             "big_gemm_tn: a partial last column tile must still lie inside the row pitch");
+  JEN1_CHECK((int64_t)M * lda * 2 < ((int64_t)1 << 31) && (int64_t)M * ldb * 2 < ((int64_t)1 << 31), "big_gemm_tn: operand too large for 31-bit offsets");
+  TArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
+  g.tiles_n = (N + 127) / 128;
+  g.tiles_k = (K + 127) / 128;
+  const int tiles = g.tiles_n * g.tiles_k, MT = (M + 63) / 64;
+  int splits = (512 + tiles - 1) / tiles;               // two workgroups per CU
+  splits = splits < 1 ? 1 : (splits > MT ? MT : splits);
+  g.mt_per_split = (MT + splits - 1) / splits;
+  g.splits = (MT + g.mt_per_split - 1) / g.mt_per_split;
+  hipLaunchKernelGGL(big_gemm_tn_kernel, dim3(tiles * g.splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -103,8 +103,8 @@ class BGemmArgs(C.Structure):
     """mirror of ``jen1_bgemm_args`` (include/jen1_hip.h)"""
     _fields_ = [("a", c_void_p), ("b", c_void_p), ("groups", c_void_p), ("row_scale", c_void_p),
                 ("M", c_int), ("Ntot", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("n_groups", c_int),
-                ("rows_in", c_int), ("rows_out", c_int), ("c_f32", c_int), ("accumulate", c_int), ("dtype", c_int), ("reserved", c_int),
-                ("alpha", c_float), ("reserved_f", c_float)]
+                ("rows_in", c_int), ("rows_out", c_int), ("c_f32", c_int), ("accumulate", c_int), ("dtype", c_int), ("ldc", c_int),
+                ("alpha", c_float), ("reserved_f", c_float), ("c", c_void_p), ("bias", c_void_p)]
 
 
 class RepackEntry(C.Structure):
@@ -141,6 +141,7 @@ SYMBOLS = {
     "jen1_adamw_step_counted": (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 5 + [_P, _P, c_float, c_int, _P]),
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
     "jen1_big_gemm": (c_int, [C.POINTER(BGemmArgs), _P]),
+    "jen1_big_gemm_tn": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "jen1_standardize_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "jen1_kv_fixed_fill": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "jen1_train_gemm": (c_int, [C.POINTER(GemmArgs), _P]),

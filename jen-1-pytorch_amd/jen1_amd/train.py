@@ -19,6 +19,7 @@ There is no fallback: without libjen1_hip.so / a ROCm device every entry point r
 from __future__ import annotations
 
 import contextlib
+import ctypes as C
 import math
 import os
 import weakref
@@ -75,8 +76,8 @@ class TrainRuntime:
         # keep a second, transposed compute copy of every weight so that the data gradient is K-contiguous on both operands
         self.dgrad_copies = os.environ.get("JEN1_TRAIN_DGRAD_COPIES", "1") == "1"
         self.wgrad_plain_rmw = os.environ.get("JEN1_TRAIN_WGRAD_RMW", "1") == "1"
-        # plain many-row linears (the text-context K/V projections) as library GEMMs (PlainLinearFn)
-        self.blas_linears = os.environ.get("JEN1_TRAIN_BLAS_LINEARS", "1") == "1"
+        # plain many-row linears (the text-context K/V projections) on the large-M matrix-core kernels (BigLinearFn, csrc/big_gemm.hip)
+        self.big_linears = os.environ.get("JEN1_TRAIN_BIG_LINEARS", "1") == "1"
         self.skinny_gemm = os.environ.get("JEN1_TRAIN_SKINNY", "1") == "1"
         self.fused_repack = os.environ.get("JEN1_TRAIN_FUSED_REPACK", "1") == "1"      # every compute copy in one launch (jen1_repack)
         self.repack_twins = os.environ.get("JEN1_TRAIN_REPACK_TWINS", "1") == "1"      # ... a weight's two copies from one read of it
@@ -624,26 +625,51 @@ def conv_transpose1d(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: in
     return ConvFn.apply(x, weight, bias, rt, ConvGeom("convT", k, stride, padding, Lin, Lout, ci, co))
 
 
-class PlainLinearFn(Function):
-    """A PLAIN bias-free linear with many rows and a big weight (the to_kv projections of the text context, blocks.py:428: 2B x 129
-    rows, 1024 -> 1024 / 2048): three library GEMMs (hipBLASLt behind torch.matmul) instead of jen1_train_gemm, whose 64 x 64 tiles
-    reach 37 - 80 TFLOP/s on these shapes (115 us for one weight gradient).  bf16 compute only: the weight gradient is rounded to
-    bf16 once (after a float32 accumulation over the rows) before it is added to the float32 ``.grad``."""
+def _big_gemm(rt: "TrainRuntime", a2d: torch.Tensor, b2d: torch.Tensor, out: torch.Tensor, K: int) -> None:
+    """out[M][N] = a2d[M][:K] @ b2d[N][:K]^T on jen1_big_gemm (one column group)"""
+    g = L.BGemmArgs()
+    g.a, g.b, g.c, g.ldc = a2d.data_ptr(), b2d.data_ptr(), out.data_ptr(), out.stride(0)      # (one inline group: nothing to copy while capturing)
+    g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups = a2d.shape[0], b2d.shape[0], K, a2d.stride(0), b2d.stride(0), 1
+    g.dtype, g.alpha = rt.dt_of(a2d), 1.0
+    L.check(rt.lib.jen1_big_gemm(C.byref(g), rt.stream()), "jen1_big_gemm")
+
+
+class BigLinearFn(Function):
+    """A PLAIN bias-free linear with many rows and a big weight -- the to_kv projections of the text context (blocks.py:402-407,
+    :428: 2B x 129 rows, 1024 -> 512 / 1024 / 2048) -- on the large-M matrix-core kernels of csrc/big_gemm.hip: forward and data
+    gradient are jen1_big_gemm (LDS-DMA staged 128 x 128 tiles; the data gradient reads the transposed compute copy, so both are
+    K-contiguous products), the weight gradient is jen1_big_gemm_tn (both operands as they lie in memory, transposing LDS reads,
+    float32 atomics straight into ``.grad``).  bf16 compute only (float32 mode keeps jen1_train_gemm)."""
 
     @staticmethod
     def forward(ctx, x2d, weight, rt: TrainRuntime):
         wp = rt.packed(weight, "linear", x2d.dtype)[0]              # [co][pad8(ci)] in the compute dtype
-        ctx.rt, ctx.weight, ctx.wp = rt, weight, wp
+        ctx.rt, ctx.weight = rt, weight
         ctx.save_for_backward(x2d)
-        return torch.matmul(x2d, wp.t())
+        y = torch.empty((x2d.shape[0], wp.shape[0]), dtype=x2d.dtype, device=x2d.device)
+        _big_gemm(rt, x2d, wp, y, wp.shape[1])
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         (x2d,) = ctx.saved_tensors
+        rt, weight = ctx.rt, ctx.weight
         dy = dy.contiguous()
-        gw = ctx.rt.grad_of(ctx.weight)
-        ctx.rt.weight_grad(lambda: gw.add_(torch.matmul(dy.t(), x2d)[:, : gw.shape[1]]), x2d, dy)
-        dx = torch.matmul(dy, ctx.wp) if ctx.needs_input_grad[0] else None
+        co, ci = weight.shape
+        gw = rt.grad_of(weight)
+        rows = x2d.shape[0]
+
+        def wgrad():
+            L.check(rt.lib.jen1_big_gemm_tn(dy.data_ptr(), x2d.data_ptr(), gw.data_ptr(), rows, co, ci, dy.stride(0), x2d.stride(0), gw.stride(0), 1.0,
+                                            rt.stream()), "jen1_big_gemm_tn")
+        rt.weight_grad(wgrad, x2d, dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = rt.packed(weight, "linearD", x2d.dtype)[0]         # [ci][pad8(co)]: the data gradient is K-contiguous too
+            dx = torch.empty_like(x2d)
+            if x2d.shape[1] != ci:
+                dx.zero_()
+            _big_gemm(rt, dy, wt, dx, co)
         return dx, None, None
 
 
@@ -659,9 +685,9 @@ def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None, residual=None, 
         y, xa = ConvFn.apply(x.view(1, rows, x.shape[-1]), weight, bias, rt, ConvGeom("linear", 1, 1, 0, rows, rows, ci, co),
                              None if residual is None else residual.reshape(1, rows, residual.shape[-1]), True)
         return y.view(*lead, y.shape[-1]), xa.view(x.shape)
-    if (rt.blas_linears and residual is None and bias is None and x.dtype == torch.bfloat16 and rows >= 1024 and ci >= 512 and co >= 512 and co % 8 == 0
-            and x.shape[-1] == pad8(ci)):
-        return PlainLinearFn.apply(x.reshape(rows, x.shape[-1]), weight, rt).view(*lead, co)
+    if (rt.big_linears and residual is None and bias is None and x.dtype == torch.bfloat16 and rows >= 1024 and ci >= 512 and co >= 512 and co % 64 == 0
+            and ci % 64 == 0 and x.shape[-1] == ci):
+        return BigLinearFn.apply(x.reshape(rows, x.shape[-1]), weight, rt).view(*lead, co)
     y = ConvFn.apply(x.reshape(1, rows, x.shape[-1]), weight, bias, rt, ConvGeom("linear", 1, 1, 0, rows, rows, ci, co),
                      None if residual is None else residual.reshape(1, rows, residual.shape[-1]))
     return y.view(*lead, y.shape[-1])

@@ -57,6 +57,8 @@ int main(void) {
   printf("%zu %zu %zu %d\n", offsetof(jen1_conv_args, nseg), offsetof(jen1_conv_args, seg), sizeof(jen1_conv_seg), JEN1_MAX_SEG);
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(jen1_gemm_operand), offsetof(jen1_gemm_operand, zdiv), sizeof(jen1_gemm_args),
          offsetof(jen1_gemm_args, c), offsetof(jen1_gemm_args, M), offsetof(jen1_gemm_args, alpha));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(jen1_bgemm_group), sizeof(jen1_bgemm_args), offsetof(jen1_bgemm_args, M), offsetof(jen1_bgemm_args, alpha),
+         offsetof(jen1_bgemm_args, c));
   return 0;
 }
 '''
@@ -69,7 +71,8 @@ int main(void) {
     want = [C.sizeof(a), a.dtype.offset, a.gn_eps.offset, a.cfg.offset, a.zeros.offset, a.ln_fold.offset, C.sizeof(L.NormArgs),
             a.nseg.offset, a.seg.offset, C.sizeof(L.ConvSeg), L.MAX_SEG,
             C.sizeof(L.GemmOperand), L.GemmOperand.zdiv.offset, C.sizeof(L.GemmArgs), L.GemmArgs.c.offset, L.GemmArgs.M.offset,
-            L.GemmArgs.alpha.offset]
+            L.GemmArgs.alpha.offset,
+            C.sizeof(L.BGemmGroup), C.sizeof(L.BGemmArgs), L.BGemmArgs.M.offset, L.BGemmArgs.alpha.offset, L.BGemmArgs.c.offset]
     assert got == want
 
 

@@ -117,3 +117,22 @@ def test_kv_fixed_fill_matches_torch_expression():
     torch.cuda.synchronize()
     for fixed, out in keep:
         assert torch.equal(out, fixed[None] * mask[:, :, None].to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(2064, 2048, 1024), (2064, 512, 1024), (130, 128, 256), (64, 256, 128), (1, 128, 128), (200, 136, 264)])
+def test_weight_gradient_tn_matches_torch(M, N, K):
+    """C[n][k] += sum_m A[m][n] B[m][k] (both operands as they lie in memory, reduction over the rows, float32 atomics into C): ragged
+    M (rows past M read as zeros), partial last column tiles inside a wider pitch, accumulation into existing values"""
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(M + N + K)
+    lda, ldb = -(-N // 128) * 128, -(-K // 128) * 128
+    a_full = (torch.randn((M, lda), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    b_full = (torch.randn((M, ldb), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    c = torch.randn((N, K), device="cuda", generator=gen)
+    c0 = c.clone()
+    L.check(lib.jen1_big_gemm_tn(a_full.data_ptr(), b_full.data_ptr(), c.data_ptr(), M, N, K, lda, ldb, K, 0.5,
+                                 torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn")
+    torch.cuda.synchronize()
+    ref = c0 + 0.5 * (a_full[:, :N].float().t() @ b_full[:, :K].float())
+    err = float((c - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err

@@ -53,3 +53,18 @@ for (M, N, K, label) in [(2064, 2048, 1024, "to_kv fwd C=1024 (2B*129 rows)"), (
     fl = 2.0 * M * N * K
     print(f"{label:40s} M={M:5d} N={N:5d} K={K:5d}  own {t_own:8.1f} us = {fl / t_own / 1e6:7.1f} TF/s ({fl / t_own / 1e6 / 2500 * 100:4.1f} % of peak)   "
           f"hipBLASLt {t_blas:8.1f} us = {fl / t_blas / 1e6:7.1f} TF/s", flush=True)
+
+for (M, N, K, label) in [(2064, 2048, 1024, "to_kv wgrad C=1024"), (2064, 1024, 1024, "to_kv wgrad C=512"), (2064, 512, 1024, "to_kv wgrad C=256")]:
+    a = (torch.randn((M, N), device="cuda") * 0.5).to(torch.bfloat16)
+    b = (torch.randn((M, K), device="cuda") * 0.5).to(torch.bfloat16)
+    c = torch.zeros((N, K), device="cuda")
+
+    def own():
+        L.check(lib.jen1_big_gemm_tn(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, N, K, K, 1.0, torch.cuda.current_stream().cuda_stream), "tn")
+
+    def blas():
+        c.add_(torch.matmul(a.t(), b))
+    t_own, t_blas = graph_us(own), graph_us(blas)
+    fl = 2.0 * M * N * K
+    print(f"{label:40s} M={M:5d} N={N:5d} K={K:5d}  own {t_own:8.1f} us = {fl / t_own / 1e6:7.1f} TF/s ({fl / t_own / 1e6 / 2500 * 100:4.1f} % of peak)   "
+          f"hipBLASLt + add {t_blas:8.1f} us = {fl / t_blas / 1e6:7.1f} TF/s", flush=True)
