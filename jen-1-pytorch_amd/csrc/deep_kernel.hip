@@ -290,7 +290,8 @@ static_assert(CUR_OFF + NW * 32 <= BLOB, "run / slot / cursor tables must fit th
 static_assert(JEN1_DEEP_PF_B <= SLOTS && JEN1_DEEP_PF_F <= SLOTS, "the slot table covers the ring");
 constexpr int HDR_BYTES = JEN1_DEEP_MAX_PHASES * 16;
 constexpr int TICKET_OFF = HDR_BYTES + 2 * BLOB;       // LDS: headers | two descriptor slots | the next ticket | unit workspace
-constexpr int WS_OFF = TICKET_OFF + 16;
+constexpr int XW_OFF = TICKET_OFF + 16;                  // 8 x (sum, sumsq): lane sets of two waves meet here (groups of 1024 channels)
+constexpr int WS_OFF = TICKET_OFF + 16 + 64;
 static_assert(sizeof(jen1_deep_phase) <= TAB_OFF, "descriptor must fit ahead of the chunk table");
 static_assert(BLOB == NT * 8, "one 8-byte word per thread moves a blob");
 static_assert(JEN1_DEEP_MAX_PHASES <= NT, "one header per thread at start-up");
@@ -986,8 +987,18 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
         q += ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
       }
     }
-    s = lane_set_sum(s, lS);
-    q = lane_set_sum(q, lS);
+    s = lane_set_sum(s, lS < 6 ? lS : 6);
+    q = lane_set_sum(q, lS < 6 ? lS : 6);
+    if (lS == 7) {
+      // a group of 1024 channels (LayerNorm over the channels of ONE position, folded single-position self-attention: engine.py
+      // "s1q2") is 128 columns: the pair's two waves exchange their sums through LDS and add them in a fixed order
+      float2* xw = reinterpret_cast<float2*>(smem + XW_OFF);
+      if (lane == 0) xw[wk] = make_float2(s, q);
+      __syncthreads();
+      const float2 e = xw[wk & ~1], o = xw[wk | 1];
+      s = e.x + o.x;
+      q = e.y + o.y;
+    }
     const float inv_count = HF(inv_count);
     const float gn_eps = HF(gn_eps);
     const float mean = s * inv_count;
@@ -2409,7 +2420,7 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
   int lvpg = 0, lgroups = 0;
   if (p.h.norm_C) {
     const int vpg = p.h.gn_cpg / 8;
-    JEN1_CHECK(p.h.gn_cpg % 8 == 0 && (vpg & (vpg - 1)) == 0 && (a->gn_groups & (a->gn_groups - 1)) == 0 && vpg <= 64,
+    JEN1_CHECK(p.h.gn_cpg % 8 == 0 && (vpg & (vpg - 1)) == 0 && (a->gn_groups & (a->gn_groups - 1)) == 0 && vpg <= 128,
                "deep conv: %d groups of %d channels: the persistent kernel needs power-of-two groups of at least 8 channels", a->gn_groups, p.h.gn_cpg);
     while ((1 << lvpg) < vpg) ++lvpg;
     while ((1 << lgroups) < a->gn_groups) ++lgroups;
@@ -2444,7 +2455,8 @@ extern "C" int jen1_deep_phase_conv(const jen1_conv_args* a, int nb_max, jen1_de
       const int pairs = nb * a->gn_groups;
       if (pairs > JEN1_DEEP_THREADS / 2) continue;                       // at least 2 lanes per pair
       int S = JEN1_DEEP_THREADS / pairs;
-      S = S > 64 ? 64 : S;
+      const int S_max = (1 << lvpg) > 64 ? 128 : 64;                      // a lane set is one wave, or two for groups of 128 columns
+      S = S > S_max ? S_max : S;
       lS = 0;
       while ((1 << lS) < S) ++lS;
       if ((1 << lvpg) > S) continue;                                      // a lane owns a column

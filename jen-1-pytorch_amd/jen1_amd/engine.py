@@ -206,6 +206,19 @@ class Weights:
             self.v[f"{n}.o1q2.bias"] = torch.cat([bo164, wq264 @ bo164]).float().contiguous()
             self.v[f"{n}.o1q2.u"] = torch.cat([zc(Cc_), self.v[f"{n}.q2.u"]]).contiguous()
             self.v[f"{n}.o1q2.b"] = torch.cat([zc(Cc_), self.v[f"{n}.q2.bias"]]).contiguous()
+            # ONE position (the levels with T' = 1): softmax over a single key is 1, so self-attention is to_out(v) with
+            # v = to_v(norm_context(x1)) (blocks.py:355-380, :427-437), and a LayerNorm over the channels of a single position is a
+            # one-group GroupNorm -- the staging prologue of the GEMM that follows.  The whole sub-block is then
+            #   [x2 | q2_raw] = [W_o W_v | 0 ; Wq2' W_o W_v | Wq2'] [LN_ctx(x1) | x1] + [b_o ; Wq2' b_o]     (+ x1 on the x2 rows)
+            # (same biases and finish vectors as o1q2; gamma / beta of norm_context are applied by the prologue): no q / k projection, no
+            # attention phase.
+            wv64 = p[f"{a}.to_kv.weight"].double()[wq.shape[0]:]
+            wc64 = wo164 @ wv64
+            tops = torch.cat([wc64, torch.zeros(Cc_, Cc_, dtype=torch.float64, device=device)], 1)
+            bots = torch.cat([wq264 @ wc64, wq264], 1)
+            self.w[f"{n}.s1q2"] = pk(torch.cat([tops, bots], 0).float()[None]).flatten(0, 1).contiguous()
+            self.v[f"{n}.nc.g"] = f32(p[f"{a}.norm_context.weight"])
+            self.v[f"{n}.nc.b"] = f32(p[f"{a}.norm_context.bias"])
             # streaming levels: cross-attention output projection and the first FeedForward layer as ONE
             # dual-range GEMM over the K concat [a | x2]:  x3 = x2 + W_o a + b_o  (rows < C, K = a only) and
             # f = gelu(W_1 x3 + b_1) = gelu((W_1 W_o) a + W_1 x2 + W_1 b_o + b_1)   (blocks.py:485-488, :440-446)
@@ -467,6 +480,7 @@ class KernelCtx:
         self.fuse_o2_ff1 = True
         self.use_tile_kernel = True
         self.fuse_ln_proj = True
+        self.fold_single_position = True
         self.tile_min_rows = 512
         self.tile_target_wgs = 256
         self.tile_one_round = False
@@ -1193,9 +1207,22 @@ class Plan(OpBuilder):
                      extra_row=self.extra_row if eng.spec.use_xattn_time else None, ld_extra=W.kvx_ld,
                      kx_off=W.kvx_off[n], vx_off=W.kvx_off[n] + mid,
                      extra_step=self.step_idx if (self.table_mode and eng.spec.use_xattn_time) else None)
-        a1 = self.new_act(Bf, Lx, mid)
+        fold1 = (eng.fold_single_position and Lx == 1 and eng.fuse_ln_proj and self.streams(Bf, Lx, Cc) and Cc % 256 == 0 and mid % 32 == 0
+                 and Cc <= 1024)
+        a1 = None if fold1 else self.new_act(Bf, Lx, mid)
         a2 = self.new_act(Bf, Lx, mid)
-        if eng.fuse_ln_proj and self.streams(Bf, Lx, Cc) and Cc % 32 == 0 and mid % 32 == 0 and Lx * (d // 8) <= 512:
+        if fold1:
+            # one position: self-attention == to_out(to_v(norm_context(x1))) exactly (see Weights: s1q2); two GEMMs instead of
+            # GEMM -> attention -> GEMM, and the first one is 4x narrower (no q / k / v rows)
+            x1 = self.new_act(Bf, Lx, Cc, gn=True)
+            self.conv(ops, src0=x, w=W.w[f"{n}.proj"], bias=W.v[f"{n}.proj.bias"], out=x1, pro=L.PRO_GN, gn=gn_in)
+            xq2 = self.new_act(Bf, Lx, Cc + mid, rs=True)
+            self.conv(ops, src0=x1, w=W.w[f"{n}.s1q2"], bias=W.v[f"{n}.o1q2.bias"], out=xq2, pro=L.PRO_GN,
+                      gn=(1, Cc, W.v[f"{n}.nc.g"], W.v[f"{n}.nc.b"], 1e-5), residual=x1, extra_segs=[(x1, 0)], m_split=Cc, k_split=Cc // 32,
+                      flat_w=True)
+            x2 = xq2.cols(0, Cc, rs=xq2.rs)
+            self.attention(ops, q=xq2, q_off=Cc, out=a2, fin=(xq2.rs, W.v[f"{n}.o1q2.u"], W.v[f"{n}.o1q2.b"], Cc, 1e-5, 1, 0), **xattn)
+        elif eng.fuse_ln_proj and self.streams(Bf, Lx, Cc) and Cc % 32 == 0 and mid % 32 == 0 and Lx * (d // 8) <= 512:
             # 5 launches instead of 7: each projection rides with the LayerNorm-folded projection that follows it,
             # the LayerNorm finish is applied by the attention kernel (jen1_attention_fin)
             xq1 = self.new_act(Bf, Lx, Cc + 3 * mid, rs=True)
@@ -1555,6 +1582,7 @@ class Engine:
         self.fuse_ff_out = os.environ.get("JEN1_FUSE_FF_OUT", "1") != "0"
         self.fuse_o2_ff1 = os.environ.get("JEN1_FUSE_O2_FF1", "1") != "0"
         self.fuse_ln_proj = os.environ.get("JEN1_FUSE_LN_PROJ", "1") != "0"
+        self.fold_single_position = os.environ.get("JEN1_FOLD_N1", "1") != "0"        # Nq = Nk = 1 self-attention as one GEMM (exact)
         self.use_tile_kernel = os.environ.get("JEN1_TILE_KERNEL", "1") != "0"
         self.tile_min_rows = int(os.environ.get("JEN1_TILE_MIN_ROWS", "512"))
         self.tile_target_wgs = int(os.environ.get("JEN1_TILE_TARGET_WGS", "256"))
