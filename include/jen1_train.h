@@ -172,6 +172,35 @@ int jen1_lstm_layer(const float* gin, const void* whh_t, const void* skip, void*
 int jen1_lstm_layer_multi(const float* gin, const void* whh, const void* skip, void* y, float* hbuf, uint32_t* counters, int B, int T,
                           int H, int ld_y, int dtype, void* stream);
 
+/* --- the two ends of a training pass (csrc/train_glue.hip): what the reference writes as ATen elementwise / cat / reduce ops around
+ * the network, one launch each ---
+ * jen1_train_pack_input: x_t = ca[b] x0 + cb[b] noise (q_sample, gdm.py:232-243), torch.cat([x_t, input_concat_cond], 1)
+ *   (model.py:240), the CFG pair's torch.cat([x, x]) (model.py:332; nrep = 2) and the change to channel-last rows
+ *   y[(r B + b) T + t][0..ld) in `dtype` (zero padding columns); with tgt != NULL also the loss target of the objective
+ *   (gdm.py:260-266) tgt[(b T + t) C + c] = ta[b] noise + tb[b] x0 as float32 rows.  x0 / noise [B][C][T], ctx [B][Cc][T] float32.
+ * jen1_train_context: the cross-attention context rows out[r][n][0..F) of the pass in `dtype`: r < B: the text embedding
+ *   emb[r][n] (n < NL) followed by the time token tok[r] (model.py:315-316), or the learned fixed embedding for rows with
+ *   drop[r] != 0 (CFG dropout, model.py:323-328); B <= r < nrep B: the fixed embedding (the pair's unconditional half, :333).
+ *   _backward: d_fixed[n] += sum of d over the rows that read the fixed embedding; d_tok[r] = d[r][N - 1] (0 for dropped rows).
+ * jen1_time_features_fwd / _bwd: f[b] = [t, sin(2 pi t w), cos(2 pi t w), 0 ..] (LearnedPositionalEmbedding, utils/module.py:58-72;
+ *   phases in float32, evaluated left to right like the reference); dw[k] += its gradient.  t: int64 or float32 [B].
+ * jen1_cfg_loss_forward / _backward: on the network's output rows net[(r B + b) T + t][0..C) (`dtype`): the CFG combine
+ *   out_masked + (out - out_masked) s and the unbiased-std rescale (model.py:362-369), the elementwise l2 / l1 against tgt and the
+ *   mean over (C, T) (gdm.py:268-272) -> loss_ps[b] (float32, zeroed by the call); backward: dnet = d loss / d net for
+ *   upstream gradients gps[b] of the per-sample losses, both halves of the pair, padding columns zeroed. */
+int jen1_train_pack_input(const float* x0, const float* noise, const float* ca, const float* cb, const float* ctx, void* y, int B, int C, int Cc,
+                          int T, int ld, int nrep, const float* ta, const float* tb, float* tgt, int dtype, void* stream);
+int jen1_train_context(const float* emb, const float* tok, const float* fixed, const uint8_t* drop, void* out, int B, int NL, int N, int F,
+                       int nrep, int dtype, void* stream);
+int jen1_train_context_backward(const void* d, const uint8_t* drop, float* d_fixed, float* d_tok, int B, int NL, int N, int F, int nrep, int dtype,
+                                void* stream);
+int jen1_time_features_fwd(const void* t, int t_is_float, const float* w, float* f, int B, int half, int ld, void* stream);
+int jen1_time_features_bwd(const void* t, int t_is_float, const float* w, const float* df, float* dw, int B, int half, int ld, void* stream);
+int jen1_cfg_loss_forward(const void* net, const float* tgt, float* loss_ps, int B, int C, int T, int ld, int nrep, float embedding_scale,
+                          int scale_cfg, float scale_phi, int l1, int dtype, void* stream);
+int jen1_cfg_loss_backward(const void* net, const float* tgt, const float* gps, void* dnet, int B, int C, int T, int ld, int nrep,
+                           float embedding_scale, int scale_cfg, float scale_phi, int l1, int dtype, void* stream);
+
 /* --- the skip concat of the up path (blocks.py:732-734: torch.cat([x, skip * 2^-1/2], dim=channels)) on channel-last rows ---
  * jen1_concat2: out[row] = [a[row][0..Ca) | scale_b * b[row][0..Cb)];  jen1_split2 (its backward): da[row] = d[row][0..Ca),
  * db[row] = scale_b * d[row][Ca..Ca+Cb).  Rows are dense (pitch = channel count), channel counts multiples of 8. */

@@ -2699,7 +2699,13 @@ extern "C" int jen1_deep_link(jen1_deep_phase* phases, int n_phases, int nwg, vo
       // same rows once per tile (second K-reduction scratch behind the first)
       int mrep = 1;
       const char* cap_s = getenv("JEN1_DEEP_UNIT_CAP");          // tuning: at most this many units per phase (default: one per workgroup)
-      const int cap = cap_s ? atoi(cap_s) : nwg;
+      int cap = cap_s ? atoi(cap_s) : nwg;
+      // a phase in front of a cross-attention keeps half of the workgroups free: an attention unit stages its cached text K / V^T
+      // (up to 129 x 128 x 2 elements) BEFORE its dependency wait, ~4.7 us that are hidden only on a workgroup that sat out the phase before
+      // (tuning knob, off: measured 857 -> 875 us per launch at a cap of 128 or 192 -- the second M tile of a unit costs more than the
+      // exposed staging)
+      static const int cap_attn = getenv("JEN1_DEEP_CAP_BEFORE_ATTN") ? atoi(getenv("JEN1_DEEP_CAP_BEFORE_ATTN")) : 0;
+      if (cap_attn > 0 && p + 1 < n_phases && phases[p + 1].h.kind == JEN1_DEEP_ATTN && cap_attn < cap) cap = cap_attn;
       const int nch = P.h.n_chunks < 1 ? 1 : P.h.n_chunks;
       while (mrep < 8 && (P.h.MT / mrep) * P.h.groups_n * nch > cap && P.h.MT % (2 * mrep) == 0 && P.h.mt_split % (2 * mrep) == 0) mrep *= 2;
       if (mrep > 1 && P.h.lds_bytes + P.h.red_bytes <= LDS_BUDGET) {

@@ -55,6 +55,7 @@ class GaussianDiffusion(torch.nn.Module):
         self.cfg_dropout_proba, self.embedding_scale = cfg_dropout_proba, embedding_scale
         self.batch_cfg, self.scale_cfg, self.use_fp16 = batch_cfg, scale_cfg, use_fp16
         self.loss_fn = F.l1_loss if loss_type == "l1" else F.mse_loss
+        self.loss_type = loss_type
         self.num_timesteps = steps
         self.sampling_timesteps = steps if sampling_timesteps is None else sampling_timesteps
         assert self.sampling_timesteps <= self.num_timesteps
@@ -306,9 +307,14 @@ class GaussianDiffusion(torch.nn.Module):
         trainer merges task sub-batches that share the causal flag into one pass and weights the samples itself)."""
         if noise is None:
             noise = torch.rand_like(x_start)
-        x_t = self.q_sample(x_start, t, noise=noise)
         if torch.is_grad_enabled() and getattr(model, "training", False) and hasattr(model, "train_graph"):
             model = model.train_graph()          # the differentiable HIP path (jen1_amd/train.py)
+        if hasattr(model, "diffusion_loss") and torch.is_grad_enabled():
+            # TrainGraph: q_sample, the CFG pair, the objective's target, the loss and its gradient as fused launches around the network
+            per_sample = model.diffusion_loss(self, x_start, t, conditioning, noise, causal, dropout_rows)
+            if per_sample is not None:
+                return per_sample if reduction == "none" else per_sample.mean()
+        x_t = self.q_sample(x_start, t, noise=noise)
         model_out = self._call(model, x_t, t, conditioning, causal, dropout_rows)
         if self.objective == "noise":
             target = noise

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # 
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "deep_kernel.hip", "elementwise.hip",
-           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip", "big_gemm.hip"]
+           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip", "big_gemm.hip", "train_glue.hip"]
 
 F32, BF16, FP8 = 0, 1, 2
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -155,6 +155,13 @@ SYMBOLS = {
     "jen1_gn_backward_add": (c_int, [_P] * 6 + [c_int] + [_P] * 7 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_ln_backward_add": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
     "jen1_repack": (c_int, [_P, c_int, c_int, c_int, _P]),
+    "jen1_train_pack_input": (c_int, [_P] * 6 + [c_int] * 6 + [_P, _P, _P, c_int, _P]),
+    "jen1_train_context": (c_int, [_P] * 5 + [c_int] * 6 + [_P]),
+    "jen1_train_context_backward": (c_int, [_P] * 4 + [c_int] * 6 + [_P]),
+    "jen1_time_features_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "jen1_time_features_bwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "jen1_cfg_loss_forward": (c_int, [_P, _P, _P] + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, _P]),
+    "jen1_cfg_loss_backward": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, _P]),
     "jen1_concat2": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_int, _P]),
     "jen1_split2": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_int, _P]),
     "jen1_gn_forward": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),

@@ -78,6 +78,10 @@ class TrainRuntime:
         self.wgrad_plain_rmw = os.environ.get("JEN1_TRAIN_WGRAD_RMW", "1") == "1"
         # plain many-row linears (the text-context K/V projections) on the large-M matrix-core kernels (BigLinearFn, csrc/big_gemm.hip)
         self.big_linears = os.environ.get("JEN1_TRAIN_BIG_LINEARS", "1") == "1"
+        # the ends of a pass (q_sample / cat / layout change, context rows, time features, CFG combine + loss) as own launches
+        # (csrc/train_glue.hip) instead of ATen elementwise / cat / reduce kernels
+        self.fused_glue = os.environ.get("JEN1_TRAIN_FUSED_GLUE", "1") == "1"
+        self._consts: Dict[tuple, torch.Tensor] = {}
         self.skinny_gemm = os.environ.get("JEN1_TRAIN_SKINNY", "1") == "1"
         self.fused_repack = os.environ.get("JEN1_TRAIN_FUSED_REPACK", "1") == "1"      # every compute copy in one launch (jen1_repack)
         self.repack_twins = os.environ.get("JEN1_TRAIN_REPACK_TWINS", "1") == "1"      # ... a weight's two copies from one read of it
@@ -104,6 +108,13 @@ class TrainRuntime:
         # a tensor that feeds a norm / linear AND a branch around it: forked, its gradients merge inside the layer's backward kernel
         self.fork_norms = os.environ.get("JEN1_TRAIN_FORK", "1") == "1"
         self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
+
+    def const(self, n: int, v: float) -> torch.Tensor:
+        """a cached float32 vector of n copies of v (read-only operands of the glue kernels)"""
+        t = self._consts.get((n, v))
+        if t is None:
+            t = self._consts[(n, v)] = torch.full((n,), float(v), dtype=torch.float32, device=self.device)
+        return t
 
     # ------------------------------------------------------------------ plumbing
     def stream(self) -> int:
@@ -1065,6 +1076,88 @@ def attention_core(rt, q, kv, heads: int, causal, kv_mask=None):
 
 
 # =====================================================================================================================
+# the two ends of a pass (csrc/train_glue.hip): input packing, context rows, time features, CFG combine + loss
+# =====================================================================================================================
+class ContextRowsFn(Function):
+    """cat([embedding, time token]) (model.py:315-316), CFG-dropout rows swapped to the fixed embedding (:323-328), the pair's
+    unconditional half (:333), cast to the compute dtype: one launch.  Gradients: the time token's as a tensor, the fixed
+    embedding's straight into its ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, tok, fixed, emb, drop, rt: TrainRuntime, nrep: int):
+        B, NL, F = emb.shape
+        N = NL + (1 if tok is not None else 0)
+        out = torch.empty((nrep * B, N, F), dtype=rt.tdtype, device=emb.device)
+        d8 = None if drop is None else drop.to(torch.uint8)
+        L.check(rt.lib.jen1_train_context(emb.data_ptr(), None if tok is None else tok.data_ptr(), fixed.data_ptr(),
+                                          None if d8 is None else d8.data_ptr(), out.data_ptr(), B, NL, N, F, nrep, rt.dt, rt.stream()), "jen1_train_context")
+        ctx.rt, ctx.fixed, ctx.d8, ctx.dims, ctx.has_tok = rt, fixed, d8, (B, NL, N, F, nrep), tok is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        rt = ctx.rt
+        B, NL, N, F, nrep = ctx.dims
+        d = d.contiguous()
+        gf = rt.grad_of(ctx.fixed)
+        d_tok = torch.empty((B, F), dtype=torch.float32, device=d.device) if ctx.has_tok else None
+        L.check(rt.lib.jen1_train_context_backward(d.data_ptr(), None if ctx.d8 is None else ctx.d8.data_ptr(), gf.data_ptr(),
+                                                   None if d_tok is None else d_tok.data_ptr(), B, NL, N, F, nrep, rt.dt_of(d), rt.stream()),
+                "jen1_train_context_backward")
+        return d_tok, None, None, None, None, None
+
+
+class TimeFeaturesFn(Function):
+    """[t, sin(2 pi t w), cos(2 pi t w)] zero-padded to a multiple of 8 columns (LearnedPositionalEmbedding, utils/module.py:58-72)"""
+
+    @staticmethod
+    def forward(ctx, t, w, rt: TrainRuntime):
+        B, half = t.shape[0], w.shape[0]
+        ld = pad8(2 * half + 1)
+        f = torch.empty((B, ld), dtype=torch.float32, device=w.device)
+        tt = t if t.dtype in (torch.int64, torch.float32) else (t.to(torch.float32) if t.is_floating_point() else t.to(torch.int64))
+        isf = 1 if tt.dtype == torch.float32 else 0
+        L.check(rt.lib.jen1_time_features_fwd(tt.data_ptr(), isf, w.data_ptr(), f.data_ptr(), B, half, ld, rt.stream()), "jen1_time_features_fwd")
+        ctx.rt, ctx.w, ctx.t, ctx.isf, ctx.dims = rt, w, tt, isf, (B, half, ld)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        rt = ctx.rt
+        B, half, ld = ctx.dims
+        df = df.contiguous()
+        gw = rt.grad_of(ctx.w)
+        L.check(rt.lib.jen1_time_features_bwd(ctx.t.data_ptr(), ctx.isf, ctx.w.data_ptr(), df.data_ptr(), gw.data_ptr(), B, half, ld, rt.stream()),
+                "jen1_time_features_bwd")
+        return None, None, None
+
+
+class CfgLossFn(Function):
+    """network output rows [nrep B, T, ld] -> per-sample losses [B]: CFG combine + unbiased-std rescale (model.py:362-369), l2 / l1
+    against the target rows, mean over (C, T) (gdm.py:268-272); the backward writes the gradient of the rows directly."""
+
+    @staticmethod
+    def forward(ctx, net, tgt, rt: TrainRuntime, B: int, C: int, nrep: int, scale: float, scale_cfg: bool, phi: float, l1: bool):
+        assert net.is_contiguous() and net.shape[0] == nrep * B
+        T, ld = net.shape[1], net.shape[2]
+        loss = torch.empty((B,), dtype=torch.float32, device=net.device)
+        a = (B, C, T, ld, nrep, float(scale), 1 if scale_cfg else 0, float(phi), 1 if l1 else 0, rt.dt_of(net))
+        L.check(rt.lib.jen1_cfg_loss_forward(net.data_ptr(), tgt.data_ptr(), loss.data_ptr(), *a, rt.stream()), "jen1_cfg_loss_forward")
+        ctx.rt, ctx.a = rt, a
+        ctx.save_for_backward(net, tgt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        net, tgt = ctx.saved_tensors
+        rt = ctx.rt
+        g = g.to(torch.float32).contiguous()
+        dnet = torch.empty_like(net)
+        L.check(rt.lib.jen1_cfg_loss_backward(net.data_ptr(), tgt.data_ptr(), g.data_ptr(), dnet.data_ptr(), *ctx.a, rt.stream()), "jen1_cfg_loss_backward")
+        return dnet, None, None, None, None, None, None, None, None, None
+
+
+# =====================================================================================================================
 # the differentiable UNet (mirrors UNet1d.forward model.py:225-265 and UNetCFG1d.forward model.py:299-376)
 # =====================================================================================================================
 class TrainGraph:
@@ -1137,11 +1230,14 @@ class TrainGraph:
     def _time_features(self, prefix: str, t: torch.Tensor) -> torch.Tensor:
         """LearnedPositionalEmbedding + Linear (utils/module.py:58-79) in float32"""
         w = self.p[f"{prefix}.0.weights"]
-        x = t.to(torch.float32)[:, None]
-        freqs = x * w[None, :] * 2 * math.pi
-        f = torch.cat([x, freqs.sin(), freqs.cos()], dim=-1)
-        fp = torch.zeros((f.shape[0], pad8(f.shape[1])), dtype=torch.float32, device=f.device)
-        fp = torch.cat([f, fp[:, f.shape[1]:]], dim=-1)
+        if self.rt.fused_glue:
+            fp = TimeFeaturesFn.apply(t, w, self.rt)
+        else:
+            x = t.to(torch.float32)[:, None]
+            freqs = x * w[None, :] * 2 * math.pi
+            f = torch.cat([x, freqs.sin(), freqs.cos()], dim=-1)
+            fp = torch.zeros((f.shape[0], pad8(f.shape[1])), dtype=torch.float32, device=f.device)
+            fp = torch.cat([f, fp[:, f.shape[1]:]], dim=-1)
         return linear(self.rt, fp, self.p[f"{prefix}.1.weight"], self.p[f"{prefix}.1.bias"])
 
     def mapping(self, t: torch.Tensor) -> torch.Tensor:
@@ -1240,10 +1336,15 @@ class TrainGraph:
     # ------------------------------------------------------------------ UNet1d.forward
     def unet(self, x: torch.Tensor, t: torch.Tensor, embedding: torch.Tensor, embedding_mask, ctx_channels, causal: bool) -> torch.Tensor:
         """x [B, C, T] float32 (+ ctx_channels [B, 129, T]) -> [B, out_channels, T] float32"""
-        rt, p, sp = self.rt, self.p, self.spec
+        sp = self.spec
         if ctx_channels is not None:
             x = torch.cat([x, ctx_channels.to(x.dtype)], dim=1)
-        h = self._to_rows(x)
+        h = self.unet_rows(self._to_rows(x), t, embedding, embedding_mask, causal)
+        return h[:, :, :sp.out_channels].to(torch.float32).transpose(1, 2)
+
+    def unet_rows(self, h: torch.Tensor, t: torch.Tensor, embedding: torch.Tensor, embedding_mask, causal) -> torch.Tensor:
+        """the same on channel-last rows: h [B, T, pad8(C_in + C_ctx)] in the compute dtype -> [B, T, pad8(out_channels)]"""
+        rt, p, sp = self.rt, self.p, self.spec
         mp = self.mapping(t)
         smap = silu(rt, mp).to(rt.tdtype)
         films = self.films(smap)
@@ -1282,8 +1383,7 @@ class TrainGraph:
                 h = conv_transpose1d(rt, h, w, b, f, f // 2 + f % 2, f % 2)
         h = h + skips_list.pop()                                         # model.py:261
         h = self._mark(h, "to_out")
-        h = self.res_block(sp.to_out, h, smap, False, films)
-        return h[:, :, :sp.out_channels].to(torch.float32).transpose(1, 2)
+        return self.res_block(sp.to_out, h, smap, False, films)
 
     # ------------------------------------------------------------------ UNetCFG1d.forward
     def forward(self, x: torch.Tensor, time: torch.Tensor, *, embedding: torch.Tensor, embedding_mask: Optional[torch.Tensor] = None,
@@ -1336,6 +1436,70 @@ class TrainGraph:
                 return scale_phi * (out_cfg * (out_std / out_cfg_std)) + (1 - scale_phi) * out_cfg
             return out_cfg
         return self.unet(x, time, emb.contiguous(), mask, ctx, causal)
+
+    def diffusion_loss(self, gd, x_start: torch.Tensor, t: torch.Tensor, conditioning, noise: torch.Tensor, causal, dropout_rows=None):
+        """``GaussianDiffusion.training_loosses`` (gdm.py:245-272) around this network with both ends fused: q_sample + concat + CFG
+        pair + layout change in one launch, the context rows in one, the CFG combine + rescale + loss in one (and one each way
+        back) -- per-sample losses [B].  None when the settings need the literal path (an unbatched CFG pair)."""
+        rt, p, sp = self.rt, self.p, self.spec
+        cfg = gd.embedding_scale != 1.0
+        if not rt.fused_glue or (cfg and not gd.batch_cfg) or conditioning.get("global_cond") is not None or sp.out_channels > 256:
+            return None
+        self.rt.abandon_weight_grads()
+        rows_c = CausalRows(causal) if torch.is_tensor(causal) else None
+        causal = rows_c if rows_c is not None else bool(causal)
+        nrep = 2 if cfg else 1
+        if nrep == 2 and rows_c is not None:
+            causal = rows_c.twice()
+        B, C, T = x_start.shape
+        dev = x_start.device
+        x_start = x_start.to(torch.float32).contiguous()
+        noise = noise.to(torch.float32).contiguous()
+        ca = gd.sqrt_alphas_cumprod.to(dev)[t].to(torch.float32).contiguous()
+        cb = gd.sqrt_one_minus_alphas_cumprod.to(dev)[t].to(torch.float32).contiguous()
+        if gd.objective == "noise":
+            ta, tb = rt.const(B, 1.0), rt.const(B, 0.0)
+        elif gd.objective == "x0":
+            ta, tb = rt.const(B, 0.0), rt.const(B, 1.0)
+        elif gd.objective == "v":
+            ta, tb = ca, -cb
+        else:
+            raise ValueError(f"unknown objective {gd.objective}")
+        ctxc = conditioning["input_concat_cond"] if sp.ctx_ch0 else None
+        if sp.ctx_ch0:
+            assert ctxc is not None, "Missing context"                    # model.py:189
+            ctxc = ctxc.to(torch.float32).contiguous()
+        Cc = 0 if ctxc is None else ctxc.shape[1]
+        ld = pad8(C + Cc)
+        h = torch.empty((nrep * B, T, ld), dtype=rt.tdtype, device=dev)
+        tgt = torch.empty((B, T, C), dtype=torch.float32, device=dev)
+        L.check(rt.lib.jen1_train_pack_input(x_start.data_ptr(), noise.data_ptr(), ca.data_ptr(), cb.data_ptr(), None if ctxc is None else ctxc.data_ptr(),
+                                             h.data_ptr(), B, C, Cc, T, ld, nrep, ta.data_ptr(), tb.data_ptr(), tgt.data_ptr(), rt.dt, rt.stream()),
+                "jen1_train_pack_input")
+        # context rows (model.py:315-337)
+        emb = conditioning["cross_attn_cond"].to(torch.float32).contiguous()
+        mask = conditioning["cross_attn_masks"]
+        tok = gelu(rt, self._time_features("to_time_embedding.0", t)) if sp.use_xattn_time else None
+        drop = None
+        if gd.cfg_dropout_proba > 0.0:
+            if dropout_rows is not None:
+                drop = dropout_rows.to(torch.bool)
+            elif gd.cfg_dropout_proba >= 1.0:
+                drop = torch.ones(B, dtype=torch.bool, device=dev)
+            else:   # rand_bool (utils/module.py:36-42)
+                drop = torch.bernoulli(torch.full((B,), float(gd.cfg_dropout_proba), device=dev)).to(torch.bool)
+        fixed = p["fixed_embedding.embedding.weight"]
+        ctx_rows = ContextRowsFn.apply(tok, fixed, emb, drop, rt, nrep)
+        if mask is not None:
+            mask = mask.to(torch.float32)
+            if sp.use_xattn_time:
+                mask = torch.cat([mask, rt.const(B, 1.0)[:, None]], dim=1)
+            if nrep == 2:
+                mask = torch.cat([mask, mask], 0)
+        t2 = torch.cat([t, t], 0) if nrep == 2 else t
+        out = self.unet_rows(h, t2, ctx_rows, mask, causal)
+        return CfgLossFn.apply(out.contiguous(), tgt, rt, B, sp.out_channels, nrep, float(gd.embedding_scale), bool(gd.scale_cfg), 0.7,
+                               getattr(gd, "loss_type", "l2") == "l1")
 
     def __call__(self, *args, **kwargs) -> torch.Tensor:
         """``forward``; a call from the legacy default stream is moved to a private stream.  A backward pass that ran
