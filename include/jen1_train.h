@@ -107,6 +107,11 @@ int jen1_gn_backward(const void* dy, const void* x, const float* sums, const flo
 int jen1_gn_backward_add(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,
                          int film_ld, void* dx, const void* dx_add, float* dgamma, float* dbeta, void* dfilm, float* P, float* Gm, int B,
                          int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
+/* ... and with a second one, dx_add2 (may be NULL): a ResnetBlock1d input that is also a skip connection of the U-Net (blocks.py:641-643
+ * collects every block output for the up path, :732-734 consumes it) receives three gradients. */
+int jen1_gn_backward_add2(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta, const void* film,
+                          int film_ld, void* dx, const void* dx_add, const void* dx_add2, float* dgamma, float* dbeta, void* dfilm, float* P,
+                          float* Gm, int B, int L, int C, int ld, int groups, float eps, int flags, int dtype, void* stream);
 
 /* --- LayerNorm over the last axis (blocks.py:400-401): stats[rows][2] = (mean, rstd) --- */
 int jen1_ln_forward(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, int ld,

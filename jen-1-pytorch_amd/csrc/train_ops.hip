@@ -88,6 +88,7 @@ struct GnDev {
   const void* x; const void* dy; const float* sums; const float* gamma; const float* beta; const void* film;
   void* y; float* P; float* Gm; float* dgamma; float* dbeta; float* dfilm;
   const void* dx_add;      // backward: added to dx (the gradient that reached the same tensor along another branch), or NULL
+  const void* dx_add2;     // ... and a third branch (a ResnetBlock1d input that is also a skip connection of the U-Net), or NULL
   int B, L, C, ld, groups, cpg, film_ld, flags, film_bf16;
   float eps, inv_count;
 };
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_kernel(const GnDev g, void* dx_)
     const float* gm = g.Gm + ((long long)b * g.groups + c / g.cpg) * 2;
     float o = rstd * (dxh - gm[0] - xh * gm[1]);
     if (g.dx_add != nullptr) o += (float)reinterpret_cast<const T*>(g.dx_add)[row * g.ld + c];
+    if (g.dx_add2 != nullptr) o += (float)reinterpret_cast<const T*>(g.dx_add2)[row * g.ld + c];
     dx[row * g.ld + c] = (T)o;
   }
 }
@@ -347,6 +349,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_vec_kernel(const GnDev g, void* 
     if (g.dx_add != nullptr) {
       float ad[8];
       load8(reinterpret_cast<const T*>(g.dx_add) + row * g.C + c0, ad);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += ad[j];
+    }
+    if (g.dx_add2 != nullptr) {
+      float ad[8];
+      load8(reinterpret_cast<const T*>(g.dx_add2) + row * g.C + c0, ad);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += ad[j];
     }
@@ -569,6 +577,12 @@ __global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* 
         load8(x + (long long)(t + u * RT) * g.C, w[u]);
         load8(dy + (long long)(t + u * RT) * g.C, d[u]);
         if (g.dx_add != nullptr) load8(reinterpret_cast<const T*>(g.dx_add) + base + (long long)(t + u * RT) * g.C, ad[u]);
+        if (g.dx_add2 != nullptr) {
+          float a2[8];
+          load8(reinterpret_cast<const T*>(g.dx_add2) + base + (long long)(t + u * RT) * g.C, a2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ad[u][j] = (g.dx_add != nullptr ? ad[u][j] : 0.f) + a2[j];
+        }
       }
 #pragma unroll
     for (int u = 0; u < GU; ++u)
@@ -579,7 +593,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_fused_kernel(const GnDev g, void* 
           float df = d[u][j];
           if (g.flags & 1) df *= silu_grad_t<T>((xh * ga[j] + be[j]) * s1[j] + s0[j]);
           w[u][j] = rstd * (df * s1[j] * ga[j] - m1 - xh * m2);
-          if (g.dx_add != nullptr) w[u][j] += ad[u][j];
+          if (g.dx_add != nullptr || g.dx_add2 != nullptr) w[u][j] += ad[u][j];
         }
         store8(dx + (long long)(t + u * RT) * g.C, w[u]);
       }
@@ -1088,14 +1102,23 @@ extern "C" int jen1_gn_backward_add(const void* dy, const void* x, const float* 
                                     const void* film, int film_ld, void* dx, const void* dx_add, float* dgamma, float* dbeta,
                                     void* dfilm, float* P, float* Gm, int B, int L, int C, int ld, int groups, float eps, int flags,
                                     int dtype, void* stream) {
+  return jen1_gn_backward_add2(dy, x, sums, gamma, beta, film, film_ld, dx, dx_add, nullptr, dgamma, dbeta, dfilm, P, Gm, B, L, C, ld, groups, eps,
+                               flags, dtype, stream);
+}
+
+extern "C" int jen1_gn_backward_add2(const void* dy, const void* x, const float* sums, const float* gamma, const float* beta,
+                                     const void* film, int film_ld, void* dx, const void* dx_add, const void* dx_add2, float* dgamma,
+                                     float* dbeta, void* dfilm, float* P, float* Gm, int B, int L, int C, int ld, int groups, float eps,
+                                     int flags, int dtype, void* stream) {
   if (check_dtype(dtype, "jen1_gn_backward")) return 1;
-  JEN1_CHECK(((uintptr_t)dx_add & 15) == 0, "jen1_gn_backward_add: dx_add must start on a 16-byte boundary");
+  JEN1_CHECK((((uintptr_t)dx_add | (uintptr_t)dx_add2) & 15) == 0, "jen1_gn_backward_add: dx_add must start on a 16-byte boundary");
   GnDev g;
   if (gn_fill(g, "jen1_gn_backward", x, sums, gamma, beta, film, film_ld, B, L, C, ld, groups, eps, flags)) return 1;
   JEN1_CHECK(dy && dx && dgamma && dbeta && P && Gm, "jen1_gn_backward: NULL argument");
   JEN1_CHECK((film == nullptr) == (dfilm == nullptr), "jen1_gn_backward: dfilm must be given exactly when film is");
   g.dy = dy; g.P = P; g.Gm = Gm; g.dgamma = dgamma; g.dbeta = dbeta; g.dfilm = reinterpret_cast<float*>(dfilm);
   g.dx_add = dx_add;
+  g.dx_add2 = dx_add2;
   g.film_bf16 = dtype == JEN1_BF16 ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int lvpg = 0;

@@ -153,6 +153,7 @@ SYMBOLS = {
     "jen1_gn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_gn_backward": (c_int, [_P] * 6 + [c_int] + [_P] * 6 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_gn_backward_add": (c_int, [_P] * 6 + [c_int] + [_P] * 7 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
+    "jen1_gn_backward_add2": (c_int, [_P] * 6 + [c_int] + [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_ln_backward_add": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
     "jen1_repack": (c_int, [_P, c_int, c_int, c_int, _P]),
     "jen1_train_pack_input": (c_int, [_P] * 6 + [c_int] * 6 + [_P, _P, _P, c_int, _P]),

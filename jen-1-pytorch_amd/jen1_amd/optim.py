@@ -79,7 +79,11 @@ class FusedAdamW:
         self._steps.fill_(int(n))
 
     def zero_grad(self) -> None:
-        self.flat_grad.zero_()
+        g = self.flat_grad
+        if g.is_cuda:
+            L.check(L.load().jen1_memset_zero(g.data_ptr(), g.numel() * 4, torch.cuda.current_stream(g.device).cuda_stream), "jen1_memset_zero")
+        else:
+            g.zero_()
 
     def grad_norm(self) -> torch.Tensor:
         """total L2 norm of the gradient as a device scalar (what clip_grad_norm_ returns)"""

@@ -107,6 +107,8 @@ class TrainRuntime:
         self.small_attn = os.environ.get("JEN1_TRAIN_SMALL_ATTN", "1") == "1"
         # a tensor that feeds a norm / linear AND a branch around it: forked, its gradients merge inside the layer's backward kernel
         self.fork_norms = os.environ.get("JEN1_TRAIN_FORK", "1") == "1"
+        # ... and a skip connection of the U-Net / the text context of the 13 cross-attentions: handed on as aliases by their consumers
+        self.fork_skips = os.environ.get("JEN1_TRAIN_FORK_SKIPS", "1") == "1"
         self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
 
     def const(self, n: int, v: float) -> torch.Tensor:
@@ -545,12 +547,15 @@ class ConvFn(Function):
         ctx.has_res = residual is not None
         ctx.save_for_backward(x)
         y = _conv_forward(rt, x, wp, None if bias is None else bias.detach(), g, None if residual is None else residual.detach().contiguous())
+        ctx.set_materialize_grads(False)
         return (y, x.view_as(x)) if fork else y
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
         (x,) = ctx.saved_tensors
         rt, g = ctx.rt, ctx.g
+        if dy is None:
+            return None, None, None, None, None, None, None
         dy = dy.contiguous()
         if dskip is not None:
             dskip = dskip.contiguous().view(-1, g.L_in, x.shape[-1])
@@ -608,7 +613,7 @@ class CausalRows:
         return CausalRows(torch.cat([self.flags, self.flags]))
 
 
-def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal, residual=None) -> torch.Tensor:
+def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, causal, residual=None, fork: bool = False) -> torch.Tensor:
     """_Conv1d (blocks.py:34-53): total padding k - 1, all on the left when causal else split evenly.  ``residual`` (the output's
     shape) is added in the GEMM's epilogue.  ``causal``: bool, or CausalRows (the flag per batch element)."""
     co, ci, k = weight.shape
@@ -616,9 +621,9 @@ def conv1d_same(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: int, ca
     if isinstance(causal, CausalRows) and k > 1:
         assert causal.flags.shape[0] == B
         g = ConvGeom("conv", k, stride, (k - 1) // 2, Lin, (Lin - 1) // stride + 1, ci, co, pad_b=causal.pads(k))
-        return ConvFn.apply(x, weight, bias, rt, g, residual)
+        return ConvFn.apply(x, weight, bias, rt, g, residual, fork)
     pad = (k - 1) if (causal is True) else (k - 1) // 2
-    return ConvFn.apply(x, weight, bias, rt, ConvGeom("conv", k, stride, pad, Lin, (Lin - 1) // stride + 1, ci, co), residual)
+    return ConvFn.apply(x, weight, bias, rt, ConvGeom("conv", k, stride, pad, Lin, (Lin - 1) // stride + 1, ci, co), residual, fork)
 
 
 def conv1d_zero_pad(rt: TrainRuntime, x: torch.Tensor, weight, bias, padding: int) -> torch.Tensor:
@@ -736,21 +741,30 @@ class GroupNormFn(Function):
         ctx.rt, ctx.C, ctx.groups, ctx.eps, ctx.silu, ctx.gamma, ctx.beta = rt, C, groups, eps, silu, gamma, beta
         ctx.has_film = film is not None
         ctx.film_ld, ctx.dfilm_slot = film_ld, (dfilm_slot if film is not None else None)
-        if fork:
-            ctx.save_for_backward(x, sums, film if film is not None else x.new_empty(0))
-            return y, x.view_as(x)
         ctx.save_for_backward(x, sums, film if film is not None else x.new_empty(0))
+        ctx.set_materialize_grads(False)           # an alias nobody used comes back as None, not as a tensor of zeros
+        if fork == 2:                              # ... and a second alias: the tensor is also a skip connection of the U-Net
+            return y, x.view_as(x), x.view_as(x)
+        if fork:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy, dskip=None):
+    def backward(ctx, dy, dskip=None, dskip2=None):
         x, sums, film = ctx.saved_tensors
         rt, C, groups = ctx.rt, ctx.C, ctx.groups
         B, Lx, ld = x.shape
+        if dy is None:
+            dy = torch.zeros_like(x)
         dy = dy.contiguous()
+        if dskip is None:
+            dskip, dskip2 = dskip2, None
         if dskip is not None:
             dskip = dskip.contiguous()
             assert dskip.shape == x.shape and dskip.dtype == x.dtype
+        if dskip2 is not None:
+            dskip2 = dskip2.contiguous()
+            assert dskip2.shape == x.shape and dskip2.dtype == x.dtype
         dt = rt.dt_of(x)
         dx = (torch.zeros_like if ld != C else torch.empty_like)(x)
         P = torch.empty((B, C, 4), dtype=torch.float32, device=x.device)
@@ -760,12 +774,13 @@ class GroupNormFn(Function):
         if ctx.has_film:
             dfilm = slot.view if slot is not None else torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
         flags = (1 if ctx.silu else 0) | (2 if slot is not None else 0)
-        L.check(rt.lib.jen1_gn_backward_add(dy.data_ptr(), x.data_ptr(), sums.data_ptr(), ctx.gamma.data_ptr(), ctx.beta.data_ptr(),
-                                            film.data_ptr() if ctx.has_film else None, ctx.film_ld,
-                                            dx.data_ptr(), None if dskip is None else dskip.data_ptr(),
-                                            rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(),
-                                            None if dfilm is None else dfilm.data_ptr(), P.data_ptr(), Gm.data_ptr(), B, Lx, C, ld,
-                                            groups, float(ctx.eps), flags, dt, rt.stream()), "jen1_gn_backward_add")
+        L.check(rt.lib.jen1_gn_backward_add2(dy.data_ptr(), x.data_ptr(), sums.data_ptr(), ctx.gamma.data_ptr(), ctx.beta.data_ptr(),
+                                             film.data_ptr() if ctx.has_film else None, ctx.film_ld,
+                                             dx.data_ptr(), None if dskip is None else dskip.data_ptr(),
+                                             None if dskip2 is None else dskip2.data_ptr(),
+                                             rt.grad_of(ctx.gamma).data_ptr(), rt.grad_of(ctx.beta).data_ptr(),
+                                             None if dfilm is None else dfilm.data_ptr(), P.data_ptr(), Gm.data_ptr(), B, Lx, C, ld,
+                                             groups, float(ctx.eps), flags, dt, rt.stream()), "jen1_gn_backward_add2")
         if slot is not None:
             df = slot.view                     # (written in place: FilmBankFn.backward recognises its own slice)
             slot.written()
@@ -781,9 +796,11 @@ class GroupNormFn(Function):
 
 
 def group_norm(rt, x, gamma, beta, C, groups, eps, film=None, silu=False, dfilm_slot=None, fork=False):
-    """``fork``: -> (norm(x), x) with the two gradients of x merged inside the backward kernel (GroupNormFn.forward)"""
+    """``fork``: -> (norm(x), x) with the two gradients of x merged inside the backward kernel (GroupNormFn.forward); ``fork=2``:
+    -> (norm(x), x, x) for a tensor that has a third consumer (a skip connection)"""
     if fork and x.shape[-1] != C:
-        return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu, dfilm_slot, False), x     # (padded rows: plain accumulation)
+        y = GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu, dfilm_slot, False)     # (padded rows: plain accumulation)
+        return (y, x, x) if fork == 2 else (y, x)
     return GroupNormFn.apply(x, gamma, beta, film, rt, C, groups, eps, silu, dfilm_slot, fork)
 
 
@@ -873,6 +890,7 @@ class LayerNormFn(Function):
                                        float(eps), rt.dt_of(x), rt.stream()), "jen1_ln_forward")
         ctx.rt, ctx.C, ctx.gamma, ctx.beta = rt, C, gamma, beta
         ctx.save_for_backward(x, stats)
+        ctx.set_materialize_grads(False)           # an alias nobody used comes back as None, not as a tensor of zeros
         if fork:
             return y, x.view_as(x)
         return y
@@ -881,6 +899,8 @@ class LayerNormFn(Function):
     def backward(ctx, dy, dskip=None):
         x, stats = ctx.saved_tensors
         rt, C = ctx.rt, ctx.C
+        if dy is None:
+            dy = torch.zeros_like(x)
         dy = dy.contiguous()
         if dskip is not None:
             dskip = dskip.contiguous()
@@ -1260,11 +1280,16 @@ class TrainGraph:
             return None
         return {r.name: fs for r, fs in zip(blocks, film_bank(rt, smap, ws, bs))}
 
-    def res_block(self, r: ResSpec, x: torch.Tensor, smap: torch.Tensor, causal: bool, films: Optional[dict] = None) -> torch.Tensor:
-        """ResnetBlock1d.forward (blocks.py:219-231); ``smap`` = SiLU(mapping) in the compute dtype"""
+    def res_block(self, r: ResSpec, x: torch.Tensor, smap: torch.Tensor, causal: bool, films: Optional[dict] = None, skip: bool = False):
+        """ResnetBlock1d.forward (blocks.py:219-231); ``smap`` = SiLU(mapping) in the compute dtype.  ``skip``: -> (output, alias of
+        x): x is also a skip connection of the U-Net; the gradient that comes back through the alias is added inside the GroupNorm
+        backward kernel together with the residual branch's (no accumulation launches)."""
         rt, p, n = self.rt, self.p, r.name
+        xs = x
         # x feeds the first norm AND the residual / shortcut: forked, its two gradients meet inside the GroupNorm backward kernel
-        if rt.fork_norms and x.requires_grad:
+        if rt.fork_norms and x.requires_grad and skip and rt.fork_skips:
+            h, x, xs = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True, fork=2)
+        elif rt.fork_norms and x.requires_grad:
             h, x = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True, fork=True)
         else:
             h = group_norm(rt, x, p[f"{n}.block1.groupnorm.weight"], p[f"{n}.block1.groupnorm.bias"], r.c_in, r.groups, 1e-5, None, True)
@@ -1277,12 +1302,18 @@ class TrainGraph:
         if r.has_shortcut:
             x = conv1d_same(rt, x, p[f"{n}.to_out.conv.weight"], p[f"{n}.to_out.conv.bias"], 1, causal)
         # h + x (blocks.py:231) in the epilogue of the second conv
-        return conv1d_same(rt, h, p[f"{n}.block2.project.conv.weight"], p[f"{n}.block2.project.conv.bias"], 1, causal, residual=x)
+        y = conv1d_same(rt, h, p[f"{n}.block2.project.conv.weight"], p[f"{n}.block2.project.conv.bias"], 1, causal, residual=x)
+        return (y, xs) if skip else y
 
-    def attention(self, n: str, x: torch.Tensor, context: Optional[torch.Tensor], context_mask: Optional[torch.Tensor],
+    def attention(self, n: str, x: torch.Tensor, context, context_mask: Optional[torch.Tensor],
                   heads: int, causal: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Attention.forward (blocks.py:415-437): the padding mask multiplies K and V (:431-434); ``residual`` is added by to_out's GEMM"""
+        """Attention.forward (blocks.py:415-437): the padding mask multiplies K and V (:431-434); ``residual`` is added by to_out's GEMM.
+        ``context``: a tensor, or a one-element list holding it -- the text context feeds the norm_context of all 13 cross-attentions;
+        handed on as an alias from one LayerNorm to the next, its 13 gradients are summed inside the LayerNorm backward kernels"""
         rt, p = self.rt, self.p
+        box = context if isinstance(context, list) else None
+        if box is not None:
+            context = box[0]
         # x feeds the norm(s) AND (as ``residual``) the sum after to_out: forked through the LayerNorms, so its gradients meet
         # inside their backward kernels instead of in accumulation launches
         fork = rt.fork_norms and residual is x and x.requires_grad
@@ -1290,6 +1321,8 @@ class TrainGraph:
             xn, x = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"], fork=True)
             if context is None:
                 cn, x = layer_norm(rt, x, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"], fork=True)
+            elif box is not None and rt.fork_skips and context.requires_grad:
+                cn, box[0] = layer_norm(rt, context, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"], fork=True)
             else:
                 cn = layer_norm(rt, context, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"])
             residual = x
@@ -1304,11 +1337,16 @@ class TrainGraph:
         o = attention_core(rt, q, kv, heads, causal, context_mask)
         return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"], residual=residual)
 
-    def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool) -> torch.Tensor:
-        """Transformer1d.forward (blocks.py:528-537): the SAME 1x1 conv before and after the blocks"""
+    def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool, skip: bool = False):
+        """Transformer1d.forward (blocks.py:528-537): the SAME 1x1 conv before and after the blocks.  ``skip``: -> (output, alias of x)
+        as in ``res_block``"""
         rt, p, n = self.rt, self.p, t.name
         w, b = p[f"{n}.conv1d.conv.weight"], p[f"{n}.conv1d.conv.bias"]
-        h = group_norm(rt, x, p[f"{n}.group_norm.weight"], p[f"{n}.group_norm.bias"], t.channels, 32, 1e-6, None, False)
+        xs = x
+        if skip and rt.fork_skips and rt.fork_norms and x.requires_grad:
+            h, xs = group_norm(rt, x, p[f"{n}.group_norm.weight"], p[f"{n}.group_norm.bias"], t.channels, 32, 1e-6, None, False, fork=True)
+        else:
+            h = group_norm(rt, x, p[f"{n}.group_norm.weight"], p[f"{n}.group_norm.bias"], t.channels, 32, 1e-6, None, False)
         h = conv1d_same(rt, h, w, b, 1, causal)
         for l in range(t.num_layers):
             bn = f"{n}.blocks.{l}"
@@ -1319,7 +1357,8 @@ class TrainGraph:
             else:
                 f = linear(rt, h, p[f"{bn}.feed_forward.0.weight"], p[f"{bn}.feed_forward.0.bias"])
             h = linear(rt, gelu(rt, f), p[f"{bn}.feed_forward.2.weight"], p[f"{bn}.feed_forward.2.bias"], residual=h)
-        return conv1d_same(rt, h, w, b, 1, causal)
+        y = conv1d_same(rt, h, w, b, 1, causal)
+        return (y, xs) if skip else y
 
     @staticmethod
     def _crop_pair(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -1349,22 +1388,47 @@ class TrainGraph:
         smap = silu(rt, mp).to(rt.tdtype)
         films = self.films(smap)
         h = self.res_block(sp.to_in, h, smap, False, films)          # Patcher / Unpatcher are never causal (blocks.py:256-259)
-        skips_list: List = [h]
+        # Every block output of the down path is a skip connection (blocks.py:641-643).  What goes on the skip list is not the output
+        # itself but the ALIAS its next consumer hands back (res_block / transformer / the next level's down conv with skip=True): the
+        # gradient that arrives through the alias from the up path is then added inside that consumer's backward kernel instead of
+        # by an accumulation launch of autograd (~30 per pass).
+        emb_box = [embedding]                                           # (the context is handed from one cross-attention to the next)
+        skips_list: List = [[None]]
+        slot = (skips_list[0], 0)                                       # where the alias of the current ``h`` belongs
+
+        def put(alias):
+            slot[0][slot[1]] = alias
         for d in sp.downs:
             h = self._mark(h, d.name)
-            h = conv1d_same(rt, h, p[f"{d.name}.downsample.conv.weight"], p[f"{d.name}.downsample.conv.bias"], d.factor, causal)
-            skips = []
+            h, al = conv1d_same(rt, h, p[f"{d.name}.downsample.conv.weight"], p[f"{d.name}.downsample.conv.bias"], d.factor, causal,
+                                fork=True) if (rt.fork_skips and h.requires_grad) else \
+                (conv1d_same(rt, h, p[f"{d.name}.downsample.conv.weight"], p[f"{d.name}.downsample.conv.bias"], d.factor, causal), h)
+            put(al)
+            skips: List = []
+            first = True
             for r in d.blocks:
-                h = self.res_block(r, h, smap, causal, films)
-                skips.append(h)
+                if first:
+                    h = self.res_block(r, h, smap, causal, films)
+                else:
+                    h, al = self.res_block(r, h, smap, causal, films, skip=True)
+                    put(al)
+                first = False
+                skips.append(None)
+                slot = (skips, len(skips) - 1)
             if d.transformer:
-                h = self.transformer(d.transformer, h, embedding, embedding_mask, causal)
-                skips.append(h)
+                if first:
+                    h = self.transformer(d.transformer, h, emb_box, embedding_mask, causal)
+                else:
+                    h, al = self.transformer(d.transformer, h, emb_box, embedding_mask, causal, skip=True)
+                    put(al)
+                skips.append(None)
+                slot = (skips, len(skips) - 1)
             skips_list.append(skips)
         h = self._mark(h, "bottleneck")
-        h = self.res_block(sp.bott_pre, h, smap, causal, films)
+        h, al = self.res_block(sp.bott_pre, h, smap, causal, films, skip=True)
+        put(al)
         if sp.bott_tr:
-            h = self.transformer(sp.bott_tr, h, embedding, embedding_mask, causal)
+            h = self.transformer(sp.bott_tr, h, emb_box, embedding_mask, causal)
         h = self.res_block(sp.bott_post, h, smap, causal, films)
         for u in sp.ups:
             h = self._mark(h, u.name)
@@ -1374,14 +1438,14 @@ class TrainGraph:
                 h = concat_scale(rt, a, sk, self.skip_scale)
                 h = self.res_block(r, h, smap, causal, films)
             if u.transformer:
-                h = self.transformer(u.transformer, h, embedding, embedding_mask, causal)
+                h = self.transformer(u.transformer, h, emb_box, embedding_mask, causal)
             w, b = p[f"{u.name}.upsample.weight"], p[f"{u.name}.upsample.bias"]
             f = u.factor
             if f == 1:
                 h = conv1d_zero_pad(rt, h, w, b, 1)
             else:
                 h = conv_transpose1d(rt, h, w, b, f, f // 2 + f % 2, f % 2)
-        h = h + skips_list.pop()                                         # model.py:261
+        h = h + skips_list.pop()[0]                                      # model.py:261
         h = self._mark(h, "to_out")
         return self.res_block(sp.to_out, h, smap, False, films)
 
@@ -1585,7 +1649,11 @@ class GraphedLossStep:
         try:
             if exchange is not None:
                 exchange.begin()
-            with torch.cuda.graph(g):
+            # with a process group alive its watchdog thread queries events while this thread records: only THIS thread's calls may be
+            # checked against the capture ("global" mode makes the watchdog's hipEventQuery fail the whole process)
+            import torch.distributed as dist
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 loss = self._body(static, causal)
                 if exchange is not None:
                     exchange.finish()      # recorded: the leftover regions, the join of the communication stream, the 1 / world scale

@@ -653,6 +653,25 @@ def test_training_overfits_one_batch():
     assert min(losses[20:]) < min(losses[:5])
 
 
+def _collect(q, procs, n: int, timeout: float):
+    """n results from the workers' queue; gives up early when a worker has died without a message (an abort in native code would
+    otherwise cost the whole time-out in GPU minutes)"""
+    import queue as _queue
+    import time as _time
+    out, t0 = [], _time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=5))
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"workers died / timed out: exit codes {[p.exitcode for p in procs]}")
+    return out
+
+
 def _ddp_worker(rank, world, port, q):
     try:
         _ddp_worker_body(rank, world, port, q)
@@ -749,7 +768,7 @@ def test_data_parallel_step_two_ranks_gloo():
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
+    res = dict(_collect(q, procs, 2, 600))
     for r in res.values():
         assert "error" not in r, r["error"]
     for p in procs:
@@ -803,6 +822,7 @@ def _rccl_single_worker(port, q):
             torch.cuda.synchronize()
             want = opt.flat_grad.clone()
             blocking_collectives = ex.collectives - c0
+            torch.cuda.synchronize()
             identity = bool(torch.equal(want, before_exchange))      # one rank: the RCCL all-reduce and the 1 / world scale change nothing
             # the exchange recorded into the replayed pass: armed, captured as the second variant of the pass (first call), then
             # replayed three times from the same generator state as the reference pass
@@ -845,7 +865,7 @@ def test_recorded_rccl_exchange_single_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_single_worker, args=(_free_port(), q))
     p.start()
-    res = q.get(timeout=900)
+    res = _collect(q, [p], 1, 300)[0]
     p.join(timeout=120)
     assert "error" not in res, res["error"]
     assert p.exitcode == 0
