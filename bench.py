@@ -386,7 +386,7 @@ def optimizer_step_bench(n_params, device, reps=5):
             "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 
-def train_step_bench(cfg, B, T, dtype, device, reps=5, fwd_flops=None):
+def train_step_bench(cfg, B, T, dtype, device, reps=5, fwd_flops=None):      # (fwd_flops: unused, kept for callers)
     """BASELINE configs[3] on one GPU (SURVEY.md section 8 rows a14 / a16 / e): one micro-batch of the trainer --
     ``training_loosses`` forward + backward of B clips through the CFG pair (2B rows, gdm.py:245-272, model.py:332-369)
     on the HIP training path, replayed as a HIP graph -- and one clip + AdamW step.  Not the headline metric."""
@@ -421,11 +421,20 @@ def train_step_bench(cfg, B, T, dtype, device, reps=5, fwd_flops=None):
     e[2].record()
     torch.cuda.synchronize()
     fb = e[0].elapsed_time(e[1]) / reps
+    # the pass's OWN launch list, counted in one eager pass outside the timed region: executed FLOPs and algorithmic bytes of every GEMM
+    # launch (forward, data gradient, weight gradient; the text-context to_kv products run here, they are not hoisted in training), split
+    # by kernel family.  There is no vendor GEMM on the path (profiles/r04_train_step_kernel_stats.txt: no Cijk_* kernels).
+    graph.rt.stats = {}
+    opt.zero_grad()
+    lc = gd.training_loosses(graph, x0, t, cond, causal=False)
+    (lc * 0.1).backward()
+    torch.cuda.synchronize()
+    counted, graph.rt.stats = graph.rt.stats, None
+    fl = sum(v[1] for v in counted.values())
+    by = sum(v[2] for v in counted.values())
     mfma = None
-    if fwd_flops:
-        # GEMM work of the pass: the forward of 2B rows (the CFG pair) + data and weight gradients = 3 x 2 x the B-row forward that the
-        # sampling plan counts; against the dense bf16 MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s; f32 mode is not priced)
-        tf = 6.0 * fwd_flops / (fb * 1e-3) / 1e12
+    if dtype == "bf16":
+        tf = fl / (fb * 1e-3) / 1e12
         busy = tp = None
         try:
             tp = latest_profile("train_pmc.json")
@@ -433,8 +442,13 @@ def train_step_bench(cfg, B, T, dtype, device, reps=5, fwd_flops=None):
         except Exception:
             pass
         mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
-                "kernel": "train_gemm_kernel<bf16> (forward, data-gradient and weight-gradient GEMMs of the pass)",
-                "executed_gflop_per_pass": round(6.0 * fwd_flops / 1e9, 1), "mfma_busy_pct": busy, "pmc_source": None if busy is None else "profiles/" + os.path.basename(tp)}
+                "kernel": "the pass's GEMM launches: train_gemm_* (conv / linear forward, data and weight gradients) and big_gemm_nt / big_gemm_tn "
+                          "(text-context to_kv); own kernels only, vendor GEMMs: 0",
+                "executed_gflop_per_pass": round(fl / 1e9, 1),
+                "by_family": {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "alg_MB": round(v[2] / 1e6, 1)} for k, v in counted.items()},
+                "hbm": {"bound": "hbm", "alg_bytes_per_pass": int(by), "achieved": round(by / (fb * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(by / (fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "mfma_busy_pct": busy, "pmc_source": None if busy is None else "profiles/" + os.path.basename(tp)}
     return {"what": f"configs[3] per-GPU shape: forward + backward of {B} clips x 128x{T} through the CFG pair (2B rows), hipGraph replay",
             "fwd_bwd_ms": round(fb, 2), "roofline_mfma": mfma, "clips_per_s": round(B / fb * 1e3, 1), "optimizer_ms": round(e[1].elapsed_time(e[2]), 2),
             "loss": round(float(loss), 4), "grad_allreduce_bytes": 4 * opt.numel,
@@ -611,14 +625,39 @@ def train_mode(args, world, rank, device, dist, barrier):
         "loss": round(float(loss), 4),
     }
     if world > 1:
+        # the exchange on its own (blocking form: every region, then wait), the same steps with the exchange switched off, and from the
+        # two how much of it the overlapped / recorded form hides behind the backward pass
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
         for _ in range(3):
             tr.exchange.blocking()
         torch.cuda.synchronize()
-        out["exchange_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        ex_ms = (time.perf_counter() - t0) / 3 * 1e3
+        tr.exchange.disabled = True
+        for _ in range(4):
+            tr.train_step(audio, meta)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.train_step(audio, meta)
+        torch.cuda.synchronize()
+        barrier()
+        dt0, _ = aggregate(dist, time.perf_counter() - t0, args.steps, world, device)
+        tr.exchange.disabled = False
+        ms0 = dt0 / args.steps * 1e3
+        exposed = max(0.0, out["ms_per_step"] - ms0)
+        seen = torch.zeros(world, dtype=torch.int32, device=device)
+        seen[rank] = 1
+        dist.all_reduce(seen)
+        out["exchange_ms"] = round(ex_ms, 3)
         out["exchange_bytes"] = 4 * opt.numel
+        out["ms_per_step_without_exchange"] = round(ms0, 3)
+        out["exchange_exposed_ms"] = round(exposed, 3)
+        out["exchange_overlapped_fraction"] = round(max(0.0, 1.0 - exposed / ex_ms), 3) if ex_ms > 0 else None
+        out["exchange_recorded_in_graph"] = bool(tr.exchange.capturable and not args.eager_train)
+        out["ranks_seen"] = int(seen.sum().item())
     out["peak_mem_GiB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
     if rank == 0:
         print(json.dumps(out))

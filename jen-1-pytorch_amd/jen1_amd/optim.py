@@ -262,7 +262,7 @@ class GradExchange:
     @property
     def enabled(self) -> bool:
         """more than one rank -- or one rank of an initialised process group when ``single_rank`` asks for the path anyway"""
-        return self.world > 1 or (self.single_rank and self.backend is not None)
+        return (self.world > 1 or (self.single_rank and self.backend is not None)) and not getattr(self, "disabled", False)
 
     def begin(self) -> None:
         """arm the exchange for the backward pass(es) that follow (the last micro-batch of an accumulation window)"""

@@ -82,6 +82,7 @@ class TrainRuntime:
         # (csrc/train_glue.hip) instead of ATen elementwise / cat / reduce kernels
         self.fused_glue = os.environ.get("JEN1_TRAIN_FUSED_GLUE", "1") == "1"
         self._consts: Dict[tuple, torch.Tensor] = {}
+        self.stats: Optional[dict] = None        # {"family": [launches, flops, algorithmic bytes]} while a counting pass runs (bench.py)
         self.skinny_gemm = os.environ.get("JEN1_TRAIN_SKINNY", "1") == "1"
         self.fused_repack = os.environ.get("JEN1_TRAIN_FUSED_REPACK", "1") == "1"      # every compute copy in one launch (jen1_repack)
         self.repack_twins = os.environ.get("JEN1_TRAIN_REPACK_TWINS", "1") == "1"      # ... a weight's two copies from one read of it
@@ -346,6 +347,16 @@ class TrainRuntime:
         g.residual = None if residual is None else residual.data_ptr()
         g.reserved = 1 if skinny else 0
         g.map_shift_b = None if shift_b is None else shift_b.data_ptr()
+        if self.stats is not None:
+            # executed work of the launch (bench.py's training roofline counts the pass's OWN launch list): 2 M N K per tap and batch;
+            # algorithmic bytes = the two operands once + the result (float32 read-modify-write when it accumulates)
+            es = 4 if dtype == L.F32 else 2
+            fl = 2.0 * M * N * K * taps * batches
+            by = (M * K * taps + N * K * taps) * batches * es + M * N * batches * (taps if taps_in_z else 1) * ((8 if (atomic or accumulate) else 4) if c_f32 else es)
+            e = self.stats.setdefault("train_gemm", [0, 0.0, 0.0])
+            e[0] += 0 if pair_with is not None else 1
+            e[1] += fl
+            e[2] += by
         if defer:
             return g
         if pair_with is not None:
@@ -647,6 +658,11 @@ def _big_gemm(rt: "TrainRuntime", a2d: torch.Tensor, b2d: torch.Tensor, out: tor
     g.a, g.b, g.c, g.ldc = a2d.data_ptr(), b2d.data_ptr(), out.data_ptr(), out.stride(0)      # (one inline group: nothing to copy while capturing)
     g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups = a2d.shape[0], b2d.shape[0], K, a2d.stride(0), b2d.stride(0), 1
     g.dtype, g.alpha = rt.dt_of(a2d), 1.0
+    if rt.stats is not None:
+        e = rt.stats.setdefault("big_gemm", [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += 2.0 * a2d.shape[0] * b2d.shape[0] * K
+        e[2] += (a2d.shape[0] * K + b2d.shape[0] * K + a2d.shape[0] * b2d.shape[0]) * a2d.element_size()
     L.check(rt.lib.jen1_big_gemm(C.byref(g), rt.stream()), "jen1_big_gemm")
 
 
@@ -674,6 +690,12 @@ class BigLinearFn(Function):
         co, ci = weight.shape
         gw = rt.grad_of(weight)
         rows = x2d.shape[0]
+
+        if rt.stats is not None:
+            e = rt.stats.setdefault("big_gemm", [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += 2.0 * rows * co * ci
+            e[2] += (rows * co + rows * ci) * 2 + co * ci * 8
 
         def wgrad():
             L.check(rt.lib.jen1_big_gemm_tn(dy.data_ptr(), x2d.data_ptr(), gw.data_ptr(), rows, co, ci, dy.stride(0), x2d.stride(0), gw.stride(0), 1.0,
