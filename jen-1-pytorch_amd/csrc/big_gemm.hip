@@ -178,6 +178,9 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
         wa[s] = *reinterpret_cast<const u32x4*>(base + fa + s * SUB * ROWB + xo[kb]);
         xb[s] = *reinterpret_cast<const u32x4*>(base + fb + s * SUB * ROWB + xo[kb]);
       }
+#ifdef JEN1_BGEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int i = 0; i < NSUB; ++i)
 #pragma unroll
@@ -191,6 +194,9 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb[j]), acc[i][j], 0, 0, 0);
           }
         }
+#ifdef JEN1_BGEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     if constexpr (NSTAGE == 2) __builtin_amdgcn_s_barrier();     // the stage is free for the loads of tile kt + 2
     stage = stage == NSTAGE - 1 ? 0 : stage + 1;
@@ -484,12 +490,14 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
   // 760 TFLOP/s at 4096^3.  JEN1_BGEMM_WM = 2 / 4 forces a form (tuning runs).
   static const int force_wm = getenv("JEN1_BGEMM_WM") ? atoi(getenv("JEN1_BGEMM_WM")) : 0;
   const int t256 = ((a->M + 255) / 256) * ((a->Ntot + BN - 1) / BN);
-  const int wm = force_wm ? force_wm : ((t256 >= 512 && a->K >= 2048) ? 4 : 2);
+  const int wm = force_wm ? (force_wm == 5 ? 4 : force_wm) : ((t256 >= 512 && a->K >= 2048) ? 4 : 2);
   g.tiles_m = (a->M + wm * 64 - 1) / (wm * 64);
   g.tiles_n = (a->Ntot + BN - 1) / BN;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(g.tiles_m * g.tiles_n);
-  if (wm == 4) {
+  if (wm == 4 && force_wm == 5) {                       // (tuning: 256 x 128 tiles on two stages)
+    hipLaunchKernelGGL((big_gemm_nt_kernel<bf16_t, 4, 2>), grid, dim3(512), 0, s, g);
+  } else if (wm == 4) {
     if (a->dtype == JEN1_F32) hipLaunchKernelGGL((big_gemm_nt_kernel<float, 4, 3>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((big_gemm_nt_kernel<bf16_t, 4, 3>), grid, dim3(512), 0, s, g);
   } else {

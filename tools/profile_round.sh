@@ -1,7 +1,7 @@
 # round profile: kernel stats + per-step breakdown + PMC passes (HBM traffic, MFMA busy) of the default bench command.
 # run on the GPU box:  bash tools/profile_round.sh [tag]     outputs under gpurun_out/profile (copy the summaries to profiles/)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/profile; mkdir -p $O
 B="python bench.py --no-extra --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format rocpd -- $B --steps 20 --warmup 5 > $O/trace.log 2>&1
