@@ -1,6 +1,6 @@
 # MFMA-busy of the training step's kernels: rocprofv3 PMC pass over tools/train_step.py (counters in their own run)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/trainpmc; mkdir -p $O
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc -o p --output-format rocpd -- python tools/train_step.py --iters 3 > $O/pmc.log 2>&1
 python - $(find $O/pmc -name "*.db" | head -1) > $O/${TAG}_train_pmc.txt <<'PY'
@@ -20,7 +20,7 @@ for counter, fn in (("SQ_VALU_MFMA_BUSY_CYCLES", "sum"), ("GRBM_GUI_ACTIVE", "av
             where p.pmc_id in ({','.join(str(i) for i in ids)}) group by d.id"""
     agg = collections.defaultdict(lambda: [0, 0.0])
     for n, v in c.execute(q):
-        k = "train_gemm" if "train_gemm" in n else ("gn/ln/act kernels" if any(x in n for x in ("gn_", "ln_", "act_", "softmax", "colsum")) else "other")
+        k = "train_gemm" if ("train_gemm" in n or "big_gemm" in n) else ("gn/ln/act kernels" if any(x in n for x in ("gn_", "ln_", "act_", "softmax", "colsum")) else "other")
         agg[k][0] += 1; agg[k][1] += v
     res[counter] = agg
 out = {}
