@@ -153,6 +153,19 @@ int jen1_attn_small_backward(const void* q, int64_t ldq, const void* k, int64_t 
                              int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
                              int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, const float* kv_mask, int dtype,
                              void* stream);
+/* the same with a row map for K / V: batch element b READS k / v of batch row kv_row[b] (NULL: b).  The unconditional half of the CFG
+ * pair attends to the learned fixed embedding whatever the batch element (model.py:333): its context rows are projected ONCE and
+ * shared; dk / dv are still written per batch element (jen1_sum_rows_inplace adds the sharers' rows up afterwards). */
+int jen1_attn_small_forward_rows(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                                 void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal, const int32_t* causal_b,
+                                 const float* kv_mask, const int32_t* kv_row, int dtype, void* stream);
+int jen1_attn_small_backward_rows(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* p,
+                                  int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                                  int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, const float* kv_mask, const int32_t* kv_row,
+                                  int dtype, void* stream);
+/* p[0 .. n) = sum over r < rows of p[r * n .. r * n + n)  (in place, float32 accumulation): the gradients of context rows that several
+ * batch elements shared */
+int jen1_sum_rows_inplace(void* p, int rows, int64_t n, int dtype, void* stream);
 
 /* dst[i] = (dtype) src[i]; src[i] = 0  for i < n (n a multiple of 4): hands the float32 accumulator of a split-K GEMM
  * over in the compute dtype and leaves it zeroed for the next launch of the stream. */
@@ -186,6 +199,8 @@ int jen1_lstm_layer_multi(const float* gin, const void* whh, const void* skip, v
  * jen1_train_context: the cross-attention context rows out[r][n][0..F) of the pass in `dtype`: r < B: the text embedding
  *   emb[r][n] (n < NL) followed by the time token tok[r] (model.py:315-316), or the learned fixed embedding for rows with
  *   drop[r] != 0 (CFG dropout, model.py:323-328); B <= r < nrep B: the fixed embedding (the pair's unconditional half, :333).
+ *   nrep = 0: B + 1 rows -- the unconditional half as ONE shared row set (it is the same for every batch element; the attention
+ *   kernels read it through a row map, jen1_attn_small_forward_rows).
  *   _backward: d_fixed[n] += sum of d over the rows that read the fixed embedding; d_tok[r] = d[r][N - 1] (0 for dropped rows).
  * jen1_time_features_fwd / _bwd: f[b] = [t, sin(2 pi t w), cos(2 pi t w), 0 ..] (LearnedPositionalEmbedding, utils/module.py:58-72;
  *   phases in float32, evaluated left to right like the reference); dw[k] += its gradient.  t: int64 or float32 [B].

@@ -21,6 +21,8 @@ struct AttnDev {
   float scale;
   const int* causal_b;      // per batch element: causal or not (a pass that mixes both), or NULL: `causal` for all
   const float* kmask;       // [B][Nk] float32 multiplied into the rows of K and V (the padding mask of the context, blocks.py:431-434), or NULL
+  const int* kv_row;        // which batch row of k / v batch element b READS (NULL: b): the unconditional half of a CFG pair shares ONE set of
+                            // context rows (the fixed embedding, model.py:333), projected once instead of once per batch element
 };
 
 // rows [n][d] of one head from a [B][n][ld] tensor -> float32 LDS rows of pitch dp; 16-byte global vectors when the head's rows
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
   float* Vs = Ks + Nk * dp;
   float* S = Vs + Nk * dp;
   const T* q = reinterpret_cast<const T*>(a.q) + (long long)b * Nq * a.ldq + h * d;
-  const T* k = reinterpret_cast<const T*>(a.k) + (long long)b * Nk * a.ldk + h * d;
-  const T* v = reinterpret_cast<const T*>(a.v) + (long long)b * Nk * a.ldv + h * d;
+  const int bk = a.kv_row != nullptr ? a.kv_row[b] : b;
+  const T* k = reinterpret_cast<const T*>(a.k) + (long long)bk * Nk * a.ldk + h * d;
+  const T* v = reinterpret_cast<const T*>(a.v) + (long long)bk * Nk * a.ldv + h * d;
   stage_rows<T>(Qs, dp, q, a.ldq, Nq, d, rows_aligned(q, a.ldq, d, sizeof(T)));
   const float* km = a.kmask != nullptr ? a.kmask + (long long)b * Nk : nullptr;
   stage_rows<T>(Ks, dp, k, a.ldk, Nk, d, rows_aligned(k, a.ldk, d, sizeof(T)), km);
@@ -141,8 +144,9 @@ __global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
   float* Pf = Gs + Nq * dp;
   float* dS = Pf + Nq * sp;
   const T* q = reinterpret_cast<const T*>(a.q) + (long long)b * Nq * a.ldq + h * d;
-  const T* k = reinterpret_cast<const T*>(a.k) + (long long)b * Nk * a.ldk + h * d;
-  const T* v = reinterpret_cast<const T*>(a.v) + (long long)b * Nk * a.ldv + h * d;
+  const int bk = a.kv_row != nullptr ? a.kv_row[b] : b;
+  const T* k = reinterpret_cast<const T*>(a.k) + (long long)bk * Nk * a.ldk + h * d;
+  const T* v = reinterpret_cast<const T*>(a.v) + (long long)bk * Nk * a.ldv + h * d;
   const T* g = reinterpret_cast<const T*>(a.d_o) + (long long)b * Nq * a.ldo + h * d;
   const T* P = reinterpret_cast<const T*>(a.p) + (long long)z * Nq * a.ldp;
   stage_rows<T>(Qs, dp, q, a.ldq, Nq, d, rows_aligned(q, a.ldq, d, sizeof(T)));
@@ -218,6 +222,12 @@ extern "C" int jen1_attn_small_fits(int Nq, int Nk, int d, int dtype) {
 extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                                        int64_t ldo, void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal,
                                        const int32_t* causal_b, const float* kv_mask, int dtype, void* stream) {
+  return jen1_attn_small_forward_rows(q, ldq, k, ldk, v, ldv, o, ldo, p, ldp, B, H, Nq, Nk, d, scale, causal, causal_b, kv_mask, nullptr, dtype, stream);
+}
+
+extern "C" int jen1_attn_small_forward_rows(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                                            int64_t ldo, void* p, int64_t ldp, int B, int H, int Nq, int Nk, int d, float scale, int causal,
+                                            const int32_t* causal_b, const float* kv_mask, const int32_t* kv_row, int dtype, void* stream) {
   if (check_common("jen1_attn_small_forward", B, H, Nq, Nk, d, dtype)) return 1;
   JEN1_CHECK(q && k && v && o && p, "jen1_attn_small_forward: NULL argument");
   JEN1_CHECK(ldp >= Nk, "jen1_attn_small_forward: ldp must be >= Nk");
@@ -228,6 +238,7 @@ extern "C" int jen1_attn_small_forward(const void* q, int64_t ldq, const void* k
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.causal = causal ? 1 : 0; a.scale = scale;
   a.causal_b = reinterpret_cast<const int*>(causal_b);
   a.kmask = kv_mask;
+  a.kv_row = reinterpret_cast<const int*>(kv_row);
   const size_t lds = fwd_lds(Nq, Nk, d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == JEN1_F32) {
@@ -245,6 +256,14 @@ extern "C" int jen1_attn_small_backward(const void* q, int64_t ldq, const void* 
                                         int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk,
                                         void* dv, int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, const float* kv_mask,
                                         int dtype, void* stream) {
+  return jen1_attn_small_backward_rows(q, ldq, k, ldk, v, ldv, p, ldp, d_o, ldo, dq, lddq, dk, lddk, dv, lddv, B, H, Nq, Nk, d, scale, kv_mask, nullptr,
+                                       dtype, stream);
+}
+
+extern "C" int jen1_attn_small_backward_rows(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* p,
+                                             int64_t ldp, const void* d_o, int64_t ldo, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                                             void* dv, int64_t lddv, int B, int H, int Nq, int Nk, int d, float scale, const float* kv_mask,
+                                             const int32_t* kv_row, int dtype, void* stream) {
   if (check_common("jen1_attn_small_backward", B, H, Nq, Nk, d, dtype)) return 1;
   JEN1_CHECK(q && k && v && p && d_o && dq && dk && dv, "jen1_attn_small_backward: NULL argument");
   JEN1_CHECK(ldp >= Nk, "jen1_attn_small_backward: ldp must be >= Nk");
@@ -254,6 +273,7 @@ extern "C" int jen1_attn_small_backward(const void* q, int64_t ldq, const void* 
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.ldp = ldp; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
   a.kmask = kv_mask;
+  a.kv_row = reinterpret_cast<const int*>(kv_row);
   const size_t lds = bwd_lds(Nq, Nk, d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == JEN1_F32) {

@@ -265,6 +265,20 @@ __global__ __launch_bounds__(256) void cfg_loss_bwd_kernel(const T* __restrict__
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void sum_rows_kernel(T* __restrict__ p, int rows, long long n) {
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long long)gridDim.x * 256 * 8) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < rows; ++r) {
+      float v[8];
+      load8(p + (long long)r * n + i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+    store8(p + i, acc);
+  }
+}
+
 __global__ void zero_f32_kernel(float* p, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -287,10 +301,10 @@ extern "C" int jen1_train_pack_input(const float* x0, const float* noise, const 
 
 extern "C" int jen1_train_context(const float* emb, const float* tok, const float* fixed, const uint8_t* drop, void* out, int B, int NL, int N, int F,
                                   int nrep, int dtype, void* stream) {
-  JEN1_CHECK(emb && fixed && out && B >= 1 && NL >= 1 && (N == NL || (N == NL + 1 && tok)) && F % 4 == 0 && nrep >= 1 && nrep <= 2,
+  JEN1_CHECK(emb && fixed && out && B >= 1 && NL >= 1 && (N == NL || (N == NL + 1 && tok)) && F % 4 == 0 && nrep >= 0 && nrep <= 2,
              "train_context: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int rows = nrep * B;
+  const int rows = nrep == 0 ? B + 1 : nrep * B;        // nrep = 0: ONE shared set of unconditional rows behind the B conditional ones
   const long long total = (long long)rows * N * (F / 4);
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   if (dtype == JEN1_F32) hipLaunchKernelGGL(context_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, emb, tok, fixed, drop, (float*)out, B, NL, N, F, rows);
@@ -302,12 +316,13 @@ extern "C" int jen1_train_context(const float* emb, const float* tok, const floa
 
 extern "C" int jen1_train_context_backward(const void* d, const uint8_t* drop, float* d_fixed, float* d_tok, int B, int NL, int N, int F, int nrep,
                                            int dtype, void* stream) {
-  JEN1_CHECK(d && d_fixed && B >= 1 && (N == NL || N == NL + 1) && F % 4 == 0 && nrep >= 1 && nrep <= 2, "train_context_backward: bad arguments");
+  JEN1_CHECK(d && d_fixed && B >= 1 && (N == NL || N == NL + 1) && F % 4 == 0 && nrep >= 0 && nrep <= 2, "train_context_backward: bad arguments");
+  const int rows_total = nrep == 0 ? B + 1 : nrep * B;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int total = N * (F / 4);
   const int blocks = (total + 255) / 256;
-  if (dtype == JEN1_F32) hipLaunchKernelGGL(context_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)d, drop, d_fixed, d_tok, B, NL, N, F, nrep * B);
-  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(context_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)d, drop, d_fixed, d_tok, B, NL, N, F, nrep * B);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(context_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)d, drop, d_fixed, d_tok, B, NL, N, F, rows_total);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(context_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)d, drop, d_fixed, d_tok, B, NL, N, F, rows_total);
   else return jen1_set_error("train_context_backward: bad dtype");
   JEN1_HIP(hipGetLastError());
   return 0;
@@ -352,6 +367,17 @@ extern "C" int jen1_cfg_loss_backward(const void* net, const float* tgt, const f
   if (dtype == JEN1_F32) hipLaunchKernelGGL(cfg_loss_bwd_kernel<float>, dim3(bx, B), dim3(256), 0, s, (const float*)net, tgt, gps, (float*)dnet, B, C, T, ld, nrep, embedding_scale, scale_cfg, scale_phi, l1);
   else if (dtype == JEN1_BF16) hipLaunchKernelGGL(cfg_loss_bwd_kernel<bf16_t>, dim3(bx, B), dim3(256), 0, s, (const bf16_t*)net, tgt, gps, (bf16_t*)dnet, B, C, T, ld, nrep, embedding_scale, scale_cfg, scale_phi, l1);
   else return jen1_set_error("cfg_loss_backward: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_sum_rows_inplace(void* p, int rows, int64_t n, int dtype, void* stream) {
+  JEN1_CHECK(p && rows >= 1 && n >= 8 && n % 8 == 0 && ((uintptr_t)p & 15) == 0, "sum_rows_inplace: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (int)((n / 8 + 255) / 256 > 1024 ? 1024 : (n / 8 + 255) / 256);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(sum_rows_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)p, rows, (long long)n);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(sum_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (bf16_t*)p, rows, (long long)n);
+  else return jen1_set_error("sum_rows_inplace: bad dtype");
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -149,6 +149,9 @@ SYMBOLS = {
     "jen1_attn_small_fits": (c_int, [c_int, c_int, c_int, c_int]),
     "jen1_attn_small_forward": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64] + [c_int] * 5 + [c_float, c_int, _P, _P, c_int, _P]),
     "jen1_attn_small_backward": (c_int, [_P, c_int64] * 8 + [c_int] * 5 + [c_float, _P, c_int, _P]),
+    "jen1_attn_small_forward_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64] + [c_int] * 5 + [c_float, c_int, _P, _P, _P, c_int, _P]),
+    "jen1_attn_small_backward_rows": (c_int, [_P, c_int64] * 8 + [c_int] * 5 + [c_float, _P, _P, c_int, _P]),
+    "jen1_sum_rows_inplace": (c_int, [_P, c_int, c_int64, c_int, _P]),
     "jen1_gn_sums": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "jen1_gn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P] + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_gn_backward": (c_int, [_P] * 6 + [c_int] + [_P] * 6 + [c_int] * 5 + [c_float, c_int, c_int, _P]),

@@ -110,7 +110,17 @@ class TrainRuntime:
         self.fork_norms = os.environ.get("JEN1_TRAIN_FORK", "1") == "1"
         # ... and a skip connection of the U-Net / the text context of the 13 cross-attentions: handed on as aliases by their consumers
         self.fork_skips = os.environ.get("JEN1_TRAIN_FORK_SKIPS", "1") == "1"
+        # the unconditional half of the CFG pair reads ONE shared set of context rows (the fixed embedding) instead of B copies
+        self.share_fixed_context = os.environ.get("JEN1_TRAIN_SHARE_FIXED", "1") == "1"
         self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
+
+    def kv_rows(self, B: int) -> torch.Tensor:
+        """[0 .. B - 1, B, B, ... B] (int32, 2 B entries): the K / V row every element of a CFG pair reads when the unconditional
+        half shares one set of context rows"""
+        t = self._consts.get(("kv_rows", B))
+        if t is None:
+            t = self._consts[("kv_rows", B)] = torch.cat([torch.arange(B, dtype=torch.int32), torch.full((B,), B, dtype=torch.int32)]).to(self.device)
+        return t
 
     def const(self, n: int, v: float) -> torch.Tensor:
         """a cached float32 vector of n copies of v (read-only operands of the glue kernels)"""
@@ -1017,9 +1027,11 @@ def _rows_view(t: torch.Tensor) -> Tuple[int, int]:
 
 class AttentionCoreFn(Function):
     @staticmethod
-    def forward(ctx, q, kv, rt: TrainRuntime, heads: int, causal: bool, kv_mask=None):
+    def forward(ctx, q, kv, rt: TrainRuntime, heads: int, causal: bool, kv_mask=None, kv_row=None):
         """kv: [B, Nk, 2 C] = to_kv's output (K | V): the gradient comes back as ONE tensor (two column windows written by the data-gradient
-        GEMMs) instead of two slice gradients that autograd pads with zeros and adds"""
+        GEMMs) instead of two slice gradients that autograd pads with zeros and adds.  ``kv_row`` (int32 [B], one-launch core only): batch
+        element b attends to kv[kv_row[b]]; kv then has Bk = kv_row[-1] + 1 rows, the first Bk - 1 mapped one to one, the last one shared by
+        all the others (the CFG pair's unconditional half)."""
         mid = kv.shape[-1] // 2
         k, v = kv[..., :mid], kv[..., mid:]
         B, Nq, C = q.shape
@@ -1042,14 +1054,17 @@ class AttentionCoreFn(Function):
                                  f"(Nq = {Nq}, Nk = {Nk}, d = {d} do not fit one workgroup)")
         assert kv_mask is None or ctx.small, "kv_mask rides on the one-launch attention core only (attention() multiplies otherwise)"
         ctx.kv_mask = None if kv_mask is None else kv_mask.to(torch.float32).contiguous()
+        ctx.kv_row = kv_row
+        assert kv_row is None or (ctx.small and kv_row.dtype == torch.int32 and kv_row.shape[0] == B)
         if ctx.small:
             assert rows is None or rows.flags.shape[0] == B
             assert ctx.kv_mask is None or ctx.kv_mask.shape == (B, Nk)
-            L.check(rt.lib.jen1_attn_small_forward(qp, ldq, kp, ldk, vp, ldv, O.data_ptr(), C, P.data_ptr(), ldS, B, heads, Nq, Nk, d,
-                                                   float(scale), 1 if (rows is None and causal) else 0,
-                                                   None if rows is None else rows.flags.data_ptr(),
-                                                   None if ctx.kv_mask is None else ctx.kv_mask.data_ptr(), dt, rt.stream()),
-                    "jen1_attn_small_forward")
+            L.check(rt.lib.jen1_attn_small_forward_rows(qp, ldq, kp, ldk, vp, ldv, O.data_ptr(), C, P.data_ptr(), ldS, B, heads, Nq, Nk, d,
+                                                        float(scale), 1 if (rows is None and causal) else 0,
+                                                        None if rows is None else rows.flags.data_ptr(),
+                                                        None if ctx.kv_mask is None else ctx.kv_mask.data_ptr(),
+                                                        None if kv_row is None else kv_row.data_ptr(), dt, rt.stream()),
+                    "jen1_attn_small_forward_rows")
             ctx.save_for_backward(q, kv, P)
             return O
         S = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
@@ -1083,11 +1098,19 @@ class AttentionCoreFn(Function):
         dKV = torch.empty((B, Nk, 2 * C), dtype=q.dtype, device=q.device)
         esz = dKV.element_size()
         if ctx.small:
-            L.check(rt.lib.jen1_attn_small_backward(qp, ldq, kp, ldk, vp, ldv, P.data_ptr(), ldS, dO.data_ptr(), C, dQ.data_ptr(), C,
-                                                    dKV.data_ptr(), 2 * C, dKV.data_ptr() + C * esz, 2 * C, B, heads, Nq, Nk, d,
-                                                    float(scale), None if ctx.kv_mask is None else ctx.kv_mask.data_ptr(), dt, rt.stream()),
-                    "jen1_attn_small_backward")
-            return dQ, dKV, None, None, None, None
+            kv_row = ctx.kv_row
+            L.check(rt.lib.jen1_attn_small_backward_rows(qp, ldq, kp, ldk, vp, ldv, P.data_ptr(), ldS, dO.data_ptr(), C, dQ.data_ptr(), C,
+                                                         dKV.data_ptr(), 2 * C, dKV.data_ptr() + C * esz, 2 * C, B, heads, Nq, Nk, d,
+                                                         float(scale), None if ctx.kv_mask is None else ctx.kv_mask.data_ptr(),
+                                                         None if kv_row is None else kv_row.data_ptr(), dt, rt.stream()),
+                    "jen1_attn_small_backward_rows")
+            if kv_row is not None:
+                # dk / dv were written per batch element; the rows behind the one-to-one part all read the same K / V: their sum, in place
+                Bk = kv.shape[0]
+                n = Nk * 2 * C
+                L.check(rt.lib.jen1_sum_rows_inplace(dKV.data_ptr() + (Bk - 1) * n * esz, B - (Bk - 1), n, dt, rt.stream()), "jen1_sum_rows_inplace")
+                dKV = dKV[:Bk]
+            return dQ, dKV, None, None, None, None, None
         dP = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
         dS = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
         o_do = lambda ld_r, ld_k: _operand(dO.data_ptr(), ld_r, ld_k, zs0=Nq * C, zs1=d, zdiv=heads)
@@ -1103,18 +1126,22 @@ class AttentionCoreFn(Function):
                 dKV.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads, alpha=scale)
         rt.gemm(_operand(P.data_ptr(), 1, ldS, zs0=Nq * ldS), o_do(1, C),
                 dKV.data_ptr() + C * esz, Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads)
-        return dQ, dKV, None, None, None, None
+        return dQ, dKV, None, None, None, None, None
 
 
-def attention_core(rt, q, kv, heads: int, causal, kv_mask=None):
+def attention_core(rt, q, kv, heads: int, causal, kv_mask=None, kv_row=None):
     """``kv_mask`` [B, Nk]: multiplied into the rows of K and V (blocks.py:431-434) -- inside the one-launch kernels when the shape
-    fits them, else as a tensor product before the GEMM path"""
-    if kv_mask is not None:
-        B, Nq, C = q.shape
-        if not (rt.small_attn and rt.lib.jen1_attn_small_fits(Nq, kv.shape[1], C // heads, rt.dt_of(q))):
-            kv = kv * kv_mask.to(kv.dtype)[:, :, None]
-            kv_mask = None
-    return AttentionCoreFn.apply(q, kv.contiguous(), rt, heads, causal, kv_mask)
+    fits them, else as a tensor product before the GEMM path.  ``kv_row``: see AttentionCoreFn.forward (GEMM path: the rows are
+    gathered first)"""
+    B, Nq, C = q.shape
+    small = bool(rt.small_attn and rt.lib.jen1_attn_small_fits(Nq, kv.shape[1], C // heads, rt.dt_of(q)))
+    if kv_row is not None and not small:
+        kv = kv.index_select(0, kv_row.to(torch.int64))
+        kv_row = None
+    if kv_mask is not None and not small:
+        kv = kv * kv_mask.to(kv.dtype)[:, :, None]
+        kv_mask = None
+    return AttentionCoreFn.apply(q, kv.contiguous(), rt, heads, causal, kv_mask, kv_row)
 
 
 # =====================================================================================================================
@@ -1129,7 +1156,7 @@ class ContextRowsFn(Function):
     def forward(ctx, tok, fixed, emb, drop, rt: TrainRuntime, nrep: int):
         B, NL, F = emb.shape
         N = NL + (1 if tok is not None else 0)
-        out = torch.empty((nrep * B, N, F), dtype=rt.tdtype, device=emb.device)
+        out = torch.empty(((B + 1) if nrep == 0 else nrep * B, N, F), dtype=rt.tdtype, device=emb.device)
         d8 = None if drop is None else drop.to(torch.uint8)
         L.check(rt.lib.jen1_train_context(emb.data_ptr(), None if tok is None else tok.data_ptr(), fixed.data_ptr(),
                                           None if d8 is None else d8.data_ptr(), out.data_ptr(), B, NL, N, F, nrep, rt.dt, rt.stream()), "jen1_train_context")
@@ -1334,8 +1361,10 @@ class TrainGraph:
         handed on as an alias from one LayerNorm to the next, its 13 gradients are summed inside the LayerNorm backward kernels"""
         rt, p = self.rt, self.p
         box = context if isinstance(context, list) else None
+        kv_row = None
         if box is not None:
             context = box[0]
+            kv_row = box[1] if len(box) > 1 else None
         # x feeds the norm(s) AND (as ``residual``) the sum after to_out: forked through the LayerNorms, so its gradients meet
         # inside their backward kernels instead of in accumulation launches
         fork = rt.fork_norms and residual is x and x.requires_grad
@@ -1356,7 +1385,7 @@ class TrainGraph:
         kv = linear(rt, cn, p[f"{n}.to_kv.weight"])
         mid = kv.shape[-1] // 2
         # the padding mask multiplies K and V (blocks.py:431-434): inside the attention kernels when the shape fits them
-        o = attention_core(rt, q, kv, heads, causal, context_mask)
+        o = attention_core(rt, q, kv, heads, causal, context_mask, kv_row)
         return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"], residual=residual)
 
     def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool, skip: bool = False):
@@ -1414,7 +1443,8 @@ class TrainGraph:
         # itself but the ALIAS its next consumer hands back (res_block / transformer / the next level's down conv with skip=True): the
         # gradient that arrives through the alias from the up path is then added inside that consumer's backward kernel instead of
         # by an accumulation launch of autograd (~30 per pass).
-        emb_box = [embedding]                                           # (the context is handed from one cross-attention to the next)
+        emb_box = list(embedding) if isinstance(embedding, (tuple, list)) else [embedding]     # (handed from one cross-attention to the next;
+                                                                                             #  optionally with the K / V row map of the batch)
         skips_list: List = [[None]]
         slot = (skips_list[0], 0)                                       # where the alias of the current ``h`` belongs
 
@@ -1575,7 +1605,12 @@ class TrainGraph:
             else:   # rand_bool (utils/module.py:36-42)
                 drop = torch.bernoulli(torch.full((B,), float(gd.cfg_dropout_proba), device=dev)).to(torch.bool)
         fixed = p["fixed_embedding.embedding.weight"]
-        ctx_rows = ContextRowsFn.apply(tok, fixed, emb, drop, rt, nrep)
+        share = nrep == 2 and rt.share_fixed_context
+        ctx_rows = ContextRowsFn.apply(tok, fixed, emb, drop, rt, 0 if share else nrep)
+        if share:
+            # the pair's unconditional half attends to the fixed embedding whatever the batch element (model.py:333): ONE row set, projected
+            # once per layer and read by all B of them through a row map (B + 1 instead of 2 B context rows through LayerNorm and to_kv)
+            ctx_rows = (ctx_rows, rt.kv_rows(B))
         if mask is not None:
             mask = mask.to(torch.float32)
             if sp.use_xattn_time:
