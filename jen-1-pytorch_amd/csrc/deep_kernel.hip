@@ -330,6 +330,11 @@ __device__ unsigned long long* g_deep_dbg = nullptr;
 #define DK_STAMP(sy, i) do { } while (0)
 #define DK_FLUSH(sy) do { } while (0)
 #endif
+#if defined(JEN1_DEEP_PROFILE) && defined(JEN1_DEEP_PROFILE_NORM)
+#define DK_STAMPN(sy, i) DK_STAMP(sy, i)     // finer stamps inside the normalised staging part; they reuse the set-up slots 7..10
+#else
+#define DK_STAMPN(sy, i) do { } while (0)
+#endif
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -633,14 +638,25 @@ __device__ __forceinline__ void k_round_n(f32x4 (&acc)[4], const Frag (&ra)[PF],
 }
 
 // sum over the aligned group of 2^lS lanes (1 <= lS <= 6) that holds v, in a fixed order
-__device__ __forceinline__ float lane_set_sum(float v, int lS) {
-  v += ddpp<0xB1>(v);                       // lanes ^ 1
-  if (lS >= 2) v += ddpp<0x4E>(v);          // lanes ^ 2
-  if (lS >= 3) v += ddpp<0x141>(v);         // row_half_mirror: the other quad of the 8
-  if (lS >= 4) v += ddpp<0x140>(v);         // row_mirror: the other half of the 16
-  if (lS >= 5) v += __shfl_xor(v, 16);
-  if (lS >= 6) v += __shfl_xor(v, 32);
-  return v;
+// x[lane] + x[lane ^ 16] / x[lane ^ 32] without the LDS crossbar: v_permlane16_swap exchanges the odd rows of its first operand with
+// the even rows of its second, v_permlane32_swap the upper half with the lower half; with both operands the same value the two
+// results hold the value of the even / odd row (lower / upper half) of every row pair -- their sum is the butterfly step
+__device__ __forceinline__ float xor16_add(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum and sum of squares over the 2^lS lanes of a lane set (lS wave-uniform, 1..6), the two chains interleaved
+__device__ __forceinline__ void lane_set_sum2(float& s, float& q, int lS) {
+  s += ddpp<0xB1>(s); q += ddpp<0xB1>(q);                         // lanes ^ 1
+  if (lS >= 2) { s += ddpp<0x4E>(s); q += ddpp<0x4E>(q); }        // lanes ^ 2
+  if (lS >= 3) { s += ddpp<0x141>(s); q += ddpp<0x141>(q); }      // row_half_mirror: the other quad of the 8
+  if (lS >= 4) { s += ddpp<0x140>(s); q += ddpp<0x140>(q); }      // row_mirror: the other half of the 16
+  if (lS >= 5) { s = xor16_add(s); q = xor16_add(q); }
+  if (lS >= 6) { s = xor32_add(s); q = xor32_add(q); }
 }
 
 template <typename T, typename Frag, int PF, typename FPub>
@@ -987,8 +1003,8 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
         q += ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
       }
     }
-    s = lane_set_sum(s, lS < 6 ? lS : 6);
-    q = lane_set_sum(q, lS < 6 ? lS : 6);
+    DK_STAMPN(sy, 7);
+    lane_set_sum2(s, q, lS < 6 ? lS : 6);
     if (lS == 7) {
       // a group of 1024 channels (LayerNorm over the channels of ONE position, folded single-position self-attention: engine.py
       // "s1q2") is 128 columns: the pair's two waves exchange their sums through LDS and add them in a fixed order
@@ -1006,17 +1022,25 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
     var = var < 0.f ? 0.f : var;
     const float rstd = PRECISE ? 1.0f / sqrtf(var + gn_eps) : rsqrtf(var + gn_eps);
     const bool silu = HI(pro_mode) == JEN1_PRO_GN_SILU;
+    DK_STAMPN(sy, 8);
+    // bf16 / fp8 staging: the affine map as ONE fused multiply-add per element (a = rstd * gamma', b = beta' - mean * a)
+    float pa[8], pb[8];
+    if (!PRECISE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pa[j] = rstd * p1[j]; pb[j] = p2[j] - mean * pa[j]; }
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       if (i >= nvn) continue;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xf[i][j] = (xf[i][j] - mean) * rstd * p1[j] + p2[j];
+      for (int j = 0; j < 8; ++j) xf[i][j] = PRECISE ? (xf[i][j] - mean) * rstd * p1[j] + p2[j] : xf[i][j] * pa[j] + pb[j];
       if (silu) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) xf[i][j] = PRECISE ? silu_precise(xf[i][j]) : silu_f(xf[i][j]);
       }
       store8(tile + ntile[i], xf[i]);
     }
+    DK_STAMPN(sy, 9);
     for (int trip = 1; trip < ntrips; ++trip) {
       Raw8<GT> xt[MAXV];
       int tt[MAXV];
@@ -1034,7 +1058,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
         float x[8];
         raw_to_float(xt[i], x);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (x[j] * mt_[i] - mean) * rstd * p1[j] + p2[j];
+        for (int j = 0; j < 8; ++j) x[j] = PRECISE ? (x[j] * mt_[i] - mean) * rstd * p1[j] + p2[j] : (x[j] * mt_[i]) * pa[j] + pb[j];
         if (silu) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
@@ -1046,6 +1070,7 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 #else
   float rres[4] = {0.f, 0.f, 0.f, 0.f};
 #endif
+  DK_STAMP(sy, 13);
   __syncthreads();
   DK_STAMP(sy, 3);
 

@@ -102,7 +102,7 @@ for p in range(n):
 print(f"# whole launch: {prev_end - t0:.1f} us")
 # critical path of the data-is-the-flag protocol: stamp 2 = the unit's polled loads came back complete, stamp 15 = its epilogue stores
 # are issued.  exchange = last store of phase p-1 -> loads complete in phase p (first / mean / last unit); compute = 2 -> 15 per unit
-print("# chain: phase | exchange first / mean / last consumer | compute 2->15 mean / max | 2->3 stage 3->4 kloop 4->14 reduce-barrier 14->15 epilogue")
+print("# chain: phase | exchange first / mean / last consumer | compute 2->15 mean / max | 2->3 stage 3->4 kloop 4->14 reduce-barrier 14->15 epilogue | 2->11 raw part staged 11->13 normalised part stored 13->3 barrier")
 ex_l, cp_l = [], []
 for p in range(1, n):
     m, mp = d[p, :, 2] > 0, d[p - 1, :, 15] > 0
@@ -112,9 +112,18 @@ for p in range(1, n):
     v = d[p, m, 2] - last_store
     c = d[p, m, 15] - d[p, m, 2] if (d[p, m, 15] > 0).all() else d[p, m, 5] - d[p, m, 2]
     ex_l.append(v.max()); cp_l.append(c.max())
-    seg = [np.mean(d[p, m, b] - d[p, m, a]) if (d[p, m, b] > 0).all() and (d[p, m, a] > 0).all() else float("nan") for a, b in ((2, 3), (3, 4), (4, 14), (14, 15))]
+    seg = [np.mean(d[p, m, b] - d[p, m, a]) if (d[p, m, b] > 0).all() and (d[p, m, a] > 0).all() else float("nan") for a, b in ((2, 3), (3, 4), (4, 14), (14, 15), (2, 11), (11, 13), (13, 3))]
     print(f"{p:3d} | {v.min():6.2f} {v.mean():6.2f} {v.max():6.2f} | {c.mean():6.2f} {c.max():6.2f} | " + " ".join(f"{x:5.2f}" for x in seg) + f"  {prog.labels[p][:60]}")
 print(f"# chain totals: sum of (exchange to the last consumer) {sum(ex_l):.1f} us, sum of (slowest unit's compute) {sum(cp_l):.1f} us over {len(ex_l)} phases")
+if "JEN1_DEEP_PROFILE_NORM" in args.defs:
+    # slots 7..9 restamped inside the normalised part: 11->7 own sums, 7->8 lane-set sums + statistics, 8->9 normalise + SiLU + LDS stores
+    print("# norm part: phase | 11->7 sums 7->8 lane-set reduction 8->9 normalise+store 9->13 further trips")
+    for p in range(1, n):
+        m = (d[p, :, 11] > 0) & (d[p, :, 7] > d[p, :, 11]) & (d[p, :, 9] > 0)
+        if not m.any():
+            continue
+        seg = [np.mean(d[p, m, b] - d[p, m, a]) for a, b in ((11, 7), (7, 8), (8, 9), (9, 13))]
+        print(f"{p:3d} | " + " ".join(f"{x:5.2f}" for x in seg) + f"  {prog.labels[p][:60]}")
 raw = dbg.cpu().numpy().astype(np.float64)
 mm = (raw[:, :, 7] > 0) & (raw[:, :, 8] > 0) & (raw[:, :, 6] > raw[:, :, 0])
 fr = (raw[:, :, 8] - raw[:, :, 7])[mm] / ((raw[:, :, 6] - raw[:, :, 0])[mm] * 0.01)
