@@ -55,7 +55,6 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
   const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   if (threadIdx.x < 64) st[threadIdx.x] = 0.f;
-  __syncthreads();
   const int cpf = ld / JEN1_FINE_GROUPS;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -67,20 +66,6 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
       else if (c < C + Cc) v = ctx[((size_t)b * Cc + (c - C)) * Tn + t];
     }
     tile[r][tx] = v;
-    if (stats) {
-      // the 32 lanes of a half-wave hold one channel: reduce over time with shuffles, one LDS atomic per channel
-      float sv = v, sq = v * v;
-#pragma unroll
-      for (int off = 1; off < 32; off <<= 1) {
-        sv += __shfl_xor(sv, off);
-        sq += __shfl_xor(sq, off);
-      }
-      if (tx == 0 && sq != 0.f) {
-        const int fg = c / cpf;
-        atomicAdd(&st[2 * fg - 2 * (c0 / cpf)], sv);          // local fine groups of this 32-channel slab
-        atomicAdd(&st[2 * fg - 2 * (c0 / cpf) + 1], sq);
-      }
-    }
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
@@ -90,12 +75,32 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
       for (int rep = 0; rep < nrep; ++rep) y[((size_t)(rep * B + b) * Tn + t) * ld + c] = v;
     }
   }
-  if (stats && threadIdx.x < 64) {
-    const int fgl = threadIdx.x >> 1;
-    const int fg = c0 / cpf + fgl;
-    const float v = st[threadIdx.x];
-    if (fg < JEN1_FINE_GROUPS && v != 0.f)
-      for (int rep = 0; rep < nrep; ++rep) unsafeAtomicAdd(stats + (size_t)(rep * B + b) * 64 + fg * 2 + (threadIdx.x & 1), v);
+  if (stats) {
+    // one lane per channel of the slab walks its 32 time steps in LDS (lane r reads bank (r + j) mod 32: no conflicts), then one LDS
+    // atomic pair per channel into the fine groups of this 32-channel slab -- no cross-lane traffic on the way
+    if (threadIdx.x < 32) {
+      const int r = threadIdx.x;
+      float sv = 0.f, sq = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) {
+        const float v = tile[r][j];
+        sv += v;
+        sq += v * v;
+      }
+      if (sq != 0.f) {
+        const int fg = (c0 + r) / cpf;
+        atomicAdd(&st[2 * fg - 2 * (c0 / cpf)], sv);
+        atomicAdd(&st[2 * fg - 2 * (c0 / cpf) + 1], sq);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int fgl = threadIdx.x >> 1;
+      const int fg = c0 / cpf + fgl;
+      const float v = st[threadIdx.x];
+      if (fg < JEN1_FINE_GROUPS && v != 0.f)
+        for (int rep = 0; rep < nrep; ++rep) unsafeAtomicAdd(stats + (size_t)(rep * B + b) * 64 + fg * 2 + (threadIdx.x & 1), v);
+    }
   }
 }
 
@@ -388,6 +393,158 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const T* __restrict__ net
   }
 }
 
+
+// ---- the same step for C % 8 == 0 (the latent channels of the model: 128): 16-byte row loads, no LDS crossbar -----------------------
+// Half a wave owns a (b, t) row, a lane 8 consecutive channels of it; the row reductions of the std rescale are DPP row steps and one
+// v_permlane16_swap; x_t and the step's noise -- which do not depend on the network output -- are requested before anything else.
+template <int CTRL>
+__device__ __forceinline__ float edpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {           // over the 32 lanes of a half wave, every lane gets the sum
+  v += edpp<0xB1>(v);                                                // lanes ^ 1
+  v += edpp<0x4E>(v);                                                // lanes ^ 2
+  v += edpp<0x141>(v);                                               // row_half_mirror
+  v += edpp<0x140>(v);                                               // row_mirror
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);              // lanes ^ 16
+}
+
+template <typename T, bool DDIM>
+__global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__ net, const float* __restrict__ x,
+                                                            const float* __restrict__ noise, const float* __restrict__ coef,
+                                                            float* __restrict__ x_out, float* __restrict__ eps_out,
+                                                            float* __restrict__ x0_out, const int32_t* step_idx,
+                                                            int B, int C, int Tn, int ld, int nrep,
+                                                            float scale, int scale_cfg, float phi, int objective, int clip_x0,
+                                                            int32_t* adv_step, unsigned* __restrict__ adv_ticket) {
+  extern __shared__ float tile[];   // [C][33] + one word per 8 channels
+  float cf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (DDIM) {
+    if (step_idx) {                  // (see cfg_step_kernel: the counter may be advanced by this launch's last block)
+      const int st = __hip_atomic_load(step_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      coef += (size_t)st * 8;
+      if (noise) noise += (size_t)st * B * C * Tn;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cf[i] = coef[i];
+  }
+  const int t0 = blockIdx.x * 32, b = blockIdx.y;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t = t0 + tx;
+  const int tcl = t < Tn ? t : Tn - 1;
+  // phase-2 operands: [C][T]-major, 8 channels per 64-channel block and thread
+  constexpr int NBLK = 4;           // C <= 256
+  float xv[NBLK][8], nv[NBLK][8];
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    if (blk * 64 >= C) continue;     // uniform
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = blk * 64 + ty + 8 * k;
+      const size_t idx = ((size_t)b * C + (c < C ? c : 0)) * Tn + tcl;
+      xv[blk][k] = DDIM ? x[idx] : 0.f;
+      nv[blk][k] = (DDIM && noise) ? noise[idx] : 0.f;
+    }
+  }
+  // phase 1: 8 rows per pass (4 waves x 2 half waves), every load of the block in flight before the first reduction
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, c8 = (lane & 31) * 8;
+  const bool cv = c8 < C;
+  const int cl = cv ? c8 : 0;
+  float oc[4][8], ou[4][8];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 8 + wave * 2 + half;
+    const int tr = (t0 + r < Tn) ? t0 + r : Tn - 1;
+    load8(net + ((size_t)b * Tn + tr) * ld + cl, oc[p]);
+    if (nrep == 2) load8(net + ((size_t)(B + b) * Tn + tr) * ld + cl, ou[p]);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 8 + wave * 2 + half;
+    float og[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) og[j] = (nrep == 2) ? ou[p][j] + (oc[p][j] - ou[p][j]) * scale : oc[p][j];
+    if (nrep == 2 && scale_cfg) {
+      float s_c = 0.f, s_g = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_c += oc[p][j]; s_g += og[j]; }
+      s_c = half_wave_sum(cv ? s_c : 0.f);
+      s_g = half_wave_sum(cv ? s_g : 0.f);
+      const float m_c = s_c / (float)C, m_g = s_g / (float)C;
+      float v_c = 0.f, v_g = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dc = oc[p][j] - m_c, dg = og[j] - m_g;
+        v_c += dc * dc;
+        v_g += dg * dg;
+      }
+      v_c = half_wave_sum(cv ? v_c : 0.f);
+      v_g = half_wave_sum(cv ? v_g : 0.f);
+      const float ratio = sqrtf(v_c / (float)(C - 1)) / sqrtf(v_g / (float)(C - 1));   // unbiased std (torch.std)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) og[j] = phi * (og[j] * ratio) + (1.0f - phi) * og[j];
+    }
+    if (cv) {
+      // (lane i of a half wave writes channel rows 8 i .. 8 i + 7; the extra word per 8 channels puts the 32 lanes in 32 banks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tile[(c8 + j) * 33 + (c8 >> 3) + r] = og[j];
+    }
+  }
+  __syncthreads();
+  if (adv_ticket != nullptr && threadIdx.x == 0) {
+    const unsigned nblk = gridDim.x * gridDim.y;
+    if (atomicAdd(adv_ticket, 1u) == nblk - 1u) {
+      __hip_atomic_fetch_add(adv_step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      adv_ticket[0] = 0u;
+    }
+  }
+  if (t >= Tn) return;
+  const float sr = cf[0], srm1 = cf[1], sa_n = cf[2], cc = cf[3], sg = cf[4], last = cf[5], sa_t = cf[6], s1m_t = cf[7];
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    if (blk * 64 >= C) continue;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = blk * 64 + ty + 8 * k;
+      if (c >= C) continue;
+      const size_t idx = ((size_t)b * C + c) * Tn + t;
+      const float o = tile[c * 33 + (c >> 3) + tx];
+      if (!DDIM) {
+        x_out[idx] = o;
+        continue;
+      }
+      const float xt = xv[blk][k];
+      float x0, eps;
+      if (objective == 0) {          // 'noise'
+        eps = o;
+        x0 = sr * xt - srm1 * eps;
+        if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      } else if (objective == 1) {   // 'x0'
+        x0 = o;
+        if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        eps = (sr * xt - x0) / srm1;
+      } else {                       // 'v'
+        x0 = sa_t * xt - s1m_t * o;
+        if (clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        eps = (sr * xt - x0) / srm1;
+      }
+      float xn;
+      if (last == 3.f) {             // VDM row (see cfg_step_kernel)
+        x0 = sr * xt - srm1 * o;
+        eps = srm1 * xt + sr * o;
+        xn = sa_n * x0 + cc * eps;
+      } else if (last == 1.f) xn = x0;
+      else if (last == 2.f) xn = x0 * sa_n + cc * xt + sg * nv[blk][k];
+      else xn = x0 * sa_n + cc * eps + sg * nv[blk][k];
+      x_out[idx] = xn;
+      if (eps_out) eps_out[idx] = eps;
+      if (x0_out) x0_out[idx] = x0;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int jen1_pack_input(const float* x, const float* ctx, void* y, float* gn_stats, int B, int C, int Cc, int T,
@@ -477,8 +634,20 @@ static int launch_cfg(const void* net, const float* x, const float* noise, const
   JEN1_CHECK(C >= 2 && C <= 256 && ld >= C, "cfg step: C must be in [2, 256]");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((T + 31) / 32, B);
-  const size_t lds = sizeof(float) * (size_t)C * 33;
-  if (dtype == JEN1_F32) {
+  const size_t lds = sizeof(float) * ((size_t)C * 33 + C / 8 + 1);
+  // rows of 8-channel vectors on 16-byte boundaries: the vector form (JEN1_CFG_STEP_SCALAR=1 keeps the general kernel: A-B switch)
+  static const bool scalar_only = getenv("JEN1_CFG_STEP_SCALAR") != nullptr;
+  const int esz = dtype == JEN1_F32 ? 4 : 2;
+  const bool vec = !scalar_only && C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)net & 15) == 0 && ((size_t)ld * esz) % 16 == 0;
+  if (vec && dtype == JEN1_F32) {
+    auto kern = cfg_step_vec_kernel<float, DDIM>;
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket);
+  } else if (vec && dtype == JEN1_BF16) {
+    auto kern = cfg_step_vec_kernel<bf16_t, DDIM>;
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket);
+  } else if (dtype == JEN1_F32) {
     auto kern = cfg_step_kernel<float, DDIM>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket);
