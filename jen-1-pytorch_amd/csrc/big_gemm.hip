@@ -520,7 +520,21 @@ extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, i
   g.tiles_n = (N + 127) / 128;
   g.tiles_k = (K + 127) / 128;
   const int tiles = g.tiles_n * g.tiles_k, MT = (M + 63) / 64;
-  int splits = (512 + tiles - 1) / tiles;               // two workgroups per CU
+  // slices of the reduction: every slice adds its 128 x 128 partial with float atomics, and the atomics (slices x N x K of them, at
+  // ~280 per ns through the L2s) are what a small output costs -- 24 000 rows x 128 x 128 on 375 slices: 27.8 us, 6 of them atomics
+  // alone would take.  Cost model  t(s) = a ceil(MT / s) + b s tiles  (a = 0.5 us per 64-row step of a workgroup, b = 0.058 us per
+  // tile of atomics): the s with the smallest t, among those that put at least half of the CUs to work
+  int splits = 1;
+  {
+    const int s_min = (128 + tiles - 1) / tiles;
+    float best = 1e30f;
+    for (int s = s_min < MT ? s_min : MT; s <= MT; ++s) {
+      const float t = 0.5f * (float)((MT + s - 1) / s) + 0.058f * (float)s * (float)tiles;
+      if (t < best) { best = t; splits = s; }
+    }
+  }
+  static const int force_splits = getenv("JEN1_BGEMM_TN_SPLITS") ? atoi(getenv("JEN1_BGEMM_TN_SPLITS")) : 0;      // tuning
+  if (force_splits > 0) splits = force_splits;
   splits = splits < 1 ? 1 : (splits > MT ? MT : splits);
   g.mt_per_split = (MT + splits - 1) / splits;
   g.splits = (MT + g.mt_per_split - 1) / g.mt_per_split;
