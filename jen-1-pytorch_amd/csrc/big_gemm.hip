@@ -277,6 +277,11 @@ struct TArgs {
   float* c;                     // [N][ldc] float32, accumulated with atomics
   int32_t M, N, K, lda, ldb, ldc, tiles_n, tiles_k, splits, mt_per_split;
   float alpha;
+  // convolution form (jen1_big_gemm_tn_conv): K = taps * ci columns, column block [tap ci, (tap + 1) ci) reads row
+  // b T_in + t stride + tap - pad of the input for reduction row m = b T_out + t (zero outside [0, T_in)), C is [N][ci][taps]
+  int32_t conv, taps, ci, T_out, T_in, stride, pad, rows_b;
+  float inv_T_out;
+  float* bias_grad;             // [N] += column sums of A (the bias gradient), or NULL
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -310,9 +315,13 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.a) + (size_t)n0 * 2), 0,
       (int)(((size_t)g.M * (size_t)g.lda - (size_t)n0) * 2), RSRC_FLAGS);
+  const bool conv = g.conv != 0;
+  const int tap = conv ? k0 / g.ci : 0;                       // (ci is a multiple of 128: a tile lies inside one tap)
+  const int kb0 = conv ? k0 - tap * g.ci : k0;                // first input column of the tile
+  const int shift = tap - g.pad;
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.b) + (size_t)k0 * 2), 0,
-      (int)(((size_t)g.M * (size_t)g.ldb - (size_t)k0) * 2), RSRC_FLAGS);
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.b) + (size_t)kb0 * 2), 0,
+      (int)(((size_t)(conv ? g.rows_b : g.M) * (size_t)g.ldb - (size_t)kb0) * 2), RSRC_FLAGS);
   // instruction i of wave w fills rows (i * 4 + w) * 4 .. + 4 of a tile; lane l lands at row + (l >> 4), 16-byte chunk l & 15 =
   // (block l >> 1 & 7, half l & 1) and fetches block ((l >> 1) & 7) ^ (2 (row & 3)) of that row
   unsigned voa[4], vob[4];
@@ -322,8 +331,16 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
     const int blk = ((lane >> 1) & 7) ^ (2 * (row & 3));
     const unsigned col = (unsigned)(blk * 32 + (lane & 1) * 16);
     voa[i] = (unsigned)row * (unsigned)(g.lda * 2) + col;
-    vob[i] = (unsigned)row * (unsigned)(g.ldb * 2) + col;
+    vob[i] = conv ? col : (unsigned)row * (unsigned)(g.ldb * 2) + col;
   }
+  // convolution form: the input row of reduction row m (an offset far outside the descriptor reads as zeros)
+  auto conv_off = [&](int mt, int i) -> unsigned {
+    const int m = mt * 64 + (i * 4 + w) * 4 + (lane >> 4);
+    const int b = (int)(((float)m + 0.5f) * g.inv_T_out);     // m < 2^22: exact
+    const int xp = (m - b * g.T_out) * g.stride + shift;
+    const bool ok = xp >= 0 && xp < g.T_in && m < g.M;
+    return ok ? (unsigned)(b * g.T_in + xp) * (unsigned)(g.ldb * 2) + vob[i] : 0x7ffffff0u;
+  };
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   lds_u8* const lds0 = (lds_u8*)smem;
 #define TN_ISSUE(stage_, mt_)                                                                                                  \
@@ -332,8 +349,13 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
     lds_u8* const sb_ = lds0 + (stage_) * 2 * TB + w * 1024;                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_ + i_ * 4096), 16, voa[i_], soa_, 0, 0);                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + TB + i_ * 4096), 16, vob[i_], sob_, 0, 0);              \
+    if (conv) {                                                                                                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                         \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + TB + i_ * 4096), 16, conv_off((mt_), i_), 0u, 0, 0);  \
+    } else {                                                                                                                   \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                         \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + TB + i_ * 4096), 16, vob[i_], sob_, 0, 0);            \
+    }                                                                                                                          \
   } while (0)
 
   // fragment addressing: wave (wn, wk) owns 64 n x 64 k; lane = (g2 = lane >> 5: rows 8 g2 .. + 8 of a 16-row block, h = bit 4:
@@ -355,6 +377,17 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // bias gradient (column sums of A): one more MFMA against a block of ones in the waves that own the first k tile's first half
+  const bool do_bias = g.bias_grad != nullptr && tk == 0 && wk == 0;
+  f32x16 accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
   TN_ISSUE(0, mt0);
   int stage = 0;
@@ -379,6 +412,10 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i], vb[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i], ones, accb[i], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_barrier();
     stage ^= 1;
@@ -394,7 +431,20 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
-        if (n < g.N) unsafeAtomicAdd(g.c + (size_t)n * (size_t)g.ldc + (size_t)k, acc[i][j][r] * g.alpha);
+        if (n >= g.N) continue;
+        const size_t off = conv ? (size_t)n * (size_t)g.ldc + (size_t)(k - tap * g.ci) * (size_t)g.taps + (size_t)tap
+                                : (size_t)n * (size_t)g.ldc + (size_t)k;
+        unsafeAtomicAdd(g.c + off, acc[i][j][r] * g.alpha);
+      }
+    }
+  }
+  if (do_bias && (lane & 31) == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
+        if (n < g.N) unsafeAtomicAdd(g.bias_grad + n, accb[i][r] * g.alpha);
       }
     }
   }
@@ -508,6 +558,27 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
   return 0;
 }
 
+// slices of the reduction of a TN product
+static int tn_splits(int tiles, int MT, float atomics_cost = 0.058f) {
+  // slices of the reduction: every slice adds its 128 x 128 partial with float atomics, and the atomics (slices x N x K of them, at
+  // ~280 per ns through the L2s) are what a small output costs -- 24 000 rows x 128 x 128 on 375 slices: 27.8 us, 6 of them atomics
+  // alone would take.  Cost model  t(s) = a ceil(MT / s) + b s tiles  (a = 0.5 us per 64-row step of a workgroup, b = 0.058 us per
+  // tile of atomics): the s with the smallest t, among those that put at least half of the CUs to work
+  int splits = 1;
+  {
+    const int s_min = (128 + tiles - 1) / tiles;
+    float best = 1e30f;
+    for (int s = s_min < MT ? s_min : MT; s <= MT; ++s) {
+      const float t = 0.5f * (float)((MT + s - 1) / s) + atomics_cost * (float)s * (float)tiles;
+      if (t < best) { best = t; splits = s; }
+    }
+  }
+  static const int force_splits = getenv("JEN1_BGEMM_TN_SPLITS") ? atoi(getenv("JEN1_BGEMM_TN_SPLITS")) : 0;      // tuning
+  if (force_splits > 0) splits = force_splits;
+  splits = splits < 1 ? 1 : (splits > MT ? MT : splits);
+  return splits;
+}
+
 extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream) {
   JEN1_CHECK(a && b && c && M >= 1 && N >= 1 && K >= 1, "big_gemm_tn: bad arguments");
   JEN1_CHECK(lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0 && K % 8 == 0, "big_gemm_tn: widths and pitches must be multiples of 8 elements");
@@ -520,22 +591,34 @@ extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, i
   g.tiles_n = (N + 127) / 128;
   g.tiles_k = (K + 127) / 128;
   const int tiles = g.tiles_n * g.tiles_k, MT = (M + 63) / 64;
-  // slices of the reduction: every slice adds its 128 x 128 partial with float atomics, and the atomics (slices x N x K of them, at
-  // ~280 per ns through the L2s) are what a small output costs -- 24 000 rows x 128 x 128 on 375 slices: 27.8 us, 6 of them atomics
-  // alone would take.  Cost model  t(s) = a ceil(MT / s) + b s tiles  (a = 0.5 us per 64-row step of a workgroup, b = 0.058 us per
-  // tile of atomics): the s with the smallest t, among those that put at least half of the CUs to work
-  int splits = 1;
-  {
-    const int s_min = (128 + tiles - 1) / tiles;
-    float best = 1e30f;
-    for (int s = s_min < MT ? s_min : MT; s <= MT; ++s) {
-      const float t = 0.5f * (float)((MT + s - 1) / s) + 0.058f * (float)s * (float)tiles;
-      if (t < best) { best = t; splits = s; }
-    }
-  }
-  static const int force_splits = getenv("JEN1_BGEMM_TN_SPLITS") ? atoi(getenv("JEN1_BGEMM_TN_SPLITS")) : 0;      // tuning
-  if (force_splits > 0) splits = force_splits;
-  splits = splits < 1 ? 1 : (splits > MT ? MT : splits);
+  const int splits = tn_splits(tiles, MT);
+  g.mt_per_split = (MT + splits - 1) / splits;
+  g.splits = (MT + g.mt_per_split - 1) / g.mt_per_split;
+  hipLaunchKernelGGL(big_gemm_tn_kernel, dim3(tiles * g.splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, float* gb, int B, int T_out, int T_in, int co, int ci, int taps,
+                                     int stride, int pad, int ld_dy, int ld_x, float alpha, void* stream) {
+  JEN1_CHECK(dy && x && gw && B >= 1 && T_out >= 1 && T_in >= 1 && co >= 8 && ci >= 8 && taps >= 1 && stride >= 1, "big_gemm_tn_conv: bad arguments");
+  JEN1_CHECK(co % 8 == 0 && ci % 8 == 0 && ld_dy >= co && ld_x >= ci && ld_dy % 8 == 0 && ld_x % 8 == 0, "big_gemm_tn_conv: widths and pitches must be multiples of 8 elements");
+  JEN1_CHECK(taps == 1 || ci % 128 == 0, "big_gemm_tn_conv: with more than one tap the input channels must be a multiple of 128 (a column tile lies inside one tap)");
+  JEN1_CHECK((co % 128 == 0 || ld_dy >= ((co + 127) / 128) * 128) && (ci % 128 == 0 || ld_x >= ((ci + 127) / 128) * 128),
+             "big_gemm_tn_conv: a partial last column tile must still lie inside the row pitch");
+  const int64_t M = (int64_t)B * T_out, Mx = (int64_t)B * T_in;
+  JEN1_CHECK(M < ((int64_t)1 << 22) && M * ld_dy * 2 < ((int64_t)1 << 31) && Mx * ld_x * 2 < 0x7ffffff0ll, "big_gemm_tn_conv: operand too large");
+  TArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = dy; g.b = x; g.c = gw; g.M = (int)M; g.N = co; g.K = taps * ci; g.lda = ld_dy; g.ldb = ld_x; g.ldc = ci * taps; g.alpha = alpha;
+  g.conv = 1; g.taps = taps; g.ci = ci; g.T_out = T_out; g.T_in = T_in; g.stride = stride; g.pad = pad; g.rows_b = (int)Mx;
+  g.inv_T_out = 1.0f / (float)T_out; g.bias_grad = gb;
+  g.tiles_n = (co + 127) / 128;
+  g.tiles_k = taps * ((ci + 127) / 128);
+  const int tiles = g.tiles_n * g.tiles_k, MT = (int)((M + 63) / 64);
+  // (with taps > 1 consecutive lanes add to floats `taps` apart and the taps' tiles meet in the same lines: an atomic costs ~3 x)
+  static const float conv_cost = getenv("JEN1_BGEMM_TN_CONV_COST") ? (float)atof(getenv("JEN1_BGEMM_TN_CONV_COST")) : 0.17f;
+  int splits = tn_splits(tiles, MT, taps > 1 ? conv_cost : 0.058f);
   g.mt_per_split = (MT + splits - 1) / splits;
   g.splits = (MT + g.mt_per_split - 1) / g.mt_per_split;
   hipLaunchKernelGGL(big_gemm_tn_kernel, dim3(tiles * g.splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);

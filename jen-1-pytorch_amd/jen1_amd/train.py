@@ -90,6 +90,12 @@ class TrainRuntime:
         self.skinny_max_steps = int(os.environ.get("JEN1_TRAIN_SKINNY_STEPS", "64"))      # K steps per wave
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "256"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
+        # weight gradients over many rows on jen1_big_gemm_tn_conv.  Off: measured in the pass 45 - 50 us per launch at 24 000 x 128 x (3 x 128)
+        # against 40 on train_gemm's weight-gradient form (pass 13.65 against 13.56 ms) -- the plain product of that size takes 16 us, but
+        # with taps the output floats of consecutive lanes lie `taps` apart and the taps' tiles meet in the same lines (float atomics ~5 x
+        # dearer), and a 64-row step costs twice the plain one
+        self.big_wgrads = os.environ.get("JEN1_TRAIN_BIG_WGRADS", "0") == "1"
+        self.big_wgrad_rows = int(os.environ.get("JEN1_TRAIN_BIG_WGRAD_ROWS", "4096"))
         # weight gradients on their own stream (weight_grad below)
         # layers per fork; 0 (default): on the pass's own stream.  The fork was worth 1 ms while every weight gradient went through it; since
         # a layer's two gradients share a launch only the FiLM / many-row / library-GEMM ones are left, and the branch costs the replayed
@@ -544,6 +550,19 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
         a = _operand(dy.data_ptr(), 1, ldy)
         b = _operand(x.data_ptr(), 1, ldx, m=g.fwd_map(2))
         M, N = g.co, g.ci
+    if (rt.big_wgrads and not defer and g.kind in ("conv", "linear") and dt == L.BF16 and K >= rt.big_wgrad_rows and g.pad_b is None
+            and not g.reflect and x.is_contiguous() and dy.is_contiguous() and g.co % 8 == 0 and g.ci % 8 == 0 and K % g.L_out == 0
+            and (g.ci % 128 == 0 if k > 1 else ldx >= -(-g.ci // 128) * 128) and (g.co % 128 == 0 or ldy >= -(-g.co // 128) * 128)
+            and (x.numel() // ldx) * g.L_out == K * g.L_in and gw.is_contiguous()):
+        # many reduction rows against a small output (the long levels): the transposing matrix-core kernel with the tap shift in its
+        # row map and the bias gradient as one more MFMA (switch: TrainRuntime.big_wgrads, off by default)
+        L.check(rt.lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), None if gb is None else gb.data_ptr(), K // g.L_out,
+                                             g.L_out, g.L_in, g.co, g.ci, k, g.stride if g.kind == "conv" else 1, g.pad if g.kind == "conv" else 0,
+                                             ldy, ldx, 1.0, rt.stream()), "jen1_big_gemm_tn_conv")
+        if rt.stats is not None:
+            e = rt.stats.setdefault("big_gemm", [0, 0.0, 0.0])
+            e[0] += 1; e[1] += 2.0 * K * g.co * g.ci * k; e[2] += 2.0 * K * (g.co + g.ci) + 8.0 * g.co * g.ci * k
+        return gb is not None
     sk = rt.pick_splitk(M, N, (K + 31) // 32, z=k)
     fused_bias = gb is not None and g.kind != "convT"
     # one K slice: every (tap, tile) of the gradient belongs to exactly one workgroup of this launch and launches are

@@ -136,3 +136,46 @@ def test_weight_gradient_tn_matches_torch(M, N, K):
     ref = c0 + 0.5 * (a_full[:, :N].float().t() @ b_full[:, :K].float())
     err = float((c - ref).abs().max() / ref.abs().max())
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("B,T_in,ci,co,taps,stride,pad,with_bias", [
+    (3, 50, 128, 64, 3, 1, 1, True),        # centred k = 3 (ResnetBlock1d conv, blocks.py:137-145)
+    (3, 50, 128, 128, 3, 1, 2, False),      # causal k = 3 (left pad 2, blocks.py:45-50)
+    (2, 257, 256, 96, 5, 2, 2, True),       # strided k = 5 (Downsample1d, blocks.py:56-66), ragged rows
+    (16, 1500, 128, 128, 3, 1, 1, True),    # the level-0 shape of the pass: 24 000 reduction rows
+    (4, 129, 200, 72, 1, 1, 0, True),       # Linear over many rows, widths that are no multiple of 128 (inside a wider pitch)
+])
+def test_conv_weight_gradient_tn_matches_torch(B, T_in, ci, co, taps, stride, pad, with_bias):
+    """jen1_big_gemm_tn_conv: gw[co][ci][tap] += sum dy x (tap shift, stride, zero padding at the sequence ends, per batch element) and
+    the bias gradient, against torch's conv1d autograd on the same bf16-rounded operands; accumulation into a non-zero gradient"""
+    import torch.nn.functional as F
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(B * 131 + T_in + ci + taps)
+    T_out = (T_in + (taps - 1 if taps > 1 else 0) - taps) // stride + 1 if taps > 1 else T_in
+    if taps > 1:
+        T_out = (T_in + taps - 1 - taps) // stride + 1          # total padding taps - 1 (left `pad`, right the rest)
+    ldx, ldy = -(-ci // 128) * 128, -(-co // 128) * 128
+    x = torch.zeros((B, T_in, ldx), device="cuda", dtype=torch.bfloat16)
+    dy = torch.zeros((B, T_out, ldy), device="cuda", dtype=torch.bfloat16)
+    x[..., :ci] = (torch.randn((B, T_in, ci), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    dy[..., :co] = (torch.randn((B, T_out, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    x[..., ci:] = 7.0       # pitch padding must never reach the result
+    dy[..., co:] = -5.0
+    gw0 = torch.randn((co, ci, taps), device="cuda", generator=gen)
+    gb0 = torch.randn((co,), device="cuda", generator=gen)
+    gw, gb = gw0.clone(), gb0.clone()
+    L.check(lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if with_bias else None, B, T_out, T_in, co, ci, taps,
+                                      stride, pad, ldy, ldx, 1.0, torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn_conv")
+    torch.cuda.synchronize()
+    w = torch.zeros((co, ci, taps), device="cuda", requires_grad=True)
+    bias = torch.zeros((co,), device="cuda", requires_grad=True)
+    xin = x[..., :ci].float().permute(0, 2, 1)
+    xin = F.pad(xin, (pad, taps - 1 - pad)) if taps > 1 else xin
+    y = F.conv1d(xin, w, bias, stride=stride)
+    assert y.shape[-1] == T_out, (y.shape, T_out)
+    y.backward(dy[..., :co].float().permute(0, 2, 1))
+    assert rel_err((gw - gw0).cpu().numpy(), w.grad.cpu().numpy()) < 2e-5
+    if with_bias:
+        assert rel_err((gb - gb0).cpu().numpy(), bias.grad.cpu().numpy()) < 2e-5
+    else:
+        assert torch.equal(gb, gb0)
