@@ -91,9 +91,10 @@ class TrainRuntime:
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "256"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
         # weight gradients over many rows on jen1_big_gemm_tn_conv.  Off: measured in the pass 45 - 50 us per launch at 24 000 x 128 x (3 x 128)
-        # against 40 on train_gemm's weight-gradient form (pass 13.65 against 13.56 ms) -- the plain product of that size takes 16 us, but
-        # with taps the output floats of consecutive lanes lie `taps` apart and the taps' tiles meet in the same lines (float atomics ~5 x
-        # dearer), and a 64-row step costs twice the plain one
+        # against 40 on train_gemm's weight-gradient form (pass 13.65 against 13.56 ms).  The plain product of that size takes 13 - 16 us and the
+        # row map is free (13.4), but (a) with taps the floats consecutive lanes add to lie `taps` apart and the taps' tiles meet in the same
+        # lines (41.6 us at 3 taps), (b) the bias gradient's atomics of ~100 reduction slices all land on the same four lines (+23 us).  Both
+        # are epilogue work (interleave the taps through LDS; shard the bias sums) that round 4 did not get to
         self.big_wgrads = os.environ.get("JEN1_TRAIN_BIG_WGRADS", "0") == "1"
         self.big_wgrad_rows = int(os.environ.get("JEN1_TRAIN_BIG_WGRAD_ROWS", "4096"))
         # weight gradients on their own stream (weight_grad below)
