@@ -282,6 +282,10 @@ struct TArgs {
   int32_t conv, taps, ci, T_out, T_in, stride, pad, rows_b;
   float inv_T_out;
   float* bias_grad;             // [N] += column sums of A (the bias gradient), or NULL
+  // taps > 1: a column tile holds cpt 8-channel chunks of EVERY tap ([tap][chunk][8]: taps * cpt <= 16 chunks), so that a workgroup owns
+  // runs of cpt * 8 * taps consecutive floats of C and adds them with coalesced atomics (a tile of ONE tap would add floats `taps` apart,
+  // in lines it shares with the other taps' workgroups: 41.6 against 16 us at 24 000 x 128 x (3 x 128))
+  int32_t cpt, main_blocks, bias_blocks, bias_rows;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -300,7 +304,51 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TB];     // [stage][A | B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int id = xcd_remap(blockIdx.x, g.tiles_n * g.tiles_k * g.splits);
+  if ((int)blockIdx.x >= g.main_blocks) {
+    // bias gradient: the column sums of A over a slice of the rows, by workgroups of their own (every reduction slice adding its
+    // partial sums would put ~100 workgroups' atomics on the same four lines: +23 us)
+    float* colsum = reinterpret_cast<float*>(smem);                  // [16][128]
+    const int j = (int)blockIdx.x - g.main_blocks;
+    const int r0 = j * g.bias_rows;
+    int r1 = r0 + g.bias_rows;
+    r1 = r1 < g.M ? r1 : g.M;
+    const int cg = tid & 15, rl = tid >> 4;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.a);
+    for (int nb = 0; nb < g.N; nb += 128) {
+      float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int c = nb + cg * 8;
+      if (c < g.N) {
+        // eight rows in flight per thread: the slice is a latency chain otherwise (one 16-byte load per trip: 35 us for 1 600 rows)
+        for (int r = r0 + rl; r < r1; r += 16 * 8) {
+          bf16x8 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int ru = r + 16 * u;
+            v[u] = *reinterpret_cast<const bf16x8*>(A + (size_t)(ru < r1 ? ru : r0) * (size_t)g.lda + c);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (r + 16 * u < r1) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc8[e] += (float)v[u][e];
+            }
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) colsum[rl * 128 + cg * 8 + e] = acc8[e];
+      __syncthreads();
+      if (tid < 128 && nb + tid < g.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += colsum[q * 128 + tid];
+        unsafeAtomicAdd(g.bias_grad + nb + tid, t * g.alpha);
+      }
+    }
+    return;
+  }
+  int id = xcd_remap(blockIdx.x, g.main_blocks);
   const int split = id % g.splits;
   id /= g.splits;
   const int tk = id % g.tiles_k, tn = id / g.tiles_k;
@@ -316,12 +364,18 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
       const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.a) + (size_t)n0 * 2), 0,
       (int)(((size_t)g.M * (size_t)g.lda - (size_t)n0) * 2), RSRC_FLAGS);
   const bool conv = g.conv != 0;
-  const int tap = conv ? k0 / g.ci : 0;                       // (ci is a multiple of 128: a tile lies inside one tap)
-  const int kb0 = conv ? k0 - tap * g.ci : k0;                // first input column of the tile
-  const int shift = tap - g.pad;
+  const bool inter = conv && g.taps > 1;                      // interleaved taps: tile tk = input chunks [tk cpt, (tk + 1) cpt) of every tap
+  const int kb0 = inter ? 0 : k0;                             // first input column behind the descriptor
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.b) + (size_t)kb0 * 2), 0,
       (int)(((size_t)(conv ? g.rows_b : g.M) * (size_t)g.ldb - (size_t)kb0) * 2), RSRC_FLAGS);
+  // this lane's SOURCE chunk position in a tile row is the same for all its DMA instructions ((row & 3) = (lane >> 4) & 3): its tap,
+  // its input chunk and whether that chunk exists
+  const int pc_src = ((((lane >> 1) & 7) ^ (2 * ((lane >> 4) & 3))) << 1) | (lane & 1);
+  const int tap_l = inter ? pc_src / g.cpt : 0;
+  const int cc_l = inter ? tk * g.cpt + (pc_src - tap_l * g.cpt) : 0;
+  const bool ok_l = !inter || (tap_l < g.taps && cc_l * 8 < g.ci);
+  const int shift = tap_l - g.pad;
   // instruction i of wave w fills rows (i * 4 + w) * 4 .. + 4 of a tile; lane l lands at row + (l >> 4), 16-byte chunk l & 15 =
   // (block l >> 1 & 7, half l & 1) and fetches block ((l >> 1) & 7) ^ (2 (row & 3)) of that row
   unsigned voa[4], vob[4];
@@ -331,14 +385,14 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
     const int blk = ((lane >> 1) & 7) ^ (2 * (row & 3));
     const unsigned col = (unsigned)(blk * 32 + (lane & 1) * 16);
     voa[i] = (unsigned)row * (unsigned)(g.lda * 2) + col;
-    vob[i] = conv ? col : (unsigned)row * (unsigned)(g.ldb * 2) + col;
+    vob[i] = inter ? (unsigned)(cc_l * 16) : (conv ? col : (unsigned)row * (unsigned)(g.ldb * 2) + col);
   }
   // convolution form: the input row of reduction row m (an offset far outside the descriptor reads as zeros)
   auto conv_off = [&](int mt, int i) -> unsigned {
     const int m = mt * 64 + (i * 4 + w) * 4 + (lane >> 4);
     const int b = (int)(((float)m + 0.5f) * g.inv_T_out);     // m < 2^22: exact
     const int xp = (m - b * g.T_out) * g.stride + shift;
-    const bool ok = xp >= 0 && xp < g.T_in && m < g.M;
+    const bool ok = xp >= 0 && xp < g.T_in && m < g.M && ok_l;
     return ok ? (unsigned)(b * g.T_in + xp) * (unsigned)(g.ldb * 2) + vob[i] : 0x7ffffff0u;
   };
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -378,17 +432,6 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // bias gradient (column sums of A): one more MFMA against a block of ones in the waves that own the first k tile's first half
-  const bool do_bias = g.bias_grad != nullptr && tk == 0 && wk == 0;
-  f32x16 accb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
-
   TN_ISSUE(0, mt0);
   int stage = 0;
   for (int mt = mt0; mt < mt1; ++mt) {
@@ -412,15 +455,39 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i], vb[j], acc[i][j], 0, 0, 0);
-      if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i], ones, accb[i], 0, 0, 0);
-      }
     }
     __builtin_amdgcn_s_barrier();
     stage ^= 1;
   }
 #undef TN_ISSUE
+  if (inter) {
+    // the tile through LDS: [128 n][128 columns = tap, chunk, channel] -> per n one run of cpt * 8 * taps floats in C's order
+    // (channel-major, tap-minor), added with coalesced atomics
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ct[(wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2) * 128 + kc] = acc[i][j][r] * g.alpha;
+    }
+    __syncthreads();
+    const int ch0 = tk * g.cpt * 8;                                       // first input channel of the tile
+    int nch = g.ci - ch0;
+    nch = nch < g.cpt * 8 ? nch : g.cpt * 8;
+    const int run = nch * g.taps;
+    for (int nl = w; nl < 128; nl += 4) {
+      const int n = n0 + nl;
+      if (n >= g.N) break;
+      float* dst = g.c + (size_t)n * (size_t)g.ldc + (size_t)ch0 * (size_t)g.taps;
+      for (int e = lane; e < run; e += 64) {
+        const int c = (int)(((float)e + 0.5f) / (float)g.taps), tp = e - c * g.taps;
+        unsafeAtomicAdd(dst + e, ct[nl * 128 + tp * g.cpt * 8 + c]);
+      }
+    }
+    return;
+  }
   // D[n][k]: column (B operand index) k = lane & 31, rows n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -432,19 +499,7 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
         if (n >= g.N) continue;
-        const size_t off = conv ? (size_t)n * (size_t)g.ldc + (size_t)(k - tap * g.ci) * (size_t)g.taps + (size_t)tap
-                                : (size_t)n * (size_t)g.ldc + (size_t)k;
-        unsafeAtomicAdd(g.c + off, acc[i][j][r] * g.alpha);
-      }
-    }
-  }
-  if (do_bias && (lane & 31) == 0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
-        if (n < g.N) unsafeAtomicAdd(g.bias_grad + n, accb[i][r] * g.alpha);
+        unsafeAtomicAdd(g.c + (size_t)n * (size_t)g.ldc + (size_t)k, acc[i][j][r] * g.alpha);
       }
     }
   }
@@ -559,7 +614,7 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
 }
 
 // slices of the reduction of a TN product
-static int tn_splits(int tiles, int MT, float atomics_cost = 0.058f) {
+static int tn_splits(int tiles, int MT) {
   // slices of the reduction: every slice adds its 128 x 128 partial with float atomics, and the atomics (slices x N x K of them, at
   // ~280 per ns through the L2s) are what a small output costs -- 24 000 rows x 128 x 128 on 375 slices: 27.8 us, 6 of them atomics
   // alone would take.  Cost model  t(s) = a ceil(MT / s) + b s tiles  (a = 0.5 us per 64-row step of a workgroup, b = 0.058 us per
@@ -569,7 +624,7 @@ static int tn_splits(int tiles, int MT, float atomics_cost = 0.058f) {
     const int s_min = (128 + tiles - 1) / tiles;
     float best = 1e30f;
     for (int s = s_min < MT ? s_min : MT; s <= MT; ++s) {
-      const float t = 0.5f * (float)((MT + s - 1) / s) + atomics_cost * (float)s * (float)tiles;
+      const float t = 0.5f * (float)((MT + s - 1) / s) + 0.058f * (float)s * (float)tiles;
       if (t < best) { best = t; splits = s; }
     }
   }
@@ -594,7 +649,8 @@ extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, i
   const int splits = tn_splits(tiles, MT);
   g.mt_per_split = (MT + splits - 1) / splits;
   g.splits = (MT + g.mt_per_split - 1) / g.mt_per_split;
-  hipLaunchKernelGGL(big_gemm_tn_kernel, dim3(tiles * g.splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
+  g.main_blocks = tiles * g.splits;
+  hipLaunchKernelGGL(big_gemm_tn_kernel, dim3(g.main_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
   JEN1_HIP(hipGetLastError());
   return 0;
 }
@@ -603,7 +659,7 @@ extern "C" int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, f
                                      int stride, int pad, int ld_dy, int ld_x, float alpha, void* stream) {
   JEN1_CHECK(dy && x && gw && B >= 1 && T_out >= 1 && T_in >= 1 && co >= 8 && ci >= 8 && taps >= 1 && stride >= 1, "big_gemm_tn_conv: bad arguments");
   JEN1_CHECK(co % 8 == 0 && ci % 8 == 0 && ld_dy >= co && ld_x >= ci && ld_dy % 8 == 0 && ld_x % 8 == 0, "big_gemm_tn_conv: widths and pitches must be multiples of 8 elements");
-  JEN1_CHECK(taps == 1 || ci % 128 == 0, "big_gemm_tn_conv: with more than one tap the input channels must be a multiple of 128 (a column tile lies inside one tap)");
+  JEN1_CHECK(taps <= 16, "big_gemm_tn_conv: at most 16 taps (a column tile holds an 8-channel chunk of every tap)");
   JEN1_CHECK((co % 128 == 0 || ld_dy >= ((co + 127) / 128) * 128) && (ci % 128 == 0 || ld_x >= ((ci + 127) / 128) * 128),
              "big_gemm_tn_conv: a partial last column tile must still lie inside the row pitch");
   const int64_t M = (int64_t)B * T_out, Mx = (int64_t)B * T_in;
@@ -614,14 +670,20 @@ extern "C" int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, f
   g.conv = 1; g.taps = taps; g.ci = ci; g.T_out = T_out; g.T_in = T_in; g.stride = stride; g.pad = pad; g.rows_b = (int)Mx;
   g.inv_T_out = 1.0f / (float)T_out; g.bias_grad = gb;
   g.tiles_n = (co + 127) / 128;
-  g.tiles_k = taps * ((ci + 127) / 128);
+  g.cpt = taps > 1 ? 16 / taps : 16;
+  g.tiles_k = taps > 1 ? (ci / 8 + g.cpt - 1) / g.cpt : (ci + 127) / 128;
   const int tiles = g.tiles_n * g.tiles_k, MT = (int)((M + 63) / 64);
-  // (with taps > 1 consecutive lanes add to floats `taps` apart and the taps' tiles meet in the same lines: an atomic costs ~3 x)
-  static const float conv_cost = getenv("JEN1_BGEMM_TN_CONV_COST") ? (float)atof(getenv("JEN1_BGEMM_TN_CONV_COST")) : 0.17f;
-  int splits = tn_splits(tiles, MT, taps > 1 ? conv_cost : 0.058f);
+  int splits = tn_splits(tiles, MT);
   g.mt_per_split = (MT + splits - 1) / splits;
   g.splits = (MT + g.mt_per_split - 1) / g.mt_per_split;
-  hipLaunchKernelGGL(big_gemm_tn_kernel, dim3(tiles * g.splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
+  g.main_blocks = tiles * g.splits;
+  if (gb) {
+    int nbk = (int)(M / 1536);
+    nbk = nbk < 1 ? 1 : (nbk > 32 ? 32 : nbk);
+    g.bias_rows = (int)((M + nbk - 1) / nbk);
+    g.bias_blocks = (int)((M + g.bias_rows - 1) / g.bias_rows);
+  }
+  hipLaunchKernelGGL(big_gemm_tn_kernel, dim3(g.main_blocks + g.bias_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

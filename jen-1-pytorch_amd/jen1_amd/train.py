@@ -90,12 +90,13 @@ class TrainRuntime:
         self.skinny_max_steps = int(os.environ.get("JEN1_TRAIN_SKINNY_STEPS", "64"))      # K steps per wave
         self.target_wgs = int(os.environ.get("JEN1_TRAIN_TARGET_WGS", "256"))
         self.min_steps = int(os.environ.get("JEN1_TRAIN_MIN_STEPS", "4"))      # K steps (of 32) a split keeps at least
-        # weight gradients over many rows on jen1_big_gemm_tn_conv.  Off: measured in the pass 45 - 50 us per launch at 24 000 x 128 x (3 x 128)
-        # against 40 on train_gemm's weight-gradient form (pass 13.65 against 13.56 ms).  The plain product of that size takes 13 - 16 us and the
-        # row map is free (13.4), but (a) with taps the floats consecutive lanes add to lie `taps` apart and the taps' tiles meet in the same
-        # lines (41.6 us at 3 taps), (b) the bias gradient's atomics of ~100 reduction slices all land on the same four lines (+23 us).  Both
-        # are epilogue work (interleave the taps through LDS; shard the bias sums) that round 4 did not get to
-        self.big_wgrads = os.environ.get("JEN1_TRAIN_BIG_WGRADS", "0") == "1"
+        # weight gradients over many rows (>= big_wgrad_rows) on jen1_big_gemm_tn_conv: 23 us at 24 000 x 128 x (3 x 128) with the bias
+        # gradient against 40 on train_gemm's weight-gradient form; the pass 13.58 -> 13.31 ms.  (First version: 45 us -- a tile of one tap adds
+        # floats `taps` apart in lines it shares with the other taps' workgroups, and every reduction slice's bias atomics land on the same
+        # four lines; the kernel now holds a chunk of every tap per tile and interleaves them through LDS, bias sums have workgroups of
+        # their own.)  big_wgrad_unpair: also take the mid-size layers out of the paired launches (measured: nothing, 13.34)
+        self.big_wgrads = os.environ.get("JEN1_TRAIN_BIG_WGRADS", "1") == "1"
+        self.big_wgrad_unpair = os.environ.get("JEN1_TRAIN_BIG_WGRAD_UNPAIR", "0") == "1"
         self.big_wgrad_rows = int(os.environ.get("JEN1_TRAIN_BIG_WGRAD_ROWS", "4096"))
         # weight gradients on their own stream (weight_grad below)
         # layers per fork; 0 (default): on the pass's own stream.  The fork was worth 1 ms while every weight gradient went through it; since
@@ -611,7 +612,8 @@ class ConvFn(Function):
         # (many-row layers: both products fill the chip, a pair would last their sum; the data gradient runs as the lean register-direct
         # kernel instead and the weight gradient goes to the queue)
         rows = (x.numel() // x.shape[-1])
-        many_rows = ((rows + 63) // 64) * ((g.ci + 63) // 64) >= rt.target_wgs
+        many_rows = ((rows + 63) // 64) * ((g.ci + 63) // 64) >= rt.target_wgs or (
+            rt.big_wgrads and rt.big_wgrad_unpair and rows >= rt.big_wgrad_rows and g.kind in ("conv", "linear") and rt.dt_of(x) == L.BF16)
         if ctx.needs_input_grad[0] and rt.pair_grads and not many_rows:
             # both gradients of the layer in one launch: they share dY and nothing orders them
             fused, blk = _conv_wgrad(rt, x, dy, gw, g, gb, defer=True)
