@@ -53,6 +53,32 @@ struct f32x8 {
   float v[8];
 };
 
+// sum over the 64 lanes of a wave, every lane gets it: DPP row steps and the two v_permlane swaps of gfx950 -- no LDS crossbar
+// (six ds_bpermute steps of __shfl_xor cost ~0.1 us each on a dependent chain)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0xB1>(v);                    // lanes ^ 1
+  v += dpp_mov<0x4E>(v);                    // lanes ^ 2
+  v += dpp_mov<0x141>(v);                   // row_half_mirror
+  v += dpp_mov<0x140>(v);                   // row_mirror
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);      // lanes ^ 16
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);   // lanes ^ 32
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 __device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p);
   const float4 b = *reinterpret_cast<const float4*>(p + 4);

@@ -109,10 +109,10 @@ __global__ __launch_bounds__(ANT) void attn_small_fwd_kernel(const AttnDev a) {
     const int lim = causal ? min(Nk, i + (Nk - Nq) + 1) : Nk;       // keys j < lim are kept (blocks.py:315-319)
     float m = -3.0e38f;
     for (int j = lane; j < lim; j += 64) m = fmaxf(m, S[i * sp + j]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    m = wave_max(m);
     float zs = 0.f;
     for (int j = lane; j < lim; j += 64) zs += expf(S[i * sp + j] - m);
-    for (int o = 32; o > 0; o >>= 1) zs += __shfl_xor(zs, o);
+    zs = wave_sum(zs);
     const float inv = 1.0f / zs;
     for (int j = lane; j < (int)a.ldp; j += 64) {
       const T pv = (T)(j < lim ? expf(S[i * sp + j] - m) * inv : 0.f);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(ANT) void attn_small_bwd_kernel(const AttnDev a) {
   for (int i = wave; i < Nq; i += ANT / 64) {
     float t = 0.f;
     for (int j = lane; j < Nk; j += 64) t += Pf[i * sp + j] * dS[i * sp + j];
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    t = wave_sum(t);
     for (int j = lane; j < Nk; j += 64) dS[i * sp + j] = Pf[i * sp + j] * (dS[i * sp + j] - t);
   }
   __syncthreads();

@@ -162,8 +162,7 @@ __device__ __forceinline__ void cfg_row(const T* __restrict__ pc, const T* __res
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) { a += r.oc[j]; b += r.g[j]; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    a = wave_sum(a); b = wave_sum(b);
     r.mc = a / (float)C;
     r.mg = b / (float)C;
     float va = 0.f, vb = 0.f;
@@ -174,8 +173,7 @@ __device__ __forceinline__ void cfg_row(const T* __restrict__ pc, const T* __res
       va += in ? dc * dc : 0.f;
       vb += in ? dg * dg : 0.f;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { va += __shfl_xor(va, off); vb += __shfl_xor(vb, off); }
+    va = wave_sum(va); vb = wave_sum(vb);
     r.sc = sqrtf(va / (float)(C - 1));           // unbiased (torch.std)
     r.sg = sqrtf(vb / (float)(C - 1));
     r.k = phi * (r.sc / r.sg) + (1.0f - phi);
@@ -203,8 +201,7 @@ __global__ __launch_bounds__(256) void cfg_loss_fwd_kernel(const T* __restrict__
       }
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  acc = wave_sum(acc);
   if (lane == 0) red[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(loss_ps + b, ((red[0] + red[1]) + (red[2] + red[3])) / ((float)C * (float)Tn));
@@ -234,8 +231,7 @@ __global__ __launch_bounds__(256) void cfg_loss_bwd_kernel(const T* __restrict__
       dk += dy[j] * r.g[j];
     }
     if (nrep == 2 && scale_cfg) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) dk += __shfl_xor(dk, off);
+      dk = wave_sum(dk);
       const float dr = phi * dk;
       const float dsc = dr / r.sg, dsg = -dr * r.sc / (r.sg * r.sg);
       const float fc = dsc / ((float)(C - 1) * r.sc), fg = dsg / ((float)(C - 1) * r.sg);

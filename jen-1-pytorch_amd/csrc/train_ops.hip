@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void gn_bwd_finish_kernel(const GnDev g) {
       m2 += ga * P[1];
       if (g.dfilm != nullptr) store_dfilm(g, b, c, P[2], P[3]);
     }
-    for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+    m1 = wave_sum(m1); m2 = wave_sum(m2);
     if (threadIdx.x == 0) {
       g.Gm[2 * (long long)blockIdx.x] = m1 * g.inv_count;
       g.Gm[2 * (long long)blockIdx.x + 1] = m2 * g.inv_count;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_dx_vec_kernel(const GnDev g, void* 
 constexpr int GU = 4;        // rows per thread whose loads are in flight together
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* red) {       // all threads of the NW waves get the sum; fixed order
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -663,11 +663,11 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const void* x_, const float*
   float s = 0.f;
   int n = 0;
   for (int c = lane; c < C; c += 64, ++n) { v[n] = (float)xr[c]; s += v[n]; }
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  s = wave_sum(s);
   const float mean = s / C;
   float q = 0.f;
   for (int i = 0; i < n; ++i) { const float d = v[i] - mean; q += d * d; }
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  q = wave_sum(q);
   const float rstd = 1.0f / sqrtf(q / C + eps);
   T* yr = y + (long long)row * ld;
   n = 0;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const void* x_, const fl
       for (int e = 0; e < 8; ++e) s += v[j][e];
     }
   }
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  s = wave_sum(s);
   const float mean = s / C;
   float q = 0.f;
 #pragma unroll
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const void* x_, const fl
       for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; q += d * d; }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  q = wave_sum(q);
   const float rstd = 1.0f / sqrtf(q / C + eps);
   T* yr = y + (long long)row * ld;
 #pragma unroll
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(NTB) void ln_bwd_kernel(const void* dy_, const void
       ab[n] += d;
     }
     if (dx_ == nullptr) continue;
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
     s1 /= C; s2 /= C;
     T* xo = dx + (long long)row * ld;
     n = 0;
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(NTB) void ln_bwd_vec_kernel(const void* dy_, const 
       }
     }
     if (dx_ == nullptr) continue;            // (the input needs no gradient -- the text context: only the column sums are wanted)
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
     s1 *= inv_C; s2 *= inv_C;
     T* xo = dx + (long long)row * ld;
 #pragma unroll
@@ -919,10 +919,10 @@ __global__ __launch_bounds__(NT) void softmax_fwd_kernel(const float* __restrict
   const float* sr = s + (long long)row * ld_s;
   float m = -3.0e38f;
   for (int j = lane; j < lim; j += 64) m = fmaxf(m, sr[j]);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  m = wave_max(m);
   float z = 0.f;
   for (int j = lane; j < lim; j += 64) z += expf(sr[j] - m);
-  for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+  z = wave_sum(z);
   const float inv = 1.0f / z;
   T* pr = p + (long long)row * ld_p;
   for (int j = lane; j < ld_p; j += 64) pr[j] = (T)(j < lim ? expf(sr[j] - m) * inv : 0.f);
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(NT) void softmax_bwd_kernel(const void* p_, const f
   const float* dr = dp + (long long)row * ld_s;
   float d = 0.f;
   for (int j = lane; j < Nk; j += 64) d += (float)pr[j] * dr[j];
-  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+  d = wave_sum(d);
   T* so = ds + (long long)row * ld_p;
   for (int j = lane; j < ld_p; j += 64) so[j] = (T)(j < Nk ? (float)pr[j] * (dr[j] - d) : 0.f);
 }
