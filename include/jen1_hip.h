@@ -362,11 +362,17 @@ int jen1_big_gemm(const jen1_bgemm_args* args, void* stream);
  * A = dY [M][lda >= N], B = the layer's input [M][ldb >= K] (bf16, as they lie in memory: the reduction index is the row), C float32
  * [N][ldc] accumulated with float atomics (the reduction is split over workgroups): ``param.grad`` of the reference layout. */
 int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream);
+/* the convolution form of jen1_big_gemm (bf16): y[b T_out + t][n] = sum_tap sum_c x[b T_in + t * stride + tap - pad][c] * W_tap[n][c] (+ bias[n])
+ * (+ residual[row][n]); rows outside [0, T_in) count as zeros.  W_tap = w + tap * w_tap_stride (tap_rev: taps - 1 - tap), [co][ld_w] with the
+ * ci input channels contiguous.  The forward and (stride 1, pad' = taps - 1 - pad, tap_rev) data-gradient passes of `_Conv1d`
+ * (blocks.py:34-53) over many rows: the long levels of the training pass.  ci must be a multiple of 64. */
+int jen1_big_gemm_conv(const void* x, const void* w, const float* bias, const void* residual, void* y, int B, int T_in, int T_out, int ci, int co,
+                       int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y, void* stream);
 /* the weight (and bias) gradient of a Conv1d / Linear over many rows (autograd of blocks.py:34-53 `_Conv1d`, the long levels of the
  * pass: B * T_out = 6 000 .. 24 000 reduction rows against 128 .. 512 channels): gw[co][ci][tap] += alpha * sum_{b,t} dy[b T_out + t][co] *
  * x[b T_in + t * stride + tap - pad][ci] (rows outside [0, T_in) count as zeros), gb[co] += alpha * sum_{b,t} dy[..][co] when gb is not
  * NULL.  dy [B T_out][ld_dy], x [B T_in][ld_x] bf16 as they lie in memory, gw float32 in the reference layout (`param.grad`),
- * accumulated with float atomics.  taps > 1 needs ci % 128 == 0. */
+ * accumulated with float atomics (runs of consecutive floats: a column tile of the kernel holds an 8-channel chunk of every tap).  taps <= 16. */
 int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, float* gb, int B, int T_out, int T_in, int co, int ci, int taps, int stride,
                           int pad, int ld_dy, int ld_x, float alpha, void* stream);
 

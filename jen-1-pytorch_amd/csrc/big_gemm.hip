@@ -263,6 +263,152 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Convolution form of the NT product (bf16): y[b T_out + t][n] = sum_tap sum_c x[b T_in + t stride + tap - pad][c] W_tap[n][c]
+// (+ bias[n]) (+ residual[row][n]) -- the forward and (stride 1, taps reversed) data-gradient passes of _Conv1d over many rows
+// (blocks.py:34-53; the long levels of the training pass).  The 128 x 128 / two-stage structure of big_gemm_nt_kernel<bf16, 2, 2>; the
+// activation tile of K step kt is the rows of ONE tap (ci is a multiple of the 64-channel step), fetched through the row map by
+// the LDS-DMA (rows outside [0, T_in) get an offset beyond the descriptor and arrive as zeros); the weight tile comes from that
+// tap's [N][ldw] matrix.
+// ---------------------------------------------------------------------------------------------------------------------
+struct CArgs {
+  const void* x;                // [B T_in][ldx]
+  const void* w;                // [taps][N][ldw], tap matrices w_tap_stride elements apart
+  const float* bias;            // [N] or null
+  const void* residual;         // [M][ldy] or null
+  void* y;                      // [M][ldy]
+  int32_t M, N, ldx, ldw, ldy, tiles_m, tiles_n;
+  int32_t taps, ci, T_out, T_in, stride, pad, rows_x, tap_rev, w_tap_stride;
+  float inv_T_out;
+};
+
+__global__ __launch_bounds__(256, 2) void big_gemm_conv_kernel(const CArgs g) {
+  constexpr int ES = 2, BK = 64, NWV = 4, TM = 128;
+  constexpr int A_B = TM * ROWB, STAGE = A_B + BN * ROWB;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tn = tile / g.tiles_m, tm = tile - tn * g.tiles_m;
+  const int m0 = tm * TM, n0 = tn * BN;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, (int)((size_t)g.rows_x * (size_t)g.ldx * ES), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w), 0, (int)((size_t)g.taps * (size_t)g.w_tap_stride * ES), RSRC_FLAGS);
+  // instruction i of wave w fills rows (i * 4 + w) * 8 .. + 8 of a tile; lane l lands at row + (l >> 3), physical chunk l & 7, and
+  // fetches chunk (l & 7) ^ ((row >> 1) & 7) of that row.  The activation rows go through the map: (batch element, position) of the
+  // lane's four rows are fixed, the tap's shift changes with the K step
+  int xb[4], xt[4];
+  unsigned xc[4], vob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * NWV + w) * 8 + (lane >> 3);
+    const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+    const int m = m0 + row;
+    const int b = (int)(((float)m + 0.5f) * g.inv_T_out);             // m < 2^22: exact
+    xb[i] = m < g.M ? b * g.T_in : -(1 << 28);                           // (rows past M: never valid)
+    xt[i] = (m - b * g.T_out) * g.stride;
+    xc[i] = chunk;
+    vob[i] = (unsigned)(n0 + row) * (unsigned)(g.ldw * ES) + chunk;
+  }
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const lds0 = (lds_u8*)smem;
+  const int spt = g.ci / BK;                                              // K steps per tap
+  auto a_off = [&](int i, int shift, unsigned cin_b) -> unsigned {
+    const int xp = xt[i] + shift;
+    const bool ok = xp >= 0 && xp < g.T_in && xb[i] >= 0;
+    return ok ? (unsigned)(xb[i] + xp) * (unsigned)(g.ldx * ES) + xc[i] + cin_b : 0x7ffffff0u;
+  };
+#define CG_ISSUE(stage_, kt_)                                                                                                        \
+  do {                                                                                                                               \
+    const int tap_ = (kt_) / spt;                                                                                                    \
+    const unsigned cin_b_ = (unsigned)(((kt_) - tap_ * spt) * BK * ES);                                                              \
+    const unsigned sob_ = (unsigned)((g.tap_rev ? g.taps - 1 - tap_ : tap_) * g.w_tap_stride * ES) + cin_b_;                         \
+    lds_u8* const sb_ = lds0 + (stage_) * STAGE + w * 1024;                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_ + i_ * NWV * 1024), 16, a_off(i_, tap_ - g.pad, cin_b_), 0u, 0, 0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B + i_ * NWV * 1024), 16, vob[i_], sob_, 0, 0);             \
+  } while (0)
+
+  // fragments: the weight tile is the MFMA's A operand (rows n), the activation tile its B operand (rows m)
+  const int wm = w & 1, wn = w >> 1;
+  const int fi = lane & 31, fg = lane >> 5;
+  const int swz = (fi >> 1) & 7;
+  const unsigned fa = (unsigned)(wn * 64 + fi) * ROWB + A_B;
+  const unsigned fb = (unsigned)(wm * 64 + fi) * ROWB;
+  unsigned xo[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) xo[kb] = (unsigned)((kb * 2 + fg) ^ swz) * 16u;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = g.taps * spt;
+  CG_ISSUE(0, 0);
+  int stage = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) {
+      CG_ISSUE(stage ^ 1, kt + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      u32x4 wa[2], xv[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        wa[q] = *reinterpret_cast<const u32x4*>(base + fa + q * 32 * ROWB + xo[kb]);
+        xv[q] = *reinterpret_cast<const u32x4*>(base + fb + q * 32 * ROWB + xo[kb]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xv[j]), acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+    stage ^= 1;
+  }
+#undef CG_ISSUE
+  // C / D layout of the 32 x 32 MFMA: column (here m) = lane & 31, rows (here n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  bf16_t* y = reinterpret_cast<bf16_t*>(g.y);
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(g.residual);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + fi;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int n = n0 + wn * 64 + i * 32 + q4 * 8 + fg * 4;
+        if (n >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q4 * 4 + r];
+        if (g.bias) {
+          const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        const size_t off = (size_t)m * (size_t)g.ldy + (size_t)n;
+        if (res) {
+          float o[4];
+          load4(res + off, o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += o[r];
+        }
+        store_out(y + off, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // TN form (weight gradients, bf16): C[n][k] += alpha * sum_m A[m][n] B[m][k], float32 atomics (the reduction over m is split
 // across workgroups), both operands with the reduction index as their ROW index ([m][cols], cols contiguous: dY and the layer's
 // input as they lie in memory).  Tiles go into LDS as they are (LDS-DMA: 64 reduction rows x 128 columns per operand and stage,
@@ -609,6 +755,28 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
     if (a->dtype == JEN1_F32) hipLaunchKernelGGL((big_gemm_nt_kernel<float, 2, 2>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((big_gemm_nt_kernel<bf16_t, 2, 2>), grid, dim3(256), 0, s, g);
   }
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_big_gemm_conv(const void* x, const void* w, const float* bias, const void* residual, void* y, int B, int T_in, int T_out, int ci,
+                                  int co, int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y, void* stream) {
+  JEN1_CHECK(x && w && y && B >= 1 && T_in >= 1 && T_out >= 1 && taps >= 1 && stride >= 1, "big_gemm_conv: bad arguments");
+  JEN1_CHECK(ci >= 64 && ci % 64 == 0, "big_gemm_conv: the input channels (%d) must be a multiple of 64 (a K step lies inside one tap)", ci);
+  JEN1_CHECK(co >= 4 && co % 4 == 0 && ld_x >= ci && ld_w >= ci && ld_y >= co && ld_x % 8 == 0 && ld_w % 8 == 0 && ld_y % 4 == 0,
+             "big_gemm_conv: widths / pitches (ci, ld_x, ld_w multiples of 8 elements; co, ld_y of 4)");
+  JEN1_CHECK(w_tap_stride >= co * ld_w || taps == 1, "big_gemm_conv: tap matrices overlap");
+  const int64_t M = (int64_t)B * T_out, Mx = (int64_t)B * T_in;
+  JEN1_CHECK(M < ((int64_t)1 << 22) && Mx * ld_x * 2 < 0x7ffffff0ll && (int64_t)taps * w_tap_stride * 2 < ((int64_t)1 << 31) && M * ld_y * 2 < ((int64_t)1 << 40),
+             "big_gemm_conv: operand too large");
+  CArgs g;
+  memset(&g, 0, sizeof(g));
+  g.x = x; g.w = w; g.bias = bias; g.residual = residual; g.y = y;
+  g.M = (int)M; g.N = co; g.ldx = ld_x; g.ldw = ld_w; g.ldy = ld_y;
+  g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (co + BN - 1) / BN;
+  g.taps = taps; g.ci = ci; g.T_out = T_out; g.T_in = T_in; g.stride = stride; g.pad = pad; g.rows_x = (int)Mx; g.tap_rev = tap_rev ? 1 : 0;
+  g.w_tap_stride = w_tap_stride; g.inv_T_out = 1.0f / (float)T_out;
+  hipLaunchKernelGGL(big_gemm_conv_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -97,6 +97,9 @@ class TrainRuntime:
         # their own.)  big_wgrad_unpair: also take the mid-size layers out of the paired launches (measured: nothing, 13.34)
         self.big_wgrads = os.environ.get("JEN1_TRAIN_BIG_WGRADS", "1") == "1"
         self.big_wgrad_unpair = os.environ.get("JEN1_TRAIN_BIG_WGRAD_UNPAIR", "0") == "1"
+        # forward / data gradient of convolutions over many rows on jen1_big_gemm_conv
+        self.big_convs = os.environ.get("JEN1_TRAIN_BIG_CONVS", "1") == "1"
+        self.big_conv_rows = int(os.environ.get("JEN1_TRAIN_BIG_CONV_ROWS", "4096"))
         self.big_wgrad_rows = int(os.environ.get("JEN1_TRAIN_BIG_WGRAD_ROWS", "4096"))
         # weight gradients on their own stream (weight_grad below)
         # layers per fork; 0 (default): on the pass's own stream.  The fork was worth 1 ms while every weight gradient went through it; since
@@ -409,6 +412,12 @@ class TrainRuntime:
         wgs = ((M + 31) // 32) * ((N + 15) // 16)
         return tiles < self.target_wgs // 2 and wgs <= 4096 and ksteps <= 4 * self.skinny_max_steps
 
+    def count(self, family: str, flops: float, nbytes: float) -> None:
+        """one launch of ``family`` in the counting pass of bench.py"""
+        if self.stats is not None:
+            e = self.stats.setdefault(family, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += flops; e[2] += nbytes
+
     def pick_splitk(self, M: int, N: int, ksteps: int, z: int = 1) -> int:
         tiles = ((M + 63) // 64) * ((N + 63) // 64) * z
         if tiles >= self.target_wgs // 2:
@@ -472,11 +481,23 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     a = _operand(x.data_ptr(), ldx, 1, m=g.fwd_map(1))
     b = _operand(wp.data_ptr(), cip, 1, tap_stride=co * cip)
     ksteps = k * ((cip + 31) // 32)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.numel() == B * g.L_out * ldy and residual.dtype == x.dtype, (residual.shape, B, g.L_out, ldy)
+    if (rt.big_convs and dt == L.BF16 and g.kind in ("conv", "linear") and M >= rt.big_conv_rows and g.pad_b is None and not g.reflect
+            and g.ci % 64 == 0 and cip == g.ci and co % 4 == 0):
+        # many rows (the long levels): the 128 x 128 matrix-core kernel with the taps in its row map (jen1_big_gemm_conv: 10 us at
+        # 24 000 x 128 x (3 x 128) against 25 on the register-direct form)
+        y = (torch.zeros if ldy != co else torch.empty)((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
+        conv = g.kind == "conv"
+        L.check(rt.lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
+                                          None if residual is None else residual.data_ptr(), y.data_ptr(), B if conv else M, g.L_in if conv else 1,
+                                          g.L_out if conv else 1, g.ci, co, k, g.stride if conv else 1, g.pad if conv else 0, 0, ldx, cip, co * cip, ldy,
+                                          rt.stream()), "jen1_big_gemm_conv")
+        rt.count("big_gemm", 2.0 * M * co * cip * k, 2.0 * (rows_in * ldx + k * co * cip + M * ldy))
+        return y
     skinny = rt.want_skinny(M, co, ksteps)
     sk = 1 if skinny else rt.pick_splitk(M, co, ksteps)
     alloc = torch.zeros if (ldy != co or sk > 1) else torch.empty
-    if residual is not None:
-        assert residual.is_contiguous() and residual.numel() == B * g.L_out * ldy and residual.dtype == x.dtype, (residual.shape, B, g.L_out, ldy)
     if sk > 1:
         acc = rt.split_accumulator(B * g.L_out * ldy)
         rt.gemm(a, b, acc.data_ptr(), M, co, cip, dtype=dt, taps=k, ldc_m=ldy, bias=bias, splitk=sk, atomic=True, c_f32=True, shift_b=g.fwd_shift_b)
@@ -512,6 +533,16 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     else:
         b = _operand(wp.data_ptr(), 1, cip, tap_stride=co * cip)
         cip_n = cip
+    if (rt.big_convs and wd is not None and pair_with is None and dt == L.BF16 and M >= rt.big_conv_rows and g.pad_b is None and ldy % 64 == 0
+            and (g.kind == "linear" or (g.kind == "conv" and g.stride == 1)) and cip_n % 4 == 0):
+        # the data gradient over many rows: the same kernel on dy, taps reversed, pad' = taps - 1 - pad
+        dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
+        conv = g.kind == "conv"
+        L.check(rt.lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None if residual is None else residual.data_ptr(), dx.data_ptr(),
+                                          B if conv else M, g.L_out if conv else 1, g.L_in if conv else 1, ldy, cip_n, k, 1, (k - 1 - g.pad) if conv else 0, 1,
+                                          ldy, ldy, cip_n * ldy, cip, rt.stream()), "jen1_big_gemm_conv")
+        rt.count("big_gemm", 2.0 * M * cip_n * ldy * k, 2.0 * (B * g.L_out * ldy + k * cip_n * ldy + M * cip))
+        return dx
     ksteps = k * ((co + 31) // 32)
     skinny = wd is not None and rt.want_skinny(M, cip_n, ksteps)
     sk = 1 if skinny else rt.pick_splitk(M, cip, ksteps)

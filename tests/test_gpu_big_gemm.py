@@ -179,3 +179,48 @@ def test_conv_weight_gradient_tn_matches_torch(B, T_in, ci, co, taps, stride, pa
         assert rel_err((gb - gb0).cpu().numpy(), bias.grad.cpu().numpy()) < 2e-5
     else:
         assert torch.equal(gb, gb0)
+
+
+@pytest.mark.parametrize("B,T_in,ci,co,taps,stride,pad,with_bias,with_res", [
+    (3, 50, 128, 64, 3, 1, 1, True, False),       # centred k = 3
+    (3, 50, 128, 128, 3, 1, 2, False, True),      # causal k = 3 + residual
+    (2, 257, 256, 96, 5, 2, 2, True, False),      # strided k = 5, ragged rows, 96 output channels inside a 128-column tile
+    (16, 1500, 128, 128, 3, 1, 1, True, True),    # the level-0 shape of the training pass
+    (4, 129, 192, 72, 1, 1, 0, True, False),      # 1 x 1
+])
+def test_conv_form_forward_and_data_gradient_match_torch(B, T_in, ci, co, taps, stride, pad, with_bias, with_res):
+    """jen1_big_gemm_conv: y = conv1d(x, W) (+ bias) (+ residual) through the row map of the matrix-core GEMM, and -- for stride 1 -- the
+    data gradient as the same kernel on dy with the taps reversed and pad' = taps - 1 - pad, against torch conv1d and its autograd"""
+    import torch.nn.functional as F
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(B * 17 + T_in + ci + taps)
+    T_out = (T_in - 1) // stride + 1 if taps > 1 else T_in        # total padding taps - 1
+    ldy = -(-co // 8) * 8
+    x = (torch.randn((B, T_in, ci), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((co, ci, taps), device="cuda", generator=gen) * 0.1).to(torch.bfloat16)
+    wp = w.permute(2, 0, 1).contiguous()                            # [taps][co][ci]: the forward compute copy
+    bias = torch.randn((co,), device="cuda", generator=gen) if with_bias else None
+    res = (torch.randn((B, T_out, ldy), device="cuda", generator=gen) * 0.5).to(torch.bfloat16) if with_res else None
+    y = torch.full((B, T_out, ldy), 3.0, device="cuda", dtype=torch.bfloat16)
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(), None if res is None else res.data_ptr(),
+                                   y.data_ptr(), B, T_in, T_out, ci, co, taps, stride, pad, 0, ci, ci, co * ci, ldy, s), "jen1_big_gemm_conv")
+    torch.cuda.synchronize()
+    xin = x.float().permute(0, 2, 1).requires_grad_(True)
+    xp = F.pad(xin, (pad, taps - 1 - pad)) if taps > 1 else xin
+    ref = F.conv1d(xp, w.float(), bias, stride=stride)
+    assert ref.shape[-1] == T_out
+    want = ref.permute(0, 2, 1) + (res[..., :co].float() if with_res else 0.0)
+    assert rel_err(y[..., :co].float().cpu().numpy(), want.detach().cpu().numpy()) < 6e-3          # (bf16 output rounding)
+    if stride != 1:
+        return
+    dy = (torch.randn((B, T_out, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    if co % 64:
+        return                                                     # (the data gradient reduces over co: multiples of 64 only)
+    wd = w.permute(2, 1, 0).contiguous()                            # [taps][ci][co]: the data-gradient twin
+    dx = torch.zeros((B, T_in, ci), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T_out, T_in, co, ci, taps, 1, taps - 1 - pad, 1, co, co,
+                                   ci * co, ci, s), "jen1_big_gemm_conv")
+    torch.cuda.synchronize()
+    ref.backward(dy.float().permute(0, 2, 1))
+    assert rel_err(dx.float().cpu().numpy(), xin.grad.permute(0, 2, 1).cpu().numpy()) < 6e-3
