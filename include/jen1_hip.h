@@ -367,14 +367,15 @@ int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K
  * ci input channels contiguous.  The forward and (stride 1, pad' = taps - 1 - pad, tap_rev) data-gradient passes of `_Conv1d`
  * (blocks.py:34-53) over many rows: the long levels of the training pass.  ci must be a multiple of 64. */
 int jen1_big_gemm_conv(const void* x, const void* w, const float* bias, const void* residual, void* y, int B, int T_in, int T_out, int ci, int co,
-                       int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y, void* stream);
+                       int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y, const int32_t* shift_b /* [B] added to
+                       the row shift tap - pad per batch element (causal and centred clips in one pass, blocks.py:45-50), or NULL */, void* stream);
 /* the weight (and bias) gradient of a Conv1d / Linear over many rows (autograd of blocks.py:34-53 `_Conv1d`, the long levels of the
  * pass: B * T_out = 6 000 .. 24 000 reduction rows against 128 .. 512 channels): gw[co][ci][tap] += alpha * sum_{b,t} dy[b T_out + t][co] *
  * x[b T_in + t * stride + tap - pad][ci] (rows outside [0, T_in) count as zeros), gb[co] += alpha * sum_{b,t} dy[..][co] when gb is not
  * NULL.  dy [B T_out][ld_dy], x [B T_in][ld_x] bf16 as they lie in memory, gw float32 in the reference layout (`param.grad`),
  * accumulated with float atomics (runs of consecutive floats: a column tile of the kernel holds an 8-channel chunk of every tap).  taps <= 16. */
 int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, float* gb, int B, int T_out, int T_in, int co, int ci, int taps, int stride,
-                          int pad, int ld_dy, int ld_x, float alpha, void* stream);
+                          int pad, int ld_dy, int ld_x, float alpha, const int32_t* shift_b /* as in jen1_big_gemm_conv */, void* stream);
 
 /* y[r][0..C) = (x[r] - mean_r) / sqrt(var_r + eps): LayerNorm's standardisation (blocks.py:400-401 ``norm_context`` without its
  * affine, which the packed weights carry) of float32 rows, written in the compute dtype; statistics over the ROUNDED values */

@@ -279,6 +279,7 @@ struct CArgs {
   int32_t M, N, ldx, ldw, ldy, tiles_m, tiles_n;
   int32_t taps, ci, T_out, T_in, stride, pad, rows_x, tap_rev, w_tap_stride;
   float inv_T_out;
+  const int32_t* shift_b;       // per batch element, added to the row shift tap - pad (a pass that mixes causal and centred padding), or null
 };
 
 __global__ __launch_bounds__(256, 2) void big_gemm_conv_kernel(const CArgs g) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void big_gemm_conv_kernel(const CArgs g) {
     const int m = m0 + row;
     const int b = (int)(((float)m + 0.5f) * g.inv_T_out);             // m < 2^22: exact
     xb[i] = m < g.M ? b * g.T_in : -(1 << 28);                           // (rows past M: never valid)
-    xt[i] = (m - b * g.T_out) * g.stride;
+    xt[i] = (m - b * g.T_out) * g.stride + ((g.shift_b && m < g.M) ? g.shift_b[b] : 0);
     xc[i] = chunk;
     vob[i] = (unsigned)(n0 + row) * (unsigned)(g.ldw * ES) + chunk;
   }
@@ -432,6 +433,7 @@ struct TArgs {
   // runs of cpt * 8 * taps consecutive floats of C and adds them with coalesced atomics (a tile of ONE tap would add floats `taps` apart,
   // in lines it shares with the other taps' workgroups: 41.6 against 16 us at 24 000 x 128 x (3 x 128))
   int32_t cpt, main_blocks, bias_blocks, bias_rows;
+  const int32_t* shift_b;       // convolution form: per batch element, added to the row shift tap - pad, or null
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -537,8 +539,9 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
   auto conv_off = [&](int mt, int i) -> unsigned {
     const int m = mt * 64 + (i * 4 + w) * 4 + (lane >> 4);
     const int b = (int)(((float)m + 0.5f) * g.inv_T_out);     // m < 2^22: exact
-    const int xp = (m - b * g.T_out) * g.stride + shift;
-    const bool ok = xp >= 0 && xp < g.T_in && m < g.M && ok_l;
+    const bool mv = m < g.M;
+    const int xp = (m - b * g.T_out) * g.stride + shift + ((g.shift_b && mv) ? g.shift_b[b] : 0);
+    const bool ok = xp >= 0 && xp < g.T_in && mv && ok_l;
     return ok ? (unsigned)(b * g.T_in + xp) * (unsigned)(g.ldb * 2) + vob[i] : 0x7ffffff0u;
   };
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -760,7 +763,8 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
 }
 
 extern "C" int jen1_big_gemm_conv(const void* x, const void* w, const float* bias, const void* residual, void* y, int B, int T_in, int T_out, int ci,
-                                  int co, int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y, void* stream) {
+                                  int co, int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y,
+                                  const int32_t* shift_b, void* stream) {
   JEN1_CHECK(x && w && y && B >= 1 && T_in >= 1 && T_out >= 1 && taps >= 1 && stride >= 1, "big_gemm_conv: bad arguments");
   JEN1_CHECK(ci >= 64 && ci % 64 == 0, "big_gemm_conv: the input channels (%d) must be a multiple of 64 (a K step lies inside one tap)", ci);
   JEN1_CHECK(co >= 4 && co % 4 == 0 && ld_x >= ci && ld_w >= ci && ld_y >= co && ld_x % 8 == 0 && ld_w % 8 == 0 && ld_y % 4 == 0,
@@ -775,7 +779,7 @@ extern "C" int jen1_big_gemm_conv(const void* x, const void* w, const float* bia
   g.M = (int)M; g.N = co; g.ldx = ld_x; g.ldw = ld_w; g.ldy = ld_y;
   g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (co + BN - 1) / BN;
   g.taps = taps; g.ci = ci; g.T_out = T_out; g.T_in = T_in; g.stride = stride; g.pad = pad; g.rows_x = (int)Mx; g.tap_rev = tap_rev ? 1 : 0;
-  g.w_tap_stride = w_tap_stride; g.inv_T_out = 1.0f / (float)T_out;
+  g.w_tap_stride = w_tap_stride; g.inv_T_out = 1.0f / (float)T_out; g.shift_b = shift_b;
   hipLaunchKernelGGL(big_gemm_conv_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
   JEN1_HIP(hipGetLastError());
   return 0;
@@ -824,7 +828,7 @@ extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, i
 }
 
 extern "C" int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, float* gb, int B, int T_out, int T_in, int co, int ci, int taps,
-                                     int stride, int pad, int ld_dy, int ld_x, float alpha, void* stream) {
+                                     int stride, int pad, int ld_dy, int ld_x, float alpha, const int32_t* shift_b, void* stream) {
   JEN1_CHECK(dy && x && gw && B >= 1 && T_out >= 1 && T_in >= 1 && co >= 8 && ci >= 8 && taps >= 1 && stride >= 1, "big_gemm_tn_conv: bad arguments");
   JEN1_CHECK(co % 8 == 0 && ci % 8 == 0 && ld_dy >= co && ld_x >= ci && ld_dy % 8 == 0 && ld_x % 8 == 0, "big_gemm_tn_conv: widths and pitches must be multiples of 8 elements");
   JEN1_CHECK(taps <= 16, "big_gemm_tn_conv: at most 16 taps (a column tile holds an 8-channel chunk of every tap)");
@@ -836,7 +840,7 @@ extern "C" int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, f
   memset(&g, 0, sizeof(g));
   g.a = dy; g.b = x; g.c = gw; g.M = (int)M; g.N = co; g.K = taps * ci; g.lda = ld_dy; g.ldb = ld_x; g.ldc = ci * taps; g.alpha = alpha;
   g.conv = 1; g.taps = taps; g.ci = ci; g.T_out = T_out; g.T_in = T_in; g.stride = stride; g.pad = pad; g.rows_b = (int)Mx;
-  g.inv_T_out = 1.0f / (float)T_out; g.bias_grad = gb;
+  g.inv_T_out = 1.0f / (float)T_out; g.bias_grad = gb; g.shift_b = shift_b;
   g.tiles_n = (co + 127) / 128;
   g.cpt = taps > 1 ? 16 / taps : 16;
   g.tiles_k = taps > 1 ? (ci / 8 + g.cpt - 1) / g.cpt : (ci + 127) / 128;

@@ -483,7 +483,7 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     ksteps = k * ((cip + 31) // 32)
     if residual is not None:
         assert residual.is_contiguous() and residual.numel() == B * g.L_out * ldy and residual.dtype == x.dtype, (residual.shape, B, g.L_out, ldy)
-    if (rt.big_convs and dt == L.BF16 and g.kind in ("conv", "linear") and M >= rt.big_conv_rows and g.pad_b is None and not g.reflect
+    if (rt.big_convs and dt == L.BF16 and g.kind in ("conv", "linear") and M >= rt.big_conv_rows and not g.reflect
             and g.ci % 64 == 0 and cip == g.ci and co % 4 == 0):
         # many rows (the long levels): the 128 x 128 matrix-core kernel with the taps in its row map (jen1_big_gemm_conv: 10 us at
         # 24 000 x 128 x (3 x 128) against 25 on the register-direct form)
@@ -491,8 +491,8 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
         conv = g.kind == "conv"
         L.check(rt.lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
                                           None if residual is None else residual.data_ptr(), y.data_ptr(), B if conv else M, g.L_in if conv else 1,
-                                          g.L_out if conv else 1, g.ci, co, k, g.stride if conv else 1, g.pad if conv else 0, 0, ldx, cip, co * cip, ldy,
-                                          rt.stream()), "jen1_big_gemm_conv")
+                                          g.L_out if conv else 1, g.ci, co, k, g.stride if conv else 1, (0 if g.pad_b is not None else g.pad) if conv else 0,
+                                          0, ldx, cip, co * cip, ldy, None if g.pad_b is None else g.fwd_shift_b.data_ptr(), rt.stream()), "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * co * cip * k, 2.0 * (rows_in * ldx + k * co * cip + M * ldy))
         return y
     skinny = rt.want_skinny(M, co, ksteps)
@@ -533,14 +533,15 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
     else:
         b = _operand(wp.data_ptr(), 1, cip, tap_stride=co * cip)
         cip_n = cip
-    if (rt.big_convs and wd is not None and pair_with is None and dt == L.BF16 and M >= rt.big_conv_rows and g.pad_b is None and ldy % 64 == 0
+    if (rt.big_convs and wd is not None and pair_with is None and dt == L.BF16 and M >= rt.big_conv_rows and ldy % 64 == 0
             and (g.kind == "linear" or (g.kind == "conv" and g.stride == 1)) and cip_n % 4 == 0):
         # the data gradient over many rows: the same kernel on dy, taps reversed, pad' = taps - 1 - pad
         dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
         conv = g.kind == "conv"
         L.check(rt.lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None if residual is None else residual.data_ptr(), dx.data_ptr(),
-                                          B if conv else M, g.L_out if conv else 1, g.L_in if conv else 1, ldy, cip_n, k, 1, (k - 1 - g.pad) if conv else 0, 1,
-                                          ldy, ldy, cip_n * ldy, cip, rt.stream()), "jen1_big_gemm_conv")
+                                          B if conv else M, g.L_out if conv else 1, g.L_in if conv else 1, ldy, cip_n, k, 1,
+                                          ((k - 1) if g.pad_b is not None else (k - 1 - g.pad)) if conv else 0, 1, ldy, ldy, cip_n * ldy, cip,
+                                          None if g.pad_b is None else g.bwd_shift_b.data_ptr(), rt.stream()), "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * cip_n * ldy * k, 2.0 * (B * g.L_out * ldy + k * cip_n * ldy + M * cip))
         return dx
     ksteps = k * ((co + 31) // 32)
@@ -583,15 +584,16 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
         a = _operand(dy.data_ptr(), 1, ldy)
         b = _operand(x.data_ptr(), 1, ldx, m=g.fwd_map(2))
         M, N = g.co, g.ci
-    if (rt.big_wgrads and not defer and g.kind in ("conv", "linear") and dt == L.BF16 and K >= rt.big_wgrad_rows and g.pad_b is None
+    if (rt.big_wgrads and not defer and g.kind in ("conv", "linear") and dt == L.BF16 and K >= rt.big_wgrad_rows
             and not g.reflect and x.is_contiguous() and dy.is_contiguous() and g.co % 8 == 0 and g.ci % 8 == 0 and K % g.L_out == 0
             and (g.ci % 128 == 0 if k > 1 else ldx >= -(-g.ci // 128) * 128) and (g.co % 128 == 0 or ldy >= -(-g.co // 128) * 128)
             and (x.numel() // ldx) * g.L_out == K * g.L_in and gw.is_contiguous()):
         # many reduction rows against a small output (the long levels): the transposing matrix-core kernel with the tap shift in its
         # row map and the bias gradient as one more MFMA (switch: TrainRuntime.big_wgrads, off by default)
         L.check(rt.lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), None if gb is None else gb.data_ptr(), K // g.L_out,
-                                             g.L_out, g.L_in, g.co, g.ci, k, g.stride if g.kind == "conv" else 1, g.pad if g.kind == "conv" else 0,
-                                             ldy, ldx, 1.0, rt.stream()), "jen1_big_gemm_tn_conv")
+                                             g.L_out, g.L_in, g.co, g.ci, k, g.stride if g.kind == "conv" else 1,
+                                             (0 if g.pad_b is not None else g.pad) if g.kind == "conv" else 0, ldy, ldx, 1.0,
+                                             None if g.pad_b is None else g.fwd_shift_b.data_ptr(), rt.stream()), "jen1_big_gemm_tn_conv")
         if rt.stats is not None:
             e = rt.stats.setdefault("big_gemm", [0, 0.0, 0.0])
             e[0] += 1; e[1] += 2.0 * K * g.co * g.ci * k; e[2] += 2.0 * K * (g.co + g.ci) + 8.0 * g.co * g.ci * k

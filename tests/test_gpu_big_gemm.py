@@ -165,7 +165,7 @@ def test_conv_weight_gradient_tn_matches_torch(B, T_in, ci, co, taps, stride, pa
     gb0 = torch.randn((co,), device="cuda", generator=gen)
     gw, gb = gw0.clone(), gb0.clone()
     L.check(lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if with_bias else None, B, T_out, T_in, co, ci, taps,
-                                      stride, pad, ldy, ldx, 1.0, torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn_conv")
+                                      stride, pad, ldy, ldx, 1.0, None, torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn_conv")
     torch.cuda.synchronize()
     w = torch.zeros((co, ci, taps), device="cuda", requires_grad=True)
     bias = torch.zeros((co,), device="cuda", requires_grad=True)
@@ -204,7 +204,7 @@ def test_conv_form_forward_and_data_gradient_match_torch(B, T_in, ci, co, taps, 
     y = torch.full((B, T_out, ldy), 3.0, device="cuda", dtype=torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
     L.check(lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(), None if res is None else res.data_ptr(),
-                                   y.data_ptr(), B, T_in, T_out, ci, co, taps, stride, pad, 0, ci, ci, co * ci, ldy, s), "jen1_big_gemm_conv")
+                                   y.data_ptr(), B, T_in, T_out, ci, co, taps, stride, pad, 0, ci, ci, co * ci, ldy, None, s), "jen1_big_gemm_conv")
     torch.cuda.synchronize()
     xin = x.float().permute(0, 2, 1).requires_grad_(True)
     xp = F.pad(xin, (pad, taps - 1 - pad)) if taps > 1 else xin
@@ -220,7 +220,44 @@ def test_conv_form_forward_and_data_gradient_match_torch(B, T_in, ci, co, taps, 
     wd = w.permute(2, 1, 0).contiguous()                            # [taps][ci][co]: the data-gradient twin
     dx = torch.zeros((B, T_in, ci), device="cuda", dtype=torch.bfloat16)
     L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T_out, T_in, co, ci, taps, 1, taps - 1 - pad, 1, co, co,
-                                   ci * co, ci, s), "jen1_big_gemm_conv")
+                                   ci * co, ci, None, s), "jen1_big_gemm_conv")
     torch.cuda.synchronize()
     ref.backward(dy.float().permute(0, 2, 1))
     assert rel_err(dx.float().cpu().numpy(), xin.grad.permute(0, 2, 1).cpu().numpy()) < 6e-3
+
+
+def test_conv_form_with_padding_per_batch_element():
+    """causal (left pad k - 1) and centred clips side by side in one pass (trainer.py:189-211 merged; blocks.py:45-50): the row shift of
+    jen1_big_gemm_conv / jen1_big_gemm_tn_conv per batch element, forward, data gradient and weight gradient against torch per clip"""
+    import torch.nn.functional as F
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    B, T, ci, co, k = 4, 300, 128, 128, 3
+    pads = [2, 1, 2, 1]
+    x = (torch.randn((B, T, ci), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((co, ci, k), device="cuda", generator=gen) * 0.1).to(torch.bfloat16)
+    dy = (torch.randn((B, T, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    wp, wd = w.permute(2, 0, 1).contiguous(), w.permute(2, 1, 0).contiguous()
+    fwd_shift = torch.tensor([-p for p in pads], dtype=torch.int32, device="cuda")
+    bwd_shift = torch.tensor(pads, dtype=torch.int32, device="cuda")
+    y = torch.zeros((B, T, co), device="cuda", dtype=torch.bfloat16)
+    dx = torch.zeros((B, T, ci), device="cuda", dtype=torch.bfloat16)
+    gw = torch.zeros((co, ci, k), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), B, T, T, ci, co, k, 1, 0, 0, ci, ci, co * ci, co,
+                                   fwd_shift.data_ptr(), s), "fwd")
+    L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T, T, co, ci, k, 1, k - 1, 1, co, co, ci * co, ci,
+                                   bwd_shift.data_ptr(), s), "dgrad")
+    L.check(lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), None, B, T, T, co, ci, k, 1, 0, co, ci, 1.0, fwd_shift.data_ptr(), s), "wgrad")
+    torch.cuda.synchronize()
+    wf = w.float().requires_grad_(True)
+    ys, dxs = [], []
+    for b in range(B):
+        xin = x[b:b + 1].float().permute(0, 2, 1).requires_grad_(True)
+        yb = F.conv1d(F.pad(xin, (pads[b], k - 1 - pads[b])), wf)
+        yb.backward(dy[b:b + 1].float().permute(0, 2, 1))
+        ys.append(yb.detach().permute(0, 2, 1))
+        dxs.append(xin.grad.permute(0, 2, 1))
+    assert rel_err(y.float().cpu().numpy(), torch.cat(ys).cpu().numpy()) < 6e-3
+    assert rel_err(dx.float().cpu().numpy(), torch.cat(dxs).cpu().numpy()) < 6e-3
+    assert rel_err(gw.cpu().numpy(), wf.grad.cpu().numpy()) < 2e-5
