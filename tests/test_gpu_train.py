@@ -1206,3 +1206,22 @@ def test_layer_norm_backward_without_input_gradient(rts, mode, rows, C):
         assert (x.grad is not None) == needs
     for a, b in zip(got[True], got[False]):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("rows,C,ld", [(24000, 128, 128), (2500, 72, 128), (6016, 256, 256), (37, 40, 40)])
+def test_colsum_many_rows_and_few(mode, rows, C, ld):
+    """jen1_colsum (the bias gradient where no GEMM carries it: sum over (b, t) of dy): the long-slice form of the long levels and the
+    small form, accumulated into a non-zero vector; padding columns of the pitch never reach the result"""
+    from jen1_amd import lib as L
+    lib = L.load()
+    td = torch.float32 if mode == "f32" else torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(rows + C)
+    x = torch.full((rows, ld), 9.0, device="cuda", dtype=td)
+    x[:, :C] = (torch.randn((rows, C), device="cuda", generator=gen)).to(td)
+    out0 = torch.randn((C,), device="cuda", generator=gen)
+    out = out0.clone()
+    L.check(lib.jen1_colsum(x.data_ptr(), out.data_ptr(), rows, C, ld, L.F32 if mode == "f32" else L.BF16, torch.cuda.current_stream().cuda_stream), "jen1_colsum")
+    torch.cuda.synchronize()
+    want = out0.double() + x[:, :C].double().sum(0)
+    assert rel_err(out.cpu().numpy(), want.float().cpu().numpy()) < 1e-5
