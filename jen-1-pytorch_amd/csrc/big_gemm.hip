@@ -830,9 +830,12 @@ extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, i
 extern "C" int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, float* gb, int B, int T_out, int T_in, int co, int ci, int taps,
                                      int stride, int pad, int ld_dy, int ld_x, float alpha, const int32_t* shift_b, void* stream) {
   JEN1_CHECK(dy && x && gw && B >= 1 && T_out >= 1 && T_in >= 1 && co >= 8 && ci >= 8 && taps >= 1 && stride >= 1, "big_gemm_tn_conv: bad arguments");
-  JEN1_CHECK(co % 8 == 0 && ci % 8 == 0 && ld_dy >= co && ld_x >= ci && ld_dy % 8 == 0 && ld_x % 8 == 0, "big_gemm_tn_conv: widths and pitches must be multiples of 8 elements");
+  // (ci itself may be ragged, e.g. 257 latent + context channels: its last 8-channel chunk is read up to the pitch and only the real
+  // channels are added to gw)
+  JEN1_CHECK(co % 8 == 0 && ci >= 1 && ld_dy >= co && ld_x >= ((ci + 7) / 8) * 8 && ld_dy % 8 == 0 && ld_x % 8 == 0,
+             "big_gemm_tn_conv: co and the pitches must be multiples of 8 elements, ld_x >= ci rounded up to 8");
   JEN1_CHECK(taps <= 16, "big_gemm_tn_conv: at most 16 taps (a column tile holds an 8-channel chunk of every tap)");
-  JEN1_CHECK((co % 128 == 0 || ld_dy >= ((co + 127) / 128) * 128) && (ci % 128 == 0 || ld_x >= ((ci + 127) / 128) * 128),
+  JEN1_CHECK((co % 128 == 0 || ld_dy >= ((co + 127) / 128) * 128) && (taps > 1 || ci % 128 == 0 || ld_x >= ((ci + 127) / 128) * 128),
              "big_gemm_tn_conv: a partial last column tile must still lie inside the row pitch");
   const int64_t M = (int64_t)B * T_out, Mx = (int64_t)B * T_in;
   JEN1_CHECK(M < ((int64_t)1 << 22) && M * ld_dy * 2 < ((int64_t)1 << 31) && Mx * ld_x * 2 < 0x7ffffff0ll, "big_gemm_tn_conv: operand too large");
@@ -843,7 +846,7 @@ extern "C" int jen1_big_gemm_tn_conv(const void* dy, const void* x, float* gw, f
   g.inv_T_out = 1.0f / (float)T_out; g.bias_grad = gb; g.shift_b = shift_b;
   g.tiles_n = (co + 127) / 128;
   g.cpt = taps > 1 ? 16 / taps : 16;
-  g.tiles_k = taps > 1 ? (ci / 8 + g.cpt - 1) / g.cpt : (ci + 127) / 128;
+  g.tiles_k = taps > 1 ? ((ci + 7) / 8 + g.cpt - 1) / g.cpt : (ci + 127) / 128;
   const int tiles = g.tiles_n * g.tiles_k, MT = (int)((M + 63) / 64);
   int splits = tn_splits(tiles, MT);
   g.mt_per_split = (MT + splits - 1) / splits;

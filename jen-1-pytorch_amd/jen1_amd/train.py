@@ -585,8 +585,8 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
         b = _operand(x.data_ptr(), 1, ldx, m=g.fwd_map(2))
         M, N = g.co, g.ci
     if (rt.big_wgrads and not defer and g.kind in ("conv", "linear") and dt == L.BF16 and K >= rt.big_wgrad_rows
-            and not g.reflect and x.is_contiguous() and dy.is_contiguous() and g.co % 8 == 0 and g.ci % 8 == 0 and K % g.L_out == 0
-            and (g.ci % 128 == 0 if k > 1 else ldx >= -(-g.ci // 128) * 128) and (g.co % 128 == 0 or ldy >= -(-g.co // 128) * 128)
+            and not g.reflect and x.is_contiguous() and dy.is_contiguous() and g.co % 8 == 0 and K % g.L_out == 0
+            and (k > 1 or ldx >= -(-g.ci // 128) * 128) and (g.co % 128 == 0 or ldy >= -(-g.co // 128) * 128)
             and (x.numel() // ldx) * g.L_out == K * g.L_in and gw.is_contiguous()):
         # many reduction rows against a small output (the long levels): the transposing matrix-core kernel with the tap shift in its
         # row map and the bias gradient as one more MFMA (switch: TrainRuntime.big_wgrads, off by default)
@@ -598,6 +598,15 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
             e = rt.stats.setdefault("big_gemm", [0, 0.0, 0.0])
             e[0] += 1; e[1] += 2.0 * K * g.co * g.ci * k; e[2] += 2.0 * K * (g.co + g.ci) + 8.0 * g.co * g.ci * k
         return gb is not None
+    if (rt.big_wgrads and not defer and g.kind == "convT" and dt == L.BF16 and K >= rt.big_wgrad_rows // 4 and x.is_contiguous() and dy.is_contiguous()
+            and g.co % 8 == 0 and g.ci % 8 == 0 and k <= 16 and K % g.L_in == 0 and rows_dy * g.L_in == K * g.L_out and gw.is_contiguous()
+            and (g.ci % 128 == 0 or ldx >= -(-g.ci // 128) * 128)):
+        # ConvTranspose1d W[ci][co][k]: dW[ci][co][tap] = sum x[b, t][ci] dy[b, t stride + tap - padding][co]: the same kernel with the input
+        # as its row operand and dY as the shifted one (82 us on train_gemm's weight-gradient form at 6 000 x 128 x (8 x 128))
+        L.check(rt.lib.jen1_big_gemm_tn_conv(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), None, K // g.L_in, g.L_in, g.L_out, g.ci, g.co, k, g.stride,
+                                             g.pad, ldx, ldy, 1.0, None, rt.stream()), "jen1_big_gemm_tn_conv")
+        rt.count("big_gemm", 2.0 * K * g.co * g.ci * k, 2.0 * (K * g.ci + rows_dy * g.co) + 8.0 * g.co * g.ci * k)
+        return (False, None) if defer else False
     sk = rt.pick_splitk(M, N, (K + 31) // 32, z=k)
     fused_bias = gb is not None and g.kind != "convT"
     # one K slice: every (tap, tile) of the gradient belongs to exactly one workgroup of this launch and launches are

@@ -261,3 +261,49 @@ def test_conv_form_with_padding_per_batch_element():
     assert rel_err(y.float().cpu().numpy(), torch.cat(ys).cpu().numpy()) < 6e-3
     assert rel_err(dx.float().cpu().numpy(), torch.cat(dxs).cpu().numpy()) < 6e-3
     assert rel_err(gw.cpu().numpy(), wf.grad.cpu().numpy()) < 2e-5
+
+
+def test_conv_transpose_weight_gradient_tn_matches_torch():
+    """nn.ConvTranspose1d (Upsample1d, blocks.py:80-88) W[ci][co][k]: its weight gradient on jen1_big_gemm_tn_conv with the layer's
+    input as the row operand and dY as the shifted, strided one"""
+    import torch.nn.functional as F
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    B, L_in, ci, co, k, stride, padding, opad = 3, 97, 128, 64, 8, 4, 2, 0
+    L_out = (L_in - 1) * stride - 2 * padding + k + opad
+    x = (torch.randn((B, L_in, ci), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    dy = torch.zeros((B, L_out, 128), device="cuda", dtype=torch.bfloat16)
+    dy[..., :co] = (torch.randn((B, L_out, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    gw0 = torch.randn((ci, co, k), device="cuda", generator=gen)
+    gw = gw0.clone()
+    L.check(lib.jen1_big_gemm_tn_conv(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), None, B, L_in, L_out, ci, co, k, stride, padding, ci, 128, 1.0, None,
+                                      torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn_conv")
+    torch.cuda.synchronize()
+    w = torch.zeros((ci, co, k), device="cuda", requires_grad=True)
+    y = F.conv_transpose1d(x.float().permute(0, 2, 1), w, None, stride=stride, padding=padding, output_padding=opad)
+    assert y.shape[-1] == L_out
+    y.backward(dy[..., :co].float().permute(0, 2, 1))
+    assert rel_err((gw - gw0).cpu().numpy(), w.grad.cpu().numpy()) < 2e-5
+
+
+def test_conv_weight_gradient_tn_ragged_input_channels():
+    """257 input channels in a pitch of 264 (the latent + context channels of `to_in`, model.py:240): the last 8-channel chunk is read up to
+    the pitch and only the real channels reach gw"""
+    import torch.nn.functional as F
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    B, T, ci, co, k, ldx = 4, 700, 257, 128, 3, 264
+    x = torch.full((B, T, ldx), 3.0, device="cuda", dtype=torch.bfloat16)
+    x[..., :ci] = (torch.randn((B, T, ci), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    dy = (torch.randn((B, T, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    gw = torch.zeros((co, ci, k), device="cuda")
+    gb = torch.zeros((co,), device="cuda")
+    L.check(lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, T, T, co, ci, k, 1, 1, co, ldx, 1.0, None,
+                                      torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn_conv")
+    torch.cuda.synchronize()
+    w = torch.zeros((co, ci, k), device="cuda", requires_grad=True)
+    bias = torch.zeros((co,), device="cuda", requires_grad=True)
+    y = F.conv1d(F.pad(x[..., :ci].float().permute(0, 2, 1), (1, 1)), w, bias)
+    y.backward(dy.float().permute(0, 2, 1))
+    assert rel_err(gw.cpu().numpy(), w.grad.cpu().numpy()) < 2e-5
+    assert rel_err(gb.cpu().numpy(), bias.grad.cpu().numpy()) < 2e-5
