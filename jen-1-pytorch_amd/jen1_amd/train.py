@@ -422,7 +422,10 @@ class TrainRuntime:
         tiles = ((M + 63) // 64) * ((N + 63) // 64) * z
         if tiles >= self.target_wgs // 2:
             return 1
-        s = min(max(1, self.target_wgs // tiles), max(1, ksteps // self.min_steps))
+        # (a few rows against a very long K -- the data gradient of the stacked FiLM projections, 16 x 512 x 55 296: the output is tiny, the
+        # atomics cost nothing, and 256 workgroups of 54 serial steps took 82 us)
+        wgs = self.target_wgs * (4 if (M <= 64 and ksteps >= 1024) else 1)
+        s = min(max(1, wgs // tiles), max(1, ksteps // self.min_steps))
         return max(1, min(s, 65535 // max(1, z)))
 
 
@@ -586,7 +589,7 @@ def _conv_wgrad(rt: TrainRuntime, x: torch.Tensor, dy: torch.Tensor, gw: torch.T
         M, N = g.co, g.ci
     if (rt.big_wgrads and not defer and g.kind in ("conv", "linear") and dt == L.BF16 and K >= rt.big_wgrad_rows
             and not g.reflect and x.is_contiguous() and dy.is_contiguous() and g.co % 8 == 0 and K % g.L_out == 0
-            and (k > 1 or ldx >= -(-g.ci // 128) * 128) and (g.co % 128 == 0 or ldy >= -(-g.co // 128) * 128)
+            and (g.co % 128 == 0 or ldy >= -(-g.co // 128) * 128)
             and (x.numel() // ldx) * g.L_out == K * g.L_in and gw.is_contiguous()):
         # many reduction rows against a small output (the long levels): the transposing matrix-core kernel with the tap shift in its
         # row map and the bias gradient as one more MFMA (switch: TrainRuntime.big_wgrads, off by default)

@@ -286,24 +286,25 @@ def test_conv_transpose_weight_gradient_tn_matches_torch():
     assert rel_err((gw - gw0).cpu().numpy(), w.grad.cpu().numpy()) < 2e-5
 
 
-def test_conv_weight_gradient_tn_ragged_input_channels():
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_weight_gradient_tn_ragged_input_channels(k):
     """257 input channels in a pitch of 264 (the latent + context channels of `to_in`, model.py:240): the last 8-channel chunk is read up to
     the pitch and only the real channels reach gw"""
     import torch.nn.functional as F
     lib = L.load()
     gen = torch.Generator(device="cuda").manual_seed(11)
-    B, T, ci, co, k, ldx = 4, 700, 257, 128, 3, 264
+    B, T, ci, co, ldx = 4, 700, 257, 128, 264
     x = torch.full((B, T, ldx), 3.0, device="cuda", dtype=torch.bfloat16)
     x[..., :ci] = (torch.randn((B, T, ci), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
     dy = (torch.randn((B, T, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
     gw = torch.zeros((co, ci, k), device="cuda")
     gb = torch.zeros((co,), device="cuda")
-    L.check(lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, T, T, co, ci, k, 1, 1, co, ldx, 1.0, None,
+    L.check(lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, T, T, co, ci, k, 1, k // 2, co, ldx, 1.0, None,
                                       torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn_conv")
     torch.cuda.synchronize()
     w = torch.zeros((co, ci, k), device="cuda", requires_grad=True)
     bias = torch.zeros((co,), device="cuda", requires_grad=True)
-    y = F.conv1d(F.pad(x[..., :ci].float().permute(0, 2, 1), (1, 1)), w, bias)
+    y = F.conv1d(F.pad(x[..., :ci].float().permute(0, 2, 1), (k // 2, k // 2)), w, bias)
     y.backward(dy.float().permute(0, 2, 1))
     assert rel_err(gw.cpu().numpy(), w.grad.cpu().numpy()) < 2e-5
     assert rel_err(gb.cpu().numpy(), bias.grad.cpu().numpy()) < 2e-5
