@@ -547,6 +547,15 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
                                           None if g.pad_b is None else g.bwd_shift_b.data_ptr(), rt.stream()), "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * cip_n * ldy * k, 2.0 * (B * g.L_out * ldy + k * cip_n * ldy + M * cip))
         return dx
+    if (rt.big_convs and wd is not None and pair_with is None and dt == L.BF16 and M >= rt.big_conv_rows // 4 and g.kind == "convT" and ldy % 64 == 0
+            and cip_n % 4 == 0):
+        # ConvTranspose1d's data gradient IS a strided convolution of dY (row t_in stride + tap - padding) with the [k][Ci][Co] copy
+        dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
+        L.check(rt.lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None if residual is None else residual.data_ptr(), dx.data_ptr(),
+                                          B, g.L_out, g.L_in, ldy, cip_n, k, g.stride, g.pad, 0, ldy, ldy, cip_n * ldy, cip, None, rt.stream()),
+                "jen1_big_gemm_conv")
+        rt.count("big_gemm", 2.0 * M * cip_n * ldy * k, 2.0 * (B * g.L_out * ldy + k * cip_n * ldy + M * cip))
+        return dx
     ksteps = k * ((co + 31) // 32)
     skinny = wd is not None and rt.want_skinny(M, cip_n, ksteps)
     sk = 1 if skinny else rt.pick_splitk(M, cip, ksteps)

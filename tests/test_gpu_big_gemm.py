@@ -308,3 +308,25 @@ def test_conv_weight_gradient_tn_ragged_input_channels(k):
     y.backward(dy.float().permute(0, 2, 1))
     assert rel_err(gw.cpu().numpy(), w.grad.cpu().numpy()) < 2e-5
     assert rel_err(gb.cpu().numpy(), bias.grad.cpu().numpy()) < 2e-5
+
+
+def test_conv_transpose_data_gradient_is_a_strided_conv_form():
+    """nn.ConvTranspose1d (Upsample1d, blocks.py:80-88): dx[b, t][ci] = sum_tap dy[b, t stride + tap - padding][co] W[ci][co][tap] on
+    jen1_big_gemm_conv (stride in the row map, the [k][Ci][Co] copy as the weight), against torch autograd"""
+    import torch.nn.functional as F
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    B, L_in, ci, co, k, stride, padding = 3, 211, 128, 128, 8, 4, 2
+    L_out = (L_in - 1) * stride - 2 * padding + k
+    w = (torch.randn((ci, co, k), device="cuda", generator=gen) * 0.1).to(torch.bfloat16)
+    dy = (torch.randn((B, L_out, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    wd = w.permute(2, 0, 1).contiguous()                            # [k][ci][co]
+    dx = torch.zeros((B, L_in, ci), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, L_out, L_in, co, ci, k, stride, padding, 0, co, co,
+                                   ci * co, ci, None, torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_conv")
+    torch.cuda.synchronize()
+    x = torch.zeros((B, ci, L_in), device="cuda", requires_grad=True)
+    y = F.conv_transpose1d(x, w.float(), None, stride=stride, padding=padding)
+    assert y.shape[-1] == L_out
+    y.backward(dy.float().permute(0, 2, 1))
+    assert rel_err(dx.float().cpu().numpy(), x.grad.permute(0, 2, 1).cpu().numpy()) < 6e-3
