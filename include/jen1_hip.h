@@ -368,7 +368,10 @@ int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K
  * (blocks.py:34-53) over many rows: the long levels of the training pass.  ci must be a multiple of 64. */
 int jen1_big_gemm_conv(const void* x, const void* w, const float* bias, const void* residual, void* y, int B, int T_in, int T_out, int ci, int co,
                        int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y, const int32_t* shift_b /* [B] added to
-                       the row shift tap - pad per batch element (causal and centred clips in one pass, blocks.py:45-50), or NULL */, void* stream);
+                       the row shift tap - pad per batch element (causal and centred clips in one pass, blocks.py:45-50), or NULL */,
+                       int div /* > 1: the mapped position t * stride + tap - pad must be a multiple of div and is divided by it, other taps read
+                       zeros: the forward pass of nn.ConvTranspose1d (blocks.py:80-88) with stride = 1, tap_rev, pad' = taps - 1 - padding */,
+                       void* stream);
 /* the weight (and bias) gradient of a Conv1d / Linear over many rows (autograd of blocks.py:34-53 `_Conv1d`, the long levels of the
  * pass: B * T_out = 6 000 .. 24 000 reduction rows against 128 .. 512 channels): gw[co][ci][tap] += alpha * sum_{b,t} dy[b T_out + t][co] *
  * x[b T_in + t * stride + tap - pad][ci] (rows outside [0, T_in) count as zeros), gb[co] += alpha * sum_{b,t} dy[..][co] when gb is not

@@ -280,6 +280,8 @@ struct CArgs {
   int32_t taps, ci, T_out, T_in, stride, pad, rows_x, tap_rev, w_tap_stride;
   float inv_T_out;
   const int32_t* shift_b;       // per batch element, added to the row shift tap - pad (a pass that mixes causal and centred padding), or null
+  int32_t div;                  // > 1: the mapped position must be a multiple of div and is divided by it (ConvTranspose1d forward: the
+  float inv_div;                //      taps that do not meet an input sample read zeros)
 };
 
 __global__ __launch_bounds__(256, 2) void big_gemm_conv_kernel(const CArgs g) {
@@ -313,8 +315,14 @@ __global__ __launch_bounds__(256, 2) void big_gemm_conv_kernel(const CArgs g) {
   lds_u8* const lds0 = (lds_u8*)smem;
   const int spt = g.ci / BK;                                              // K steps per tap
   auto a_off = [&](int i, int shift, unsigned cin_b) -> unsigned {
-    const int xp = xt[i] + shift;
-    const bool ok = xp >= 0 && xp < g.T_in && xb[i] >= 0;
+    int xp = xt[i] + shift;
+    bool ok = xp >= 0 && xb[i] >= 0;
+    if (g.div > 1) {
+      const int q = (int)(((float)xp + 0.5f) * g.inv_div);            // xp < 2^22: exact
+      ok = ok && q * g.div == xp;
+      xp = q;
+    }
+    ok = ok && xp < g.T_in;
     return ok ? (unsigned)(xb[i] + xp) * (unsigned)(g.ldx * ES) + xc[i] + cin_b : 0x7ffffff0u;
   };
 #define CG_ISSUE(stage_, kt_)                                                                                                        \
@@ -764,7 +772,7 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
 
 extern "C" int jen1_big_gemm_conv(const void* x, const void* w, const float* bias, const void* residual, void* y, int B, int T_in, int T_out, int ci,
                                   int co, int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y,
-                                  const int32_t* shift_b, void* stream) {
+                                  const int32_t* shift_b, int div, void* stream) {
   JEN1_CHECK(x && w && y && B >= 1 && T_in >= 1 && T_out >= 1 && taps >= 1 && stride >= 1, "big_gemm_conv: bad arguments");
   JEN1_CHECK(ci >= 64 && ci % 64 == 0, "big_gemm_conv: the input channels (%d) must be a multiple of 64 (a K step lies inside one tap)", ci);
   JEN1_CHECK(co >= 4 && co % 4 == 0 && ld_x >= ci && ld_w >= ci && ld_y >= co && ld_x % 8 == 0 && ld_w % 8 == 0 && ld_y % 4 == 0,
@@ -780,6 +788,7 @@ extern "C" int jen1_big_gemm_conv(const void* x, const void* w, const float* bia
   g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (co + BN - 1) / BN;
   g.taps = taps; g.ci = ci; g.T_out = T_out; g.T_in = T_in; g.stride = stride; g.pad = pad; g.rows_x = (int)Mx; g.tap_rev = tap_rev ? 1 : 0;
   g.w_tap_stride = w_tap_stride; g.inv_T_out = 1.0f / (float)T_out; g.shift_b = shift_b;
+  g.div = div > 1 ? div : 1; g.inv_div = 1.0f / (float)g.div;
   hipLaunchKernelGGL(big_gemm_conv_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
   JEN1_HIP(hipGetLastError());
   return 0;

@@ -495,8 +495,17 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
         L.check(rt.lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
                                           None if residual is None else residual.data_ptr(), y.data_ptr(), B if conv else M, g.L_in if conv else 1,
                                           g.L_out if conv else 1, g.ci, co, k, g.stride if conv else 1, (0 if g.pad_b is not None else g.pad) if conv else 0,
-                                          0, ldx, cip, co * cip, ldy, None if g.pad_b is None else g.fwd_shift_b.data_ptr(), rt.stream()), "jen1_big_gemm_conv")
+                                          0, ldx, cip, co * cip, ldy, None if g.pad_b is None else g.fwd_shift_b.data_ptr(), 1, rt.stream()), "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * co * cip * k, 2.0 * (rows_in * ldx + k * co * cip + M * ldy))
+        return y
+    if (rt.big_convs and dt == L.BF16 and g.kind == "convT" and M >= rt.big_conv_rows and g.ci % 64 == 0 and cip == g.ci and co % 4 == 0):
+        # ConvTranspose1d: output position t reads input (t + padding - tap) / stride where that is whole -- the conv form with the taps
+        # reversed and the division in its row map (the other taps' rows arrive as zeros: no traffic, wasted MFMA steps only)
+        y = (torch.zeros if ldy != co else torch.empty)((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
+        L.check(rt.lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
+                                          None if residual is None else residual.data_ptr(), y.data_ptr(), B, g.L_in, g.L_out, g.ci, co, k, 1,
+                                          k - 1 - g.pad, 1, ldx, cip, co * cip, ldy, None, g.stride, rt.stream()), "jen1_big_gemm_conv")
+        rt.count("big_gemm", 2.0 * M * co * cip * k / g.stride, 2.0 * (rows_in * ldx + k * co * cip + M * ldy))
         return y
     skinny = rt.want_skinny(M, co, ksteps)
     sk = 1 if skinny else rt.pick_splitk(M, co, ksteps)
@@ -544,7 +553,7 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
         L.check(rt.lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None if residual is None else residual.data_ptr(), dx.data_ptr(),
                                           B if conv else M, g.L_out if conv else 1, g.L_in if conv else 1, ldy, cip_n, k, 1,
                                           ((k - 1) if g.pad_b is not None else (k - 1 - g.pad)) if conv else 0, 1, ldy, ldy, cip_n * ldy, cip,
-                                          None if g.pad_b is None else g.bwd_shift_b.data_ptr(), rt.stream()), "jen1_big_gemm_conv")
+                                          None if g.pad_b is None else g.bwd_shift_b.data_ptr(), 1, rt.stream()), "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * cip_n * ldy * k, 2.0 * (B * g.L_out * ldy + k * cip_n * ldy + M * cip))
         return dx
     if (rt.big_convs and wd is not None and pair_with is None and dt == L.BF16 and M >= rt.big_conv_rows // 4 and g.kind == "convT" and ldy % 64 == 0
@@ -552,7 +561,7 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
         # ConvTranspose1d's data gradient IS a strided convolution of dY (row t_in stride + tap - padding) with the [k][Ci][Co] copy
         dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
         L.check(rt.lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None if residual is None else residual.data_ptr(), dx.data_ptr(),
-                                          B, g.L_out, g.L_in, ldy, cip_n, k, g.stride, g.pad, 0, ldy, ldy, cip_n * ldy, cip, None, rt.stream()),
+                                          B, g.L_out, g.L_in, ldy, cip_n, k, g.stride, g.pad, 0, ldy, ldy, cip_n * ldy, cip, None, 1, rt.stream()),
                 "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * cip_n * ldy * k, 2.0 * (B * g.L_out * ldy + k * cip_n * ldy + M * cip))
         return dx

@@ -204,7 +204,7 @@ def test_conv_form_forward_and_data_gradient_match_torch(B, T_in, ci, co, taps, 
     y = torch.full((B, T_out, ldy), 3.0, device="cuda", dtype=torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
     L.check(lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(), None if res is None else res.data_ptr(),
-                                   y.data_ptr(), B, T_in, T_out, ci, co, taps, stride, pad, 0, ci, ci, co * ci, ldy, None, s), "jen1_big_gemm_conv")
+                                   y.data_ptr(), B, T_in, T_out, ci, co, taps, stride, pad, 0, ci, ci, co * ci, ldy, None, 1, s), "jen1_big_gemm_conv")
     torch.cuda.synchronize()
     xin = x.float().permute(0, 2, 1).requires_grad_(True)
     xp = F.pad(xin, (pad, taps - 1 - pad)) if taps > 1 else xin
@@ -220,7 +220,7 @@ def test_conv_form_forward_and_data_gradient_match_torch(B, T_in, ci, co, taps, 
     wd = w.permute(2, 1, 0).contiguous()                            # [taps][ci][co]: the data-gradient twin
     dx = torch.zeros((B, T_in, ci), device="cuda", dtype=torch.bfloat16)
     L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T_out, T_in, co, ci, taps, 1, taps - 1 - pad, 1, co, co,
-                                   ci * co, ci, None, s), "jen1_big_gemm_conv")
+                                   ci * co, ci, None, 1, s), "jen1_big_gemm_conv")
     torch.cuda.synchronize()
     ref.backward(dy.float().permute(0, 2, 1))
     assert rel_err(dx.float().cpu().numpy(), xin.grad.permute(0, 2, 1).cpu().numpy()) < 6e-3
@@ -245,9 +245,9 @@ def test_conv_form_with_padding_per_batch_element():
     gw = torch.zeros((co, ci, k), device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     L.check(lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), B, T, T, ci, co, k, 1, 0, 0, ci, ci, co * ci, co,
-                                   fwd_shift.data_ptr(), s), "fwd")
+                                   fwd_shift.data_ptr(), 1, s), "fwd")
     L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T, T, co, ci, k, 1, k - 1, 1, co, co, ci * co, ci,
-                                   bwd_shift.data_ptr(), s), "dgrad")
+                                   bwd_shift.data_ptr(), 1, s), "dgrad")
     L.check(lib.jen1_big_gemm_tn_conv(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), None, B, T, T, co, ci, k, 1, 0, co, ci, 1.0, fwd_shift.data_ptr(), s), "wgrad")
     torch.cuda.synchronize()
     wf = w.float().requires_grad_(True)
@@ -323,10 +323,32 @@ def test_conv_transpose_data_gradient_is_a_strided_conv_form():
     wd = w.permute(2, 0, 1).contiguous()                            # [k][ci][co]
     dx = torch.zeros((B, L_in, ci), device="cuda", dtype=torch.bfloat16)
     L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, L_out, L_in, co, ci, k, stride, padding, 0, co, co,
-                                   ci * co, ci, None, torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_conv")
+                                   ci * co, ci, None, 1, torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_conv")
     torch.cuda.synchronize()
     x = torch.zeros((B, ci, L_in), device="cuda", requires_grad=True)
     y = F.conv_transpose1d(x, w.float(), None, stride=stride, padding=padding)
     assert y.shape[-1] == L_out
     y.backward(dy.float().permute(0, 2, 1))
     assert rel_err(dx.float().cpu().numpy(), x.grad.permute(0, 2, 1).cpu().numpy()) < 6e-3
+
+
+@pytest.mark.parametrize("stride,k,padding,opad", [(4, 8, 2, 0), (2, 4, 1, 0), (2, 5, 2, 1)])
+def test_conv_transpose_forward_on_the_conv_form(stride, k, padding, opad):
+    """nn.ConvTranspose1d forward (Upsample1d, blocks.py:80-88) as jen1_big_gemm_conv with the taps reversed and the stride as the
+    divisor of its row map, against torch"""
+    import torch.nn.functional as F
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(31 + stride + k)
+    B, L_in, ci, co = 3, 157, 128, 64
+    L_out = (L_in - 1) * stride - 2 * padding + k + opad
+    x = (torch.randn((B, L_in, ci), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((ci, co, k), device="cuda", generator=gen) * 0.1).to(torch.bfloat16)
+    bias = torch.randn((co,), device="cuda", generator=gen)
+    wp = w.permute(2, 1, 0).contiguous()                            # [k][co][ci]
+    y = torch.zeros((B, L_out, co), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, L_in, L_out, ci, co, k, 1, k - 1 - padding, 1,
+                                   ci, ci, co * ci, co, None, stride, torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_conv")
+    torch.cuda.synchronize()
+    ref = F.conv_transpose1d(x.float().permute(0, 2, 1), w.float(), bias, stride=stride, padding=padding, output_padding=opad)
+    assert ref.shape[-1] == L_out
+    assert rel_err(y.float().cpu().numpy(), ref.permute(0, 2, 1).cpu().numpy()) < 6e-3
