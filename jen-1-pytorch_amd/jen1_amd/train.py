@@ -546,14 +546,15 @@ def _conv_dgrad(rt: TrainRuntime, dy: torch.Tensor, wp: torch.Tensor, g: ConvGeo
         b = _operand(wp.data_ptr(), 1, cip, tap_stride=co * cip)
         cip_n = cip
     if (rt.big_convs and wd is not None and pair_with is None and dt == L.BF16 and M >= rt.big_conv_rows and ldy % 64 == 0
-            and (g.kind == "linear" or (g.kind == "conv" and g.stride == 1)) and cip_n % 4 == 0):
-        # the data gradient over many rows: the same kernel on dy, taps reversed, pad' = taps - 1 - pad
+            and g.kind in ("linear", "conv") and cip_n % 4 == 0):
+        # the data gradient over many rows: the same kernel on dy, taps reversed, pad' = taps - 1 - pad (a strided convolution: the
+        # stride as the divisor of the row map)
         dx = (torch.zeros if cip_n != cip else torch.empty)((B, g.L_in, cip), dtype=dy.dtype, device=dy.device)
         conv = g.kind == "conv"
         L.check(rt.lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None if residual is None else residual.data_ptr(), dx.data_ptr(),
                                           B if conv else M, g.L_out if conv else 1, g.L_in if conv else 1, ldy, cip_n, k, 1,
                                           ((k - 1) if g.pad_b is not None else (k - 1 - g.pad)) if conv else 0, 1, ldy, ldy, cip_n * ldy, cip,
-                                          None if g.pad_b is None else g.bwd_shift_b.data_ptr(), 1, rt.stream()), "jen1_big_gemm_conv")
+                                          None if g.pad_b is None else g.bwd_shift_b.data_ptr(), g.stride if conv else 1, rt.stream()), "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * cip_n * ldy * k, 2.0 * (B * g.L_out * ldy + k * cip_n * ldy + M * cip))
         return dx
     if (rt.big_convs and wd is not None and pair_with is None and dt == L.BF16 and M >= rt.big_conv_rows // 4 and g.kind == "convT" and ldy % 64 == 0

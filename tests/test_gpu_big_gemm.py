@@ -187,6 +187,8 @@ def test_conv_weight_gradient_tn_matches_torch(B, T_in, ci, co, taps, stride, pa
     (2, 257, 256, 96, 5, 2, 2, True, False),      # strided k = 5, ragged rows, 96 output channels inside a 128-column tile
     (16, 1500, 128, 128, 3, 1, 1, True, True),    # the level-0 shape of the training pass
     (4, 129, 192, 72, 1, 1, 0, True, False),      # 1 x 1
+    (2, 257, 128, 128, 5, 2, 2, False, False),    # strided: the data gradient divides in its row map
+    (2, 300, 128, 128, 9, 4, 4, True, False),     # Downsample1d factor 4 (k = 2 f + 1)
 ])
 def test_conv_form_forward_and_data_gradient_match_torch(B, T_in, ci, co, taps, stride, pad, with_bias, with_res):
     """jen1_big_gemm_conv: y = conv1d(x, W) (+ bias) (+ residual) through the row map of the matrix-core GEMM, and -- for stride 1 -- the
@@ -212,15 +214,13 @@ def test_conv_form_forward_and_data_gradient_match_torch(B, T_in, ci, co, taps, 
     assert ref.shape[-1] == T_out
     want = ref.permute(0, 2, 1) + (res[..., :co].float() if with_res else 0.0)
     assert rel_err(y[..., :co].float().cpu().numpy(), want.detach().cpu().numpy()) < 6e-3          # (bf16 output rounding)
-    if stride != 1:
-        return
     dy = (torch.randn((B, T_out, co), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
     if co % 64:
         return                                                     # (the data gradient reduces over co: multiples of 64 only)
     wd = w.permute(2, 1, 0).contiguous()                            # [taps][ci][co]: the data-gradient twin
     dx = torch.zeros((B, T_in, ci), device="cuda", dtype=torch.bfloat16)
     L.check(lib.jen1_big_gemm_conv(dy.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T_out, T_in, co, ci, taps, 1, taps - 1 - pad, 1, co, co,
-                                   ci * co, ci, None, 1, s), "jen1_big_gemm_conv")
+                                   ci * co, ci, None, stride, s), "jen1_big_gemm_conv")
     torch.cuda.synchronize()
     ref.backward(dy.float().permute(0, 2, 1))
     assert rel_err(dx.float().cpu().numpy(), xin.grad.permute(0, 2, 1).cpu().numpy()) < 6e-3
