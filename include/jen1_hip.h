@@ -365,7 +365,8 @@ int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K
 /* the convolution form of jen1_big_gemm (bf16): y[b T_out + t][n] = sum_tap sum_c x[b T_in + t * stride + tap - pad][c] * W_tap[n][c] (+ bias[n])
  * (+ residual[row][n]); rows outside [0, T_in) count as zeros.  W_tap = w + tap * w_tap_stride (tap_rev: taps - 1 - tap), [co][ld_w] with the
  * ci input channels contiguous.  The forward and (stride 1, pad' = taps - 1 - pad, tap_rev) data-gradient passes of `_Conv1d`
- * (blocks.py:34-53) over many rows: the long levels of the training pass.  ci must be a multiple of 64. */
+ * (blocks.py:34-53) over many rows: the long levels of the training pass.  ci must be a multiple of 8 (the last 64-channel K step of a tap
+ * may be ragged: its missing chunks are not read). */
 int jen1_big_gemm_conv(const void* x, const void* w, const float* bias, const void* residual, void* y, int B, int T_in, int T_out, int ci, int co,
                        int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y, const int32_t* shift_b /* [B] added to
                        the row shift tap - pad per batch element (causal and centred clips in one pass, blocks.py:45-50), or NULL */,

@@ -313,10 +313,11 @@ __global__ __launch_bounds__(256, 2) void big_gemm_conv_kernel(const CArgs g) {
   }
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   lds_u8* const lds0 = (lds_u8*)smem;
-  const int spt = g.ci / BK;                                              // K steps per tap
+  const int spt = (g.ci + BK - 1) / BK;                                   // K steps per tap (the last one may be ragged: ci % 8 == 0)
+  const unsigned ci_b = (unsigned)(g.ci * ES);
   auto a_off = [&](int i, int shift, unsigned cin_b) -> unsigned {
     int xp = xt[i] + shift;
-    bool ok = xp >= 0 && xb[i] >= 0;
+    bool ok = xp >= 0 && xb[i] >= 0 && cin_b + xc[i] < ci_b;
     if (g.div > 1) {
       const int q = (int)(((float)xp + 0.5f) * g.inv_div);            // xp < 2^22: exact
       ok = ok && q * g.div == xp;
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(256, 2) void big_gemm_conv_kernel(const CArgs g) {
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                                 \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_ + i_ * NWV * 1024), 16, a_off(i_, tap_ - g.pad, cin_b_), 0u, 0, 0); \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                                 \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B + i_ * NWV * 1024), 16, vob[i_], sob_, 0, 0);             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B + i_ * NWV * 1024), 16,                                   \
+                                                 cin_b_ + xc[i_] < ci_b ? vob[i_] : 0x7ffffff0u, sob_, 0, 0);                        \
   } while (0)
 
   // fragments: the weight tile is the MFMA's A operand (rows n), the activation tile its B operand (rows m)
@@ -774,7 +776,7 @@ extern "C" int jen1_big_gemm_conv(const void* x, const void* w, const float* bia
                                   int co, int taps, int stride, int pad, int tap_rev, int ld_x, int ld_w, int w_tap_stride, int ld_y,
                                   const int32_t* shift_b, int div, void* stream) {
   JEN1_CHECK(x && w && y && B >= 1 && T_in >= 1 && T_out >= 1 && taps >= 1 && stride >= 1, "big_gemm_conv: bad arguments");
-  JEN1_CHECK(ci >= 64 && ci % 64 == 0, "big_gemm_conv: the input channels (%d) must be a multiple of 64 (a K step lies inside one tap)", ci);
+  JEN1_CHECK(ci >= 8 && ci % 8 == 0, "big_gemm_conv: the input channels (%d) must be a multiple of 8 (the columns [ci, pitch) are not read)", ci);
   JEN1_CHECK(co >= 4 && co % 4 == 0 && ld_x >= ci && ld_w >= ci && ld_y >= co && ld_x % 8 == 0 && ld_w % 8 == 0 && ld_y % 4 == 0,
              "big_gemm_conv: widths / pitches (ci, ld_x, ld_w multiples of 8 elements; co, ld_y of 4)");
   JEN1_CHECK(w_tap_stride >= co * ld_w || taps == 1, "big_gemm_conv: tap matrices overlap");

@@ -487,14 +487,14 @@ def _conv_forward(rt: TrainRuntime, x: torch.Tensor, wp: torch.Tensor, bias: Opt
     if residual is not None:
         assert residual.is_contiguous() and residual.numel() == B * g.L_out * ldy and residual.dtype == x.dtype, (residual.shape, B, g.L_out, ldy)
     if (rt.big_convs and dt == L.BF16 and g.kind in ("conv", "linear") and M >= rt.big_conv_rows and not g.reflect
-            and g.ci % 64 == 0 and cip == g.ci and co % 4 == 0):
+            and cip % 8 == 0 and co % 4 == 0):
         # many rows (the long levels): the 128 x 128 matrix-core kernel with the taps in its row map (jen1_big_gemm_conv: 10 us at
         # 24 000 x 128 x (3 x 128) against 25 on the register-direct form)
         y = (torch.zeros if ldy != co else torch.empty)((B, g.L_out, ldy), dtype=x.dtype, device=x.device)
         conv = g.kind == "conv"
         L.check(rt.lib.jen1_big_gemm_conv(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
                                           None if residual is None else residual.data_ptr(), y.data_ptr(), B if conv else M, g.L_in if conv else 1,
-                                          g.L_out if conv else 1, g.ci, co, k, g.stride if conv else 1, (0 if g.pad_b is not None else g.pad) if conv else 0,
+                                          g.L_out if conv else 1, cip, co, k, g.stride if conv else 1, (0 if g.pad_b is not None else g.pad) if conv else 0,
                                           0, ldx, cip, co * cip, ldy, None if g.pad_b is None else g.fwd_shift_b.data_ptr(), 1, rt.stream()), "jen1_big_gemm_conv")
         rt.count("big_gemm", 2.0 * M * co * cip * k, 2.0 * (rows_in * ldx + k * co * cip + M * ldy))
         return y

@@ -187,6 +187,7 @@ def test_conv_weight_gradient_tn_matches_torch(B, T_in, ci, co, taps, stride, pa
     (2, 257, 256, 96, 5, 2, 2, True, False),      # strided k = 5, ragged rows, 96 output channels inside a 128-column tile
     (16, 1500, 128, 128, 3, 1, 1, True, True),    # the level-0 shape of the training pass
     (4, 129, 192, 72, 1, 1, 0, True, False),      # 1 x 1
+    (3, 200, 264, 128, 3, 1, 1, True, False),     # 257 channels padded to 264: a ragged last K step per tap
     (2, 257, 128, 128, 5, 2, 2, False, False),    # strided: the data gradient divides in its row map
     (2, 300, 128, 128, 9, 4, 4, True, False),     # Downsample1d factor 4 (k = 2 f + 1)
 ])
