@@ -49,6 +49,8 @@ for p in (ROOT, os.path.join(ROOT, "jen-1-pytorch_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from jen1_amd.graphs import capture as capture_graph  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
@@ -207,7 +209,7 @@ def graph_time_ms(fn, R=20):
     stream.wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with capture_graph(g):
         fn(torch.cuda.current_stream().cuda_stream)
     g.replay()
     torch.cuda.synchronize()
@@ -298,7 +300,7 @@ def conv_roofline(st, reps=3):
     stream.wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with capture_graph(g):
         cs = torch.cuda.current_stream().cuda_stream
         for op in convs:
             op(cs)

@@ -20,7 +20,8 @@ import torch
 import torch.nn.functional as F
 
 from . import lib as L
-from .model import UNetCFG1d
+from .graphs import capture as capture_graph
+from .model import _STEPPER_CACHES, UNetCFG1d
 
 _OBJ = {"noise": 0, "x0": 1, "v": 2}
 
@@ -215,6 +216,10 @@ class GaussianDiffusion(torch.nn.Module):
         rebinds its conditioning (text K/V projection, concat context) and replays the graph captured the first time instead of
         planning and capturing again (the reference rebuilds everything per ``generate`` call, generation.py:36-74: A-20)"""
         cache = self.__dict__.setdefault("_steppers", {})
+        _STEPPER_CACHES.add(self)                  # (an engine invalidation drops this model's steppers: model._drop_steppers_of)
+        eng = model.engine()
+        for k in [k for k, old in cache.items() if old.model is model and old.eng is not eng]:
+            cache.pop(k)                           # built on an engine the model has dropped since (an optimiser step): dead weight
         key = (id(model), id(model.engine()), tuple(shape), bool(causal), bool(use_graph), n_streams, plan_slot, mode,
                float(self.embedding_scale), bool(self.batch_cfg), bool(self.scale_cfg), getattr(self, "sampling_timesteps", None),
                float(getattr(self, "ddim_sampling_eta", 0.0)), bool(model.deterministic), bool(model.engine().use_tile_phases))
@@ -251,6 +256,7 @@ class GaussianDiffusion(torch.nn.Module):
             c = (1 - alpha_next - sigma ** 2).sqrt()
             noise = torch.randn_like(audio) if step_noises is None else step_noises[i].to(self.device, torch.float32)
             audio = x_start * alpha_next.sqrt() + c * pred_noise + sigma * noise
+        _check_model_errors(model)               # the LAST call's persistent launch too (forward checks its predecessor asynchronously)
         return audio if not return_all_timesteps else torch.stack(audios, dim=1)
 
     # ------------------------------------------------------------------ DDPM (gdm.py:144-179)
@@ -283,6 +289,7 @@ class GaussianDiffusion(torch.nn.Module):
         for i, t in enumerate(reversed(range(0, self.num_timesteps))):
             audio, _ = self.p_sample(audio, t, model, conditioning, None if step_noises is None else step_noises[i].to(self.device))
             audios.append(audio)
+        _check_model_errors(model)
         return audio if not return_all_timesteps else torch.stack(audios, dim=1)
 
     @torch.no_grad()
@@ -327,6 +334,14 @@ class GaussianDiffusion(torch.nn.Module):
         loss = self.loss_fn(model_out, target, reduction="none")
         per_sample = loss.reshape(loss.shape[0], -1).mean(dim=1)
         return per_sample if reduction == "none" else per_sample.mean()
+
+
+def _check_model_errors(model) -> None:
+    """end of a literal sampling loop: ``UNetCFG1d.forward`` reports a timed-out persistent launch one call late (model._check_deep), so
+    the loop's last call is checked here, before its result is returned (one host synchronisation per sampling run)"""
+    chk = getattr(model, "check_errors", None)
+    if chk is not None:
+        chk()
 
 
 class DDIMStepper:
@@ -435,12 +450,12 @@ class DDIMStepper:
             self.graphs = []
             for _, _, run, _ in self.parts:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with capture_graph(g):
                     run(torch.cuda.current_stream(dev).cuda_stream)
                 self.graphs.append(g)
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_graph(g):
                 self._run_all()
             self.graph = g
         self._cap_modes = self._modes()

@@ -1415,7 +1415,8 @@ class Plan(OpBuilder):
             f = u.factor
             last = idx == len(spec.ups) - 1
             # length the next consumer needs: the skips of the next level (or T at the top)
-            L_need = skip0.L if last else skips_list[-1][-1].L
+            # (a next level without blocks or transformer has no skip to crop against: its upsample takes the full f * L)
+            L_need = skip0.L if last else (skips_list[-1][-1].L if skips_list[-1] else f * x.L)
             y = self.new_act(Be, L_need, u.c_out, gn=True)
             if f == 1:
                 assert L_need == x.L
@@ -1525,6 +1526,15 @@ class Plan(OpBuilder):
         eng, B = self.eng, self.B
         if not self.kv_ctx:
             return
+        # the standardisation launch reads B * ctx_max_length * features floats through a raw pointer: the shape is checked HERE (a
+        # shorter token axis or another batch would be an out-of-range device read, not an exception).  The plan's K/V cache, masks
+        # and cross-attention units are laid out for exactly ctx_max_length text tokens (+ the time token); the conditioner pads to it
+        # (conditioners.py:84-111: tokenizer max_length = 128)
+        if tuple(embedding.shape) != tuple(self.emb_in.shape):
+            raise ValueError(f"cross-attention embedding of shape {tuple(embedding.shape)}: this plan was built for {tuple(self.emb_in.shape)} "
+                             "(batch, context_embedding_max_length, context_embedding_features); pad the tokens to the maximum length with a False mask")
+        if mask is not None and tuple(mask.shape) != (B, eng.spec.ctx_max_length):
+            raise ValueError(f"embedding_mask of shape {tuple(mask.shape)}: expected {(B, eng.spec.ctx_max_length)}")
         if embedding.dtype == torch.float32 and embedding.is_contiguous() and embedding.device == self.emb_in.device:
             self._ctx_src, self._ctx_keep = embedding.data_ptr(), embedding       # read in place by the standardisation launch
         else:

@@ -63,6 +63,20 @@ def _torch_default_init(key: str, shape, shapes) -> torch.Tensor:
     return torch.randn(shape)
 
 
+_STEPPER_CACHES = weakref.WeakSet()          # the diffusion objects that cache fused steppers (diffusion.GaussianDiffusion.stepper, vdm.VDM)
+
+
+def _drop_steppers_of(model) -> None:
+    """steppers hold the packed weights, plan buffers, a captured graph and the [S][B][C][T] noise table of an engine (~614 MB at
+    B = 8, T = 1500 plus 0.6 GB of weights): when the engine they were built on is dropped they are dead weight, release them now instead
+    of one by one when the cache wraps"""
+    for gd in list(_STEPPER_CACHES):
+        cache = gd.__dict__.get("_steppers")
+        if cache:
+            for k in [k for k, st in cache.items() if st.model is model]:
+                cache.pop(k)
+
+
 class UNetCFG1d(nn.Module):
     """UNet1d with classifier-free guidance on MI355X (reference model.py:268)."""
 
@@ -102,10 +116,16 @@ class UNetCFG1d(nn.Module):
     # ------------------------------------------------------------------ plumbing
     def _invalidate_engine(self):
         """the parameters changed in place (an optimiser step): the inference engine's packed weights, its plans and their
-        captured graphs are stale; the next ``engine()`` call packs again"""
-        self._pending_err = None
-        self._engine = None
-        self._ctx_key = None
+        captured graphs are stale; the next ``engine()`` call packs again.  An error word that is still on its way to the host is
+        looked at first: a timed-out launch is reported (``Jen1HipError``) even when an optimiser step comes between the call and the
+        next one; the engine is dropped either way"""
+        try:
+            self.check_errors()
+        finally:
+            self._pending_err = None
+            self._engine = None
+            self._ctx_key = None
+            _drop_steppers_of(self)
 
     def _invalidate(self):
         self._invalidate_engine()

@@ -29,6 +29,7 @@ import torch
 from torch.autograd import Function, Variable
 
 from . import lib as L
+from .graphs import capture as capture_graph
 from .config import ResSpec, TransformerSpec, UNetSpec
 
 
@@ -1535,7 +1536,11 @@ class TrainGraph:
         slot = (skips_list[0], 0)                                       # where the alias of the current ``h`` belongs
 
         def put(alias):
-            slot[0][slot[1]] = alias
+            # fill once: the slot belongs to the ``h`` that was current when it was opened, and only that tensor's FIRST consumer hands
+            # back its alias.  (A down level with neither blocks nor a transformer opens no slot: the next level's down conv must not
+            # overwrite the previous level's skip with an alias of another tensor.)
+            if slot[0][slot[1]] is None:
+                slot[0][slot[1]] = alias
         for d in sp.downs:
             h = self._mark(h, d.name)
             h, al = conv1d_same(rt, h, p[f"{d.name}.downsample.conv.weight"], p[f"{d.name}.downsample.conv.bias"], d.factor, causal,
@@ -1640,6 +1645,12 @@ class TrainGraph:
         return self.unet(x, time, emb.contiguous(), mask, ctx, causal)
 
     def diffusion_loss(self, gd, x_start: torch.Tensor, t: torch.Tensor, conditioning, noise: torch.Tensor, causal, dropout_rows=None):
+        """``_diffusion_loss`` off the legacy default stream (see ``_off_default_stream``): ``training_loosses`` enters here directly, not
+        through ``__call__``, and an eager pass with injected noise or ``use_graph=False`` (trainer.py) must not leave a null-stream
+        backward behind for a later capture of the same parameters to trip over"""
+        return self._off_default_stream(self._diffusion_loss, gd, x_start, t, conditioning, noise, causal, dropout_rows)
+
+    def _diffusion_loss(self, gd, x_start: torch.Tensor, t: torch.Tensor, conditioning, noise: torch.Tensor, causal, dropout_rows=None):
         """``GaussianDiffusion.training_loosses`` (gdm.py:245-272) around this network with both ends fused: q_sample + concat + CFG
         pair + layout change in one launch, the context rows in one, the CFG combine + rescale + loss in one (and one each way
         back) -- per-sample losses [B].  None when the settings need the literal path (an unbatched CFG pair)."""
@@ -1708,22 +1719,28 @@ class TrainGraph:
         return CfgLossFn.apply(out.contiguous(), tgt, rt, B, sp.out_channels, nrep, float(gd.embedding_scale), bool(gd.scale_cfg), 0.7,
                                getattr(gd, "loss_type", "l2") == "l1")
 
-    def __call__(self, *args, **kwargs) -> torch.Tensor:
-        """``forward``; a call from the legacy default stream is moved to a private stream.  A backward pass that ran
-        on the null stream makes a later graph capture of the same parameters crash inside hipStreamEndCapture
-        (ROCm 7.2 / torch 2.10, reproduced in tests/test_gpu_train.py), so the eager path never uses it."""
+    def _off_default_stream(self, fn, *args, **kwargs):
+        """run ``fn`` (launches of a differentiable pass) on a private stream when the caller is on the legacy default stream.  A backward
+        pass that ran on the null stream makes a later graph capture of the same parameters crash inside hipStreamEndCapture (ROCm 7.2 /
+        torch 2.10, reproduced in tests/test_gpu_train.py), so the eager path never uses it; autograd replays each node on the stream
+        its forward ran on, so moving the forward moves the backward."""
         dev = self.rt.device
         cur = torch.cuda.current_stream(dev)
         if torch.cuda.is_current_stream_capturing() or cur != torch.cuda.default_stream(dev):
-            return self.forward(*args, **kwargs)
+            return fn(*args, **kwargs)
         if self._side is None:
             self._side = torch.cuda.Stream(dev)
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
-            out = self.forward(*args, **kwargs)
+            out = fn(*args, **kwargs)
         cur.wait_stream(self._side)
-        out.record_stream(cur)
+        if torch.is_tensor(out):
+            out.record_stream(cur)
         return out
+
+    def __call__(self, *args, **kwargs) -> torch.Tensor:
+        """``forward``, off the legacy default stream (``_off_default_stream``)"""
+        return self._off_default_stream(self.forward, *args, **kwargs)
 
 
 # =====================================================================================================================
@@ -1792,11 +1809,9 @@ class GraphedLossStep:
         try:
             if exchange is not None:
                 exchange.begin()
-            # with a process group alive its watchdog thread queries events while this thread records: only THIS thread's calls may be
-            # checked against the capture ("global" mode makes the watchdog's hipEventQuery fail the whole process)
-            import torch.distributed as dist
-            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
-            with torch.cuda.graph(g, capture_error_mode=mode):
+            # jen1_amd/graphs.py: the collector is kept out of the capture, and only THIS thread's calls are checked against it (with a
+            # process group alive its watchdog thread queries events while this thread records)
+            with capture_graph(g):
                 loss = self._body(static, causal)
                 if exchange is not None:
                     exchange.finish()      # recorded: the leftover regions, the join of the communication stream, the 1 / world scale

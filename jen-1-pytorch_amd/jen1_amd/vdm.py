@@ -33,8 +33,8 @@ from typing import Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F
 
-from .diffusion import DDIMStepper
-from .model import UNetCFG1d
+from .diffusion import DDIMStepper, _check_model_errors
+from .model import _STEPPER_CACHES, UNetCFG1d
 
 
 class VDM(torch.nn.Module):
@@ -96,6 +96,7 @@ class VDM(torch.nn.Module):
             self._steps = step
             # one stepper (plan + schedule tables + captured graph) per (model, shape, causal, steps): later calls rebind the conditioning
             cache = self.__dict__.setdefault("_steppers", {})
+            _STEPPER_CACHES.add(self)            # (an engine invalidation drops this model's steppers: model._drop_steppers_of)
             key = (id(model), id(model.engine()), tuple(shape), bool(causal), bool(use_graph), int(step), float(self.embedding_scale),
                    bool(self.batch_cfg), bool(self.scale_cfg), bool(model.deterministic))
             st = cache.get(key)
@@ -126,6 +127,8 @@ class VDM(torch.nn.Module):
         if fused:
             audio = st.x.clone()
             st.check()
+        else:
+            _check_model_errors(model)           # the literal loop's last call (diffusion._check_model_errors)
         return audio if not return_all_timesteps else torch.stack(audios, dim=1)
 
     @torch.no_grad()

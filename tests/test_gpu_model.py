@@ -545,3 +545,22 @@ def test_independent_batches_in_flight_match_solo_runs(tiny_models):
     for i, st in enumerate(sts):
         assert torch.equal(st.x, want[i]), (i, rel_err(st.x.cpu().numpy(), want[i].cpu().numpy()))
     assert rel_err(want[0].cpu().numpy(), want[1].cpu().numpy()) > 1e-2      # the three really are different trajectories
+
+
+def test_context_of_another_shape_is_refused_not_read_out_of_range(tiny_models):
+    """``Plan.set_context`` hands the caller's embedding pointer to a launch that reads B x max_length x features floats: a shorter token
+    axis, another batch or a mask of another shape must raise (ValueError), as the ``copy_`` of earlier rounds did -- never a silent
+    out-of-range device read.  The conditioner pads to max_length (conditioners.py:84-111), so this is the contract."""
+    m = tiny_models["f32"]
+    x, t, cond = _inputs()
+    good = _fwd(m, x, t, cond)
+    emb, msk = dev(cond["cross_attn_cond"]), dev(cond["cross_attn_masks"])
+    kw = dict(embedding_scale=1.0, channels_list=[dev(cond["input_concat_cond"])], causal=False)
+    with pytest.raises(ValueError, match="context_embedding_max_length"):
+        m(dev(x), dev(t), embedding=emb[:, :64].contiguous(), embedding_mask=msk[:, :64].contiguous(), **kw)
+    with pytest.raises(ValueError):
+        m(dev(x), dev(t), embedding=emb[:1].contiguous(), embedding_mask=msk[:1].contiguous(), **kw)
+    with pytest.raises(ValueError, match="embedding_mask"):
+        m(dev(x), dev(t), embedding=emb, embedding_mask=msk[:, :64].contiguous(), **kw)
+    again = _fwd(m, x, t, cond)
+    assert rel_err(again, good) < 1e-5

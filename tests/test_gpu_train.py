@@ -1225,3 +1225,85 @@ def test_colsum_many_rows_and_few(mode, rows, C, ld):
     torch.cuda.synchronize()
     want = out0.double() + x[:, :C].double().sum(0)
     assert rel_err(out.cpu().numpy(), want.float().cpu().numpy()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the fused ends of a pass (csrc/train_glue.hip: pack_input, ContextRowsFn, CfgLossFn), the shared fixed-context rows and the skip
+# aliases against the LITERAL path (ATen glue, one context copy per row, autograd's own accumulation) -- same loss, same gradients
+# ---------------------------------------------------------------------------------------------------------------------
+def _ab_loss_and_grads(model, fused, *, loss_type, objective, scale_cfg, drop, task="music_inpaint", causal=False):
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.init_fill import fill_uniform
+    B, T = 3, 96
+    betas, _ = get_beta_schedule("linear", 1000)
+    t = torch.tensor([17, 801, 433], dtype=torch.long, device="cuda")
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, task).items()}
+    assert cond["cross_attn_masks"] is not None and not bool(cond["cross_attn_masks"].all())      # a partial text mask
+    noise = dev(fill_uniform("synth.trainnoise.ab", (B, 128, T), 3, 0.0, 1.0))
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective=objective, loss_type=loss_type, device="cuda",
+                           cfg_dropout_proba=0.5 if drop else 0.0, embedding_scale=0.8, batch_cfg=True, scale_cfg=scale_cfg)
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    graph = model.train_graph("f32")
+    rt = graph.rt
+    old = (rt.fused_glue, rt.share_fixed_context, rt.fork_skips)
+    rt.fused_glue = rt.share_fixed_context = rt.fork_skips = bool(fused)
+    try:
+        rows = torch.tensor([False, True, False], device="cuda") if drop else None
+        loss = gd.training_loosses(graph, x0, t, cond, noise=noise, causal=causal, dropout_rows=rows)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        rt.fused_glue, rt.share_fixed_context, rt.fork_skips = old
+    return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("loss_type", ["l1", "l2"])
+@pytest.mark.parametrize("objective,scale_cfg,drop,causal", [("noise", True, False, False), ("x0", False, True, False), ("v", True, True, True)])
+def test_fused_glue_shared_context_and_skip_aliases_equal_the_literal_path(tiny_model, loss_type, objective, scale_cfg, drop, causal):
+    kw = dict(loss_type=loss_type, objective=objective, scale_cfg=scale_cfg, drop=drop, causal=causal,
+              task="music_cont" if causal else "music_inpaint")
+    l0, g0 = _ab_loss_and_grads(tiny_model, False, **kw)
+    l1, g1 = _ab_loss_and_grads(tiny_model, True, **kw)
+    assert abs(l1 - l0) <= 1e-5 * abs(l0), (l0, l1)
+    gmax = max(float(g.norm()) for g in g0.values())
+    for n in g0:
+        d = float((g1[n] - g0[n]).norm())
+        assert d <= 2e-4 * max(float(g0[n].norm()), 1e-3 * gmax), (n, d, float(g0[n].norm()))
+
+
+def test_down_level_without_blocks_keeps_the_previous_skip():
+    """a level with neither ResBlocks nor a transformer opens no skip slot: the next level's forked down conv must not overwrite the slot
+    of the level before (train.TrainGraph.unet_rows, ``put``); skip aliases on == off"""
+    from jen1_amd.model import UNetCFG1d
+    cfg = tiny_model_config()
+    cfg.update(multipliers=[1, 1, 2, 2], factors=[1, 2, 2], num_blocks=[2, 0, 2], attentions=[0, 0, 0, 1])
+    try:
+        model = UNetCFG1d(**cfg, init_seed=1234, compute_dtype="f32", device="cuda")
+    except AssertionError as e:          # (the spec may refuse an empty level: then there is nothing to mis-slot)
+        pytest.skip(f"configuration refused: {e}")
+    kw = dict(loss_type="l2", objective="noise", scale_cfg=True, drop=False)
+    graph = model.train_graph("f32")
+    # the differentiable forward against the sampling engine's forward of the same module (two implementations of model.py:225-265)
+    B, T = 3, 96
+    x, cond = dev(synth.latents(B, T)), {k: dev(v) for k, v in synth.conditioning(B, T, "music_inpaint").items()}
+    t = torch.tensor([17, 801, 433], dtype=torch.long, device="cuda")
+    fkw = dict(embedding=cond["cross_attn_cond"], embedding_mask=cond["cross_attn_masks"], embedding_scale=0.8, batch_cfg=True, scale_cfg=True,
+               channels_list=[cond["input_concat_cond"]], causal=False)
+    model.eval()
+    y_eng = model(x, t, **fkw)
+    with torch.no_grad():
+        y_tr = graph(x, t, **fkw)
+    torch.cuda.synchronize()
+    assert float((y_tr - y_eng).abs().max()) <= 1e-4 * float(y_eng.abs().max())
+    outs = []
+    for on in (False, True):
+        l, g = _ab_loss_and_grads(model, on, **kw)
+        outs.append((l, g))
+    (l0, g0), (l1, g1) = outs
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    gmax = max(float(g.norm()) for g in g0.values())
+    for n in g0:
+        assert float((g1[n] - g0[n]).norm()) <= 2e-4 * max(float(g0[n].norm()), 1e-3 * gmax), n

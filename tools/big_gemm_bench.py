@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "jen-1-pytorch_amd")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
+from jen1_amd.graphs import capture as capture_graph  # noqa: E402
 from jen1_amd import lib as L  # noqa: E402
 
 lib = L.load()
@@ -20,7 +21,7 @@ def graph_us(fn, R=50):
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with capture_graph(g):
             for _ in range(10):
                 fn()
         g.replay()

@@ -9,6 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "jen-1-pytorch_amd"))
 import torch  # noqa: E402
+from jen1_amd.graphs import capture as capture_graph  # noqa: E402
 
 from jen1_amd import train as T  # noqa: E402
 
@@ -21,7 +22,7 @@ def timed(fn):
     with torch.cuda.stream(s):
         fn()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with capture_graph(g):
             for _ in range(N):
                 fn()
         g.replay()
