@@ -498,6 +498,32 @@ def encodec_decode_bench(B, T, dtype, device):
     return out
 
 
+def golden_parity(cfg, device, model_bf16=None):
+    """max-abs / max-ref of ONE forward of the bench workload (B = 8, 128 x 1500, full model) against the reference's own output on the same
+    inputs and weights (tests/golden/full_bench.npz, written by tests/golden/make_golden.py from the unmodified reference; every 16th frame):
+    the float32 mode is the mode of BASELINE's 1e-3 gate, bf16 is the benched dtype.  A fixture is data: nothing under oracle/ runs here."""
+    from jen1_amd import synth
+    from jen1_amd.model import UNetCFG1d
+    path = os.path.join(ROOT, "tests", "golden", "full_bench.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    B, T = 8, 1500
+    x, c = synth.latents(B, T), synth.conditioning(B, T)
+    want = g["B8.y.nocfg"]
+    out = {"what": "UNetCFG1d.forward, B=8, 128x1500, against the reference's output (tests/golden/full_bench.npz); max-abs/max-ref", "tol_f32": 1e-3}
+    for mode in ("f32", "bf16"):
+        m = model_bf16 if (mode == "bf16" and model_bf16 is not None) else UNetCFG1d(**cfg, init_seed=1234, compute_dtype=mode, device=device)
+        y = m(dev(x, device), dev(g["B8.t"], device), embedding=dev(c["cross_attn_cond"], device), embedding_mask=dev(c["cross_attn_masks"], device),
+              embedding_scale=1.0, channels_list=[dev(c["input_concat_cond"], device)], causal=False)
+        torch.cuda.synchronize()
+        m.check_errors()
+        out[mode] = float(f"{float(np.abs(y.cpu().numpy()[:, :, ::16] - want).max() / np.abs(want).max()):.3e}")
+        del m, y
+    out["ok"] = bool(out["f32"] < 1e-3)
+    return out
+
+
 def physical_cores():
     """physical cores this process may run on (SMT siblings counted once): (physical id, core id) pairs of /proc/cpuinfo
     restricted to the affinity mask"""
@@ -756,12 +782,13 @@ def main():
             kvr = kv_gemm_roofline(st)
             if kvr is not None:
                 out["roofline"]["to_kv_gemm"] = kvr
+        extra = None
         if not args.no_extra:
             st2 = build_stepper(model, B, T, device, cfg_pair=True, use_graph=not args.no_graph)
             dt2 = timed_steps(st2, max(10, args.steps // 2), max(3, args.warmup // 2), lambda: None)
             n2 = max(10, args.steps // 2)
             r2 = conv_roofline(st2)
-            out["extra"] = {"configs[2] CFG pair (2B=16) + rescale, steps/s": round(n2 / dt2, 2),
+            extra = {"configs[2] CFG pair (2B=16) + rescale, steps/s": round(n2 / dt2, 2),
                             "ms_per_step": round(dt2 / n2 * 1e3, 4),
                             "roofline_frac": r2["frac"], "alg_bytes_per_step": r2["alg_bytes_per_step"],
                             "conv_ms_per_step": r2["conv_ms_per_step"]}
@@ -770,23 +797,23 @@ def main():
             st_d = build_stepper(model, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
             n_d = max(10, args.steps // 2)
             dt_d = timed_steps(st_d, n_d, max(3, args.warmup // 2), lambda: None)
-            out["extra"]["deterministic statistics mode, steps/s"] = round(n_d / dt_d, 2)
-            out["extra"]["deterministic statistics mode, launches_per_step"] = st_d.plan.n_launch + 1
+            extra["deterministic statistics mode, steps/s"] = round(n_d / dt_d, 2)
+            extra["deterministic statistics mode, launches_per_step"] = st_d.plan.n_launch + 1
             del st_d
             model.deterministic = False
             if not args.tiny and not args.no_graph:
                 # first of the extras: HIP maps streams onto four hardware queues in creation order, and every stepper built below
                 # creates streams -- measured later, two of the four chains can land on one queue (1 409 -> 819 steps/s)
-                out["extra"]["concurrent_batches"] = [concurrent_batches_bench(model, B, T, device, n, max(20, args.steps // 2), 5)
+                extra["concurrent_batches"] = [concurrent_batches_bench(model, B, T, device, n, max(20, args.steps // 2), 5)
                                                       for n in (2, 4)]
-            out["extra"]["end_to_end"] = end_to_end_bench(model, st, B, T, device)
+            extra["end_to_end"] = end_to_end_bench(model, st, B, T, device)
             if args.dtype != "f32":
                 # the parity dtype (tests gate f32 at 1e-3 against the reference) timed on the same workload
                 m32 = UNetCFG1d(**cfg, init_seed=1234, compute_dtype="f32", device=device)
                 st32 = build_stepper(m32, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
                 n32 = max(10, args.steps // 2)
                 dt32 = timed_steps(st32, n32, max(3, args.warmup // 2), lambda: None)
-                out["extra"]["f32 mode (the dtype of the 1e-3 parity gate), steps/s"] = round(n32 / dt32, 2)
+                extra["f32 mode (the dtype of the 1e-3 parity gate), steps/s"] = round(n32 / dt32, 2)
                 del st32, m32
             if not args.tiny and not args.no_graph:
                 # the long levels as tile phases of two more persistent launches (JEN1_TILE_PHASES=1; off by default: DESIGN.md 4b)
@@ -796,26 +823,26 @@ def main():
                 ntl = max(10, args.steps // 2)
                 dtt = timed_steps(stt, ntl, max(3, args.warmup // 2), lambda: None)
                 stt.check()
-                out["extra"]["long levels as tile phases (JEN1_TILE_PHASES=1)"] = {
+                extra["long levels as tile phases (JEN1_TILE_PHASES=1)"] = {
                     "steps_per_s": round(ntl / dtt, 2), "launches_per_step": stt.plan.n_launch + 1,
                     "programs": [{"phases": len(p_), "tile_phases": p_.kinds.count("tile")} for p_ in stt.plan.progs]}
                 del stt, mt
             if not args.tiny:
-                out["extra"]["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
+                extra["optimizer_step"] = optimizer_step_bench(sum(p.numel() for p in model.parameters()), device)
                 fwd_flops = sum(getattr(op, "flops", 0) for op in st.plan.ops)
-                out["extra"]["train_step"] = train_step_bench(cfg, B, T, args.dtype, device, fwd_flops=fwd_flops if args.dtype == "bf16" else None)
-                out["extra"]["encodec_decode"] = encodec_decode_bench(B, T, args.dtype, device)
+                extra["train_step"] = train_step_bench(cfg, B, T, args.dtype, device, fwd_flops=fwd_flops if args.dtype == "bf16" else None)
+                extra["encodec_decode"] = encodec_decode_bench(B, T, args.dtype, device)
                 if not args.no_graph:
                     # BASELINE configs[4] shape (long-form continuation / inpaint, T ~ 9000), bf16, no fp8 path yet
                     st5 = build_stepper(model, 1, 9000, device, cfg_pair=True, use_graph=True)
                     n5 = max(10, args.steps // 5)
                     dt5 = timed_steps(st5, n5, 3, lambda: None)
-                    out["extra"]["configs[4] long-form B=1 T=9000 CFG pair, steps/s"] = round(n5 / dt5, 2)
+                    extra["configs[4] long-form B=1 T=9000 CFG pair, steps/s"] = round(n5 / dt5, 2)
                     # per-kernel figures of that plan: the tiled conv launches of its long levels (T' = 9000 ... 71) and its
                     # persistent launch (levels 5..8)
                     r5 = conv_roofline(st5)
                     d5 = deep_roofline(st5, args.dtype)
-                    out["extra"]["configs[4] kernels"] = {
+                    extra["configs[4] kernels"] = {
                         "launches_per_step": st5.plan.n_launch + 1,
                         "long_levels": {k: r5[k] for k in ("launches_per_step", "avg_launch_us", "conv_ms_per_step", "alg_bytes_per_step", "achieved",
                                                            "frac", "executed_gflop_per_step", "slowest_launches_us")},
@@ -840,10 +867,32 @@ def main():
                         d8 = deep_roofline(st8, "fp8")
                         if d8 is not None:
                             e8["configs[1] shape deep_kernel<fp8>"] = {k: d8[k] for k in ("avg_launch_us", "us_per_phase", "alg_bytes_per_launch", "achieved", "frac")}
-                        out["extra"]["configs[4] fp8"] = e8
+                        extra["configs[4] fp8"] = e8
                         del st8, m8
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.tiny)
+        if extra is not None:
+            # the numbers a reader wants first, as short top-level keys (the full records follow in "extra", LAST in the line: a log tail that
+            # truncates the line loses detail, not these)
+            ts = extra.get("train_step")
+            if ts is not None:
+                rm = ts.get("roofline_mfma") or {}
+                out["train"] = {"what": "configs[3] per-GPU shape, 8 clips, fwd+bwd through the CFG pair, hipGraph replay (1 GPU)", "fwd_bwd_ms": ts["fwd_bwd_ms"],
+                                "clips_per_s": ts["clips_per_s"], "optimizer_ms": ts["optimizer_ms"], "mfma_frac": rm.get("frac"),
+                                "hbm_frac": (rm.get("hbm") or {}).get("frac")}
+            cf = {"configs[2] CFG pair 2B=16, steps/s": extra.get("configs[2] CFG pair (2B=16) + rescale, steps/s"),
+                  "configs[4] B=1 T=9000 CFG pair bf16, steps/s": extra.get("configs[4] long-form B=1 T=9000 CFG pair, steps/s")}
+            f8 = extra.get("configs[4] fp8")
+            if f8 is not None:
+                cf["configs[4] B=1 T=9000 CFG pair JEN1_FP8, steps/s"] = f8["steps_per_s"]
+                cf["fp8 note"] = "latency-bound chain: fp8 halves weight bytes of a launch that sits at ~8 % of the HBM roofline; no gain expected, none measured"
+            e2e = extra.get("end_to_end")
+            if isinstance(e2e, dict):
+                cf["configs[1] end to end through sample() incl. set-up, steps/s"] = e2e.get("steps_per_s_end_to_end")
+            out["configs"] = cf
+            if not args.tiny:
+                out["parity"] = golden_parity(cfg, device, model if args.dtype == "bf16" else None)
+            out["extra"] = extra
         print(json.dumps(out))
     barrier()
     if dist is not None:
