@@ -353,7 +353,9 @@ typedef struct jen1_bgemm_args {
   int32_t M, Ntot, K, lda, ldb, n_groups;
   int32_t rows_in, rows_out;
   int32_t c_f32, accumulate, dtype, ldc;
-  float alpha, reserved_f;
+  float alpha;
+  int32_t group_align;              /* the caller's promise about the group table: every n0 and N is a multiple of it (0 = 128, the minimum);
+                                       256 and up lets large products run on the 256 x 256 tile form */
   void* c;                          /* groups == NULL: ONE group over all Ntot columns, given inline (c, bias, ldc) */
   const float* bias;
 } jen1_bgemm_args;

@@ -51,6 +51,7 @@ struct BArgs {
   int32_t rows_in, rows_out;    // output row of GEMM row m: (m / rows_in) * rows_out + m % rows_in  (rows_in = 0: m itself)
   int32_t c_f32, tiles_m, tiles_n, accumulate;
   float inv_rows_in, alpha;
+  int32_t n_begin, pad0;        // first weight row (output column) of this launch: a product may be split by columns over two launches
   BGroup inl;                   // the one group of a launch whose ``groups`` is null (no device table: capturable without a copy)
 };
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
   const int tn = tile / g.tiles_m, tm = tile - tn * g.tiles_m;         // consecutive ids: same weight tile, next M tile
-  const int m0 = tm * TM, n0 = tn * BN;
+  const int m0 = tm * TM, n0 = g.n_begin + tn * BN;
 
   // ---- LDS-DMA addressing: instruction i of wave w fills rows (i * NWV + w) * 8 .. + 8 of a tile; lane l lands at row + (l >> 3),
   // physical chunk l & 7, and fetches the global chunk (l & 7) ^ ((row >> 1) & 7) of that row --------------------------------
@@ -229,6 +230,194 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
       for (int q4 = 0; q4 < (F32 ? 1 : 4); ++q4) {
         const int nl = F32 ? (wn * 64 + i * 16 + fg * 4) : (wn * 64 + i * 32 + q4 * 8 + fg * 4);
         const int n = n0 + nl - grp.n0;                              // column inside the group
+        if (n >= grp.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q4 * 4 + r] * g.alpha;
+        if (grp.bias) {
+          const float4 bb = *reinterpret_cast<const float4*>(grp.bias + n);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rs;
+        const size_t off = (size_t)orow * (size_t)grp.ldc + (size_t)n;
+        if (g.c_f32) {
+          if (g.accumulate) {
+            float o[4];
+            load4(cF + off, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += o[r];
+          }
+          store_out(cF + off, v);
+        } else {
+          if (g.accumulate) {
+            float o[4];
+            load4(cT + off, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += o[r];
+          }
+          store_out(cT + off, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NT form, 256 x 256 output tile (bf16): 8 waves = 2 along m (128 activation rows each) x 4 along n (64 weight rows each), so a wave
+// owns 2 x 4 MFMA tiles of 32 x 32 (128 accumulator registers) and feeds 8 MFMAs from 6 fragment reads per k block -- the 64 x 64 waves
+// of the kernel above feed 4 from 4, and issue one LDS-DMA piece per 2 MFMAs where this one issues one per 4 (the two ratios
+// DESIGN.md 4c names as what is left to the vendor kernel on big products).  Two LDS stages of 64 KiB (one workgroup, two waves per
+// SIMD), ONE barrier per K step: behind the barrier of step kt every wave has left step kt - 1, so the stage that step read is refilled
+// with tile kt + 1 right there and has the whole step to land.  Same swizzle, same epilogue, same column groups (256-column
+// multiples here) as above.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void big_gemm_nt256_kernel(const BArgs g) {
+  typedef bf16_t T;
+  constexpr int ES = 2, BK = 64, NWV = 8, TM = 256, TN = 256;
+  constexpr int A_B = TM * ROWB, B_B = TN * ROWB, STAGE = A_B + B_B;      // 32 KiB + 32 KiB
+  constexpr int PA = TM / 8 / NWV, PB = TN / 8 / NWV;                     // 4 + 4 LDS-DMA pieces per wave and K step
+  constexpr int NSA = 2, NSB = 4;                                         // MFMA tiles of a wave: weight rows (n) x activation rows (m)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  // Tile order inside an XCD's run of ids.  The 32 CUs of an XCD work on ~32 consecutive ids at a time and share one 4 MiB L2: as a
+  // column of 32 M tiles under one weight tile they pull 32 + 1 operand slices per K step through it, as a bm x bn block (bm * bn = 32)
+  // bm + bn.  Measured without the MFMAs (-DJEN1_BG256_NOMMA) the kernel moved its operands at 7.7 TB/s whatever the tile -- the
+  // traffic behind the L2s is the bound of big products, not the matrix cores.
+  int tn, tm;
+  {
+    const int bm = (g.tiles_m & 7) == 0 ? 8 : ((g.tiles_m & 3) == 0 ? 4 : ((g.tiles_m & 1) == 0 ? 2 : 1));
+    const int bn = 32 / bm;
+    if (g.tiles_n % bn == 0 && bm > 1) {
+      const int grp = tile >> 5, r = tile & 31;
+      const int gpm = g.tiles_m / bm;                   // blocks along m
+      const int gn_ = grp / gpm, gm_ = grp - gn_ * gpm;
+      tm = gm_ * bm + (r % bm);
+      tn = gn_ * bn + (r / bm);
+    } else {
+      tn = tile / g.tiles_m;
+      tm = tile - tn * g.tiles_m;                       // consecutive ids: same weight tile, next M tile
+    }
+  }
+  const int m0 = tm * TM, n0 = g.n_begin + tn * TN;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.a) + (size_t)m0 * (size_t)g.lda * ES), 0,
+      (int)((size_t)((g.M - m0) < TM ? (g.M - m0) : TM) * (size_t)g.lda * ES), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.b) + (size_t)n0 * (size_t)g.ldb * ES), 0,
+      (int)((size_t)((g.Ntot - n0) < TN ? (g.Ntot - n0) : TN) * (size_t)g.ldb * ES), RSRC_FLAGS);
+  unsigned voa[PA], vob[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (i * NWV + w) * 8 + (lane >> 3);
+    voa[i] = (unsigned)row * (unsigned)(g.lda * ES) + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (i * NWV + w) * 8 + (lane >> 3);
+    vob[i] = (unsigned)row * (unsigned)(g.ldb * ES) + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const lds0 = (lds_u8*)smem;
+#define BG_ISSUE(stage_, kt_)                                                                                                        \
+  do {                                                                                                                               \
+    const unsigned so_ = (unsigned)(kt_) * (unsigned)ROWB;                                                                           \
+    lds_u8* const sb_ = lds0 + (stage_) * STAGE + w * 1024;                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < PA; ++i_)                                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_ + i_ * NWV * 1024), 16, voa[i_], so_, 0, 0);                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < PB; ++i_)                                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B + i_ * NWV * 1024), 16, vob[i_], so_, 0, 0);              \
+  } while (0)
+
+  const int wm = w & 1, wn = w >> 1;
+  const int fi = lane & 31, fg = lane >> 5;
+  const int swz = (fi >> 1) & 7;
+  const unsigned fa = (unsigned)(wn * (NSA * 32) + fi) * ROWB + A_B;      // weight tile rows of this lane
+  const unsigned fb = (unsigned)(wm * (NSB * 32) + fi) * ROWB;            // activation tile rows
+  unsigned xo[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) xo[kb] = (unsigned)((kb * 2 + fg) ^ swz) * 16u;
+
+  f32x16 acc[NSA][NSB];
+#pragma unroll
+  for (int i = 0; i < NSA; ++i)
+#pragma unroll
+    for (int j = 0; j < NSB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = g.K / BK;
+  BG_ISSUE(0, 0);
+  int stage = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of tile kt have landed ...
+#ifndef JEN1_BG256_NOBAR
+    __builtin_amdgcn_s_barrier();                                // ... and everybody else's; every wave has left step kt - 1
+#endif
+#ifndef JEN1_BG256_NODMA
+    if (kt + 1 < KT) BG_ISSUE(stage ^ 1, kt + 1);                // refill the stage step kt - 1 read; a whole step to land
+#endif
+    const unsigned char* base = smem + stage * STAGE;
+#ifdef JEN1_BG256_NOMMA
+    if (g.alpha == 1234.5f)
+#endif
+    {
+      // fragments of k block kb + 1 are requested BEFORE the MFMAs of k block kb (two register sets): left to itself the compiler
+      // requests a block's fragments right in front of its MFMAs and the matrix cores idle for every LDS round trip
+      u32x4 wa[2][NSA], xb[2][NSB];
+#pragma unroll
+      for (int s = 0; s < NSA; ++s) wa[0][s] = *reinterpret_cast<const u32x4*>(base + fa + s * 32 * ROWB + xo[0]);
+#pragma unroll
+      for (int s = 0; s < NSB; ++s) xb[0][s] = *reinterpret_cast<const u32x4*>(base + fb + s * 32 * ROWB + xo[0]);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int c = kb & 1, nx = c ^ 1;
+        if (kb + 1 < 4) {
+#pragma unroll
+          for (int s = 0; s < NSA; ++s) wa[nx][s] = *reinterpret_cast<const u32x4*>(base + fa + s * 32 * ROWB + xo[kb + 1]);
+#pragma unroll
+          for (int s = 0; s < NSB; ++s) xb[nx][s] = *reinterpret_cast<const u32x4*>(base + fb + s * 32 * ROWB + xo[kb + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NSB; ++j)
+#pragma unroll
+          for (int i = 0; i < NSA; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[c][i]), __builtin_bit_cast(bf16x8, xb[c][j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    stage ^= 1;
+  }
+#undef BG_ISSUE
+
+  // ---- epilogue (as above; C/D layout 32x32: column (here m) = lane & 31, rows (here n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+  int gi = 0;
+  if (g.groups)
+    for (int k = 1; k < g.n_groups; ++k) gi += (n0 >= g.groups[k].n0) ? 1 : 0;
+  const BGroup grp = g.groups ? g.groups[gi] : g.inl;
+  T* cT = reinterpret_cast<T*>(grp.c);
+  float* cF = reinterpret_cast<float*>(grp.c);
+#pragma unroll
+  for (int j = 0; j < NSB; ++j) {
+    const int m = m0 + wm * (NSB * 32) + j * 32 + fi;
+    if (m >= g.M) continue;
+    int orow = m;
+    if (g.rows_in > 0) {
+      const int q = (int)(((float)m + 0.5f) * g.inv_rows_in);
+      orow = q * g.rows_out + (m - q * g.rows_in);
+    }
+    const float rs = g.row_scale ? g.row_scale[orow] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NSA; ++i) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int nl = wn * (NSA * 32) + i * 32 + q4 * 8 + fg * 4;
+        const int n = n0 + nl - grp.n0;
         if (n >= grp.N) continue;
         float v[4];
 #pragma unroll
@@ -748,16 +937,48 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
   g.rows_in = a->rows_in; g.rows_out = a->rows_out; g.c_f32 = a->c_f32; g.accumulate = a->accumulate;
   g.inv_rows_in = a->rows_in > 0 ? 1.0f / (float)a->rows_in : 0.f;
   g.alpha = a->alpha;
-  // Two forms.  128 x 128 tiles, two LDS stages (64 KiB: two workgroups per CU cover each other's barriers and waits) -- the shapes of
-  // this path (1024 .. 2064 rows): 742 TFLOP/s on the stacked projection of a sampling plan, 590 with the other form.  256 x 128
-  // tiles, 8 waves, three stages (one barrier per K step, two tiles in flight) once there are several rounds of them: 935 against
-  // 760 TFLOP/s at 4096^3.  JEN1_BGEMM_WM = 2 / 4 forces a form (tuning runs).
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // Three forms.  (1) 128 x 128 tiles, two LDS stages (64 KiB: two workgroups per CU cover each other's barriers and waits): products
+  // of a few hundred tiles (the training shapes, 1024 .. 2064 rows against 512 .. 2048 columns).  (2) 256 x 128 tiles, 8 waves, three
+  // stages: float32, and bf16 products whose groups are not 256-column multiples.  (3) 256 x 256 tiles (big_gemm_nt256_kernel), bf16:
+  // products of >= ~200 such tiles.  A launch runs in rounds of one tile per CU, so the columns are cut where the big tiles fill whole
+  // rounds and the rest goes to form (1) in a second launch: the stacked projection of a sampling plan (1024 x 17408: 4 x 68 tiles)
+  // is one full round of 256 big tiles + 64 small ones instead of a second round that 16 of the 256 CUs work on.
+  // JEN1_BGEMM_WM = 2 / 4 forces form (1) / (2), JEN1_BGEMM_T256 = 0 / 1 forbids / forces form (3) (tuning runs).
   static const int force_wm = getenv("JEN1_BGEMM_WM") ? atoi(getenv("JEN1_BGEMM_WM")) : 0;
-  const int t256 = ((a->M + 255) / 256) * ((a->Ntot + BN - 1) / BN);
+  const char* e256 = getenv("JEN1_BGEMM_T256");      // (read per call: the parity tests switch it)
+  const int force_t256 = e256 ? atoi(e256) : -1;
+  static const int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0; return n > 0 ? n : 256; }();
+  const bool ok256 = a->dtype == JEN1_BF16 && !force_wm && force_t256 != 0 && (g.n_groups == 1 || (a->group_align >= 256 && a->group_align % 256 == 0));
+  int n_big = 0;                                        // columns [0, n_big) on the 256 x 256 form
+  if (ok256) {
+    const int tm = (a->M + 255) / 256, tn_all = (a->Ntot + 255) / 256;
+    if (force_t256 == 1) {
+      n_big = a->Ntot;
+    } else if (tm * tn_all >= (n_cu * 3) / 4 && a->K >= 512) {
+      // whole rounds of big tiles; the last round may stay if it is at least 3/4 full, and a remainder narrower than 256 columns rides along
+      const int rounds = (tm * tn_all) / n_cu, tail = tm * tn_all - rounds * n_cu;
+      int tn_big = tn_all;
+      if (tail > 0 && tail * 4 < n_cu * 3 && rounds >= 1) tn_big = (rounds * n_cu) / tm;
+      n_big = tn_big >= tn_all ? a->Ntot : tn_big * 256;
+      if (g.n_groups > 1 && n_big < a->Ntot && n_big % a->group_align != 0) n_big -= n_big % a->group_align;      // (cut on a group boundary multiple)
+    }
+  }
+  if (n_big > 0) {
+    BArgs gb = g;
+    gb.Ntot = n_big;
+    gb.tiles_m = (a->M + 255) / 256;
+    gb.tiles_n = (n_big + 255) / 256;
+    hipLaunchKernelGGL(big_gemm_nt256_kernel, dim3(gb.tiles_m * gb.tiles_n), dim3(512), 0, s, gb);
+    JEN1_HIP(hipGetLastError());
+    if (n_big >= a->Ntot) return 0;
+    g.n_begin = n_big;
+  }
+  const int n_rest = a->Ntot - g.n_begin;
+  const int t256 = ((a->M + 255) / 256) * ((n_rest + BN - 1) / BN);
   const int wm = force_wm ? (force_wm == 5 ? 4 : force_wm) : ((t256 >= 512 && a->K >= 2048) ? 4 : 2);
   g.tiles_m = (a->M + wm * 64 - 1) / (wm * 64);
-  g.tiles_n = (a->Ntot + BN - 1) / BN;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  g.tiles_n = (n_rest + BN - 1) / BN;
   const dim3 grid(g.tiles_m * g.tiles_n);
   if (wm == 4 && force_wm == 5) {                       // (tuning: 256 x 128 tiles on two stages)
     hipLaunchKernelGGL((big_gemm_nt_kernel<bf16_t, 4, 2>), grid, dim3(512), 0, s, g);

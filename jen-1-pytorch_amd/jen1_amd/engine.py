@@ -274,6 +274,13 @@ def _bgemm_parts(groups):
     return [[gr] for gr in groups]
 
 
+def _group_align(part) -> int:
+    """``jen1_bgemm_args.group_align`` of one launch's groups (c, bias, n0, N, ldc): 256 when every boundary RELATIVE to the launch's
+    first column is a 256-column multiple (the kernel may then use its 256 x 256 tile form), else 128 (the minimum)"""
+    n_lo = part[0][2]
+    return 256 if all((n0 - n_lo) % 256 == 0 and N % 256 == 0 for _, _, n0, N, _ in part) else 128
+
+
 class DeepIneligible(Exception):
     """a layer does not fit the persistent deep-level kernel (LDS / staging registers / unsupported option)"""
 
@@ -1472,6 +1479,7 @@ class Plan(OpBuilder):
                 g.b = W.w["kv2_all"].data_ptr() + n_lo * F * W.w["kv2_all"].element_size()
                 g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups = B * NL, n_hi - n_lo, F, F, F, len(part)
                 g.rows_in, g.rows_out, g.dtype, g.alpha = NL, spec.ctx_len, eng.dt, 1.0
+                g.group_align = _group_align(part)      # (256-column multiples: the product may run on the 256 x 256 tile form)
                 self._kv_gemms.append((g, tab))
                 fn = lambda s, g=g: L.check(lib.jen1_big_gemm(C.byref(g), s), "jen1_big_gemm")
                 fn.kind, fn.label = "big_gemm", f"to_kv of {len(part)} layers: [{B * NL} x {F}] x [{n_hi - n_lo} x {F}]^T"
@@ -1655,6 +1663,7 @@ class Engine:
             g.a, g.groups = fx.data_ptr(), tab.data_ptr()
             g.b = W.w["kv2_all"].data_ptr() + n_lo * F * W.w["kv2_all"].element_size()
             g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups, g.dtype, g.alpha = n, n_hi - n_lo, F, F, F, len(part), self.dt, 1.0
+            g.group_align = _group_align(part)
             L.check(lib.jen1_big_gemm(C.byref(g), s), "jen1_big_gemm")
         torch.cuda.synchronize(dev)
 

@@ -104,7 +104,7 @@ class BGemmArgs(C.Structure):
     _fields_ = [("a", c_void_p), ("b", c_void_p), ("groups", c_void_p), ("row_scale", c_void_p),
                 ("M", c_int), ("Ntot", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("n_groups", c_int),
                 ("rows_in", c_int), ("rows_out", c_int), ("c_f32", c_int), ("accumulate", c_int), ("dtype", c_int), ("ldc", c_int),
-                ("alpha", c_float), ("reserved_f", c_float), ("c", c_void_p), ("bias", c_void_p)]
+                ("alpha", c_float), ("group_align", c_int), ("c", c_void_p), ("bias", c_void_p)]
 
 
 class RepackEntry(C.Structure):

@@ -14,7 +14,7 @@ from jen1_amd import lib as L
 pytestmark = pytest.mark.gpu
 
 
-def _run(a, b, groups, *, row_scale=None, rows_in=0, rows_out=0, c_f32=False, accumulate=False, alpha=1.0, dtype="bf16"):
+def _run(a, b, groups, *, row_scale=None, rows_in=0, rows_out=0, c_f32=False, accumulate=False, alpha=1.0, dtype="bf16", group_align=0):
     lib = L.load()
     tab = L.bgemm_group_table([(c.data_ptr(), None if bias is None else bias.data_ptr(), n0, N, c.stride(-2)) for c, bias, n0, N in groups], a.device)
     g = L.BGemmArgs()
@@ -24,6 +24,7 @@ def _run(a, b, groups, *, row_scale=None, rows_in=0, rows_out=0, c_f32=False, ac
     g.rows_in, g.rows_out, g.c_f32, g.accumulate = rows_in, rows_out, int(c_f32), int(accumulate)
     g.dtype = L.F32 if dtype == "f32" else L.BF16
     g.alpha = alpha
+    g.group_align = group_align
     L.check(lib.jen1_big_gemm(C.byref(g), torch.cuda.current_stream().cuda_stream), "jen1_big_gemm")
     torch.cuda.synchronize()
 
@@ -353,3 +354,66 @@ def test_conv_transpose_forward_on_the_conv_form(stride, k, padding, opad):
     ref = F.conv_transpose1d(x.float().permute(0, 2, 1), w.float(), bias, stride=stride, padding=padding, output_padding=opad)
     assert ref.shape[-1] == L_out
     assert rel_err(y.float().cpu().numpy(), ref.permute(0, 2, 1).cpu().numpy()) < 6e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the 256 x 256 tile form (big_gemm_nt256_kernel) and the column split of a product between it and the 128 x 128 form
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 1024), (2064, 2048, 512), (300, 768, 128), (257, 256, 64), (1, 512, 64), (1161, 1280, 1024)])
+def test_tile256_form_forced_matches_torch(monkeypatch, M, N, K):
+    """JEN1_BGEMM_T256=1: every bf16 product runs on the 256 x 256 tiles -- ragged M (rows past M read zeros, are never stored), column
+    counts that are not 256 multiples (one group: the last tile is cut by the buffer descriptor and the column test of the epilogue)"""
+    monkeypatch.setenv("JEN1_BGEMM_T256", "1")
+    gen = torch.Generator(device="cuda").manual_seed(M * 3 + N + K)
+    a = (torch.randn((M, K), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    b = (torch.randn((N, K), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    guard = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    c = guard[:M]
+    _run(a, b, [(c, None, 0, N)])
+    ref = a.float() @ b.float().t()
+    assert float((c.float() - ref).abs().max() / ref.abs().max()) < 1e-2
+    assert bool((guard[M:] == 7.0).all())
+    # the other form on the same operands: the two kernels accumulate in the same order along K (bit-identical results)
+    monkeypatch.setenv("JEN1_BGEMM_T256", "0")
+    c2 = torch.empty_like(c)
+    _run(a, b, [(c2, None, 0, N)])
+    assert torch.equal(c, c2)
+
+
+def test_tile256_epilogue_accumulate_alpha_float32_output(monkeypatch):
+    monkeypatch.setenv("JEN1_BGEMM_T256", "1")
+    M, N, K = 515, 512, 256
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    a = (torch.randn((M, K), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    b = (torch.randn((N, K), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    c = torch.randn((M, N), device="cuda", generator=gen)
+    want = c + 0.25 * (a.float() @ b.float().t())
+    _run(a, b, [(c, None, 0, N)], c_f32=True, accumulate=True, alpha=0.25)
+    assert float((c - want).abs().max() / want.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B", [8, 3])
+def test_stacked_projection_splits_between_the_two_tile_forms(B):
+    """the sampling plan's shape: 13 column groups (widths 512 / 1024 / 2048, 256-column multiples: group_align = 256) over B x 128 rows,
+    row map into [B][129] caches, padding mask, bias.  B = 8: 4 x 68 big tiles = one full round on 256 CUs + 64 columns-of-1024 on the
+    128 x 128 form (the split lands on a group boundary); B = 3: too few tiles, everything on the small form.  Same results either way."""
+    NL, K = 128, 1024
+    widths = [512] * 2 + [1024] * 7 + [2048] * 4          # (the full model's 13 cross-attention layers: 17408 columns)
+    gen = torch.Generator(device="cuda").manual_seed(11 + B)
+    xs = (torch.randn((B * NL, K), device="cuda", generator=gen)).to(torch.bfloat16)
+    w = (torch.randn((sum(widths), K), device="cuda", generator=gen) * 0.05).to(torch.bfloat16)
+    mask_b = (torch.rand((B, NL + 1), device="cuda", generator=gen) > 0.3).float()
+    mask = mask_b[:, :NL].reshape(-1)
+    outs, groups, n0 = [], [], 0
+    for wd in widths:
+        cache = torch.full((B, NL + 1, wd), -3.0, device="cuda", dtype=torch.bfloat16)
+        bias = torch.randn((wd,), device="cuda", generator=gen)
+        outs.append((cache, bias, n0, wd))
+        groups.append((cache.view(B * (NL + 1), wd), bias, n0, wd))
+        n0 += wd
+    _run(xs, w, groups, row_scale=mask_b, rows_in=NL, rows_out=NL + 1, group_align=256)
+    for cache, bias, n0, wd in outs:
+        ref = (xs.float() @ w[n0:n0 + wd].float().t() + bias[None]) * mask[:, None]
+        got = cache[:, :NL].reshape(B * NL, wd).float()
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2, (n0, wd)
+        assert bool((cache[:, NL] == -3.0).all())          # the time token's row is not this launch's
