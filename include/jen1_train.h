@@ -243,6 +243,27 @@ typedef struct jen1_repack_entry {
 } jen1_repack_entry;
 int jen1_repack(const jen1_repack_entry* entries_dev, int n, int total_tiles, int dtype, void* stream);
 
+/* --- the text-context K / V projections of all cross-attention layers as one product (csrc/train_kvbank.hip; reference
+ * jen1/model/blocks.py:400-407, :427-434: k, v = chunk(to_kv(norm_context(context))) on the same context in every layer).
+ * to_kv_l(norm_context_l(x)) = xhat Wf_l^T + bias_l with Wf_l = W_l diag(gamma_l), bias_l = W_l beta_l and xhat the standardised rows
+ * (shared).  One table entry per layer, n0 ascending; every n0 and N a multiple of 32. */
+typedef struct jen1_kv_layer {
+  const float* w;          /* to_kv.weight [N][K], the float32 parameter */
+  const float* gamma;      /* norm_context.weight [K] */
+  const float* beta;       /* norm_context.bias [K] */
+  float* gw;               /* their gradients (``param.grad``), accumulated by jen1_kv_fold_backward */
+  float* ggamma;
+  float* gbeta;
+  int32_t n0, N;           /* the layer's rows in the stacked operands */
+} jen1_kv_layer;
+/* wf [Ntot][K] bf16 = W diag(gamma), wft [K][ld_wft >= Ntot] bf16 = its transpose, bias [Ntot] float32 = W beta */
+int jen1_kv_fold(const jen1_kv_layer* table_dev, int n_layers, int Ntot, int K, void* wf, void* wft, int ld_wft, float* bias, void* stream);
+/* gw += dwf diag(gamma) + dbias beta^T, ggamma += colsum(dwf * W), gbeta += W^T dbias; dwf [Ntot][K], dbias [Ntot] float32 */
+int jen1_kv_fold_backward(const jen1_kv_layer* table_dev, int n_layers, int Ntot, int K, const float* dwf, const float* dbias, void* stream);
+/* block 0 += blocks 1 .. nblk - 1 in place; a block = rows_per_block rows of row_elems elements (a multiple of 8), rows ld apart, blocks
+ * rows_per_block * ld apart: dK | dV of the batch elements that share one set of context rows, inside the stacked gradient matrix */
+int jen1_sum_rows_strided(void* p, int nblk, int rows_per_block, int row_elems, int64_t ld, int dtype, void* stream);
+
 /* out[c] += sum_rows x[row][c]  (bias gradients), float32 accumulate */
 int jen1_colsum(const void* x, float* out, int rows, int C, int ld, int dtype, void* stream);
 

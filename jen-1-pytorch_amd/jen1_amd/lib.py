@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # 
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "deep_kernel.hip", "elementwise.hip",
-           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip", "big_gemm.hip", "train_glue.hip"]
+           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip", "big_gemm.hip", "train_glue.hip", "train_kvbank.hip"]
 
 F32, BF16, FP8 = 0, 1, 2
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -113,6 +113,12 @@ class RepackEntry(C.Structure):
                 ("s0", c_int64), ("s1", c_int64), ("s2", c_int64), ("tile0", c_int), ("ld2", c_int), ("dst2", c_void_p)]
 
 
+class KvLayer(C.Structure):
+    """mirror of ``jen1_kv_layer`` (include/jen1_train.h)"""
+    _fields_ = [("w", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("gw", c_void_p), ("ggamma", c_void_p), ("gbeta", c_void_p),
+                ("n0", c_int), ("N", c_int)]
+
+
 # every symbol include/jen1_hip.h and include/jen1_train.h declare: (name, restype, argtypes)
 _P = c_void_p
 SYMBOLS = {
@@ -161,6 +167,9 @@ SYMBOLS = {
     "jen1_gn_backward_add2": (c_int, [_P] * 6 + [c_int] + [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_ln_backward_add": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
     "jen1_repack": (c_int, [_P, c_int, c_int, c_int, _P]),
+    "jen1_kv_fold": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
+    "jen1_kv_fold_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "jen1_sum_rows_strided": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, _P]),
     "jen1_train_pack_input": (c_int, [_P] * 6 + [c_int] * 6 + [_P, _P, _P, c_int, _P]),
     "jen1_train_context": (c_int, [_P] * 5 + [c_int] * 6 + [_P]),
     "jen1_train_context_backward": (c_int, [_P] * 4 + [c_int] * 6 + [_P]),

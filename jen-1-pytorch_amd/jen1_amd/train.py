@@ -125,6 +125,9 @@ class TrainRuntime:
         # the unconditional half of the CFG pair reads ONE shared set of context rows (the fixed embedding) instead of B copies
         self.share_fixed_context = os.environ.get("JEN1_TRAIN_SHARE_FIXED", "1") == "1"
         self._banks: Dict[tuple, list] = {}      # (ids of the weights, dtype) -> [weakrefs, weight matrix, weakrefs of the biases, bias vector, epoch]
+        # the text-context K / V projections of all cross-attention layers as ONE product per pass (KvBank, ContextKVFn; csrc/train_kvbank.hip)
+        self.kv_grouped = os.environ.get("JEN1_TRAIN_KV_GROUPED", "1") == "1"
+        self._kv_banks: Dict[tuple, "KvBank"] = {}
 
     def kv_rows(self, B: int) -> torch.Tensor:
         """[0 .. B - 1, B, B, ... B] (int32, 2 B entries): the K / V row every element of a CFG pair reads when the unconditional
@@ -281,6 +284,18 @@ class TrainRuntime:
         self._refresh_bank_bias(hit)
         return hit[1], hit[3]
 
+    def kv_bank(self, weights: Sequence[torch.Tensor], gammas: Sequence[torch.Tensor], betas: Sequence[torch.Tensor]) -> "KvBank":
+        """the folded operands of the stacked text-context projection (KvBank), cached on the identity of the parameters and kept up to
+        date like the other compute copies (one jen1_kv_fold launch per optimiser step)"""
+        key = tuple(id(w) for w in weights)
+        hit = self._kv_banks.get(key)
+        if hit is not None and not hit.same(weights, gammas, betas):
+            hit = None
+        if hit is None:
+            hit = self._kv_banks[key] = KvBank(self, weights, gammas, betas)
+        hit.refresh()
+        return hit
+
     def _refresh_bank_bias(self, hit) -> None:
         if hit[4] != self.epoch:
             bs = [r() for r in hit[2]]
@@ -301,6 +316,8 @@ class TrainRuntime:
             return
         for bank in self._banks.values():
             self._refresh_bank_bias(bank)
+        for kvb in self._kv_banks.values():
+            kvb.refresh()
         live = [(hit, hit[0]()) for hit in self._packed.values() if hit[2] != -1]
         live = [(hit, w) for hit, w in live if w is not None]
         if self.fused_repack and live:
@@ -749,10 +766,11 @@ def conv_transpose1d(rt: TrainRuntime, x: torch.Tensor, weight, bias, stride: in
     return ConvFn.apply(x, weight, bias, rt, ConvGeom("convT", k, stride, padding, Lin, Lout, ci, co))
 
 
-def _big_gemm(rt: "TrainRuntime", a2d: torch.Tensor, b2d: torch.Tensor, out: torch.Tensor, K: int) -> None:
-    """out[M][N] = a2d[M][:K] @ b2d[N][:K]^T on jen1_big_gemm (one column group)"""
+def _big_gemm(rt: "TrainRuntime", a2d: torch.Tensor, b2d: torch.Tensor, out: torch.Tensor, K: int, bias: Optional[torch.Tensor] = None) -> None:
+    """out[M][N] = a2d[M][:K] @ b2d[N][:K]^T (+ bias[N], float32) on jen1_big_gemm (one column group)"""
     g = L.BGemmArgs()
     g.a, g.b, g.c, g.ldc = a2d.data_ptr(), b2d.data_ptr(), out.data_ptr(), out.stride(0)      # (one inline group: nothing to copy while capturing)
+    g.bias = None if bias is None else bias.data_ptr()
     g.M, g.Ntot, g.K, g.lda, g.ldb, g.n_groups = a2d.shape[0], b2d.shape[0], K, a2d.stride(0), b2d.stride(0), 1
     g.dtype, g.alpha = rt.dt_of(a2d), 1.0
     if rt.stats is not None:
@@ -806,6 +824,144 @@ class BigLinearFn(Function):
                 dx.zero_()
             _big_gemm(rt, dy, wt, dx, co)
         return dx, None, None
+
+
+class KvBank:
+    """Folded operands of ``to_kv_l(norm_context_l(x))`` for all cross-attention layers l (blocks.py:400-407, :427-434; the algebra is in
+    csrc/train_kvbank.hip): wf [Ntot][K] bf16 = W diag(gamma) row-stacked, wft [K][Ntot] its transpose (the data gradient's operand),
+    bias [Ntot] float32 = W beta.  ``refresh`` folds again when the parameters moved (TrainRuntime.epoch); the device table carries the
+    parameters' AND their gradients' addresses (``jen1_kv_layer``) and is rebuilt when one of them changed."""
+
+    def __init__(self, rt: "TrainRuntime", weights, gammas, betas):
+        self.rt = rt
+        self.refs = [[weakref.ref(t) for t in ts] for ts in (weights, gammas, betas)]
+        self.K = weights[0].shape[1]
+        self.widths = [w.shape[0] for w in weights]
+        assert all(w.shape[1] == self.K and w.shape[0] % 32 == 0 and w.dtype == torch.float32 and w.is_contiguous() for w in weights)
+        assert all(g.shape == (self.K,) and b.shape == (self.K,) for g, b in zip(gammas, betas)) and self.K % 64 == 0
+        self.offs = [0]
+        for n in self.widths:
+            self.offs.append(self.offs[-1] + n)
+        self.Ntot = self.offs[-1]
+        dev = weights[0].device
+        self.wf = torch.zeros((self.Ntot, self.K), dtype=torch.bfloat16, device=dev)
+        self.wft = torch.zeros((self.K, self.Ntot), dtype=torch.bfloat16, device=dev)
+        self.bias = torch.zeros((self.Ntot,), dtype=torch.float32, device=dev)
+        self.ones = torch.ones((self.K,), dtype=torch.float32, device=dev)
+        self.zeros = torch.zeros((self.K,), dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros((2, self.K), dtype=torch.float32, device=dev)       # dgamma / dbeta of the unit affine map (discarded)
+        self.dwf = torch.empty((self.Ntot * self.K + self.Ntot,), dtype=torch.float32, device=dev)      # dWf | dbias, zeroed per pass
+        self.epoch = -2
+        self._tab, self._tab_key = None, None
+
+    def params(self):
+        return [[r() for r in rs] for rs in self.refs]
+
+    def same(self, weights, gammas, betas) -> bool:
+        return all(r() is t for rs, ts in zip(self.refs, (weights, gammas, betas)) for r, t in zip(rs, ts))
+
+    def table(self) -> torch.Tensor:
+        ws, gs, bs = self.params()
+        rt = self.rt
+        key = tuple(t.data_ptr() for t in ws + gs + bs) + tuple(rt.grad_of(t).data_ptr() for t in ws + gs + bs)
+        if key != self._tab_key:
+            ents = (L.KvLayer * len(ws))()
+            for i, (w, g, b) in enumerate(zip(ws, gs, bs)):
+                e = ents[i]
+                e.w, e.gamma, e.beta = w.data_ptr(), g.data_ptr(), b.data_ptr()
+                e.gw, e.ggamma, e.gbeta = rt.grad_of(w).data_ptr(), rt.grad_of(g).data_ptr(), rt.grad_of(b).data_ptr()
+                e.n0, e.N = self.offs[i], self.widths[i]
+            raw = bytes(ents)
+            assert not torch.cuda.is_current_stream_capturing(), "the table of a KvBank must exist before a pass is recorded"
+            self._tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.wf.device)
+            self._tab_key = key
+        return self._tab
+
+    def refresh(self) -> None:
+        if self.epoch == self.rt.epoch:
+            return
+        rt = self.rt
+        L.check(rt.lib.jen1_kv_fold(self.table().data_ptr(), len(self.widths), self.Ntot, self.K, self.wf.data_ptr(), self.wft.data_ptr(), self.Ntot,
+                                    self.bias.data_ptr(), rt.stream()), "jen1_kv_fold")
+        self.epoch = rt.epoch
+
+
+class KvSlot:
+    """where the attention backward of one cross-attention layer writes dK | dV: a column window [B_eff, Nk, 2C] of the stacked gradient matrix
+    (rows ``Ntot`` apart) -- the operand of ONE weight-gradient and ONE data-gradient product (ContextKVFn.backward)"""
+
+    def __init__(self, view: torch.Tensor):
+        self.view = view
+
+
+class ContextKVFn(Function):
+    """K | V of every cross-attention layer from the context rows in one standardisation + one product (see KvBank); outputs: one
+    [Bk, Nk, 2 C_l] column window of the stacked result per layer (rows Ntot apart: the attention kernels take the pitch)."""
+
+    @staticmethod
+    def forward(ctx, rows, rt: TrainRuntime, bank: KvBank, slots, n_share: int):
+        Bk, Nk, K = rows.shape
+        assert rows.is_contiguous() and rows.dtype == torch.bfloat16 and K == bank.K
+        R = Bk * Nk
+        x2d = rows.view(R, K)
+        xhat = torch.empty_like(x2d)
+        stats = torch.empty((R, 2), dtype=torch.float32, device=rows.device)
+        L.check(rt.lib.jen1_ln_forward(x2d.data_ptr(), bank.ones.data_ptr(), bank.zeros.data_ptr(), xhat.data_ptr(), stats.data_ptr(), R, K, K, 1e-5,
+                                       L.BF16, rt.stream()), "jen1_ln_forward")
+        kv_all = torch.empty((R, bank.Ntot), dtype=torch.bfloat16, device=rows.device)
+        _big_gemm(rt, xhat, bank.wf, kv_all, K, bias=bank.bias)
+        ctx.rt, ctx.bank, ctx.slots, ctx.n_share, ctx.dims = rt, bank, slots, n_share, (Bk, Nk, K)
+        ctx.save_for_backward(x2d, xhat, stats)
+        kv3 = kv_all.view(Bk, Nk, bank.Ntot)
+        return tuple(kv3[:, :, o:o + n] for o, n in zip(bank.offs, bank.widths))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x2d, xhat, stats = ctx.saved_tensors
+        rt, bank, slots = ctx.rt, ctx.bank, ctx.slots
+        Bk, Nk, K = ctx.dims
+        R, Ntot = Bk * Nk, bank.Ntot
+        dall = slots[0].view._base                                   # [B_eff * Nk, Ntot]
+        for slot, gr in zip(slots, grads):
+            if gr is None:
+                slot.view[:Bk].zero_()
+            elif gr.data_ptr() != slot.view.data_ptr() or gr.stride() != slot.view[:Bk].stride():
+                slot.view[:Bk].copy_(gr)        # (a gradient that did not come from the one-launch attention core's in-place write)
+        s = rt.stream()
+        if ctx.n_share > 1:
+            # the unconditional half of the CFG pair read ONE set of context rows: its batch elements' dK | dV blocks, all layers at once
+            L.check(rt.lib.jen1_sum_rows_strided(dall.data_ptr() + (Bk - 1) * Nk * Ntot * 2, ctx.n_share, Nk, Ntot, Ntot, L.BF16, s), "jen1_sum_rows_strided")
+        dwf, dbias = bank.dwf[: Ntot * K], bank.dwf[Ntot * K:]
+        L.check(rt.lib.jen1_memset_zero(bank.dwf.data_ptr(), bank.dwf.numel() * 4, s), "jen1_memset_zero")
+        L.check(rt.lib.jen1_colsum(dall.data_ptr(), dbias.data_ptr(), R, Ntot, Ntot, L.BF16, s), "jen1_colsum")
+        L.check(rt.lib.jen1_big_gemm_tn(dall.data_ptr(), xhat.data_ptr(), dwf.data_ptr(), R, Ntot, K, Ntot, K, K, 1.0, s), "jen1_big_gemm_tn")
+        L.check(rt.lib.jen1_kv_fold_backward(bank.table().data_ptr(), len(bank.widths), Ntot, K, dwf.data_ptr(), dbias.data_ptr(), s), "jen1_kv_fold_backward")
+        if rt.stats is not None:
+            e = rt.stats.setdefault("big_gemm", [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += 2.0 * R * Ntot * K
+            e[2] += (R * Ntot + R * K) * 2 + Ntot * K * 8
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxh = torch.empty_like(xhat)
+            _big_gemm(rt, dall[:R], bank.wft, dxh, Ntot)
+            dx = torch.empty_like(x2d)
+            L.check(rt.lib.jen1_ln_backward(dxh.data_ptr(), x2d.data_ptr(), stats.data_ptr(), bank.ones.data_ptr(), dx.data_ptr(), bank.scratch[0].data_ptr(),
+                                            bank.scratch[1].data_ptr(), R, K, K, L.BF16, s), "jen1_ln_backward")
+            dx = dx.view(Bk, Nk, K)
+        return dx, None, None, None, None
+
+
+def context_kv(rt: TrainRuntime, rows: torch.Tensor, weights, gammas, betas, b_eff: int):
+    """-> [(kv_l, KvSlot_l)] for the cross-attention layers whose parameters are given: kv_l [Bk, Nk, 2 C_l]; ``b_eff``: batch elements of
+    the pass (the last b_eff - (Bk - 1) of them read the last set of context rows: AttentionCoreFn's ``kv_row``)"""
+    Bk, Nk, _ = rows.shape
+    bank = rt.kv_bank(weights, gammas, betas)
+    dall = torch.empty((b_eff * Nk, bank.Ntot), dtype=torch.bfloat16, device=rows.device)
+    d3 = dall.view(b_eff, Nk, bank.Ntot)
+    slots = tuple(KvSlot(d3[:, :, o:o + n]) for o, n in zip(bank.offs, bank.widths))
+    outs = ContextKVFn.apply(rows, rt, bank, slots, b_eff - (Bk - 1))
+    return list(zip(outs, slots))
 
 
 def linear(rt: TrainRuntime, x: torch.Tensor, weight, bias=None, residual=None, fork: bool = False):
@@ -1114,8 +1270,10 @@ def _rows_view(t: torch.Tensor) -> Tuple[int, int]:
 
 class AttentionCoreFn(Function):
     @staticmethod
-    def forward(ctx, q, kv, rt: TrainRuntime, heads: int, causal: bool, kv_mask=None, kv_row=None):
-        """kv: [B, Nk, 2 C] = to_kv's output (K | V): the gradient comes back as ONE tensor (two column windows written by the data-gradient
+    def forward(ctx, q, kv, rt: TrainRuntime, heads: int, causal: bool, kv_mask=None, kv_row=None, dkv_slot=None):
+        """``dkv_slot`` (KvSlot, one-launch core only): kv is a column window of the stacked projection of all cross-attention layers
+        (ContextKVFn; rows a pitch apart) and dK | dV are written into the same window of the stacked gradient matrix.
+        kv: [B, Nk, 2 C] = to_kv's output (K | V): the gradient comes back as ONE tensor (two column windows written by the data-gradient
         GEMMs) instead of two slice gradients that autograd pads with zeros and adds.  ``kv_row`` (int32 [B], one-launch core only): batch
         element b attends to kv[kv_row[b]]; kv then has Bk = kv_row[-1] + 1 rows, the first Bk - 1 mapped one to one, the last one shared by
         all the others (the CFG pair's unconditional half)."""
@@ -1142,6 +1300,8 @@ class AttentionCoreFn(Function):
         assert kv_mask is None or ctx.small, "kv_mask rides on the one-launch attention core only (attention() multiplies otherwise)"
         ctx.kv_mask = None if kv_mask is None else kv_mask.to(torch.float32).contiguous()
         ctx.kv_row = kv_row
+        ctx.dkv_slot = dkv_slot
+        assert dkv_slot is None or ctx.small
         assert kv_row is None or (ctx.small and kv_row.dtype == torch.int32 and kv_row.shape[0] == B)
         if ctx.small:
             assert rows is None or rows.flags.shape[0] == B
@@ -1182,6 +1342,19 @@ class AttentionCoreFn(Function):
         kp, ldk = _rows_view(k)
         vp, ldv = _rows_view(v)
         dQ = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+        slot = ctx.dkv_slot
+        if slot is not None:
+            # dK | dV of every batch element straight into this layer's window of the stacked gradient matrix; the blocks of the batch
+            # elements that share context rows are added up there for all layers at once (ContextKVFn.backward)
+            dW = slot.view
+            assert dW.shape[0] == B and dW.shape[1] == Nk and dW.shape[2] == 2 * C and dW.stride(2) == 1 and dW.stride(0) == Nk * dW.stride(1)
+            esz, ldw = dW.element_size(), dW.stride(1)
+            L.check(rt.lib.jen1_attn_small_backward_rows(qp, ldq, kp, ldk, vp, ldv, P.data_ptr(), ldS, dO.data_ptr(), C, dQ.data_ptr(), C,
+                                                         dW.data_ptr(), ldw, dW.data_ptr() + C * esz, ldw, B, heads, Nq, Nk, d,
+                                                         float(scale), None if ctx.kv_mask is None else ctx.kv_mask.data_ptr(),
+                                                         None if ctx.kv_row is None else ctx.kv_row.data_ptr(), dt, rt.stream()),
+                    "jen1_attn_small_backward_rows")
+            return dQ, dW[: kv.shape[0]], None, None, None, None, None, None
         dKV = torch.empty((B, Nk, 2 * C), dtype=q.dtype, device=q.device)
         esz = dKV.element_size()
         if ctx.small:
@@ -1197,7 +1370,7 @@ class AttentionCoreFn(Function):
                 n = Nk * 2 * C
                 L.check(rt.lib.jen1_sum_rows_inplace(dKV.data_ptr() + (Bk - 1) * n * esz, B - (Bk - 1), n, dt, rt.stream()), "jen1_sum_rows_inplace")
                 dKV = dKV[:Bk]
-            return dQ, dKV, None, None, None, None, None
+            return dQ, dKV, None, None, None, None, None, None
         dP = torch.empty((Z, Nq, ldS), dtype=torch.float32, device=q.device)
         dS = torch.empty((Z, Nq, ldS), dtype=q.dtype, device=q.device)
         o_do = lambda ld_r, ld_k: _operand(dO.data_ptr(), ld_r, ld_k, zs0=Nq * C, zs1=d, zdiv=heads)
@@ -1213,22 +1386,24 @@ class AttentionCoreFn(Function):
                 dKV.data_ptr(), Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads, alpha=scale)
         rt.gemm(_operand(P.data_ptr(), 1, ldS, zs0=Nq * ldS), o_do(1, C),
                 dKV.data_ptr() + C * esz, Nk, d, Nq, dtype=dt, batches=Z, ldc_m=2 * C, c_zs0=Nk * 2 * C, c_zs1=d, c_zdiv=heads)
-        return dQ, dKV, None, None, None, None, None
+        return dQ, dKV, None, None, None, None, None, None
 
 
-def attention_core(rt, q, kv, heads: int, causal, kv_mask=None, kv_row=None):
+def attention_core(rt, q, kv, heads: int, causal, kv_mask=None, kv_row=None, dkv_slot=None):
     """``kv_mask`` [B, Nk]: multiplied into the rows of K and V (blocks.py:431-434) -- inside the one-launch kernels when the shape
     fits them, else as a tensor product before the GEMM path.  ``kv_row``: see AttentionCoreFn.forward (GEMM path: the rows are
     gathered first)"""
     B, Nq, C = q.shape
     small = bool(rt.small_attn and rt.lib.jen1_attn_small_fits(Nq, kv.shape[1], C // heads, rt.dt_of(q)))
+    if not small:
+        dkv_slot = None                 # (the GEMM path takes contiguous K | V; the stacked window's gradient is then copied in: ContextKVFn.backward)
     if kv_row is not None and not small:
         kv = kv.index_select(0, kv_row.to(torch.int64))
         kv_row = None
     if kv_mask is not None and not small:
         kv = kv * kv_mask.to(kv.dtype)[:, :, None]
         kv_mask = None
-    return AttentionCoreFn.apply(q, kv.contiguous(), rt, heads, causal, kv_mask, kv_row)
+    return AttentionCoreFn.apply(q, kv if dkv_slot is not None else kv.contiguous(), rt, heads, causal, kv_mask, kv_row, dkv_slot)
 
 
 # =====================================================================================================================
@@ -1334,6 +1509,7 @@ class TrainGraph:
         self._side: Optional[torch.cuda.Stream] = None
         self._module = weakref.ref(module)
         self.exchange = None        # optim.GradExchange: told when the gradients of a top-level block are complete
+        self._kv = None             # {cross-attention name: (K | V window, KvSlot)} of the pass being built (_stacked_context_kv)
 
     def _mark(self, h: torch.Tensor, region: str) -> torch.Tensor:
         """``h`` enters the top-level block ``region``: once the gradient with respect to ``h`` exists, every parameter
@@ -1452,12 +1628,15 @@ class TrainGraph:
         if box is not None:
             context = box[0]
             kv_row = box[1] if len(box) > 1 else None
+        pre = self._kv.get(n) if (box is not None and self._kv) else None      # (K | V of this layer from the pass's stacked projection)
         # x feeds the norm(s) AND (as ``residual``) the sum after to_out: forked through the LayerNorms, so its gradients meet
         # inside their backward kernels instead of in accumulation launches
         fork = rt.fork_norms and residual is x and x.requires_grad
         if fork:
             xn, x = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"], fork=True)
-            if context is None:
+            if pre is not None:
+                cn = None
+            elif context is None:
                 cn, x = layer_norm(rt, x, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"], fork=True)
             elif box is not None and rt.fork_skips and context.requires_grad:
                 cn, box[0] = layer_norm(rt, context, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"], fork=True)
@@ -1467,12 +1646,11 @@ class TrainGraph:
         else:
             ctx = x if context is None else context
             xn = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"])
-            cn = layer_norm(rt, ctx, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"])
+            cn = None if pre is not None else layer_norm(rt, ctx, p[f"{n}.norm_context.weight"], p[f"{n}.norm_context.bias"])
         q = linear(rt, xn, p[f"{n}.to_q.weight"])
-        kv = linear(rt, cn, p[f"{n}.to_kv.weight"])
-        mid = kv.shape[-1] // 2
+        kv, slot = pre if pre is not None else (linear(rt, cn, p[f"{n}.to_kv.weight"]), None)
         # the padding mask multiplies K and V (blocks.py:431-434): inside the attention kernels when the shape fits them
-        o = attention_core(rt, q, kv, heads, causal, context_mask, kv_row)
+        o = attention_core(rt, q, kv, heads, causal, context_mask, kv_row, slot)
         return linear(rt, o, p[f"{n}.attention.to_out.weight"], p[f"{n}.attention.to_out.bias"], residual=residual)
 
     def transformer(self, t: TransformerSpec, x: torch.Tensor, embedding, embedding_mask, causal: bool, skip: bool = False):
@@ -1510,6 +1688,28 @@ class TrainGraph:
         d = lb - la
         return a, b[:, d // 2: lb - (d - d // 2)]
 
+    def _cross_attention_names(self) -> List[str]:
+        sp = self.spec
+        trs = [d.transformer for d in sp.downs if d.transformer] + ([sp.bott_tr] if sp.bott_tr else []) + [u.transformer for u in sp.ups if u.transformer]
+        return [f"{t.name}.blocks.{l}.cross_attention" for t in trs for l in range(t.num_layers)]
+
+    def _stacked_context_kv(self, rows: Optional[torch.Tensor], b_eff: int):
+        """{cross-attention name: (K | V window, KvSlot)} -- every layer's ``to_kv(norm_context(context))`` from ONE standardisation and ONE
+        product over the context rows (ContextKVFn), or None when the pass keeps one LayerNorm + Linear per layer: float32 mode (the
+        weight-gradient product is bf16), layer widths that are not 32-column multiples, no context"""
+        rt, p = self.rt, self.p
+        if not (rt.kv_grouped and rt.small_attn and rows is not None and rows.dim() == 3 and rows.dtype == torch.bfloat16 and rows.is_contiguous()):
+            return None
+        names = self._cross_attention_names()
+        if not names:
+            return None
+        ws = [p[f"{n}.to_kv.weight"] for n in names]
+        K = rows.shape[-1]
+        if K % 64 or any(w.shape[1] != K or w.shape[0] % 32 for w in ws):
+            return None
+        pairs = context_kv(rt, rows, ws, [p[f"{n}.norm_context.weight"] for n in names], [p[f"{n}.norm_context.bias"] for n in names], b_eff)
+        return dict(zip(names, pairs))
+
     # ------------------------------------------------------------------ UNet1d.forward
     def unet(self, x: torch.Tensor, t: torch.Tensor, embedding: torch.Tensor, embedding_mask, ctx_channels, causal: bool) -> torch.Tensor:
         """x [B, C, T] float32 (+ ctx_channels [B, 129, T]) -> [B, out_channels, T] float32"""
@@ -1532,6 +1732,7 @@ class TrainGraph:
         # by an accumulation launch of autograd (~30 per pass).
         emb_box = list(embedding) if isinstance(embedding, (tuple, list)) else [embedding]     # (handed from one cross-attention to the next;
                                                                                              #  optionally with the K / V row map of the batch)
+        self._kv = self._stacked_context_kv(emb_box[0], h.shape[0])
         skips_list: List = [[None]]
         slot = (skips_list[0], 0)                                       # where the alias of the current ``h`` belongs
 
@@ -1590,6 +1791,7 @@ class TrainGraph:
                 h = conv_transpose1d(rt, h, w, b, f, f // 2 + f % 2, f % 2)
         h = h + skips_list.pop()[0]                                      # model.py:261
         h = self._mark(h, "to_out")
+        self._kv = None
         return self.res_block(sp.to_out, h, smap, False, films)
 
     # ------------------------------------------------------------------ UNetCFG1d.forward

@@ -417,8 +417,8 @@ def test_ctypes_mirrors_have_the_size_of_the_c_structs(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stdint.h>\n#include "jen1_hip.h"\n#include "jen1_train.h"\n'
-                   'int main(void) { printf("%zu %zu %zu\\n", sizeof(jen1_gemm_operand), sizeof(jen1_gemm_args), sizeof(jen1_repack_entry)); return 0; }\n')
+                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(jen1_gemm_operand), sizeof(jen1_gemm_args), sizeof(jen1_repack_entry), sizeof(jen1_kv_layer)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", f"-I{os.path.join(root, 'include')}", str(src), "-o", str(exe)], check=True)
     sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    assert sizes == [ctypes.sizeof(L.GemmOperand), ctypes.sizeof(L.GemmArgs), ctypes.sizeof(L.RepackEntry)]
+    assert sizes == [ctypes.sizeof(L.GemmOperand), ctypes.sizeof(L.GemmArgs), ctypes.sizeof(L.RepackEntry), ctypes.sizeof(L.KvLayer)]
