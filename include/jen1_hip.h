@@ -364,6 +364,9 @@ int jen1_big_gemm(const jen1_bgemm_args* args, void* stream);
  * A = dY [M][lda >= N], B = the layer's input [M][ldb >= K] (bf16, as they lie in memory: the reduction index is the row), C float32
  * [N][ldc] accumulated with float atomics (the reduction is split over workgroups): ``param.grad`` of the reference layout. */
 int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream);
+/* the same product WRITTEN to C (C = alpha * A^T B): the reduction is not split, every workgroup stores its own tile -- no atomics and no
+ * zero-fill in front (the stacked weight gradient of the text-context projections, 17408 x 1024 floats: csrc/train_kvbank.hip) */
+int jen1_big_gemm_tn_store(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream);
 /* the convolution form of jen1_big_gemm (bf16): y[b T_out + t][n] = sum_tap sum_c x[b T_in + t * stride + tap - pad][c] * W_tap[n][c] (+ bias[n])
  * (+ residual[row][n]); rows outside [0, T_in) count as zeros.  W_tap = w + tap * w_tap_stride (tap_rev: taps - 1 - tap), [co][ld_w] with the
  * ci input channels contiguous.  The forward and (stride 1, pad' = taps - 1 - pad, tap_rev) data-gradient passes of `_Conv1d`

@@ -633,6 +633,7 @@ struct TArgs {
   // in lines it shares with the other taps' workgroups: 41.6 against 16 us at 24 000 x 128 x (3 x 128))
   int32_t cpt, main_blocks, bias_blocks, bias_rows;
   const int32_t* shift_b;       // convolution form: per batch element, added to the row shift tap - pad, or null
+  int32_t store, pad1;          // plain form, unsplit reduction: C = (not +=) the product, plain stores (jen1_big_gemm_tn_store)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -847,7 +848,8 @@ __global__ __launch_bounds__(256, 2) void big_gemm_tn_kernel(const TArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
         if (n >= g.N) continue;
-        unsafeAtomicAdd(g.c + (size_t)n * (size_t)g.ldc + (size_t)k, acc[i][j][r] * g.alpha);
+        if (g.store) g.c[(size_t)n * (size_t)g.ldc + (size_t)k] = acc[i][j][r] * g.alpha;
+        else unsafeAtomicAdd(g.c + (size_t)n * (size_t)g.ldc + (size_t)k, acc[i][j][r] * g.alpha);
       }
     }
   }
@@ -1038,7 +1040,14 @@ static int tn_splits(int tiles, int MT) {
   return splits;
 }
 
+static int big_gemm_tn_launch(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, int store, void* stream);
 extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream) {
+  return big_gemm_tn_launch(a, b, c, M, N, K, lda, ldb, ldc, alpha, 0, stream);
+}
+extern "C" int jen1_big_gemm_tn_store(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, void* stream) {
+  return big_gemm_tn_launch(a, b, c, M, N, K, lda, ldb, ldc, alpha, 1, stream);
+}
+static int big_gemm_tn_launch(const void* a, const void* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, float alpha, int store, void* stream) {
   JEN1_CHECK(a && b && c && M >= 1 && N >= 1 && K >= 1, "big_gemm_tn: bad arguments");
   JEN1_CHECK(lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0 && K % 8 == 0, "big_gemm_tn: widths and pitches must be multiples of 8 elements");
   JEN1_CHECK((N % 128 == 0 || lda >= ((N + 127) / 128) * 128) && (K % 128 == 0 || ldb >= ((K + 127) / 128) * 128),
@@ -1050,7 +1059,8 @@ extern "C" int jen1_big_gemm_tn(const void* a, const void* b, float* c, int M, i
   g.tiles_n = (N + 127) / 128;
   g.tiles_k = (K + 127) / 128;
   const int tiles = g.tiles_n * g.tiles_k, MT = (M + 63) / 64;
-  const int splits = tn_splits(tiles, MT);
+  const int splits = store ? 1 : tn_splits(tiles, MT);      // (store: every workgroup owns its output tile; no atomics, no zero-fill before)
+  g.store = store;
   g.mt_per_split = (MT + splits - 1) / splits;
   g.splits = (MT + g.mt_per_split - 1) / g.mt_per_split;
   g.main_blocks = tiles * g.splits;

@@ -148,6 +148,7 @@ SYMBOLS = {
     "jen1_memset_zero": (c_int, [_P, c_int64, _P]),
     "jen1_big_gemm": (c_int, [C.POINTER(BGemmArgs), _P]),
     "jen1_big_gemm_tn": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "jen1_big_gemm_tn_store": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "jen1_big_gemm_conv": (c_int, [_P] * 5 + [c_int] * 13 + [_P, c_int, _P]),
     "jen1_big_gemm_tn_conv": (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [c_float, _P, _P]),
     "jen1_standardize_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),

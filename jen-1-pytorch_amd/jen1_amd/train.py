@@ -932,9 +932,9 @@ class ContextKVFn(Function):
             # the unconditional half of the CFG pair read ONE set of context rows: its batch elements' dK | dV blocks, all layers at once
             L.check(rt.lib.jen1_sum_rows_strided(dall.data_ptr() + (Bk - 1) * Nk * Ntot * 2, ctx.n_share, Nk, Ntot, Ntot, L.BF16, s), "jen1_sum_rows_strided")
         dwf, dbias = bank.dwf[: Ntot * K], bank.dwf[Ntot * K:]
-        L.check(rt.lib.jen1_memset_zero(bank.dwf.data_ptr(), bank.dwf.numel() * 4, s), "jen1_memset_zero")
+        L.check(rt.lib.jen1_memset_zero(dbias.data_ptr(), Ntot * 4, s), "jen1_memset_zero")           # (the column sums accumulate; dWf is stored)
         L.check(rt.lib.jen1_colsum(dall.data_ptr(), dbias.data_ptr(), R, Ntot, Ntot, L.BF16, s), "jen1_colsum")
-        L.check(rt.lib.jen1_big_gemm_tn(dall.data_ptr(), xhat.data_ptr(), dwf.data_ptr(), R, Ntot, K, Ntot, K, K, 1.0, s), "jen1_big_gemm_tn")
+        L.check(rt.lib.jen1_big_gemm_tn_store(dall.data_ptr(), xhat.data_ptr(), dwf.data_ptr(), R, Ntot, K, Ntot, K, K, 1.0, s), "jen1_big_gemm_tn_store")
         L.check(rt.lib.jen1_kv_fold_backward(bank.table().data_ptr(), len(bank.widths), Ntot, K, dwf.data_ptr(), dbias.data_ptr(), s), "jen1_kv_fold_backward")
         if rt.stats is not None:
             e = rt.stats.setdefault("big_gemm", [0, 0.0, 0.0])

@@ -137,6 +137,12 @@ def test_weight_gradient_tn_matches_torch(M, N, K):
     ref = c0 + 0.5 * (a_full[:, :N].float().t() @ b_full[:, :K].float())
     err = float((c - ref).abs().max() / ref.abs().max())
     assert err < 2e-5, err
+    # the store form: C = the product (unsplit reduction, plain stores); whatever C held before is overwritten
+    c2 = torch.full((N, K), float("nan"), device="cuda")
+    L.check(lib.jen1_big_gemm_tn_store(a_full.data_ptr(), b_full.data_ptr(), c2.data_ptr(), M, N, K, lda, ldb, K, 0.5,
+                                       torch.cuda.current_stream().cuda_stream), "jen1_big_gemm_tn_store")
+    torch.cuda.synchronize()
+    assert float((c2 - (ref - c0)).abs().max() / ref.abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("B,T_in,ci,co,taps,stride,pad,with_bias", [
