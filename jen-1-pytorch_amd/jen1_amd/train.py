@@ -1700,6 +1700,13 @@ class TrainGraph:
         rt, p = self.rt, self.p
         if not (rt.kv_grouped and rt.small_attn and rows is not None and rows.dim() == 3 and rows.dtype == torch.bfloat16 and rows.is_contiguous()):
             return None
+        ex = self.exchange
+        if ex is not None and ex.active:
+            # the overlapped gradient exchange sends a top-level block's slice of the flat gradient as soon as the gradient of the block's
+            # input exists (optim.GradExchange.region_ready); the stacked projection writes the norm_context / to_kv gradients of ALL blocks
+            # at the END of the backward pass, after most of those slices have left.  The pass that carries the exchange (the last of an
+            # accumulation window) therefore keeps one LayerNorm + Linear per layer; the others take the stacked form.
+            return None
         names = self._cross_attention_names()
         if not names:
             return None

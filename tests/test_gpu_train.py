@@ -1396,6 +1396,17 @@ def test_stacked_context_projection_equals_one_layernorm_and_linear_per_layer(sh
     rows = torch.tensor([False, True], device="cuda")
     graph = model.train_graph("bf16")
     rt = graph.rt
+    # a pass that carries the overlapped gradient exchange keeps the per-layer form (the stacked form finishes these gradients last,
+    # after their blocks' slices of the flat gradient have been sent: train.TrainGraph._stacked_context_kv)
+    class _Armed:
+        active = True
+    probe = torch.zeros((3, 129, 1024), dtype=torch.bfloat16, device="cuda")
+    assert graph._stacked_context_kv(probe, 4) is not None
+    graph.exchange = _Armed()
+    try:
+        assert graph._stacked_context_kv(probe, 4) is None
+    finally:
+        graph.exchange = None
     res = []
     old = (rt.kv_grouped, rt.share_fixed_context)
     try:
