@@ -967,11 +967,13 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       const float nm = ntile[i] != dummy_tile ? nscale : 0.f;           // scale of the source, 0 for vectors that do not exist
 #pragma unroll
       for (int j = 0; j < 8; ++j) xf[i][j] *= nm;
+#ifndef JEN1_DEEP_EXP_NOSUMS      // timing experiment only (results are garbage): what ANY scheme that ships the statistics with the data could save
       const float a0 = (xf[i][0] + xf[i][1]) + (xf[i][2] + xf[i][3]), a1 = (xf[i][4] + xf[i][5]) + (xf[i][6] + xf[i][7]);
       const float c0 = (xf[i][0] * xf[i][0] + xf[i][1] * xf[i][1]) + (xf[i][2] * xf[i][2] + xf[i][3] * xf[i][3]);
       const float c1 = (xf[i][4] * xf[i][4] + xf[i][5] * xf[i][5]) + (xf[i][6] * xf[i][6] + xf[i][7] * xf[i][7]);
       s += a0 + a1;
       q += c0 + c1;
+#endif
     }
     // long rows (more than MAXV vectors per lane: e.g. 36 positions x 512 channels of one batch element): the further trips are
     // summed here and read again below for the normalisation (their second read is an L2 hit)
@@ -1004,7 +1006,11 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
       }
     }
     DK_STAMPN(sy, 7);
+#ifndef JEN1_DEEP_EXP_NOSUMS
     lane_set_sum2(s, q, lS < 6 ? lS : 6);
+#else
+    s = 0.5f; q = 1.0f;
+#endif
     if (lS == 7) {
       // a group of 1024 channels (LayerNorm over the channels of ONE position, folded single-position self-attention: engine.py
       // "s1q2") is 128 columns: the pair's two waves exchange their sums through LDS and add them in a fixed order
@@ -1032,12 +1038,16 @@ __device__ __forceinline__ void gemm_unit(const unsigned char* D, int u, Sync& s
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       if (i >= nvn) continue;
+#ifndef JEN1_DEEP_EXP_NONORM      // timing experiment only (results are garbage): what a consumer would save if producers stored the normalised activation
 #pragma unroll
       for (int j = 0; j < 8; ++j) xf[i][j] = PRECISE ? (xf[i][j] - mean) * rstd * p1[j] + p2[j] : xf[i][j] * pa[j] + pb[j];
       if (silu) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) xf[i][j] = PRECISE ? silu_precise(xf[i][j]) : silu_f(xf[i][j]);
       }
+#else
+      xf[i][0] += mean + rstd + pa[0] + pb[0];
+#endif
       store8(tile + ntile[i], xf[i]);
     }
     DK_STAMPN(sy, 9);

@@ -9,6 +9,6 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   out=gpurun_out/libjen1_exp_$name.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags -Iinclude -I$CS $SRCS -o $out || { echo "$name: build failed"; continue; }
-  r=$(JEN1_LIB=$PWD/$out timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+  r=$(JEN1_LIB=$PWD/$out timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get(\"roofline\",{}); print(d[\"value\"], d[\"ms_per_step\"], \"deep launch us\", r.get(\"avg_launch_us\"), \"us/phase\", r.get(\"us_per_phase\"))")
   echo "$name [$flags]: steps/s, ms/step = $r"
 done
