@@ -422,3 +422,47 @@ def test_ctypes_mirrors_have_the_size_of_the_c_structs(tmp_path):
     subprocess.run(["gcc", f"-I{os.path.join(root, 'include')}", str(src), "-o", str(exe)], check=True)
     sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [ctypes.sizeof(L.GemmOperand), ctypes.sizeof(L.GemmArgs), ctypes.sizeof(L.RepackEntry), ctypes.sizeof(L.KvLayer)]
+
+
+def test_capture_helper_keeps_the_collector_out_of_the_window(monkeypatch):
+    """jen1_amd/graphs.py (the fix of the round-4 SIGABRT): the cyclic collector runs BEFORE the capture window, is off inside it (a dead
+    hipGraph reaching torch's ~CUDAGraph inside somebody's capture aborts the process on ROCm), and comes back afterwards -- also when the
+    recorded code raises, and only if it was on before.  Host logic only: torch.cuda.graph is replaced by a recorder."""
+    import contextlib
+    import gc
+    import torch
+    from jen1_amd import graphs
+    seen = {}
+
+    class Cycle:
+        def __init__(self):
+            self.me = self
+
+        def __del__(self):
+            seen.setdefault("collected_while_enabled", []).append(gc.isenabled())
+
+    @contextlib.contextmanager
+    def fake_graph(g, capture_error_mode=None, **kw):
+        seen["mode"], seen["inside_enabled"], seen["kw"] = capture_error_mode, gc.isenabled(), kw
+        yield
+
+    monkeypatch.setattr(torch.cuda, "graph", fake_graph)
+    assert gc.isenabled()
+    Cycle()                                               # garbage in a reference cycle, pending
+    with graphs.capture(object()):
+        assert not gc.isenabled()
+        assert seen["collected_while_enabled"] == [True]  # the pending cycle went BEFORE the window opened
+    assert gc.isenabled()
+    assert seen["mode"] == "thread_local" and seen["inside_enabled"] is False and seen["kw"] == {}
+    with pytest.raises(RuntimeError):
+        with graphs.capture(object(), pool=(0, 1)):
+            assert seen["kw"] == {"pool": (0, 1)}
+            raise RuntimeError("recorded code failed")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with graphs.capture(object()):
+            pass
+        assert not gc.isenabled()                         # it was off before: it stays off
+    finally:
+        gc.enable()
