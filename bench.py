@@ -512,15 +512,22 @@ def golden_parity(cfg, device, model_bf16=None):
     x, c = synth.latents(B, T), synth.conditioning(B, T)
     want = g["B8.y.nocfg"]
     out = {"what": "UNetCFG1d.forward, B=8, 128x1500, against the reference's output (tests/golden/full_bench.npz); max-abs/max-ref", "tol_f32": 1e-3}
+    want_cfg = g["B8.y.cfg"]
     for mode in ("f32", "bf16"):
         m = model_bf16 if (mode == "bf16" and model_bf16 is not None) else UNetCFG1d(**cfg, init_seed=1234, compute_dtype=mode, device=device)
-        y = m(dev(x, device), dev(g["B8.t"], device), embedding=dev(c["cross_attn_cond"], device), embedding_mask=dev(c["cross_attn_masks"], device),
-              embedding_scale=1.0, channels_list=[dev(c["input_concat_cond"], device)], causal=False)
+        kw = dict(embedding=dev(c["cross_attn_cond"], device), embedding_mask=dev(c["cross_attn_masks"], device),
+                  channels_list=[dev(c["input_concat_cond"], device)], causal=False)
+        y = m(dev(x, device), dev(g["B8.t"], device), embedding_scale=1.0, **kw)
         torch.cuda.synchronize()
         m.check_errors()
         out[mode] = float(f"{float(np.abs(y.cpu().numpy()[:, :, ::16] - want).max() / np.abs(want).max()):.3e}")
+        # configs[2]: the CFG pair (2B = 16) + rescale of the same inputs
+        y = m(dev(x, device), dev(g["B8.t"], device), embedding_scale=0.8, batch_cfg=True, scale_cfg=True, **kw)
+        torch.cuda.synchronize()
+        m.check_errors()
+        out[mode + " CFG pair"] = float(f"{float(np.abs(y.cpu().numpy()[:, :, ::16] - want_cfg).max() / np.abs(want_cfg).max()):.3e}")
         del m, y
-    out["ok"] = bool(out["f32"] < 1e-3)
+    out["ok"] = bool(out["f32"] < 1e-3 and out["f32 CFG pair"] < 1e-3)
     return out
 
 
