@@ -359,7 +359,7 @@ def kv_gemm_roofline(st):
     fl = sum(op.flops for op in ops)
     tf = fl / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "kernel": "big_gemm_nt256_kernel + big_gemm_nt_kernel<bf16> (LDS-DMA staged 256x256 / 128x128 tiles x 64, v_mfma_f32_32x32x16_bf16; the product is cut by columns between the two forms): " + "; ".join(op.label for op in ops),
+            "kernel": "big_gemm_nt_s4_kernel<272> (four LDS-DMA stages of 256x272 tiles x 32, v_mfma_f32_16x16x32_bf16, row-wise coalesced epilogue; 17408 = 64 x 272 columns: one round of 256 tiles): " + "; ".join(op.label for op in ops),
             "launches": len(ops), "us": round(ms * 1e3, 1), "executed_gflop": round(fl / 1e9, 2),
             "alg_bytes": int(sum(getattr(op, "bytes", 0) for op in ops)),
             "when": "once per conditioning (Plan.set_context), outside the timed region; extra.end_to_end includes it"}

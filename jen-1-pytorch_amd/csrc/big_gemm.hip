@@ -264,6 +264,74 @@ __global__ __launch_bounds__(512) void big_gemm_nt_kernel(const BArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Row-wise epilogue of the large tile forms (bf16 output, no accumulation): the finished tile goes through LDS -- the stages are free
+// behind the K loop -- and leaves as whole rows, 16 bytes per lane with consecutive lanes along a row.  Measured with the stores removed:
+// the direct form (a lane's 4 consecutive n of ONE row: 8-byte stores to 16 - 32 different rows per wave instruction) cost 17 of the
+// stacked projection's 54 us and 13 of 4096^3's 123.
+//   rowwise_tables  per 16-column block of the tile: output pointer, bias, pitch, first column inside its group, the group's width; per
+//                   tile row: the mapped output row (-1 past M) and the row scale
+//   rowwise_store   LDS tile [TM][CP bytes] -> global rows
+// ---------------------------------------------------------------------------------------------------------------------
+struct RowTab {
+  bf16_t* c;
+  const float* bias;
+  int ldc, n_first, n_lim, pad;
+};
+
+template <int TM, int NB16>
+__device__ __forceinline__ void rowwise_tables(const BArgs& g, int m0, int n0, int tid, RowTab* gt, int* orl, float* rsl) {
+  if (tid < NB16) {
+    const int nb16 = n0 + tid * 16;
+    RowTab e;
+    e.c = nullptr; e.bias = nullptr; e.ldc = 0; e.n_first = 0; e.n_lim = 0; e.pad = 0;
+    if (nb16 < g.Ntot) {
+      int gi = 0;
+      if (g.groups)
+        for (int k = 1; k < g.n_groups; ++k) gi += (nb16 >= g.groups[k].n0) ? 1 : 0;
+      const BGroup grp = g.groups ? g.groups[gi] : g.inl;
+      e.c = reinterpret_cast<bf16_t*>(grp.c); e.bias = grp.bias; e.ldc = grp.ldc; e.n_first = nb16 - grp.n0; e.n_lim = grp.N;
+    }
+    gt[tid] = e;
+  }
+  if (tid < TM) {
+    const int m = m0 + tid;
+    int orow = -1;
+    float rs = 1.0f;
+    if (m < g.M) {
+      orow = m;
+      if (g.rows_in > 0) {
+        const int q = (int)(((float)m + 0.5f) * g.inv_rows_in);
+        orow = q * g.rows_out + (m - q * g.rows_in);
+      }
+      if (g.row_scale) rs = g.row_scale[orow];
+    }
+    orl[tid] = orow;
+    rsl[tid] = rs;
+  }
+}
+
+template <int TM, int TN, int NTHR>
+__device__ __forceinline__ void rowwise_store(const unsigned char* ct, int CP, const RowTab* gt, const int* orl, int tid) {
+  constexpr int CPR = TN / 8;                         // 16-byte chunks per tile row
+  for (int ch = tid; ch < TM * CPR; ch += NTHR) {
+    const int row = ch / CPR, c8 = ch - row * CPR;
+    const int orow = orl[row];
+    if (orow < 0) continue;
+    const RowTab e = gt[c8 >> 1];
+    const int n = e.n_first + (c8 & 1) * 8;
+    if (e.c == nullptr || n >= e.n_lim) continue;
+    const uint4 val = *reinterpret_cast<const uint4*>(ct + row * CP + c8 * 16);
+    bf16_t* dst = e.c + (size_t)orow * (size_t)e.ldc + (size_t)n;
+    if (n + 8 <= e.n_lim && (((size_t)dst) & 15) == 0) {
+      *reinterpret_cast<uint4*>(dst) = val;
+    } else {                                          // ragged group end / unaligned row pitch: 8-byte halves (widths are multiples of 4 here)
+      *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
+      if (n + 4 < e.n_lim) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(val.z, val.w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // NT form, 256 x 256 output tile (bf16): 8 waves = 2 along m (128 activation rows each) x 4 along n (64 weight rows each), so a wave
 // owns 2 x 4 MFMA tiles of 32 x 32 (128 accumulator registers) and feeds 8 MFMAs from 6 fragment reads per k block -- the 64 x 64 waves
 // of the kernel above feed 4 from 4, and issue one LDS-DMA piece per 2 MFMAs where this one issues one per 4 (the two ratios
@@ -278,7 +346,7 @@ __global__ __launch_bounds__(512) void big_gemm_nt256_kernel(const BArgs g) {
   constexpr int A_B = TM * ROWB, B_B = TN * ROWB, STAGE = A_B + B_B;      // 32 KiB + 32 KiB
   constexpr int PA = TM / 8 / NWV, PB = TN / 8 / NWV;                     // 4 + 4 LDS-DMA pieces per wave and K step
   constexpr int NSA = 2, NSB = 4;                                         // MFMA tiles of a wave: weight rows (n) x activation rows (m)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 12288];      // (+12 KiB: the row-wise epilogue's output tile)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,6 +464,46 @@ __global__ __launch_bounds__(512) void big_gemm_nt256_kernel(const BArgs g) {
 #undef BG_ISSUE
 
   // ---- epilogue (as above; C/D layout 32x32: column (here m) = lane & 31, rows (here n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+  if (!g.c_f32 && !g.accumulate && (g.groups != nullptr || (g.inl.N & 3) == 0)) {      // (group widths are multiples of 128)
+    // bf16 output without accumulation: row-wise through LDS (rowwise_tables / rowwise_store above)
+    constexpr int CP = TN * 2 + 16;
+    constexpr int NB16 = TN / 16;
+    __syncthreads();
+    unsigned char* ct = smem;
+    RowTab* gt = reinterpret_cast<RowTab*>(smem + TM * CP);
+    int* orl = reinterpret_cast<int*>(smem + TM * CP + NB16 * (int)sizeof(RowTab));
+    float* rsl = reinterpret_cast<float*>(orl + TM);
+    static_assert(TM * CP + NB16 * (int)sizeof(RowTab) + TM * 8 <= 2 * STAGE + 12288, "epilogue tile must fit the LDS allocation");
+    rowwise_tables<TM, NB16>(g, m0, n0, tid, gt, orl, rsl);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NSB; ++j) {
+      const int ml = wm * (NSB * 32) + j * 32 + fi;
+      const float rs = rsl[ml];
+#pragma unroll
+      for (int i = 0; i < NSA; ++i) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int nl = wn * (NSA * 32) + i * 32 + q4 * 8 + fg * 4;
+          const RowTab e = gt[nl >> 4];
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q4 * 4 + r] * g.alpha;
+          const int nn = e.n_first + (nl & 15);
+          if (e.bias && nn < e.n_lim) {
+            const float4 bb = *reinterpret_cast<const float4*>(e.bias + nn);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= rs;
+          store4(reinterpret_cast<T*>(ct + ml * CP) + nl, v);
+        }
+      }
+    }
+    __syncthreads();
+    rowwise_store<TM, TN, NWV * 64>(ct, CP, gt, orl, tid);
+    return;
+  }
   int gi = 0;
   if (g.groups)
     for (int k = 1; k < g.n_groups; ++k) gi += (n0 >= g.groups[k].n0) ? 1 : 0;
@@ -446,6 +554,204 @@ __global__ __launch_bounds__(512) void big_gemm_nt256_kernel(const BArgs g) {
           }
           store_out(cT + off, v);
         }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NT form with FOUR LDS stages (bf16, v_mfma_f32_16x16x32_bf16): 256 x TN output tile (built for TN = 272), K step 32 (64-byte tile rows).
+// Why: with two 64 KiB stages ONE tile is in flight per CU while one is multiplied, and a K step then lasts as long as the delivery of
+// 64 KB to every CU at once (~3.3 us on the stacked projection, whatever the MFMAs do: 0.9 us) -- the 256 x 256 form above moved operands
+// at 5 - 6 TB/s where the 128 x 128 form (two workgroups per CU) reached 10.  Here a stage is 32 / 33 KiB and THREE tiles are in flight.
+// 8 waves stacked along m (32 activation rows each), every wave walks all TN / 16 weight tiles: 32 / 34 accumulators of 4 registers.
+// TN = 272: the stacked text-context projection has N = 17408 = 64 x 272 columns -- 4 x 64 = 256 tiles at B = 8: one round of one tile
+// per CU (256-wide tiles: 1.06 rounds); such a column tile may straddle two groups, so the epilogue looks the group up per 16 columns.
+// LDS image: 64-byte rows, 16-byte chunk c of row r at chunk c ^ S[(r >> 2) & 3], S = {0, 2, 3, 1}: the four 16-lane groups of a
+// ds_read_b128 (MI355X_MICROARCH.md LDS table) then hold 16 distinct (row mod 4, chunk) pairs = all 64 banks once.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TN>
+__global__ __launch_bounds__(512) void big_gemm_nt_s4_kernel(const BArgs g) {
+  typedef bf16_t T;
+  constexpr int ES = 2, BK4 = 32, RB = 64, NWV = 8, TM = 256, NST = 4;
+  constexpr int A_B = TM * RB, B_B = TN * RB, STAGE = A_B + B_B;          // 16 KiB + 16 / 17 KiB
+  constexpr int NPA = TM / 16, NPB = TN / 16, NP = NPA + NPB;             // LDS-DMA pieces of 16 rows per K step: 16 + 16 / 17
+  constexpr int NI = TN / 16, NJ = 2;
+  static_assert(NPA == 2 * NWV && NPB >= 2 * NWV && NPB <= 2 * NWV + 1, "piece distribution");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE + 16384];      // (+16 KiB: the epilogue's output tile is a little larger)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  int tn, tm;
+  {
+    const int bm = (g.tiles_m & 7) == 0 ? 8 : ((g.tiles_m & 3) == 0 ? 4 : ((g.tiles_m & 1) == 0 ? 2 : 1));
+    const int bn = 32 / bm;
+    if (g.tiles_n % bn == 0 && bm > 1) {
+      const int grp = tile >> 5, r = tile & 31;
+      const int gpm = g.tiles_m / bm;
+      const int gn_ = grp / gpm, gm_ = grp - gn_ * gpm;
+      tm = gm_ * bm + (r % bm);
+      tn = gn_ * bn + (r / bm);
+    } else {
+      tn = tile / g.tiles_m;
+      tm = tile - tn * g.tiles_m;
+    }
+  }
+  const int m0 = tm * TM, n0 = g.n_begin + tn * TN;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.a) + (size_t)m0 * (size_t)g.lda * ES), 0,
+      (int)((size_t)((g.M - m0) < TM ? (g.M - m0) : TM) * (size_t)g.lda * ES), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.b) + (size_t)n0 * (size_t)g.ldb * ES), 0,
+      (int)((size_t)((g.Ntot - n0) < TN ? (g.Ntot - n0) : TN) * (size_t)g.ldb * ES), RSRC_FLAGS);
+  // wave w: activation pieces w and w + 8, weight pieces w and w + 8 (+ weight piece 16 for wave 0 when TN = 272); lane l of a piece lands at
+  // row l >> 2, physical chunk l & 3 and fetches the global chunk (l & 3) ^ S[(row >> 2) & 3]
+  const unsigned sw4 = 0x1320u;                                            // S[k] = (sw4 >> (4 k)) & 3  ->  {0, 2, 3, 1}
+  unsigned vo[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int pc = j < 2 ? w + NWV * j : (j < 4 ? w + NWV * (j - 2) : 2 * NWV);
+    const bool isb = j >= 2;
+    const int row = pc * 16 + (lane >> 2);
+    const unsigned sx = (sw4 >> (4 * ((row >> 2) & 3))) & 3u;
+    vo[j] = (unsigned)row * (unsigned)((isb ? g.ldb : g.lda) * ES) + (((unsigned)(lane & 3)) ^ sx) * 16u;
+  }
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const lds0 = (lds_u8*)smem;
+  const bool extra = (NPB > 2 * NWV) && w == 0;
+#define S4_ISSUE(stage_, kt_)                                                                                                        \
+  do {                                                                                                                               \
+    const unsigned so_ = (unsigned)(kt_) * (unsigned)RB;                                                                             \
+    lds_u8* const sb_ = lds0 + (stage_) * STAGE + w * 1024;                                                                          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_), 16, vo[0], so_, 0, 0);                                             \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sb_ + NWV * 1024), 16, vo[1], so_, 0, 0);                                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B), 16, vo[2], so_, 0, 0);                                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B + NWV * 1024), 16, vo[3], so_, 0, 0);                          \
+    if (extra) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb_ + A_B + 2 * NWV * 1024), 16, vo[4], so_, 0, 0);          \
+  } while (0)
+
+  const int fi = lane & 15, fg = lane >> 4;
+  const unsigned xo = (((unsigned)fg) ^ ((sw4 >> (4 * ((fi >> 2) & 3))) & 3u)) * 16u;      // (tile bases are multiples of 16 rows)
+  const unsigned fa = (unsigned)fi * RB + A_B + xo;                        // weight tile i: + i * 16 rows
+  const unsigned fb = (unsigned)(w * 32 + fi) * RB + xo;                   // activation tile j: + j * 16 rows
+
+  f32x4 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int KT = g.K / BK4;
+  S4_ISSUE(0, 0);
+  if (KT > 1) S4_ISSUE(1, 1);
+  if (KT > 2) S4_ISSUE(2, 2);
+  for (int kt = 0; kt < KT; ++kt) {
+    // this wave's pieces of tile kt have landed; the (up to two) later tiles may still fly: 4 pieces each (5 for wave 0 at TN = 272)
+    const int later = KT - 1 - kt;
+    if (later >= 2) { if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (later == 1) { if (extra) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                          // everybody's pieces; every wave has left step kt - 1
+    if (kt + 3 < KT) S4_ISSUE((kt + 3) & 3, kt + 3);                       // into the stage step kt - 1 read
+    const unsigned char* base = smem + (kt & 3) * STAGE;
+    u32x4 xb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xb[j] = *reinterpret_cast<const u32x4*>(base + fb + j * 16 * RB);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const u32x4 wa = *reinterpret_cast<const u32x4*>(base + fa + i * 16 * RB);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xb[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+#undef S4_ISSUE
+
+  // ---- epilogue, bf16 output without accumulation: row-wise through LDS (rowwise_tables / rowwise_store above) ------------------------
+  constexpr int CP = TN * 2 + 16;                     // bytes of a tile row in LDS (+16: the 16 rows of a store instruction hit 16 bank groups)
+  if (!g.c_f32 && !g.accumulate && (g.groups != nullptr || (g.inl.N & 3) == 0)) {      // (group widths are multiples of 128)
+    __syncthreads();                                  // every wave has left the K loop: the stages are free
+    unsigned char* ct = smem;
+    RowTab* gt = reinterpret_cast<RowTab*>(smem + TM * CP);
+    int* orl = reinterpret_cast<int*>(smem + TM * CP + NI * (int)sizeof(RowTab));
+    float* rsl = reinterpret_cast<float*>(orl + TM);
+    static_assert(TM * CP + NI * (int)sizeof(RowTab) + TM * 8 <= NST * STAGE + 16384, "epilogue tile must fit the LDS allocation");
+    rowwise_tables<TM, NI>(g, m0, n0, tid, gt, orl, rsl);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int ml = w * 32 + j * 16 + fi;
+      const float rs = rsl[ml];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const RowTab e = gt[i];
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
+        const int nn = e.n_first + fg * 4;
+        if (e.bias && nn < e.n_lim) {
+          const float4 bb = *reinterpret_cast<const float4*>(e.bias + nn);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rs;
+        store4(reinterpret_cast<T*>(ct + ml * CP) + i * 16 + fg * 4, v);
+      }
+    }
+    __syncthreads();
+    rowwise_store<TM, TN, NWV * 64>(ct, CP, gt, orl, tid);
+    return;
+  }
+  // ---- epilogue: C/D layout 16x16: column (here m) = lane & 15, rows (here n) = 4 (lane >> 4) + r ---------------------------------
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int m = m0 + w * 32 + j * 16 + fi;
+    if (m >= g.M) continue;
+    int orow = m;
+    if (g.rows_in > 0) {
+      const int q = (int)(((float)m + 0.5f) * g.inv_rows_in);
+      orow = q * g.rows_out + (m - q * g.rows_in);
+    }
+    const float rs = g.row_scale ? g.row_scale[orow] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int nb16 = n0 + i * 16;                                        // first column of this 16-column block (inside ONE group)
+      if (nb16 >= g.Ntot) continue;
+      int gi = 0;
+      if (g.groups)
+        for (int k = 1; k < g.n_groups; ++k) gi += (nb16 >= g.groups[k].n0) ? 1 : 0;
+      const BGroup grp = g.groups ? g.groups[gi] : g.inl;
+      const int n = nb16 + fg * 4 - grp.n0;
+      if (n >= grp.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
+      if (grp.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(grp.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= rs;
+      const size_t off = (size_t)orow * (size_t)grp.ldc + (size_t)n;
+      if (g.c_f32) {
+        float* cF = reinterpret_cast<float*>(grp.c);
+        if (g.accumulate) {
+          float o[4];
+          load4(cF + off, o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += o[r];
+        }
+        store_out(cF + off, v);
+      } else {
+        T* cT = reinterpret_cast<T*>(grp.c);
+        if (g.accumulate) {
+          float o[4];
+          load4(cT + off, o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += o[r];
+        }
+        store_out(cT + off, v);
       }
     }
   }
@@ -964,6 +1270,29 @@ extern "C" int jen1_big_gemm(const jen1_bgemm_args* a, void* stream) {
       if (tail > 0 && tail * 4 < n_cu * 3 && rounds >= 1) tn_big = (rounds * n_cu) / tm;
       n_big = tn_big >= tn_all ? a->Ntot : tn_big * 256;
       if (g.n_groups > 1 && n_big < a->Ntot && n_big % a->group_align != 0) n_big -= n_big % a->group_align;      // (cut on a group boundary multiple)
+    }
+  }
+  {
+    // the four-stage form (big_gemm_nt_s4_kernel<272>): column counts that are multiples of 272 when that tiling fills its rounds of one
+    // tile per CU better than 256-wide tiles (the stacked projection, M = 1024: 256 tiles = exactly one round against 272 = 1.06: 54 -> 47 us;
+    // the 256-wide instance of the same kernel measured slower than the two-stage 32 x 32 form everywhere and is not built).
+    // JEN1_BGEMM_S4 = 0: never; 272: whenever the shape allows (tuning / parity tests)
+    const char* es4 = getenv("JEN1_BGEMM_S4");
+    const int force_s4 = es4 ? atoi(es4) : -1;
+    if (a->dtype == JEN1_BF16 && !force_wm && force_s4 != 0 && force_t256 != 1 && a->K >= 32 && a->K % 32 == 0 && a->Ntot % 272 == 0 &&
+        (g.n_groups == 1 || (a->group_align >= 16 && a->group_align % 16 == 0))) {
+      const int tm = (a->M + 255) / 256;
+      const long long t272 = (long long)tm * (a->Ntot / 272), t256 = (long long)tm * ((a->Ntot + 255) / 256);
+      // rounds of one tile per CU x tile width: which tiling fills the chip better
+      const double c272 = (double)((t272 + n_cu - 1) / n_cu) * 272.0, c256 = (double)((t256 + n_cu - 1) / n_cu) * 256.0;
+      if (force_s4 == 272 || (t272 >= (n_cu * 3) / 4 && c272 < c256 && a->K >= 512)) {
+        BArgs gc = g;
+        gc.tiles_m = tm;
+        gc.tiles_n = a->Ntot / 272;
+        hipLaunchKernelGGL(big_gemm_nt_s4_kernel<272>, dim3(gc.tiles_m * gc.tiles_n), dim3(512), 0, s, gc);
+        JEN1_HIP(hipGetLastError());
+        return 0;
+      }
     }
   }
   if (n_big > 0) {

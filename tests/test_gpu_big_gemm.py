@@ -423,3 +423,54 @@ def test_stacked_projection_splits_between_the_two_tile_forms(B):
         got = cache[:, :NL].reshape(B * NL, wd).float()
         assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2, (n0, wd)
         assert bool((cache[:, NL] == -3.0).all())          # the time token's row is not this launch's
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the four-stage forms (big_gemm_nt_s4_kernel<256 / 272>): K step 32, three tiles in flight, 16 x 16 x 32 MFMA, 64-byte-row swizzle
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tnw,M,N,K", [(272, 1024, 544, 512), (272, 300, 272, 128), (272, 257, 816, 64), (272, 1, 272, 64), (272, 515, 1088, 192)])
+def test_four_stage_form_forced_matches_torch(monkeypatch, tnw, M, N, K):
+    """K-step counts around the pipeline depth (2, 4, 6, 16 steps of 32), ragged M, one to four column tiles"""
+    monkeypatch.setenv("JEN1_BGEMM_S4", str(tnw))
+    gen = torch.Generator(device="cuda").manual_seed(M * 5 + N + K + tnw)
+    a = (torch.randn((M, K), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    b = (torch.randn((N, K), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    guard = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    c = guard[:M]
+    _run(a, b, [(c, None, 0, N)])
+    ref = a.float() @ b.float().t()
+    assert float((c.float() - ref).abs().max() / ref.abs().max()) < 1e-2
+    assert bool((guard[M:] == 7.0).all())
+    monkeypatch.setenv("JEN1_BGEMM_S4", "0")
+    c2 = torch.empty_like(c)
+    _run(a, b, [(c2, None, 0, N)])
+    assert float((c.float() - c2.float()).abs().max() / ref.abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("force", ["auto", "0"])
+def test_stacked_projection_on_the_272_column_tiles(monkeypatch, force):
+    """B = 8: 4 x 64 tiles of 256 x 272 = one round of one tile per CU (chosen automatically); the column tiles straddle the 13 groups
+    (layer widths 512 / 1024 / 2048 are no multiples of 272): the epilogue finds the group of every 16-column block.  Same result as the
+    other forms; row map, padding mask, bias, the untouched 129th row as in the sampling plan."""
+    if force != "auto":
+        monkeypatch.setenv("JEN1_BGEMM_S4", force)
+    B, NL, K = 8, 128, 1024
+    widths = [512] * 2 + [1024] * 7 + [2048] * 4
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    xs = (torch.randn((B * NL, K), device="cuda", generator=gen)).to(torch.bfloat16)
+    w = (torch.randn((sum(widths), K), device="cuda", generator=gen) * 0.05).to(torch.bfloat16)
+    mask_b = (torch.rand((B, NL + 1), device="cuda", generator=gen) > 0.3).float()
+    mask = mask_b[:, :NL].reshape(-1)
+    outs, groups, n0 = [], [], 0
+    for wd in widths:
+        cache = torch.full((B, NL + 1, wd), -3.0, device="cuda", dtype=torch.bfloat16)
+        bias = torch.randn((wd,), device="cuda", generator=gen)
+        outs.append((cache, bias, n0, wd))
+        groups.append((cache.view(B * (NL + 1), wd), bias, n0, wd))
+        n0 += wd
+    _run(xs, w, groups, row_scale=mask_b, rows_in=NL, rows_out=NL + 1, group_align=256)
+    for cache, bias, n0, wd in outs:
+        ref = (xs.float() @ w[n0:n0 + wd].float().t() + bias[None]) * mask[:, None]
+        got = cache[:, :NL].reshape(B * NL, wd).float()
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2, (n0, wd)
+        assert bool((cache[:, NL] == -3.0).all())

@@ -52,13 +52,19 @@ for (M, N, K, label) in [(2064, 2048, 1024, "to_kv fwd C=1024 (2B*129 rows)"), (
         torch.matmul(a, b.t(), out=c)
     t_own, t_blas = graph_us(own), graph_us(blas)
     forms = {}
+    os.environ["JEN1_BGEMM_S4"] = "0"
     for form in ("0", "1"):                 # 128 x 128 / 256 x 128 only; 256 x 256 tiles forced (auto: the dispatcher's choice, above)
         os.environ["JEN1_BGEMM_T256"] = form
         forms[form] = graph_us(own)
     del os.environ["JEN1_BGEMM_T256"]
+    forms["272"] = float("nan")
+    if N % 272 == 0:                        # the four-stage 256 x 272 form
+        os.environ["JEN1_BGEMM_S4"] = "272"
+        forms["272"] = graph_us(own)
+    del os.environ["JEN1_BGEMM_S4"]
     fl = 2.0 * M * N * K
     print(f"{label:40s} M={M:5d} N={N:5d} K={K:5d}  own {t_own:8.1f} us = {fl / t_own / 1e6:7.1f} TF/s ({fl / t_own / 1e6 / 2500 * 100:4.1f} % of peak)   "
-          f"[small tiles only {forms['0']:7.1f} us, 256x256 only {forms['1']:7.1f} us]   hipBLASLt {t_blas:8.1f} us = {fl / t_blas / 1e6:7.1f} TF/s", flush=True)
+          f"[small tiles only {forms['0']:7.1f} us, 256x256 only {forms['1']:7.1f}, 4-stage 256x272 {forms['272']:7.1f}]   hipBLASLt {t_blas:8.1f} us = {fl / t_blas / 1e6:7.1f} TF/s", flush=True)
 
 for (M, N, K, label) in [(2064, 2048, 1024, "to_kv wgrad C=1024"), (2064, 1024, 1024, "to_kv wgrad C=512"), (2064, 512, 1024, "to_kv wgrad C=256")]:
     a = (torch.randn((M, N), device="cuda") * 0.5).to(torch.bfloat16)
