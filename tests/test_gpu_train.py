@@ -1036,7 +1036,9 @@ def test_fused_repack_equals_per_tensor_copies(mode):
     rt = TR.TrainRuntime(mode, "cuda")
     torch.manual_seed(5)
     ws = [(torch.randn((48, 36, 3), device="cuda"), "conv"), (torch.randn((40, 70, 5), device="cuda"), "convT"),
-          (torch.randn((100, 52), device="cuda"), "linear"), (torch.randn((33, 129, 9), device="cuda"), "conv")]
+          (torch.randn((100, 52), device="cuda"), "linear"), (torch.randn((33, 129, 9), device="cuda"), "conv"),
+          (torch.randn((1000, 776, 3), device="cuda"), "conv"), (torch.randn((264, 520, 4), device="cuda"), "convT"),
+          (torch.randn((24, 40, 11), device="cuda"), "conv")]     # thousands of tiles; 4 and 11 taps
     keys = []
     for w, kind in ws:
         for k in (kind, kind + "D"):
