@@ -123,6 +123,15 @@ int jen1_ln_backward(const void* dy, const void* x, const float* stats, const fl
  * embedding, blocks.py:426): only dgamma / dbeta are accumulated. */
 int jen1_ln_backward_add(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, const void* dx_add,
                          float* dgamma, float* dbeta, int rows, int C, int ld, int dtype, void* stream);
+/* Two LayerNorms of ONE input in one launch (self-attention: ``norm`` for to_q and ``norm_context`` for to_kv over the same x,
+ * blocks.py:427-429 with context = x): y1 = LN(x; gamma1, beta1), y2 = LN(x; gamma2, beta2), one (mean, rstd) pair per row.  Backward:
+ * dx = LN'(dy1 gamma1 + dy2 gamma2) (+ dx_add), the four parameter gradients accumulate.  Rows of a multiple of 8 channels, C <= 1024,
+ * 16-byte aligned tensors (callers fall back to two jen1_ln_forward / jen1_ln_backward_add launches otherwise). */
+int jen1_ln2_forward(const void* x, const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, void* y1, void* y2,
+                     float* stats, int rows, int C, int ld, float eps, int dtype, void* stream);
+int jen1_ln2_backward_add(const void* dy1, const void* dy2, const void* x, const float* stats, const float* gamma1, const float* gamma2,
+                          void* dx, const void* dx_add, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, int rows, int C,
+                          int ld, int dtype, void* stream);
 
 /* --- pointwise activations: mode 0 GELU(erf) (blocks.py:443, model.py:77-89), 1 SiLU (blocks.py:158),
  *     2 ELU(alpha = 1) (the SEANet decoder behind generation.py:130) --- */

@@ -885,6 +885,165 @@ __global__ __launch_bounds__(NTB) void ln_bwd_vec_kernel(const void* dy_, const 
   }
 }
 
+// ---- two LayerNorms of ONE input in one launch: self-attention normalises x twice, ``norm`` for to_q and ``norm_context`` for to_kv
+// (blocks.py:427-429 with context = x): the statistics are shared, only (gamma, beta) differ.  Backward: both branches are linear in
+// the standardised row, so dx is ONE LayerNorm backward of the upstream sum g = dy1 gamma1 + dy2 gamma2; four column sums.
+constexpr int LN2_MAXV = 2;       // 8-channel vectors per lane: C <= 1024
+template <typename T>
+__global__ __launch_bounds__(NT) void ln2_fwd_vec_kernel(const void* x_, const float* __restrict__ g1, const float* __restrict__ b1,
+                                                          const float* __restrict__ g2, const float* __restrict__ b2, void* y1_, void* y2_,
+                                                          float* __restrict__ stats, int rows, int C, int ld, float eps) {
+  const T* x = reinterpret_cast<const T*>(x_);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C >> 3;
+  const T* xr = x + (long long)row * ld;
+  float v[LN2_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN2_MAXV; ++j) {
+    const int vi = lane + 64 * j;
+    if (vi < nvec) {
+      load8(xr + vi * 8, v[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[j][e];
+    }
+  }
+  s = wave_sum(s);
+  const float mean = s / C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN2_MAXV; ++j) {
+    if (lane + 64 * j < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; q += d * d; }
+    }
+  }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / C + eps);
+  T* y1 = reinterpret_cast<T*>(y1_) + (long long)row * ld;
+  T* y2 = reinterpret_cast<T*>(y2_) + (long long)row * ld;
+#pragma unroll
+  for (int j = 0; j < LN2_MAXV; ++j) {
+    const int vi = lane + 64 * j;
+    if (vi < nvec) {
+      float ga[8], be[8], o[8];
+      load8(g1 + vi * 8, ga);
+      load8(b1 + vi * 8, be);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[j][e] = (v[j][e] - mean) * rstd; o[e] = v[j][e] * ga[e] + be[e]; }
+      store8(y1 + vi * 8, o);
+      load8(g2 + vi * 8, ga);
+      load8(b2 + vi * 8, be);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = v[j][e] * ga[e] + be[e];
+      store8(y2 + vi * 8, o);
+    }
+  }
+  if (lane == 0) { stats[2 * (long long)row] = mean; stats[2 * (long long)row + 1] = rstd; }
+}
+
+template <typename T, int NTB>
+__global__ __launch_bounds__(NTB) void ln2_bwd_vec_kernel(const void* dy1_, const void* dy2_, const void* x_, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma1, const float* __restrict__ gamma2, void* dx_,
+                                                           const void* add_, float* __restrict__ dgamma1, float* __restrict__ dbeta1,
+                                                           float* __restrict__ dgamma2, float* __restrict__ dbeta2, int rows, int C, int ld) {
+  extern __shared__ float ln_col[];            // [NTB / 64 - 1][4][C]
+  const T* dy1 = reinterpret_cast<const T*>(dy1_);
+  const T* dy2 = reinterpret_cast<const T*>(dy2_);
+  const T* x = reinterpret_cast<const T*>(x_);
+  T* dx = reinterpret_cast<T*>(dx_);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wid = blockIdx.x * (NTB / 64) + w, nw = gridDim.x * (NTB / 64);
+  const int nvec = C >> 3;
+  float ac[4][LN2_MAXV][8], gv1[LN2_MAXV][8], gv2[LN2_MAXV][8];      // column sums: dgamma1, dbeta1, dgamma2, dbeta2
+#pragma unroll
+  for (int j = 0; j < LN2_MAXV; ++j) {
+    const int v = lane + 64 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ac[0][j][e] = ac[1][j][e] = ac[2][j][e] = ac[3][j][e] = 0.f; gv1[j][e] = gv2[j][e] = 0.f; }
+    if (v < nvec) { load8(gamma1 + v * 8, gv1[j]); load8(gamma2 + v * 8, gv2[j]); }
+  }
+  const float inv_C = 1.0f / (float)C;
+  for (int row = wid; row < rows; row += nw) {
+    const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
+    const long long ro = (long long)row * ld;
+    float xh[LN2_MAXV][8], dh[LN2_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN2_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        float d1[8], d2[8];
+        load8(x + ro + v * 8, xh[j]);
+        load8(dy1 + ro + v * 8, d1);
+        load8(dy2 + ro + v * 8, d2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[j][e] = (xh[j][e] - mean) * rstd;
+          dh[j][e] = d1[e] * gv1[j][e] + d2[e] * gv2[j][e];
+          s1 += dh[j][e];
+          s2 += dh[j][e] * xh[j][e];
+          ac[0][j][e] += d1[e] * xh[j][e];
+          ac[1][j][e] += d1[e];
+          ac[2][j][e] += d2[e] * xh[j][e];
+          ac[3][j][e] += d2[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    s1 *= inv_C; s2 *= inv_C;
+#pragma unroll
+    for (int j = 0; j < LN2_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = rstd * (dh[j][e] - s1 - xh[j][e] * s2);
+        if (add_ != nullptr) {
+          float ad[8];
+          load8(reinterpret_cast<const T*>(add_) + ro + v * 8, ad);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] += ad[e];
+        }
+        store8(dx + ro + v * 8, o8);
+      }
+    }
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int j = 0; j < LN2_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store8(ln_col + ((w - 1) * 4 + k) * C + v * 8, ac[k][j]);
+      }
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    float* outs[4] = {dgamma1, dbeta1, dgamma2, dbeta2};
+#pragma unroll
+    for (int j = 0; j < LN2_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          for (int ww = 0; ww < NTB / 64 - 1; ++ww) {
+            float a8[8];
+            load8(ln_col + (ww * 4 + k) * C + v * 8, a8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ac[k][j][e] += a8[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) atomicAdd(outs[k] + v * 8 + e, ac[k][j][e]);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- pointwise
 template <typename T>
 __global__ __launch_bounds__(NT) void act_fwd_kernel(const void* x_, void* y_, long long n, int mode) {
@@ -1259,6 +1418,38 @@ extern "C" int jen1_ln_backward_add(const void* dy, const void* x, const float* 
   const size_t lds = (size_t)3 * 2 * C * sizeof(float);
   if (dtype == JEN1_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
   else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy, x, stats, gamma, dx, dx_add, dgamma, dbeta, rows, C, ld);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_ln2_forward(const void* x, const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, void* y1,
+                                void* y2, float* stats, int rows, int C, int ld, float eps, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_ln2_forward")) return 1;
+  JEN1_CHECK(x && gamma1 && beta1 && gamma2 && beta2 && y1 && y2 && stats, "jen1_ln2_forward: NULL argument");
+  JEN1_CHECK(rows >= 1 && C >= 8 && ld >= C && (C & 7) == 0 && (ld & 7) == 0 && C <= 512 * LN2_MAXV,
+             "jen1_ln2_forward: rows of a multiple of 8 channels, C <= %d (rows=%d C=%d ld=%d)", 512 * LN2_MAXV, rows, C, ld);
+  JEN1_CHECK((((uintptr_t)x | (uintptr_t)y1 | (uintptr_t)y2 | (uintptr_t)gamma1 | (uintptr_t)beta1 | (uintptr_t)gamma2 | (uintptr_t)beta2) & 15) == 0,
+             "jen1_ln2_forward: 16-byte aligned tensors");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH(dtype, ln2_fwd_vec_kernel, dim3((rows + 3) / 4), x, gamma1, beta1, gamma2, beta2, y1, y2, stats, rows, C, ld, eps);
+  return 0;
+}
+
+extern "C" int jen1_ln2_backward_add(const void* dy1, const void* dy2, const void* x, const float* stats, const float* gamma1,
+                                     const float* gamma2, void* dx, const void* dx_add, float* dgamma1, float* dbeta1, float* dgamma2,
+                                     float* dbeta2, int rows, int C, int ld, int dtype, void* stream) {
+  if (check_dtype(dtype, "jen1_ln2_backward_add")) return 1;
+  JEN1_CHECK(dy1 && dy2 && x && stats && gamma1 && gamma2 && dx && dgamma1 && dbeta1 && dgamma2 && dbeta2, "jen1_ln2_backward_add: NULL argument");
+  JEN1_CHECK(rows >= 1 && C >= 8 && ld >= C && (C & 7) == 0 && (ld & 7) == 0 && C <= 512 * LN2_MAXV,
+             "jen1_ln2_backward_add: rows of a multiple of 8 channels, C <= %d (rows=%d C=%d ld=%d)", 512 * LN2_MAXV, rows, C, ld);
+  JEN1_CHECK((((uintptr_t)dy1 | (uintptr_t)dy2 | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)gamma1 | (uintptr_t)gamma2) & 15) == 0,
+             "jen1_ln2_backward_add: 16-byte aligned tensors");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int blocks = (rows + 3) / 4;
+  if (blocks > 32) blocks = 32;
+  const size_t lds = (size_t)3 * 4 * C * sizeof(float);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL((ln2_bwd_vec_kernel<float, 256>), dim3(blocks), dim3(256), lds, s, dy1, dy2, x, stats, gamma1, gamma2, dx, dx_add, dgamma1, dbeta1, dgamma2, dbeta2, rows, C, ld);
+  else hipLaunchKernelGGL((ln2_bwd_vec_kernel<bf16_t, 256>), dim3(blocks), dim3(256), lds, s, dy1, dy2, x, stats, gamma1, gamma2, dx, dx_add, dgamma1, dbeta1, dgamma2, dbeta2, rows, C, ld);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

@@ -167,6 +167,8 @@ SYMBOLS = {
     "jen1_gn_backward_add": (c_int, [_P] * 6 + [c_int] + [_P] * 7 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_gn_backward_add2": (c_int, [_P] * 6 + [c_int] + [_P] * 8 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "jen1_ln_backward_add": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
+    "jen1_ln2_forward": (c_int, [_P] * 8 + [c_int] * 3 + [C.c_float, c_int, _P]),
+    "jen1_ln2_backward_add": (c_int, [_P] * 12 + [c_int] * 4 + [_P]),
     "jen1_repack": (c_int, [_P, c_int, c_int, c_int, _P]),
     "jen1_kv_fold": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "jen1_kv_fold_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),

@@ -85,6 +85,7 @@ class TrainRuntime:
         self._consts: Dict[tuple, torch.Tensor] = {}
         self.stats: Optional[dict] = None        # {"family": [launches, flops, algorithmic bytes]} while a counting pass runs (bench.py)
         self.skinny_gemm = os.environ.get("JEN1_TRAIN_SKINNY", "1") == "1"
+        self.dual_norms = os.environ.get("JEN1_TRAIN_DUAL_NORMS", "1") == "1"          # self-attention's two LayerNorms of x in one launch
         self.fused_repack = os.environ.get("JEN1_TRAIN_FUSED_REPACK", "1") == "1"      # every compute copy in one launch (jen1_repack)
         self.repack_twins = os.environ.get("JEN1_TRAIN_REPACK_TWINS", "1") == "1"      # ... a weight's two copies from one read of it
         self._repack_tab, self._repack_meta, self._repack_n = None, (0, 0), -1
@@ -1192,6 +1193,44 @@ class LayerNormFn(Function):
         return dx, None, None, None, None, None, None
 
 
+class DualLayerNormFn(Function):
+    """(LN(x; gamma1, beta1), LN(x; gamma2, beta2), alias of x) in one launch each way -- self-attention's ``norm`` and ``norm_context``
+    over the same x (blocks.py:427-429 with context = x): shared statistics; the backward is ONE LayerNorm backward of
+    dy1 gamma1 + dy2 gamma2 with the residual branch's gradient added in the kernel (jen1_ln2_forward / jen1_ln2_backward_add)"""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, g2, b2, rt: TrainRuntime, eps: float):
+        assert x.is_contiguous()
+        C = ld = x.shape[-1]
+        rows = x.numel() // ld
+        y1, y2 = torch.empty_like(x), torch.empty_like(x)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        L.check(rt.lib.jen1_ln2_forward(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr(), y1.data_ptr(), y2.data_ptr(),
+                                        stats.data_ptr(), rows, C, ld, float(eps), rt.dt_of(x), rt.stream()), "jen1_ln2_forward")
+        ctx.rt, ctx.params = rt, (g1, b1, g2, b2)
+        ctx.save_for_backward(x, stats)
+        ctx.set_materialize_grads(False)
+        return y1, y2, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy1, dy2, dskip=None):
+        x, stats = ctx.saved_tensors
+        rt = ctx.rt
+        g1, b1, g2, b2 = ctx.params
+        dy1 = torch.zeros_like(x) if dy1 is None else dy1.contiguous()
+        dy2 = torch.zeros_like(x) if dy2 is None else dy2.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            assert dskip.shape == x.shape and dskip.dtype == x.dtype
+        C = ld = x.shape[-1]
+        dx = torch.empty_like(x)
+        L.check(rt.lib.jen1_ln2_backward_add(dy1.data_ptr(), dy2.data_ptr(), x.data_ptr(), stats.data_ptr(), g1.data_ptr(), g2.data_ptr(),
+                                             dx.data_ptr(), None if dskip is None else dskip.data_ptr(), rt.grad_of(g1).data_ptr(),
+                                             rt.grad_of(b1).data_ptr(), rt.grad_of(g2).data_ptr(), rt.grad_of(b2).data_ptr(),
+                                             x.numel() // ld, C, ld, rt.dt_of(x), rt.stream()), "jen1_ln2_backward_add")
+        return dx, None, None, None, None, None, None
+
+
 def layer_norm(rt, x, gamma, beta, eps: float = 1e-5, fork: bool = False):
     """``fork``: -> (norm(x), x) with the two gradients of x merged inside the backward kernel (LayerNormFn.forward)"""
     if fork and (not x.is_contiguous() or x.shape[-1] != gamma.shape[0]):
@@ -1632,7 +1671,13 @@ class TrainGraph:
         # x feeds the norm(s) AND (as ``residual``) the sum after to_out: forked through the LayerNorms, so its gradients meet
         # inside their backward kernels instead of in accumulation launches
         fork = rt.fork_norms and residual is x and x.requires_grad
-        if fork:
+        if (fork and pre is None and context is None and rt.dual_norms and x.is_contiguous() and x.shape[-1] == p[f"{n}.norm.weight"].shape[0]
+                and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024):
+            # self-attention: both LayerNorms of x in one launch (forward and backward)
+            xn, cn, x = DualLayerNormFn.apply(x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"], p[f"{n}.norm_context.weight"],
+                                              p[f"{n}.norm_context.bias"], rt, 1e-5)
+            residual = x
+        elif fork:
             xn, x = layer_norm(rt, x, p[f"{n}.norm.weight"], p[f"{n}.norm.bias"], fork=True)
             if pre is not None:
                 cn = None

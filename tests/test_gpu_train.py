@@ -1187,6 +1187,37 @@ def test_forked_layers_merge_the_gradient_of_the_branch_around_them(rts, mode, o
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("rows,C", [(384, 1024), (192, 512), (48, 256), (5, 72), (1, 8)])
+def test_dual_layer_norm_equals_two_layer_norms(rts, mode, rows, C):
+    """DualLayerNormFn (self-attention's norm / norm_context of the same x, blocks.py:427-429): both outputs, the merged input gradient
+    (two branches + the alias of x around the sub-block) and the four parameter gradients against float64 autograd of two F.layer_norm"""
+    from jen1_amd import train as TR
+    rt = rts[mode]
+    gen = torch.Generator(device="cuda").manual_seed(rows * 7 + C)
+    x0 = (torch.randn(rows, C, device="cuda", generator=gen) * 1.5 + 0.3).to(rt.tdtype)
+    ws = [torch.randn(rows, C, device="cuda", generator=gen).to(rt.tdtype) for _ in range(3)]
+    ps = [torch.nn.Parameter(torch.rand(C, device="cuda", generator=gen) + 0.5) if i % 2 == 0 else
+          torch.nn.Parameter(torch.randn(C, device="cuda", generator=gen)) for i in range(4)]
+    rt.invalidate()
+    x = x0.clone().requires_grad_()
+    y1, y2, xa = TR.DualLayerNormFn.apply(x, *ps, rt, 1e-5)
+    ((y1 * ws[0]).float().sum() + (y2 * ws[1]).float().sum() + (xa * ws[2]).float().sum()).backward()
+    torch.cuda.synchronize()
+    xr = x0.double().requires_grad_()
+    pr = [p_.detach().double().requires_grad_() for p_ in ps]
+    r1 = torch.nn.functional.layer_norm(xr, (C,), pr[0], pr[1], 1e-5)
+    r2 = torch.nn.functional.layer_norm(xr, (C,), pr[2], pr[3], 1e-5)
+    ((r1 * ws[0].double()).sum() + (r2 * ws[1].double()).sum() + (xr * ws[2].double()).sum()).backward()
+    tol = 2e-6 if mode == "f32" else 1.5e-2
+    rel = lambda a, b: float((a.double() - b).abs().max()) / max(float(b.abs().max()), 1e-30)   # noqa: E731
+    assert rel(y1, r1.detach()) <= tol and rel(y2, r2.detach()) <= tol
+    assert rel(x.grad, xr.grad) <= tol
+    for p_, q_ in zip(ps, pr):
+        assert rel(p_.grad, q_.grad) <= (2e-5 if mode == "f32" else 1.5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("rows,C", [(2080, 1024), (48, 512), (7, 64)])
 def test_layer_norm_backward_without_input_gradient(rts, mode, rows, C):
     """norm_context over the text embedding (blocks.py:426): the input needs no gradient, jen1_ln_backward_add runs with dx = NULL and
