@@ -35,9 +35,9 @@ class UnifiedMultiTaskTrainer:
                                 cross_attn_cond_ids=['prompt'], global_cond_ids=[], input_concat_ids=['masked_input', 'mask'])
 
     What each argument means here:
-      config        read for ``tasks``, ``device``, ``num_epoch``, ``eval_interval``, ``save_dir``, ``diffusion_type`` and
+      config        read for ``tasks``, ``device``, ``num_epoch``, ``diffusion_type`` and
                     ``optimizer_config.lr`` (utils/config.py:84-100; ``jen1_amd.config.TrainConfig`` has the same fields)
-      rank          rank 0 logs and writes scalars (trainer.py:151)
+      rank          kept (the reference's rank 0 logs: out of scope here)
       epoch_str / global_step   where ``train_loop`` resumes
       model         ``jen1_amd.model.UNetCFG1d`` (a ``.module`` wrapper, as DDP adds one, is unwrapped: the gradient exchange is
                     ``optim.GradExchange`` over ``process_group``, not a module wrapper)
@@ -235,93 +235,15 @@ class UnifiedMultiTaskTrainer:
         self.global_step += 1
         return all_task_loss.detach(), loss_dict, stepped
 
-    # ------------------------------------------------------------------ trainer.py:126-181
+    # ------------------------------------------------------------------ trainer.py:126-150
     def train_loop(self, max_steps: Optional[int] = None) -> None:
-        """``train_loop`` (trainer.py:126-181) over ``self.train_dl``: micro-batches accumulate, every ``grad_accum_every`` of them
-        clip + AdamW + LinearLR run (one fused optimiser step), rank 0 logs the window's losses and writes the scalars, every
-        ``config.eval_interval`` steps (and at the end) the validation pass runs.  ``max_steps`` (not in the reference) bounds the
-        number of micro-batches, for tests and benchmarks."""
-        cfg = self.config
-        num_epoch = int(getattr(cfg, "num_epoch", 1))
-        eval_interval = int(getattr(cfg, "eval_interval", 0) or 0)
-        all_loss = torch.zeros((), device=self.device)
-        loss_dict = {task: torch.zeros((), device=self.device) for task in self.tasks}
+        """the micro-batch loop of ``train_loop`` (trainer.py:126-150) over ``self.train_dl``, so that train.py:110-125's call site works
+        unchanged; the logging, TensorBoard scalars and validation pass around it (:151-181, :61-124) are out of scope (SURVEY.md
+        section 2).  ``max_steps`` (not in the reference) bounds the number of micro-batches."""
         done = 0
-        epoch = self.epoch_str
-        for epoch in range(self.epoch_str, int(self.epoch_str + num_epoch + 1)):
-            for batch_idx, (audio_emb, metadata) in enumerate(self.train_dl):
-                step_before = self.global_step
-                all_task_loss, all_loss_dict, stepped = self.train_step(audio_emb.to(self.device), metadata)
-                all_loss = all_loss + all_task_loss / self.grad_accum_every
-                for task in all_loss_dict:
-                    loss_dict[task] = loss_dict[task] + all_loss_dict[task] / self.grad_accum_every
-                if stepped:
-                    if self.rank == 0 and (self.logger is not None or self.writer is not None):
-                        vals = {k: float(v) for k, v in loss_dict.items()}          # the window's only host sync
-                        total = float(all_loss)
-                        lr = self.optimizer.lr if self.lr_scheduler is None else self.lr_scheduler.get_last_lr()
-                        if self.logger is not None:
-                            n = len(self.train_dl) if hasattr(self.train_dl, "__len__") else 0
-                            self.logger.info("Train Epoch: {}, [{:.0f}%]".format(epoch, 100.0 * batch_idx / n if n else 0.0))
-                            self.logger.info(f"loss: {total} " + " ".join(f"loss_{k}: {v}" for k, v in vals.items()) +
-                                             f" global_step: {step_before}, lr:{lr}")
-                        self._summarize(self.writer, step_before, {"loss/train": total, **{f"loss_{k}/train": v for k, v in vals.items()}})
-                    all_loss = torch.zeros((), device=self.device)
-                    loss_dict = {task: torch.zeros((), device=self.device) for task in self.tasks}
-                if eval_interval and step_before % eval_interval == 0 and step_before != 0 and self.valid_dl is not None:
-                    self.eval_all_tasks(epoch=epoch)
+        for _ in range(self.epoch_str, int(self.epoch_str + int(getattr(self.config, "num_epoch", 1)) + 1)):
+            for audio_emb, metadata in self.train_dl:
+                self.train_step(audio_emb.to(self.device), metadata)
                 done += 1
                 if max_steps is not None and done >= max_steps:
                     return
-        if self.valid_dl is not None:
-            self.eval_all_tasks(epoch=epoch)
-
-    @staticmethod
-    def _summarize(writer, global_step: int, scalars: Dict[str, float]) -> None:
-        """utils/logger.py summarize(): scalars only"""
-        if writer is not None:
-            for k, v in scalars.items():
-                writer.add_scalar(k, v, global_step)
-
-    @torch.no_grad()
-    def eval(self) -> Tuple[Dict[str, float], int]:
-        """trainer.py:90-124: the per-task losses over the validation loader through the inference engine (no gradients)"""
-        self.model.eval()
-        loss_dict = {task: 0.0 for task in self.tasks}
-        count = 0
-        for audio_emb, metadata in self.valid_dl:
-            for task, x, t, conditioning, causal in self.prepare_parts(audio_emb.to(self.device), metadata):
-                if self.is_gdm:
-                    loss = self.diffusion.training_loosses(self.model, x, t, conditioning, causal=causal)
-                else:
-                    loss = self.diffusion.training_loosses(self.model, x, conditioning, causal=causal)
-                loss_dict[task] += float(loss)
-            count += 1
-        return loss_dict, count
-
-    def eval_all_tasks(self, epoch: int) -> float:
-        """trainer.py:61-88: average validation loss per task, best-so-far checkpoint in the reference's wire format"""
-        import os
-        from .checkpoint import save_checkpoint
-        all_task_loss_dict, task_count = self.eval()
-        avg_total_loss = 0.0
-        for task in self.tasks:
-            avg_loss = all_task_loss_dict[task] / task_count if task_count > 0 else 0
-            avg_total_loss += avg_loss
-            if self.logger is not None:
-                self.logger.info(f"Average validation loss for task {task}: {avg_loss}")
-            if self.rank == 0:
-                self._summarize(self.writer, self.global_step, {f"loss/val_{task}": avg_loss})
-        if self.logger is not None:
-            self.logger.info(f"Average total validation loss: {avg_total_loss}")
-        if avg_total_loss < self.best_avg_total_loss:
-            self.best_avg_total_loss = avg_total_loss
-            save_dir = getattr(self.config, "save_dir", "")
-            if save_dir and self.rank == 0:
-                lr = getattr(getattr(self.config, "optimizer_config", None), "lr", self.optimizer.lr)
-                save_checkpoint(model=self.model, optimizer=self.optimizer, lr=lr, iteration=epoch, logger=self.logger,
-                                checkpoint_path=os.path.join(save_dir, f"Jen1_step_{self.global_step}_loss_{self.best_avg_total_loss}.pth"))
-        if self.rank == 0:
-            self._summarize(self.writer, self.global_step, {"loss/val_total": avg_total_loss})
-        self.model.train()
-        return avg_total_loss
