@@ -478,6 +478,40 @@ def test_unified_multitask_trainer_steps(tiny_model, use_graph):
     assert tr.global_step == 4 and tr.grad_accum == 0
 
 
+@pytest.mark.gpu
+def test_train_loop_walks_the_loader_through_train_step(tiny_model):
+    """train_loop (trainer.py:126-150, the call site of train.py:110-125): the micro-batches of ``dls[0]`` go through ``train_step``;
+    ``max_steps`` bounds them; the accumulation window closes with an optimiser step"""
+    import random
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    from jen1_amd.trainer import UnifiedMultiTaskTrainer
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.2, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    B, T = 6, 300
+    emb = dev(synth.conditioning(B, T, "text_guided")["cross_attn_cond"])
+    msk = dev(synth.conditioning(B, T, "text_guided")["cross_attn_masks"])
+
+    def conditioner(metadata, device):
+        idx = torch.tensor(metadata, device=device)
+        return {"prompt": (emb[idx], msk[idx])}
+
+    audio = torch.from_numpy(np.ascontiguousarray(synth.latents(B, T, key="clip")))
+    loader = [(audio, list(range(B))) for _ in range(5)]
+    tr = UnifiedMultiTaskTrainer.build(model, gd, conditioner, opt, None, grad_accum_every=2, rng=random.Random(0), use_graph=False,
+                                       dls=(loader, None))
+    p0 = opt.flat_param.clone()
+    torch.manual_seed(0)
+    tr.train_loop(max_steps=4)
+    torch.cuda.synchronize()
+    assert tr.global_step == 4 and opt.step_count == 2 and tr.grad_accum == 0
+    assert float((opt.flat_param - p0).abs().max()) > 0
+
+
 def test_graphed_step_matches_eager_gradients():
     """the captured forward + backward (train.GraphedLossStep) accumulates the same gradients as the eager path, replay
     after replay, also after the parameters moved (the weight packing is part of the graph)"""
