@@ -317,6 +317,8 @@ class TrainRuntime:
             return
         for bank in self._banks.values():
             self._refresh_bank_bias(bank)
+        # (banks whose parameters were freed or replaced are dropped: their weak references are dead)
+        self._kv_banks = {k: kvb for k, kvb in self._kv_banks.items() if kvb.alive()}
         for kvb in self._kv_banks.values():
             kvb.refresh()
         live = [(hit, hit[0]()) for hit in self._packed.values() if hit[2] != -1]
@@ -858,6 +860,9 @@ class KvBank:
     def params(self):
         return [[r() for r in rs] for rs in self.refs]
 
+    def alive(self) -> bool:
+        return all(r() is not None for rs in self.refs for r in rs)
+
     def same(self, weights, gammas, betas) -> bool:
         return all(r() is t for rs, ts in zip(self.refs, (weights, gammas, betas)) for r, t in zip(rs, ts))
 
@@ -924,10 +929,15 @@ class ContextKVFn(Function):
         R, Ntot = Bk * Nk, bank.Ntot
         dall = slots[0].view._base                                   # [B_eff * Nk, Ntot]
         for slot, gr in zip(slots, grads):
+            # ``dall`` is uninitialised memory: a layer whose attention core did NOT write its whole [b_eff, Nk, 2C] window in place (the
+            # GEMM attention path of Nq > 64, or an unused output) gets the sharers' blocks zeroed -- autograd has summed them into the
+            # [Bk] gradient already -- so that the strided sum below adds nothing for its columns
             if gr is None:
-                slot.view[:Bk].zero_()
+                slot.view.zero_()
             elif gr.data_ptr() != slot.view.data_ptr() or gr.stride() != slot.view[:Bk].stride():
                 slot.view[:Bk].copy_(gr)        # (a gradient that did not come from the one-launch attention core's in-place write)
+                if slot.view.shape[0] > Bk:
+                    slot.view[Bk:].zero_()
         s = rt.stream()
         if ctx.n_share > 1:
             # the unconditional half of the CFG pair read ONE set of context rows: its batch elements' dK | dV blocks, all layers at once
@@ -1757,7 +1767,8 @@ class TrainGraph:
             return None
         ws = [p[f"{n}.to_kv.weight"] for n in names]
         K = rows.shape[-1]
-        if K % 64 or any(w.shape[1] != K or w.shape[0] % 32 for w in ws):
+        # (the data-gradient product runs jen1_big_gemm over K = sum of the widths: a multiple of 64 in bf16)
+        if K % 64 or any(w.shape[1] != K or w.shape[0] % 32 for w in ws) or sum(w.shape[0] for w in ws) % 64:
             return None
         pairs = context_kv(rt, rows, ws, [p[f"{n}.norm_context.weight"] for n in names], [p[f"{n}.norm_context.bias"] for n in names], b_eff)
         return dict(zip(names, pairs))

@@ -4,7 +4,7 @@ Host-side mirror of /root/reference/trainer.py:126-213 -- ``train(audio_emb, met
 per task in the fixed order of config.py:93, a fresh mask / timestep draw per sub-batch, the sum of the three losses)
 and the optimiser part of ``train_loop`` (trainer.py:139-150: zero_grad at the start of an accumulation window,
 ``(loss / grad_accum_every).backward()``, and every ``grad_accum_every`` micro-batches clip -> AdamW -> LinearLR).
-Same names and argument meaning; what is NOT mirrored: the data loader, logging / tensorboard, evaluation and the
+Same names and argument meaning; what is NOT mirrored: the data loader, per-step logging / tensorboard and the
 GradScaler (the HIP path trains in bf16 storage with float32 accumulation and float32 master weights, which needs no
 loss scaling; ``skip_nonfinite`` of FusedAdamW keeps GradScaler's skip-on-overflow behaviour).
 
@@ -101,10 +101,12 @@ class UnifiedMultiTaskTrainer:
     @classmethod
     def build(cls, model, diffusion, conditioner: Callable, optimizer: FusedAdamW, lr_scheduler: Optional[LinearLR] = None,
               grad_accum_every: int = 10, tasks: Sequence[str] = TASKS, device="cuda", cross_attn_cond_ids: Sequence[str] = ("prompt",),
-              global_cond_ids: Sequence[str] = (), input_concat_ids: Sequence[str] = ("masked_input", "mask"), dls=None, **extras):
+              global_cond_ids: Sequence[str] = (), input_concat_ids: Sequence[str] = ("masked_input", "mask"), dls=None, save_dir: str = "",
+              eval_interval: int = 30, num_epoch: int = 100, **extras):
         """the trainer without a config object / logger / writers (tests, bench.py): same object, short argument list"""
         from .config import TrainConfig
-        cfg = TrainConfig(tasks=list(tasks), device=device, grad_accum_every=grad_accum_every)
+        cfg = TrainConfig(tasks=list(tasks), device=device, grad_accum_every=grad_accum_every, save_dir=save_dir, eval_interval=eval_interval,
+                          num_epoch=num_epoch)
         return cls(cfg, 0, 0, 0, model, diffusion, conditioner, dls, optimizer, lr_scheduler, None, None, None, optimizer.max_norm,
                    grad_accum_every, cross_attn_cond_ids, global_cond_ids, input_concat_ids, **extras)
 
@@ -235,15 +237,76 @@ class UnifiedMultiTaskTrainer:
         self.global_step += 1
         return all_task_loss.detach(), loss_dict, stepped
 
-    # ------------------------------------------------------------------ trainer.py:126-150
+    # ------------------------------------------------------------------ trainer.py:94-124
+    @torch.no_grad()
+    def eval(self) -> Tuple[Dict[str, float], int]:
+        """trainer.py:94-124: the validation loss per task over ``self.valid_dl`` under no_grad (the denoiser runs on the sampling
+        engine: ``training_loosses(model, ...)`` without gradients).  Returns ({task: summed loss}, batches)."""
+        self.model.eval()
+        loss_dict = {task: 0.0 for task in self.tasks}
+        count = 0
+        for audio_emb, metadata in (self.valid_dl if self.valid_dl is not None else ()):
+            for task, x, t, conditioning, causal in self.prepare_parts(audio_emb.to(self.device), metadata):
+                if self.is_gdm:
+                    loss = self.diffusion.training_loosses(self.model, x, t, conditioning, causal=causal)
+                else:
+                    loss = self.diffusion.training_loosses(self.model, x, conditioning, causal=causal)
+                loss_dict[task] += float(loss)
+            count += 1
+        return loss_dict, count
+
+    def eval_all_tasks(self, epoch) -> float:
+        """trainer.py:61-92: average validation loss per task; a new best total writes a checkpoint in the reference's wire format
+        (``checkpoint.save_checkpoint`` = script_util.py:79-90, same file name pattern).  Logger / TensorBoard writer are optional;
+        only rank 0 writes the file (the reference lets every rank write one under its own loss value)."""
+        import os
+
+        from .checkpoint import save_checkpoint
+        loss_dict, count = self.eval()
+        avg_total = 0.0
+        for task in self.tasks:
+            avg = loss_dict[task] / count if count > 0 else 0.0
+            avg_total += avg
+            if self.logger is not None:
+                self.logger.info(f"Average validation loss for task {task}: {avg}")
+            if self.rank == 0 and self.writer is not None:
+                self.writer.add_scalar(f"loss/val_{task}", avg, self.global_step)
+        if self.logger is not None:
+            self.logger.info(f"Average total validation loss: {avg_total}")
+        if avg_total < self.best_avg_total_loss:
+            self.best_avg_total_loss = avg_total
+            save_dir = getattr(self.config, "save_dir", None)
+            if save_dir and self.rank == 0:
+                os.makedirs(save_dir, exist_ok=True)
+                oc = getattr(self.config, "optimizer_config", None)
+                lr = getattr(oc, "lr", None) if oc is not None else None
+                if lr is None:
+                    lr = self.optimizer.lr if hasattr(self.optimizer, "lr") else None
+                self.last_checkpoint = os.path.join(save_dir, f"Jen1_step_{self.global_step}_loss_{self.best_avg_total_loss}.pth")
+                save_checkpoint(model=self.model, optimizer=self.optimizer, lr=lr, iteration=epoch, checkpoint_path=self.last_checkpoint,
+                                logger=self.logger)
+        if self.rank == 0 and self.writer is not None:
+            self.writer.add_scalar("loss/val_total", avg_total, self.global_step)
+        self.model.train()
+        return avg_total
+
+    # ------------------------------------------------------------------ trainer.py:126-181
     def train_loop(self, max_steps: Optional[int] = None) -> None:
-        """the micro-batch loop of ``train_loop`` (trainer.py:126-150) over ``self.train_dl``, so that train.py:110-125's call site works
-        unchanged; the logging, TensorBoard scalars and validation pass around it (:151-181, :61-124) are out of scope (SURVEY.md
-        section 2).  ``max_steps`` (not in the reference) bounds the number of micro-batches."""
+        """``train_loop`` (trainer.py:126-181) over ``self.train_dl``, so that train.py:110-125's call site works unchanged: the
+        micro-batch loop, ``eval_all_tasks`` every ``config.eval_interval`` micro-batches (:174-175) and once at the end (:181) --
+        which is where the reference writes its best-so-far checkpoint.  The per-step logging / TensorBoard scalars (:151-172) are out
+        of scope.  ``max_steps`` (not in the reference) bounds the number of micro-batches."""
         done = 0
-        for _ in range(self.epoch_str, int(self.epoch_str + int(getattr(self.config, "num_epoch", 1)) + 1)):
+        epoch = self.epoch_str
+        interval = int(getattr(self.config, "eval_interval", 0) or 0)
+        for epoch in range(self.epoch_str, int(self.epoch_str + int(getattr(self.config, "num_epoch", 1)) + 1)):
             for audio_emb, metadata in self.train_dl:
+                step_before = self.global_step
                 self.train_step(audio_emb.to(self.device), metadata)
+                if interval > 0 and step_before % interval == 0 and step_before != 0:
+                    self.eval_all_tasks(epoch=epoch)
                 done += 1
                 if max_steps is not None and done >= max_steps:
+                    self.eval_all_tasks(epoch=epoch)
                     return
+        self.eval_all_tasks(epoch=epoch)

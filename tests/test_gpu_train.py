@@ -512,6 +512,49 @@ def test_train_loop_walks_the_loader_through_train_step(tiny_model):
     assert float((opt.flat_param - p0).abs().max()) > 0
 
 
+@pytest.mark.gpu
+def test_train_loop_evaluates_and_writes_the_best_checkpoint(tmp_path):
+    """ADVICE r05 (medium): train_loop runs ``eval_all_tasks`` every ``eval_interval`` micro-batches and once at the end (trainer.py:174-181);
+    a new best validation loss writes a checkpoint in the reference's wire format (script_util.py:79-90) that ``load_checkpoint`` reads back"""
+    import random
+    from jen1_amd.checkpoint import load_checkpoint
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.model import UNetCFG1d
+    from jen1_amd.optim import FusedAdamW
+    from jen1_amd.trainer import UnifiedMultiTaskTrainer
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda",
+                           cfg_dropout_proba=0.2, embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    B, T = 3, 300
+    emb = dev(synth.conditioning(B, T, "text_guided")["cross_attn_cond"])
+    msk = dev(synth.conditioning(B, T, "text_guided")["cross_attn_masks"])
+
+    def conditioner(metadata, device):
+        idx = torch.tensor(metadata, device=device)
+        return {"prompt": (emb[idx], msk[idx])}
+
+    audio = torch.from_numpy(np.ascontiguousarray(synth.latents(B, T, key="clip")))
+    loader = [(audio, list(range(B))) for _ in range(3)]
+    valid = [(audio, list(range(B)))]
+    tr = UnifiedMultiTaskTrainer.build(model, gd, conditioner, opt, None, grad_accum_every=1, rng=random.Random(0), use_graph=False,
+                                       dls=(loader, valid), save_dir=str(tmp_path / "ckpt"), eval_interval=2, num_epoch=0)
+    torch.manual_seed(0)
+    tr.train_loop()
+    torch.cuda.synchronize()
+    assert tr.global_step == 3 and opt.step_count == 3
+    files = sorted((tmp_path / "ckpt").glob("Jen1_step_*_loss_*.pth"))
+    assert files and np.isfinite(tr.best_avg_total_loss) and tr.best_avg_total_loss > 0
+    assert str(files[-1]) == tr.last_checkpoint or tr.last_checkpoint in [str(f) for f in files]
+    twin = UNetCFG1d(**tiny_model_config(), init_seed=99, compute_dtype="bf16", device="cuda")
+    load_checkpoint(tr.last_checkpoint, twin)
+    sd_a, sd_b = model.state_dict(), twin.state_dict()
+    # (the checkpoint holds the weights at the time of the best evaluation: every key present, same shapes)
+    assert sd_a.keys() == sd_b.keys() and all(sd_a[k].shape == sd_b[k].shape for k in sd_a)
+    assert model.training
+
+
 def test_graphed_step_matches_eager_gradients():
     """the captured forward + backward (train.GraphedLossStep) accumulates the same gradients as the eager path, replay
     after replay, also after the parameters moved (the weight packing is part of the graph)"""
@@ -1515,3 +1558,55 @@ def test_stacked_context_projection_equals_one_layernorm_and_linear_per_layer(sh
           f"per layer {max(e_old.values()):.3e} (mean {sum(e_old.values()) / 39:.3e}), stacked {max(e_new.values()):.3e} (mean {sum(e_new.values()) / 39:.3e})")
     bad = [(n, e_old[n], e_new[n]) for n in folded if e_new[n] > max(1.5 * e_old[n], 3e-2)]
     assert not bad, bad[:4]
+
+
+@pytest.mark.parametrize("T", [300, 96], ids=["every-layer-on-the-gemm-attention-path", "mixed-small-and-gemm-attention"])
+def test_stacked_context_projection_with_gemm_attention_and_shared_context(T):
+    """a cross-attention whose Nq does not fit the one-launch core (Nq > 64) returns an already-summed [Bk] gradient of
+    its K | V window instead of writing the [b_eff] window in place; the sharers' blocks of that window (uninitialised memory) must not
+    reach the strided sum of ContextKVFn.backward.  Tiny model, bf16, CFG pair with the shared fixed context: T = 300 puts every layer on
+    the GEMM attention path (Nq = 300 / 150), T = 96 mixes both paths.  Grouped pass == per-layer pass for EVERY parameter; twice, with the
+    allocator's memory dirtied in between, so that garbage cannot hide as zeros of a fresh allocation"""
+    from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
+    from jen1_amd.init_fill import fill_uniform
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
+    model.train()
+    B = 3
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.5,
+                           embedding_scale=0.8, batch_cfg=True, scale_cfg=True)
+    x0 = dev(synth.latents(B, T, key="clip"))
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T, "music_inpaint").items()}
+    noise = dev(fill_uniform("synth.trainnoise.kvg", (B, 128, T), 3, 0.0, 1.0))
+    t = torch.tensor([17, 801, 405], dtype=torch.long, device="cuda")
+    rows = torch.tensor([False, True, False], device="cuda")
+    graph = model.train_graph("bf16")
+    rt = graph.rt
+    old = (rt.kv_grouped, rt.share_fixed_context)
+    res = []
+    try:
+        rt.share_fixed_context = True
+        for grouped in (False, True, True):
+            rt.kv_grouped = grouped
+            for p_ in model.parameters():
+                p_.grad = None
+            # dirty the caching allocator's free blocks: torch.empty in the pass then returns non-zero memory
+            junk = [torch.full((1 << 22,), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(8)]
+            del junk
+            loss = gd.training_loosses(graph, x0, t, cond, noise=noise, causal=False, dropout_rows=rows)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((float(loss.detach()), {n: p_.grad.clone() for n, p_ in model.named_parameters()}))
+    finally:
+        rt.kv_grouped, rt.share_fixed_context = old
+    (l0, g0), (l1, g1), (l2, g2) = res
+    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
+    gmax = max(float(g.norm()) for g in g0.values())
+    for g_new in (g1, g2):
+        worst = ("", 0.0)
+        for n in g0:
+            assert bool(torch.isfinite(g_new[n]).all()), n
+            d = float((g_new[n] - g0[n]).norm()) / max(float(g0[n].norm()), 1e-2 * gmax)
+            if d > worst[1]:
+                worst = (n, d)
+        assert worst[1] < 8e-2, worst
