@@ -69,7 +69,31 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="configs[0] tiny UNet (plumbing check)")
     ap.add_argument("--mode", default="sample", choices=["sample", "train"])
     ap.add_argument("--eager-train", action="store_true", help="--mode train: eager backward (overlapped exchange) only")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="sampling with --gpus N: weak = every rank its own --batch samples (replicas); strong = --batch is the GLOBAL batch, "
+                         "split over the ranks (SURVEY.md section 8e: both forms)")
+    ap.add_argument("--accum", type=int, default=1, help="--mode train: micro-batches per optimiser step (the reference's window is 10, "
+                                                         "trainer.py:139-143, utils/config.py:96): the gradient exchange runs once per window")
+    ap.add_argument("--grad-bf16", action="store_true", help="--mode train: gradient exchange in bf16 buckets (float32 master accumulate)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL on ROCm; gloo: CPU plumbing check)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / collective plumbing only: no GPU work, value null")
     return ap.parse_args()
+
+
+def relaunch_under_torchrun(args) -> int:
+    """``python bench.py --gpus N`` with N > 1 and no torchrun around it: start the N ranks ourselves (one process per GPU, the
+    reference's mp.spawn + init_process_group, train.py:14-31) through ``python -m torch.distributed.run`` on 127.0.0.1 and hand
+    the child's exit code back.  The children see WORLD_SIZE and take the normal path."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def dev(a, device):
@@ -627,29 +651,37 @@ def train_mode(args, world, rank, device, dist, barrier):
     def conditioner(metadata, device_):
         idx = torch.tensor(metadata, device=device_)
         return {"prompt": (emb[idx], msk[idx])}
-    tr = UnifiedMultiTaskTrainer.build(model, gd, conditioner, opt, sched, grad_accum_every=1, rng=random.Random(rank), device=device,
-                                 use_graph=not args.eager_train, allow_uneven_tasks=True)
+    accum = max(1, args.accum)
+    tr = UnifiedMultiTaskTrainer.build(model, gd, conditioner, opt, sched, grad_accum_every=accum, rng=random.Random(rank), device=device,
+                                 use_graph=not args.eager_train, allow_uneven_tasks=True, grad_dtype="bf16" if args.grad_bf16 else "f32")
     audio = dev(synth.latents(B, T, key="clip", seed=rank), device)
     meta = list(range(B))
     torch.manual_seed(rank)
-    for _ in range(max(args.warmup, 8)):      # the merged passes come in four (size, causal) shapes (text_guided flips a coin for
+    # a "step" of this mode is one MICRO-batch (forward + backward of B clips); with --accum A every A-th one also carries the gradient
+    # exchange and ends with clip + AdamW + LinearLR (trainer.py:139-149: A = 10 in the reference).  Warm-up and the timed region are whole
+    # windows, so the region holds exactly steps / A optimiser steps.
+    n_warm = -(-max(args.warmup, 8) // accum) * accum
+    n_steps = -(-args.steps // accum) * accum
+    for _ in range(n_warm):                   # the merged passes come in four (size, causal) shapes (text_guided flips a coin for
                                               # causal): all of them are captured before the timed region
         loss, _, _ = tr.train_step(audio, meta)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_steps):
         loss, _, _ = tr.train_step(audio, meta)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    args.steps = n_steps
     dt, steps_per_s = aggregate(dist, dt, args.steps, world, device)
     out = {
         "metric": "training clips/sec (multi-task DDP step, 8 clips x 128x1500 latents per GPU)", "value": round(steps_per_s * B, 2),
-        "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 8),
+        "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic", "grad_accum_every": accum, "optimizer_steps": n_steps // accum,
+        "grad_exchange_dtype": "bf16" if args.grad_bf16 else "f32",
         "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[3] full JEN-1 1D-UNet (296.5M params)")
                    + f", {B} clips per GPU (3/3/2 over text_guided / music_inpaint / music_cont; all sub-batches share ONE pass per "
                    + f"micro-batch: the causal flag travels per clip), latents 128x{T}, CFG pair, "
@@ -670,7 +702,7 @@ def train_mode(args, world, rank, device, dist, barrier):
         torch.cuda.synchronize()
         ex_ms = (time.perf_counter() - t0) / 3 * 1e3
         tr.exchange.disabled = True
-        for _ in range(4):
+        for _ in range(-(-4 // accum) * accum):
             tr.train_step(audio, meta)
         torch.cuda.synchronize()
         barrier()
@@ -687,7 +719,7 @@ def train_mode(args, world, rank, device, dist, barrier):
         seen[rank] = 1
         dist.all_reduce(seen)
         out["exchange_ms"] = round(ex_ms, 3)
-        out["exchange_bytes"] = 4 * opt.numel
+        out["exchange_bytes"] = (2 if args.grad_bf16 else 4) * opt.numel
         out["ms_per_step_without_exchange"] = round(ms0, 3)
         out["exchange_exposed_ms"] = round(exposed, 3)
         out["exchange_overlapped_fraction"] = round(max(0.0, 1.0 - exposed / ex_ms), 3) if ex_ms > 0 else None
@@ -720,16 +752,38 @@ def aggregate(dist, dt, steps, world, device):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    device = f"cuda:{local}"
-    dist = init_dist(world, rank, device)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N starts them itself; "
+                         "or torchrun --nproc-per-node N bench.py --gpus N)")
+    on_gpu = not args.dry_run
+    if on_gpu:
+        torch.cuda.set_device(local)
+    device = f"cuda:{local}" if on_gpu else "cpu"
+    dist = init_dist(world, rank, device, backend=args.backend)
 
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    # every rank that takes part in the run adds 1: the line shows how many processes were actually there
+    ranks_seen = 1
+    if dist is not None:
+        one = torch.ones((1,), dtype=torch.int32, device=device)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({"metric": "denoiser steps/sec (B=8, 128x1500 latents)", "value": None, "unit": "denoiser steps/s", "n_gpus": world,
+                              "ranks_seen": ranks_seen, "scaling": args.scaling, "mode": args.mode, "dry_run": True, "backend": args.backend}))
+        barrier()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     if args.mode == "train":
         train_mode(args, world, rank, device, dist, barrier)
@@ -742,6 +796,13 @@ def main():
     from jen1_amd.model import UNetCFG1d
     cfg = tiny_model_config() if args.tiny else full_model_config()
     B, T = args.batch, args.length
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # strong scaling: --batch is the GLOBAL batch (configs[1]: 8 samples), rank r denoises samples [r B / N, (r + 1) B / N) -- still no
+        # data-path collective (samples are independent); a step of the job = one step of every sample, so value = steps / slowest rank
+        if B % world:
+            raise SystemExit(f"bench.py: --scaling strong needs --batch {B} divisible by --gpus {world}")
+        B = B // world
     model = UNetCFG1d(**cfg, init_seed=1234, compute_dtype=args.dtype, device=device)
     st = build_stepper(model, B, T, device, cfg_pair=False, use_graph=not args.no_graph)
     # the timed region is EXACTLY --steps steps; it is repeated (>= 3 regions, >= 600 steps in total) and the MEDIAN region is the
@@ -753,18 +814,21 @@ def main():
         d_, _ = aggregate(dist, d, args.steps, world, device)
         per_region.append(d_)
     dt = float(np.median(per_region))
-    value = world * args.steps / dt
+    value = (1 if strong else world) * args.steps / dt
 
     out = {
         "metric": "denoiser steps/sec (B=8, 128x1500 latents)", "value": round(value, 2), "unit": "denoiser steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "ranks_seen": ranks_seen, "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
         "config": {"workload": ("configs[0] tiny 1D-UNet" if args.tiny else "configs[1] full JEN-1 1D-UNet (296.5M params)")
                    + f", B={B} per GPU, latents 128x{T}, 100-step DDIM schedule, eta=1 (the reference's default, gdm.py:28: every step adds "
                      "sigma * noise; the per-step noise is a table drawn before the timed region and READ inside it), no CFG (CFG dropout off: "
                      "sampling), hipGraph-replayed step; per sampling run and outside the timed region: the text K/V projection and the "
                      "time-embedding / FiLM / time-token K/V tables of the schedule (extra.end_to_end times a whole sample() call with them)",
-                   "global_batch": B * world, "seq_len": T, "parallelism": f"replicas x{world} (independent samples)"},
+                   "global_batch": B * world, "seq_len": T,
+                   "parallelism": (f"global batch {B * world} split over {world} ranks (independent samples, no collective)" if strong
+                                   else f"replicas x{world} (independent samples)")},
         "regions": {"count": len(per_region), "steps_each": args.steps, "ms_per_step": [round(d / args.steps * 1e3, 4) for d in per_region],
                     "min": round(min(per_region) / args.steps * 1e3, 4), "median": round(dt / args.steps * 1e3, 4),
                     "max": round(max(per_region) / args.steps * 1e3, 4), "headline": "median"},

@@ -54,7 +54,7 @@ class UnifiedMultiTaskTrainer:
       grad_clip     the clip norm of the fused optimiser step (nn.utils.clip_grad_norm_, trainer.py:145)
       grad_accum_every   micro-batches per optimiser step (trainer.py:139-149)
     Keyword-only extras (not in the reference): ``process_group``, ``rng``, ``compute_dtype``, ``use_graph``,
-    ``allow_uneven_tasks``, ``bucket_bytes``, ``merge_tasks``, ``merge_causal``.  ``UnifiedMultiTaskTrainer.build(model, diffusion, conditioner,
+    ``allow_uneven_tasks``, ``bucket_bytes``, ``merge_tasks``, ``merge_causal``, ``grad_dtype``.  ``UnifiedMultiTaskTrainer.build(model, diffusion, conditioner,
     optimizer, ...)`` is the short form for code that has no config object."""
 
     def __init__(self, config, rank: int, epoch_str: int, global_step: int, model, diffusion, conditioner: Callable, dls, optimizer,
@@ -62,7 +62,7 @@ class UnifiedMultiTaskTrainer:
                  cross_attn_cond_ids: Sequence[str] = ("prompt",), global_cond_ids: Sequence[str] = (),
                  input_concat_ids: Sequence[str] = ("masked_input", "mask"), *, process_group=None, rng=_random,
                  compute_dtype: Optional[str] = None, use_graph: bool = True, allow_uneven_tasks: bool = False,
-                 bucket_bytes: int = 128 << 20, merge_tasks: bool = True, merge_causal: bool = True):
+                 bucket_bytes: int = 128 << 20, merge_tasks: bool = True, merge_causal: bool = True, grad_dtype: str = "f32"):
         self.config = config
         self.tasks = tuple(getattr(config, "tasks", TASKS))
         self.device = getattr(config, "device", "cuda")
@@ -95,7 +95,9 @@ class UnifiedMultiTaskTrainer:
         # DDP's gradient exchange (train.py:88-89): buckets in reverse execution order; in eager mode each bucket leaves as soon
         # as the backward pass has finished it, behind a replayed graph the regions leave between the segments of the replay
         names = [n for n, _ in model.named_parameters()]
-        self.exchange = GradExchange(optimizer, names, process_group, bucket_bytes, params=dict(model.named_parameters()))
+        # grad_dtype="bf16": the buckets cross xGMI as bfloat16 (0.59 GB instead of 1.19 GB for the 296.5 M gradients) and are widened into
+        # the float32 flat gradient again -- the optimiser, its moments and the master weights stay float32 (optim.GradExchange)
+        self.exchange = GradExchange(optimizer, names, process_group, bucket_bytes, params=dict(model.named_parameters()), grad_dtype=grad_dtype)
         self.graph.exchange = self.exchange
 
     @classmethod
