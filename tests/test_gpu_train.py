@@ -14,7 +14,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import golden, rel_err
+from helpers import bf16_gate, golden, record_parity, rel_err
 from jen1_amd import synth
 from jen1_amd.config import tiny_model_config
 
@@ -642,7 +642,10 @@ def test_full_model_training_gradients_vs_reference_autograd_f32():
     print(f"full model: worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
 
 
-@pytest.mark.parametrize("mode,tol_loss,tol_norm,tol_samp", [("f32", 1e-3, 1e-3, 5e-3), ("bf16", 2e-2, 3e-2, 1.0)])
+@pytest.mark.parametrize("mode,tol_loss,tol_norm,tol_samp", [("f32", 1e-3, 1e-3, 5e-3),
+                                                             ("bf16", bf16_gate("configs3_micro_batch", "bf16", "loss"),
+                                                              bf16_gate("configs3_micro_batch", "bf16", "norm"),
+                                                              bf16_gate("configs3_micro_batch", "bf16", "samp"))])
 def test_configs3_micro_batch_merged_passes_vs_reference_autograd(mode, tol_loss, tol_norm, tol_samp):
     """BASELINE configs[3] at its per-GPU shape: the full model, 8 clips as the 3 / 3 / 2 task sub-batches (text_guided,
     music_inpaint, music_cont with their masks) of one micro-batch.  The reference runs one pass per task and sums the three
@@ -672,15 +675,13 @@ def test_configs3_micro_batch_merged_passes_vs_reference_autograd(mode, tol_loss
     loss, per_task = tr.run_parts(parts, noises)
     loss.backward()
     torch.cuda.synchronize()
-    for task in per_task:
-        ref = float(g[f"loss.{task}"])
-        assert abs(float(per_task[task]) - ref) <= tol_loss * abs(ref), (task, float(per_task[task]), ref)
-    assert abs(float(loss.detach()) - float(g["loss"])) <= tol_loss * abs(float(g["loss"]))
+    worst_l = max(abs(float(per_task[task]) - float(g[f"loss.{task}"])) / abs(float(g[f"loss.{task}"])) for task in per_task)
+    worst_l = max(worst_l, abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"])))
     grads = {n: p.grad for n, p in model.named_parameters()}
     assert sorted(names) == sorted(grads.keys()) and len(names) == 979
     ref_norm, ref_samp = g["gradnorm_all"], g["gradsample_all"]
     gmax = float(ref_norm.max())
-    off, worst_n, worst_s = 0, 0.0, 0.0
+    off, worst_n, worst_s = 0, ("", 0.0), ("", 0.0)
     for i, n in enumerate(names):
         gr = grads[n]
         samp = gr.reshape(-1)[:: max(1, gr.numel() // 16)][:16].cpu().numpy()
@@ -690,11 +691,17 @@ def test_configs3_micro_batch_merged_passes_vs_reference_autograd(mode, tol_loss
         en = abs(nrm - ref_norm[i]) / max(ref_norm[i], 1e-3 * gmax)
         scale = max(float(np.abs(ref).max()), ref_norm[i] / np.sqrt(gr.numel()))
         es = float(np.abs(samp - ref).max() / max(scale, 1e-12))
-        worst_n, worst_s = max(worst_n, en), max(worst_s, es)
-        assert en <= tol_norm, (n, nrm, ref_norm[i])
-        assert es <= tol_samp, (n, es)
+        if en > worst_n[1]:
+            worst_n = (n, en)
+        if es > worst_s[1]:
+            worst_s = (n, es)
     assert off == ref_samp.size
-    print(f"configs[3] micro-batch (3/3/2, one pass, {mode}): worst norm error {worst_n:.2e}, worst sampled-entry error {worst_s:.2e}")
+    print(f"configs[3] micro-batch (3/3/2, one pass, {mode}): worst loss error {worst_l:.2e}, worst norm error {worst_n[1]:.2e} ({worst_n[0]}), "
+          f"worst sampled-entry error {worst_s[1]:.2e} ({worst_s[0]})")
+    record_parity("configs3_micro_batch", mode, mode, loss=worst_l, norm=worst_n[1], samp=worst_s[1])
+    assert worst_l <= tol_loss, worst_l
+    assert worst_n[1] <= tol_norm, worst_n
+    assert worst_s[1] <= tol_samp, worst_s
 
 
 def test_training_overfits_one_batch():
@@ -1569,6 +1576,7 @@ def test_stacked_context_projection_with_gemm_attention_and_shared_context(T):
     allocator's memory dirtied in between, so that garbage cannot hide as zeros of a fresh allocation"""
     from jen1_amd.diffusion import GaussianDiffusion, get_beta_schedule
     from jen1_amd.init_fill import fill_uniform
+    from jen1_amd.model import UNetCFG1d
     model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
     model.train()
     B = 3

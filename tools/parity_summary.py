@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""gpurun_out/parity.jsonl (tests/helpers.py::record_parity) -> a table: the measured value of every parity metric of the multi-step
+sampler and training-pass tests, the worst over repeated runs, and the gate it is held to (tests/helpers.py::BF16_GATES).
+
+    python tools/parity_summary.py [gpurun_out/parity.jsonl] > profiles/r06_parity.txt
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity.jsonl")
+    from helpers import BF16_GATES
+    rows = {}
+    for ln in open(path):
+        r = json.loads(ln)
+        key = (r["test"], r["case"], r["mode"])
+        m = rows.setdefault(key, {"n": 0})
+        m["n"] += 1
+        for k, v in r.items():
+            if k not in ("test", "case", "mode"):
+                m[k] = max(m.get(k, 0.0), v)
+    print(f"# measured parity against the reference's float32 outputs (worst over the runs in {os.path.basename(path)})")
+    print(f"{'test':<22} {'case':<26} {'mode':<5} {'runs':>4}  metrics (measured -> gate where one is set; gate / measured)")
+    for (test, case, mode), m in sorted(rows.items()):
+        gates = BF16_GATES.get((test, case), {}) if mode == "bf16" else {}
+        parts = []
+        for k, v in sorted(m.items()):
+            if k == "n":
+                continue
+            g = gates.get(k)
+            parts.append(f"{k} {v:.3e}" + (f" -> {g:.1e} ({g / v:.2f}x)" if g is not None and v > 0 else ""))
+        print(f"{test:<22} {case:<26} {mode:<5} {m['n']:>4}  " + ", ".join(parts))
+
+
+if __name__ == "__main__":
+    main()
