@@ -50,13 +50,15 @@ class Act:
     """a channel-last activation [B][L][ld] plus the statistics its consumers need.
     ``ld`` is the row pitch; ``cp`` the channels a GEMM reads (C padded to 32): they differ only for a column
     window of a wider tensor (``cols``)."""
-    __slots__ = ("t", "B", "L", "C", "ld", "gn", "rs", "cp", "part", "gn_valid")
+    __slots__ = ("t", "B", "L", "C", "ld", "gn", "rs", "cp", "part", "gn_valid", "lp")
 
     def __init__(self, t, B, L, C, ld, gn=None, rs=None, cp=None):
         self.t, self.B, self.L, self.C, self.ld, self.gn, self.rs = t, B, L, C, ld, gn, rs
         self.cp = cp if cp is not None else ld
         # GroupNorm statistics as a tile phase of the persistent launch leaves them: (tensor [B][tiles][groups][2], tiles, groups)
         self.part = None
+        # ... and as a phase of the sample-resident long-level launch leaves them: (tensor [B][8][entries][2], entries, M blocks, 16-channel sub-groups)
+        self.lp = None
         # ``gn`` (the fine-group totals) is written by whoever produces the tensor -- except phases of the persistent launch
         self.gn_valid = True
 
@@ -469,6 +471,84 @@ class DeepProgram:
         return e
 
 
+class LongIneligible(DeepIneligible):
+    """a layer of a long level does not fit the sample-resident launch (include/jen1_long.h): the plan keeps one launch per layer there"""
+
+
+class LongProgram(DeepProgram):
+    """Host side of one sample-resident long-level launch (include/jen1_long.h): to_in + the down path above the deep levels, or the
+    up path above them + to_out.  One 512-byte descriptor per convolution; sample b runs on workgroups b, b + B, ... (G = nwg // B per
+    sample).  Shares the plan's leader (static schedule claim, error word) with the deep program(s)."""
+
+    POISON_CHUNK = 1 << 18          # a poisoned tensor is cut into table rows of this many bytes (8 workgroups per row)
+
+    def __init__(self, eng, Bs: int, leader: Optional["DeepProgram"] = None, err: Optional[torch.Tensor] = None):
+        super().__init__(eng, leader=leader, err=err)
+        self.Bs = Bs
+        self.G = self.nwg // Bs
+        self.dsize = 512
+        if self.G < 1:
+            raise LongIneligible(f"{Bs} samples on {self.nwg} workgroups")
+
+    def geometry(self, M: int, L_out: int):
+        mb, tl, tb = C.c_int(0), C.c_int(0), C.c_int(0)
+        if self.lib.jen1_long_geometry(M, L_out, self.G, C.byref(mb), C.byref(tl), C.byref(tb)) != 0:
+            msg = self.lib.jen1_last_error()
+            raise LongIneligible(msg.decode() if msg else "geometry")
+        return mb.value, tl.value, tb.value
+
+    def add_long(self, a: "L.ConvArgs", st, st_live: int, out_part, label: str, out):
+        """st: per normalised source None or (pointer, entries, mblocks, nsub) -- entries = 0: fine-group totals"""
+        buf = (C.c_char * self.dsize)()
+        st = list(st) + [None] * (2 - len(st))
+        q = [(None, 0, 1, 8) if e is None else e for e in st]
+        rc = self.lib.jen1_long_phase_conv(C.byref(a), self.G, q[0][0], q[0][1], q[0][2], q[0][3], q[1][0], q[1][1], q[1][2], q[1][3], st_live,
+                                           None if out_part is None else out_part.data_ptr(), C.cast(buf, C.c_void_p))
+        if rc != 0:
+            msg = self.lib.jen1_last_error()
+            raise LongIneligible(f"{label}: {msg.decode() if msg else 'does not fit'}")
+        self.bufs.append(buf)
+        self.labels.append(label)
+        self.outs.append(out)
+        self.kinds.append("long")
+        self._note_output(out)
+        if out_part is not None:
+            self._produced.setdefault(out_part.untyped_storage().data_ptr(), out_part)
+
+    def sync_words(self) -> int:
+        return 64                   # word 0: the ticket counter of the ticket form (zero when the launch starts)
+
+    def finalize(self, sync: torch.Tensor):
+        n = len(self.bufs)
+        host = (C.c_char * (self.dsize * n))()
+        lds = 0
+        for i, b in enumerate(self.bufs):
+            C.memmove(C.addressof(host) + i * self.dsize, b, self.dsize)
+            lds = max(lds, int(self.lib.jen1_long_phase_lds(C.cast(b, C.c_void_p))))
+        self.lds = lds
+        self.dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.eng.device)
+        self.sync = sync
+        self.err = self._err_shared if self._err_shared is not None else torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
+        ent = []
+        for ptr, t in self._produced.items():
+            nb = t.untyped_storage().nbytes()
+            assert ptr % 16 == 0 and nb % 16 == 0, (ptr, nb)
+            for o in range(0, nb, self.POISON_CHUNK):
+                ent += [ptr + o, min(self.POISON_CHUNK, nb - o)]
+        if self.leader is self:
+            self.claim_static()
+        self.poison_tab = torch.tensor(ent, dtype=torch.int64).view(-1, 2).to(self.eng.device)
+        self.poison_bytes = int(sum(ent[1::2]))
+
+    def launch(self, stream: int):
+        self.touch()
+        n = len(self.bufs)
+        if os.environ.get("JEN1_LONG_RUN_PHASES"):          # debugging: run only the first phases of the program
+            n = min(n, int(os.environ["JEN1_LONG_RUN_PHASES"]))
+        L.check(self.lib.jen1_long_run(self.dev.data_ptr(), n, self.Bs, self.err.data_ptr(), None if self.exclusive else self.sync.data_ptr(),
+                                       self.nwg, self.lds, self.eng.dt, stream), "jen1_long_run")
+
+
 class KernelCtx:
     """what an OpBuilder needs to know about the device / dtype (Engine provides the same fields)."""
 
@@ -514,6 +594,8 @@ class OpBuilder:
         self._prog: Optional[DeepProgram] = None    # the open program, if any
         self.tile_lens = getattr(self, "tile_lens", frozenset())      # input lengths whose layers are tile phases (Plan)
         self.tile_errors: List[str] = []
+        self._long_on = False                       # layers are phases of a sample-resident long-level launch (Plan._long_begin)
+        self._lprog: Optional[LongProgram] = None   # the open one
 
     def _empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.eng.tdtype, device=self.eng.device)
@@ -604,6 +686,9 @@ class OpBuilder:
             a.out_gn_stats, a.out_cpf = out.gn.data_ptr(), out.ld // FG
         if out.rs is not None:
             a.out_rowstats = out.rs.data_ptr()
+        if self._long_on:
+            return self._conv_long(a, src0=src0, src1=src1, w=w, bias=bias, out=out, pro=pro, gn=gn, film=film, act=act, residual=residual,
+                                   row_scale=row_scale, y_f32=y_f32, extra_segs=extra_segs, m_split=m_split, label=label, taps=taps, out_C=out_C)
         if self._deep_on:
             # persistent deep-level kernel: one phase descriptor instead of a launch (norm_apply + streaming GEMM); the consumer
             # computes the GroupNorm statistics itself, FiLM comes from the fused GroupNorm-FiLM table
@@ -857,6 +942,64 @@ class OpBuilder:
         prog.flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
         return out
 
+    # ---------------------------------------------------------------- phases of the sample-resident long-level launches
+    def _conv_long(self, a: "L.ConvArgs", *, src0, src1, w, bias, out, pro, gn, film, act, residual, row_scale, y_f32, extra_segs, m_split, label,
+                   taps, out_C):
+        eng = self.eng
+        if pro not in (L.PRO_NONE, L.PRO_GN, L.PRO_GN_SILU) or act != L.ACT_NONE or row_scale is not None or m_split or out.rs is not None or y_f32:
+            raise LongIneligible(f"{label}: option outside the long-level phases")
+        if out.ld != out.C:
+            raise LongIneligible(f"{label}: {out.C} output channels are not a multiple of 32 (padding columns would stay poisoned)")
+        if extra_segs and not (len(extra_segs) <= 2 and all(sh == 0 and e.cp % 32 == 0 for e, sh in extra_segs)):
+            raise LongIneligible(f"{label}: extra K segments outside the long-level phases")
+        normed = [s_ for s_ in (src0, src1) if s_ is not None and pro in (L.PRO_GN, L.PRO_GN_SILU)]
+        if self._prog is not None:
+            # the deep program ends here, with the totals of what this layer normalises (tensors a deep phase produced)
+            self._prog_close([s_ for s_ in normed if not s_.gn_valid and s_.lp is None])
+        prog = self._lprog
+        assert prog is not None
+        a.out_gn_stats = a.out_rowstats = None
+        a.dtype = eng.dt                                     # (JEN1_FP8: the long levels stay bf16)
+        if pro in (L.PRO_GN, L.PRO_GN_SILU) and film is not None:
+            a.film = self.film2.data_ptr()
+        a.nseg = 0
+        if extra_segs:
+            for i, (e, sh) in enumerate(extra_segs):
+                assert e.B == a.B and e.L == a.L_in and e.t.dtype == eng.tdtype
+                a.seg[i].x, a.seg[i].ld, a.seg[i].shift, a.seg[i].kch = e.t.data_ptr(), e.ld, 0, e.cp // 32
+            a.nseg = len(extra_segs)
+        srcs_ = [src0] + ([src1] if src1 is not None else []) + [e for e, _ in (extra_segs or [])]
+        a.live_mask = sum(1 << i for i, s_ in enumerate(srcs_) if prog.is_live(s_.t)) | \
+            (256 if residual is not None and prog.is_live(residual.t) else 0)
+        st, st_live = [], 0
+        for k, s_ in enumerate(normed):
+            if s_.lp is not None:
+                pt, entries, mblocks, nsub = s_.lp
+                st.append((pt.data_ptr(), entries, mblocks, nsub))
+                st_live |= (1 << k) if prog.is_live(pt) else 0
+            elif s_.gn is not None and s_.gn_valid:
+                st.append((s_.gn.data_ptr(), 0, 1, 32))
+            else:
+                raise LongIneligible(f"{label}: no GroupNorm statistics for a normalised source")
+        part, lp = None, None
+        if out.gn is not None:
+            mb, tiles, _ = prog.geometry(a.M, a.L_out)
+            if out_C not in (128, 256):
+                raise LongIneligible(f"{label}: statistics partials of {out_C} output channels")
+            part = torch.empty((a.B, 8, tiles * mb, 2), dtype=torch.float32, device=eng.device)
+            lp = (part, tiles * mb, mb, out_C // 16)
+        prog.add_long(a, st, st_live, part, f"long[{label}] B={a.B} Lin={a.L_in} Lout={a.L_out} c0={a.c0} c1={a.c1} taps={a.taps} s={a.stride} M={a.M}", out)
+        self._keep.append((a, src0, src1, w, bias, out, residual, gn, film, extra_segs, part))
+        out.lp = lp
+        out.gn_valid = False
+        es_ = 4 if eng.dt == L.F32 else 2
+        c_real_ = src0.C + (src1.C if src1 is not None else 0)
+        c_extra_ = sum(e.C for e, _ in extra_segs) if extra_segs else 0
+        prog.w_bytes += (taps * c_real_ + c_extra_) * a.M * es_
+        prog.act_bytes += a.B * a.L_in * (c_real_ + c_extra_) * es_ + a.B * a.L_y * out_C * es_
+        prog.flops += 2 * (taps * c_real_ + c_extra_) * a.M * a.B * a.L_out
+        return out
+
     def _prog_open(self):
         raise DeepIneligible("no persistent program outside a Plan")
 
@@ -1072,6 +1215,10 @@ class Plan(OpBuilder):
         # long levels as tile phases of the persistent launch(es): layers whose input has at least eng.tile_phase_min_len positions
         self.tile_lens = frozenset(l for l in lens if l >= eng.tile_phase_min_len) if (deep and eng.use_deep and eng.use_tile_phases
                                                                                        and not self.det) else frozenset()
+        # to_in, the levels above the deep ones and to_out as two sample-resident launches (LongProgram): needs the persistent deep-level launch
+        # behind it; a layer that does not fit sends the plan back to one launch per layer on those levels
+        self.use_long = bool(deep and eng.use_deep and eng.use_long and not self.tile_lens)
+        self.long_errors: List[str] = []
         while True:
             super().__init__(eng)
             self.progs: List[DeepProgram] = []
@@ -1086,6 +1233,9 @@ class Plan(OpBuilder):
             try:
                 self._build()
                 break
+            except LongIneligible as e:
+                self.long_errors.append(str(e))
+                self.use_long = False
             except DeepIneligible as e:
                 self.deep_errors.append(f"level {first}: {e}")
                 if first >= n_lv:
@@ -1120,6 +1270,35 @@ class Plan(OpBuilder):
                 self._deep_err = torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
             self._prog = DeepProgram(self.eng, leader=self.progs[0] if self.progs else None, err=self._deep_err)
             self.deep = self._prog
+
+    def _long_begin(self):
+        """from here on layers are phases of ONE sample-resident launch (LongProgram) until _long_end"""
+        self._long_open()               # (a deep program that is still open is closed by the first long layer, with the totals it needs)
+
+    def _long_open(self):
+        if self._deep_err is None:
+            self._deep_err = torch.zeros((16,), dtype=torch.int32, device=self.eng.device)
+        self._lprog = LongProgram(self.eng, self.Beff, leader=self.progs[0] if self.progs else None, err=self._deep_err)
+        self._long_on = True
+
+    def _long_end(self):
+        prog, self._lprog, self._long_on = self._lprog, None, False
+        if prog is None or len(prog) == 0:
+            return
+        sync = self._stats(prog.sync_words()).view(torch.int32)
+        prog.finalize(sync)
+        self.progs.append(prog)
+        pz = lambda s, prog=prog: prog.poison(s)
+        pz.kind = "deep_poison"
+        pz.prog = prog
+        pz.label = f"long_poison[{prog.poison_tab.shape[0]} rows, {prog.poison_bytes} B]"
+        self.ops.insert(1, pz)
+        fn = lambda s, prog=prog: prog.launch(s)
+        fn.kind = "long"
+        fn.prog = prog
+        fn.label = f"long[{len(prog)} phases, {prog.Bs} samples x {prog.G} workgroups, {prog.lds} B LDS]"
+        fn.w_bytes, fn.act_bytes, fn.flops = prog.w_bytes, prog.act_bytes, prog.flops
+        self.ops.append(fn)
 
     def _deep_begin(self):
         if self._prog is not None and "tile" in self._prog.kinds:
@@ -1383,12 +1562,21 @@ class Plan(OpBuilder):
                       ln=(F, None, None, W.v["kvx.u"]))
 
         # ---- 4. UNet1d.forward (model.py:243-262) ------------------------------------------------
+        n_lv = len(spec.downs)
+        first_tr = next((i for i, d in enumerate(spec.downs) if d.transformer), n_lv)
+        # levels [0, long_levels) (+ to_in / to_out) run as phases of the two sample-resident launches
+        self.long_levels = min(self.deep_level, first_tr) if (self.use_long and self.deep_level is not None) else 0
+        use_long = self.long_levels >= 1
+        if use_long:
+            self._long_begin()
         x = self.resblock(spec.to_in, X0, None, causal=False)
         self.taps["to_in"] = x
         skip0 = x
         skips_list: List[List[Act]] = []
         n_lv = len(spec.downs)
         for i, d in enumerate(spec.downs):
+            if use_long and i == self.long_levels:
+                self._long_end()
             if i == self.deep_level:
                 self._deep_begin()        # from this level's downsampling conv on, layers are phases of one launch
             f, k = d.factor, d.kernel
@@ -1412,6 +1600,8 @@ class Plan(OpBuilder):
         x = self.resblock(spec.bott_post, x, None, causal)
         self.taps["bottleneck"] = x
         for idx, u in enumerate(spec.ups):
+            if use_long and n_lv - 1 - idx == self.long_levels - 1:
+                self._long_begin()
             skips = skips_list.pop()
             for r in u.blocks:
                 sk = skips.pop()
@@ -1443,15 +1633,22 @@ class Plan(OpBuilder):
         out = self.resblock(spec.to_out, x, None, causal=False, gn=False)
         self.net_out = out
         self.taps["out"] = out
+        if use_long:
+            self._long_end()
         if self._prog is not None:
             self._prog_close()            # (the network's output is read by a launch that normalises nothing)
         self.deep = self._deep_prog if self._deep_prog is not None else (self.progs[-1] if self.progs else None)
-        if self.progs and getattr(self.ops[1], "kind", "") == "deep_poison" and arena_bytes % 16 == 0 and arena_ptr % 16 == 0:
-            # the arena reset rides on the first poisoning launch: one node at the head of the step instead of two
-            pz0 = self.ops[1]
-            fused = lambda s, prog=pz0.prog, z=(arena_ptr, arena_bytes): prog.poison(s, zero=z)
-            fused.kind, fused.label, fused.prog = "deep_poison", pz0.label + " + arena reset", pz0.prog
-            self.ops[0:2] = [fused]
+        pzs = [op for op in self.ops if getattr(op, "kind", "") == "deep_poison"]
+        if pzs and arena_bytes % 16 == 0 and arena_ptr % 16 == 0:
+            # ONE node at the head of the step: the arena reset and the poisoning of every persistent launch's tensors (every program's
+            # synchronisation words live inside the arena: zeroed with it)
+            tab = torch.cat([op.prog.poison_tab for op in pzs], 0).contiguous()
+            self._poison_tab = tab
+            sync0 = pzs[0].prog.sync.data_ptr()
+            fused = lambda s, a=(tab.data_ptr(), tab.shape[0], sync0, arena_ptr, arena_bytes): L.check(lib.jen1_deep_poison_zero(*a, s), "jen1_deep_poison_zero")
+            fused.kind, fused.prog = "deep_poison", pzs[0].prog
+            fused.label = f"poison[{tab.shape[0]} rows, {sum(op.prog.poison_bytes for op in pzs)} B] + arena reset"
+            self.ops = [fused] + [op for op in self.ops[1:] if getattr(op, "kind", "") != "deep_poison"]
 
         # ---- 5. context ops: text K/V (hoisted out of the step loop) -------------------------------
         if n_tr:
@@ -1607,6 +1804,8 @@ class Engine:
         self.tile_one_round = os.environ.get("JEN1_TILE_ONE_ROUND", "0") != "0"
         # persistent deep-level kernel (DeepProgram): levels of at most deep_max_len positions
         self.use_deep = os.environ.get("JEN1_DEEP", "1") != "0"
+        # to_in / the levels above the deep ones / to_out as two sample-resident launches (include/jen1_long.h; JEN1_LONG=0: one launch per layer)
+        self.use_long = os.environ.get("JEN1_LONG", "1") != "0"
         self.deep_all_slots = os.environ.get("JEN1_DEEP_ALL_SLOTS", "0") != "0"
         self.deterministic = os.environ.get("JEN1_DETERMINISTIC", "0") != "0"
         # (a library built with -DJEN1_DEEP_CHUNKS runs a level of more than 64 positions in column chunks -- a unit computes <= 64

@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("JEN1_LIB", os.path.join(HERE, "libjen1_hip.so"))   # 
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 SOURCES = ["conv_gemm.hip", "stream_gemm.hip", "tile_gemm.hip", "norm_apply.hip", "attention.hip", "deep_kernel.hip", "elementwise.hip",
-           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip", "big_gemm.hip", "train_glue.hip", "train_kvbank.hip"]
+           "optimizer.hip", "train_gemm.hip", "train_ops.hip", "train_attn.hip", "encodec.hip", "big_gemm.hip", "train_glue.hip", "train_kvbank.hip",
+           "long_kernel.hip"]
 
 F32, BF16, FP8 = 0, 1, 2
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_SILU = 0, 1, 2, 3, 4
@@ -215,6 +216,13 @@ SYMBOLS = {
     "jen1_deep_error_word": (c_int, [c_int]),
     "jen1_deep_run_mode": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_deep_run_kinds": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    # include/jen1_long.h: the sample-resident long-level kernel
+    "jen1_long_geometry": (c_int, [c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
+    "jen1_long_phase_conv": (c_int, [C.POINTER(ConvArgs), c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "jen1_long_phase_lds": (c_int, [_P]),
+    "jen1_long_phase_units": (c_int, [_P]),
+    "jen1_long_run": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "jen1_long_debug_buffer": (c_int, [_P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),
     "jen1_abi_version": (c_int, []),
@@ -233,7 +241,7 @@ def build(verbose: bool = False) -> str:
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "jen1_hip.h"), os.path.join(INCLUDE, "jen1_train.h"),
-            os.path.join(INCLUDE, "jen1_deep.h")]
+            os.path.join(INCLUDE, "jen1_deep.h"), os.path.join(INCLUDE, "jen1_long.h")]
     hdrs += [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h") and h != "common.h"]
     deps = srcs + hdrs
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):

@@ -1,0 +1,171 @@
+"""-m gpu: the sample-resident long-level kernel (include/jen1_long.h, csrc/long_kernel.hip) against the launch-per-layer path.
+
+to_in, the levels above the deep ones and to_out (reference jen1/model/model.py:243-262; blocks.py:98-145, :168-231, :540-650, :653-764)
+run as two launches of 256 resident workgroups, sample b on workgroups b, b + B, ...; the golden / oracle parity of the whole model is
+tests/test_gpu_model.py (the default plans use these launches).  Here EVERY intermediate activation of the two execution paths is
+compared, the launches are replayed on unchanged inputs (fixed-order statistics: bit-reproducible), the ticket form is compared with
+the static one, and configurations that do not fit fall back to one launch per layer.
+"""
+import numpy as np
+import pytest
+import torch
+
+from jen1_amd import synth
+from jen1_amd.config import full_model_config, tiny_model_config
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def full_f32():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
+
+
+@pytest.fixture(scope="module")
+def full_bf16():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from jen1_amd.model import UNetCFG1d
+    return UNetCFG1d(**full_model_config(), init_seed=1234, compute_dtype="bf16", device="cuda")
+
+
+def run_plan(model, plan, x, t, cond, drop=None):
+    s = torch.cuda.current_stream().cuda_stream
+    model._prepare(plan, dev(x), dev(t), dev(cond["cross_attn_cond"]), dev(cond["cross_attn_masks"]), [dev(cond["input_concat_cond"])], drop)
+    plan.run(s)
+    torch.cuda.synchronize()
+
+
+def make_plan(model, B, T, nrep, causal, long_levels: bool):
+    """a plan with the persistent deep-level launch, with or without the two sample-resident long-level launches around it (built
+    directly: the engine's plan cache is keyed without the knob)"""
+    from jen1_amd.engine import Plan
+    eng = model.engine()
+    old = eng.use_long
+    eng.use_long = long_levels
+    try:
+        return Plan(eng, B, T, nrep, causal, None, deep=True)
+    finally:
+        eng.use_long = old
+
+
+def compare_acts(pa, pb, tol):
+    assert len(pa.acts) == len(pb.acts), (len(pa.acts), len(pb.acts))
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(pa.acts, pb.acts)):
+        ra, rb = a.t[:, :, : a.C].float(), b.t[:, :, : b.C].float()
+        if not torch.isfinite(rb).all() or float(rb.abs().max()) == 0.0:
+            continue
+        assert torch.isfinite(ra).all(), f"activation {i}: a sentinel / non-finite value survived"
+        e = float((ra - rb).abs().max()) / float(rb.abs().max())
+        worst = max(worst, e)
+        assert e < tol, f"activation {i} of {len(pa.acts)} (shape {tuple(a.t.shape)}): {e:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("B,T,nrep,causal", [(8, 1500, 1, False), (2, 1500, 2, True), (8, 1500, 2, False), (3, 1499, 1, False), (1, 9000, 2, True)],
+                         ids=["B8", "B2-pair-causal", "B8-pair", "B3-T1499", "T9000-pair-causal"])
+def test_long_levels_equal_launch_path_f32(full_f32, B, T, nrep, causal):
+    """every activation of the plan with the two long-level launches against the plan that runs those levels one launch per layer
+    (float32: 2e-5); the long-level programs alone, twice, on unchanged inputs: bit-identical (fixed-order statistics, no atomics)"""
+    model = full_f32
+    pn = make_plan(model, B, T, nrep, causal, True)
+    pl = make_plan(model, B, T, nrep, causal, False)
+    assert pn.long_levels >= 1 and not pn.long_errors, pn.long_errors
+    kinds = [p.kinds[0] for p in pn.progs]
+    assert kinds[0] == "long" and kinds[-1] == "long" and "gemm" in kinds, kinds
+    assert len(pn.progs[0]) >= 19 and len(pn.progs[-1]) >= 19, [len(p) for p in pn.progs]
+    assert pl.long_levels == 0 and all(p.kinds[0] != "long" for p in pl.progs)
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "music_cont" if causal else "text_guided")
+    t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+    run_plan(model, pl, x, t, cond)
+    run_plan(model, pn, x, t, cond)
+    assert pn.take_error() == 0
+    worst = compare_acts(pn, pl, 2e-5)
+    s = torch.cuda.current_stream().cuda_stream
+    for prog, out in ((pn.progs[0], pn.taps[f"down{pn.long_levels - 1}"].t), (pn.progs[-1], pn.net_out.t)):
+        res = []
+        for _ in range(2):
+            prog.poison(s)
+            prog.launch(s)
+            torch.cuda.synchronize()
+            res.append(out.clone())
+        assert pn.take_error() == 0
+        assert torch.isfinite(res[0].float()).all() and torch.equal(res[0], res[1]), "two runs of a long-level program differ bitwise"
+    print(f"long levels B={B} T={T} nrep={nrep}: {pn.n_launch} launches (one launch per layer there: {pl.n_launch}), worst activation difference {worst:.2e}")
+
+
+def test_long_levels_ticket_form_equals_static(full_f32):
+    """the ticket form of the launch (any number of resident workgroups makes progress: what a plan uses while another program holds the
+    device's static schedule) computes the same bits as the static form: each long-level program alone, on unchanged inputs"""
+    model = full_f32
+    B, T = 8, 1500
+    pn = make_plan(model, B, T, 1, False, True)
+    assert pn.long_levels >= 1
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "text_guided")
+    t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+    run_plan(model, pn, x, t, cond)
+    assert pn.take_error() == 0
+    s = torch.cuda.current_stream().cuda_stream
+    lead = pn.progs[0]
+    was = lead.exclusive
+    try:
+        for prog, out in ((pn.progs[0], pn.taps[f"down{pn.long_levels - 1}"].t), (pn.progs[-1], pn.net_out.t)):
+            res = []
+            for form in (True, False, False):
+                lead.exclusive = form
+                prog.sync.zero_()                     # (the ticket counter: part of the per-step arena reset in a plan)
+                prog.poison(s)
+                prog.launch(s)
+                torch.cuda.synchronize()
+                res.append(out.clone())
+            assert pn.take_error() == 0
+            assert torch.isfinite(res[0].float()).all()
+            assert torch.equal(res[0], res[1]) and torch.equal(res[1], res[2]), "the ticket form and the static form differ bitwise"
+    finally:
+        lead.exclusive = was
+    # and through the whole plan (the pack kernel's statistics use float atomics: compared at the float32 tolerance)
+    ref = [a.t.clone() for a in pn.acts]
+    lead.exclusive = False
+    try:
+        run_plan(model, pn, x, t, cond)
+    finally:
+        lead.exclusive = was
+    assert pn.take_error() == 0
+    for i, (a, r) in enumerate(zip(pn.acts, ref)):
+        ra, rb = a.t[:, :, : a.C].float(), r[:, :, : a.C].float()
+        if torch.isfinite(rb).all() and float(rb.abs().max()) > 0:
+            assert float((ra - rb).abs().max()) <= 2e-5 * float(rb.abs().max()), i
+
+
+def test_long_levels_bf16(full_bf16):
+    """bf16 storage: close to the launch path on every activation, same final output within bf16 rounding"""
+    B, T = 8, 1500
+    x, cond = synth.latents(B, T), synth.conditioning(B, T, "text_guided")
+    t = np.array([(131 * i + 7) % 1000 for i in range(B)], dtype=np.int64)
+    pn = make_plan(full_bf16, B, T, 1, False, True)
+    pl = make_plan(full_bf16, B, T, 1, False, False)
+    assert pn.long_levels >= 1 and len(pn.progs) == 3
+    run_plan(full_bf16, pl, x, t, cond)
+    run_plan(full_bf16, pn, x, t, cond)
+    assert pn.take_error() == 0
+    worst = compare_acts(pn, pl, 6e-2)
+    print(f"long levels bf16: {pn.n_launch} launches (launch path {pl.n_launch}), worst activation difference {worst:.2e}")
+
+
+def test_configurations_that_do_not_fit_keep_one_launch_per_layer():
+    """the tiny configuration (64 channels: an M block of 128 GEMM rows does not exist) refuses the long-level launch and runs as before"""
+    from jen1_amd.model import UNetCFG1d
+    model = UNetCFG1d(**tiny_model_config(), init_seed=1234, compute_dtype="f32", device="cuda")
+    p = model.engine().plan(2, 300, 2, False)
+    assert p.long_levels == 0 and all(pr.kinds[0] != "long" for pr in p.progs)
+    x, cond = synth.latents(2, 300), synth.conditioning(2, 300, "text_guided")
+    run_plan(model, p, x, np.array([999, 499], dtype=np.int64), cond)
+    assert torch.isfinite(p.net_out.t.float()).all()
