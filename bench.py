@@ -266,7 +266,8 @@ def deep_roofline(st, dtype):
     t_zero = graph_time_ms(zero)
     t_both = graph_time_ms(both)
     ms = t_both - t_zero
-    assert prog.error() == 0, "deep kernel: dependency wait timed out"
+    e_ = prog.error()
+    assert e_ == 0, f"deep kernel: dependency wait timed out (error word {e_:#x})"
     alg = op.w_bytes + op.act_bytes
     achieved = alg / (ms * 1e-3) / 1e9
     pm = pmc_entry("deep_kernel") or {}
@@ -293,14 +294,17 @@ def conv_roofline(st, reps=3):
     plan = st.plan
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
-    convs = [op for op in plan.ops if getattr(op, "kind", "") == "conv_gemm"]
+    FAM = ("conv_gemm", "long")        # launch-per-layer convs and the sample-resident launches that replace them (include/jen1_long.h)
+    convs = [op for op in plan.ops if getattr(op, "kind", "") in FAM]
     n = len(convs)
+    n_long = sum(1 for op in convs if op.kind == "long")
+    long_phases = sum(len(op.prog) for op in convs if op.kind == "long")
     tot_ms = 0.0
     per_op = np.zeros(n)
     for rep in range(reps + 1):
         evs = []
         for op in plan.ops:
-            if getattr(op, "kind", "") == "conv_gemm":
+            if getattr(op, "kind", "") in FAM:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 op(s)
@@ -316,17 +320,19 @@ def conv_roofline(st, reps=3):
         tot_ms += float(d.sum())
     per_op /= reps
     # the figure that feeds `achieved`: conv-family launches only, as one replayed graph
+    # (a sample-resident launch polls tensors that start the step poisoned: the step's poisoning node rides along in the replayed family)
+    fam_ops = ([op for op in plan.ops if getattr(op, "kind", "") == "deep_poison"] if n_long else []) + convs
     side = torch.cuda.Stream()
     side.wait_stream(stream)
     with torch.cuda.stream(side):
-        for op in convs:
+        for op in fam_ops:
             op(side.cuda_stream)
     stream.wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with capture_graph(g):
         cs = torch.cuda.current_stream().cuda_stream
-        for op in convs:
+        for op in fam_ops:
             op(cs)
     R = 20
     g.replay()
@@ -358,8 +364,13 @@ def conv_roofline(st, reps=3):
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_busy_pct": mfma_busy,
         "mfma": {"bound": "mfma", "achieved": round(flops / (conv_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                  "frac": round(flops / (conv_ms * 1e-3) / 1e12 / 2500.0, 5)},
-        "kernel": "jen1_conv_gemm launches of the levels above the persistent launch: tile_gemm_kernel<*> (fused GroupNorm+FiLM+SiLU "
-                  "prologue + conv implicit GEMM) and the few stream_gemm / conv_gemm launches among them",
+        "kernel": (f"long_kernel<*> (include/jen1_long.h): {n_long} sample-resident launches, {long_phases} phases (one convolution each: fused "
+                   "GroupNorm+FiLM+SiLU prologue from fixed-order partial statistics + conv implicit GEMM), sample b on workgroups b, b + B, ...; "
+                   "timed together with the step's poisoning node" if n_long else
+                   "jen1_conv_gemm launches of the levels above the persistent launch: tile_gemm_kernel<*> (fused GroupNorm+FiLM+SiLU "
+                   "prologue + conv implicit GEMM) and the few stream_gemm / conv_gemm launches among them"),
+        "sample_resident_launches": n_long, "phases": long_phases,
+        "us_per_layer": round(conv_ms * 1e3 / max(1, long_phases + (n - n_long)), 2),
         "launches_per_step": n, "avg_launch_us": round(conv_ms * 1e3 / n, 2), "conv_ms_per_step": round(conv_ms, 4),
         "conv_ms_per_step_eager_with_event_pairs": round(eager_ms, 4),
         "alg_bytes_per_step": int(alg), "alg_weight_bytes": int(w_bytes), "alg_act_bytes": int(a_bytes),

@@ -50,6 +50,7 @@ extern "C" {
 #define JEN1_LONG_MAX_PHASES 128
 #define JEN1_LONG_MAX_NF 6            /* 16-position fragments per unit: a tile has at most 96 positions */
 #define JEN1_LONG_BM 128              /* GEMM rows per unit: 8 waves x one 16-row M tile */
+#define JEN1_LONG_MAX_KS 64           /* k-steps (32 input channels of one tap each) of a phase */
 
 typedef struct jen1_long_src {
   const void* x;              /* [B][L_in][ld] in the launch dtype */
@@ -89,7 +90,13 @@ typedef struct jen1_long_phase {
   int32_t st_gran[2];         /* channels per statistics entry of source k as the consumer sees them (16, or ld / 32 for totals) */
   int32_t tab_off, st_off, lds_bytes;             /* LDS byte offsets behind the staged tile; total */
   float inv_count, gn_eps, src1_scale, inv_vpr;
-  int32_t reserved_[42];
+  /* log2 of mblocks, out_C, gn_cpg and st_gran[k] (all powers of two in a phase that jen1_long_phase_conv accepts; gn_cpg / st_gran only
+   * when gn_groups > 1): the unit's index arithmetic is shifts */
+  int32_t mb_shift, outc_shift, cpg_shift, gran_shift[2];
+  /* element offset into the staged tile of k-step ks: tap * pitch + 32 * chunk in (tap, chunk) order, then the extra chunks at the
+   * centre row (pad_left * pitch + cmain + 32 j) */
+  uint16_t koff[JEN1_LONG_MAX_KS];
+  int32_t reserved_[5];
 } jen1_long_phase;
 
 /* geometry of a phase with M GEMM rows and L_out GEMM positions on G workgroups per sample: mblocks = M / 128, tiles = G / mblocks
@@ -120,9 +127,18 @@ int jen1_long_phase_units(const jen1_long_phase* p);
  * runs at most ONE static persistent launch per device at a time, like jen1_deep_run_mode with tickets = 0).  ticket = one uint32 that
  * is ZERO when the launch starts: units are handed out by ticket, the launch makes progress with any number of resident workgroups
  * and may share the GPU with other persistent launches.
+ * local = 1 (static form, B a multiple of 8, nwg a multiple of 8): a sample's group of workgroups sits on ONE XCD (workgroup i runs on
+ * XCD i % 8), so the phases' outputs are stored PLAIN -- they stay in that XCD's L2 where the readers' L1-bypassing polls find them
+ * (the hand-off costs ~0.3 us instead of ~0.5 - 0.6 written through) and are written back when the kernel ends.  The caller checks the
+ * placement rule once per device with jen1_long_census; a workgroup that finds itself on another XCD raises the error word
+ * (0x40000000 | workgroup) instead of computing garbage silently.
  * Every tensor and every partial array the phases write must be poisoned (jen1_deep_poison) between the previous launch's last
  * reader and this launch.  Capturable. */
-int jen1_long_run(const void* descs_dev, int n_phases, int B, uint32_t* err, uint32_t* ticket, int nwg, int lds_bytes, int dtype, void* stream);
+int jen1_long_run(const void* descs_dev, int n_phases, int B, uint32_t* err, uint32_t* ticket, int nwg, int lds_bytes, int dtype, int local,
+                  void* stream);
+
+/* one launch of the kernel's shape (nwg workgroups x 512 threads, one per CU): out_dev[i] = the XCD (HW_REG_XCC_ID) workgroup i ran on */
+int jen1_long_census(int* out_dev, int nwg, void* stream);
 
 /* tuning builds (-DJEN1_LONG_PROFILE): per (phase, workgroup) 8 stamps of the 100 MHz counter */
 int jen1_long_debug_buffer(void* p);

@@ -116,21 +116,27 @@ __device__ __forceinline__ void raw_to_float(const Raw8<float>& r, float (&o)[8]
   }
 }
 // The all-ones 8-byte word is reserved ("not stored yet", include/jen1_deep.h): every live store breaks exactly that pattern
-template <typename G>
+// LOC: every reader of the word runs on the XCD of the writer (a sample's group of workgroups on one XCD): a PLAIN store -- the line
+// stays in that XCD's L2, where the readers' L1-bypassing polls find it (0.30 us hand-off against 0.47 - 0.60 written through,
+// tools/xcd_handoff_probe.hip; a plain store never arrives on ANOTHER XCD before the kernel ends)
+template <bool LOC, typename G>
 __device__ __forceinline__ void st_word(G* p, int i, unsigned lo, unsigned hi) {
   lo -= ((lo & hi) == 0xffffffffu) ? 1u : 0u;
-  __hip_atomic_store(g64(p) + i, ((u64)hi << 32) | lo, RLX_AGENT);
+  if constexpr (LOC) *(g64(p) + i) = ((u64)hi << 32) | lo;
+  else __hip_atomic_store(g64(p) + i, ((u64)hi << 32) | lo, RLX_AGENT);
 }
+template <bool LOC>
 __device__ __forceinline__ void st_live4(bf16_t* p, const float (&v)[4]) {
   bf16x4 a;
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
   const u32x2 w = __builtin_bit_cast(u32x2, a);
-  st_word(p, 0, w[0], w[1]);
+  st_word<LOC>(p, 0, w[0], w[1]);
 }
+template <bool LOC>
 __device__ __forceinline__ void st_live4(float* p, const float (&v)[4]) {
-  st_word(p, 0, __float_as_uint(v[0]), __float_as_uint(v[1]));
-  st_word(p, 1, __float_as_uint(v[2]), __float_as_uint(v[3]));
+  st_word<LOC>(p, 0, __float_as_uint(v[0]), __float_as_uint(v[1]));
+  st_word<LOC>(p, 1, __float_as_uint(v[2]), __float_as_uint(v[3]));
 }
 template <typename T> struct Raw4;
 template <> struct Raw4<bf16_t> { u64 d[1]; };
@@ -201,7 +207,7 @@ template <typename T> struct LongCfg;
 #define JEN1_LONG_RING_B 24
 #endif
 #ifndef JEN1_LONG_VB_B
-#define JEN1_LONG_VB_B 6
+#define JEN1_LONG_VB_B 5
 #endif
 #ifndef JEN1_LONG_RING_F
 #define JEN1_LONG_RING_F 12
@@ -276,23 +282,27 @@ __device__ __forceinline__ const T* src_vec_ptr(const SrcTab t, int v, bool& lv)
 
 // ---- (0) the unit's weight slice: wave wv owns M tile mblk * 8 + wv; the first RING k-steps -------------------------------------------
 template <typename T>
-__device__ __forceinline__ void ring_fill(const DescRegs& dr, int slot, int lane, int wv, typename LFrag<T>::type (&ring)[LongCfg<T>::RING]) {
-  constexpr int RING = LongCfg<T>::RING;
+__device__ __forceinline__ void ring_fill(const DescRegs& dr, int slot, int lane, int wv, typename LFrag<T>::type (&ringA)[LongCfg<T>::RING / 2],
+                                          typename LFrag<T>::type (&ringB)[LongCfg<T>::RING / 2]) {
+  constexpr int HR = LongCfg<T>::RING / 2;
   constexpr unsigned ES = sizeof(T), BLK = 512 * ES;
-  const int mblocks = LI(mblocks), MT = LI(MT), KS = LI(KS);
-  const int mblk = slot % mblocks;
+  const int MT = LI(MT), KS = LI(KS);
+  const int mblk = slot & (LI(mblocks) - 1);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(LP(w, const void*)), 0, LI(w_bytes), RSRC_FLAGS);
   const unsigned voff = (unsigned)(mblk * 8 + wv) * BLK + (unsigned)lane * (8u * ES);
   const unsigned step = (unsigned)MT * BLK;
 #pragma unroll
-  for (int s = 0; s < RING; ++s) wload(ring[s], rw, s < KS ? voff : OOB, s < KS ? (unsigned)s * step : 0u);
+  for (int s = 0; s < HR; ++s) wload(ringA[s], rw, s < KS ? voff : OOB, s < KS ? (unsigned)s * step : 0u);
+#pragma unroll
+  for (int s = 0; s < HR; ++s) wload(ringB[s], rw, HR + s < KS ? voff : OOB, HR + s < KS ? (unsigned)(HR + s) * step : 0u);
 }
 
 // ======================================================================================================================================
 // one unit: sample b, slot (= entry index of its partials) of phase dr
 // ======================================================================================================================================
-template <typename T>
-__device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, LSync& sy, typename LFrag<T>::type (&ring)[LongCfg<T>::RING], int tid) {
+template <typename T, bool LOC>
+__device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, LSync& sy, typename LFrag<T>::type (&ringA)[LongCfg<T>::RING / 2],
+                                          typename LFrag<T>::type (&ringB)[LongCfg<T>::RING / 2], int tid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef typename LFrag<T>::type Frag;
   constexpr bool PRECISE = is_f32<T>::value;
@@ -303,8 +313,8 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
   const int li = lane & 15, lg = lane >> 4;
   LK_STAMP(sy, 0);
   // ---- geometry (all scalar) -------------------------------------------------------------------------------------------------------
-  const int mblocks = LI(mblocks), tb = LI(tb);
-  const int mblk = slot % mblocks, tt = slot / mblocks;
+  const int tb = LI(tb);
+  const int mblk = slot & (LI(mblocks) - 1), tt = slot >> LI(mb_shift);
   const int t0 = tt * tb;
   const int L_in = LI(L_in), L_out = LI(L_out), stride = LI(stride), taps = LI(taps), pad_left = LI(pad_left);
   const int cmain = LI(cmain), call = LI(call), pitch = LI(pitch), kch = LI(kch), KS = LI(KS), MT = LI(MT), NF = LI(NF);
@@ -320,28 +330,8 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
   float* tabS = tabA + cmain;
   float2* stl = reinterpret_cast<float2*>(smem + LI(st_off));        // [2 sources][32 entries] (sum, sumsq)
 
-  // ---- per-channel parameters of the prologue and the bias: requested before the wait ------------------------------------------------
-  float g1 = 0.f, g2 = 0.f;
-  if (gn && tid < cmain) {
-    const int p_ld = LI(p_ld);
-    const int* fstep = LP(film_step, const int*);
-    const int* frow = LP(film_row, const int*);
-    const int fr = p_ld ? (fstep ? fstep[0] : (frow ? frow[b] : b)) : 0;
-    const size_t po = (size_t)((unsigned)fr * (unsigned)p_ld) + (unsigned)tid;
-    g1 = LP(p1, const float*)[po];
-    g2 = LP(p2, const float*)[po];
-  }
-  const int out_C = LI(out_C), ps_f = LI(ps_f), ps_off = LI(ps_off), L_y = LI(L_y), y_brows = LI(y_brows), y_row0 = LI(y_row0);
-  const int m0 = mblk * JEN1_LONG_BM;                        // first GEMM row of the unit; one sub-pixel phase per M block (out_C % 128 == 0)
-  const int ph = m0 / out_C;
-  const int co = (m0 - ph * out_C) + wv * 16 + lg * 4;       // this lane's 4 consecutive output channels
-  f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  {
-    const float* biasp = LP(bias, const float*);
-    if (biasp) bias4 = *reinterpret_cast<const f32x4*>(biasp + co);
-  }
-
-  // ---- (1) addresses of the staging vectors + the statistics words; the polled round ----------------------------------------------------
+  // ---- (1) addresses of the staging vectors + the statistics words; the polled round goes out FIRST, everything else of the set-up
+  // (parameters of the prologue, bias, output rows, the residual's addresses) is computed while it is in flight ------------------------------
   const int vpr = call >> 3;
   const float inv_vpr = LF(inv_vpr);
   const int nvec = rows_in * vpr;
@@ -364,15 +354,20 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
       if (v0 + k * NT < nvec) bt.gp[k] = vec_ptr(v0 + k * NT + tid, bt.lv[k]);
     }
   };
-  auto load_batch = [&](Batch& bt, int v0) __attribute__((always_inline)) -> bool {
-    bool bad = false;
+  auto issue_batch = [&](Batch& bt, int v0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < MAXVB; ++k) {
       if (v0 + k * NT < nvec) {
         if (bt.lv[k]) ld_live(bt.x[k], bt.gp[k]);
         else ld_plain(bt.x[k], bt.gp[k]);
-        bad |= bt.lv[k] && raw_bad(bt.x[k]);
       }
+    }
+  };
+  auto batch_bad = [&](const Batch& bt, int v0) __attribute__((always_inline)) -> bool {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < MAXVB; ++k) {
+      if (v0 + k * NT < nvec) bad |= bt.lv[k] && raw_bad(bt.x[k]);
     }
     return bad;
   };
@@ -402,31 +397,56 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
     }
     return bad;
   };
+  issue_stats();
+  issue_batch(cur, 0);
   u64 t0w = 0, t1w = 0;
   if (tot0 && wv == 0 && lane < 32) t0w = q0[lane];
   if (tot1 && wv == 0 && lane < 32) t1w = q1[lane];
   LK_STAMP(sy, 1);
+
+  // ---- behind the first polled round: per-channel parameters of the prologue, bias, output rows, the residual -------------------------------
+  float g1 = 0.f, g2 = 0.f;
+  if (gn && tid < cmain) {
+    const int p_ld = LI(p_ld);
+    const int* fstep = LP(film_step, const int*);
+    const int* frow = LP(film_row, const int*);
+    const int fr = p_ld ? (fstep ? fstep[0] : (frow ? frow[b] : b)) : 0;
+    const size_t po = (size_t)((unsigned)fr * (unsigned)p_ld) + (unsigned)tid;
+    g1 = LP(p1, const float*)[po];
+    g2 = LP(p2, const float*)[po];
+  }
+  const int out_C = LI(out_C), ps_f = LI(ps_f), ps_off = LI(ps_off), L_y = LI(L_y), y_brows = LI(y_brows), y_row0 = LI(y_row0);
+  const int m0 = mblk * JEN1_LONG_BM;                        // first GEMM row of the unit; one sub-pixel phase per M block (out_C % 128 == 0)
+  const int ph = m0 >> LI(outc_shift);
+  const int co = (m0 - ph * out_C) + wv * 16 + lg * 4;       // this lane's 4 consecutive output channels
+  f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* biasp = LP(bias, const float*);
+    if (biasp) bias4 = *reinterpret_cast<const f32x4*>(biasp + co);
+  }
+  constexpr int NFM = JEN1_LONG_MAX_NF;
   {
     unsigned spins = 0;
-    bool bad;
-    do {
+    bool bad = batch_bad(cur, 0) | stats_bad();
+    while (poll_again(sy, bad, spins)) {
       issue_stats();
-      bad = load_batch(cur, 0);
-      bad |= stats_bad();
-    } while (poll_again(sy, bad, spins));
+      issue_batch(cur, 0);
+      bad = batch_bad(cur, 0) | stats_bad();
+    }
   }
   LK_STAMP(sy, 2);
 
   // ---- (2) partials -> sub-sums in LDS -> the affine pair of every channel ------------------------------------------------------------------
   if (gn) {
-    auto reduce_src = [&](const u64 (&w)[SPL], int ne, int mb, int nsub, float2* dst) __attribute__((always_inline)) {
+    auto reduce_src = [&](const u64 (&w)[SPL], int ne, int nsub, float2* dst) __attribute__((always_inline)) {
       // entry e was written by M block e % mb of its phase: slot wv of it holds channels 16 (wv + 8 cls), cls = (e % mb) * 8 % nsub / 8
+      // = e & 1 for 256 channels (mb is even there: 2 M blocks per sub-pixel phase), 0 for 128
       float s0 = 0.f, qq0 = 0.f, s1 = 0.f, qq1 = 0.f;
 #pragma unroll
       for (int k = 0; k < SPL; ++k) {
         if (k * 64 < ne) {
           const int e = lane + k * 64;
-          const int cls = (((e % mb) * 8) % nsub) >> 3;
+          const int cls = nsub > 8 ? (e & 1) : 0;
           const float s = __uint_as_float((unsigned)w[k]), q = __uint_as_float((unsigned)(w[k] >> 32));
           const bool in = e < ne;
           s0 += (in && cls == 0) ? s : 0.f; qq0 += (in && cls == 0) ? q : 0.f;
@@ -440,32 +460,38 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
         if (nsub > 8) dst[8 + wv] = make_float2(s1, qq1);
       }
     };
-    if (ne0) reduce_src(w0, ne0, LI(st_mblocks[0]), LI(st_nsub[0]), stl);
+    if (ne0) reduce_src(w0, ne0, LI(st_nsub[0]), stl);
     else if (wv == 0 && lane < 32) stl[lane] = make_float2(__uint_as_float((unsigned)t0w), __uint_as_float((unsigned)(t0w >> 32)));
-    if (ne1) reduce_src(w1, ne1, LI(st_mblocks[1]), LI(st_nsub[1]), stl + 32);
+    if (ne1) reduce_src(w1, ne1, LI(st_nsub[1]), stl + 32);
     else if (tot1 && wv == 0 && lane < 32) stl[32 + lane] = make_float2(__uint_as_float((unsigned)t1w), __uint_as_float((unsigned)(t1w >> 32)));
   }
   __syncthreads();              // (also: every wave has left the previous unit's MFMA loop before the tile is written again)
   if (gn && tid < cmain) {
     const int c = tid;
-    const int groups = LI(gn_groups), cpg = LI(gn_cpg);
+    const int groups = LI(gn_groups);
     const bool k1 = c >= c0;
-    const int gran = k1 ? LI(st_gran[1]) : LI(st_gran[0]);
     int i0, cnt;
     if (groups == 1) {
       i0 = 0;
       cnt = k1 ? LI(st_nsub[1]) : LI(st_nsub[0]);        // one group over everything (Patcher / Unpatcher, blocks.py:251, :279)
     } else {
-      const int g = c / cpg;
-      const int lo = g * cpg - (k1 ? c0 : 0);
-      i0 = lo / gran;
-      cnt = cpg / gran;
+      const int cs = LI(cpg_shift), gs = k1 ? LI(gran_shift[1]) : LI(gran_shift[0]);
+      const int lo = ((c >> cs) << cs) - (k1 ? c0 : 0);
+      i0 = lo >> gs;
+      cnt = 1 << (cs - gs);
     }
     const float2* rk = stl + (k1 ? 32 : 0);
     float s = 0.f, q = 0.f;
-    for (int i = i0; i < i0 + cnt && i < 32; ++i) {
-      const float2 e2 = rk[i];
-      s += e2.x; q += e2.y;
+    // (entries in fixed order; four independent reads in flight)
+    for (int i = 0; i < cnt; i += 4) {
+      float2 e4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e4[j] = rk[(i + j < cnt) ? i0 + i + j : i0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s += (i + j < cnt) ? e4[j].x : 0.f;
+        q += (i + j < cnt) ? e4[j].y : 0.f;
+      }
     }
     const float sc = k1 ? LF(src1_scale) : 1.0f;
     s *= sc;
@@ -490,7 +516,8 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
       unsigned spins = 0;
       bool bad;
       do {
-        bad = load_batch(cur, v0);
+        issue_batch(cur, v0);
+        bad = batch_bad(cur, v0);
       } while (poll_again(sy, bad, spins));
     }
 #pragma unroll
@@ -526,22 +553,16 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
       store8(tile + row * pitch + c, x);
     }
   }
-  // the residual of the epilogue: requested here, its round trip hides behind the loop
-  const T* resb = LP(residual, const T*);
-  const bool reslive = resb && ((live >> 8) & 1);
-  const int ld_res = LI(ld_res), ld_y = LI(ld_y);
   __syncthreads();
   LK_STAMP(sy, 4);
 
   // ---- (4), (5): MFMA loop and epilogue, specialised by the number of position fragments ----------------------------------------------------
   float* const out_part = LP(out_part, float*);
-  // (ONE body with guarded fragments: specialised copies per fragment count make the compiler hoist every copy's address arithmetic
-  // above the dispatch -- all of it live at once: 150 spilled registers)
   {
-    constexpr int NFW = JEN1_LONG_MAX_NF;
-    int ldsrow[NFW], yrow[NFW];
+    constexpr int HR = RING / 2;
+    int ldsrow[NFM], yrow[NFM];
 #pragma unroll
-    for (int nf = 0; nf < NFW; ++nf) {
+    for (int nf = 0; nf < NFM; ++nf) {
       const int n = nf * 16 + li;
       ldsrow[nf] = ((n < tb ? n : 0) * stride) * pitch + lg * 8;
       const int q = t0 + n;
@@ -549,64 +570,112 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
       const bool ok = nf < NF && n < tb && q < L_out && ty >= 0 && ty < L_y;
       yrow[nf] = ok ? b * y_brows + y_row0 + ty : -1;
     }
-    Raw4<T> rr[NFW];
-    auto load_res = [&]() __attribute__((always_inline)) -> bool {
+    // the residual of the epilogue: requested here, UNCONDITIONALLY (a phase without one reads the first word of its weights): behind a
+    // conditional load the compiler no longer knows how many loads are in flight and waits for ALL of them -- this one included -- before
+    // the first weight fragment is used
+    const T* resb = LP(residual, const T*);
+    const bool reslive = resb && ((live >> 8) & 1);
+    const int ld_res = resb ? LI(ld_res) : 0, ld_y = LI(ld_y);
+    const T* resp = resb ? resb + co : LP(w, const T*);
+    Raw4<T> rr[NFM];
+    auto issue_res = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int nf = 0; nf < NFM; ++nf) ld_live4r(rr[nf], resp + (unsigned)(yrow[nf] < 0 ? 0 : yrow[nf]) * (unsigned)ld_res);
+    };
+    auto res_bad = [&]() __attribute__((always_inline)) -> bool {
       bool bad = false;
 #pragma unroll
-      for (int nf = 0; nf < NFW; ++nf) {
-        if (nf < NF && yrow[nf] >= 0) {
-          ld_live4r(rr[nf], resb + ((unsigned)yrow[nf] * (unsigned)ld_res + (unsigned)co));
-          bad |= reslive && raw_bad(rr[nf]);
-        }
-      }
+      for (int nf = 0; nf < NFM; ++nf) bad |= yrow[nf] >= 0 && raw_bad(rr[nf]);
       return bad;
     };
-    bool rbad = false;
-    if (resb) rbad = load_res();
-    f32x4 acc[NFW];
+    issue_res();
+    f32x4 acc[NFM];
 #pragma unroll
-    for (int nf = 0; nf < NFW; ++nf) acc[nf] = bias4;                 // the accumulators start from the bias
+    for (int nf = 0; nf < NFM; ++nf) acc[nf] = bias4;                 // the accumulators start from the bias
     {
       const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(LP(w, const void*)), 0, LI(w_bytes), RSRC_FLAGS);
       const unsigned voff = (unsigned)(mblk * 8 + wv) * BLK + (unsigned)lane * (8u * ES);
       const unsigned step = (unsigned)MT * BLK;
-      // k-steps in (tap, chunk) order; behind the last tap the extra chunks follow at the centre row, columns cmain + 32 j
-      int c_tap = 0, c_kc = 0;
-      bool in_extra = false;
-      const bool xs = call > cmain;
-      auto kstep = [&](const Frag& a) __attribute__((always_inline)) {
-        const T* bp = tile + c_tap * pitch + c_kc * 32;
+      // k-step ks reads the staged tile at element offset koff[ks] = tap * pitch + 32 chunk ((tap, chunk) order; behind the last tap the
+      // extra chunks at the centre row): tabulated by the host, two per descriptor dword, a field read is one v_readlane.
+      constexpr int KOFF_DW = offsetof(jen1_long_phase, koff) / 4 - 64;
+      static_assert(offsetof(jen1_long_phase, koff) % 4 == 0 && KOFF_DW >= 0 && KOFF_DW + JEN1_LONG_MAX_KS / 2 <= 64, "the k-step table lies in the second descriptor register");
+      auto koff = [&](int ks, bool odd) __attribute__((always_inline)) -> int {
+        const int w2 = __builtin_amdgcn_readlane((int)dr.d1, KOFF_DW + (ks >> 1));
+        return odd ? (int)((unsigned)w2 >> 16) : (w2 & 0xffff);
+      };
+      // HALF a ring round (HR k-steps from one half of the weight ring), one straight-line copy per fragment count: a wave retires an
+      // instruction every ~2 ns here, guards per fragment and k-step cost more than the matrix work.  The copies only READ the ring:
+      // refills happen outside the dispatch (a copy that redefines ring registers leaves the allocator with six-way merges of all 96 of
+      // them -- 150 spilled registers).  Activation fragments of k-step k + 1 are requested before the MFMAs of k-step k (two register
+      // sets by the parity of the slot; HR is even).
+      auto half = [&](auto nfc, const Frag (&rg)[HR], int ksb) __attribute__((always_inline)) {
+        constexpr int NFW = decltype(nfc)::value;
+        // fragment sets in flight: the LDS round trip (~130 clocks) against the matrix work of a k-step (NFW x 32 clocks)
+        constexpr int D = is_f32<T>::value ? 2 : (NFW == 1 ? 4 : NFW == 2 ? 3 : 2);
+        Frag bb[D][NFW];
+        auto bload = [&](Frag (&dst)[NFW], int off) __attribute__((always_inline)) {
+          const T* bp = tile + off;
 #pragma unroll
-        for (int nf = 0; nf < NFW; ++nf) {
-          if (nf < NF) {
-            Frag bfr;
-            llds(bfr, bp + ldsrow[nf]);
-            lmma(acc[nf], a, bfr);
-          }
-        }
-        if (++c_kc == kch && !in_extra) {
-          c_kc = 0;
-          if (++c_tap == taps && xs) { in_extra = true; c_tap = pad_left; c_kc = kch; }
+          for (int nf = 0; nf < NFW; ++nf) llds(dst[nf], bp + ldsrow[nf]);
+        };
+        // straight-line, no guard per k-step (a conditional LDS read makes the compiler wait for ALL reads in flight at every join): a
+        // k-step beyond KS multiplies a ZERO weight fragment (ring slots beyond the slice are out-of-range loads) with the tile's first
+        // rows (the table's entries beyond KS are 0)
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) bload(bb[j], koff(ksb + j, (j & 1) != 0));
+#pragma unroll
+        for (int s = 0; s < HR; ++s) {
+          if (s + D - 1 < HR) bload(bb[(s + D - 1) % D], koff(ksb + s + D - 1, ((s + D - 1) & 1) != 0));
+#pragma unroll
+          for (int nf = 0; nf < NFW; ++nf) lmma(acc[nf], rg[s], bb[s % D][nf]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
+      auto dispatch = [&](const Frag (&rg)[HR], int ksb) __attribute__((always_inline)) {
+        switch (NF) {
+          case 1: half(std::integral_constant<int, 1>(), rg, ksb); break;
+          case 2: half(std::integral_constant<int, 2>(), rg, ksb); break;
+          case 3: half(std::integral_constant<int, 3>(), rg, ksb); break;
+          case 4: half(std::integral_constant<int, 4>(), rg, ksb); break;
+          case 5: half(std::integral_constant<int, 5>(), rg, ksb); break;
+          default: half(std::integral_constant<int, 6>(), rg, ksb); break;
+        }
+      };
+      static_assert(HR % 2 == 0, "the parity of a k-step is the parity of its slot");
       for (int ks0 = 0; ks0 < KS; ks0 += RING) {
+        dispatch(ringA, ks0);
+        if (ks0 + RING < KS) {                            // the next round's first half: in flight during this round's second half
 #pragma unroll
-        for (int s = 0; s < RING; ++s) {
-          if (ks0 + s < KS) {
-            kstep(ring[s]);
-            if (ks0 + s + RING < KS) wload(ring[s], rw, voff, (unsigned)(ks0 + s + RING) * step);
+          for (int s = 0; s < HR; ++s) {
+            const bool in = ks0 + RING + s < KS;
+            wload(ringA[s], rw, in ? voff : OOB, in ? (unsigned)(ks0 + RING + s) * step : 0u);
+          }
+        }
+        if (ks0 + HR < KS) {
+          dispatch(ringB, ks0 + HR);
+          if (ks0 + RING + HR < KS) {
+#pragma unroll
+            for (int s = 0; s < HR; ++s) {
+              const bool in = ks0 + RING + HR + s < KS;
+              wload(ringB[s], rw, in ? voff : OOB, in ? (unsigned)(ks0 + RING + HR + s) * step : 0u);
+            }
           }
         }
       }
     }
     LK_STAMP(sy, 5);
-    if (resb) {
+    if (reslive) {
       unsigned spins = 0;
-      while (poll_again(sy, rbad, spins)) rbad = load_res();
+      bool rbad = res_bad();
+      while (poll_again(sy, rbad, spins)) {
+        issue_res();
+        rbad = res_bad();
+      }
     }
     float gs = 0.f, gq = 0.f;
 #pragma unroll
-    for (int nf = 0; nf < NFW; ++nf) {
+    for (int nf = 0; nf < NFM; ++nf) {
       if (nf < NF && yrow[nf] >= 0) {
         float v[4] = {acc[nf][0], acc[nf][1], acc[nf][2], acc[nf][3]};
         if (resb) {
@@ -615,7 +684,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += r4[r];
         }
-        st_live4(LP(y, T*) + ((unsigned)yrow[nf] * (unsigned)ld_y + (unsigned)co), v);
+        st_live4<LOC>(LP(y, T*) + ((unsigned)yrow[nf] * (unsigned)ld_y + (unsigned)co), v);
         gs += (v[0] + v[1]) + (v[2] + v[3]);
         gq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
       }
@@ -627,7 +696,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
       const float tq = (rlane(gq, 0) + rlane(gq, 16)) + (rlane(gq, 32) + rlane(gq, 48));
       if (lane == 0) {
         const int ne = LI(out_entries);
-        st_word(out_part + 2 * ((size_t)(b * 8 + wv) * ne + slot), 0, __float_as_uint(ts), __float_as_uint(tq));
+        st_word<LOC>(out_part + 2 * ((size_t)(b * 8 + wv) * ne + slot), 0, __float_as_uint(ts), __float_as_uint(tq));
       }
     }
   }
@@ -641,7 +710,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
 // U = B * G unit slots per phase (slots beyond a phase's units are empty).  Whoever holds the smallest unfinished ticket depends only on
 // smaller tickets, which are finished or held by running workgroups: the launch makes progress with ANY number of resident workgroups, so
 // it can share the GPU with other persistent launches.  No cross-phase prefetch: slower, safe.
-template <typename T, bool TK>
+template <typename T, bool TK, bool LOC>
 __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restrict__ descs, int n_phases, int Bs, unsigned* err, unsigned* ticket) {
   typedef typename LFrag<T>::type Frag;
   constexpr int RING = LongCfg<T>::RING;
@@ -652,7 +721,7 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
   LSync sy;
   sy.err = err;
   sy.dead = false;
-  Frag ring[RING];
+  Frag ringA[RING / 2], ringB[RING / 2];
   if constexpr (TK) {
     __shared__ int tick_s;
     const int U = Bs * G, total = n_phases * U;
@@ -667,15 +736,25 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
       const DescRegs dr = load_desc(descs, p, lane);
       if (slot >= LI(out_entries)) continue;
       sy.p = p;
-      ring_fill<T>(dr, slot, lane, wv, ring);
-      long_unit<T>(dr, b, slot, sy, ring, tid);
+      ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
+      long_unit<T, false>(dr, b, slot, sy, ringA, ringB, tid);
     }
     return;
   }
   const int b = wg % Bs, slot = wg / Bs;
   if (slot >= G) return;
+  if constexpr (LOC) {
+    // plain stores reach their readers only inside one XCD: the group of sample b must sit on XCD b % 8 (workgroups are dealt to the
+    // XCDs round-robin: jen1_long_census checks that once per device; this is the guard behind it)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((int)(xcc & 0xfu) != (wg & 7)) {
+      if (tid == 0) __hip_atomic_store(g32(err), 0x40000000u | (unsigned)wg, RLX_AGENT);
+      sy.dead = true;
+    }
+  }
   DescRegs dr = load_desc(descs, 0, lane);
-  if (slot < LI(out_entries)) ring_fill<T>(dr, slot, lane, wv, ring);
+  if (slot < LI(out_entries)) ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
   for (int p = 0; p < n_phases; ++p) {
     const bool more = p + 1 < n_phases;
     DescRegs nx = dr;
@@ -686,7 +765,7 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
 #pragma unroll
     for (int i_ = 0; i_ < 8; ++i_) sy.tt[i_] = 0;
 #endif
-    if (mine) long_unit<T>(dr, b, slot, sy, ring, tid);
+    if (mine) long_unit<T, LOC>(dr, b, slot, sy, ringA, ringB, tid);
 #ifdef JEN1_LONG_PROFILE
     sy.tt[7] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0 && g_long_dbg) {
@@ -697,7 +776,7 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
     if (!more) break;
     dr = nx;
     // the next unit's weight slice: requested right behind this unit's stores, long before its dependency wait ends
-    if (slot < LI(out_entries)) ring_fill<T>(dr, slot, lane, wv, ring);
+    if (slot < LI(out_entries)) ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
   }
 }
 
@@ -848,35 +927,71 @@ extern "C" int jen1_long_phase_conv(const jen1_conv_args* a, int G, const float*
   JEN1_CHECK(tot <= LDS_TOTAL - 1024, "long phase: %d B of LDS", tot);
   p.lds_bytes = tot;
   p.inv_vpr = 1.0f / (float)(call / 8);
+  // (the unit reads table entries up to 14 k-steps beyond KS: zeros, inside the 64-entry table)
+  JEN1_CHECK(p.KS <= JEN1_LONG_MAX_KS - 16, "long phase: %d k-steps (at most %d)", p.KS, JEN1_LONG_MAX_KS - 16);
+  JEN1_CHECK((a->taps - 1) * p.pitch + call < 65536, "long phase: staged tile offsets do not fit 16 bits");
+  {
+    int ks = 0;
+    for (int tap = 0; tap < a->taps; ++tap)
+      for (int c = 0; c < p.kch; ++c) p.koff[ks++] = (uint16_t)(tap * p.pitch + c * 32);
+    for (int j = 0; j < kx; ++j) p.koff[ks++] = (uint16_t)(a->pad_left * p.pitch + cmain + j * 32);
+  }
+  auto log2i = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  p.mb_shift = log2i(mb);
+  p.outc_shift = log2i(a->out_C);
+  JEN1_CHECK(p.mb_shift >= 0 && p.outc_shift >= 0, "long phase: %d M blocks / %d output channels are not powers of two", mb, a->out_C);
+  if (gn && a->gn_groups > 1) {
+    p.cpg_shift = log2i(p.gn_cpg);
+    p.gran_shift[0] = log2i(p.st_gran[0]);
+    p.gran_shift[1] = log2i(p.st_gran[1]);
+    JEN1_CHECK(p.cpg_shift >= 0 && p.gran_shift[0] >= 0 && p.gran_shift[1] >= 0 && p.cpg_shift >= p.gran_shift[0] && p.cpg_shift >= p.gran_shift[1],
+               "long phase: GroupNorm groups of %d channels over statistics entries of %d / %d channels (powers of two)", p.gn_cpg, p.st_gran[0], p.st_gran[1]);
+  }
   return 0;
 }
 
 namespace {
-template <typename T, bool TK>
+template <typename T, bool TK, bool LOC>
 int launch_long(const unsigned char* descs, int n_phases, int B, uint32_t* err, uint32_t* ticket, int nwg, int lds, hipStream_t s) {
-  auto kern = long_kernel<T, TK>;
+  auto kern = long_kernel<T, TK, LOC>;
   JEN1_MAX_LDS_ONCE(kern, LDS_TOTAL - 1024);      // (the ticket form keeps one static LDS word)
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), (size_t)lds, s, descs, n_phases, B, err, ticket);
   JEN1_HIP(hipGetLastError());
   return 0;
+}
+__global__ __launch_bounds__(NT) void census_kernel(int* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[blockIdx.x] = (int)(xcc & 0xfu);
+    smem[0] = 0;
+  }
 }
 }  // namespace
 
 extern "C" int jen1_long_phase_lds(const jen1_long_phase* p) { return p ? p->lds_bytes : 0; }
 extern "C" int jen1_long_phase_units(const jen1_long_phase* p) { return p ? p->out_entries : 0; }
 
+extern "C" int jen1_long_census(int* out_dev, int nwg, void* stream) {
+  JEN1_CHECK(out_dev && nwg >= 1, "long census: bad arguments");
+  JEN1_MAX_LDS_ONCE(census_kernel, LDS_TOTAL - 1024);
+  hipLaunchKernelGGL(census_kernel, dim3(nwg), dim3(NT), (size_t)LDS_MIN, reinterpret_cast<hipStream_t>(stream), out_dev);
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int jen1_long_run(const void* descs_dev, int n_phases, int B, uint32_t* err, uint32_t* ticket, int nwg, int lds_bytes, int dtype,
-                             void* stream) {
+                             int local, void* stream) {
   JEN1_CHECK(descs_dev && err && n_phases >= 1 && n_phases <= JEN1_LONG_MAX_PHASES && B >= 1 && nwg >= B, "long run: bad arguments");
   JEN1_CHECK(lds_bytes > 0 && lds_bytes <= LDS_TOTAL - 1024, "long run: %d B of LDS", lds_bytes);
   JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "long run: bad dtype");
+  JEN1_CHECK(!local || (!ticket && B % 8 == 0 && nwg % 8 == 0), "long run: XCD-local stores need the static form and a multiple of 8 samples (a sample's workgroups on one XCD)");
   const int lds = lds_bytes < LDS_MIN ? LDS_MIN : lds_bytes;       // one workgroup per CU, always
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned char* d = reinterpret_cast<const unsigned char*>(descs_dev);
-  if (ticket) {
-    if (dtype == JEN1_F32) return launch_long<float, true>(d, n_phases, B, err, ticket, nwg, lds, s);
-    return launch_long<bf16_t, true>(d, n_phases, B, err, ticket, nwg, lds, s);
-  }
-  if (dtype == JEN1_F32) return launch_long<float, false>(d, n_phases, B, err, ticket, nwg, lds, s);
-  return launch_long<bf16_t, false>(d, n_phases, B, err, ticket, nwg, lds, s);
+  const bool f32 = dtype == JEN1_F32;
+  if (ticket) return f32 ? launch_long<float, true, false>(d, n_phases, B, err, ticket, nwg, lds, s) : launch_long<bf16_t, true, false>(d, n_phases, B, err, ticket, nwg, lds, s);
+  if (local) return f32 ? launch_long<float, false, true>(d, n_phases, B, err, ticket, nwg, lds, s) : launch_long<bf16_t, false, true>(d, n_phases, B, err, ticket, nwg, lds, s);
+  return f32 ? launch_long<float, false, false>(d, n_phases, B, err, ticket, nwg, lds, s) : launch_long<bf16_t, false, false>(d, n_phases, B, err, ticket, nwg, lds, s);
 }

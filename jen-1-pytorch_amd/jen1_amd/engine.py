@@ -539,14 +539,38 @@ class LongProgram(DeepProgram):
             self.claim_static()
         self.poison_tab = torch.tensor(ent, dtype=torch.int64).view(-1, 2).to(self.eng.device)
         self.poison_bytes = int(sum(ent[1::2]))
+        self.local = self.xcd_local()
+
+    _placement: Dict[str, bool] = {}      # per device: workgroup i of a launch of this shape runs on XCD i % 8 (jen1_long_census)
+
+    def xcd_local(self) -> bool:
+        """may this program keep its outputs in the L2 of the XCD that wrote them?  A sample's workgroups b, b + B, ... sit on ONE XCD
+        when B is a multiple of 8 and workgroups are dealt to the 8 XCDs round-robin -- checked once per device by a census launch;
+        OFF by default (JEN1_LONG_LOCAL=1 switches it on): the placement rule holds on an idle device but NOT for a launch queued right behind
+        other kernels of a replayed graph (measured: workgroup 89 not on XCD 1; the kernel's guard then raises the error word), and HIP
+        promises nothing about it (MI355X_MICROARCH.md, "Workgroup dispatch")"""
+        if os.environ.get("JEN1_LONG_LOCAL", "0") != "1" or self.Bs % 8 or self.nwg % 8:
+            return False
+        key = str(self.eng.device)
+        ok = LongProgram._placement.get(key)
+        if ok is None:
+            out = torch.full((self.nwg,), -1, dtype=torch.int32, device=self.eng.device)
+            ok = True
+            for _ in range(2):
+                L.check(self.lib.jen1_long_census(out.data_ptr(), self.nwg, torch.cuda.current_stream(self.eng.device).cuda_stream), "jen1_long_census")
+                torch.cuda.synchronize(self.eng.device)
+                ok = ok and bool((out.cpu() == (torch.arange(self.nwg, dtype=torch.int32) % 8)).all())
+            LongProgram._placement[key] = ok
+        return ok
 
     def launch(self, stream: int):
         self.touch()
         n = len(self.bufs)
         if os.environ.get("JEN1_LONG_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_LONG_RUN_PHASES"]))
-        L.check(self.lib.jen1_long_run(self.dev.data_ptr(), n, self.Bs, self.err.data_ptr(), None if self.exclusive else self.sync.data_ptr(),
-                                       self.nwg, self.lds, self.eng.dt, stream), "jen1_long_run")
+        static = self.exclusive
+        L.check(self.lib.jen1_long_run(self.dev.data_ptr(), n, self.Bs, self.err.data_ptr(), None if static else self.sync.data_ptr(),
+                                       self.nwg, self.lds, self.eng.dt, 1 if (static and self.local) else 0, stream), "jen1_long_run")
 
 
 class KernelCtx:

@@ -221,7 +221,8 @@ SYMBOLS = {
     "jen1_long_phase_conv": (c_int, [C.POINTER(ConvArgs), c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "jen1_long_phase_lds": (c_int, [_P]),
     "jen1_long_phase_units": (c_int, [_P]),
-    "jen1_long_run": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "jen1_long_run": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "jen1_long_census": (c_int, [_P, c_int, _P]),
     "jen1_long_debug_buffer": (c_int, [_P]),
     "jen1_last_error": (C.c_char_p, []),
     "jen1_build_info": (C.c_char_p, []),

@@ -218,8 +218,11 @@ class UNetCFG1d(nn.Module):
         pend[3] = True
 
     def _raise_deep(self, plan: Plan, e: int) -> None:
+        if e & 0x40000000:
+            raise L.Jen1HipError(f"sample-resident long-level launch: workgroup {e & 0xffff} does not run on XCD {e & 7} (the XCD-local exchange "
+                                 "assumes workgroup i on XCD i % 8); set JEN1_LONG_LOCAL=0 to write the exchange through")
         if e:
-            raise L.Jen1HipError(f"persistent deep-level launch: the wait for phase {e - 1} timed out (another persistent "
+            raise L.Jen1HipError(f"persistent launch: the wait for phase {e - 1} timed out (another persistent "
                                  "launch on the same GPU?); the error word was cleared, the call can be repeated")
 
     def _poll_errors(self) -> None:
