@@ -127,11 +127,13 @@ int jen1_long_phase_units(const jen1_long_phase* p);
  * runs at most ONE static persistent launch per device at a time, like jen1_deep_run_mode with tickets = 0).  ticket = one uint32 that
  * is ZERO when the launch starts: units are handed out by ticket, the launch makes progress with any number of resident workgroups
  * and may share the GPU with other persistent launches.
- * local = 1 (static form, B a multiple of 8, nwg a multiple of 8): a sample's group of workgroups sits on ONE XCD (workgroup i runs on
- * XCD i % 8), so the phases' outputs are stored PLAIN -- they stay in that XCD's L2 where the readers' L1-bypassing polls find them
- * (the hand-off costs ~0.3 us instead of ~0.5 - 0.6 written through) and are written back when the kernel ends.  The caller checks the
- * placement rule once per device with jen1_long_census; a workgroup that finds itself on another XCD raises the error word
- * (0x40000000 | workgroup) instead of computing garbage silently.
+ * local = 1 (B a multiple of 8, nwg a multiple of B and of 8; `ticket` must point at 16 ZERO words): the static form with the groups
+ * formed from where the workgroups actually run -- every workgroup reads its XCD (HW_REG_XCC_ID) and takes a number on it (words
+ * ticket[8 + xcd]); XCD x hosts samples x, x + 8, ... -- so that a sample's group sits on ONE XCD by construction and the phases'
+ * outputs can be stored PLAIN: they stay in that XCD's L2, where the readers' L1-bypassing polls find them (a hand-off costs ~0.3 us
+ * instead of ~0.5 - 0.6 written through), and are written back when the kernel ends.  HIP promises nothing about workgroup -> XCD
+ * placement; what this form needs is only that every XCD holds nwg / 8 workgroups of the launch, which one workgroup per CU and full
+ * residency imply.  A workgroup that finds its XCD full raises the error word (0x40000000 | workgroup).
  * Every tensor and every partial array the phases write must be poisoned (jen1_deep_poison) between the previous launch's last
  * reader and this launch.  Capturable. */
 int jen1_long_run(const void* descs_dev, int n_phases, int B, uint32_t* err, uint32_t* ticket, int nwg, int lds_bytes, int dtype, int local,

@@ -466,6 +466,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
     else if (tot1 && wv == 0 && lane < 32) stl[32 + lane] = make_float2(__uint_as_float((unsigned)t1w), __uint_as_float((unsigned)(t1w >> 32)));
   }
   __syncthreads();              // (also: every wave has left the previous unit's MFMA loop before the tile is written again)
+  LK_STAMP(sy, 3);
   if (gn && tid < cmain) {
     const int c = tid;
     const int groups = LI(gn_groups);
@@ -506,7 +507,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
     tabS[c] = g2 - mean * A;
   }
   if (gn) __syncthreads();
-  LK_STAMP(sy, 3);
+  LK_STAMP(sy, 4);
 
   // ---- (3) stage the tile: prologue applied once, zero padding applied after it ------------------------------------------------------------
   const float sc1 = LF(src1_scale);
@@ -554,7 +555,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
     }
   }
   __syncthreads();
-  LK_STAMP(sy, 4);
+  LK_STAMP(sy, 5);
 
   // ---- (4), (5): MFMA loop and epilogue, specialised by the number of position fragments ----------------------------------------------------
   float* const out_part = LP(out_part, float*);
@@ -664,7 +665,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
         }
       }
     }
-    LK_STAMP(sy, 5);
+    LK_STAMP(sy, 6);
     if (reslive) {
       unsigned spins = 0;
       bool rbad = res_bad();
@@ -700,7 +701,7 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
       }
     }
   }
-  LK_STAMP(sy, 6);
+  LK_STAMP(sy, 7);
 }
 
 // TK = false: the static map -- sample b = workgroup % B, slot = workgroup / B in EVERY phase; the next unit's descriptor and weight
@@ -741,18 +742,29 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
     }
     return;
   }
-  const int b = wg % Bs, slot = wg / Bs;
-  if (slot >= G) return;
+  int b = wg % Bs, slot = wg / Bs;
   if constexpr (LOC) {
-    // plain stores reach their readers only inside one XCD: the group of sample b must sit on XCD b % 8 (workgroups are dealt to the
-    // XCDs round-robin: jen1_long_census checks that once per device; this is the guard behind it)
+    // plain stores reach their readers only inside one XCD, and HIP promises nothing about which XCD a workgroup runs on (observed: workgroup
+    // i on XCD i % 8 on an idle device, a rotation of that behind other kernels).  So the groups are formed from where the workgroups
+    // ACTUALLY are: every workgroup reads its XCD and takes a number t on it (one counter per XCD, zero when the launch starts); XCD x
+    // hosts samples x, x + 8, ... -- sample x + 8 (t / G), slot t % G.  With one workgroup per CU and every workgroup resident each XCD
+    // holds exactly nwg / 8 of them; one that finds its XCD full raises the error word.
+    __shared__ int xt_s;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    if ((int)(xcc & 0xfu) != (wg & 7)) {
+    xcc &= 0xfu;
+    if (tid == 0) xt_s = (int)__hip_atomic_fetch_add(g32(ticket) + 8 + xcc, 1u, RLX_AGENT);
+    __syncthreads();
+    const int t = rfl(xt_s);
+    const int cap = (int)gridDim.x / 8;
+    if (xcc >= 8u || t >= cap) {
       if (tid == 0) __hip_atomic_store(g32(err), 0x40000000u | (unsigned)wg, RLX_AGENT);
-      sy.dead = true;
+      return;
     }
+    b = (int)xcc + 8 * (t / G);
+    slot = t % G;
   }
+  if (slot >= G || b >= Bs) return;
   DescRegs dr = load_desc(descs, 0, lane);
   if (slot < LI(out_entries)) ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
   for (int p = 0; p < n_phases; ++p) {
@@ -767,7 +779,6 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
 #endif
     if (mine) long_unit<T, LOC>(dr, b, slot, sy, ringA, ringB, tid);
 #ifdef JEN1_LONG_PROFILE
-    sy.tt[7] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0 && g_long_dbg) {
 #pragma unroll
       for (int i_ = 0; i_ < 8; ++i_) g_long_dbg[((size_t)p * gridDim.x + wg) * 8 + i_] = sy.tt[i_];
@@ -986,12 +997,13 @@ extern "C" int jen1_long_run(const void* descs_dev, int n_phases, int B, uint32_
   JEN1_CHECK(descs_dev && err && n_phases >= 1 && n_phases <= JEN1_LONG_MAX_PHASES && B >= 1 && nwg >= B, "long run: bad arguments");
   JEN1_CHECK(lds_bytes > 0 && lds_bytes <= LDS_TOTAL - 1024, "long run: %d B of LDS", lds_bytes);
   JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16 || dtype == JEN1_FP8, "long run: bad dtype");
-  JEN1_CHECK(!local || (!ticket && B % 8 == 0 && nwg % 8 == 0), "long run: XCD-local stores need the static form and a multiple of 8 samples (a sample's workgroups on one XCD)");
+  JEN1_CHECK(!local || (ticket && B % 8 == 0 && nwg % B == 0 && nwg % 8 == 0),
+             "long run: XCD-local stores need the zeroed synchronisation words, a multiple of 8 samples and whole groups (a sample's workgroups on one XCD)");
   const int lds = lds_bytes < LDS_MIN ? LDS_MIN : lds_bytes;       // one workgroup per CU, always
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned char* d = reinterpret_cast<const unsigned char*>(descs_dev);
   const bool f32 = dtype == JEN1_F32;
-  if (ticket) return f32 ? launch_long<float, true, false>(d, n_phases, B, err, ticket, nwg, lds, s) : launch_long<bf16_t, true, false>(d, n_phases, B, err, ticket, nwg, lds, s);
   if (local) return f32 ? launch_long<float, false, true>(d, n_phases, B, err, ticket, nwg, lds, s) : launch_long<bf16_t, false, true>(d, n_phases, B, err, ticket, nwg, lds, s);
+  if (ticket) return f32 ? launch_long<float, true, false>(d, n_phases, B, err, ticket, nwg, lds, s) : launch_long<bf16_t, true, false>(d, n_phases, B, err, ticket, nwg, lds, s);
   return f32 ? launch_long<float, false, false>(d, n_phases, B, err, ticket, nwg, lds, s) : launch_long<bf16_t, false, false>(d, n_phases, B, err, ticket, nwg, lds, s);
 }

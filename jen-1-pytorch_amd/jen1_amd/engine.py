@@ -348,6 +348,7 @@ class DeepProgram:
         key = str(self.eng.device)
         ref = DeepProgram._static_owner.get(key)
         owner = None if ref is None else ref()
+        owner = None if owner is None else owner.leader        # (whoever registered a program of a plan meant the plan's leader)
         if owner is not None and owner is not me and owner._exclusive:
             if time.monotonic() - getattr(owner, "_last_use", 0.0) < self.STATIC_IDLE_S:
                 return False
@@ -541,27 +542,17 @@ class LongProgram(DeepProgram):
         self.poison_bytes = int(sum(ent[1::2]))
         self.local = self.xcd_local()
 
-    _placement: Dict[str, bool] = {}      # per device: workgroup i of a launch of this shape runs on XCD i % 8 (jen1_long_census)
-
     def xcd_local(self) -> bool:
-        """may this program keep its outputs in the L2 of the XCD that wrote them?  A sample's workgroups b, b + B, ... sit on ONE XCD
-        when B is a multiple of 8 and workgroups are dealt to the 8 XCDs round-robin -- checked once per device by a census launch;
-        OFF by default (JEN1_LONG_LOCAL=1 switches it on): the placement rule holds on an idle device but NOT for a launch queued right behind
-        other kernels of a replayed graph (measured: workgroup 89 not on XCD 1; the kernel's guard then raises the error word), and HIP
-        promises nothing about it (MI355X_MICROARCH.md, "Workgroup dispatch")"""
-        if os.environ.get("JEN1_LONG_LOCAL", "0") != "1" or self.Bs % 8 or self.nwg % 8:
-            return False
-        key = str(self.eng.device)
-        ok = LongProgram._placement.get(key)
-        if ok is None:
-            out = torch.full((self.nwg,), -1, dtype=torch.int32, device=self.eng.device)
-            ok = True
-            for _ in range(2):
-                L.check(self.lib.jen1_long_census(out.data_ptr(), self.nwg, torch.cuda.current_stream(self.eng.device).cuda_stream), "jen1_long_census")
-                torch.cuda.synchronize(self.eng.device)
-                ok = ok and bool((out.cpu() == (torch.arange(self.nwg, dtype=torch.int32) % 8)).all())
-            LongProgram._placement[key] = ok
-        return ok
+        """may this program keep its outputs in the L2 of the XCD that wrote them (jen1_long_run's ``local`` form)?  The groups are then
+        formed inside the kernel from the XCD every workgroup actually runs on; needs a multiple of 8 samples and one workgroup per CU
+        on 8 XCDs.  OFF by default (JEN1_LONG_LOCAL=1 switches it on): measured at B = 8, T = 1500 the step is not faster with it (836.3 against
+        835.5 steps/s) -- a phase is bound by the consumer's own instruction stream, not by the hand-off."""
+        return os.environ.get("JEN1_LONG_LOCAL", "0") == "1" and self.Bs % 8 == 0 and self.nwg % 8 == 0 and self.nwg % self.Bs == 0
+
+    def poison(self, stream: int, zero=None):
+        # (stand-alone use -- tests, tools: the synchronisation words are part of the plan's per-step arena reset otherwise)
+        L.check(self.lib.jen1_memset_zero(self.sync.data_ptr(), self.sync.numel() * 4, stream), "memset")
+        super().poison(stream, zero)
 
     def launch(self, stream: int):
         self.touch()
@@ -569,8 +560,9 @@ class LongProgram(DeepProgram):
         if os.environ.get("JEN1_LONG_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_LONG_RUN_PHASES"]))
         static = self.exclusive
-        L.check(self.lib.jen1_long_run(self.dev.data_ptr(), n, self.Bs, self.err.data_ptr(), None if static else self.sync.data_ptr(),
-                                       self.nwg, self.lds, self.eng.dt, 1 if (static and self.local) else 0, stream), "jen1_long_run")
+        loc = static and self.local
+        L.check(self.lib.jen1_long_run(self.dev.data_ptr(), n, self.Bs, self.err.data_ptr(), None if (static and not loc) else self.sync.data_ptr(),
+                                       self.nwg, self.lds, self.eng.dt, 1 if loc else 0, stream), "jen1_long_run")
 
 
 class KernelCtx:
@@ -1381,8 +1373,10 @@ class Plan(OpBuilder):
         gn2 = (r.groups, r.c_out, W.v[f"{n}.gn2.g"], W.v[f"{n}.gn2.b"], 1e-5)
         film = (self.film, self.film_row, W.film_off[n], r.c_out, self.step_idx if self.table_mode else None)
         srcs_raw = [src0] + ([src1] if src1 is not None else [])
+        # (a source with padded channels -- the 257-channel network input -- rides along only in the sample-resident launches: their extra
+        # segments read the padded pitch, the padding columns meet zero weights)
         if r.has_shortcut and self.eng.fuse_shortcut and f"{n}.conv2s" in W.w \
-                and all(s_.cp == s_.C for s_ in srcs_raw) and 3 + len(srcs_raw) <= L.MAX_SEG:
+                and (self._long_on or all(s_.cp == s_.C for s_ in srcs_raw)) and 3 + len(srcs_raw) <= L.MAX_SEG:
             # the 1x1 shortcut is one or two more K segments of the second conv (streaming levels, the persistent kernel and the
             # tiled long levels; a wide-tile launch declines and the separate shortcut launch below is used)
             try:
@@ -1390,10 +1384,11 @@ class Plan(OpBuilder):
                              pro=L.PRO_GN_SILU, gn=gn2, film=film, extra_segs=[(s_, 0) for s_ in srcs_raw]) is not None:
                     return y
             except DeepIneligible:
-                if not self._deep_on:
+                if not (self._deep_on or self._long_on):
                     raise
                 # (the persistent kernel stages the whole batch element: with the block's input riding along a 94-position, 768-channel
-                # tile does not fit LDS -- the shortcut becomes a phase of its own below)
+                # tile does not fit LDS -- the shortcut becomes a phase of its own below; the same in a sample-resident launch whose tile
+                # with the extra segment does not fit: float32, CFG pair of 8, the 288-channel network input)
         if r.has_shortcut:
             res = self.new_act(src0.B, src0.L, r.c_out)
             self.conv(ops, src0=src0, src1=src1, src1_scale=1.0, w=W.w[f"{n}.short"], bias=W.v[f"{n}.short.bias"], out=res)

@@ -93,7 +93,7 @@ def concurrent(n):
     old = DeepProgram._static_owner.get(str(m.engine().device))
     if old is not None and old() is not None:
         old().exclusive = False
-    DeepProgram._static_owner[str(m.engine().device)] = weakref.ref(sts[0].plan.deep)
+    DeepProgram._static_owner[str(m.engine().device)] = weakref.ref(sts[0].plan.deep.leader)      # (the plan's first persistent program holds the claim)
     sts[0].plan.deep.exclusive = True
     streams = [torch.cuda.Stream() for _ in range(n)]
     for rep in range(3):

@@ -57,16 +57,30 @@ def make_plan(model, B, T, nrep, causal, long_levels: bool):
 
 
 def compare_acts(pa, pb, tol):
-    assert len(pa.acts) == len(pb.acts), (len(pa.acts), len(pb.acts))
-    worst = 0.0
-    for i, (a, b) in enumerate(zip(pa.acts, pb.acts)):
+    """every activation of plan ``pa`` against its counterpart in ``pb`` (same creation order; ``pb`` may hold a few extra tensors -- the
+    output of a 1x1 shortcut that ``pa`` fused into the block's second conv -- which are skipped: a tensor of ``pb`` that does not match is
+    passed over as long as ``pb`` has tensors to spare)"""
+    def err(a, b):
         ra, rb = a.t[:, :, : a.C].float(), b.t[:, :, : b.C].float()
         if not torch.isfinite(rb).all() or float(rb.abs().max()) == 0.0:
-            continue
-        assert torch.isfinite(ra).all(), f"activation {i}: a sentinel / non-finite value survived"
-        e = float((ra - rb).abs().max()) / float(rb.abs().max())
-        worst = max(worst, e)
-        assert e < tol, f"activation {i} of {len(pa.acts)} (shape {tuple(a.t.shape)}): {e:.3e}"
+            return None
+        assert torch.isfinite(ra).all(), "a sentinel / non-finite value survived"
+        return float((ra - rb).abs().max()) / float(rb.abs().max())
+
+    spare = len(pb.acts) - len(pa.acts)
+    assert 0 <= spare <= 2, (len(pa.acts), len(pb.acts))
+    worst, j = 0.0, 0
+    for i, a in enumerate(pa.acts):
+        while True:
+            b = pb.acts[j]
+            j += 1
+            e = err(a, b) if tuple(a.t.shape) == tuple(b.t.shape) else 1.0
+            if e is None or e < tol or spare == 0:
+                break
+            spare -= 1
+        if e is not None:
+            worst = max(worst, e)
+            assert e < tol, f"activation {i} of {len(pa.acts)} (shape {tuple(a.t.shape)}): {e:.3e}"
     return worst
 
 

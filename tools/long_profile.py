@@ -4,8 +4,8 @@
 Builds a second copy of the library with -DJEN1_LONG_PROFILE (thread 0 of every workgroup stamps the 100 MHz counter at the stages
 of each unit), replays one denoiser step of the bench workload, then each long-level program alone, and prints per phase the mean
 duration of the stages over the workgroups that had a unit:
-  0 unit start | 1 addresses + parameters requested | 2 polled round complete | 3 affine tables | 4 tile staged (+ barrier) |
-  5 MFMA loop done | 6 epilogue stores issued | 7 next unit's weight slice requested (phase loop)
+  0 unit start | 1 polled round issued | 2 polled round complete (wave 0) | 3 statistics reduced + barrier (= every wave's poll complete) |
+  4 affine tables (+ barrier) | 5 tile staged (+ barrier) | 6 MFMA loop done | 7 epilogue stores issued
 
     python tools/long_profile.py [--batch 8] [--length 1500] [--cfg] [--dtype bf16] > gpurun_out/long_profile.txt
 """
@@ -75,7 +75,7 @@ for rep in range(args.reps):
     plan.run(s)
 torch.cuda.synchronize()
 assert plan.take_error() == 0
-names = ["setup", "poll", "tables", "stage", "mfma", "epilogue", "next ring"]
+names = ["setup", "poll", "bar1", "tables", "stage", "mfma", "epilogue"]
 for pi, prog in enumerate(plan.progs):
     if prog.kinds[0] != "long":
         continue
@@ -103,12 +103,12 @@ for pi, prog in enumerate(plan.progs):
         if not m.any():
             continue
         st = d[p, m]
-        start, end = st[:, 0].min() - t0, st[:, 6].max() - t0
+        start, end = st[:, 0].min() - t0, st[:, 7].max() - t0
         seg = [np.mean(st[:, i + 1] - st[:, i]) for i in range(7)]
         ex = ""
-        if p > 0 and (d[p - 1, :, 6] > 0).any():
-            v = st[:, 2] - d[p - 1, d[p - 1, :, 6] > 0, 6].max()
+        if p > 0 and (d[p - 1, :, 7] > 0).any():
+            v = st[:, 2] - d[p - 1, d[p - 1, :, 7] > 0, 7].max()
             ex = f"{v.min():6.2f} {v.mean():6.2f} {v.max():6.2f}"
         print(f"{p:3d} {int(m.sum()):5d} {start:8.2f} {end:8.2f} {end - (prev_end - t0):6.2f} | " + " ".join(f"{v:8.2f}" for v in seg) + f" | {ex:>20}  {prog.labels[p][:110]}")
-        prev_end = st[:, 6].max()
+        prev_end = st[:, 7].max()
     print(f"# whole launch: {prev_end - t0:.1f} us")
