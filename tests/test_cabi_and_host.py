@@ -17,7 +17,7 @@ from jen1_amd import lib as L
 from jen1_amd.config import UNetSpec, full_model_config, tiny_model_config
 from oracle import jen1_oracle as O
 
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("jen1_hip.h", "jen1_train.h", "jen1_deep.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("jen1_hip.h", "jen1_train.h", "jen1_deep.h", "jen1_long.h")]
 
 
 @pytest.fixture(scope="module")
@@ -466,3 +466,44 @@ def test_capture_helper_keeps_the_collector_out_of_the_window(monkeypatch):
         assert not gc.isenabled()                         # it was off before: it stays off
     finally:
         gc.enable()
+
+
+def test_long_phase_host_helpers_without_a_gpu(lib):
+    """include/jen1_long.h host helpers (no GPU): geometry of the sample-resident launches at the bench shapes, a descriptor for a
+    level-0 ConvBlock1d (GroupNorm + FiLM + SiLU prologue over [x, skip], k = 3, 1x1 shortcut as extra K segments), and the refusals that
+    send a plan back to one launch per layer"""
+    mb, tl, tb = C.c_int(0), C.c_int(0), C.c_int(0)
+    geo = lambda M, L_out, G: (lib.jen1_long_geometry(M, L_out, G, C.byref(mb), C.byref(tl), C.byref(tb)), mb.value, tl.value, tb.value)
+    assert geo(128, 1500, 32) == (0, 1, 32, 47)            # B = 8: 32 workgroups per sample, 47 positions per tile at T = 1500
+    assert geo(128, 375, 32) == (0, 1, 32, 12)
+    assert geo(256, 94, 32) == (0, 2, 16, 6)               # 256 output channels: two M blocks x 16 position tiles
+    assert geo(512, 376, 32) == (0, 4, 8, 47)              # ConvTranspose1d(k = 8, s = 4) as a sub-pixel GEMM of 4 x 128 rows
+    assert geo(128, 1500, 16) == (0, 1, 16, 94)            # CFG pair: 16 samples
+    assert geo(128, 9000, 128) == (0, 1, 128, 71)          # T = 9000, CFG pair of one clip
+    assert geo(64, 300, 64)[0] != 0 and b"multiple of 128" in lib.jen1_last_error()       # the tiny configuration: 64 channels
+    assert geo(128, 9000, 32)[0] != 0                      # 282 positions per tile: more than 96
+    buf = (C.c_char * 512)()
+    a = L.ConvArgs()
+    fake = 1 << 20                                         # (descriptors only store the pointers)
+    a.x0, a.x1, a.w, a.bias, a.y = fake, fake + 4096, fake + 8192, fake + 12288, fake + 16384
+    a.dtype, a.B, a.L_in, a.L_out = L.BF16, 8, 1500, 1500
+    a.c0, a.c1, a.ld0, a.ld1 = 128, 128, 128, 128
+    a.taps, a.stride, a.pad_left = 3, 1, 1
+    a.M, a.out_C, a.ps_f, a.ps_off, a.L_y, a.y_brows, a.ld_y = 128, 128, 1, 0, 1500, 1500, 128
+    a.pro_mode, a.gn_groups, a.gn_cpg, a.gn_count, a.gn_eps, a.src1_scale = L.PRO_GN_SILU, 8, 32, 32 * 1500, 1e-5, 2 ** -0.5
+    a.gn_gamma, a.gn_beta = fake + 20480, fake + 24576
+    a.live_mask = 1
+    st = fake + 32768
+    rc = lib.jen1_long_phase_conv(C.byref(a), 32, st, 32, 1, 8, st + 4096, 32, 1, 8, 1, fake + 65536, C.cast(buf, C.c_void_p))
+    assert rc == 0, lib.jen1_last_error()
+    assert lib.jen1_long_phase_units(C.cast(buf, C.c_void_p)) == 32
+    lds = lib.jen1_long_phase_lds(C.cast(buf, C.c_void_p))
+    assert 49 * 264 * 2 <= lds <= 49 * 264 * 2 + 4096      # 47 + 2 halo rows x (256 + 8) bf16 + the affine tables
+    a.out_C = a.M = 192                                    # not a multiple of 128
+    assert lib.jen1_long_phase_conv(C.byref(a), 32, st, 32, 1, 8, st + 4096, 32, 1, 8, 1, None, C.cast(buf, C.c_void_p)) != 0
+    a.out_C = a.M = 128
+    a.y_f32 = 1
+    assert lib.jen1_long_phase_conv(C.byref(a), 32, st, 32, 1, 8, st + 4096, 32, 1, 8, 1, None, C.cast(buf, C.c_void_p)) != 0
+    # launch arguments are checked before anything is enqueued
+    assert lib.jen1_long_run(None, 1, 8, None, None, 256, 1 << 15, L.BF16, 0, None) != 0
+    assert lib.jen1_long_run(fake, 1, 6, fake, None, 256, 1 << 15, L.BF16, 1, None) != 0     # XCD-local stores: a multiple of 8 samples
