@@ -854,9 +854,17 @@ def main():
             out["roofline"] = long_levels
         # the whole step against the HBM roofline: SURVEY.md 8(d)'s algorithmic bytes of one denoiser step (every layer's weights once +
         # its input and output activations once, summed over the plan's launches and phases) / the headline time per step
-        step_alg = sum(getattr(op, "w_bytes", 0) + getattr(op, "act_bytes", 0) for op in st.plan.ops)
+        es_ = 4 if args.dtype == "f32" else 2
+        pl_ = st.plan
+        Cx_, Cc_ = model.spec.in_channels, model.spec.ctx_ch0
+        # the two kernels at the step's boundary: pack_input reads x and the concat context as float32 [B, C, T] and writes the channel-last
+        # network input; the fused CFG / DDIM step reads the network output, x and the noise and writes x
+        pack_bytes = B * (Cx_ + Cc_) * T * 4 + pl_.Beff * T * (-(-(Cx_ + Cc_) // 32) * 32) * es_
+        cfg_bytes = pl_.Beff * T * model.spec.out_channels * es_ + B * model.spec.out_channels * T * 12
+        step_alg = sum(getattr(op, "w_bytes", 0) + getattr(op, "act_bytes", 0) for op in st.plan.ops) + pack_bytes + cfg_bytes
         step_gbs = step_alg / (dt / args.steps) / 1e9
-        out["roofline"]["whole_step"] = {"bound": "hbm", "alg_bytes_per_step": int(step_alg), "ms_per_step": round(dt / args.steps * 1e3, 4),
+        out["roofline"]["whole_step"] = {"bound": "hbm", "alg_bytes_per_step": int(step_alg), "of_which_pack_input": int(pack_bytes),
+                                         "of_which_cfg_ddim_step": int(cfg_bytes), "ms_per_step": round(dt / args.steps * 1e3, 4),
                                          "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                                          "executed_gflop_per_step": round(sum(getattr(op, "flops", 0) for op in st.plan.ops) / 1e9, 2)}
         out["launches_per_step"] = st.plan.n_launch + 1

@@ -403,6 +403,9 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
   if (tot0 && wv == 0 && lane < 32) t0w = q0[lane];
   if (tot1 && wv == 0 && lane < 32) t1w = q1[lane];
   LK_STAMP(sy, 1);
+  // the unit's weight slice: requested right behind the polled round (the polls of a unit go out as early as possible: a poll is a
+  // round trip of ~0.7 us that starts only here), long before the MFMA loop needs it
+  ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
 
   // ---- behind the first polled round: per-channel parameters of the prologue, bias, output rows, the residual -------------------------------
   float g1 = 0.f, g2 = 0.f;
@@ -737,7 +740,6 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
       const DescRegs dr = load_desc(descs, p, lane);
       if (slot >= LI(out_entries)) continue;
       sy.p = p;
-      ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
       long_unit<T, false>(dr, b, slot, sy, ringA, ringB, tid);
     }
     return;
@@ -766,7 +768,6 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
   }
   if (slot >= G || b >= Bs) return;
   DescRegs dr = load_desc(descs, 0, lane);
-  if (slot < LI(out_entries)) ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
   for (int p = 0; p < n_phases; ++p) {
     const bool more = p + 1 < n_phases;
     DescRegs nx = dr;
@@ -786,8 +787,6 @@ __global__ __launch_bounds__(NT) void long_kernel(const unsigned char* __restric
 #endif
     if (!more) break;
     dr = nx;
-    // the next unit's weight slice: requested right behind this unit's stores, long before its dependency wait ends
-    if (slot < LI(out_entries)) ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
   }
 }
 

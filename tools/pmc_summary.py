@@ -18,15 +18,48 @@ import sys
 
 
 def family(n):
+    """kernel family of a (demangled or mangled) kernel name"""
     if "deep_kernel" in n:
         return "deep_kernel"
+    if "long_kernel" in n:
+        return "long_kernel"
     if "conv_gemm" in n or "stream_gemm" in n or "tile_gemm" in n or "TileArgs" in n:
         return "conv_family"
     if "norm_apply" in n:
         return "norm_apply"
     if "attention" in n:
         return "attention"
-    return n.split("(")[0][-40:]
+    if n.startswith("_Z"):                  # a mangled name: the length-prefixed identifier that names the kernel
+        import re
+        ids = [m.group(2)[: int(m.group(1))] for m in re.finditer(r"(\d+)([A-Za-z_][A-Za-z0-9_]*)", n)]
+        ids = [i for i in ids if "kernel" in i] or ids
+        if ids:
+            return ids[0]
+    # the function's own name: what stands in front of the argument list, without return type, namespaces and template arguments
+    # ("void (anonymous namespace)::poison_kernel(...)" -> "poison_kernel"; "void at::native::foo<float>(...)" -> "foo")
+    head = n
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):              # the first "(" outside template brackets that is not "(anonymous namespace)"
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and not n.startswith("(anonymous namespace)", i):
+            cut = i
+            break
+    head = n[:cut].strip()
+    out, depth = [], 0
+    for ch in head:                         # drop template argument lists
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif depth == 0:
+            out.append(ch)
+    head = "".join(out).strip()
+    head = head.split(" ")[-1] if " " in head else head
+    head = head.split("::")[-1]
+    return head or n.strip()[:40] or "unnamed"
 
 
 def per_step(db, counter, which):
@@ -70,8 +103,18 @@ def main():
             passes[k] = v
     data = {k: per_step(v, k, which) for k, v in passes.items()}
     fams = sorted({f for agg, _ in data.values() for f in agg})
+    import hashlib
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("JEN1_HEAD", "")
+    except OSError:
+        head = os.environ.get("JEN1_HEAD", "")
+    bench_sha = hashlib.sha256(open(os.path.join(root, "bench.py"), "rb").read()).hexdigest()[:16]
     res = {"source": "rocprofv3 --kernel-trace --pmc <one counter set per pass>, `python bench.py --steps 8 --warmup 3 --no-extra "
                      "--no-cpu-baseline`, one replayed step (tools/profile_round.sh, tools/pmc_summary.py)",
+           "collected_at": {"utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "head": head, "bench_py_sha16": bench_sha},
            "corrections": {"FETCH_SIZE": "KiB x 2 (gfx950 wide streaming reads are tallied at half)", "WRITE_SIZE": "KiB as reported"},
            "dispatches_per_step": {k: n for k, (_, n) in data.items()}, "kernels": {}}
     for f in fams:
