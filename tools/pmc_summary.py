@@ -30,9 +30,18 @@ def family(n):
     if "attention" in n:
         return "attention"
     if n.startswith("_Z"):                  # a mangled name: the length-prefixed identifier that names the kernel
-        import re
-        ids = [m.group(2)[: int(m.group(1))] for m in re.finditer(r"(\d+)([A-Za-z_][A-Za-z0-9_]*)", n)]
-        ids = [i for i in ids if "kernel" in i] or ids
+        ids, i = [], 2
+        while i < len(n):                   # <length><identifier> pieces, whatever stands between them
+            if n[i].isdigit():
+                j = i
+                while j < len(n) and n[j].isdigit():
+                    j += 1
+                k = int(n[i:j])
+                ids.append(n[j:j + k])
+                i = j + k
+            else:
+                i += 1
+        ids = [x for x in ids if "kernel" in x] or ids
         if ids:
             return ids[0]
     # the function's own name: what stands in front of the argument list, without return type, namespaces and template arguments
