@@ -237,6 +237,16 @@ int jen1_attention_fin(const void* q, const void* k, const void* v, void* out, c
 int jen1_pack_input(const float* x, const float* ctx, void* y, float* gn_stats, int B, int C, int Cc, int T,
                     int ld, int nrep, int dtype, void* stream);
 
+/*
+ * The same with the statistics in a FIXED summation order (no float atomics: two runs are bit-identical): every workgroup writes the
+ * (sum, sumsq) of its 32 channels x 32 time steps to parts[B][ceil(T / 32)][ld][2]; jen1_gn_stats_from_parts then adds the time blocks
+ * of every channel and the channels of every fine group in order and writes gn_stats[nrep * B][32][2] (the layout jen1_pack_input
+ * accumulates into).  Two launches; the second one is a few microseconds.
+ */
+int jen1_pack_input_parts(const float* x, const float* ctx, void* y, float* parts, int B, int C, int Cc, int T, int ld, int nrep, int dtype,
+                          void* stream);
+int jen1_gn_stats_from_parts(const float* parts, float* gn_stats, int B, int T, int ld, int nrep, void* stream);
+
 /* channel-last [B][T][ld] -> [B][C][T] float32 (the non-CFG exit of UNetCFG1d.forward). */
 int jen1_unpack_output(const void* y, float* out, int B, int C, int T, int ld, int dtype, void* stream);
 

@@ -49,7 +49,7 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ ctx,
                                                           T* __restrict__ y, float* __restrict__ stats, int B, int C,
-                                                          int Cc, int Tn, int ld, int nrep) {
+                                                          int Cc, int Tn, int ld, int nrep, float* __restrict__ parts) {
   __shared__ float tile[32][33];
   __shared__ float st[64];
   const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
@@ -74,6 +74,22 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
       const T v = (T)tile[tx][r];
       for (int rep = 0; rep < nrep; ++rep) y[((size_t)(rep * B + b) * Tn + t) * ld + c] = v;
     }
+  }
+  if (parts) {
+    // fixed-order statistics: the (sum, sumsq) of this block's 32 time steps per channel, written (not accumulated); summed over the
+    // time blocks and the channels of a fine group by gn_stats_from_parts_kernel
+    if (threadIdx.x < 32) {
+      const int r = threadIdx.x;
+      float sv = 0.f, sq = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) {
+        const float v = tile[r][j];
+        sv += v;
+        sq += v * v;
+      }
+      *reinterpret_cast<float2*>(parts + (((size_t)b * gridDim.x + blockIdx.x) * ld + c0 + r) * 2) = make_float2(sv, sq);
+    }
+    return;
   }
   if (stats) {
     // one lane per channel of the slab walks its 32 time steps in LDS (lane r reads bank (r + j) mod 32: no conflicts), then one LDS
@@ -100,6 +116,44 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
       const float v = st[threadIdx.x];
       if (fg < JEN1_FINE_GROUPS && v != 0.f)
         for (int rep = 0; rep < nrep; ++rep) unsafeAtomicAdd(stats + (size_t)(rep * B + b) * 64 + fg * 2 + (threadIdx.x & 1), v);
+    }
+  }
+}
+
+// parts[B][ntb][ld][2] -> stats[nrep * B][32][2]: thread c adds the time blocks of channel c in order, then one thread per fine group adds
+// its channels in order
+__global__ __launch_bounds__(512) void gn_stats_from_parts_kernel(const float* __restrict__ parts, float* __restrict__ stats, int B, int ntb,
+                                                                   int ld, int nrep) {
+  extern __shared__ float chan[];        // [ld][2]
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < ld; c += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    const float2* p = reinterpret_cast<const float2*>(parts) + (size_t)b * ntb * ld + c;
+    // (sixteen independent loads in flight, added in index order)
+    for (int i0 = 0; i0 < ntb; i0 += 16) {
+      float2 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(i0 + j < ntb ? i0 + j : 0) * ld];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        s += i0 + j < ntb ? v[j].x : 0.f;
+        q += i0 + j < ntb ? v[j].y : 0.f;
+      }
+    }
+    chan[2 * c] = s;
+    chan[2 * c + 1] = q;
+  }
+  __syncthreads();
+  const int cpf = ld / JEN1_FINE_GROUPS;
+  if (threadIdx.x < JEN1_FINE_GROUPS) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < cpf; ++k) {
+      s += chan[2 * (threadIdx.x * cpf + k)];
+      q += chan[2 * (threadIdx.x * cpf + k) + 1];
+    }
+    for (int rep = 0; rep < nrep; ++rep) {
+      stats[(size_t)(rep * B + b) * 64 + threadIdx.x * 2] = s;
+      stats[(size_t)(rep * B + b) * 64 + threadIdx.x * 2 + 1] = q;
     }
   }
 }
@@ -553,9 +607,30 @@ extern "C" int jen1_pack_input(const float* x, const float* ctx, void* y, float*
   JEN1_CHECK(ld % 32 == 0 && ld >= C + Cc && nrep >= 1, "pack_input: ld=%d must be a multiple of 32 and >= %d", ld, C + Cc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((T + 31) / 32, ld / 32, B);
-  if (dtype == JEN1_F32) hipLaunchKernelGGL(pack_input_kernel<float>, grid, dim3(256), 0, s, x, ctx, (float*)y, gn_stats, B, C, Cc, T, ld, nrep);
-  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, dim3(256), 0, s, x, ctx, (bf16_t*)y, gn_stats, B, C, Cc, T, ld, nrep);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(pack_input_kernel<float>, grid, dim3(256), 0, s, x, ctx, (float*)y, gn_stats, B, C, Cc, T, ld, nrep, (float*)nullptr);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, dim3(256), 0, s, x, ctx, (bf16_t*)y, gn_stats, B, C, Cc, T, ld, nrep, (float*)nullptr);
   else return jen1_set_error("pack_input: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_pack_input_parts(const float* x, const float* ctx, void* y, float* parts, int B, int C, int Cc, int T, int ld, int nrep,
+                                     int dtype, void* stream) {
+  JEN1_CHECK(x && y && parts && (Cc == 0 || ctx), "pack_input_parts: null pointer");
+  JEN1_CHECK(ld % 32 == 0 && ld >= C + Cc && nrep >= 1, "pack_input_parts: ld=%d must be a multiple of 32 and >= %d", ld, C + Cc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((T + 31) / 32, ld / 32, B);
+  if (dtype == JEN1_F32) hipLaunchKernelGGL(pack_input_kernel<float>, grid, dim3(256), 0, s, x, ctx, (float*)y, (float*)nullptr, B, C, Cc, T, ld, nrep, parts);
+  else if (dtype == JEN1_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, dim3(256), 0, s, x, ctx, (bf16_t*)y, (float*)nullptr, B, C, Cc, T, ld, nrep, parts);
+  else return jen1_set_error("pack_input_parts: bad dtype");
+  JEN1_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jen1_gn_stats_from_parts(const float* parts, float* gn_stats, int B, int T, int ld, int nrep, void* stream) {
+  JEN1_CHECK(parts && gn_stats && B >= 1 && T >= 1 && ld % JEN1_FINE_GROUPS == 0 && ld <= 4096 && nrep >= 1, "gn_stats_from_parts: bad arguments");
+  const int nt = ld >= 512 ? 512 : ((ld + 63) / 64) * 64;
+  hipLaunchKernelGGL(gn_stats_from_parts_kernel, dim3(B), dim3(nt), (size_t)ld * 8, reinterpret_cast<hipStream_t>(stream), parts, gn_stats, B, (T + 31) / 32, ld, nrep);
   JEN1_HIP(hipGetLastError());
   return 0;
 }

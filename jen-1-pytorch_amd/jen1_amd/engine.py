@@ -1514,11 +1514,21 @@ class Plan(OpBuilder):
 
         # ---- 1. pack [B,C,T] + context channels -> channel-last, CFG pair replicated -------------
         X0 = self.new_act(Be, T, Cx + Cc, gn=True)
-        a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), None if self.det else X0.gn.data_ptr(), B, Cx, Cc, T,
-             X0.ld, self.nrep, eng.dt)
-        ops.append(lambda s, a=a: L.check(lib.jen1_pack_input(*a, s), "jen1_pack_input"))
-        if self.det:
-            self.stats_launch(ops, X0)
+        if eng.pack_fixed_order:
+            # the GroupNorm sums of the network input in a fixed order (per-block partials + one small launch that adds them): with the
+            # persistent launches' fixed-order statistics the whole default step is run-to-run bit-reproducible
+            self._pack_parts = torch.empty((B, (T + 31) // 32, X0.ld, 2), dtype=f32, device=dev)
+            a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), self._pack_parts.data_ptr(), B, Cx, Cc, T,
+                 X0.ld, self.nrep, eng.dt)
+            ops.append(lambda s, a=a: L.check(lib.jen1_pack_input_parts(*a, s), "jen1_pack_input_parts"))
+            a2 = (self._pack_parts.data_ptr(), X0.gn.data_ptr(), B, T, X0.ld, self.nrep)
+            ops.append(lambda s, a=a2: L.check(lib.jen1_gn_stats_from_parts(*a, s), "jen1_gn_stats_from_parts"))
+        else:
+            a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), None if self.det else X0.gn.data_ptr(), B, Cx, Cc, T,
+                 X0.ld, self.nrep, eng.dt)
+            ops.append(lambda s, a=a: L.check(lib.jen1_pack_input(*a, s), "jen1_pack_input"))
+            if self.det:
+                self.stats_launch(ops, X0)
 
         # ---- 2. time -> mapping -> FiLM scale/shift of all ResBlocks (model.py:204-223) -------------
         # (timestep-only work: ``time_ops``; one row per batch element, or per schedule entry in table mode)
@@ -1827,6 +1837,8 @@ class Engine:
         self.use_long = os.environ.get("JEN1_LONG", "1") != "0"
         self.deep_all_slots = os.environ.get("JEN1_DEEP_ALL_SLOTS", "0") != "0"
         self.deterministic = os.environ.get("JEN1_DETERMINISTIC", "0") != "0"
+        # the network input's GroupNorm sums in a fixed order (jen1_pack_input_parts + jen1_gn_stats_from_parts) instead of float atomics
+        self.pack_fixed_order = os.environ.get("JEN1_PACK_FIXED_ORDER", "1") != "0"
         # (a library built with -DJEN1_DEEP_CHUNKS runs a level of more than 64 positions in column chunks -- a unit computes <= 64
         # positions but stages, and normalises over, the whole batch element: JEN1_DEEP_MAX_LEN=96 then takes the 94-position level of
         # T = 1500 in, 188 phases and 30 launches per step; measured 765 against 777 steps/s -- the 17 new phases cost 9.4 us each,

@@ -131,6 +131,8 @@ SYMBOLS = {
     "jen1_attention": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 + [c_float, c_int, _P]),
     "jen1_attention_fin": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int] + [c_int] * 12 + [c_float, _P, _P, _P, c_int, c_float, c_int, c_int, c_int, _P]),
     "jen1_pack_input": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "jen1_pack_input_parts": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "jen1_gn_stats_from_parts": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "jen1_unpack_output": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     "jen1_row_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
     "jen1_gn_stats": (c_int, [_P, _P] + [c_int] * 4 + [_P]),

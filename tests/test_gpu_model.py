@@ -456,7 +456,7 @@ def test_sampler_full_size_properties(full_model_f32):
 
 
 def test_deterministic_statistics_mode_is_bit_reproducible(full_model_f32, tiny_models):
-    """Plan(deterministic=True): the GroupNorm / LayerNorm sums of the launch-per-layer levels come from fixed-order statistics
+    """Plan(deterministic=True): the GroupNorm / LayerNorm sums of the levels that run one launch per layer come from fixed-order statistics
     launches (jen1_gn_stats, jen1_row_stats) instead of float atomics.  Two 100-step DDIM runs of the full model from the same
     inputs are bit-identical (graph replay and eager), and the mode changes nothing beyond the summation order (1e-5 against the
     default plan after one forward).  The tiny configuration covers attention on the launch path (row statistics)."""
@@ -477,7 +477,9 @@ def test_deterministic_statistics_mode_is_bit_reproducible(full_model_f32, tiny_
             assert torch.equal(y_det[0], y_det[1])
             assert rel_err(y_det[0].cpu().numpy(), y_default.cpu().numpy()) < 1e-5
             plan = m.engine().plan(B, T, 2, False)
-            assert plan.det and any(getattr(op, "kind", "") == "stats" for op in plan.ops)
+            # (the full model's long levels run as sample-resident launches with fixed-order statistics of their own and the pack kernel's
+            # sums are fixed-order by default: no statistics launch is left to add there; the tiny configuration runs launch per layer)
+            assert plan.det and (plan.long_levels >= 1 or any(getattr(op, "kind", "") == "stats" for op in plan.ops))
             outs = []
             for use_graph in (True, False, True):
                 gd = GaussianDiffusion(steps=1000, betas=betas, objective="noise", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
