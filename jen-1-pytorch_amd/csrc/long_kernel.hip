@@ -178,6 +178,9 @@ __device__ __forceinline__ void llds(f32x8& f, const float* p) {
 }
 // weight fragment through a buffer descriptor (out-of-range offsets return 0 and move no bytes)
 __device__ __forceinline__ void wload(bf16x8& f, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+#ifdef JEN1_LONG_EXP_NOW         // timing experiment only: every weight request is out of range (no bytes move)
+  voff = OOB;
+#endif
   f = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 __device__ __forceinline__ void wload(f32x8& f, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -241,6 +244,9 @@ __device__ unsigned long long* g_long_dbg = nullptr;
 #endif
 // behind a round of loads of one wave: `bad` = this lane saw a sentinel word.  True when the wave has to load again.
 __device__ __forceinline__ bool poll_again(LSync& sy, bool bad, unsigned& spins) {
+#ifdef JEN1_LONG_EXP_NOWAIT      // timing experiment only (results are garbage): no dependency waits at all
+  return false;
+#endif
   if (!__builtin_amdgcn_ballot_w64(bad) || sy.dead) return false;
   ++spins;
   if ((spins & 63u) == 0u) {
@@ -293,8 +299,10 @@ __device__ __forceinline__ void ring_fill(const DescRegs& dr, int slot, int lane
   const unsigned step = (unsigned)MT * BLK;
 #pragma unroll
   for (int s = 0; s < HR; ++s) wload(ringA[s], rw, s < KS ? voff : OOB, s < KS ? (unsigned)s * step : 0u);
+  if (KS > HR) {                 // (a 128-channel k = 3 slice is 12 k-steps: the second half of the ring stays untouched)
 #pragma unroll
-  for (int s = 0; s < HR; ++s) wload(ringB[s], rw, HR + s < KS ? voff : OOB, HR + s < KS ? (unsigned)(HR + s) * step : 0u);
+    for (int s = 0; s < HR; ++s) wload(ringB[s], rw, HR + s < KS ? voff : OOB, HR + s < KS ? (unsigned)(HR + s) * step : 0u);
+  }
 }
 
 // ======================================================================================================================================
@@ -403,6 +411,44 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
   if (tot0 && wv == 0 && lane < 32) t0w = q0[lane];
   if (tot1 && wv == 0 && lane < 32) t1w = q1[lane];
   LK_STAMP(sy, 1);
+  // the residual of the epilogue: requested here, OLDER than the weight ring (the compiler counts the loads YOUNGER than a fragment to wait
+  // for it: conditional loads in front of the ring cost nothing, behind it they make every fragment wait for everything in flight)
+  constexpr int NFM = JEN1_LONG_MAX_NF;
+  const int out_C = LI(out_C), ps_f = LI(ps_f), ps_off = LI(ps_off), L_y = LI(L_y), y_brows = LI(y_brows), y_row0 = LI(y_row0);
+  const int m0 = mblk * JEN1_LONG_BM;                        // first GEMM row of the unit; one sub-pixel phase per M block (out_C % 128 == 0)
+  const int ph = m0 >> LI(outc_shift);
+  const int co = (m0 - ph * out_C) + wv * 16 + lg * 4;       // this lane's 4 consecutive output channels
+  const T* resb = LP(residual, const T*);
+  const bool reslive = resb && ((live >> 8) & 1);
+  const int ld_res = LI(ld_res), ld_y = LI(ld_y);
+  int yrow[NFM];
+#pragma unroll
+  for (int nf = 0; nf < NFM; ++nf) {
+    yrow[nf] = -1;
+    if (nf < NF) {
+      const int n = nf * 16 + li;
+      const int q = t0 + n;
+      const int ty = q * ps_f + ph - ps_off;
+      const bool ok = n < tb && q < L_out && ty >= 0 && ty < L_y;
+      yrow[nf] = ok ? b * y_brows + y_row0 + ty : -1;
+    }
+  }
+  Raw4<T> rr[NFM];
+  auto issue_res = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nf = 0; nf < NFM; ++nf) {
+      if (nf < NF) ld_live4r(rr[nf], resb + ((unsigned)(yrow[nf] < 0 ? 0 : yrow[nf]) * (unsigned)ld_res + (unsigned)co));
+    }
+  };
+  auto res_bad = [&]() __attribute__((always_inline)) -> bool {
+    bool bad = false;
+#pragma unroll
+    for (int nf = 0; nf < NFM; ++nf) {
+      if (nf < NF) bad |= yrow[nf] >= 0 && raw_bad(rr[nf]);
+    }
+    return bad;
+  };
+  if (resb) issue_res();
   // the unit's weight slice: requested right behind the polled round (the polls of a unit go out as early as possible: a poll is a
   // round trip of ~0.7 us that starts only here), long before the MFMA loop needs it
   ring_fill<T>(dr, slot, lane, wv, ringA, ringB);
@@ -418,16 +464,11 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
     g1 = LP(p1, const float*)[po];
     g2 = LP(p2, const float*)[po];
   }
-  const int out_C = LI(out_C), ps_f = LI(ps_f), ps_off = LI(ps_off), L_y = LI(L_y), y_brows = LI(y_brows), y_row0 = LI(y_row0);
-  const int m0 = mblk * JEN1_LONG_BM;                        // first GEMM row of the unit; one sub-pixel phase per M block (out_C % 128 == 0)
-  const int ph = m0 >> LI(outc_shift);
-  const int co = (m0 - ph * out_C) + wv * 16 + lg * 4;       // this lane's 4 consecutive output channels
   f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     const float* biasp = LP(bias, const float*);
     if (biasp) bias4 = *reinterpret_cast<const f32x4*>(biasp + co);
   }
-  constexpr int NFM = JEN1_LONG_MAX_NF;
   {
     unsigned spins = 0;
     bool bad = batch_bad(cur, 0) | stats_bad();
@@ -541,10 +582,12 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
             const float4 e0 = *reinterpret_cast<const float4*>(tabS + c), e1 = *reinterpret_cast<const float4*>(tabS + c + 4);
             x[0] = x[0] * a0.x + e0.x; x[1] = x[1] * a0.y + e0.y; x[2] = x[2] * a0.z + e0.z; x[3] = x[3] * a0.w + e0.w;
             x[4] = x[4] * a1.x + e1.x; x[5] = x[5] * a1.y + e1.y; x[6] = x[6] * a1.z + e1.z; x[7] = x[7] * a1.w + e1.w;
+#ifndef JEN1_LONG_EXP_NOSILU     // (timing experiment only: staging without the activation)
             if (do_silu) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) x[j] = PRECISE ? silu_precise(x[j]) : silu_f(x[j]);
             }
+#endif
           } else if (c >= c0 && sc1 != 1.0f) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] *= sc1;
@@ -564,35 +607,12 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
   float* const out_part = LP(out_part, float*);
   {
     constexpr int HR = RING / 2;
-    int ldsrow[NFM], yrow[NFM];
+    int ldsrow[NFM];
 #pragma unroll
     for (int nf = 0; nf < NFM; ++nf) {
       const int n = nf * 16 + li;
       ldsrow[nf] = ((n < tb ? n : 0) * stride) * pitch + lg * 8;
-      const int q = t0 + n;
-      const int ty = q * ps_f + ph - ps_off;
-      const bool ok = nf < NF && n < tb && q < L_out && ty >= 0 && ty < L_y;
-      yrow[nf] = ok ? b * y_brows + y_row0 + ty : -1;
     }
-    // the residual of the epilogue: requested here, UNCONDITIONALLY (a phase without one reads the first word of its weights): behind a
-    // conditional load the compiler no longer knows how many loads are in flight and waits for ALL of them -- this one included -- before
-    // the first weight fragment is used
-    const T* resb = LP(residual, const T*);
-    const bool reslive = resb && ((live >> 8) & 1);
-    const int ld_res = resb ? LI(ld_res) : 0, ld_y = LI(ld_y);
-    const T* resp = resb ? resb + co : LP(w, const T*);
-    Raw4<T> rr[NFM];
-    auto issue_res = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int nf = 0; nf < NFM; ++nf) ld_live4r(rr[nf], resp + (unsigned)(yrow[nf] < 0 ? 0 : yrow[nf]) * (unsigned)ld_res);
-    };
-    auto res_bad = [&]() __attribute__((always_inline)) -> bool {
-      bool bad = false;
-#pragma unroll
-      for (int nf = 0; nf < NFM; ++nf) bad |= yrow[nf] >= 0 && raw_bad(rr[nf]);
-      return bad;
-    };
-    issue_res();
     f32x4 acc[NFM];
 #pragma unroll
     for (int nf = 0; nf < NFM; ++nf) acc[nf] = bias4;                 // the accumulators start from the bias
@@ -647,7 +667,11 @@ __device__ __forceinline__ void long_unit(const DescRegs& dr, int b, int slot, L
         }
       };
       static_assert(HR % 2 == 0, "the parity of a k-step is the parity of its slot");
+#ifdef JEN1_LONG_EXP_NOMMA       // timing experiment only: no MFMA loop
+      for (int ks0 = KS; ks0 < KS; ks0 += RING) {
+#else
       for (int ks0 = 0; ks0 < KS; ks0 += RING) {
+#endif
         dispatch(ringA, ks0);
         if (ks0 + RING < KS) {                            // the next round's first half: in flight during this round's second half
 #pragma unroll
