@@ -116,19 +116,21 @@ def nan_flow(mode):
     channel -- stored as it is, every 8-byte word of the layer's output would be the 'not stored yet' sentinel and its consumers would
     spin to the time-out.  The stores canonicalise the pattern: the launch completes at its usual speed with NO error word, NaNs come
     out (as the reference produces them for NaN weights), and the next launch with the bias restored is clean and equal to the one before."""
+    mode, _, where = str(mode).partition(":")       # "bf16" (a deep level: downsamples.3) or "bf16:long" (a long level: downsamples.1)
+    level = "downsamples.1" if where == "long" else "downsamples.3"
     model = full(mode)
     eng = model.engine()
     B, T = 2, 1500
     plan = eng.plan(B, T, 1, False, deep=True)
-    assert plan.deep_level is not None
+    assert plan.deep_level is not None and (where != "long" or plan.long_levels >= 2)
     x, cond = synth.latents(B, T), synth.conditioning(B, T)
     t = np.array([999, 3], dtype=np.int64)
     run_plan(model, plan, x, t, cond)
     assert plan.take_error() == 0
     want = plan.net_out.t.clone()
     assert torch.isfinite(want.float()).all()
-    keys = [k for k in eng.W.v if k.endswith("blocks.0.conv1.bias") and k.startswith("downsamples.3")]
-    assert keys, [k for k in eng.W.v if "downsamples.3" in k][:8]
+    keys = [k for k in eng.W.v if k.endswith("blocks.0.conv1.bias") and k.startswith(level)]
+    assert keys, [k for k in eng.W.v if level in k][:8]
     bias = eng.W.v[keys[0]]
     saved = bias.clone()
     bias.view(torch.int32).fill_(-1)                    # 0xFFFFFFFF: -NaN, all mantissa bits
@@ -146,7 +148,7 @@ def nan_flow(mode):
     assert rel_err(plan.net_out.t.float().cpu().numpy(), want.float().cpu().numpy()) < (1e-4 if mode == "f32" else 3e-2)
 
 
-def time_out(_=None):
+def time_out(which=None):
     """The persistent program re-linked WITHOUT its first phase: the first remaining phase polls a tensor nobody produces (it starts the
     launch poisoned).  The bounded spin gives up after JEN1_DEEP_POLL_LIMIT polls, the error word says which phase, every other waiter
     is released (the launch ends in a fraction of a second instead of hanging the GPU), ``take_error`` reports and clears the word, and
@@ -155,7 +157,10 @@ def time_out(_=None):
     eng = model.engine()
     B, T = 2, 1500
     plan = eng.plan(B, T, 1, False, deep=True)
-    prog = plan.deep
+    # ("long": the same injection into a sample-resident long-level launch, include/jen1_long.h -- the up half: its phase 1 then polls the
+    # output of a phase 0 that never runs)
+    prog = plan.deep if which != "long" else plan.progs[-1]
+    assert which != "long" or prog.kinds[0] == "long"
     x, cond = synth.latents(B, T), synth.conditioning(B, T)
     t = np.array([999, 3], dtype=np.int64)
     run_plan(model, plan, x, t, cond)

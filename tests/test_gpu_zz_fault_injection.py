@@ -38,13 +38,14 @@ def test_gc_inside_capture_window_does_not_abort():
     run_case("gc_in_capture")
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f32:long", "bf16:long"])
 def test_nan_activations_flow_through_the_launch(mode):
     run_case("nan_flow", mode)
 
 
-def test_time_out_is_reported_and_cleared():
-    run_case("time_out")
+@pytest.mark.parametrize("which", ["deep", "long"])
+def test_time_out_is_reported_and_cleared(which):
+    run_case("time_out", which)
 
 
 def test_forward_time_out_raises_through_the_public_call():
