@@ -301,6 +301,15 @@ int jen1_step_advance(int32_t* step_idx, void* stream);
 int jen1_cfg_ddim_step_adv(const void* net, const float* x, const float* noise, const float* coef, float* x_out, float* eps_out,
                            float* x0_out, int32_t* step_idx, uint32_t* ticket, int B, int C, int T, int ld, int nrep,
                            float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype, void* stream);
+/* jen1_cfg_ddim_step_adv that also writes the NEXT step's network input, so that a replayed sampler step needs no jen1_pack_input
+ * launch at its head (the loop of gdm.py:202-222 feeds x_{t-1} straight back into model.py:240, :332-349): the new latents go, in the
+ * compute dtype, into channels [0, C) of rows [nrep * B][T][ld_rows] (the concat-context channels behind them are written once, by
+ * jen1_pack_input_parts, and do not change between steps) and their per-channel (sum, sumsq) over each block of 32 time steps into
+ * parts [B][ceil(T / 32)][ld_rows][2] -- the layout and summation order of jen1_pack_input_parts, so jen1_gn_stats_from_parts after
+ * this call gives bit-identical statistics.  Needs C % 8 == 0 and 16-byte aligned rows; deterministic rows (coef[4] == 0) read no noise. */
+int jen1_cfg_ddim_step_pack(const void* net, const float* x, const float* noise, const float* coef, float* x_out, int32_t* step_idx,
+                            uint32_t* ticket, void* rows, float* parts, int ld_rows, int B, int C, int T, int ld, int nrep,
+                            float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype, void* stream);
 
 /* CFG combine + rescale only: writes the guided denoiser output [B][C][T] float32 (model.py:362-369). */
 int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale, int scale_cfg,

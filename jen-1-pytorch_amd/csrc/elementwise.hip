@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
                                                             float* __restrict__ x0_out, const int32_t* step_idx,
                                                             int B, int C, int Tn, int ld, int nrep,
                                                             float scale, int scale_cfg, float phi, int objective, int clip_x0,
-                                                            int32_t* adv_step, unsigned* __restrict__ adv_ticket) {
+                                                            int32_t* adv_step, unsigned* __restrict__ adv_ticket,
+                                                            T* __restrict__ rows, float* __restrict__ parts, int ld_rows) {
   extern __shared__ float tile[];   // [C][33] + one word per 8 channels
   float cf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (DDIM) {
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
       const int c = blk * 64 + ty + 8 * k;
       const size_t idx = ((size_t)b * C + (c < C ? c : 0)) * Tn + tcl;
       xv[blk][k] = DDIM ? x[idx] : 0.f;
-      nv[blk][k] = (DDIM && noise) ? noise[idx] : 0.f;
+      nv[blk][k] = (DDIM && noise && cf[4] != 0.f) ? noise[idx] : 0.f;   // (a deterministic row -- sigma = 0 -- reads no noise)
     }
   }
   // phase 1: 8 rows per pass (4 waves x 2 half waves), every load of the block in flight before the first reduction
@@ -554,7 +555,8 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
       adv_ticket[0] = 0u;
     }
   }
-  if (t >= Tn) return;
+  const bool pack = DDIM && rows != nullptr;     // (uniform)
+  if (t >= Tn && !pack) return;
   const float sr = cf[0], srm1 = cf[1], sa_n = cf[2], cc = cf[3], sg = cf[4], last = cf[5], sa_t = cf[6], s1m_t = cf[7];
 #pragma unroll
   for (int blk = 0; blk < NBLK; ++blk) {
@@ -563,6 +565,10 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
     for (int k = 0; k < 8; ++k) {
       const int c = blk * 64 + ty + 8 * k;
       if (c >= C) continue;
+      if (t >= Tn) {                 // (pack only: the columns past the end count as zeros in the next step's statistics)
+        tile[c * 33 + (c >> 3) + tx] = 0.f;
+        continue;
+      }
       const size_t idx = ((size_t)b * C + c) * Tn + t;
       const float o = tile[c * 33 + (c >> 3) + tx];
       if (!DDIM) {
@@ -595,7 +601,34 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
       x_out[idx] = xn;
       if (eps_out) eps_out[idx] = eps;
       if (x0_out) x0_out[idx] = x0;
+      if (pack) tile[c * 33 + (c >> 3) + tx] = xn;       // (the element this thread read: nobody else touches it before the barrier)
     }
+  }
+  if (!pack) return;
+  // ---- the next step's network input, written here instead of by a pack_input launch at its head (model.py:240, :332-349): the new
+  // latents go back through the tile into the channel-last rows [nrep * B][T][ld_rows] (the concat-context channels behind them do not
+  // change between steps), and their per-channel (sum, sumsq) over this block's 32 time steps into the partials that
+  // gn_stats_from_parts_kernel adds in a fixed order -- same values, same order as pack_input_kernel
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 8 + wave * 2 + half;
+    if (!cv || t0 + r >= Tn) continue;
+    float o8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o8[j] = tile[(c8 + j) * 33 + (c8 >> 3) + r];
+    for (int rep = 0; rep < nrep; ++rep) store8(rows + ((size_t)(rep * B + b) * Tn + t0 + r) * ld_rows + c8, o8);
+  }
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    float sv = 0.f, sq = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+      const float v = tile[c * 33 + (c >> 3) + j];
+      sv += v;
+      sq += v * v;
+    }
+    *reinterpret_cast<float2*>(parts + (((size_t)b * gridDim.x + blockIdx.x) * ld_rows + c) * 2) = make_float2(sv, sq);
   }
 }
 
@@ -703,7 +736,8 @@ extern "C" int jen1_linear_f32(const float* x, const float* w, const float* bias
 template <bool DDIM>
 static int launch_cfg(const void* net, const float* x, const float* noise, const float* coef, float* x_out, float* eps_out,
                       float* x0_out, const int32_t* step_idx, int B, int C, int T, int ld, int nrep, float scale, int scale_cfg, float phi,
-                      int objective, int clip_x0, int dtype, void* stream, int32_t* adv_step = nullptr, unsigned* adv_ticket = nullptr) {
+                      int objective, int clip_x0, int dtype, void* stream, int32_t* adv_step = nullptr, unsigned* adv_ticket = nullptr,
+                      void* rows = nullptr, float* parts = nullptr, int ld_rows = 0) {
   JEN1_CHECK(net && x_out, "cfg step: null pointer");
   JEN1_CHECK(nrep == 1 || nrep == 2, "cfg step: nrep must be 1 or 2");
   JEN1_CHECK(C >= 2 && C <= 256 && ld >= C, "cfg step: C must be in [2, 256]");
@@ -714,14 +748,19 @@ static int launch_cfg(const void* net, const float* x, const float* noise, const
   static const bool scalar_only = getenv("JEN1_CFG_STEP_SCALAR") != nullptr;
   const int esz = dtype == JEN1_F32 ? 4 : 2;
   const bool vec = !scalar_only && C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)net & 15) == 0 && ((size_t)ld * esz) % 16 == 0;
+  if (rows) {
+    JEN1_CHECK(vec && DDIM && parts, "cfg step + pack: needs the vector form (C % 8 == 0, 16-byte rows) and the partials buffer");
+    JEN1_CHECK(ld_rows >= C && ((size_t)ld_rows * esz) % 16 == 0 && ((uintptr_t)rows & 15) == 0 && ((uintptr_t)parts & 7) == 0,
+               "cfg step + pack: rows must be 16-byte aligned with ld_rows >= C");
+  }
   if (vec && dtype == JEN1_F32) {
     auto kern = cfg_step_vec_kernel<float, DDIM>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket, (float*)rows, parts, ld_rows);
   } else if (vec && dtype == JEN1_BF16) {
     auto kern = cfg_step_vec_kernel<bf16_t, DDIM>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, scale, scale_cfg, phi, objective, clip_x0, adv_step, adv_ticket, (bf16_t*)rows, parts, ld_rows);
   } else if (dtype == JEN1_F32) {
     auto kern = cfg_step_kernel<float, DDIM>;
     JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
@@ -764,6 +803,16 @@ extern "C" int jen1_cfg_ddim_step_adv(const void* net, const float* x, const flo
   JEN1_CHECK(objective >= 0 && objective <= 2, "cfg_ddim_step_adv: bad objective");
   return launch_cfg<true>(net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, T, ld, nrep, embedding_scale, scale_cfg,
                           scale_phi, objective, clip_x0, dtype, stream, step_idx, ticket);
+}
+
+extern "C" int jen1_cfg_ddim_step_pack(const void* net, const float* x, const float* noise, const float* coef, float* x_out,
+                                       int32_t* step_idx, uint32_t* ticket, void* rows, float* parts, int ld_rows, int B, int C, int T,
+                                       int ld, int nrep, float embedding_scale, int scale_cfg, float scale_phi, int objective,
+                                       int clip_x0, int dtype, void* stream) {
+  JEN1_CHECK(x && coef && step_idx && ticket && rows && parts, "cfg_ddim_step_pack: null x / coef / step_idx / ticket / rows / parts");
+  JEN1_CHECK(objective >= 0 && objective <= 2, "cfg_ddim_step_pack: bad objective");
+  return launch_cfg<true>(net, x, noise, coef, x_out, nullptr, nullptr, step_idx, B, C, T, ld, nrep, embedding_scale, scale_cfg,
+                          scale_phi, objective, clip_x0, dtype, stream, step_idx, ticket, rows, parts, ld_rows);
 }
 
 extern "C" int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale,

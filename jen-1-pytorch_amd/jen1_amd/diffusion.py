@@ -412,16 +412,31 @@ class DDIMStepper:
             # the step counter advances inside the CFG / DDIM kernel (its last block; jen1_cfg_ddim_step_adv): one launch fewer per step
             ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
             adv_args = args[:7] + (sp, ticket.data_ptr()) + args[8:]
+            # fused step (JEN1_STEP_PACK, default on): the step kernel also writes the next step's network input -- rows in the compute
+            # dtype + the statistics partials -- so a replayed step has no pack launch at its head; the plan's own pack runs once per
+            # trajectory (``_pack_dirty``: after reset / rebind, before the first step)
+            fused = (os.environ.get("JEN1_STEP_PACK", "1") == "1" and plan.pack_rows is not None and Co % 8 == 0
+                     and Co == model.spec.in_channels and os.environ.get("JEN1_CFG_STEP_SCALAR") is None)
+            if fused:
+                rows_ptr, parts_ptr, ld_rows = plan.pack_rows
+                pk_args = args[:5] + (sp, ticket.data_ptr(), rows_ptr, parts_ptr, ld_rows) + args[8:]
 
-            def run(s, plan=plan, adv_args=adv_args, ticket=ticket):
-                plan.run(s)
-                L.check(lib.jen1_cfg_ddim_step_adv(*adv_args, s), "jen1_cfg_ddim_step_adv")
+                def run(s, plan=plan, pk_args=pk_args, ticket=ticket):
+                    plan.run(s, pack=False)
+                    L.check(lib.jen1_cfg_ddim_step_pack(*pk_args, s), "jen1_cfg_ddim_step_pack")
+                    plan.pack_stats_op(s)
+            else:
+                def run(s, plan=plan, adv_args=adv_args, ticket=ticket):
+                    plan.run(s)
+                    L.check(lib.jen1_cfg_ddim_step_adv(*adv_args, s), "jen1_cfg_ddim_step_adv")
+            self.fused_pack = getattr(self, "fused_pack", True) and fused
 
             self.parts.append((sl, plan, run, ntab))
             b0 += nb
         self.plan = self.parts[0][1]                  # (first sub-plan; used by the bench's per-launch roofline)
         self.streams = [torch.cuda.Stream(dev) for _ in self.parts] if len(self.parts) > 1 else []
         self._next = 0
+        self._pack_dirty = True
         self._set_step(0)                             # the cached plan may carry a previous run's counter
         self.graph = None
         self.graphs = None
@@ -442,6 +457,7 @@ class DDIMStepper:
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):             # warm-up outside capture (lazy attribute init)
+            self._pack_if_dirty()
             self._run_all()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -473,6 +489,7 @@ class DDIMStepper:
             self._capture()
             for sl, plan, _, _ in self.parts:
                 plan.x_in.copy_(saved[sl])
+            self._pack_dirty = True
             self._set_step(nxt)
 
     def rebind(self, conditioning) -> None:
@@ -485,6 +502,17 @@ class DDIMStepper:
             cc = conditioning["input_concat_cond"]
             self.model._prepare(plan, plan.x_in, None, emb, msk, [None if cc is None else cc[sl]], None)
             plan._cond_refs = (emb, msk)
+        self._pack_dirty = True                    # (the concat context is part of the packed rows)
+
+    def mark_dirty(self) -> None:
+        """the latents (``x``) or the concat context were written from outside: the next step re-packs the network input from them"""
+        self._pack_dirty = True
+
+    def _pack_if_dirty(self):
+        if self._pack_dirty and self.fused_pack:
+            for _, plan, _, _ in self.parts:
+                plan.run_pack(torch.cuda.current_stream(self.gd.device).cuda_stream)
+        self._pack_dirty = False
 
     def _run_all(self):
         """enqueue every sub-batch; with several parts they fork onto side streams and join back."""
@@ -530,6 +558,7 @@ class DDIMStepper:
             self._sync_modes(claim=True)
         for sl, plan, _, _ in self.parts:
             plan.x_in.copy_(x0[sl])
+        self._pack_dirty = True
         if fresh_noise and self.mode != "vdm":
             if self.mode == "ddim":
                 self.noise_all.normal_()
@@ -561,6 +590,7 @@ class DDIMStepper:
         if noise is not None and i < self.num_steps - 1 and self.mode != "vdm":
             self.noise_all[i].copy_(noise.to(self.noise_all.device, torch.float32))
             self._push_noise(i)
+        self._pack_if_dirty()
         if self.graphs is not None:
             cur = torch.cuda.current_stream(self.gd.device)
             for st, g in zip(self.streams, self.graphs):

@@ -625,16 +625,18 @@ class OpBuilder:
             for a in self._splitk_args:
                 a.slab, a.counters = self.slab.data_ptr(), self.counters.data_ptr()
 
-    def run(self, stream: Optional[int] = None):
+    def run(self, stream: Optional[int] = None, pack: bool = True):
+        """pack=False leaves out the ops that write the network input (kind "pack"): the fused sampler's step kernel wrote it"""
         if stream is None:
             stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        ops = self.ops if pack else [op for op in self.ops if getattr(op, "kind", "") != "pack"]
         if os.environ.get("JEN1_DEBUG_SYNC"):
-            for i, op in enumerate(self.ops):
+            for i, op in enumerate(ops):
                 print(f"[jen1] op {i}: {getattr(op, 'label', '?')}", flush=True)
                 op(stream)
                 torch.cuda.synchronize(self.eng.device)
             return
-        for op in self.ops:
+        for op in ops:
             op(stream)
 
     # ---------------------------------------------------------------- the fused conv / linear op
@@ -1242,6 +1244,8 @@ class Plan(OpBuilder):
             self._deep_err = None
             self.time_ops: List[Callable[[int], None]] = []
             self.ctx_ops: List[Callable[[int], None]] = []
+            self.pack_ops: List[Callable[[int], None]] = []
+            self.pack_rows = None
             self.taps: Dict[str, Act] = {}
             self.acts: List[Act] = []
             self.n_launch = 0
@@ -1518,11 +1522,19 @@ class Plan(OpBuilder):
             # the GroupNorm sums of the network input in a fixed order (per-block partials + one small launch that adds them): with the
             # persistent launches' fixed-order statistics the whole default step is run-to-run bit-reproducible
             self._pack_parts = torch.empty((B, (T + 31) // 32, X0.ld, 2), dtype=f32, device=dev)
+            # (statistics that are written, not accumulated: outside the arena that the head of every step zeroes, so that the previous
+            # step's last kernel may already have written them -- DDIMStepper's fused step)
+            X0.gn = torch.zeros((Be * 64,), dtype=f32, device=dev)
             a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), self._pack_parts.data_ptr(), B, Cx, Cc, T,
                  X0.ld, self.nrep, eng.dt)
-            ops.append(lambda s, a=a: L.check(lib.jen1_pack_input_parts(*a, s), "jen1_pack_input_parts"))
+            pk = lambda s, a=a: L.check(lib.jen1_pack_input_parts(*a, s), "jen1_pack_input_parts")
             a2 = (self._pack_parts.data_ptr(), X0.gn.data_ptr(), B, T, X0.ld, self.nrep)
-            ops.append(lambda s, a=a2: L.check(lib.jen1_gn_stats_from_parts(*a, s), "jen1_gn_stats_from_parts"))
+            st = lambda s, a=a2: L.check(lib.jen1_gn_stats_from_parts(*a, s), "jen1_gn_stats_from_parts")
+            pk.kind = st.kind = "pack"
+            pk.label, st.label = "pack_input_parts", "gn_stats_from_parts"
+            ops += [pk, st]
+            self.pack_ops, self.pack_stats_op = [pk, st], st
+            self.pack_rows = (X0.t.data_ptr(), self._pack_parts.data_ptr(), X0.ld)      # where a fused step kernel writes the next input
         else:
             a = (self.x_in.data_ptr(), self.ctx_in.data_ptr() if Cc else None, X0.t.data_ptr(), None if self.det else X0.gn.data_ptr(), B, Cx, Cc, T,
                  X0.ld, self.nrep, eng.dt)
@@ -1743,12 +1755,20 @@ class Plan(OpBuilder):
         for op in self.time_ops:
             op(stream)
 
-    def run(self, stream: Optional[int] = None):
+    def run(self, stream: Optional[int] = None, pack: bool = True):
         if stream is None:
             stream = torch.cuda.current_stream(self.eng.device).cuda_stream
         if not self.table_mode:
             self.run_time(stream)       # general forward: the timesteps change with every call
-        super().run(stream)
+        super().run(stream, pack)
+
+    def run_pack(self, stream: Optional[int] = None):
+        """only the ops that write the network input from x_in / ctx_in (a fused sampler runs them once per trajectory: its step kernel
+        writes the next step's input itself, DDIMStepper)"""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        for op in self.pack_ops:
+            op(stream)
 
     def _add_cast(self, ops, src: torch.Tensor, dst: torch.Tensor):
         """dtype cast through torch (device plumbing, captured like any other node)."""

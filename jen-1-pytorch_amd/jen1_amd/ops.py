@@ -10,11 +10,15 @@ to ``torch.compile`` / ``torch.export`` / FakeTensor tracing and show up by name
   jen1::group_norm           GroupNorm (+FiLM) (+SiLU) on channel-last rows (blocks.py:137-143, :509), differentiable
   jen1::layer_norm           LayerNorm over the last axis (blocks.py:400-401), differentiable
   jen1::activation           GELU(erf) / SiLU (blocks.py:443, :158), differentiable
+  jen1::conv_forward         _Conv1d / nn.Conv1d / nn.ConvTranspose1d / nn.Linear (blocks.py:34-53, :69-95), differentiable: ONE backward
+                             op returns the data, weight and bias gradients (``conv1d_same`` / ``conv_transpose1d`` / ``linear`` below)
+  jen1::attention            the attention core of AttentionBase (blocks.py:300-330, :431-434), differentiable
 
 There is no CPU implementation behind any of them: without the HIP extension (or off a ROCm device) they raise ``Jen1HipError``.
 The training graph (jen1_amd/train.py) keeps its own ``autograd.Function``s for the parameterised operators: those accumulate
-weight gradients in place into the flat ``.grad`` buffer RCCL reduces, which a functional custom op cannot express without a
-copy per parameter.
+weight gradients in place into the flat ``.grad`` buffer RCCL reduces and read compute copies of the weights that are refreshed once
+per optimiser step; the functional ops here run the same kernels through the same host code (train._conv_forward / _conv_dgrad /
+_conv_wgrad, AttentionCoreFn) but return the gradients as tensors and pack the weight per call.
 """
 from __future__ import annotations
 
@@ -258,5 +262,210 @@ def _act_setup(ctx, inputs, output):
 activation.register_autograd(lambda ctx, dy: (torch.ops.jen1.activation_backward(dy, ctx.saved_tensors[0], ctx.mode), None),
                              setup_context=_act_setup)
 
+
+# ------------------------------------------------------------------------------------------------------------------ conv / linear
+# The GEMM-shaped training operators (a1, a2, a8 of SURVEY.md section 8): _Conv1d (blocks.py:34-53), nn.Conv1d / nn.ConvTranspose1d of
+# Upsample1d (blocks.py:69-95) and nn.Linear, forward on jen1_train_gemm / jen1_big_gemm_conv and -- as ONE backward op -- the data
+# gradient, the weight gradient and the bias gradient on jen1_train_gemm / jen1_big_gemm_tn_conv / jen1_colsum.  Functional form:
+# the gradients come back as tensors (the training graph's ConvFn accumulates them in place into the flat ``.grad`` buffer instead)
+# and the compute copy of the weight ([k][C_out][pad8(C_in)], the layout the kernels read) is made per call.
+_KINDS = ("conv", "convT", "linear")
+_rts: dict = {}
+
+
+def _rt(t: torch.Tensor):
+    from .train import TrainRuntime
+    _stream(t)
+    key = (t.device.index, t.dtype)
+    rt = _rts.get(key)
+    if rt is None:
+        rt = _rts[key] = TrainRuntime("f32" if _dt(t) == L.F32 else "bf16", t.device)
+    return rt
+
+
+def _pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def _compute_copy(rt, w: torch.Tensor, kind: str, dtype: torch.dtype) -> torch.Tensor:
+    d = rt._layout(w, kind)
+    k, r, c = d.shape
+    out = torch.zeros((k, r, _pad8(c)), dtype=dtype, device=w.device)
+    out[:, :, :c] = d
+    return out
+
+
+def _geom(kind: int, weight: torch.Tensor, x: torch.Tensor, stride: int, pad: int, L_out: int):
+    from .train import ConvGeom
+    if kind == 2:
+        co, ci = weight.shape
+        rows = x.numel() // x.shape[-1]
+        return ConvGeom("linear", 1, 1, 0, rows, rows, ci, co)
+    if kind == 0:
+        co, ci, k = weight.shape
+    else:
+        ci, co, k = weight.shape
+    return ConvGeom(_KINDS[kind], k, int(stride), int(pad), x.shape[1], int(L_out), ci, co)
+
+
+@custom_op("jen1::conv_forward", mutates_args=())
+def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], kind: int, stride: int, pad: int, L_out: int) -> torch.Tensor:
+    """x: channel-last [B, L_in, pad8(C_in)] in the compute dtype (padding lanes zero); weight in the reference layout
+    (kind 0 Conv1d [Co, Ci, k], 1 ConvTranspose1d [Ci, Co, k], 2 Linear [Co, Ci]); bias float32 [Co] or None.  kind 0: output position
+    t reads input rows t * stride - pad + tap (rows outside [0, L_in) are zeros); kind 1: ``pad`` is ConvTranspose1d's padding;
+    kind 2: L_out is ignored (rows in = rows out).  -> [B, L_out, pad8(Co)]"""
+    from .train import _conv_forward
+    assert 0 <= kind <= 2 and x.dim() == 3
+    rt = _rt(x)
+    x = x.contiguous()
+    g = _geom(kind, weight, x, stride, pad, L_out)
+    assert x.shape[-1] == _pad8(g.ci), f"jen1::conv_forward: {x.shape[-1]} input lanes for {g.ci} channels (pad to a multiple of 8)"
+    wp = _compute_copy(rt, weight, _KINDS[kind], x.dtype)
+    xin = x.view(1, -1, x.shape[-1]) if kind == 2 else x
+    y = _conv_forward(rt, xin, wp, None if bias is None else bias.detach().to(torch.float32).contiguous(), g)
+    return y.view(x.shape[0], x.shape[1], y.shape[-1]) if kind == 2 else y
+
+
+def _conv_out_len(kind, x, weight, L_out):
+    return x.shape[1] if kind == 2 else int(L_out)
+
+
+@conv_forward.register_fake
+def _(x, weight, bias, kind, stride, pad, L_out):
+    co = weight.shape[1] if kind == 1 else weight.shape[0]
+    return x.new_empty((x.shape[0], _conv_out_len(kind, x, weight, L_out), _pad8(co)))
+
+
+@custom_op("jen1::conv_backward", mutates_args=())
+def conv_backward(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, kind: int, stride: int, pad: int, has_bias: bool,
+                  need_dx: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(dx [x's shape; empty(0) unless need_dx], dweight float32 in the reference layout, dbias float32 [Co]; empty(0) unless has_bias)"""
+    from .train import _conv_dgrad, _conv_wgrad
+    rt = _rt(x)
+    x, dy = x.contiguous(), dy.contiguous()
+    g = _geom(kind, weight, x, stride, pad, dy.shape[1])
+    xin = x.view(1, -1, x.shape[-1]) if kind == 2 else x
+    dyin = dy.view(1, -1, dy.shape[-1]) if kind == 2 else dy
+    dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+    db = torch.zeros((g.co,), dtype=torch.float32, device=x.device) if has_bias else x.new_empty((0,), dtype=torch.float32)
+    if not _conv_wgrad(rt, xin, dyin, dw, g, db if has_bias else None) and has_bias:
+        ldy = dy.shape[-1]
+        L.check(rt.lib.jen1_colsum(dy.data_ptr(), db.data_ptr(), dy.numel() // ldy, g.co, ldy, rt.dt_of(dy), rt.stream()), "jen1_colsum")
+    if not need_dx:
+        return x.new_empty((0,)), dw, db
+    wp = _compute_copy(rt, weight, _KINDS[kind], x.dtype)
+    wd = _compute_copy(rt, weight, _KINDS[kind] + "D", x.dtype)
+    return _conv_dgrad(rt, dyin, wp, g, wd).view(x.shape), dw, db
+
+
+@conv_backward.register_fake
+def _(dy, x, weight, kind, stride, pad, has_bias, need_dx):
+    co = weight.shape[1] if kind == 1 else weight.shape[0]
+    f32 = torch.float32
+    return (torch.empty_like(x) if need_dx else x.new_empty((0,)), weight.new_empty(weight.shape, dtype=f32),
+            x.new_empty((co if has_bias else 0,), dtype=f32))
+
+
+def _conv_setup(ctx, inputs, output):
+    x, weight, bias, kind, stride, pad, L_out = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.kind, ctx.stride, ctx.pad, ctx.has_bias = kind, stride, pad, bias is not None
+    ctx.bias_dtype = None if bias is None else bias.dtype
+
+
+def _conv_backward(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dx, dw, db = torch.ops.jen1.conv_backward(dy, x, weight, ctx.kind, ctx.stride, ctx.pad, ctx.has_bias, ctx.needs_input_grad[0])
+    return (dx if ctx.needs_input_grad[0] else None, dw.to(weight.dtype), db.to(ctx.bias_dtype) if ctx.has_bias else None, None, None, None, None)
+
+
+conv_forward.register_autograd(_conv_backward, setup_context=_conv_setup)
+
+
+def conv1d_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, causal: bool = False) -> torch.Tensor:
+    """_Conv1d (blocks.py:34-53): total padding k - 1, all of it on the left when causal, else split evenly"""
+    k = weight.shape[2]
+    return torch.ops.jen1.conv_forward(x, weight, bias, 0, stride, (k - 1) if causal else (k - 1) // 2, (x.shape[1] - 1) // stride + 1)
+
+
+def conv_transpose1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, padding: int, output_padding: int) -> torch.Tensor:
+    """nn.ConvTranspose1d of Upsample1d (blocks.py:80-88)"""
+    k = weight.shape[2]
+    return torch.ops.jen1.conv_forward(x, weight, bias, 1, stride, padding, (x.shape[1] - 1) * stride - 2 * padding + k + output_padding)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear on the last axis of [B, L, pad8(C_in)]"""
+    return torch.ops.jen1.conv_forward(x, weight, bias, 2, 1, 0, x.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------------------------ attention core
+class _Ctx:
+    """what AttentionCoreFn's static methods need of an autograd context"""
+
+    def save_for_backward(self, *t):
+        self.saved_tensors = t
+
+
+@custom_op("jen1::attention", mutates_args=())
+def attention(q: torch.Tensor, kv: torch.Tensor, heads: int, causal: bool, kv_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """softmax(q k^T / sqrt(d) [+ causal mask]) v per head (blocks.py:300-330 AttentionBase; kv = to_kv's output K | V [B, Nk, 2 C],
+    kv_mask [B, Nk] multiplied into the rows of K and V, blocks.py:431-434).  -> (out [B, Nq, C], probabilities [B heads, Nq, pad8(Nk)])"""
+    from .train import AttentionCoreFn
+    rt = _rt(q)
+    q, kv = q.contiguous(), kv.contiguous()
+    small = bool(rt.small_attn and rt.lib.jen1_attn_small_fits(q.shape[1], kv.shape[1], q.shape[2] // heads, rt.dt_of(q)))
+    if kv_mask is not None and not small:
+        kv, kv_mask = kv * kv_mask.to(kv.dtype)[:, :, None], None
+    ctx = _Ctx()
+    out = AttentionCoreFn.forward(ctx, q, kv, rt, int(heads), bool(causal), kv_mask)
+    return out, ctx.saved_tensors[2]
+
+
+@attention.register_fake
+def _(q, kv, heads, causal, kv_mask):
+    return torch.empty_like(q), q.new_empty((q.shape[0] * heads, q.shape[1], _pad8(kv.shape[1])))
+
+
+@custom_op("jen1::attention_backward", mutates_args=())
+def attention_backward(dout: torch.Tensor, q: torch.Tensor, kv: torch.Tensor, probs: torch.Tensor, heads: int,
+                       kv_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dq, dkv) from the saved probabilities"""
+    from .train import AttentionCoreFn
+    rt = _rt(q)
+    q, kv = q.contiguous(), kv.contiguous()
+    ctx = _Ctx()
+    ctx.rt, ctx.heads, ctx.scale = rt, int(heads), (q.shape[2] // heads) ** -0.5
+    ctx.small = bool(rt.small_attn and rt.lib.jen1_attn_small_fits(q.shape[1], kv.shape[1], q.shape[2] // heads, rt.dt_of(q)))
+    ctx.kv_row = ctx.dkv_slot = None
+    mask = None if kv_mask is None else kv_mask.to(torch.float32).contiguous()
+    ctx.kv_mask = mask if ctx.small else None
+    kvm = kv if (mask is None or ctx.small) else kv * mask.to(kv.dtype)[:, :, None]
+    ctx.saved_tensors = (q, kvm, probs)
+    dq, dkv = AttentionCoreFn.backward(ctx, dout)[:2]
+    if mask is not None and not ctx.small:
+        dkv = dkv * mask.to(dkv.dtype)[:, :, None]
+    return dq, dkv
+
+
+@attention_backward.register_fake
+def _(dout, q, kv, probs, heads, kv_mask):
+    return torch.empty_like(q), torch.empty_like(kv)
+
+
+def _attn_setup(ctx, inputs, output):
+    q, kv, heads, causal, kv_mask = inputs
+    ctx.save_for_backward(q, kv, output[1], kv_mask if kv_mask is not None else q.new_empty(0))
+    ctx.heads, ctx.has_mask = heads, kv_mask is not None
+
+
+def _attn_backward(ctx, dout, dprobs):
+    q, kv, probs, mask = ctx.saved_tensors
+    dq, dkv = torch.ops.jen1.attention_backward(dout, q, kv, probs, ctx.heads, mask if ctx.has_mask else None)
+    return dq, dkv, None, None, None
+
+
+attention.register_autograd(_attn_backward, setup_context=_attn_setup)
+
 OPS = ("unet_cfg_forward", "cfg_combine", "group_norm", "group_norm_backward", "layer_norm", "layer_norm_backward", "activation",
-       "activation_backward")
+       "activation_backward", "conv_forward", "conv_backward", "attention", "attention_backward")

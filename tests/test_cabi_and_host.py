@@ -385,6 +385,14 @@ def test_torch_library_ops_are_registered_with_schemas_and_fake_impls():
         assert yl.shape == h.shape and tuple(st.shape) == (B * T, 2)
         assert torch.ops.jen1.activation(h, 0).shape == h.shape
         assert tuple(torch.ops.jen1.cfg_combine(torch.empty((2 * B, T, 128)), 128, 0.8, True, 0.7).shape) == (B, 128, T)
+        # the GEMM-shaped training operators: _Conv1d (strided, causal), ConvTranspose1d, Linear and the attention core
+        assert tuple(ops.conv1d_same(h, torch.empty((100, 64, 5)), torch.empty((100,)), 2, True).shape) == (B, (T - 1) // 2 + 1, 104)
+        assert tuple(ops.conv_transpose1d(h, torch.empty((64, 32, 4)), None, 2, 1, 0).shape) == (B, 2 * T, 32)
+        assert tuple(ops.linear(h, torch.empty((256, 64))).shape) == (B, T, 256)
+        o, pr = torch.ops.jen1.attention(h, torch.empty((B, 129, 128), dtype=torch.bfloat16), 8, False, torch.empty((B, 129)))
+        assert o.shape == h.shape and tuple(pr.shape) == (B * 8, T, 136)
+        dx, dw, db = torch.ops.jen1.conv_backward(torch.empty((B, T, 104), dtype=torch.bfloat16), h, torch.empty((100, 64, 5)), 0, 1, 2, True, True)
+        assert dx.shape == h.shape and tuple(dw.shape) == (100, 64, 5) and dw.dtype == torch.float32 and tuple(db.shape) == (100,)
     # the real call without a GPU fails loudly (no CPU path)
     import pytest
     from jen1_amd.lib import Jen1HipError

@@ -234,3 +234,33 @@ def test_default_sampling_is_bit_reproducible(full_bf16):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]), "two replayed trajectories differ"
     assert torch.equal(outs[0], outs[2]), "the replayed and the eager trajectory differ"
+
+
+@pytest.mark.parametrize("scale,eta", [(1.0, 1.0), (3.0, 1.0), (1.0, 0.0)])
+def test_fused_step_pack_matches_separate_pack(full_bf16, monkeypatch, scale, eta):
+    """the sampler's step kernel writes the next step's network input (jen1_cfg_ddim_step_pack: rows in the compute dtype + statistics
+    partials in pack_input's order) instead of a pack launch at the head of every step: same bits as the separate launches, with and
+    without the CFG pair, with and without per-step noise, eagerly and as a replayed graph"""
+    from jen1_amd.diffusion import DDIMStepper, GaussianDiffusion, get_beta_schedule
+    m = full_bf16
+    B, T, S = 2, 1500, 3
+    betas, _ = get_beta_schedule("linear", 1000)
+    gd = GaussianDiffusion(steps=1000, betas=betas, objective="v", loss_type="l2", device="cuda", cfg_dropout_proba=0.0,
+                           embedding_scale=scale, batch_cfg=True, scale_cfg=True, sampling_timesteps=S, ddim_sampling_eta=eta)
+    cond = {k: dev(v) for k, v in synth.conditioning(B, T).items()}
+    init = dev(synth.noise_list(1, (B, 128, T), seed=3)[0])
+    noises = [dev(n) for n in synth.noise_list(S, (B, 128, T), seed=5)]
+    outs = {}
+    for flag, ug in (("0", False), ("1", False), ("1", True)):
+        monkeypatch.setenv("JEN1_STEP_PACK", flag)
+        st = DDIMStepper(gd, m, (B, 128, T), cond, use_graph=ug)
+        assert st.fused_pack == (flag == "1")
+        st.reset(init, fresh_noise=False)
+        for i in range(S):
+            st.step(i, noise=noises[i])
+        st.check()
+        outs[(flag, ug)] = st.x.clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[("0", False)]).all()
+    assert torch.equal(outs[("0", False)], outs[("1", False)]), "fused step + pack differs from the separate pack launch"
+    assert torch.equal(outs[("1", False)], outs[("1", True)]), "replayed fused step differs from the eager one"

@@ -1092,6 +1092,71 @@ def test_torch_library_training_ops_match_torch_autograd():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_torch_library_gemm_ops_match_torch_autograd(mode):
+    """torch.ops.jen1.conv_forward (as _Conv1d causal / centred / strided, nn.ConvTranspose1d, nn.Linear) and torch.ops.jen1.attention
+    (jen1_amd/ops.py: dispatcher ops, ONE registered backward op each) against torch float32 autograd of the reference's operators
+    (blocks.py:34-53, :80-88, :300-330, :431-434): output, data gradient, weight / bias gradients.  float32 mode <= 1e-3 (the
+    north-star tolerance); bf16 operands <= 3e-2 of the largest entry"""
+    import torch.nn.functional as F
+    from jen1_amd import ops
+    torch.manual_seed(1)
+    dev = "cuda"
+    cdt = torch.float32 if mode == "f32" else torch.bfloat16
+    tol = 1e-3 if mode == "f32" else 3e-2
+    rel = lambda a, b: float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()), 1e-12)
+
+    def leaf(*shape, scale=1.0):
+        # (values on the compute dtype's grid, so that both sides see the same operands)
+        return (torch.randn(shape, device=dev) * scale).to(cdt).float().requires_grad_()
+
+    def check(name, y, yr, params, wts):
+        (y.float() * wts).sum().backward()
+        got = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        (yr * wts).sum().backward()
+        assert rel(y.detach(), yr.detach()) < tol, (name, "y", rel(y.detach(), yr.detach()))
+        for i, (a, p) in enumerate(zip(got, params)):
+            assert rel(a, p.grad) < tol, (name, i, rel(a, p.grad))
+            p.grad = None
+
+    B, Lx, Ci, Co = 3, 37, 64, 96
+    for k, stride, causal in ((3, 1, False), (3, 1, True), (5, 2, True), (1, 1, False), (9, 4, False)):
+        x, w, b = leaf(B, Lx, Ci), leaf(Co, Ci, k, scale=0.1), leaf(Co, scale=0.1)
+        xc = x.to(cdt)                                  # (a non-leaf view in the compute dtype: the gradient flows back through the cast)
+        y = ops.conv1d_same(xc, w, b, stride, causal)[..., :Co]
+        pl = (k - 1) if causal else (k - 1) // 2
+        yr = F.conv1d(F.pad(x.transpose(1, 2), (pl, k - 1 - pl)), w, b, stride=stride).transpose(1, 2)
+        assert y.shape == yr.shape, (y.shape, yr.shape)
+        check(f"conv k={k} s={stride} causal={causal}", y, yr, [x, w, b], torch.randn(yr.shape, device=dev))
+    # nn.ConvTranspose1d as Upsample1d builds it (blocks.py:80-88: kernel 2 f, stride f, padding f // 2 + f % 2, output_padding f % 2)
+    for f in (2, 4):
+        x, w, b = leaf(B, Lx, Ci), leaf(Ci, Co, 2 * f, scale=0.1), leaf(Co, scale=0.1)
+        y = ops.conv_transpose1d(x.to(cdt), w, b, f, f // 2 + f % 2, f % 2)[..., :Co]
+        yr = F.conv_transpose1d(x.transpose(1, 2), w, b, stride=f, padding=f // 2 + f % 2, output_padding=f % 2).transpose(1, 2)
+        assert y.shape == yr.shape
+        check(f"convT f={f}", y, yr, [x, w, b], torch.randn(yr.shape, device=dev))
+    x, w, b = leaf(B, Lx, Ci), leaf(100, Ci, scale=0.1), leaf(100, scale=0.1)
+    y = ops.linear(x.to(cdt), w, b)
+    assert y.shape[-1] == 104 and float(y.detach()[..., 100:].abs().max()) == 0.0   # (padding lanes stay zero)
+    check("linear", y[..., :100], F.linear(x, w, b), [x, w, b], torch.randn((B, Lx, 100), device=dev))
+    # the attention core: self-attention (causal and not) and cross-attention over masked context rows
+    heads, C = 2, 64
+    for Nq, Nk, causal, masked in ((37, 37, False, False), (37, 37, True, False), (12, 129, False, True), (300, 300, False, False)):
+        q, kv = leaf(B, Nq, C), leaf(B, Nk, 2 * C)
+        mask = (torch.rand((B, Nk), device=dev) > 0.3).float() if masked else None
+        o, _ = torch.ops.jen1.attention(q.to(cdt), kv.to(cdt), heads, causal, mask)
+        kvm = kv if mask is None else kv * mask[:, :, None]
+        split = lambda t: t.view(B, -1, heads, C // heads).transpose(1, 2)
+        sim = split(q) @ split(kvm[..., :C]).transpose(-1, -2) * (C // heads) ** -0.5
+        if causal:
+            sim = sim.masked_fill(torch.ones((Nq, Nk), dtype=torch.bool, device=dev).triu(1), -torch.finfo(sim.dtype).max)
+        orf = (sim.softmax(-1) @ split(kvm[..., C:])).transpose(1, 2).reshape(B, Nq, C)
+        check(f"attention Nq={Nq} Nk={Nk} causal={causal} masked={masked}", o, orf, [q, kv], torch.randn((B, Nq, C), device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_concat_scale_forward_backward(rts, mode):
     """jen1_concat2 / jen1_split2: torch.cat([a, b * 2^-1/2], -1) of the up path (blocks.py:732-734) and its gradient"""
     from jen1_amd import train as TR
