@@ -11,7 +11,10 @@ BASELINE.json configs[1]: full JEN-1 1D-UNet (296.5 M parameters, random init), 
 Encodec latents 128x1500, 100-step DDIM schedule, bf16 storage / fp32 accumulate.  With N>1 every
 rank runs its own B=8 batch (independent samples, no data-path collective): weak scaling.
 
-Inside the timed region: every launch of the step.  Computed once per sampling run, outside it: the text
+Inside the timed region: every launch of the step -- five since round 6: the sample-resident long-level launch of the down path
+(csrc/long_kernel.hip), the persistent deep-level launch (csrc/deep_kernel.hip), the long-level launch of the up path, the step's
+tail (jen1_step_tail: CFG / DDIM update, the next step's network input, the next step's sentinels) and the sum of the input's
+GroupNorm partials.  Computed once per sampling run, outside it: the text
 K/V projection and the time-embedding / FiLM / time-token K/V tables of the whole schedule; the DDIM
 noise (eta = 1, the reference's default) is a table drawn before the region and read inside it; CFG
 dropout is off (sampling).  ``extra.end_to_end`` times whole ``sample()`` calls including all of that.
@@ -22,8 +25,8 @@ The JSON line also carries
                    runs every level below T'=64 as one phase list): algorithmic HBM bytes of its
                    phases / its measured launch duration (HIP events on the launch stream, the
                    launch replayed alone in a HIP graph) against the 8 TB/s HBM3E peak of
-                   MI355X_MICROARCH.md; ``long_levels`` holds the same figure for the fused
-                   conv-GEMM launches of the levels above it;
+                   MI355X_MICROARCH.md; ``long_levels`` holds the same figure for the two
+                   sample-resident launches of the levels above it (``long_kernel``);
   cpu_baseline  -- the torch-CPU oracle (oracle/jen1_oracle_torch.py, a restatement of the
                    reference's CPU path, all physical host cores) on a bounded sample of the same
                    workload (rank 0, N=1 only);
@@ -859,7 +862,10 @@ def main():
         Cx_, Cc_ = model.spec.in_channels, model.spec.ctx_ch0
         # the two kernels at the step's boundary: pack_input reads x and the concat context as float32 [B, C, T] and writes the channel-last
         # network input; the fused CFG / DDIM step reads the network output, x and the noise and writes x
-        pack_bytes = B * (Cx_ + Cc_) * T * 4 + pl_.Beff * T * (-(-(Cx_ + Cc_) // 32) * 32) * es_
+        # (fused sampler step, DDIMStepper.fused_pack: the step kernel writes the latents' channels of the next network input itself -- the
+        # concat context is packed once per trajectory -- so the step's own packing traffic is those rows)
+        fused_ = bool(getattr(st, "fused_pack", False))
+        pack_bytes = (pl_.Beff * T * Cx_ * es_) if fused_ else (B * (Cx_ + Cc_) * T * 4 + pl_.Beff * T * (-(-(Cx_ + Cc_) // 32) * 32) * es_)
         cfg_bytes = pl_.Beff * T * model.spec.out_channels * es_ + B * model.spec.out_channels * T * 12
         step_alg = sum(getattr(op, "w_bytes", 0) + getattr(op, "act_bytes", 0) for op in st.plan.ops) + pack_bytes + cfg_bytes
         step_gbs = step_alg / (dt / args.steps) / 1e9
@@ -867,7 +873,9 @@ def main():
                                          "of_which_cfg_ddim_step": int(cfg_bytes), "ms_per_step": round(dt / args.steps * 1e3, 4),
                                          "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                                          "executed_gflop_per_step": round(sum(getattr(op, "flops", 0) for op in st.plan.ops) / 1e9, 2)}
-        out["launches_per_step"] = st.plan.n_launch + 1
+        out["launches_per_step"] = getattr(st, "launches_per_step", st.plan.n_launch + 1)
+        out["step_launches"] = ("long (down levels), deep, long (up levels), step_tail (CFG / DDIM update + next input rows + next step's sentinels "
+                                "and arena reset), gn_stats_from_parts" if getattr(st, "fused_tail", False) else None)
         if args.dtype == "bf16":
             kvr = kv_gemm_roofline(st)
             if kvr is not None:
@@ -888,7 +896,7 @@ def main():
             n_d = max(10, args.steps // 2)
             dt_d = timed_steps(st_d, n_d, max(3, args.warmup // 2), lambda: None)
             extra["deterministic statistics mode, steps/s"] = round(n_d / dt_d, 2)
-            extra["deterministic statistics mode, launches_per_step"] = st_d.plan.n_launch + 1
+            extra["deterministic statistics mode, launches_per_step"] = getattr(st_d, "launches_per_step", st_d.plan.n_launch + 1)
             del st_d
             model.deterministic = False
             if not args.tiny and not args.no_graph:
@@ -914,7 +922,7 @@ def main():
                 dtt = timed_steps(stt, ntl, max(3, args.warmup // 2), lambda: None)
                 stt.check()
                 extra["long levels as tile phases (JEN1_TILE_PHASES=1)"] = {
-                    "steps_per_s": round(ntl / dtt, 2), "launches_per_step": stt.plan.n_launch + 1,
+                    "steps_per_s": round(ntl / dtt, 2), "launches_per_step": getattr(stt, "launches_per_step", stt.plan.n_launch + 1),
                     "programs": [{"phases": len(p_), "tile_phases": p_.kinds.count("tile")} for p_ in stt.plan.progs]}
                 del stt, mt
             if not args.tiny:
@@ -933,7 +941,7 @@ def main():
                     r5 = conv_roofline(st5)
                     d5 = deep_roofline(st5, args.dtype)
                     extra["configs[4] kernels"] = {
-                        "launches_per_step": st5.plan.n_launch + 1,
+                        "launches_per_step": getattr(st5, "launches_per_step", st5.plan.n_launch + 1),
                         "long_levels": {k: r5[k] for k in ("launches_per_step", "avg_launch_us", "conv_ms_per_step", "alg_bytes_per_step", "achieved",
                                                            "frac", "executed_gflop_per_step", "slowest_launches_us")},
                         "deep_kernel": None if d5 is None else {k: d5[k] for k in ("phases", "avg_launch_us", "us_per_phase", "alg_bytes_per_launch",

@@ -310,6 +310,14 @@ int jen1_cfg_ddim_step_adv(const void* net, const float* x, const float* noise, 
 int jen1_cfg_ddim_step_pack(const void* net, const float* x, const float* noise, const float* coef, float* x_out, int32_t* step_idx,
                             uint32_t* ticket, void* rows, float* parts, int ld_rows, int B, int C, int T, int ld, int nrep,
                             float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype, void* stream);
+/* jen1_cfg_ddim_step_pack and the head of the NEXT replayed step in one launch: the blocks behind the step's set every tensor of the
+ * next step's persistent launches to the all-ones sentinel and zero the statistics arena (jen1_deep_poison_zero's job, include/jen1_deep.h:
+ * poison_table = its n_rows {pointer, bytes} rows, sync / zero_ptr / zero_bytes as there).  A replayed sampler step is then the three
+ * persistent launches, this one and jen1_gn_stats_from_parts. */
+int jen1_step_tail(const void* net, const float* x, const float* noise, const float* coef, float* x_out, int32_t* step_idx,
+                   uint32_t* ticket, void* rows, float* parts, int ld_rows, int B, int C, int T, int ld, int nrep,
+                   float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype,
+                   const void* poison_table, int n_rows, uint32_t* sync, void* zero_ptr, int64_t zero_bytes, void* stream);
 
 /* CFG combine + rescale only: writes the guided denoiser output [B][C][T] float32 (model.py:362-369). */
 int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale, int scale_cfg,

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
       for (int j = 0; j < 32; ++j) {
         const float v = tile[r][j];
         sv += v;
-        sq += v * v;
+        sq = __builtin_fmaf(v, v, sq);
       }
       *reinterpret_cast<float2*>(parts + (((size_t)b * gridDim.x + blockIdx.x) * ld + c0 + r) * 2) = make_float2(sv, sq);
     }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
       for (int j = 0; j < 32; ++j) {
         const float v = tile[r][j];
         sv += v;
-        sq += v * v;
+        sq = __builtin_fmaf(v, v, sq);
       }
       if (sq != 0.f) {
         const int fg = (c0 + r) / cpf;
@@ -464,15 +464,20 @@ __device__ __forceinline__ float half_wave_sum(float v) {           // over the 
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);              // lanes ^ 16
 }
 
+// (bx, by) of (nbx, nby): the block's place in the step's grid -- the kernel's own grid, or the leading blocks of step_tail_kernel's
 template <typename T, bool DDIM>
-__global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__ net, const float* __restrict__ x,
-                                                            const float* __restrict__ noise, const float* __restrict__ coef,
-                                                            float* __restrict__ x_out, float* __restrict__ eps_out,
-                                                            float* __restrict__ x0_out, const int32_t* step_idx,
-                                                            int B, int C, int Tn, int ld, int nrep,
-                                                            float scale, int scale_cfg, float phi, int objective, int clip_x0,
-                                                            int32_t* adv_step, unsigned* __restrict__ adv_ticket,
-                                                            T* __restrict__ rows, float* __restrict__ parts, int ld_rows) {
+__device__ __forceinline__ void cfg_step_vec_body(const T* __restrict__ net, const float* __restrict__ x,
+                                                  const float* __restrict__ noise, const float* __restrict__ coef,
+                                                  float* __restrict__ x_out, float* __restrict__ eps_out,
+                                                  float* __restrict__ x0_out, const int32_t* step_idx,
+                                                  int B, int C, int Tn, int ld, int nrep,
+                                                  float scale, int scale_cfg, float phi, int objective, int clip_x0,
+                                                  int32_t* adv_step, unsigned* __restrict__ adv_ticket,
+                                                  T* __restrict__ rows, float* __restrict__ parts, int ld_rows,
+                                                  const int bx, const int by, const int nbx, const int nby) {
+  // (no implicit multiply-add fusion in here: the body is inlined into two kernels and, whichever one runs a step, the trajectory must
+  // come out on the same bits; the statistics sums below fuse explicitly, as pack_input_kernel's do)
+#pragma clang fp contract(off)
   extern __shared__ float tile[];   // [C][33] + one word per 8 channels
   float cf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (DDIM) {
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; ++i) cf[i] = coef[i];
   }
-  const int t0 = blockIdx.x * 32, b = blockIdx.y;
+  const int t0 = bx * 32, b = by;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t = t0 + tx;
   const int tcl = t < Tn ? t : Tn - 1;
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
   }
   __syncthreads();
   if (adv_ticket != nullptr && threadIdx.x == 0) {
-    const unsigned nblk = gridDim.x * gridDim.y;
+    const unsigned nblk = (unsigned)(nbx * nby);
     if (atomicAdd(adv_ticket, 1u) == nblk - 1u) {
       __hip_atomic_fetch_add(adv_step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       adv_ticket[0] = 0u;
@@ -626,10 +631,62 @@ __global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__
     for (int j = 0; j < 32; ++j) {
       const float v = tile[c * 33 + (c >> 3) + j];
       sv += v;
-      sq += v * v;
+      sq = __builtin_fmaf(v, v, sq);
     }
-    *reinterpret_cast<float2*>(parts + (((size_t)b * gridDim.x + blockIdx.x) * ld_rows + c) * 2) = make_float2(sv, sq);
+    *reinterpret_cast<float2*>(parts + (((size_t)b * nbx + bx) * ld_rows + c) * 2) = make_float2(sv, sq);
   }
+}
+
+
+template <typename T, bool DDIM>
+__global__ __launch_bounds__(256) void cfg_step_vec_kernel(const T* __restrict__ net, const float* __restrict__ x,
+                                                            const float* __restrict__ noise, const float* __restrict__ coef,
+                                                            float* __restrict__ x_out, float* __restrict__ eps_out,
+                                                            float* __restrict__ x0_out, const int32_t* step_idx,
+                                                            int B, int C, int Tn, int ld, int nrep,
+                                                            float scale, int scale_cfg, float phi, int objective, int clip_x0,
+                                                            int32_t* adv_step, unsigned* __restrict__ adv_ticket,
+                                                            T* __restrict__ rows, float* __restrict__ parts, int ld_rows) {
+  cfg_step_vec_body<T, DDIM>(net, x, noise, coef, x_out, eps_out, x0_out, step_idx, B, C, Tn, ld, nrep, scale, scale_cfg, phi, objective,
+                             clip_x0, adv_step, adv_ticket, rows, parts, ld_rows, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// ---- the tail of a replayed sampler step as ONE launch: the first nbx * nby blocks are the CFG / DDIM step + the next step's packed input
+// (above), the blocks behind them set every tensor of the next step's persistent launches to the all-ones sentinel and zero the
+// statistics arena (deep_kernel.hip's poison_kernel: same table, same 8 blocks per row).  Nothing orders the two jobs -- the step
+// reads the network output and the latents, the sentinel rows are the activations in between -- and one is a latency chain of a few
+// loads per thread while the other streams ~60 MB of stores: side by side they last as long as the longer one.
+struct TailPoisonEntry {
+  unsigned long long ptr, bytes;          // bytes: a multiple of 16 (= deep_kernel.hip PoisonEntry)
+};
+struct TailArgs {
+  const void* net; const float* x; const float* noise; const float* coef; float* x_out; int32_t* step_idx; unsigned* ticket;
+  void* rows; float* parts; int ld_rows, B, C, Tn, ld, nrep; float scale; int scale_cfg; float phi; int objective, clip_x0;
+  const TailPoisonEntry* tab; int n_tab, z_rows; unsigned* sync; void* zero_ptr; unsigned long long zero_bytes;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs a) {
+  const int nbx = (a.Tn + 31) / 32, nstep = nbx * a.B;
+  if ((int)blockIdx.x < nstep) {
+    cfg_step_vec_body<T, true>((const T*)a.net, a.x, a.noise, a.coef, a.x_out, nullptr, nullptr, a.step_idx, a.B, a.C, a.Tn, a.ld, a.nrep,
+                               a.scale, a.scale_cfg, a.phi, a.objective, a.clip_x0, a.step_idx, a.ticket, (T*)a.rows, a.parts, a.ld_rows,
+                               (int)blockIdx.x % nbx, (int)blockIdx.x / nbx, nbx, a.B);
+    return;
+  }
+  const int pid = (int)blockIdx.x - nstep, px = pid & 7, py = pid >> 3;
+  if (py >= a.n_tab) {
+    uint4* z = reinterpret_cast<uint4*>(a.zero_ptr);
+    const size_t n = a.zero_bytes >> 4;
+    const size_t nblk = (size_t)8 * a.z_rows, blk = (size_t)(py - a.n_tab) * 8 + px;
+    for (size_t i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const TailPoisonEntry e = a.tab[py];
+  uint4* p = reinterpret_cast<uint4*>(e.ptr);
+  const size_t n = e.bytes >> 4;
+  const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+  for (size_t i = (size_t)px * 256 + threadIdx.x; i < n; i += (size_t)8 * 256) p[i] = ones;
+  if (a.sync && pid == 0 && threadIdx.x == 0) a.sync[0] = 0u;
 }
 
 }  // namespace
@@ -813,6 +870,45 @@ extern "C" int jen1_cfg_ddim_step_pack(const void* net, const float* x, const fl
   JEN1_CHECK(objective >= 0 && objective <= 2, "cfg_ddim_step_pack: bad objective");
   return launch_cfg<true>(net, x, noise, coef, x_out, nullptr, nullptr, step_idx, B, C, T, ld, nrep, embedding_scale, scale_cfg,
                           scale_phi, objective, clip_x0, dtype, stream, step_idx, ticket, rows, parts, ld_rows);
+}
+
+extern "C" int jen1_step_tail(const void* net, const float* x, const float* noise, const float* coef, float* x_out, int32_t* step_idx,
+                             uint32_t* ticket, void* rows, float* parts, int ld_rows, int B, int C, int T, int ld, int nrep,
+                             float embedding_scale, int scale_cfg, float scale_phi, int objective, int clip_x0, int dtype,
+                             const void* poison_table, int n_rows, uint32_t* sync, void* zero_ptr, int64_t zero_bytes, void* stream) {
+  JEN1_CHECK(net && x && coef && x_out && step_idx && ticket && rows && parts, "step_tail: null net / x / coef / x_out / step_idx / ticket / rows / parts");
+  JEN1_CHECK(objective >= 0 && objective <= 2 && (nrep == 1 || nrep == 2), "step_tail: bad objective / nrep");
+  JEN1_CHECK(dtype == JEN1_F32 || dtype == JEN1_BF16, "step_tail: bad dtype");
+  const int esz = dtype == JEN1_F32 ? 4 : 2;
+  JEN1_CHECK(C >= 8 && C <= 256 && C % 8 == 0 && ld >= C && ld % 8 == 0 && ((uintptr_t)net & 15) == 0 && ((size_t)ld * esz) % 16 == 0,
+             "step_tail: the network output must be 16-byte rows of C %% 8 == 0 channels (C <= 256)");
+  JEN1_CHECK(ld_rows >= C && ((size_t)ld_rows * esz) % 16 == 0 && ((uintptr_t)rows & 15) == 0 && ((uintptr_t)parts & 7) == 0,
+             "step_tail: rows must be 16-byte aligned with ld_rows >= C");
+  JEN1_CHECK(poison_table && n_rows >= 1 && n_rows <= 60000, "step_tail: bad sentinel table");
+  JEN1_CHECK(zero_ptr && zero_bytes > 0 && (zero_bytes & 15) == 0 && ((uintptr_t)zero_ptr & 15) == 0, "step_tail: the zeroed area must be 16-byte aligned and sized");
+  int zrows = (int)((zero_bytes + (1 << 18) - 1) >> 18);
+  zrows = zrows < 1 ? 1 : (zrows > 64 ? 64 : zrows);
+  TailArgs a;
+  a.net = net; a.x = x; a.noise = noise; a.coef = coef; a.x_out = x_out; a.step_idx = step_idx; a.ticket = ticket;
+  a.rows = rows; a.parts = parts; a.ld_rows = ld_rows; a.B = B; a.C = C; a.Tn = T; a.ld = ld; a.nrep = nrep;
+  a.scale = embedding_scale; a.scale_cfg = scale_cfg; a.phi = scale_phi; a.objective = objective; a.clip_x0 = clip_x0;
+  a.tab = reinterpret_cast<const TailPoisonEntry*>(poison_table); a.n_tab = n_rows; a.z_rows = zrows; a.sync = sync;
+  a.zero_ptr = zero_ptr; a.zero_bytes = (unsigned long long)zero_bytes;
+  const int nstep = ((T + 31) / 32) * B;
+  const dim3 grid(nstep + 8 * (n_rows + zrows));
+  const size_t lds = sizeof(float) * ((size_t)C * 33 + C / 8 + 1);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == JEN1_F32) {
+    auto kern = step_tail_kernel<float>;
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  } else {
+    auto kern = step_tail_kernel<bf16_t>;
+    JEN1_MAX_LDS_ONCE(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  }
+  JEN1_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int jen1_cfg_combine(const void* net, float* out, int B, int C, int T, int ld, float embedding_scale,

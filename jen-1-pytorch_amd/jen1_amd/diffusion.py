@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .graphs import capture as capture_graph
+from .engine import DeepProgram
 from .model import _STEPPER_CACHES, UNetCFG1d
 
 _OBJ = {"noise": 0, "x0": 1, "v": 2}
@@ -417,19 +418,28 @@ class DDIMStepper:
             # trajectory (``_pack_dirty``: after reset / rebind, before the first step)
             fused = (os.environ.get("JEN1_STEP_PACK", "1") == "1" and plan.pack_rows is not None and Co % 8 == 0
                      and Co == model.spec.in_channels and os.environ.get("JEN1_CFG_STEP_SCALAR") is None)
+            # ... and (JEN1_STEP_TAIL, default on) the same launch sets the next step's sentinels and zeroes its statistics arena, the
+            # job of the node at the head of a step: a replayed step is the three persistent launches + jen1_step_tail + the partials' sum
+            tail = fused and os.environ.get("JEN1_STEP_TAIL", "1") == "1" and plan.poison_args is not None
             if fused:
                 rows_ptr, parts_ptr, ld_rows = plan.pack_rows
                 pk_args = args[:5] + (sp, ticket.data_ptr(), rows_ptr, parts_ptr, ld_rows) + args[8:]
+                tl_args = pk_args + plan.poison_args if tail else None
 
-                def run(s, plan=plan, pk_args=pk_args, ticket=ticket):
-                    plan.run(s, pack=False)
-                    L.check(lib.jen1_cfg_ddim_step_pack(*pk_args, s), "jen1_cfg_ddim_step_pack")
+                def run(s, plan=plan, pk_args=pk_args, tl_args=tl_args, ticket=ticket):
+                    if tl_args is not None:
+                        plan.run(s, pack=False, poison=False)
+                        L.check(lib.jen1_step_tail(*tl_args, s), "jen1_step_tail")
+                    else:
+                        plan.run(s, pack=False)
+                        L.check(lib.jen1_cfg_ddim_step_pack(*pk_args, s), "jen1_cfg_ddim_step_pack")
                     plan.pack_stats_op(s)
             else:
                 def run(s, plan=plan, adv_args=adv_args, ticket=ticket):
                     plan.run(s)
                     L.check(lib.jen1_cfg_ddim_step_adv(*adv_args, s), "jen1_cfg_ddim_step_adv")
             self.fused_pack = getattr(self, "fused_pack", True) and fused
+            self.fused_tail = getattr(self, "fused_tail", True) and tail
 
             self.parts.append((sl, plan, run, ntab))
             b0 += nb
@@ -437,6 +447,7 @@ class DDIMStepper:
         self.streams = [torch.cuda.Stream(dev) for _ in self.parts] if len(self.parts) > 1 else []
         self._next = 0
         self._pack_dirty = True
+        self._seen_serial = -1
         self._set_step(0)                             # the cached plan may carry a previous run's counter
         self.graph = None
         self.graphs = None
@@ -504,6 +515,15 @@ class DDIMStepper:
             plan._cond_refs = (emb, msk)
         self._pack_dirty = True                    # (the concat context is part of the packed rows)
 
+    @property
+    def launches_per_step(self) -> int:
+        """kernel launches of one replayed step (first sub-batch): the plan's, minus what the fused step kernel took over, plus that kernel
+        and the sum of its statistics partials"""
+        plan = self.plan
+        skip = (("pack",) if self.fused_pack else ()) + (("deep_poison",) if self.fused_tail else ())
+        n = sum(1 for op in plan.ops if getattr(op, "kind", "") not in skip) + (0 if plan.table_mode else len(plan.time_ops))
+        return n + 1 + (1 if self.fused_pack else 0)
+
     def mark_dirty(self) -> None:
         """the latents (``x``) or the concat context were written from outside: the next step re-packs the network input from them"""
         self._pack_dirty = True
@@ -511,7 +531,10 @@ class DDIMStepper:
     def _pack_if_dirty(self):
         if self._pack_dirty and self.fused_pack:
             for _, plan, _, _ in self.parts:
-                plan.run_pack(torch.cuda.current_stream(self.gd.device).cuda_stream)
+                s = torch.cuda.current_stream(self.gd.device).cuda_stream
+                plan.run_pack(s)
+                if self.fused_tail:
+                    plan.run_poison(s)
         self._pack_dirty = False
 
     def _run_all(self):
@@ -590,6 +613,8 @@ class DDIMStepper:
         if noise is not None and i < self.num_steps - 1 and self.mode != "vdm":
             self.noise_all[i].copy_(noise.to(self.noise_all.device, torch.float32))
             self._push_noise(i)
+        if self.fused_pack and DeepProgram.host_serial[0] != self._seen_serial:
+            self._pack_dirty = True                # (somebody launched a persistent program from the host since this stepper's last step)
         self._pack_if_dirty()
         if self.graphs is not None:
             cur = torch.cuda.current_stream(self.gd.device)
@@ -603,4 +628,5 @@ class DDIMStepper:
             self.graph.replay()
         else:
             self._run_all()
+        self._seen_serial = DeepProgram.host_serial[0]
         self._next = i + 1

@@ -328,6 +328,10 @@ class DeepProgram:
 
     STATIC_IDLE_S = 1.0          # an owner that has not launched for this long gives the static schedule to whoever asks
 
+    # host-side launches / sentinel resets of ANY persistent program since the process started: a fused sampler, whose replayed step
+    # relies on the sentinels its own previous step left (DDIMStepper, jen1_step_tail), re-packs and re-poisons when somebody else ran
+    host_serial = [0]
+
     def touch(self) -> None:
         self.leader._last_use = time.monotonic()
 
@@ -444,6 +448,7 @@ class DeepProgram:
     def poison(self, stream: int, zero: Optional[Tuple[int, int]] = None):
         """before every launch, after the last reader of the previous one: the step's first node (Plan) does this; ``zero`` =
         (pointer, bytes) of the plan's per-step statistics arena, reset by the same launch"""
+        DeepProgram.host_serial[0] += 1
         if zero is not None:
             L.check(self.lib.jen1_deep_poison_zero(self.poison_tab.data_ptr(), self.poison_tab.shape[0], self.sync.data_ptr(), zero[0], zero[1],
                                                    stream), "jen1_deep_poison_zero")
@@ -452,6 +457,7 @@ class DeepProgram:
 
     def launch(self, stream: int):
         self.touch()
+        DeepProgram.host_serial[0] += 1
         n = len(self.bufs)
         if os.environ.get("JEN1_DEEP_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_DEEP_RUN_PHASES"]))
@@ -556,6 +562,7 @@ class LongProgram(DeepProgram):
 
     def launch(self, stream: int):
         self.touch()
+        DeepProgram.host_serial[0] += 1
         n = len(self.bufs)
         if os.environ.get("JEN1_LONG_RUN_PHASES"):          # debugging: run only the first phases of the program
             n = min(n, int(os.environ["JEN1_LONG_RUN_PHASES"]))
@@ -625,11 +632,13 @@ class OpBuilder:
             for a in self._splitk_args:
                 a.slab, a.counters = self.slab.data_ptr(), self.counters.data_ptr()
 
-    def run(self, stream: Optional[int] = None, pack: bool = True):
-        """pack=False leaves out the ops that write the network input (kind "pack"): the fused sampler's step kernel wrote it"""
+    def run(self, stream: Optional[int] = None, pack: bool = True, poison: bool = True):
+        """pack=False leaves out the ops that write the network input (kind "pack"), poison=False the head-of-step sentinel / arena
+        reset node (kind "deep_poison"): the fused sampler's previous step did both (jen1_cfg_ddim_step_pack / jen1_step_tail)"""
         if stream is None:
             stream = torch.cuda.current_stream(self.eng.device).cuda_stream
-        ops = self.ops if pack else [op for op in self.ops if getattr(op, "kind", "") != "pack"]
+        skip = (() if pack else ("pack",)) + (() if poison else ("deep_poison",))
+        ops = self.ops if not skip else [op for op in self.ops if getattr(op, "kind", "") not in skip]
         if os.environ.get("JEN1_DEBUG_SYNC"):
             for i, op in enumerate(ops):
                 print(f"[jen1] op {i}: {getattr(op, 'label', '?')}", flush=True)
@@ -1246,6 +1255,7 @@ class Plan(OpBuilder):
             self.ctx_ops: List[Callable[[int], None]] = []
             self.pack_ops: List[Callable[[int], None]] = []
             self.pack_rows = None
+            self.poison_op, self.poison_args = None, None
             self.taps: Dict[str, Act] = {}
             self.acts: List[Act] = []
             self.n_launch = 0
@@ -1689,6 +1699,15 @@ class Plan(OpBuilder):
             fused = lambda s, a=(tab.data_ptr(), tab.shape[0], sync0, arena_ptr, arena_bytes): L.check(lib.jen1_deep_poison_zero(*a, s), "jen1_deep_poison_zero")
             fused.kind, fused.prog = "deep_poison", pzs[0].prog
             fused.label = f"poison[{tab.shape[0]} rows, {sum(op.prog.poison_bytes for op in pzs)} B] + arena reset"
+            # (a fused sampler runs this node's job in the tail launch of the previous step: DDIMStepper, jen1_step_tail)
+            # -- without the rows of the network's output: that launch READS it (nobody polls it: its sentinels are not needed at all)
+            lo = out.t.data_ptr()
+            hi = lo + out.t.numel() * out.t.element_size()
+            rows_host = tab.cpu()
+            keep = [(int(p_), int(n_)) for p_, n_ in rows_host.tolist() if not (lo <= int(p_) < hi)]
+            assert all(p_ + n_ <= lo or p_ >= hi for p_, n_ in keep)
+            self._tail_tab = torch.tensor(keep, dtype=rows_host.dtype).to(dev).contiguous()
+            self.poison_op, self.poison_args = fused, (self._tail_tab.data_ptr(), self._tail_tab.shape[0], sync0, arena_ptr, arena_bytes)
             self.ops = [fused] + [op for op in self.ops[1:] if getattr(op, "kind", "") != "deep_poison"]
 
         # ---- 5. context ops: text K/V (hoisted out of the step loop) -------------------------------
@@ -1755,12 +1774,12 @@ class Plan(OpBuilder):
         for op in self.time_ops:
             op(stream)
 
-    def run(self, stream: Optional[int] = None, pack: bool = True):
+    def run(self, stream: Optional[int] = None, pack: bool = True, poison: bool = True):
         if stream is None:
             stream = torch.cuda.current_stream(self.eng.device).cuda_stream
         if not self.table_mode:
             self.run_time(stream)       # general forward: the timesteps change with every call
-        super().run(stream, pack)
+        super().run(stream, pack, poison)
 
     def run_pack(self, stream: Optional[int] = None):
         """only the ops that write the network input from x_in / ctx_in (a fused sampler runs them once per trajectory: its step kernel
@@ -1769,6 +1788,12 @@ class Plan(OpBuilder):
             stream = torch.cuda.current_stream(self.eng.device).cuda_stream
         for op in self.pack_ops:
             op(stream)
+
+    def run_poison(self, stream: Optional[int] = None):
+        """only the head-of-step sentinel / arena reset node (a fused sampler runs it once per trajectory; jen1_step_tail after that)"""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        self.poison_op(stream)
 
     def _add_cast(self, ops, src: torch.Tensor, dst: torch.Tensor):
         """dtype cast through torch (device plumbing, captured like any other node)."""

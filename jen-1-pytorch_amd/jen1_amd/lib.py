@@ -143,6 +143,7 @@ SYMBOLS = {
     "jen1_step_advance": (c_int, [_P, _P]),
     "jen1_cfg_ddim_step_adv": (c_int, [_P] * 9 + [c_int] * 5 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
     "jen1_cfg_ddim_step_pack": (c_int, [_P] * 9 + [c_int] * 6 + [c_float, c_int, c_float, c_int, c_int, c_int, _P]),
+    "jen1_step_tail": (c_int, [_P] * 9 + [c_int] * 6 + [c_float, c_int, c_float, c_int, c_int, c_int, _P, c_int, _P, _P, c_int64, _P]),
     "jen1_cfg_combine": (c_int, [_P, _P] + [c_int] * 4 + [c_float, c_int, c_float, c_int, _P]),
     "jen1_grad_sqnorm": (c_int, [_P, c_int64, _P, _P]),
     "jen1_grad_sqnorm_scratch_bytes": (c_int64, []),

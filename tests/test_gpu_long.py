@@ -239,8 +239,10 @@ def test_default_sampling_is_bit_reproducible(full_bf16):
 @pytest.mark.parametrize("scale,eta", [(1.0, 1.0), (3.0, 1.0), (1.0, 0.0)])
 def test_fused_step_pack_matches_separate_pack(full_bf16, monkeypatch, scale, eta):
     """the sampler's step kernel writes the next step's network input (jen1_cfg_ddim_step_pack: rows in the compute dtype + statistics
-    partials in pack_input's order) instead of a pack launch at the head of every step: same bits as the separate launches, with and
-    without the CFG pair, with and without per-step noise, eagerly and as a replayed graph"""
+    partials in pack_input's order) instead of a pack launch at the head of every step, and -- jen1_step_tail -- the same launch sets the
+    next step's sentinels and zeroes its statistics arena: same bits as the separate launches, with and without the CFG pair, with and
+    without per-step noise, eagerly and as a replayed graph; a foreign host-side run of the plan between two steps (which consumes the
+    sentinels) is noticed and repaired"""
     from jen1_amd.diffusion import DDIMStepper, GaussianDiffusion, get_beta_schedule
     m = full_bf16
     B, T, S = 2, 1500, 3
@@ -251,16 +253,23 @@ def test_fused_step_pack_matches_separate_pack(full_bf16, monkeypatch, scale, et
     init = dev(synth.noise_list(1, (B, 128, T), seed=3)[0])
     noises = [dev(n) for n in synth.noise_list(S, (B, 128, T), seed=5)]
     outs = {}
-    for flag, ug in (("0", False), ("1", False), ("1", True)):
-        monkeypatch.setenv("JEN1_STEP_PACK", flag)
+    for pack, tail, ug, foreign in (("0", "0", False, False), ("1", "0", False, False), ("1", "1", False, False), ("1", "1", True, False),
+                                    ("1", "1", True, True)):
+        monkeypatch.setenv("JEN1_STEP_PACK", pack)
+        monkeypatch.setenv("JEN1_STEP_TAIL", tail)
         st = DDIMStepper(gd, m, (B, 128, T), cond, use_graph=ug)
-        assert st.fused_pack == (flag == "1")
+        assert st.fused_pack == (pack == "1") and st.fused_tail == (tail == "1")
         st.reset(init, fresh_noise=False)
         for i in range(S):
             st.step(i, noise=noises[i])
+            if foreign and i == 0:
+                keep = st.x.clone()
+                st.plan.run()                  # (a full pass of the same plan from the host: packs, poisons, consumes)
+                assert torch.equal(keep, st.x)
         st.check()
-        outs[(flag, ug)] = st.x.clone()
+        outs[(pack, tail, ug, foreign)] = st.x.clone()
     torch.cuda.synchronize()
-    assert torch.isfinite(outs[("0", False)]).all()
-    assert torch.equal(outs[("0", False)], outs[("1", False)]), "fused step + pack differs from the separate pack launch"
-    assert torch.equal(outs[("1", False)], outs[("1", True)]), "replayed fused step differs from the eager one"
+    ref = outs[("0", "0", False, False)]
+    assert torch.isfinite(ref).all()
+    for k, v in outs.items():
+        assert torch.equal(ref, v), f"JEN1_STEP_PACK={k[0]} JEN1_STEP_TAIL={k[1]} graph={k[2]} foreign run={k[3]}: differs from the separate launches"
