@@ -87,7 +87,9 @@ def per_step(db, counter, which):
             join {pe} p on p.event_id = d.event_id where p.pmc_id in ({','.join(str(i) for i in ids)})
             group by d.id order by d.start"""
     rows = list(c.execute(q))
-    idx = [i for i, r in enumerate(rows) if "pack_input" in r[0]]
+    # a replayed step is delimited by its tail launch (round 6: jen1_step_tail), else by pack_input at its head
+    tails = [i + 1 for i, r in enumerate(rows) if "step_tail" in r[0]]
+    idx = tails if len(tails) > which + 1 else [i for i, r in enumerate(rows) if "pack_input" in r[0]]
     a = idx[which]
     b = idx[which + 1] if which + 1 < len(idx) else len(rows)
     agg = collections.defaultdict(lambda: [0, 0.0])

@@ -13,7 +13,9 @@ ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 scols = [r[1] for r in c.execute(f"pragma table_info({ks})")]
 name_col = "display_name" if "display_name" in scols else "kernel_name"
 rows = list(c.execute(f"select s.{name_col}, d.start, d.end, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x, d.group_segment_size from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-idx = [i for i, r in enumerate(rows) if 'pack_input' in r[0]]
+# a replayed step is delimited by its tail launch (round 6: jen1_step_tail; the next step's head work is inside it), else by pack_input
+anchor = 'step_tail' if sum('step_tail' in r[0] for r in rows) > which + 1 else 'pack_input'
+idx = [i + 1 for i, r in enumerate(rows) if anchor in r[0]] if anchor == 'step_tail' else [i for i, r in enumerate(rows) if anchor in r[0]]
 a, b = idx[which], idx[which + 1]
 step = rows[a:b]
 print("launches in step:", len(step), "span us:", (step[-1][2] - step[0][1]) / 1e3, "sum kernel us:", sum(r[2] - r[1] for r in step) / 1e3)
