@@ -438,6 +438,10 @@ class DDIMStepper:
                 def run(s, plan=plan, adv_args=adv_args, ticket=ticket):
                     plan.run(s)
                     L.check(lib.jen1_cfg_ddim_step_adv(*adv_args, s), "jen1_cfg_ddim_step_adv")
+            # (per sub-batch: a plan without persistent launches keeps its sentinel-free head; the stepper-level flags say "every part")
+            if not hasattr(self, "_part_fused"):
+                self._part_fused = {}
+            self._part_fused[id(plan)] = (fused, tail)
             self.fused_pack = getattr(self, "fused_pack", True) and fused
             self.fused_tail = getattr(self, "fused_tail", True) and tail
 
@@ -520,20 +524,23 @@ class DDIMStepper:
         """kernel launches of one replayed step (first sub-batch): the plan's, minus what the fused step kernel took over, plus that kernel
         and the sum of its statistics partials"""
         plan = self.plan
-        skip = (("pack",) if self.fused_pack else ()) + (("deep_poison",) if self.fused_tail else ())
+        fused, tail = self._part_fused[id(plan)]
+        skip = (("pack",) if fused else ()) + (("deep_poison",) if tail else ())
         n = sum(1 for op in plan.ops if getattr(op, "kind", "") not in skip) + (0 if plan.table_mode else len(plan.time_ops))
-        return n + 1 + (1 if self.fused_pack else 0)
+        return n + 1 + (1 if fused else 0)
 
     def mark_dirty(self) -> None:
         """the latents (``x``) or the concat context were written from outside: the next step re-packs the network input from them"""
         self._pack_dirty = True
 
     def _pack_if_dirty(self):
-        if self._pack_dirty and self.fused_pack:
+        if self._pack_dirty:
+            s = torch.cuda.current_stream(self.gd.device).cuda_stream
             for _, plan, _, _ in self.parts:
-                s = torch.cuda.current_stream(self.gd.device).cuda_stream
-                plan.run_pack(s)
-                if self.fused_tail:
+                fused, tail = self._part_fused[id(plan)]
+                if fused:
+                    plan.run_pack(s)
+                if tail:
                     plan.run_poison(s)
         self._pack_dirty = False
 
@@ -613,7 +620,7 @@ class DDIMStepper:
         if noise is not None and i < self.num_steps - 1 and self.mode != "vdm":
             self.noise_all[i].copy_(noise.to(self.noise_all.device, torch.float32))
             self._push_noise(i)
-        if self.fused_pack and DeepProgram.host_serial[0] != self._seen_serial:
+        if DeepProgram.host_serial[0] != self._seen_serial and any(t for _, t in self._part_fused.values()):
             self._pack_dirty = True                # (somebody launched a persistent program from the host since this stepper's last step)
         self._pack_if_dirty()
         if self.graphs is not None:
