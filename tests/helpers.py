@@ -56,18 +56,18 @@ BF16_GATES = {
     ("full_ddim", "ddim10.B2.cfg"): {"l2": 4.5e-2},                 # 2.31e-2
     ("full_ddim", "ddim2.B8.cfg"): {"l2": 7.5e-2},                  # 3.81e-2
     ("full_ddim", "ddim2.B8.nocfg"): {"l2": 7.5e-2},                # 3.93e-2
-    ("full_ddim", "ddim2.T9000.cont"): {"l2": 7.0e-2},              # 3.73e-2
-    ("full_ddim100", "ddim100.B2.cfg.step10"): {"l2": 1.6e-2},      # 8.02e-3
+    ("full_ddim", "ddim2.T9000.cont"): {"l2": 6.8e-2},              # 3.4e-2 - 3.7e-2
+    ("full_ddim100", "ddim100.B2.cfg.step10"): {"l2": 1.55e-2},     # 7.9e-3 - 8.0e-3
     ("full_ddim100", "ddim100.B2.cfg.step25"): {"l2": 1.6e-2},      # 8.41e-3
     ("full_ddim100", "ddim100.B2.cfg.step50"): {"l2": 1.9e-2},      # 9.72e-3
-    ("full_ddim100", "ddim100.B2.cfg.step75"): {"l2": 3.6e-2},      # 1.81e-2
+    ("full_ddim100", "ddim100.B2.cfg.step75"): {"l2": 3.5e-2},      # 1.79e-2
     ("full_ddim100", "ddim100.B2.cfg"): {"l2": 4.5e-2},             # 2.34e-2
-    ("full_ddim100", "ddim100.B8.nocfg.step10"): {"l2": 1.7e-2},    # 8.52e-3
-    ("full_ddim100", "ddim100.B8.nocfg.step25"): {"l2": 1.6e-2},    # 7.88e-3
+    ("full_ddim100", "ddim100.B8.nocfg.step10"): {"l2": 1.65e-2},   # 8.4e-3
+    ("full_ddim100", "ddim100.B8.nocfg.step25"): {"l2": 1.5e-2},    # 7.8e-3
     ("full_ddim100", "ddim100.B8.nocfg.step50"): {"l2": 2.6e-2},    # 1.34e-2
-    ("full_ddim100", "ddim100.B8.nocfg.step75"): {"l2": 8.0e-2},    # 4.07e-2
+    ("full_ddim100", "ddim100.B8.nocfg.step75"): {"l2": 7.8e-2},    # 4.0e-2
     ("full_ddim100", "ddim100.B8.nocfg"): {"l2": 1.0e-1},           # 6.47e-2  (100 steps, eta = 0, no CFG: the bench workload)
-    ("configs3_micro_batch", "bf16"): {"loss": 1.25e-3, "norm": 1.1e-2, "samp": 0.95},      # 6.4e-4, 5.7e-3, 0.49
+    ("configs3_micro_batch", "bf16"): {"loss": 1.2e-3, "norm": 1.1e-2, "samp": 0.74},       # 6.2e-4 - 6.4e-4, 5.7e-3 - 5.9e-3, 0.37 - 0.49 (float atomics: varies run to run)
 }
 
 
