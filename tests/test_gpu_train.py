@@ -681,7 +681,7 @@ def test_configs3_micro_batch_merged_passes_vs_reference_autograd(mode, tol_loss
     assert sorted(names) == sorted(grads.keys()) and len(names) == 979
     ref_norm, ref_samp = g["gradnorm_all"], g["gradsample_all"]
     gmax = float(ref_norm.max())
-    off, worst_n, worst_s = 0, ("", 0.0), ("", 0.0)
+    off, worst_n, worst_s, es_all = 0, ("", 0.0), ("", 0.0), []
     for i, n in enumerate(names):
         gr = grads[n]
         samp = gr.reshape(-1)[:: max(1, gr.numel() // 16)][:16].cpu().numpy()
@@ -691,17 +691,23 @@ def test_configs3_micro_batch_merged_passes_vs_reference_autograd(mode, tol_loss
         en = abs(nrm - ref_norm[i]) / max(ref_norm[i], 1e-3 * gmax)
         scale = max(float(np.abs(ref).max()), ref_norm[i] / np.sqrt(gr.numel()))
         es = float(np.abs(samp - ref).max() / max(scale, 1e-12))
+        es_all.append(float(np.sqrt(np.mean((samp - ref) ** 2)) / max(scale, 1e-12)))
         if en > worst_n[1]:
             worst_n = (n, en)
         if es > worst_s[1]:
             worst_s = (n, es)
     assert off == ref_samp.size
+    # the worst single entry of 15 664 is a tail statistic (bf16 operands, float atomics in the weight-gradient sums: 0.24 - 0.49 over
+    # runs of the same build); the root mean square over the 979 tensors of their sampled entries' error is the stable figure
+    samp_rms = float(np.sqrt(np.mean(np.square(es_all))))
     print(f"configs[3] micro-batch (3/3/2, one pass, {mode}): worst loss error {worst_l:.2e}, worst norm error {worst_n[1]:.2e} ({worst_n[0]}), "
-          f"worst sampled-entry error {worst_s[1]:.2e} ({worst_s[0]})")
-    record_parity("configs3_micro_batch", mode, mode, loss=worst_l, norm=worst_n[1], samp=worst_s[1])
+          f"worst sampled-entry error {worst_s[1]:.2e} ({worst_s[0]}), rms over the tensors {samp_rms:.2e}")
+    record_parity("configs3_micro_batch", mode, mode, loss=worst_l, norm=worst_n[1], samp=worst_s[1], samp_rms=samp_rms)
     assert worst_l <= tol_loss, worst_l
     assert worst_n[1] <= tol_norm, worst_n
     assert worst_s[1] <= tol_samp, worst_s
+    if mode == "bf16":
+        assert samp_rms <= bf16_gate("configs3_micro_batch", "bf16", "samp_rms"), samp_rms
 
 
 def test_training_overfits_one_batch():
